@@ -1,0 +1,172 @@
+/*
+ * augx.h -- C ABI of the MI355X-native AUGUSTUS decode path (libaugx.so).
+ *
+ * The reference (Gaius-Augustus/Augustus v3.5.0) has no FFI; its seam for this path is the C++ call pair
+ *     NAMGene::viterbiAndForward(const char* dna)      reference include/namgene.hh:91,  src/namgene.cc:168-365
+ *     NAMGene::getViterbiPath(const char* dna, ...)    reference include/namgene.hh:41,  src/namgene.cc:432-510
+ * driven per "piece" by NAMGene::doViterbiPiecewise     reference src/namgene.cc:516-676
+ * over the per-state virtual StateModel::viterbiForwardAndSampling (reference include/statemodel.hh:76-77).
+ * Every entry point below names the reference interface it replaces.  Plain pointers and sizes only.
+ *
+ * All functions return 0 on success and a negative AUGX_E_* code on error; the message is available from
+ * augx_last_error() (thread-local, NUL-terminated).  No entry point ever falls back to a CPU decode:
+ * without a usable HIP device augx_decoder_create() fails with AUGX_E_NODEVICE.
+ */
+#ifndef AUGX_H
+#define AUGX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUGX_MAX_STATES 80
+#define AUGX_MAX_ANC 8
+#define AUGX_MAX_CLASSES 8
+
+enum {
+    AUGX_OK = 0,
+    AUGX_E_ARG = -1,        /* bad argument                                                            */
+    AUGX_E_CONFIG = -2,     /* species / model configuration could not be read (ProjectError analogue)  */
+    AUGX_E_NODEVICE = -3,   /* no HIP device / kernel image: the product path has no CPU fallback       */
+    AUGX_E_HIP = -4,        /* HIP runtime error                                                        */
+    AUGX_E_UNSUPPORTED = -5,/* model feature outside the implemented hot path (fails loudly)            */
+    AUGX_E_NOPATH = -6      /* "No feasible path found in HMM" (reference src/namgene.cc:455-457)       */
+};
+
+/* state kinds of the GHMM (derived from the reference's StateType, include/types.hh:492-512) */
+enum {
+    AUGX_K_IGENIC = 0,
+    AUGX_K_SINGLE, AUGX_K_INITIAL, AUGX_K_INTERNAL, AUGX_K_TERMINAL,           /* forward coding exons  */
+    AUGX_K_RSINGLE, AUGX_K_RINITIAL, AUGX_K_RINTERNAL, AUGX_K_RTERMINAL,       /* reverse coding exons  */
+    AUGX_K_LESSD, AUGX_K_LONGDSS, AUGX_K_EQUALD, AUGX_K_GEOMETRIC, AUGX_K_LONGASS,      /* fwd intron  */
+    AUGX_K_RLESSD, AUGX_K_RLONGDSS, AUGX_K_REQUALD, AUGX_K_RGEOMETRIC, AUGX_K_RLONGASS  /* rev intron  */
+};
+
+/*
+ * Flat, immutable model tables.  Everything the reference keeps in static class members after
+ * StateModel::readAllParameters() (reference src/statemodel.cc:232-238; exon :604-792, intron :295-415,
+ * igenic :150-225) and NAMGene::readTransAndInitProbs (src/namgene.cc:1318-1392), as natural logarithms
+ * in fp64 (-inf for probability 0).  Pattern indices are base-4 numbers, a=0 c=1 g=2 t=3, first base most
+ * significant (reference Seq2Int, include/geneticcode.hh:163-241).  NP = 4^(k+1).
+ */
+typedef struct augx_tables {
+    int32_t S;                      /* number of states (47 for human/fly without UTR)                  */
+    int32_t n_classes;              /* GC-content classes (decomp_num_steps)                            */
+    int32_t k;                      /* order of the exon/intron/igenic Markov chains (all equal)        */
+    int32_t W, U, As, Ae, Ds, De;   /* trans_init_window, ass_upwindow_size, ass_start/end, dss_start/end */
+    int32_t Li, Le;                 /* init_coding_len, et_coding_len                                   */
+    int32_t d;                      /* /IntronModel/d                                                   */
+    int32_t max_exon_len, min_exon_len, min_coding_len;
+    int32_t tis_n, tis_k, ass_n, ass_k;   /* motif widths / orders                                      */
+    int32_t tis_nbins;              /* >0: TIS probabilities are binned (not human)                     */
+    int32_t tis_mem;                /* /ExonModel/tis_motif_memory (reference src/exonmodel.cc:1319)     */
+    int32_t synch_state;
+    int32_t gc_win;                 /* GCwinsize                                                        */
+    int32_t state_type[AUGX_MAX_STATES];  /* reference StateType id (for names / GFF logic)             */
+    int32_t state_kind[AUGX_MAX_STATES];  /* AUGX_K_*                                                   */
+    int32_t state_win[AUGX_MAX_STATES];   /* stateReadingFrames[type] (reference src/types.cc:174-189)  */
+    int32_t reachable[AUGX_MAX_STATES];
+    double ln_init[AUGX_MAX_STATES];      /* [Initial] of the transition file                           */
+    double ln_term[AUGX_MAX_STATES];      /* [Terminal]                                                 */
+    const double *ln_trans;         /* [n_classes][S][S]  ln t(a->s) after the per-class intron rewrite
+                                       (reference IntronModel::updateToLocalGCEach, src/intronmodel.cc:439-488) */
+    /* ---- per GC class, class-major ---- */
+    const double *ig_emi;           /* [C][NP]       igenic emission (intron table when tieIgenicIntron) */
+    const double *ig_short;         /* [C][k+1][NP]  ln of the short-pattern ratio used for positions <= k
+                                       (reference IGenicModel::emiProbUnderModel, src/igenicmodel.cc:342-356) */
+    const double *in_emi;           /* [C][NP]       intron emission                                    */
+    const double *ex_emi;           /* [C][3][NP]    exon content, frame-dependent                      */
+    const double *ex_init;          /* [C][3][NP]    initial content                                    */
+    const double *ex_et;            /* [C][3][NP]    exon-terminal content                              */
+    const double *ex_pls;           /* [C][k+1][3][NP] joint l-mer probabilities P_ls (only 4^(l+1) used)*/
+    const double *tis_motif;        /* [C][tis_n][4^(tis_k+1)]                                          */
+    const double *ass_motif;        /* [C][ass_n][4^(ass_k+1)]                                          */
+    const double *tis_bin_bounds;   /* [C][tis_nbins-1] (linear probabilities) or NULL                  */
+    const double *tis_bin_ln;       /* [C][tis_nbins]                                                   */
+    /* ---- class independent ---- */
+    const double *ass_pat;          /* [4^(As+Ae)]  ln of the (binned) ASS pattern probability           */
+    const double *dss_pat;          /* [4^(Ds+De)]  ln of the (binned) DSS pattern probability           */
+    double ass_pat_invalid;         /* ln(0.001 * 0.25^(As+Ae)), reference src/intronmodel.cc:1179        */
+    const double *len_intron;       /* [d+1]                                                            */
+    const double *len_single;       /* [max_exon_len+1]  ln(3*P(len)) as used in notEndPartEmiProb       */
+    const double *len_initial;
+    const double *len_internal;
+    const double *len_terminal;
+    double ln_startcodon[64];       /* ln startCodonProb, -inf if not a start codon                      */
+    double ln_stop_ochre, ln_stop_amber, ln_stop_opal;   /* taa, tag, tga                                */
+    double ln_quarter;              /* ln 0.25  */
+    double ln_n_coding;             /* ln probNinCoding (0.23) */
+    double ln4;                     /* ln 4 */
+    /* GC-class decomposition (reference ContentDecomposition, src/motif.cc:458-505) */
+    double gc_zus[AUGX_MAX_CLASSES][4];   /* ra, rc, rg, rt of the class centres                         */
+    double gc_weight_matrix[16];
+    int32_t gc_weighing_type;       /* 1 equal, 2 gcContentClasses, 3 multiNormalKernel                  */
+    int32_t n_anc[AUGX_MAX_STATES];
+    int32_t anc[AUGX_MAX_STATES][AUGX_MAX_ANC];  /* ancestors in ascending state index (tie-break order) */
+} augx_tables;
+
+typedef struct augx_model augx_model;     /* host-side immutable model: tables + option values          */
+typedef struct augx_decoder augx_decoder; /* device-side context bound to one HIP device + stream       */
+
+/* one unit of work = one "piece" (reference src/namgene.cc:584-603) */
+typedef struct augx_piece {
+    const char *seq;      /* ASCII nucleotides, any case; non-acgt = invalid (HOST pointer)               */
+    int64_t len;
+    int32_t init_kind;    /* 0: [Initial] probs of the transition file; 1: synch state only (interior cut) */
+    int32_t term_kind;    /* 0: [Terminal] probs;                        1: synch state only               */
+} augx_piece;
+
+/* == State(begin,end,type) of the reference (include/gene.hh:101-135), 0-based HMM-state coordinates */
+typedef struct augx_state {
+    int32_t begin, end;
+    int16_t state;        /* state index in the model                                                     */
+    int16_t type;         /* reference StateType id                                                        */
+} augx_state;
+
+typedef struct augx_path {
+    augx_state *states;   /* 5'->3'; runs of single-base igenic / geometric states are merged             */
+    int32_t n_states;
+    int32_t status;       /* 0 or AUGX_E_NOPATH                                                           */
+    double ln_viterbi;    /* ln of StatePath::pathemiProb (reference src/namgene.cc:462)                  */
+} augx_path;
+
+/* ---- model (replaces Properties::init + Constant::init + NAMGene() + StateModel::readAllParameters,
+ *      reference src/augustus.cc:111-176) ---- */
+int augx_model_load(const char *config_path, const char *species, int n_opts, const char *const *opt_names,
+                    const char *const *opt_values, augx_model **out);
+const augx_tables *augx_model_tables(const augx_model *m);
+const char *augx_model_option(const augx_model *m, const char *name); /* NULL if unset */
+void augx_model_destroy(augx_model *m);
+
+/* ---- decoder (device) ---- */
+int augx_decoder_create(const augx_model *m, int device, augx_decoder **out);
+void augx_decoder_destroy(augx_decoder *d);
+
+/* replaces viterbiAndForward + getViterbiPath for a batch of independent pieces */
+int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
+void augx_path_free(augx_path *p);
+
+/* ---- device-resident batch interface (bench / multi-GPU driver): the batch is staged once, decode can be
+ *      repeated and timed with the inputs resident in HBM ---- */
+typedef struct augx_batch augx_batch;
+int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_batch **out); /* H2D copy  */
+int augx_batch_decode(augx_decoder *d, augx_batch *b);            /* all kernels, async on the stream   */
+int augx_batch_sync(augx_decoder *d);
+int augx_batch_paths(augx_decoder *d, augx_batch *b, augx_path *out /* array[n] */);      /* D2H + unpack */
+int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *trellis_ms, float *back_ms);
+/* test hook: copy the dense ln V[j][s] matrix (len*S doubles, -inf = absent) of piece i to host; only
+ * valid on a decoder created with AUGX_DEBUG_CELLS=1 in the environment */
+int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out);
+void augx_batch_destroy(augx_batch *b);
+
+/* ---- whole-program driver (replaces main(), reference src/augustus.cc:94-248): same argv as `augustus`,
+ *      GFF on `out_fd`, diagnostics on `err_fd`; returns the process exit code ---- */
+int augx_main(int argc, const char *const *argv);
+
+const char *augx_last_error(void);
+const char *augx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

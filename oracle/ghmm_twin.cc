@@ -1,0 +1,755 @@
+/*
+ * ghmm_twin.cc -- CPU restatement ("twin") of the reference's single-genome GHMM Viterbi decode.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; nothing under augustus_amd/ links, imports or executes it.
+ *
+ * What it is: a plain, position-sequential, brute-force restatement of
+ *     NAMGene::viterbiAndForward      reference src/namgene.cc:168-365
+ *     NAMGene::getViterbiPath         reference src/namgene.cc:432-510
+ * and of the per-state scorers it drives (cited at each function below), with the reference's loop
+ * structure and tie-breaking kept, but in log space: probabilities are fp64 natural logs, products are
+ * sums, and every Markov-chain content product  prod_{p=l..r} e(p)  is the difference P[r]-P[l-1] of a
+ * prefix-sum array (the same formulation the HIP kernels use).  Extrinsic evidence is absent (ab initio;
+ * every malus/bonus factor of the reference is exactly 1, reference config/extrinsic/extrinsic.cfg).
+ *
+ * Parity pin: tests/test_oracle_vs_reference.py checks this file against the REAL reference built by
+ * oracle/Makefile (oracle/_ref/ref_harness: ln Viterbi score to 1e-9 relative, state path exact, every
+ * trellis cell to 1e-9) and against the committed golden vectors under tests/golden/.
+ *
+ * Known, documented deviations (none observed on any test input):
+ *  - multi-GC-class pieces: a short (lessD) intron is scored with the class of its END position; the
+ *    reference's SnippetProbs cache mixes classes in call-history order (src/statemodel.cc:312-342).
+ *  - IntronModel::codon is a shared scratch buffer in the reference; for short introns that begin before
+ *    sequence position 2 the spliced-codon stop test reads stale bytes (src/intronmodel.cc:935-958).
+ *    Here the test is skipped for those (left-truncated) introns.
+ */
+#include <cmath>
+#include <cstdint>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <vector>
+#include "../include/augx.h"
+
+namespace {
+
+const double NINF = -std::numeric_limits<double>::infinity();
+inline int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
+
+struct Twin {
+    const augx_tables &t;
+    int n;
+    std::vector<uint8_t> code; // 0..3 acgt, 4 invalid
+    std::vector<int> cls;      // GC class per position
+    int S, k, NP;
+    // prefix sums per class, allocated lazily; index [p+1], P[0]=0
+    struct ClassArrays {
+        bool built = false;
+        std::vector<double> inF, inR;       // intron fwd pattern / rc pattern (rlessD)
+        std::vector<double> ex[2][3][3];    // [strand][table: 0 emi,1 init,2 et][phase]
+    };
+    std::vector<ClassArrays> ca;
+    std::vector<int> nsF, nsR;              // nearestStopForward / Reverse
+    std::vector<double> V;                  // [n][S]
+    std::vector<int32_t> bpS, bpE;          // back pointers: pred state, endOfPred
+
+    Twin(const augx_tables &tt, const char *seq, int len) : t(tt), n(len) {
+        S = t.S; k = t.k; NP = 1 << (2 * (k + 1));
+        code.resize(n + 16, 4);
+        for (int i = 0; i < n; i++) {
+            char c = (char)tolower((unsigned char)seq[i]); // reference lower-cases the whole sequence,
+            code[i] = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4; // src/extrinsicinfo.cc:1726
+        }
+        ca.resize(t.n_classes);
+    }
+    inline int b(int p) const { return (p >= 0 && p < n) ? code[p] : 4; }
+    inline bool is2(int p, int x, int y) const { return b(p) == x && b(p + 1) == y; }
+    // forward pattern of `len` bases starting at p (first base most significant); -1 if any invalid
+    int pat(int p, int len) const {
+        int r = 0;
+        for (int i = 0; i < len; i++) {
+            int c = b(p + i);
+            if (c > 3) return -1;
+            r = (r << 2) | c;
+        }
+        return r;
+    }
+    // Seq2Int::rc (reference include/geneticcode.hh:174-179): sum complement(s[i]) << 2i
+    int rcpat(int p, int len) const {
+        int r = 0;
+        for (int i = 0; i < len; i++) {
+            int c = b(p + i);
+            if (c > 3) return -1;
+            r |= (3 - c) << (2 * i);
+        }
+        return r;
+    }
+    bool isStop(int p) const { // taa tag tga at p..p+2  (translation table 1)
+        return b(p) == 3 && ((b(p + 1) == 0 && (b(p + 2) == 0 || b(p + 2) == 2)) || (b(p + 1) == 2 && b(p + 2) == 0));
+    }
+    bool isRCStop(int p) const { // tta cta tca
+        return b(p + 2) == 0 && ((b(p + 1) == 3 && (b(p) == 3 || b(p) == 1)) || (b(p + 1) == 1 && b(p) == 3));
+    }
+    static bool stopCodon3(int c0, int c1, int c2) {
+        if (c0 > 3 || c1 > 3 || c2 > 3) return false; // translate() -> 'X' (src/geneticcode.cc:198-204)
+        return c0 == 3 && ((c1 == 0 && (c2 == 0 || c2 == 2)) || (c1 == 2 && c2 == 0));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // GC-content stairs: reference ContentStairs::computeStairs, src/motif.cc:543-616, with
+    // ContentDecomposition::getNearestBaseCountIndex :493-505 and BaseCount::doubleWeight :105-177
+    // ------------------------------------------------------------------------------------------
+    int nearestClass(const int cnt[4]) const {
+        double r[4] = {0.25, 0.25, 0.25, 0.25};
+        double sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (sum > 0.0)
+            for (int i = 0; i < 4; i++) r[i] = cnt[i] / sum;
+        double maxW = -1;
+        int ret = -1;
+        for (int c = 0; c < t.n_classes; c++) {
+            double w = 1;
+            if (t.gc_weighing_type == 3) {
+                double z[4], tmp[4] = {0, 0, 0, 0};
+                for (int i = 0; i < 4; i++) z[i] = r[i] - t.gc_zus[c][i];
+                for (int j = 0; j < 4; j++)
+                    for (int i = 0; i < 4; i++) tmp[j] += z[i] * t.gc_weight_matrix[i * 4 + j];
+                double q = 0;
+                for (int i = 0; i < 4; i++) q += tmp[i] * z[i];
+                w = 1 + 9 * exp(-q);
+            } else if (t.gc_weighing_type == 2) {
+                auto gcc = [](double g) { return g < .43 ? 0 : g < .51 ? 1 : g < .57 ? 2 : 3; };
+                w = gcc(r[1] + r[2]) == gcc(t.gc_zus[c][1] + t.gc_zus[c][2]) ? 1 : 0;
+            }
+            if (w > maxW) { maxW = w; ret = c; }
+        }
+        return ret;
+    }
+    void computeStairs() {
+        cls.assign(n, -1);
+        int win = t.gc_win;
+        if (win > n || win < 1) win = n;
+        int cnt[4] = {0, 0, 0, 0};
+        for (int i = 0; i < win; i++)
+            if (code[i] < 4) cnt[code[i]]++;
+        int x = nearestClass(cnt);
+        for (int i = 0; i <= win / 2 && i < n; i++) cls[i] = x;
+        for (int i = win / 2 + 1; i <= n - (win + 1) / 2; i++) {
+            int add = i + (win + 1) / 2 - 1, sub = i - win / 2 - 1;
+            if (code[add] < 4) cnt[code[add]]++;
+            if (code[sub] < 4) cnt[code[sub]]--;
+            cls[i] = x = nearestClass(cnt);
+        }
+        for (int i = n - (win + 1) / 2 + 1; i < n; i++) cls[i] = x;
+        const int totterywin = 1000;
+        x = -2;
+        int lastStep = 0;
+        for (int i = 0; i < n; i++)
+            if (cls[i] != x) {
+                if (i - lastStep < totterywin && lastStep > 0 && cls[lastStep - 1] == cls[i])
+                    for (int j = lastStep; j < i; j++) cls[j] = cls[i];
+                lastStep = i;
+                x = cls[i];
+            }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // OpenReadingFrame: reference src/exonmodel.cc:101-198
+    // ------------------------------------------------------------------------------------------
+    void buildORF() {
+        nsF.assign(n, 0);
+        nsR.assign(n, 0);
+        for (int r = 0; r < 3; r++) {
+            int sf = -1, sr = -1;
+            for (int i = r; i <= n - 3; i += 3) {
+                if (isStop(i)) sf = i;
+                nsF[i] = sf;
+                if (isRCStop(i)) sr = i;
+                nsR[i] = sr;
+            }
+        }
+        if (n > 5) {
+            nsF[n - 2] = nsF[n - 5]; nsF[n - 1] = nsF[n - 4];
+            nsR[n - 2] = nsR[n - 5]; nsR[n - 1] = nsR[n - 4];
+        }
+    }
+    int leftmostExonBegin(int frame, int base, bool fwd) const {
+        int pos;
+        if (fwd) pos = (frame == 0 || frame == 1) ? base - frame - 3 : base - frame;
+        else pos = (frame == 1 || frame == 2) ? base + frame - 5 : base - 2;
+        if (pos >= n) pos -= 3 * ((pos - n + 3) / 3);
+        int lmb = pos >= 0 ? (fwd ? nsF[pos] : nsR[pos]) + 1 : 0;
+        int maxAllowed = t.max_exon_len - t.U - t.As - 2 - 2 - t.Ds;
+        if (lmb < base - maxAllowed) lmb = base - maxAllowed;
+        return lmb;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // per-class prefix sums of the order-k emissions
+    // ------------------------------------------------------------------------------------------
+    void buildClass(int c) {
+        ClassArrays &A = ca[c];
+        if (A.built) return;
+        A.built = true;
+        const double *inE = t.in_emi + (size_t)c * NP;
+        A.inF.assign(n + 1, 0.0);
+        A.inR.assign(n + 1, 0.0);
+        for (int p = 0; p < n; p++) {
+            // forward: reference IntronModel::seqProb src/intronmodel.cc:1090-1101 / SnippetProbs fwd src/statemodel.cc:287-297
+            int pn = p >= k ? pat(p - k, k + 1) : -1;
+            A.inF[p + 1] = A.inF[p] + (pn >= 0 ? inE[pn] : t.ln_quarter);
+            // reverse snippet (rlessD only): src/statemodel.cc:298-309
+            int rn = (p + k < n) ? rcpat(p, k + 1) : -1;
+            A.inR[p + 1] = A.inR[p] + (rn >= 0 ? inE[rn] : t.ln_quarter);
+        }
+        const double *tabs[3] = {t.ex_emi + (size_t)c * 3 * NP, t.ex_init + (size_t)c * 3 * NP, t.ex_et + (size_t)c * 3 * NP};
+        for (int tb = 0; tb < 3; tb++)
+            for (int a = 0; a < 3; a++) {
+                std::vector<double> &F = A.ex[0][tb][a], &R = A.ex[1][tb][a];
+                F.assign(n + 1, 0.0);
+                R.assign(n + 1, 0.0);
+                for (int p = 0; p < n; p++) {
+                    // forward strand: frame f(p) = (p + a) mod 3, pattern = bases p-k..p
+                    // (reference ExonModel::seqProb, src/exonmodel.cc:1957-1966)
+                    int pn = p >= k ? pat(p - k, k + 1) : -1;
+                    F[p + 1] = F[p] + (pn >= 0 ? tabs[tb][mod3(p + a) * NP + pn] : t.ln_n_coding);
+                    // reverse strand: frame f(p) = (a - p) mod 3, pattern = rc of bases p..p+k
+                    int rn = rcpat(p, k + 1); // reading the terminating NUL / beyond = invalid
+                    R[p + 1] = R[p] + (rn >= 0 ? tabs[tb][mod3(a - p) * NP + rn] : t.ln_n_coding);
+                }
+            }
+    }
+    inline double seg(const std::vector<double> &P, int l, int r) const { return l > r ? 0.0 : P[r + 1] - P[l]; }
+
+    // ------------------------------------------------------------------------------------------
+    // igenic emission: reference IGenicModel::emiProbUnderModel, src/igenicmodel.cc:299-357
+    // ------------------------------------------------------------------------------------------
+    double eIg(int c, int p) const {
+        if (p > k) {
+            int pn = pat(p - k, k + 1);
+            return pn >= 0 ? t.ig_emi[(size_t)c * NP + pn] : t.ln_quarter;
+        }
+        int bk = pat(0, p + 1);
+        return bk >= 0 ? t.ig_short[((size_t)c * (k + 1) + p) * NP + bk] : t.ln_quarter;
+    }
+    // single-base intron emission: reference IntronModel::emiProbUnderModel geometric branch, src/intronmodel.cc:895-915
+    double eIn(int c, int p) const {
+        int pn = p >= k ? pat(p - k, k + 1) : -1;
+        return pn >= 0 ? t.in_emi[(size_t)c * NP + pn] : t.ln_quarter;
+    }
+
+    // splice-site gates: reference include/statemodel.hh:98-117 (no hints: consensus dinucleotides only)
+    bool possDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 2, 3); }      // gt at pos
+    bool possRDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 1); } // ac at pos-1
+    bool possASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 2); }  // ag at pos-1
+    bool possRASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 1, 3); }     // ct at pos
+
+    // Motif::seqProb forward, reference src/motif.cc:308-331
+    double motifF(const double *m, int mn, int mk, int start) const {
+        double s = 0;
+        int sz = 1 << (2 * (mk + 1));
+        for (int i = 0; i < mn; i++) {
+            int pn = pat(start + i - mk, mk + 1);
+            s += pn >= 0 ? m[(size_t)i * sz + pn] : t.ln_quarter;
+        }
+        return s;
+    }
+    // Motif::seqProb reverse complement
+    double motifRC(const double *m, int mn, int mk, int start) const {
+        double s = 0;
+        int sz = 1 << (2 * (mk + 1));
+        for (int i = 0; i < mn; i++) {
+            int pn = rcpat(start + i, mk + 1);
+            s += pn >= 0 ? m[(size_t)(mn - 1 - i) * sz + pn] : t.ln_quarter;
+        }
+        return s;
+    }
+    double tisBin(int c, double lnp) const {
+        if (t.tis_nbins < 1) return lnp;
+        double p = exp(lnp);
+        const double *bb = t.tis_bin_bounds + (size_t)c * (t.tis_nbins - 1);
+        int a = 0, bq = t.tis_nbins - 1;
+        while (a < bq) {
+            int m = (a + bq) / 2;
+            if (p < bb[m]) bq = m; else a = m + 1;
+        }
+        return t.tis_bin_ln[(size_t)c * t.tis_nbins + a];
+    }
+    // IntronModel::dSSProb, reference src/intronmodel.cc:1195-1248.  base = first position of the pattern
+    double dssProb(int base, bool fwd) const {
+        int pn;
+        if (fwd) {
+            int dsspos = base + t.Ds;
+            if (!possDSS(dsspos)) return NINF;
+            int a = pat(base, t.Ds), bq = pat(dsspos + 2, t.De);
+            if (a < 0 || bq < 0) return NINF;
+            pn = (a << (2 * t.De)) | bq;
+        } else {
+            int dsspos = base + t.De;
+            if (!possRDSS(dsspos + 1)) return NINF;
+            // astr = rc(s[dsspos+2 .. +Ds)) followed by rc(s[base .. +De))
+            int a = 0, bq = 0;
+            for (int i = 0; i < t.Ds; i++) { int c = b(dsspos + 2 + t.Ds - 1 - i); if (c > 3) return NINF; a = (a << 2) | (3 - c); }
+            for (int i = 0; i < t.De; i++) { int c = b(base + t.De - 1 - i); if (c > 3) return NINF; bq = (bq << 2) | (3 - c); }
+            pn = (a << (2 * t.De)) | bq;
+        }
+        return t.dss_pat[pn];
+    }
+    // IntronModel::aSSProb, reference src/intronmodel.cc:1116-1188.  base = first position of the motif window (fwd)
+    double assProb(int c, int base, bool fwd) const {
+        const double *M = t.ass_motif + (size_t)c * t.ass_n * (1 << (2 * (t.ass_k + 1)));
+        double motif, patl;
+        int a = 0, bq = 0;
+        bool valid = true;
+        if (fwd) {
+            int asspos = base + t.U + t.As;
+            if (!possASS(asspos + 1)) return NINF;
+            for (int i = 0; i < t.As; i++) { int cc = b(base + t.U + i); if (cc > 3) valid = false; a = (a << 2) | (cc & 3); }
+            for (int i = 0; i < t.Ae; i++) { int cc = b(asspos + 2 + i); if (cc > 3) valid = false; bq = (bq << 2) | (cc & 3); }
+            motif = base >= t.ass_k ? motifF(M, t.ass_n, t.ass_k, base) : NINF;
+        } else {
+            int asspos = base + t.Ae;
+            if (!possRASS(asspos)) return NINF;
+            for (int i = 0; i < t.As; i++) { int cc = b(asspos + 2 + t.As - 1 - i); if (cc > 3) valid = false; a = (a << 2) | ((3 - cc) & 3); }
+            for (int i = 0; i < t.Ae; i++) { int cc = b(base + t.Ae - 1 - i); if (cc > 3) valid = false; bq = (bq << 2) | ((3 - cc) & 3); }
+            int motifstart = base + t.As + 2 + t.Ae, motifend = motifstart + t.U;
+            motif = motifend + t.ass_k < n ? motifRC(M, t.ass_n, t.ass_k, motifstart) : t.U * t.ln_quarter;
+        }
+        patl = valid ? t.ass_pat[(a << (2 * t.Ae)) | bq] : t.ass_pat_invalid;
+        return motif + patl;
+    }
+
+    inline double &Vat(int j, int s) { return V[(size_t)j * S + s]; }
+    inline double lnT(int c, int a, int s) const { return t.ln_trans[((size_t)c * S + a) * S + s]; }
+
+    // ------------------------------------------------------------------------------------------
+    // exon scorer: reference ExonModel::viterbiForwardAndSampling src/exonmodel.cc:899-1179,
+    // endPartEmiProb :1272-1400, notEndPartEmiProb :1417-1859
+    // ------------------------------------------------------------------------------------------
+    struct ExGeom { int bpl, ipo, baseOffset, ipeo; bool fwd; };
+    ExGeom geom(int kind) const { // reference ExonModel ctor / getBaseOffset / getInnerPartEndOffset, :231-279
+        ExGeom g;
+        g.fwd = kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL || kind == AUGX_K_INTERNAL || kind == AUGX_K_TERMINAL;
+        if (kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL) { g.bpl = 3 + t.W; g.ipo = 3; }
+        else if (kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) { g.bpl = g.ipo = 3; }
+        else { g.bpl = 0; g.ipo = g.fwd ? t.Ae : t.Ds; }
+        if (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) { g.baseOffset = 0; g.ipeo = 3; }
+        else if (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) { g.baseOffset = -t.W; g.ipeo = 3; }
+        else { g.baseOffset = g.ipeo = g.fwd ? t.Ds : t.Ae; }
+        return g;
+    }
+    double endPart(int kind, int win, int c, int end) const {
+        switch (kind) {
+        case AUGX_K_SINGLE: case AUGX_K_TERMINAL: {
+            int stp = end - 2;
+            if (stp < 0 || stp > n - 3 || !isStop(stp)) return NINF;
+            if (b(stp + 1) == 0 && b(stp + 2) == 0) return t.ln_stop_ochre;
+            if (b(stp + 1) == 0 && b(stp + 2) == 2) return t.ln_stop_amber;
+            return t.ln_stop_opal;
+        }
+        case AUGX_K_RSINGLE: case AUGX_K_RINITIAL: {
+            int startpos = end - t.W - 3 + 1;
+            if (startpos < 0) return NINF;
+            int pn = rcpat(startpos, 3);
+            if (pn < 0 || t.ln_startcodon[pn] == NINF) return NINF;
+            double p = t.ln_startcodon[pn];
+            if (startpos + 3 + t.W - 1 + t.tis_mem < n) {
+                const double *M = t.tis_motif + (size_t)c * t.tis_n * (1 << (2 * (t.tis_k + 1)));
+                p = tisBin(c, p + motifRC(M, t.tis_n, t.tis_k, startpos + 3));
+            } else
+                p = (n - (startpos + 3)) * t.ln_quarter; // the reference REPLACES the start codon prob here (:1329)
+            return p;
+        }
+        case AUGX_K_INITIAL: case AUGX_K_INTERNAL: {
+            int dsspos = end + t.Ds + 1;
+            if (end == n - 1) return 0.0;
+            if ((dsspos + 2 - 1 < n && !possDSS(dsspos)) || end + t.Ds >= n ||
+                leftmostExonBegin(win - 1, end + t.Ds, true) >= end)
+                return NINF;
+            return 0.0;
+        }
+        default: { // RTERMINAL, RINTERNAL
+            int asspos = end + t.Ae + 1;
+            if (end == n - 1) return 0.0;
+            if (end + t.Ae + 2 < n && possRASS(asspos)) return 0.0;
+            return NINF;
+        }
+        }
+    }
+    double notEndPart(int kind, int win, int c, int bs, int right, int fOR, const ExGeom &g) {
+        ClassArrays &A = ca[c];
+        const int st = g.fwd ? 0 : 1;
+        double begin;
+        int bob = bs - g.ipo;
+        switch (kind) {
+        case AUGX_K_SINGLE: case AUGX_K_INITIAL: {
+            if (!(bob >= 0 && bob < n - 2)) return NINF;
+            int pn = pat(bob, 3);
+            if (pn < 0 || !(pn == 14 || pn == 30 || pn == 62)) return NINF; // isStartcodon: {a,c,t}tg
+            begin = t.ln_startcodon[pn];
+            if (begin == NINF) return NINF;
+            int tis = bob - t.W;
+            if (tis > t.tis_k) {
+                const double *M = t.tis_motif + (size_t)c * t.tis_n * (1 << (2 * (t.tis_k + 1)));
+                begin = tisBin(c, begin + motifF(M, t.tis_n, t.tis_k, tis));
+            } else
+                begin = begin + (bs - 3) * t.ln_quarter;
+            break;
+        }
+        case AUGX_K_TERMINAL: case AUGX_K_INTERNAL:
+            if (bs > 0) {
+                if (bob < 0 || (bob - 2 >= 0 && !possASS(bob - 1))) return NINF;
+                begin = 0.0;
+            } else if (bs == 0) begin = 0.0;
+            else return NINF;
+            break;
+        case AUGX_K_RSINGLE: case AUGX_K_RTERMINAL:
+            if (bob < 0) return NINF;
+            if (b(bob) == 3 && b(bob + 1) == 3 && b(bob + 2) == 0) begin = t.ln_stop_ochre;      // tta
+            else if (b(bob) == 1 && b(bob + 1) == 3 && b(bob + 2) == 0) begin = t.ln_stop_amber; // cta
+            else if (b(bob) == 3 && b(bob + 1) == 1 && b(bob + 2) == 0) begin = t.ln_stop_opal;  // tca
+            else return NINF;
+            if (begin == NINF) return NINF;
+            break;
+        default: // RINITIAL, RINTERNAL
+            if (bs == 0) begin = 0.0;
+            else if (bob < 0 || (bob - 2 > 0 && !possRDSS(bob - 1))) return NINF;
+            else begin = 0.0;
+        }
+        // ---- restSeqProb, reference :1548-1711
+        double rest;
+        if (bs > right) {
+            rest = (bs - right - 1) * t.ln4;
+        } else if (right - bs <= k) {
+            int l = right - bs;
+            int pn = g.fwd ? pat(bs, l + 1) : rcpat(bs, l + 1);
+            if (pn >= 0) {
+                int f = g.fwd ? fOR : mod3(fOR + right - bs);
+                rest = t.ex_pls[(((size_t)c * (k + 1) + l) * 3 + f) * NP + pn];
+            } else
+                rest = (l + 1) * t.ln_n_coding;
+        } else {
+            int endOfStart = bs + k - 1, beginOfInitP = right - (k - 1);
+            if (k == 0) rest = 0;
+            else if (g.fwd) {
+                int pn = pat(bs, k);
+                rest = pn >= 0 ? t.ex_pls[(((size_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR - right + endOfStart)) * NP + pn]
+                               : k * t.ln_n_coding;
+            } else {
+                int pn = rcpat(beginOfInitP, k);
+                rest = pn >= 0 ? t.ex_pls[(((size_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR + right - beginOfInitP)) * NP + pn]
+                               : k * t.ln_n_coding;
+            }
+            // phase of the prefix arrays: fwd f(p) = (p + a) mod 3 with a = fOR - right; rev f(p) = (a - p), a = fOR + right
+            const int a = g.fwd ? mod3(fOR - right) : mod3(fOR + right);
+            const std::vector<double> &PX = A.ex[st][0][a], &PI = A.ex[st][1][a], &PT = A.ex[st][2][a];
+            int endOfInitial, beginOfTerm, endOfTerm, beginOfInitial;
+            double inner;
+            switch (kind) {
+            case AUGX_K_SINGLE:
+                endOfInitial = endOfStart + t.Li;
+                if (endOfInitial > right) endOfInitial = right;
+                inner = seg(PI, endOfStart + 1, endOfInitial) + seg(PX, endOfInitial + 1, right);
+                break;
+            case AUGX_K_INITIAL:
+                endOfInitial = endOfStart + t.Li;
+                if (endOfInitial > right) { endOfInitial = right; beginOfTerm = right + 1; }
+                else { beginOfTerm = right - t.Le + 1; if (beginOfTerm <= endOfInitial) beginOfTerm = right + 1; }
+                inner = (seg(PI, endOfStart + 1, endOfInitial) + seg(PX, endOfInitial + 1, beginOfTerm - 1)) + seg(PT, beginOfTerm, right);
+                break;
+            case AUGX_K_INTERNAL:
+                beginOfTerm = right - t.Le + 1;
+                if (beginOfTerm <= endOfStart) beginOfTerm = right + 1;
+                inner = seg(PX, endOfStart + 1, beginOfTerm - 1) + seg(PT, beginOfTerm, right);
+                break;
+            case AUGX_K_TERMINAL:
+                inner = seg(PX, endOfStart + 1, right);
+                break;
+            case AUGX_K_RSINGLE:
+                beginOfInitial = beginOfInitP - t.Li;
+                if (beginOfInitial < bs) beginOfInitial = bs;
+                inner = seg(PI, beginOfInitial, beginOfInitP - 1) + seg(PX, bs, beginOfInitial - 1);
+                break;
+            case AUGX_K_RINITIAL:
+                beginOfInitial = beginOfInitP - t.Li;
+                if (beginOfInitial < bs) { beginOfInitial = bs; endOfTerm = bs - 1; }
+                else { endOfTerm = bs + t.Le - 1; if (endOfTerm >= beginOfInitial) endOfTerm = bs - 1; }
+                inner = (seg(PI, beginOfInitial, beginOfInitP - 1) + seg(PX, endOfTerm + 1, beginOfInitial - 1)) + seg(PT, bs, endOfTerm);
+                break;
+            case AUGX_K_RINTERNAL:
+                endOfTerm = bs + t.Le - 1;
+                if (endOfTerm >= beginOfInitP) endOfTerm = bs - 1;
+                inner = seg(PX, endOfTerm + 1, beginOfInitP - 1) + seg(PT, bs, endOfTerm);
+                break;
+            default: // RTERMINAL
+                inner = seg(PX, bs, beginOfInitP - 1);
+            }
+            rest = rest + inner;
+        }
+        // ---- length part, reference :1716-1762
+        int eob = right + g.ipeo;
+        int len = eob - bob + 1;
+        double lenPart;
+        if (len < 1 || len > t.max_exon_len) return NINF; // beyond max_exon_len the reference tables end (ORF clamp keeps len below)
+        switch (kind) {
+        case AUGX_K_SINGLE: case AUGX_K_RSINGLE: lenPart = len % 3 == 0 ? t.len_single[len] : NINF; break;
+        case AUGX_K_INITIAL: lenPart = (len % 3 == win && len > 2) ? t.len_initial[len] : NINF; break;
+        case AUGX_K_RINITIAL: lenPart = len > 2 ? t.len_initial[len] : NINF; break;
+        case AUGX_K_INTERNAL: case AUGX_K_RINTERNAL: lenPart = t.len_internal[len]; break;
+        case AUGX_K_TERMINAL: lenPart = t.len_terminal[len]; break;
+        default: lenPart = mod3(2 - len) == win ? t.len_terminal[len] : NINF; // RTERMINAL
+        }
+        if (lenPart == NINF) return NINF;
+        return (begin + rest) + lenPart;
+    }
+    void exonCell(int s, int j) {
+        const int kind = t.state_kind[s], win = t.state_win[s], c = cls[j];
+        const ExGeom g = geom(kind);
+        double endP = endPart(kind, win, c, j);
+        int eob = j + g.baseOffset, right = eob - g.ipeo;
+        if (endP == NINF || right < 0) return;
+        int fOR = g.fwd ? mod3(win - (eob + 1) + right) : mod3(win + eob + 1 - right);
+        int eons = (kind == AUGX_K_TERMINAL || kind == AUGX_K_SINGLE) ? eob - 3 : eob;
+        if (eons > n - 1) eons = n - 1;
+        int feons = g.fwd ? mod3(win - 1 - eob + eons) : mod3(win + 1 + eob - eons);
+        int ORFleft = leftmostExonBegin(feons, eons, g.fwd);
+        int startMax = eob + g.ipo - t.min_exon_len + 1, startMin;
+        if (kind == AUGX_K_RTERMINAL || kind == AUGX_K_RSINGLE)
+            startMin = startMax = ORFleft + 2;
+        else {
+            startMin = ORFleft <= 0 ? 0 : ORFleft + g.ipo;
+            if (startMax > j + g.bpl) startMax = j + g.bpl;
+        }
+        double best = NINF;
+        int ba = -1, be = 0;
+        for (int bs = startMax; bs >= startMin; bs--) {
+            int eop = bs - g.bpl - 1;
+            double nep = notEndPart(kind, win, c, bs, right, fOR, g);
+            if (nep == NINF || eop >= n) continue;
+            int col = eop >= 0 ? eop : 0;
+            int bob = bs - g.ipo, len = eob - bob + 1;
+            for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                int a = t.anc[s][ai];
+                double pv = Vat(col, a);
+                if (pv == NINF) continue;
+                bool ok = kind == AUGX_K_SINGLE || kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL || kind == AUGX_K_INITIAL ||
+                          win == mod3(g.fwd ? t.state_win[a] + len : t.state_win[a] - len);
+                if (!ok) continue;
+                double te = (lnT(c, a, s) + endP) + nep;
+                double val = pv + te;
+                if (val > best) { best = val; ba = a; be = eop; }
+            }
+        }
+        if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = be; }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // intron scorer: reference IntronModel::viterbiForwardAndSampling src/intronmodel.cc:509-858,
+    // emiProbUnderModel :861-1038
+    // ------------------------------------------------------------------------------------------
+    void intronCell(int s, int j) {
+        const int kind = t.state_kind[s], c = cls[j], f = t.state_win[s];
+        ClassArrays &A = ca[c];
+        const int dStateLen = t.d - 2 - t.De - t.As - 2 - t.U;
+        const int dssWhole = t.Ds + 2 + t.De, assWhole = t.As + 2 + t.Ae;
+        double best = NINF;
+        int ba = -1, be = 0;
+        if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
+            const bool fwd = kind == AUGX_K_LESSD;
+            int eobi = fwd ? j + t.U + t.As + 2 : j + t.De + 2;
+            if (fwd ? (eobi - 2 + 1 < n - 1 && !possASS(eobi)) : (eobi - 2 + 1 < n - 1 && !possRDSS(eobi))) return;
+            int cod[3] = {4, 4, 4};
+            bool haveRight = eobi < n - 2;
+            // frame of the state = number of bases of the spliced codon before the intron (fwd), see :557-580
+            if (fwd) {
+                if (f == 1) { cod[1] = haveRight ? b(eobi + 1) : 4; cod[2] = haveRight ? b(eobi + 2) : 4; }
+                if (f == 2) { cod[2] = haveRight ? b(eobi + 1) : 4; }
+            } else {
+                if (f == 0) { cod[0] = haveRight ? 3 - b(eobi + 1) : 4; if (haveRight && b(eobi + 1) > 3) cod[0] = 4; }
+                if (f == 1) {
+                    cod[0] = (haveRight && b(eobi + 2) <= 3) ? 3 - b(eobi + 2) : 4;
+                    cod[1] = (haveRight && b(eobi + 1) <= 3) ? 3 - b(eobi + 1) : 4;
+                }
+            }
+            int left = j - dStateLen;
+            if (left < 0) left = 0;
+            for (int eop = j - 1; eop >= left; eop--) {
+                bool any = false;
+                for (int ai = 0; ai < t.n_anc[s]; ai++)
+                    if (Vat(eop, t.anc[s][ai]) > NINF) any = true;
+                if (!any) continue;
+                // emiProbUnderModel(eop+1, j), lessD branch :924-1000
+                int begin = eop + 1;
+                int bobi = fwd ? begin - t.De - 2 : begin - (t.U + t.As + 2);
+                if (bobi >= 0 && !(fwd ? possDSS(bobi) : possRASS(bobi))) continue;
+                bool spliced = fwd ? (f != 0) : (f != 2);
+                if (spliced && bobi > 1) {
+                    int cc[3] = {cod[0], cod[1], cod[2]};
+                    if (fwd) {
+                        if (f == 1) cc[0] = b(bobi - 1);
+                        else { cc[0] = b(bobi - 2); cc[1] = b(bobi - 1); }
+                    } else {
+                        if (f == 0) { cc[1] = b(bobi - 1) <= 3 ? 3 - b(bobi - 1) : 4; cc[2] = b(bobi - 2) <= 3 ? 3 - b(bobi - 2) : 4; }
+                        else cc[2] = b(bobi - 1) <= 3 ? 3 - b(bobi - 1) : 4;
+                    }
+                    if (stopCodon3(cc[0], cc[1], cc[2])) continue;
+                }
+                int intronLength = eobi - bobi + 1;
+                if (intronLength > t.d) continue; // cannot happen without hints (j - eop <= dStateLen)
+                double restSeq = fwd ? seg(A.inF, begin, j) : seg(A.inR, begin, j);
+                double emi = t.len_intron[intronLength] + restSeq;
+                if (emi == NINF) continue;
+                for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                    int a = t.anc[s][ai];
+                    double pv = Vat(eop, a);
+                    if (pv == NINF) continue;
+                    double val = pv + (lnT(c, a, s) + emi);
+                    if (val > best) { best = val; ba = a; be = eop; }
+                }
+            }
+        } else {
+            int eop;
+            double emi;
+            switch (kind) {
+            case AUGX_K_LONGDSS:
+                eop = j - dssWhole;
+                if (eop < 0 || !possDSS(j - t.De - 2 + 1)) return;
+                emi = dssProb(j - dssWhole + 1, true);
+                break;
+            case AUGX_K_RLONGDSS:
+                eop = j - dssWhole;
+                if (eop < 0 || !possRDSS(j - t.Ds)) return;
+                emi = dssProb(j - dssWhole + 1, false);
+                break;
+            case AUGX_K_EQUALD: case AUGX_K_REQUALD:
+                eop = j - dStateLen;
+                if (eop < 0) return;
+                emi = seg(A.inF, eop + 1, j);
+                break;
+            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC:
+                eop = j - 1;
+                emi = eIn(c, j);
+                break;
+            case AUGX_K_LONGASS:
+                eop = j - assWhole - t.U;
+                if (eop < 0 || !possASS(j - t.Ae)) return;
+                emi = assProb(c, j - assWhole - t.U + 1, true);
+                break;
+            default: // RLONGASS
+                eop = j - assWhole - t.U;
+                if (eop < 0 || !possRASS(j - t.U - t.As - 2 + 1)) return;
+                emi = assProb(c, j - assWhole - t.U + 1, false);
+            }
+            if (emi == NINF) return;
+            for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                int a = t.anc[s][ai];
+                double pv = Vat(eop, a);
+                if (pv == NINF) continue;
+                double val = pv + (lnT(c, a, s) + emi);
+                if (val > best) { best = val; ba = a; be = eop; }
+            }
+        }
+        if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = be; }
+    }
+    // reference IGenicModel::viterbiForwardAndSampling, src/igenicmodel.cc:231-287
+    void igenicCell(int s, int j) {
+        const int c = cls[j];
+        double e = eIg(c, j), best = NINF;
+        int ba = t.n_anc[s] ? t.anc[s][0] : -1;
+        for (int ai = 0; ai < t.n_anc[s]; ai++) {
+            int a = t.anc[s][ai];
+            double pv = Vat(j - 1, a);
+            if (pv == NINF) continue;
+            double val = pv + (lnT(c, a, s) + e);
+            if (val > best) { best = val; ba = a; }
+        }
+        if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = j - 1; }
+    }
+
+    int run(int init_kind, int term_kind, double *lnv, std::vector<augx_state> &path) {
+        V.assign((size_t)n * S, NINF);
+        bpS.assign((size_t)n * S, -1);
+        bpE.assign((size_t)n * S, -1);
+        for (int i = 0; i < S; i++) // reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150
+            Vat(0, i) = init_kind == 0 ? t.ln_init[i] : (i == t.synch_state ? 0.0 : NINF);
+        computeStairs();
+        buildORF();
+        bool anyNuc = false;
+        for (int i = 0; i < n; i++) anyNuc |= code[i] < 4;
+        if (!anyNuc) { // reference src/namgene.cc:205-226
+            for (int j = 1; j < n; j++) {
+                Vat(j, t.synch_state) = Vat(j - 1, t.synch_state) - t.ln4;
+                bpS[(size_t)j * S + t.synch_state] = t.synch_state;
+                bpE[(size_t)j * S + t.synch_state] = j - 1;
+            }
+        } else {
+            for (int j = 0; j < n; j++) buildClass(cls[j]);
+            for (int j = 1; j < n; j++)
+                for (int s = 0; s < S; s++) {
+                    if (!t.reachable[s]) continue;
+                    int kind = t.state_kind[s];
+                    if (kind == AUGX_K_IGENIC) igenicCell(s, j);
+                    else if (kind <= AUGX_K_RTERMINAL) exonCell(s, j);
+                    else intronCell(s, j);
+                }
+        }
+        // termination + back-tracking: reference NAMGene::getViterbiPath, src/namgene.cc:432-510
+        double maxV = NINF;
+        int state = -1;
+        for (int i = 0; i < S; i++) {
+            double tl = term_kind == 0 ? t.ln_term[i] : (i == t.synch_state ? 0.0 : NINF);
+            double v = Vat(n - 1, i) + tl;
+            if (v > maxV) { maxV = v; state = i; }
+        }
+        *lnv = maxV;
+        path.clear();
+        if (state < 0) return AUGX_E_NOPATH;
+        int base = n - 1;
+        while (base > 0) {
+            int a = bpS[(size_t)base * S + state], e = bpE[(size_t)base * S + state];
+            if (a < 0) return AUGX_E_NOPATH;
+            augx_state st;
+            st.begin = e + 1; st.end = base; st.state = (int16_t)state; st.type = (int16_t)t.state_type[state];
+            path.push_back(st);
+            base = e;
+            state = a;
+        }
+        // reverse into 5'->3' order and merge single-base igenic / geometric runs
+        std::vector<augx_state> out;
+        for (size_t i = path.size(); i-- > 0;) {
+            const augx_state &st = path[i];
+            int kind = t.state_kind[st.state];
+            bool mergeable = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC;
+            if (mergeable && !out.empty() && out.back().state == st.state && out.back().end + 1 == st.begin)
+                out.back().end = st.end;
+            else
+                out.push_back(st);
+        }
+        path.swap(out);
+        return 0;
+    }
+};
+
+} // namespace
+
+extern "C" {
+/* decode one piece on the CPU.  V_out (len*S doubles) and gc_out (len int32) may be NULL.
+ * states_out receives at most cap records; *n_states is the number available. */
+int twin_decode(const augx_tables *t, const char *seq, int64_t len, int init_kind, int term_kind, double *V_out,
+                int32_t *gc_out, augx_state *states_out, int32_t cap, int32_t *n_states, double *ln_viterbi) {
+    if (!t || !seq || len < 1) return AUGX_E_ARG;
+    Twin tw(*t, seq, (int)len);
+    std::vector<augx_state> path;
+    double lnv;
+    int rc = tw.run(init_kind, term_kind, &lnv, path);
+    if (ln_viterbi) *ln_viterbi = lnv;
+    if (V_out) memcpy(V_out, tw.V.data(), sizeof(double) * (size_t)len * t->S);
+    if (gc_out) for (int64_t i = 0; i < len; i++) gc_out[i] = tw.cls[i];
+    if (n_states) *n_states = (int32_t)path.size();
+    if (states_out)
+        for (int32_t i = 0; i < cap && i < (int32_t)path.size(); i++) states_out[i] = path[i];
+    return rc;
+}
+}
