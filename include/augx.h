@@ -22,6 +22,11 @@ extern "C" {
 #define AUGX_MAX_STATES 80
 #define AUGX_MAX_ANC 8
 #define AUGX_MAX_CLASSES 8
+/* Markov-chain content sums are accumulated in fixed point (ln p * 2^40 rounded to int64, wrap-around
+ * uint64 adds): exactly associative, so device scans of any shape give bit-identical prefix differences. */
+#define AUGX_FX_SHIFT 40
+#define AUGX_FX_SCALE 1099511627776.0          /* 2^40  */
+#define AUGX_FX_INV (1.0 / 1099511627776.0)    /* 2^-40 */
 
 enum {
     AUGX_OK = 0,

@@ -48,8 +48,9 @@ struct Twin {
     // prefix sums per class, allocated lazily; index [p+1], P[0]=0
     struct ClassArrays {
         bool built = false;
-        std::vector<double> inF, inR;       // intron fwd pattern / rc pattern (rlessD)
-        std::vector<double> ex[2][3][3];    // [strand][table: 0 emi,1 init,2 et][phase]
+        // exactly-associative fixed-point prefix sums: term = llrint(ln p * 2^AUGX_FX_SHIFT), wrap-around uint64
+        std::vector<uint64_t> inF, inR;     // intron fwd pattern / rc pattern (rlessD)
+        std::vector<uint64_t> ex[2][3][3];  // [strand][table: 0 emi,1 init,2 et][phase]
     };
     std::vector<ClassArrays> ca;
     std::vector<int> nsF, nsR;              // nearestStopForward / Reverse
@@ -194,34 +195,37 @@ struct Twin {
         if (A.built) return;
         A.built = true;
         const double *inE = t.in_emi + (size_t)c * NP;
-        A.inF.assign(n + 1, 0.0);
-        A.inR.assign(n + 1, 0.0);
+        A.inF.assign(n + 1, 0);
+        A.inR.assign(n + 1, 0);
         for (int p = 0; p < n; p++) {
             // forward: reference IntronModel::seqProb src/intronmodel.cc:1090-1101 / SnippetProbs fwd src/statemodel.cc:287-297
             int pn = p >= k ? pat(p - k, k + 1) : -1;
-            A.inF[p + 1] = A.inF[p] + (pn >= 0 ? inE[pn] : t.ln_quarter);
+            A.inF[p + 1] = A.inF[p] + fx(pn >= 0 ? inE[pn] : t.ln_quarter);
             // reverse snippet (rlessD only): src/statemodel.cc:298-309
             int rn = (p + k < n) ? rcpat(p, k + 1) : -1;
-            A.inR[p + 1] = A.inR[p] + (rn >= 0 ? inE[rn] : t.ln_quarter);
+            A.inR[p + 1] = A.inR[p] + fx(rn >= 0 ? inE[rn] : t.ln_quarter);
         }
         const double *tabs[3] = {t.ex_emi + (size_t)c * 3 * NP, t.ex_init + (size_t)c * 3 * NP, t.ex_et + (size_t)c * 3 * NP};
         for (int tb = 0; tb < 3; tb++)
             for (int a = 0; a < 3; a++) {
-                std::vector<double> &F = A.ex[0][tb][a], &R = A.ex[1][tb][a];
-                F.assign(n + 1, 0.0);
-                R.assign(n + 1, 0.0);
+                std::vector<uint64_t> &F = A.ex[0][tb][a], &R = A.ex[1][tb][a];
+                F.assign(n + 1, 0);
+                R.assign(n + 1, 0);
                 for (int p = 0; p < n; p++) {
                     // forward strand: frame f(p) = (p + a) mod 3, pattern = bases p-k..p
                     // (reference ExonModel::seqProb, src/exonmodel.cc:1957-1966)
                     int pn = p >= k ? pat(p - k, k + 1) : -1;
-                    F[p + 1] = F[p] + (pn >= 0 ? tabs[tb][mod3(p + a) * NP + pn] : t.ln_n_coding);
+                    F[p + 1] = F[p] + fx(pn >= 0 ? tabs[tb][mod3(p + a) * NP + pn] : t.ln_n_coding);
                     // reverse strand: frame f(p) = (a - p) mod 3, pattern = rc of bases p..p+k
                     int rn = rcpat(p, k + 1); // reading the terminating NUL / beyond = invalid
-                    R[p + 1] = R[p] + (rn >= 0 ? tabs[tb][mod3(a - p) * NP + rn] : t.ln_n_coding);
+                    R[p + 1] = R[p] + fx(rn >= 0 ? tabs[tb][mod3(a - p) * NP + rn] : t.ln_n_coding);
                 }
             }
     }
-    inline double seg(const std::vector<double> &P, int l, int r) const { return l > r ? 0.0 : P[r + 1] - P[l]; }
+    static inline uint64_t fx(double lnp) { return (uint64_t)(int64_t)llrint(lnp * AUGX_FX_SCALE); }
+    inline double seg(const std::vector<uint64_t> &P, int l, int r) const {
+        return l > r ? 0.0 : (double)(int64_t)(P[r + 1] - P[l]) * AUGX_FX_INV;
+    }
 
     // ------------------------------------------------------------------------------------------
     // igenic emission: reference IGenicModel::emiProbUnderModel, src/igenicmodel.cc:299-357
@@ -444,7 +448,7 @@ struct Twin {
             }
             // phase of the prefix arrays: fwd f(p) = (p + a) mod 3 with a = fOR - right; rev f(p) = (a - p), a = fOR + right
             const int a = g.fwd ? mod3(fOR - right) : mod3(fOR + right);
-            const std::vector<double> &PX = A.ex[st][0][a], &PI = A.ex[st][1][a], &PT = A.ex[st][2][a];
+            const std::vector<uint64_t> &PX = A.ex[st][0][a], &PI = A.ex[st][1][a], &PT = A.ex[st][2][a];
             int endOfInitial, beginOfTerm, endOfTerm, beginOfInitial;
             double inner;
             switch (kind) {
