@@ -1,0 +1,469 @@
+// dp.h -- device data model and scalar helper functions of the GHMM decode kernels.
+//
+// Everything here is written once and compiled twice: by hipcc for gfx950 (the product), and by g++ with
+// -DAUGX_EMU for the lane-loop emulator under tests/emu (a debugging aid for a GPU-less container; it is
+// test infrastructure, never a product fallback).  All arithmetic on the decode path is fp64 add/compare
+// plus uint64 fixed-point sums, compiled with -ffp-contract=off, so both builds are bit-identical.
+//
+// The per-state formulas restate the reference scorers (cited per function); data layout, candidate lists
+// and the kernel decomposition are ours.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include "../../../include/augx.h"
+
+#ifdef AUGX_EMU
+#define AUGX_HD inline
+#else
+#include <hip/hip_runtime.h>
+#define AUGX_HD __host__ __device__ inline
+#endif
+
+namespace augx {
+namespace dev {
+
+constexpr int WAVE = 64;
+constexpr int SP = 48;          // column stride of the trellis storage (S <= SP)
+constexpr int NFX = 20;         // fixed-point prefix fields per slot: [strand 2][phase 3][table 3], inF, inR
+constexpr int FX_INF = 18, FX_INR = 19;
+constexpr int NSIG = 9;         // per-position signal record: eIg eIn dssF dssR assF assR tisF tisR eqD
+constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4, SIG_ASSR = 5, SIG_TISF = 6, SIG_TISR = 7, SIG_EQD = 8;
+constexpr int CHUNK = 1024;     // slots per scan chunk; every piece is padded to a multiple of CHUNK
+constexpr int LONG_RING = 1024; // ring depth for the states consumed at lag dStateLen (must exceed it)
+constexpr uint16_t BP_NONE = 0xFFFF;
+
+#define AUGX_NINF (-INFINITY)
+
+// flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
+struct DevTables {
+    int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
+    int tis_n, tis_k, ass_n, ass_k, tis_nbins, tis_mem, synch, gc_win, gc_weighing_type;
+    int kind[AUGX_MAX_STATES], win[AUGX_MAX_STATES], type[AUGX_MAX_STATES], reachable[AUGX_MAX_STATES];
+    int n_anc[AUGX_MAX_STATES], anc[AUGX_MAX_STATES][AUGX_MAX_ANC];
+    double ln_init[AUGX_MAX_STATES], ln_term[AUGX_MAX_STATES];
+    double ln_startcodon[64];
+    double ln_stop_ochre, ln_stop_amber, ln_stop_opal, ln_quarter, ln_n_coding, ln4, ass_pat_invalid;
+    double gc_zus[AUGX_MAX_CLASSES][4], gc_weight_matrix[16];
+    const double *ln_trans, *ig_emi, *ig_short, *in_emi, *ex_emi, *ex_init, *ex_et, *ex_pls, *tis_motif, *ass_motif,
+        *tis_bin_bounds, *tis_bin_ln, *ass_pat, *dss_pat, *len_intron, *len_single, *len_initial, *len_internal,
+        *len_terminal;
+};
+
+// a batch of pieces laid out in one slot space.  Piece p owns slots [off[p], off[p+1]); slot off[p] is the
+// "before the first base" slot, base q lives in slot off[p]+1+q; off[p] is a multiple of CHUNK.
+struct BatchView {
+    int nPieces;
+    int64_t N;                 // total slots
+    int nChunks;
+    const int64_t *off;        // [nPieces+1]
+    const int32_t *len;        // [nPieces]
+    const int32_t *initKind, *termKind;
+    const int32_t *chunkPiece; // [nChunks]
+    int32_t *cls;              // [nPieces] GC class of the piece (single class per piece in this version)
+    int32_t *clsMinMax;        // [nPieces][2]
+    const char *raw;           // [N] ASCII (slot layout)
+    uint8_t *code;             // [N] 0..3 acgt, 4 invalid / padding
+    uint64_t *cnt;             // [N][4] prefix base counts
+    uint64_t *nsm;             // [N][6] prefix max of (stop position+1) per residue class, fwd 0..2, rev 3..5
+    uint64_t *fx;              // [N][NFX] fixed-point prefix sums
+    double *sig;               // [N][NSIG]
+    uint64_t *gate;            // [N] bit s: variable-length state s passes its end gate at this base
+    int32_t *site;             // [N][4] list index of the splice-site candidate ending here (LA, LR, LD, RD) or -1
+    uint64_t *chunkTot;        // scratch [nChunks][NFX]
+    // trellis
+    uint16_t *bp;              // [N][SP] back pointers
+    double *cells;             // [N][S] dense ln V (debug/test only) or NULL
+    double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
+    int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]
+    int32_t *lrPos; double *lrVal;   // reverse donor candidates     (rlongdss_f live)
+    int32_t *ldPos; double *ldVal;   // forward short-intron starts  (longdss_f live)
+    int32_t *rdPos; double *rdVal;   // reverse short-intron starts  (rlongass_f live)
+    int32_t *atgPos;                 // start codons (position of the a of atg) [N/2]
+    // results
+    double *lnv;               // [nPieces]
+    int32_t *status;           // [nPieces]
+    int32_t *finalState;       // [nPieces]
+    int32_t *pathRec;          // [N/8 + 64*nPieces][3]  (begin, end, state), reverse order per piece
+    int32_t *pathCount;        // [nPieces]
+};
+
+AUGX_HD int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
+AUGX_HD int64_t listOff(const BatchView &B, int p) { return B.off[p] / 2; }
+AUGX_HD int64_t pathOff(const BatchView &B, int p) { return B.off[p] / 8 + 64 * (int64_t)p; }
+AUGX_HD int64_t pathCap(const BatchView &B, int p) { return (B.off[p + 1] - B.off[p]) / 8 + 64; }
+
+// view of one piece: pointers pre-offset so that index q is the 0-based base position
+struct Piece {
+    const DevTables *t;
+    int n, c;                  // length, GC class
+    const uint8_t *code;       // code[q]
+    const uint64_t *fx;        // fx[(q+1)*NFX + f] = prefix sum up to and including q
+    const uint64_t *nsm;       // nsm[(q+1)*6 + r]
+    const double *sig;         // sig[q*NSIG + i]
+    AUGX_HD int b(int p) const { return (p >= 0 && p < n) ? code[p] : 4; }
+    AUGX_HD bool is2(int p, int x, int y) const { return b(p) == x && b(p + 1) == y; }
+    AUGX_HD int pat(int p, int len) const {
+        int r = 0;
+        for (int i = 0; i < len; i++) {
+            int cc = b(p + i);
+            if (cc > 3) return -1;
+            r = (r << 2) | cc;
+        }
+        return r;
+    }
+    AUGX_HD int rcpat(int p, int len) const { // Seq2Int::rc, reference include/geneticcode.hh:174-179
+        int r = 0;
+        for (int i = 0; i < len; i++) {
+            int cc = b(p + i);
+            if (cc > 3) return -1;
+            r |= (3 - cc) << (2 * i);
+        }
+        return r;
+    }
+    AUGX_HD bool isStop(int p) const {
+        return b(p) == 3 && ((b(p + 1) == 0 && (b(p + 2) == 0 || b(p + 2) == 2)) || (b(p + 1) == 2 && b(p + 2) == 0));
+    }
+    AUGX_HD bool isRCStop(int p) const {
+        return b(p + 2) == 0 && ((b(p + 1) == 3 && (b(p) == 3 || b(p) == 1)) || (b(p + 1) == 1 && b(p) == 3));
+    }
+    // splice-site gates, reference include/statemodel.hh:98-117 (ab initio: consensus dinucleotides only)
+    AUGX_HD bool possDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 2, 3); }
+    AUGX_HD bool possRDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 1); }
+    AUGX_HD bool possASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 2); }
+    AUGX_HD bool possRASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 1, 3); }
+    // Markov-chain content of bases l..r from the fixed-point prefix field f
+    AUGX_HD double seg(int f, int l, int r) const {
+        if (l > r) return 0.0;
+        uint64_t hi = fx[(int64_t)(r + 1) * NFX + f], lo = fx[(int64_t)l * NFX + f];
+        return (double)(int64_t)(hi - lo) * AUGX_FX_INV;
+    }
+    // nearest in-frame stop: reference OpenReadingFrame tables, src/exonmodel.cc:101-156
+    AUGX_HD int nearestStop(int pos, bool fwd) const {
+        if (n <= 5 && pos >= n - 2) return 0; // tables left unpatched by the reference for tiny inputs
+        return (int)nsm[(int64_t)(pos + 1) * 6 + (fwd ? 0 : 3) + pos % 3] - 1;
+    }
+    // reference OpenReadingFrame::leftmostExonBegin, src/exonmodel.cc:165-198
+    AUGX_HD int leftmostExonBegin(int frame, int base, bool fwd) const {
+        int pos;
+        if (fwd) pos = (frame == 0 || frame == 1) ? base - frame - 3 : base - frame;
+        else pos = (frame == 1 || frame == 2) ? base + frame - 5 : base - 2;
+        if (pos >= n) pos -= 3 * ((pos - n + 3) / 3);
+        int lmb = pos >= 0 ? nearestStop(pos, fwd) + 1 : 0;
+        int maxAllowed = t->max_exon_len - t->U - t->As - 2 - 2 - t->Ds;
+        if (lmb < base - maxAllowed) lmb = base - maxAllowed;
+        return lmb;
+    }
+};
+
+AUGX_HD bool stopCodon3(int c0, int c1, int c2) {
+    if (c0 > 3 || c1 > 3 || c2 > 3) return false;
+    return c0 == 3 && ((c1 == 0 && (c2 == 0 || c2 == 2)) || (c1 == 2 && c2 == 0));
+}
+AUGX_HD uint64_t toFx(double lnp) { return (uint64_t)(int64_t)llrint(lnp * AUGX_FX_SCALE); }
+
+// Motif::seqProb (reference src/motif.cc:308-331), forward and reverse-complement
+AUGX_HD double motifF(const Piece &P, const double *m, int mn, int mk, int start) {
+    double s = 0;
+    int sz = 1 << (2 * (mk + 1));
+    for (int i = 0; i < mn; i++) {
+        int pn = P.pat(start + i - mk, mk + 1);
+        s += pn >= 0 ? m[(int64_t)i * sz + pn] : P.t->ln_quarter;
+    }
+    return s;
+}
+AUGX_HD double motifRC(const Piece &P, const double *m, int mn, int mk, int start) {
+    double s = 0;
+    int sz = 1 << (2 * (mk + 1));
+    for (int i = 0; i < mn; i++) {
+        int pn = P.rcpat(start + i, mk + 1);
+        s += pn >= 0 ? m[(int64_t)(mn - 1 - i) * sz + pn] : P.t->ln_quarter;
+    }
+    return s;
+}
+AUGX_HD double tisBin(const DevTables &t, int c, double lnp) {
+    if (t.tis_nbins < 1) return lnp;
+    double p = exp(lnp);
+    const double *bb = t.tis_bin_bounds + (int64_t)c * (t.tis_nbins - 1);
+    int a = 0, bq = t.tis_nbins - 1;
+    while (a < bq) {
+        int m = (a + bq) / 2;
+        if (p < bb[m]) bq = m; else a = m + 1;
+    }
+    return t.tis_bin_ln[(int64_t)c * t.tis_nbins + a];
+}
+// IntronModel::dSSProb, reference src/intronmodel.cc:1195-1248
+AUGX_HD double dssProb(const Piece &P, int base, bool fwd) {
+    const DevTables &t = *P.t;
+    int a = 0, bq = 0;
+    if (fwd) {
+        int dsspos = base + t.Ds;
+        if (!P.possDSS(dsspos)) return AUGX_NINF;
+        a = P.pat(base, t.Ds);
+        bq = P.pat(dsspos + 2, t.De);
+        if (a < 0 || bq < 0) return AUGX_NINF;
+    } else {
+        int dsspos = base + t.De;
+        if (!P.possRDSS(dsspos + 1)) return AUGX_NINF;
+        for (int i = 0; i < t.Ds; i++) { int cc = P.b(dsspos + 2 + t.Ds - 1 - i); if (cc > 3) return AUGX_NINF; a = (a << 2) | (3 - cc); }
+        for (int i = 0; i < t.De; i++) { int cc = P.b(base + t.De - 1 - i); if (cc > 3) return AUGX_NINF; bq = (bq << 2) | (3 - cc); }
+    }
+    return t.dss_pat[(a << (2 * t.De)) | bq];
+}
+// IntronModel::aSSProb, reference src/intronmodel.cc:1116-1188
+AUGX_HD double assProb(const Piece &P, int base, bool fwd) {
+    const DevTables &t = *P.t;
+    const double *M = t.ass_motif + (int64_t)P.c * t.ass_n * (1 << (2 * (t.ass_k + 1)));
+    double motif;
+    int a = 0, bq = 0;
+    bool valid = true;
+    if (fwd) {
+        int asspos = base + t.U + t.As;
+        if (!P.possASS(asspos + 1)) return AUGX_NINF;
+        for (int i = 0; i < t.As; i++) { int cc = P.b(base + t.U + i); if (cc > 3) valid = false; a = (a << 2) | (cc & 3); }
+        for (int i = 0; i < t.Ae; i++) { int cc = P.b(asspos + 2 + i); if (cc > 3) valid = false; bq = (bq << 2) | (cc & 3); }
+        motif = base >= t.ass_k ? motifF(P, M, t.ass_n, t.ass_k, base) : AUGX_NINF;
+    } else {
+        int asspos = base + t.Ae;
+        if (!P.possRASS(asspos)) return AUGX_NINF;
+        for (int i = 0; i < t.As; i++) { int cc = P.b(asspos + 2 + t.As - 1 - i); if (cc > 3) valid = false; a = (a << 2) | ((3 - cc) & 3); }
+        for (int i = 0; i < t.Ae; i++) { int cc = P.b(base + t.Ae - 1 - i); if (cc > 3) valid = false; bq = (bq << 2) | ((3 - cc) & 3); }
+        int motifstart = base + t.As + 2 + t.Ae, motifend = motifstart + t.U;
+        motif = motifend + t.ass_k < P.n ? motifRC(P, M, t.ass_n, t.ass_k, motifstart) : t.U * t.ln_quarter;
+    }
+    double patl = valid ? t.ass_pat[(a << (2 * t.Ae)) | bq] : t.ass_pat_invalid;
+    return motif + patl;
+}
+// begin part of SINGLE/INITIAL exons as a function of the start codon position bob
+// (reference ExonModel::notEndPartEmiProb, src/exonmodel.cc:1427-1463)
+AUGX_HD double tisFwd(const Piece &P, int bob) {
+    const DevTables &t = *P.t;
+    if (!(bob >= 0 && bob < P.n - 2)) return AUGX_NINF;
+    int pn = P.pat(bob, 3);
+    if (pn < 0) return AUGX_NINF;
+    double begin = t.ln_startcodon[pn];
+    if (begin == AUGX_NINF) return AUGX_NINF;
+    int tis = bob - t.W;
+    if (tis > t.tis_k) {
+        const double *M = t.tis_motif + (int64_t)P.c * t.tis_n * (1 << (2 * (t.tis_k + 1)));
+        return tisBin(t, P.c, begin + motifF(P, M, t.tis_n, t.tis_k, tis));
+    }
+    return begin + bob * t.ln_quarter; // pow(0.25, beginOfStart - STARTCODON_LEN)
+}
+// end part of RSINGLE/RINITIAL exons ending (as a state) at `end` (reference endPartEmiProb, :1313-1350)
+AUGX_HD double tisRev(const Piece &P, int end) {
+    const DevTables &t = *P.t;
+    int startpos = end - t.W - 3 + 1;
+    if (startpos < 0) return AUGX_NINF;
+    int pn = P.rcpat(startpos, 3);
+    if (pn < 0 || t.ln_startcodon[pn] == AUGX_NINF) return AUGX_NINF;
+    if (startpos + 3 + t.W - 1 + t.tis_mem < P.n) {
+        const double *M = t.tis_motif + (int64_t)P.c * t.tis_n * (1 << (2 * (t.tis_k + 1)));
+        return tisBin(t, P.c, t.ln_startcodon[pn] + motifRC(P, M, t.tis_n, t.tis_k, startpos + 3));
+    }
+    return (P.n - (startpos + 3)) * t.ln_quarter;
+}
+// single-base emissions (reference src/igenicmodel.cc:328-356, src/intronmodel.cc:895-915)
+AUGX_HD double eIg(const Piece &P, int p) {
+    const DevTables &t = *P.t;
+    if (p > t.k) {
+        int pn = P.pat(p - t.k, t.k + 1);
+        return pn >= 0 ? t.ig_emi[(int64_t)P.c * t.NP + pn] : t.ln_quarter;
+    }
+    int bk = P.pat(0, p + 1);
+    return bk >= 0 ? t.ig_short[((int64_t)P.c * (t.k + 1) + p) * t.NP + bk] : t.ln_quarter;
+}
+AUGX_HD double eIn(const Piece &P, int p) {
+    const DevTables &t = *P.t;
+    int pn = p >= t.k ? P.pat(p - t.k, t.k + 1) : -1;
+    return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NP + pn] : t.ln_quarter;
+}
+
+struct ExGeom { int bpl, ipo, baseOffset, ipeo; bool fwd; };
+AUGX_HD ExGeom exGeom(const DevTables &t, int kind) { // reference src/exonmodel.cc:231-279
+    ExGeom g;
+    g.fwd = kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL || kind == AUGX_K_INTERNAL || kind == AUGX_K_TERMINAL;
+    if (kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL) { g.bpl = 3 + t.W; g.ipo = 3; }
+    else if (kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) { g.bpl = g.ipo = 3; }
+    else { g.bpl = 0; g.ipo = g.fwd ? t.Ae : t.Ds; }
+    if (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) { g.baseOffset = 0; g.ipeo = 3; }
+    else if (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) { g.baseOffset = -t.W; g.ipeo = 3; }
+    else { g.baseOffset = g.ipeo = g.fwd ? t.Ds : t.Ae; }
+    return g;
+}
+// reference ExonModel::endPartEmiProb, src/exonmodel.cc:1272-1400.  tisR = precomputed tisRev(end)
+AUGX_HD double exEndPart(const Piece &P, int kind, int win, int end, double tisR) {
+    const DevTables &t = *P.t;
+    const int n = P.n;
+    switch (kind) {
+    case AUGX_K_SINGLE: case AUGX_K_TERMINAL: {
+        int stp = end - 2;
+        if (stp < 0 || stp > n - 3 || !P.isStop(stp)) return AUGX_NINF;
+        if (P.b(stp + 1) == 0 && P.b(stp + 2) == 0) return t.ln_stop_ochre;
+        if (P.b(stp + 1) == 0 && P.b(stp + 2) == 2) return t.ln_stop_amber;
+        return t.ln_stop_opal;
+    }
+    case AUGX_K_RSINGLE: case AUGX_K_RINITIAL:
+        return tisR;
+    case AUGX_K_INITIAL: case AUGX_K_INTERNAL: {
+        int dsspos = end + t.Ds + 1;
+        if (end == n - 1) return 0.0;
+        if ((dsspos + 2 - 1 < n && !P.possDSS(dsspos)) || end + t.Ds >= n || P.leftmostExonBegin(win - 1, end + t.Ds, true) >= end)
+            return AUGX_NINF;
+        return 0.0;
+    }
+    default: {
+        int asspos = end + t.Ae + 1;
+        if (end == n - 1) return 0.0;
+        if (end + t.Ae + 2 < n && P.possRASS(asspos)) return 0.0;
+        return AUGX_NINF;
+    }
+    }
+}
+// reference ExonModel::notEndPartEmiProb, src/exonmodel.cc:1417-1859 (ab initio: extrinsicQuot == 1).
+// tisF = value of sig[SIG_TISF] at bob (only read for SINGLE/INITIAL)
+AUGX_HD double exNotEndPart(const Piece &P, int kind, int win, int bs, int right, int fOR, const ExGeom &g, double tisF) {
+    const DevTables &t = *P.t;
+    const int n = P.n, k = t.k, c = P.c;
+    (void)n;
+    double begin;
+    int bob = bs - g.ipo;
+    switch (kind) {
+    case AUGX_K_SINGLE: case AUGX_K_INITIAL:
+        begin = tisF;
+        if (begin == AUGX_NINF) return AUGX_NINF;
+        break;
+    case AUGX_K_TERMINAL: case AUGX_K_INTERNAL:
+        if (bs > 0) {
+            if (bob < 0 || (bob - 2 >= 0 && !P.possASS(bob - 1))) return AUGX_NINF;
+            begin = 0.0;
+        } else if (bs == 0) begin = 0.0;
+        else return AUGX_NINF;
+        break;
+    case AUGX_K_RSINGLE: case AUGX_K_RTERMINAL:
+        if (bob < 0) return AUGX_NINF;
+        if (P.b(bob) == 3 && P.b(bob + 1) == 3 && P.b(bob + 2) == 0) begin = t.ln_stop_ochre;
+        else if (P.b(bob) == 1 && P.b(bob + 1) == 3 && P.b(bob + 2) == 0) begin = t.ln_stop_amber;
+        else if (P.b(bob) == 3 && P.b(bob + 1) == 1 && P.b(bob + 2) == 0) begin = t.ln_stop_opal;
+        else return AUGX_NINF;
+        if (begin == AUGX_NINF) return AUGX_NINF;
+        break;
+    default:
+        if (bs == 0) begin = 0.0;
+        else if (bob < 0 || (bob - 2 > 0 && !P.possRDSS(bob - 1))) return AUGX_NINF;
+        else begin = 0.0;
+    }
+    double rest;
+    if (bs > right) {
+        rest = (bs - right - 1) * t.ln4;
+    } else if (right - bs <= k) {
+        int l = right - bs;
+        int pn = g.fwd ? P.pat(bs, l + 1) : P.rcpat(bs, l + 1);
+        if (pn >= 0) {
+            int f = g.fwd ? fOR : mod3(fOR + right - bs);
+            rest = t.ex_pls[(((int64_t)c * (k + 1) + l) * 3 + f) * t.NP + pn];
+        } else
+            rest = (l + 1) * t.ln_n_coding;
+    } else {
+        int endOfStart = bs + k - 1, beginOfInitP = right - (k - 1);
+        if (k == 0) rest = 0;
+        else if (g.fwd) {
+            int pn = P.pat(bs, k);
+            rest = pn >= 0 ? t.ex_pls[(((int64_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR - right + endOfStart)) * t.NP + pn] : k * t.ln_n_coding;
+        } else {
+            int pn = P.rcpat(beginOfInitP, k);
+            rest = pn >= 0 ? t.ex_pls[(((int64_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR + right - beginOfInitP)) * t.NP + pn] : k * t.ln_n_coding;
+        }
+        const int a = g.fwd ? mod3(fOR - right) : mod3(fOR + right);
+        const int fb = ((g.fwd ? 0 : 1) * 3 + a) * 3; // field base: +0 exon, +1 init, +2 et
+        const int PX = fb, PI = fb + 1, PT = fb + 2;
+        int endOfInitial, beginOfTerm, endOfTerm, beginOfInitial;
+        double inner;
+        switch (kind) {
+        case AUGX_K_SINGLE:
+            endOfInitial = endOfStart + t.Li;
+            if (endOfInitial > right) endOfInitial = right;
+            inner = P.seg(PI, endOfStart + 1, endOfInitial) + P.seg(PX, endOfInitial + 1, right);
+            break;
+        case AUGX_K_INITIAL:
+            endOfInitial = endOfStart + t.Li;
+            if (endOfInitial > right) { endOfInitial = right; beginOfTerm = right + 1; }
+            else { beginOfTerm = right - t.Le + 1; if (beginOfTerm <= endOfInitial) beginOfTerm = right + 1; }
+            inner = (P.seg(PI, endOfStart + 1, endOfInitial) + P.seg(PX, endOfInitial + 1, beginOfTerm - 1)) + P.seg(PT, beginOfTerm, right);
+            break;
+        case AUGX_K_INTERNAL:
+            beginOfTerm = right - t.Le + 1;
+            if (beginOfTerm <= endOfStart) beginOfTerm = right + 1;
+            inner = P.seg(PX, endOfStart + 1, beginOfTerm - 1) + P.seg(PT, beginOfTerm, right);
+            break;
+        case AUGX_K_TERMINAL:
+            inner = P.seg(PX, endOfStart + 1, right);
+            break;
+        case AUGX_K_RSINGLE:
+            beginOfInitial = beginOfInitP - t.Li;
+            if (beginOfInitial < bs) beginOfInitial = bs;
+            inner = P.seg(PI, beginOfInitial, beginOfInitP - 1) + P.seg(PX, bs, beginOfInitial - 1);
+            break;
+        case AUGX_K_RINITIAL:
+            beginOfInitial = beginOfInitP - t.Li;
+            if (beginOfInitial < bs) { beginOfInitial = bs; endOfTerm = bs - 1; }
+            else { endOfTerm = bs + t.Le - 1; if (endOfTerm >= beginOfInitial) endOfTerm = bs - 1; }
+            inner = (P.seg(PI, beginOfInitial, beginOfInitP - 1) + P.seg(PX, endOfTerm + 1, beginOfInitial - 1)) + P.seg(PT, bs, endOfTerm);
+            break;
+        case AUGX_K_RINTERNAL:
+            endOfTerm = bs + t.Le - 1;
+            if (endOfTerm >= beginOfInitP) endOfTerm = bs - 1;
+            inner = P.seg(PX, endOfTerm + 1, beginOfInitP - 1) + P.seg(PT, bs, endOfTerm);
+            break;
+        default:
+            inner = P.seg(PX, bs, beginOfInitP - 1);
+        }
+        rest = rest + inner;
+    }
+    int eob = right + g.ipeo;
+    int len = eob - bob + 1;
+    double lenPart;
+    if (len < 1 || len > t.max_exon_len) return AUGX_NINF;
+    switch (kind) {
+    case AUGX_K_SINGLE: case AUGX_K_RSINGLE: lenPart = len % 3 == 0 ? t.len_single[len] : AUGX_NINF; break;
+    case AUGX_K_INITIAL: lenPart = (len % 3 == win && len > 2) ? t.len_initial[len] : AUGX_NINF; break;
+    case AUGX_K_RINITIAL: lenPart = len > 2 ? t.len_initial[len] : AUGX_NINF; break;
+    case AUGX_K_INTERNAL: case AUGX_K_RINTERNAL: lenPart = t.len_internal[len]; break;
+    case AUGX_K_TERMINAL: lenPart = t.len_terminal[len]; break;
+    default: lenPart = mod3(2 - len) == win ? t.len_terminal[len] : AUGX_NINF;
+    }
+    if (lenPart == AUGX_NINF) return AUGX_NINF;
+    return (begin + rest) + lenPart;
+}
+
+// geometry of one exon end (state s ending at base j), reference src/exonmodel.cc:939-1054
+struct ExEnd { int eob, right, fOR, startMin, startMax; };
+AUGX_HD ExEnd exEnd(const Piece &P, int kind, int win, int j, const ExGeom &g) {
+    const DevTables &t = *P.t;
+    ExEnd e;
+    e.eob = j + g.baseOffset;
+    e.right = e.eob - g.ipeo;
+    e.fOR = g.fwd ? mod3(win - (e.eob + 1) + e.right) : mod3(win + e.eob + 1 - e.right);
+    int eons = (kind == AUGX_K_TERMINAL || kind == AUGX_K_SINGLE) ? e.eob - 3 : e.eob;
+    if (eons > P.n - 1) eons = P.n - 1;
+    int feons = g.fwd ? mod3(win - 1 - e.eob + eons) : mod3(win + 1 + e.eob - eons);
+    int ORFleft = P.leftmostExonBegin(feons, eons, g.fwd);
+    e.startMax = e.eob + g.ipo - t.min_exon_len + 1;
+    if (kind == AUGX_K_RTERMINAL || kind == AUGX_K_RSINGLE)
+        e.startMin = e.startMax = ORFleft + 2;
+    else {
+        e.startMin = ORFleft <= 0 ? 0 : ORFleft + g.ipo;
+        if (e.startMax > j + g.bpl) e.startMax = j + g.bpl;
+    }
+    return e;
+}
+
+// lessD / rlessD end gate, reference src/intronmodel.cc:545-556
+AUGX_HD bool lessDGate(const Piece &P, bool fwd, int j) {
+    const DevTables &t = *P.t;
+    int eobi = fwd ? j + t.U + t.As + 2 : j + t.De + 2;
+    if (eobi - 2 + 1 < P.n - 1) return fwd ? P.possASS(eobi) : P.possRDSS(eobi);
+    return true;
+}
+
+} // namespace dev
+} // namespace augx

@@ -1,0 +1,718 @@
+// kernels.h -- bodies of the decode kernels, written once for gfx950 (hipcc) and for the lane-loop emulator
+// (-DAUGX_EMU, tests only).  See DESIGN.md for the kernel decomposition:
+//   K1  prep   : encode, site/stop/base-count prefix scans, GC class, fixed-point content prefix sums, signals
+//   K2  trellis: one 64-lane wavefront per piece, position-sequential, V columns in an LDS ring
+//   K3  back   : back-pointer chase, one wavefront per piece
+//
+// Lane discipline: a FOR_LANES block is executed by every lane (concurrently on the device, one after the other
+// in the emulator); lanes communicate only through LDS/global memory BETWEEN blocks, separated by WAVE_SYNC().
+#pragma once
+#include "dp.h"
+
+namespace augx {
+namespace dev {
+
+#ifdef AUGX_EMU
+#define FOR_LANES(l) for (int l = 0; l < WAVE; ++l)
+#define LV(T, name) T name[WAVE]
+#define LX(name) name[l]
+#define WAVE_SYNC() ((void)0)
+#define AUGX_KFN inline
+#else
+#define FOR_LANES(l) for (int l = (int)threadIdx.x, _once = 1; _once; _once = 0)
+#define LV(T, name) T name[1]
+#define LX(name) name[0]
+#define WAVE_SYNC() __syncthreads()
+#define AUGX_KFN __device__ inline
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// wave-wide argmax of (value, key): larger value wins, ties go to the larger key (= the candidate the
+// reference's descending loop with strict '>' meets first: src/exonmodel.cc:1059,1115, src/intronmodel.cc:589,623)
+// ------------------------------------------------------------------------------------------------
+struct Best { double v; int key; int aux; };
+AUGX_HD bool better(double v, int key, double bv, int bkey) { return v > bv || (v == bv && v > AUGX_NINF && key > bkey); }
+
+#ifdef AUGX_EMU
+inline Best waveArgMax(const double *v, const int *key, const int *aux) {
+    Best b{AUGX_NINF, -2147483647, -1};
+    for (int l = 0; l < WAVE; l++)
+        if (better(v[l], key[l], b.v, b.key)) { b.v = v[l]; b.key = key[l]; b.aux = aux[l]; }
+    return b;
+}
+#else
+__device__ inline Best waveArgMax(const double *v, const int *key, const int *aux) {
+    double bv = v[0];
+    int bk = key[0], ba = aux[0];
+    if (!(bv > AUGX_NINF)) { bk = -2147483647; ba = -1; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        double ov = __shfl_xor(bv, o, 64);
+        int ok = __shfl_xor(bk, o, 64);
+        int oa = __shfl_xor(ba, o, 64);
+        if (better(ov, ok, bv, bk)) { bv = ov; bk = ok; ba = oa; }
+    }
+    return Best{bv, bk, ba};
+}
+#endif
+
+AUGX_HD Piece makePiece(const DevTables &T, const BatchView &B, int p) {
+    Piece P;
+    int64_t o = B.off[p];
+    P.t = &T;
+    P.n = B.len[p];
+    P.c = B.cls[p];
+    P.code = B.code + o + 1;
+    P.fx = B.fx + o * NFX;
+    P.nsm = B.nsm + o * 6;
+    P.sig = B.sig + (o + 1) * NSIG;
+    return P;
+}
+
+// =================================================================================================
+// K1  prep kernels (one thread per slot unless noted).  g = global slot index.
+// =================================================================================================
+constexpr int NCNT = 9; // prefix-count fields: a c g t | atg | ag(LA) | ac(LR) | gt(LD) | ct(RD)
+constexpr int CNT_ATG = 4, CNT_LA = 5, CNT_LR = 6, CNT_LD = 7, CNT_RD = 8;
+
+AUGX_HD void k1Encode(const BatchView &B, int64_t g) {
+    int p = B.chunkPiece[g / CHUNK];
+    int64_t q = g - B.off[p] - 1;
+    uint8_t c = 4;
+    if (q >= 0 && q < B.len[p]) {
+        char ch = B.raw[g];
+        ch = (ch >= 'A' && ch <= 'Z') ? (char)(ch - 'A' + 'a') : ch; // reference lower-cases, src/extrinsicinfo.cc:1726
+        c = ch == 'a' ? 0 : ch == 'c' ? 1 : ch == 'g' ? 2 : ch == 't' ? 3 : 4;
+    }
+    B.code[g] = c;
+}
+
+// site flags and stop codons -> terms of the count / max scans
+AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
+    int p = B.chunkPiece[g / CHUNK];
+    int64_t o = B.off[p];
+    int q = (int)(g - o - 1);
+    Piece P;
+    P.t = &T; P.n = B.len[p]; P.c = 0; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    uint64_t *cnt = B.cnt + g * NCNT;
+    uint64_t *ns = B.nsm + g * 6;
+    for (int i = 0; i < NCNT; i++) cnt[i] = 0;
+    for (int i = 0; i < 6; i++) ns[i] = 0;
+    if (q < 0 || q >= P.n) return;
+    int c = P.b(q);
+    if (c < 4) cnt[c] = 1;
+    // start codon with positive probability at q (a of atg)
+    if (q < P.n - 2) { int pn = P.pat(q, 3); if (pn >= 0 && T.ln_startcodon[pn] > AUGX_NINF) cnt[CNT_ATG] = 1; }
+    if (P.possASS(q - T.Ae)) cnt[CNT_LA] = 1;                       // longass may end at q   (src/intronmodel.cc:705)
+    if (P.possRDSS(q - T.Ds)) cnt[CNT_LR] = 1;                      // rlongdss may end at q  (:709)
+    if (P.possDSS(q - T.De - 2 + 1)) cnt[CNT_LD] = 1;               // longdss may end at q   (:693)
+    if (P.possRASS(q - T.U - T.As - 2 + 1)) cnt[CNT_RD] = 1;        // rlongass may end at q  (:713)
+    if (q <= P.n - 3) {
+        if (P.isStop(q)) ns[q % 3] = (uint64_t)q + 1;
+        if (P.isRCStop(q)) ns[3 + q % 3] = (uint64_t)q + 1;
+    }
+}
+
+// GC class of the window starting at base s (one thread per slot; reference ContentStairs::computeStairs,
+// src/motif.cc:543-616; the set of window classes decides whether the piece is single-class)
+AUGX_HD int nearestClass(const DevTables &T, const double cnt[4]) {
+    double r[4] = {0.25, 0.25, 0.25, 0.25};
+    double sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (sum > 0.0)
+        for (int i = 0; i < 4; i++) r[i] = cnt[i] / sum;
+    double maxW = -1;
+    int ret = -1;
+    for (int c = 0; c < T.C; c++) {
+        double w = 1;
+        if (T.gc_weighing_type == 3) {
+            double z[4], tmp[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 4; i++) z[i] = r[i] - T.gc_zus[c][i];
+            for (int j = 0; j < 4; j++)
+                for (int i = 0; i < 4; i++) tmp[j] += z[i] * T.gc_weight_matrix[i * 4 + j];
+            double q = 0;
+            for (int i = 0; i < 4; i++) q += tmp[i] * z[i];
+            w = 1 + 9 * exp(-q);
+        } else if (T.gc_weighing_type == 2) {
+            double g1 = r[1] + r[2], g2 = T.gc_zus[c][1] + T.gc_zus[c][2];
+            int c1 = g1 < .43 ? 0 : g1 < .51 ? 1 : g1 < .57 ? 2 : 3, c2 = g2 < .43 ? 0 : g2 < .51 ? 1 : g2 < .57 ? 2 : 3;
+            w = c1 == c2 ? 1 : 0;
+        }
+        if (w > maxW) { maxW = w; ret = c; }
+    }
+    return ret;
+}
+// returns the class of window start s of piece p, or -1 if s is not a window start
+AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
+    int p = B.chunkPiece[g / CHUNK];
+    int64_t o = B.off[p];
+    int s = (int)(g - o - 1), n = B.len[p];
+    int win = T.gc_win;
+    if (win > n || win < 1) win = n;
+    if (s < 0 || s > n - win) return -1;
+    const uint64_t *lo = B.cnt + (o + s) * NCNT, *hi = B.cnt + (o + s + win) * NCNT;
+    double cnt[4];
+    for (int i = 0; i < 4; i++) cnt[i] = (double)(hi[i] - lo[i]);
+    return nearestClass(T, cnt);
+}
+
+// fixed-point terms of the 20 content prefix fields
+AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g) {
+    int p = B.chunkPiece[g / CHUNK];
+    int64_t o = B.off[p];
+    int q = (int)(g - o - 1);
+    uint64_t *out = B.fx + g * NFX;
+    for (int i = 0; i < NFX; i++) out[i] = 0;
+    if (q < 0 || q >= B.len[p]) return;
+    Piece P;
+    P.t = &T; P.n = B.len[p]; P.c = B.cls[p]; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    if (P.c < 0) return;
+    const int k = T.k, NP = T.NP, c = P.c;
+    int pn = q >= k ? P.pat(q - k, k + 1) : -1;
+    int rn = P.rcpat(q, k + 1);
+    const double *tabs[3] = {T.ex_emi + (int64_t)c * 3 * NP, T.ex_init + (int64_t)c * 3 * NP, T.ex_et + (int64_t)c * 3 * NP};
+    for (int a = 0; a < 3; a++)
+        for (int tb = 0; tb < 3; tb++) {
+            // forward strand: frame (q + a) mod 3; reverse strand: frame (a - q) mod 3
+            // (reference ExonModel::seqProb, src/exonmodel.cc:1957-1966)
+            out[(0 * 3 + a) * 3 + tb] = toFx(pn >= 0 ? tabs[tb][mod3(q + a) * NP + pn] : T.ln_n_coding);
+            out[(1 * 3 + a) * 3 + tb] = toFx(rn >= 0 ? tabs[tb][mod3(a - q) * NP + rn] : T.ln_n_coding);
+        }
+    const double *inE = T.in_emi + (int64_t)c * NP;
+    out[FX_INF] = toFx(pn >= 0 ? inE[pn] : T.ln_quarter);
+    int rn2 = (q + k < P.n) ? rn : -1;
+    out[FX_INR] = toFx(rn2 >= 0 ? inE[rn2] : T.ln_quarter);
+}
+
+// per-base signal record + end-gate mask of the variable-length states
+constexpr int NSITE = 4;
+AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
+    int p = B.chunkPiece[g / CHUNK];
+    int64_t o = B.off[p];
+    int q = (int)(g - o - 1);
+    double *sg = B.sig + g * NSIG;
+    for (int i = 0; i < NSIG; i++) sg[i] = AUGX_NINF;
+    B.gate[g] = 0;
+    int32_t *st = B.site + g * NSITE;
+    for (int i = 0; i < NSITE; i++) st[i] = -1;
+    if (q < 0 || q >= B.len[p] || B.cls[p] < 0) return;
+    Piece P = makePiece(T, B, p);
+    const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
+    sg[SIG_EIG] = q >= 1 ? eIg(P, q) : AUGX_NINF;
+    sg[SIG_EIN] = eIn(P, q);
+    // fixed-length intron states ending at q: gate && emission (reference src/intronmodel.cc:690-717,861-923)
+    if (q - dssWhole >= 0 && P.possDSS(q - T.De - 2 + 1)) sg[SIG_DSSF] = dssProb(P, q - dssWhole + 1, true);
+    if (q - dssWhole >= 0 && P.possRDSS(q - T.Ds)) sg[SIG_DSSR] = dssProb(P, q - dssWhole + 1, false);
+    if (q - assWhole - T.U >= 0 && P.possASS(q - T.Ae)) sg[SIG_ASSF] = assProb(P, q - assWhole - T.U + 1, true);
+    if (q - assWhole - T.U >= 0 && P.possRASS(q - T.U - T.As - 2 + 1)) sg[SIG_ASSR] = assProb(P, q - assWhole - T.U + 1, false);
+    sg[SIG_TISF] = tisFwd(P, q);
+    sg[SIG_TISR] = tisRev(P, q);
+    // list index of the site ending at q (prefix count - 1), -1 if q is not such a site
+    const uint64_t *cn = B.cnt + g * NCNT, *cp = B.cnt + (g - 1) * NCNT;
+    const int64_t lo = listOff(B, p);
+    for (int i = 0; i < NSITE; i++)
+        st[i] = cn[CNT_LA + i] != cp[CNT_LA + i] ? (int32_t)cn[CNT_LA + i] - 1 : -1;
+    // the candidate lists are indexed by site; positions are known here, the trellis fills in the values
+    if (st[0] >= 0) B.laPos[lo + st[0]] = q;
+    if (st[1] >= 0) B.lrPos[lo + st[1]] = q;
+    if (st[2] >= 0) B.ldPos[lo + st[2]] = q;
+    if (st[3] >= 0) B.rdPos[lo + st[3]] = q;
+    if (cn[CNT_ATG] != cp[CNT_ATG]) B.atgPos[lo + cn[CNT_ATG] - 1] = q;
+    // emission of the equalD states ending at q (reference IntronModel::seqProb, src/intronmodel.cc:1087-1107)
+    if (q - T.dStateLen >= 0) sg[SIG_EQD] = P.seg(FX_INF, q - T.dStateLen + 1, q);
+    // end gates
+    uint64_t gate = 0;
+    if (q >= 1)
+        for (int s = 0; s < T.S; s++) {
+            if (!T.reachable[s]) continue;
+            int kind = T.kind[s];
+            bool open = false;
+            if (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) {
+                ExGeom gm = exGeom(T, kind);
+                double endP = exEndPart(P, kind, T.win[s], q, sg[SIG_TISR]);
+                int right = q + gm.baseOffset - gm.ipeo;
+                open = endP > AUGX_NINF && right >= 0;
+            } else if (kind == AUGX_K_LESSD)
+                open = lessDGate(P, true, q);
+            else if (kind == AUGX_K_RLESSD)
+                open = lessDGate(P, false, q);
+            if (open) gate |= 1ull << s;
+        }
+    B.gate[g] = gate;
+}
+
+// =================================================================================================
+// K2  trellis: one wavefront per piece
+// =================================================================================================
+struct TrellisLds {
+    double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
+    double longRing[6][LONG_RING];  // states consumed at lag dStateLen: rows 0..2 longdss_f, 3..5 rlongass_f
+    double sig[WAVE][NSIG];         // tile of signal records for bases j0..j0+63
+    uint64_t gate[WAVE];
+    int32_t site[WAVE][NSITE];
+    uint16_t bp[WAVE][SP];
+    double red_v[WAVE];             // scratch
+};
+
+AUGX_HD int longRow(const DevTables &T, int s) {
+    int kind = T.kind[s];
+    if (kind == AUGX_K_LONGDSS) return T.win[s];
+    if (kind == AUGX_K_RLONGASS) return 3 + T.win[s];
+    return -1;
+}
+AUGX_HD double lnT(const DevTables &T, int c, int a, int s) { return T.ln_trans[((int64_t)c * T.S + a) * T.S + s]; }
+AUGX_HD uint16_t bpFixed(int ai) { return (uint16_t)ai; }
+AUGX_HD uint16_t bpVar(int ai, int dist) { return (uint16_t)((ai << 14) | (dist & 0x3FFF)); }
+
+struct TrellisCtx {
+    const DevTables &T;
+    const BatchView &B;
+    TrellisLds &L;
+    int p;
+    Piece P;
+    int64_t o;      // slot offset of the piece
+    int64_t lo;     // list offset
+    int n, c, S;
+    AUGX_HD TrellisCtx(const DevTables &t, const BatchView &b, TrellisLds &l, int pp) : T(t), B(b), L(l), p(pp) {
+        P = makePiece(T, B, p);
+        o = B.off[p];
+        lo = listOff(B, p);
+        n = P.n; c = P.c; S = T.S;
+    }
+    AUGX_HD uint64_t cntAt(int q, int f) const { // number of sites of field f at bases <= q (q may be -1)
+        if (q < 0) return 0;
+        if (q > n - 1) q = n - 1;
+        return B.cnt[(o + 1 + q) * NCNT + f];
+    }
+};
+
+// one variable-length state s ending at base j; all 64 lanes cooperate.  Returns the best (value, pred, eop).
+// The formulas are those of the reference loops (exon: src/exonmodel.cc:1059-1132; lessD: src/intronmodel.cc:585-629)
+AUGX_KFN void trellisVarState(TrellisCtx &X, int s, int j, double *outV, uint16_t *outBp) {
+    const DevTables &T = X.T;
+    const BatchView &B = X.B;
+    const Piece &P = X.P;
+    const int kind = T.kind[s], win = T.win[s], c = X.c, n = X.n;
+    LV(double, bv);
+    LV(int, bkey);
+    LV(int, baux);
+    FOR_LANES(l) { LX(bv) = AUGX_NINF; LX(bkey) = -2147483647; LX(baux) = -1; }
+    if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
+        const bool fwd = kind == AUGX_K_LESSD;
+        const int f = win;
+        const int eobi = fwd ? j + T.U + T.As + 2 : j + T.De + 2;
+        const bool haveRight = eobi < n - 2;
+        int cod[3] = {4, 4, 4};
+        if (fwd) {
+            if (f == 1) { cod[1] = haveRight ? P.b(eobi + 1) : 4; cod[2] = haveRight ? P.b(eobi + 2) : 4; }
+            if (f == 2) { cod[2] = haveRight ? P.b(eobi + 1) : 4; }
+        } else {
+            if (f == 0) cod[0] = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
+            if (f == 1) {
+                cod[0] = (haveRight && P.b(eobi + 2) <= 3) ? 3 - P.b(eobi + 2) : 4;
+                cod[1] = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
+            }
+        }
+        int left = j - T.dStateLen;
+        if (left < 0) left = 0;
+        const int fld = fwd ? CNT_LD : CNT_RD;
+        const int32_t *lpos = fwd ? B.ldPos : B.rdPos;
+        const double *lval = fwd ? B.ldVal : B.rdVal;
+        const int64_t i0 = (int64_t)X.cntAt(left - 1, fld), i1 = (int64_t)X.cntAt(j - 1, fld); // list indices [i0, i1)
+        const int a = T.anc[s][0]; // single ancestor (longdss_f / rlongass_f)
+        const double tr = lnT(T, c, a, s);
+        // candidate eop = 0 reads column 0 (initial probabilities); it is not a splice site, so not in the list
+        const int extra = (left == 0) ? 1 : 0;
+        const int64_t total = (i1 - i0) + extra;
+        for (int64_t base = 0; base < total; base += WAVE) {
+            FOR_LANES(l) {
+                int64_t idx = base + l;
+                if (idx < total) {
+                    int eop;
+                    double pv;
+                    if (idx < i1 - i0) {
+                        int64_t li = X.lo + (i1 - 1 - idx); // descending eop
+                        eop = lpos[li];
+                        pv = lval[li * 3 + f];
+                    } else {
+                        eop = 0;
+                        pv = (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF);
+                    }
+                    if (pv > AUGX_NINF) {
+                        int begin = eop + 1;
+                        int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
+                        bool ok = !(bobi >= 0 && !(fwd ? P.possDSS(bobi) : P.possRASS(bobi)));
+                        bool spliced = fwd ? (f != 0) : (f != 2);
+                        if (ok && spliced && bobi > 1) {
+                            int c0 = cod[0], c1 = cod[1], c2 = cod[2];
+                            if (fwd) {
+                                if (f == 1) c0 = P.b(bobi - 1);
+                                else { c0 = P.b(bobi - 2); c1 = P.b(bobi - 1); }
+                            } else {
+                                if (f == 0) { c1 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4; c2 = P.b(bobi - 2) <= 3 ? 3 - P.b(bobi - 2) : 4; }
+                                else c2 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4;
+                            }
+                            if (stopCodon3(c0, c1, c2)) ok = false;
+                        }
+                        int intronLength = eobi - bobi + 1;
+                        if (ok && intronLength <= T.d) {
+                            double restSeq = P.seg(fwd ? FX_INF : FX_INR, begin, j);
+                            double emi = T.len_intron[intronLength] + restSeq;
+                            if (emi > AUGX_NINF) {
+                                double val = pv + (tr + emi);
+                                if (better(val, eop, LX(bv), LX(bkey))) { LX(bv) = val; LX(bkey) = eop; LX(baux) = 0; }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    } else {
+        const ExGeom g = exGeom(T, kind);
+        const ExEnd e = exEnd(P, kind, win, j, g);
+        const double endP = exEndPart(P, kind, win, j, X.L.sig[j & 63][SIG_TISR]);
+        const bool fromIgenic = kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL || kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL;
+        if (endP > AUGX_NINF && e.right >= 0 && e.startMax >= e.startMin) {
+            if (fromIgenic) {
+                const int a = T.anc[s][0];
+                const double tr = lnT(T, c, a, s);
+                int64_t i0 = 0, total;
+                const bool viaAtg = kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL;
+                if (viaAtg) { // start codons with bob in [startMin-3, startMax-3]
+                    i0 = (int64_t)X.cntAt(e.startMin - 3 - 1, CNT_ATG);
+                    total = (int64_t)X.cntAt(e.startMax - 3, CNT_ATG) - i0;
+                } else
+                    total = 1; // single candidate bs = ORFleft+2 (src/exonmodel.cc:1044-1045)
+                for (int64_t base = 0; base < total; base += WAVE) {
+                    FOR_LANES(l) {
+                        int64_t idx = base + l;
+                        if (idx < total) {
+                            int bs;
+                            double tisF = AUGX_NINF;
+                            if (viaAtg) {
+                                int bob = B.atgPos[X.lo + i0 + (total - 1 - idx)];
+                                bs = bob + 3;
+                                tisF = P.sig[(int64_t)bob * NSIG + SIG_TISF];
+                            } else
+                                bs = e.startMin;
+                            int eop = bs - g.bpl - 1;
+                            // eop == j reads the igenic cell of the CURRENT column (already final: the reference
+                                // fills states in index order and igenic is state 0); later columns do not exist yet
+                                if (eop < n && eop <= j) {
+                                double pv = eop == j ? X.L.ring[j & 63][a] : B.vig[X.o + 1 + (eop >= 0 ? eop : 0)];
+                                if (eop <= 0) pv = (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF);
+                                if (pv > AUGX_NINF) {
+                                    double nep = exNotEndPart(P, kind, win, bs, e.right, e.fOR, g, tisF);
+                                    if (nep > AUGX_NINF) {
+                                        double te = (tr + endP) + nep;
+                                        double val = pv + te;
+                                        if (better(val, bs, LX(bv), LX(bkey))) { LX(bv) = val; LX(bkey) = bs; LX(baux) = 0; }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            } else {
+                // predecessors are the three longass_f (forward) or rlongdss_f (reverse) states, listed per splice site
+                const bool fwd = g.fwd;
+                const int fld = fwd ? CNT_LA : CNT_LR;
+                const int32_t *lpos = fwd ? B.laPos : B.lrPos;
+                const double *lval = fwd ? B.laVal : B.lrVal;
+                // eop = bs - 1 in [startMin-1, startMax-1]
+                const int64_t i0 = (int64_t)X.cntAt(e.startMin - 2, fld), i1 = (int64_t)X.cntAt(e.startMax - 1, fld);
+                const int extra = (e.startMin == 0) ? 1 : 0; // bs = 0: left-truncated exon, predecessor column 0
+                const int64_t total = (i1 - i0) + extra;
+                for (int64_t base = 0; base < total; base += WAVE) {
+                    FOR_LANES(l) {
+                        int64_t idx = base + l;
+                        if (idx < total) {
+                            int eop;
+                            int64_t li = -1;
+                            if (idx < i1 - i0) { li = X.lo + (i1 - 1 - idx); eop = lpos[li]; }
+                            else eop = -1;
+                            int bs = eop + 1;
+                            double nep = exNotEndPart(P, kind, win, bs, e.right, e.fOR, g, AUGX_NINF);
+                            if (nep > AUGX_NINF) {
+                                int bob = bs - g.ipo, len = e.eob - bob + 1;
+                                for (int ai = 0; ai < T.n_anc[s]; ai++) {
+                                    int a = T.anc[s][ai];
+                                    bool ok = win == mod3(fwd ? T.win[a] + len : T.win[a] - len);
+                                    if (!ok) continue;
+                                    double pv = li >= 0 ? lval[li * 3 + T.win[a]]
+                                                        : ((B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF));
+                                    if (!(pv > AUGX_NINF)) continue;
+                                    double te = (lnT(T, c, a, s) + endP) + nep;
+                                    double val = pv + te;
+                                    if (better(val, bs, LX(bv), LX(bkey))) { LX(bv) = val; LX(bkey) = bs; LX(baux) = ai; }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    Best b = waveArgMax(bv, bkey, baux);
+    *outV = b.v;
+    if (b.v > AUGX_NINF) {
+        int eop;
+        if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) eop = b.key;
+        else { ExGeom g = exGeom(T, kind); eop = b.key - g.bpl - 1; }
+        *outBp = bpVar(b.aux, j - eop);
+    } else
+        *outBp = BP_NONE;
+}
+
+AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int p) {
+    TrellisCtx X(T, B, L, p);
+    const int n = X.n, S = X.S, c = X.c;
+    const int64_t o = X.o;
+    if (c < 0) { // multi-class piece: not decoded by this version
+        FOR_LANES(l) { if (l == 0) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
+        return;
+    }
+    const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
+    {   // ---- a piece without a single nucleotide is all intergenic (reference src/namgene.cc:205-226)
+        const uint64_t *last = B.cnt + (o + n) * NCNT;
+        if (last[0] + last[1] + last[2] + last[3] == 0) {
+            const int sy = T.synch;
+            int selfAi = 0;
+            for (int ai = 0; ai < T.n_anc[sy]; ai++)
+                if (T.anc[sy][ai] == sy) selfAi = ai;
+            FOR_LANES(l) {
+                for (int q = l; q < n; q += WAVE)
+                    for (int s2 = 0; s2 < SP; s2++) B.bp[(o + 1 + q) * SP + s2] = (s2 == sy && q >= 1) ? bpFixed(selfAi) : BP_NONE;
+                if (l == 0) {
+                    double v = B.initKind[p] == 0 ? T.ln_init[sy] : 0.0;
+                    for (int q = 1; q < n; q++) v = v - T.ln4;
+                    double tl = B.termKind[p] == 0 ? T.ln_term[sy] : 0.0;
+                    B.lnv[p] = v + tl;
+                    B.finalState[p] = (v + tl) > AUGX_NINF ? sy : -1;
+                    B.status[p] = (v + tl) > AUGX_NINF ? 0 : AUGX_E_NOPATH;
+                }
+            }
+            return;
+        }
+    }
+    // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
+    FOR_LANES(l) {
+        if (l < SP) {
+            double v = AUGX_NINF;
+            if (l < S) v = B.initKind[p] == 0 ? T.ln_init[l] : (l == T.synch ? 0.0 : AUGX_NINF);
+            L.ring[0][l] = v;
+            L.bp[0][l] = BP_NONE;
+            if (l < S) {
+                int lr = longRow(T, l);
+                if (lr >= 0) L.longRing[lr][0] = v;
+                if (B.cells) B.cells[(o + 1) * S + l] = v;
+                if (T.kind[l] == AUGX_K_IGENIC) B.vig[o + 1] = v;
+            }
+        }
+    }
+    WAVE_SYNC();
+    for (int j0 = 0; j0 < n; j0 += WAVE) {
+        // ---- load the tile of per-base records for bases j0..j0+63 (coalesced)
+        FOR_LANES(l) {
+            int q = j0 + l;
+            int64_t g = o + 1 + q;
+            for (int i = 0; i < NSIG; i++) L.sig[l][i] = B.sig[g * NSIG + i];
+            L.gate[l] = B.gate[g];
+            for (int i = 0; i < NSITE; i++) L.site[l][i] = B.site[g * NSITE + i];
+        }
+        WAVE_SYNC();
+        int jend = j0 + WAVE < n ? j0 + WAVE : n;
+        for (int j = (j0 == 0 ? 1 : j0); j < jend; j++) {
+            const int col = j & 63;
+            // ---- phase A: fixed-length states, one lane per state
+            FOR_LANES(l) {
+                if (l < SP) {
+                    double best = AUGX_NINF;
+                    uint16_t bp = BP_NONE;
+                    if (l < S && T.reachable[l]) {
+                        const int s = l, kind = T.kind[s];
+                        int lag = -1;
+                        double emi = AUGX_NINF;
+                        switch (kind) {
+                        case AUGX_K_IGENIC: lag = 1; emi = L.sig[col][SIG_EIG]; break;
+                        case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: lag = 1; emi = L.sig[col][SIG_EIN]; break;
+                        case AUGX_K_LONGDSS: lag = dssWhole; emi = L.sig[col][SIG_DSSF]; break;
+                        case AUGX_K_RLONGDSS: lag = dssWhole; emi = L.sig[col][SIG_DSSR]; break;
+                        case AUGX_K_LONGASS: lag = assLag; emi = L.sig[col][SIG_ASSF]; break;
+                        case AUGX_K_RLONGASS: lag = assLag; emi = L.sig[col][SIG_ASSR]; break;
+                        case AUGX_K_EQUALD: case AUGX_K_REQUALD: lag = dL; emi = L.sig[col][SIG_EQD]; break;
+                        default: break;
+                        }
+                        if (lag > 0 && j - lag >= 0 && emi > AUGX_NINF) {
+                            for (int ai = 0; ai < T.n_anc[s]; ai++) {
+                                int a = T.anc[s][ai];
+                                double pv = lag == dL && lag >= WAVE ? L.longRing[longRow(T, a)][(j - lag) & (LONG_RING - 1)]
+                                                                     : L.ring[(j - lag) & 63][a];
+                                if (!(pv > AUGX_NINF)) continue;
+                                double val = pv + (lnT(T, c, a, s) + emi);
+                                if (val > best) { best = val; bp = bpFixed(ai); }
+                            }
+                        }
+                    }
+                    L.ring[col][l] = best;
+                    L.bp[col][l] = bp;
+                }
+            }
+            WAVE_SYNC();
+            // ---- phase B: variable-length states whose end gate is open at j (wave-cooperative, one at a time)
+            uint64_t gate = L.gate[col];
+            while (gate) {
+                int s = 0;
+                { uint64_t gg = gate; while (!(gg & 1)) { gg >>= 1; s++; } }
+                gate &= gate - 1;
+                double v;
+                uint16_t bp;
+                trellisVarState(X, s, j, &v, &bp);
+                FOR_LANES(l) { if (l == 0) { L.ring[col][s] = v; L.bp[col][s] = bp; } }
+            }
+            WAVE_SYNC();
+            // ---- phase C: publish column j
+            FOR_LANES(l) {
+                if (l < S) {
+                    double v = L.ring[col][l];
+                    int lr = longRow(T, l);
+                    if (lr >= 0) L.longRing[lr][j & (LONG_RING - 1)] = v;
+                    if (B.cells) B.cells[(o + 1 + j) * S + l] = v;
+                    const int kind = T.kind[l], f = T.win[l];
+                    if (kind == AUGX_K_IGENIC) B.vig[o + 1 + j] = v;
+                    int si = -1;
+                    double *lval = nullptr;
+                    if (kind == AUGX_K_LONGASS) { si = L.site[col][0]; lval = B.laVal; }
+                    else if (kind == AUGX_K_RLONGDSS) { si = L.site[col][1]; lval = B.lrVal; }
+                    else if (kind == AUGX_K_LONGDSS) { si = L.site[col][2]; lval = B.ldVal; }
+                    else if (kind == AUGX_K_RLONGASS) { si = L.site[col][3]; lval = B.rdVal; }
+                    if (si >= 0) lval[(X.lo + si) * 3 + f] = v;
+                }
+            }
+            WAVE_SYNC();
+        }
+        // ---- flush the back-pointer tile
+        FOR_LANES(l) {
+            for (int r = 0; r < WAVE; r++) {
+                int q = j0 + r;
+                if (q < n && l < SP) B.bp[(o + 1 + q) * SP + l] = L.bp[r][l];
+            }
+        }
+        WAVE_SYNC();
+    }
+    // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)
+    FOR_LANES(l) {
+        if (l == 0) {
+            double maxV = AUGX_NINF;
+            int state = -1;
+            for (int i = 0; i < S; i++) {
+                double tl = B.termKind[p] == 0 ? T.ln_term[i] : (i == T.synch ? 0.0 : AUGX_NINF);
+                double v = L.ring[(n - 1) & 63][i] + tl;
+                if (v > maxV) { maxV = v; state = i; }
+            }
+            B.lnv[p] = maxV;
+            B.finalState[p] = state;
+            B.status[p] = state >= 0 ? 0 : AUGX_E_NOPATH;
+        }
+    }
+}
+
+// =================================================================================================
+// K3  back-tracking: follow the back pointers from the best final state (reference NAMGene::getViterbiPath,
+// src/namgene.cc:467-506).  Runs of the single-base chain states (igenic, geometric) are skipped 64 bases at
+// a time by the whole wavefront and emitted as one merged record.  Records are written 3'->5'.
+// =================================================================================================
+#ifdef AUGX_EMU
+inline int waveFirstTrue(const int *flag) {
+    for (int l = 0; l < WAVE; l++)
+        if (flag[l]) return l;
+    return WAVE;
+}
+#else
+__device__ inline int waveFirstTrue(const int *flag) {
+    unsigned long long m = __ballot(flag[0] != 0);
+    return m ? (int)__ffsll((long long)m) - 1 : WAVE;
+}
+#endif
+
+AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
+    const int n = B.len[p];
+    const int64_t o = B.off[p];
+    const int64_t po = pathOff(B, p), cap = pathCap(B, p);
+    int state = B.finalState[p];
+    int base = n - 1;
+    int count = 0;
+    bool overflow = false;
+    if (state < 0 || B.status[p] != 0) {
+        FOR_LANES(l) { if (l == 0) B.pathCount[p] = 0; }
+        return;
+    }
+    const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U;
+    while (base > 0) {
+        const int kind = T.kind[state];
+        int eop, ai;
+        const bool chain = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC;
+        if (chain) {
+            int selfAi = -1;
+            for (int i = 0; i < T.n_anc[state]; i++)
+                if (T.anc[state][i] == state) selfAi = i;
+            int cur = base;
+            uint16_t w = BP_NONE;
+            for (;;) { // find the first base <= cur whose predecessor is not the state itself
+                LV(int, flag);
+                LV(int, wv);
+                FOR_LANES(l) {
+                    int q = cur - l;
+                    int ww = q >= 1 ? (int)B.bp[(o + 1 + q) * SP + state] : -1;
+                    LX(wv) = ww;
+                    LX(flag) = (q < 1) || ww != selfAi;
+                }
+                int first = waveFirstTrue(flag);
+                if (first < WAVE) {
+                    cur -= first;
+#ifdef AUGX_EMU
+                    w = cur >= 1 ? (uint16_t)wv[first] : BP_NONE;
+#else
+                    w = cur >= 1 ? (uint16_t)__shfl(wv[0], first, 64) : BP_NONE;
+#endif
+                    break;
+                }
+                cur -= WAVE;
+            }
+            // bases cur..base are in `state`; base `cur` was entered from another state (or cur < 1: sequence start)
+            if (cur < 1) { eop = 0; ai = -1; }
+            else { eop = cur - 1; ai = w; }
+        } else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
+            uint16_t w = B.bp[(o + 1 + base) * SP + state];
+            ai = w >> 14;
+            eop = base - (int)(w & 0x3FFF);
+            if (w == BP_NONE) { overflow = true; break; }
+        } else {
+            uint16_t w = B.bp[(o + 1 + base) * SP + state];
+            if (w == BP_NONE) { overflow = true; break; }
+            ai = w;
+            int lag = (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? dssWhole
+                      : (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? assLag : T.dStateLen;
+            eop = base - lag;
+        }
+        if (count >= cap) { overflow = true; break; }
+        FOR_LANES(l) {
+            if (l == 0) {
+                int32_t *r = B.pathRec + (po + count) * 3;
+                r[0] = eop + 1; r[1] = base; r[2] = state;
+            }
+        }
+        count++;
+        base = eop;
+        if (ai < 0 || ai >= T.n_anc[state]) { if (base > 0) overflow = true; break; }
+        state = T.anc[state][ai];
+    }
+    FOR_LANES(l) {
+        if (l == 0) {
+            B.pathCount[p] = count;
+            if (overflow) B.status[p] = AUGX_E_HIP;
+        }
+    }
+}
+
+} // namespace dev
+} // namespace augx

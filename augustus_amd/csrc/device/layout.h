@@ -1,0 +1,118 @@
+// layout.h -- host-side helpers shared by the HIP decoder and the test emulator: slot layout of a batch,
+// DevTables construction from augx_tables, buffer size bookkeeping.
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "dp.h"
+
+namespace augx {
+namespace dev {
+
+struct BatchLayout {
+    int nPieces = 0;
+    int64_t N = 0;
+    int nChunks = 0;
+    std::vector<int64_t> off;       // [nPieces+1]
+    std::vector<int32_t> len, initKind, termKind, chunkPiece;
+    void build(const augx_piece *pieces, int n) {
+        nPieces = n;
+        off.assign(n + 1, 0);
+        len.resize(n); initKind.resize(n); termKind.resize(n);
+        for (int p = 0; p < n; p++) {
+            if (pieces[p].len < 1 || pieces[p].len > 0x3fffffff) throw std::runtime_error("augx: piece length out of range");
+            len[p] = (int32_t)pieces[p].len;
+            initKind[p] = pieces[p].init_kind;
+            termKind[p] = pieces[p].term_kind;
+            int64_t slots = (int64_t)len[p] + 1 + 8;               // before-first slot + a few pad slots
+            slots = (slots + CHUNK - 1) / CHUNK * CHUNK;
+            off[p + 1] = off[p] + slots;
+        }
+        N = off[n];
+        nChunks = (int)(N / CHUNK);
+        chunkPiece.resize(nChunks);
+        for (int p = 0; p < n; p++)
+            for (int64_t ch = off[p] / CHUNK; ch < off[p + 1] / CHUNK; ch++) chunkPiece[ch] = p;
+    }
+};
+
+// element counts of every device buffer of a batch (bytes = count * sizeof(element))
+struct BatchSizes {
+    int64_t N, nChunks, nPieces, listCap, pathCap;
+    explicit BatchSizes(const BatchLayout &L) {
+        N = L.N; nChunks = L.nChunks; nPieces = L.nPieces;
+        listCap = N / 2 + 64;
+        pathCap = N / 8 + 64 * (int64_t)L.nPieces + 64;
+    }
+};
+
+inline void checkModelSupported(const augx_tables &t) {
+    if (t.S > SP) throw std::runtime_error("augx: model has more than 48 states (UTR/nc models are not on the device path yet)");
+    int dL = t.d - 2 - t.De - t.As - 2 - t.U;
+    if (dL >= LONG_RING || dL < 1) throw std::runtime_error("augx: intron d out of the supported range");
+    if (t.As + 2 + t.Ae + t.U > 63 || t.Ds + 2 + t.De > 63) throw std::runtime_error("augx: splice-site windows too long");
+    if (t.max_exon_len + t.W + 64 > 0x3FFF) throw std::runtime_error("augx: maxexonlength too large for 14-bit back pointers");
+    if (t.d > 0x3FFF) throw std::runtime_error("augx: intron d too large");
+    for (int s = 0; s < t.S; s++) {
+        int kind = t.state_kind[s];
+        bool var3 = kind == AUGX_K_INTERNAL || kind == AUGX_K_TERMINAL || kind == AUGX_K_RINTERNAL || kind == AUGX_K_RINITIAL;
+        if (var3 && t.n_anc[s] > 4) throw std::runtime_error("augx: exon state with more than 4 ancestors");
+        if ((kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD || kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL ||
+             kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) && t.n_anc[s] != 1)
+            throw std::runtime_error("augx: unexpected ancestor count (non-standard transition file)");
+    }
+}
+
+// fill the scalar part of DevTables; the caller sets the table pointers (device or host)
+inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
+    memset(&D, 0, sizeof D);
+    D.S = t.S; D.C = t.n_classes; D.k = t.k; D.NP = 1 << (2 * (t.k + 1));
+    D.W = t.W; D.U = t.U; D.As = t.As; D.Ae = t.Ae; D.Ds = t.Ds; D.De = t.De; D.Li = t.Li; D.Le = t.Le; D.d = t.d;
+    D.dStateLen = t.d - 2 - t.De - t.As - 2 - t.U;
+    D.max_exon_len = t.max_exon_len; D.min_exon_len = t.min_exon_len;
+    D.tis_n = t.tis_n; D.tis_k = t.tis_k; D.ass_n = t.ass_n; D.ass_k = t.ass_k; D.tis_nbins = t.tis_nbins; D.tis_mem = t.tis_mem;
+    D.synch = t.synch_state; D.gc_win = t.gc_win; D.gc_weighing_type = t.gc_weighing_type;
+    for (int s = 0; s < t.S; s++) {
+        D.kind[s] = t.state_kind[s]; D.win[s] = t.state_win[s]; D.type[s] = t.state_type[s]; D.reachable[s] = t.reachable[s];
+        D.n_anc[s] = t.n_anc[s];
+        for (int a = 0; a < AUGX_MAX_ANC; a++) D.anc[s][a] = t.anc[s][a];
+        D.ln_init[s] = t.ln_init[s]; D.ln_term[s] = t.ln_term[s];
+    }
+    for (int i = 0; i < 64; i++) D.ln_startcodon[i] = t.ln_startcodon[i];
+    D.ln_stop_ochre = t.ln_stop_ochre; D.ln_stop_amber = t.ln_stop_amber; D.ln_stop_opal = t.ln_stop_opal;
+    D.ln_quarter = t.ln_quarter; D.ln_n_coding = t.ln_n_coding; D.ln4 = t.ln4; D.ass_pat_invalid = t.ass_pat_invalid;
+    for (int c = 0; c < AUGX_MAX_CLASSES; c++)
+        for (int i = 0; i < 4; i++) D.gc_zus[c][i] = t.gc_zus[c][i];
+    for (int i = 0; i < 16; i++) D.gc_weight_matrix[i] = t.gc_weight_matrix[i];
+}
+
+// table element counts, in the order of tablePointers()
+struct TableSpan { const double *src; int64_t count; const double **dst; };
+inline std::vector<TableSpan> tableSpans(const augx_tables &t, DevTables &D) {
+    const int64_t C = t.n_classes, NP = 1 << (2 * (t.k + 1)), S = t.S;
+    std::vector<TableSpan> v;
+    v.push_back({t.ln_trans, C * S * S, &D.ln_trans});
+    v.push_back({t.ig_emi, C * NP, &D.ig_emi});
+    v.push_back({t.ig_short, C * (t.k + 1) * NP, &D.ig_short});
+    v.push_back({t.in_emi, C * NP, &D.in_emi});
+    v.push_back({t.ex_emi, C * 3 * NP, &D.ex_emi});
+    v.push_back({t.ex_init, C * 3 * NP, &D.ex_init});
+    v.push_back({t.ex_et, C * 3 * NP, &D.ex_et});
+    v.push_back({t.ex_pls, C * (t.k + 1) * 3 * NP, &D.ex_pls});
+    v.push_back({t.tis_motif, C * t.tis_n * (1 << (2 * (t.tis_k + 1))), &D.tis_motif});
+    v.push_back({t.ass_motif, C * t.ass_n * (1 << (2 * (t.ass_k + 1))), &D.ass_motif});
+    v.push_back({t.tis_bin_bounds, t.tis_nbins > 0 ? C * (t.tis_nbins - 1) : 0, &D.tis_bin_bounds});
+    v.push_back({t.tis_bin_ln, t.tis_nbins > 0 ? C * t.tis_nbins : 0, &D.tis_bin_ln});
+    v.push_back({t.ass_pat, (int64_t)1 << (2 * (t.As + t.Ae)), &D.ass_pat});
+    v.push_back({t.dss_pat, (int64_t)1 << (2 * (t.Ds + t.De)), &D.dss_pat});
+    v.push_back({t.len_intron, t.d + 1, &D.len_intron});
+    v.push_back({t.len_single, t.max_exon_len + 1, &D.len_single});
+    v.push_back({t.len_initial, t.max_exon_len + 1, &D.len_initial});
+    v.push_back({t.len_internal, t.max_exon_len + 1, &D.len_internal});
+    v.push_back({t.len_terminal, t.max_exon_len + 1, &D.len_terminal});
+    return v;
+}
+
+} // namespace dev
+} // namespace augx

@@ -1,0 +1,132 @@
+// emu.cc -- lane-loop emulator of the HIP decode kernels.  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles augustus_amd/csrc/device/kernels.h with -DAUGX_EMU: every kernel body runs on the CPU with the
+// 64 lanes of a wavefront executed one after the other, the grid as nested loops and the prefix scans as
+// plain sequential loops.  It exists because the build container has no GPU: it lets the CPU test-suite
+// exercise the very same source the device runs (bit-identical arithmetic, -ffp-contract=off).  It is not a
+// fallback: libaugx never links it and the product path fails without a HIP device.
+#define AUGX_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../augustus_amd/csrc/device/kernels.h"
+#include "../../augustus_amd/csrc/device/layout.h"
+
+using namespace augx::dev;
+
+namespace {
+template <class T> T *zalloc(int64_t n) { return (T *)calloc((size_t)(n > 0 ? n : 1), sizeof(T)); }
+
+// piece-local inclusive scans over the AoS field arrays (the device does the same with chunked kernels)
+template <bool MAX> void scanFields(uint64_t *a, int nf, const BatchLayout &L) {
+    for (int p = 0; p < L.nPieces; p++) {
+        std::vector<uint64_t> acc(nf, 0);
+        for (int64_t g = L.off[p]; g < L.off[p + 1]; g++)
+            for (int f = 0; f < nf; f++) {
+                uint64_t v = a[g * nf + f];
+                acc[f] = MAX ? (v > acc[f] ? v : acc[f]) : acc[f] + v;
+                a[g * nf + f] = acc[f];
+            }
+    }
+}
+} // namespace
+
+extern "C" {
+// decode a batch on the emulator.  Outputs: lnv[n], status[n]; paths as (begin,end,state) triples in 5'->3'
+// order into path_out (capacity path_cap triples per piece, counts in path_n); cells_out (optional) receives
+// the dense ln V matrices piece after piece (len*S doubles each).
+int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *lnv, int32_t *status, int32_t *path_out,
+               int32_t path_cap, int32_t *path_n, double *cells_out, int32_t *cls_out) {
+    try {
+        checkModelSupported(*t);
+    } catch (std::exception &e) {
+        fprintf(stderr, "emu: %s\n", e.what());
+        return AUGX_E_UNSUPPORTED;
+    }
+    DevTables T;
+    fillDevTablesScalars(*t, T);
+    for (auto &sp : tableSpans(*t, T)) *sp.dst = sp.src;
+    BatchLayout L;
+    L.build(pieces, n);
+    BatchSizes Z(L);
+    BatchView B;
+    memset(&B, 0, sizeof B);
+    B.nPieces = n; B.N = L.N; B.nChunks = L.nChunks;
+    B.off = L.off.data(); B.len = L.len.data(); B.initKind = L.initKind.data(); B.termKind = L.termKind.data();
+    B.chunkPiece = L.chunkPiece.data();
+    std::vector<int32_t> cls(n, -1), clsMM(2 * n);
+    B.cls = cls.data(); B.clsMinMax = clsMM.data();
+    char *raw = zalloc<char>(Z.N);
+    for (int p = 0; p < n; p++) memcpy(raw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p]);
+    B.raw = raw;
+    B.code = zalloc<uint8_t>(Z.N);
+    B.cnt = zalloc<uint64_t>(Z.N * NCNT);
+    B.nsm = zalloc<uint64_t>(Z.N * 6);
+    B.fx = zalloc<uint64_t>(Z.N * NFX);
+    B.sig = zalloc<double>(Z.N * NSIG);
+    B.gate = zalloc<uint64_t>(Z.N);
+    B.site = zalloc<int32_t>(Z.N * NSITE);
+    B.bp = zalloc<uint16_t>(Z.N * SP);
+    B.cells = cells_out ? zalloc<double>(Z.N * t->S) : nullptr;
+    B.vig = zalloc<double>(Z.N);
+    B.laPos = zalloc<int32_t>(Z.listCap); B.laVal = zalloc<double>(Z.listCap * 3);
+    B.lrPos = zalloc<int32_t>(Z.listCap); B.lrVal = zalloc<double>(Z.listCap * 3);
+    B.ldPos = zalloc<int32_t>(Z.listCap); B.ldVal = zalloc<double>(Z.listCap * 3);
+    B.rdPos = zalloc<int32_t>(Z.listCap); B.rdVal = zalloc<double>(Z.listCap * 3);
+    B.atgPos = zalloc<int32_t>(Z.listCap);
+    std::vector<double> lnvv(n);
+    std::vector<int32_t> st(n), fin(n), pc(n);
+    B.lnv = lnvv.data(); B.status = st.data(); B.finalState = fin.data(); B.pathCount = pc.data();
+    B.pathRec = zalloc<int32_t>(Z.pathCap * 3);
+
+    // ---- K1
+    for (int64_t g = 0; g < B.N; g++) k1Encode(B, g);
+    for (int64_t g = 0; g < B.N; g++) k1SiteTerms(T, B, g);
+    scanFields<false>(B.cnt, NCNT, L);
+    scanFields<true>(B.nsm, 6, L);
+    for (int p = 0; p < n; p++) { clsMM[2 * p] = 1 << 30; clsMM[2 * p + 1] = -1; }
+    for (int64_t g = 0; g < B.N; g++) {
+        int c = k1WindowClass(T, B, g);
+        if (c >= 0) {
+            int p = B.chunkPiece[g / CHUNK];
+            if (c < clsMM[2 * p]) clsMM[2 * p] = c;
+            if (c > clsMM[2 * p + 1]) clsMM[2 * p + 1] = c;
+        }
+    }
+    for (int p = 0; p < n; p++) cls[p] = clsMM[2 * p] == clsMM[2 * p + 1] ? clsMM[2 * p] : -1;
+    for (int64_t g = 0; g < B.N; g++) k1FxTerms(T, B, g);
+    scanFields<false>(B.fx, NFX, L);
+    for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
+    // ---- K2, K3
+    TrellisLds *lds = new TrellisLds();
+    for (int p = 0; p < n; p++) {
+        trellisPiece(T, B, *lds, p);
+        backtracePiece(T, B, p);
+    }
+    delete lds;
+    for (int p = 0; p < n; p++) {
+        lnv[p] = lnvv[p];
+        status[p] = st[p];
+        if (cls_out) cls_out[p] = cls[p];
+        int cnt = pc[p];
+        path_n[p] = cnt;
+        int64_t po = pathOff(B, p);
+        for (int i = 0; i < cnt && i < path_cap; i++) {
+            const int32_t *r = B.pathRec + (po + (cnt - 1 - i)) * 3;
+            int32_t *o = path_out + ((int64_t)p * path_cap + i) * 3;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+        }
+    }
+    if (cells_out) {
+        int64_t w = 0;
+        for (int p = 0; p < n; p++) {
+            memcpy(cells_out + w, B.cells + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);
+            w += (int64_t)L.len[p] * t->S;
+        }
+    }
+    free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
+    free(B.cells); free(B.vig); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldPos); free(B.ldVal);
+    free(B.rdPos); free(B.rdVal); free(B.atgPos); free(B.pathRec);
+    return 0;
+}
+}
