@@ -1,0 +1,207 @@
+"""augustus_amd -- MI355X-native ab-initio GHMM Viterbi decode (AUGUSTUS hot path), Python binding.
+
+A thin ctypes layer over the C ABI of ``libaugx.so`` (``include/augx.h``).  The decode itself runs in
+hand-written HIP kernels (``augustus_amd/csrc/device``); this module only marshals buffers.  There is no CPU
+decode path: creating a :class:`Decoder` without a HIP device raises :class:`AugxError`.
+
+Mirrors the reference's call sequence for this path
+(``Properties::init`` .. ``NAMGene()`` .. ``StateModel::readAllParameters()`` ..
+``NAMGene::doViterbiPiecewise``; reference ``src/augustus.cc:111-176,420``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaugx.so")
+
+AUGX_E_NODEVICE = -3
+AUGX_E_UNSUPPORTED = -5
+AUGX_E_NOPATH = -6
+
+
+class AugxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("augx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _Piece(ctypes.Structure):
+    _fields_ = [("seq", ctypes.c_char_p), ("len", ctypes.c_int64), ("init_kind", ctypes.c_int32),
+                ("term_kind", ctypes.c_int32)]
+
+
+class _State(ctypes.Structure):
+    _fields_ = [("begin", ctypes.c_int32), ("end", ctypes.c_int32), ("state", ctypes.c_int16),
+                ("type", ctypes.c_int16)]
+
+
+class _Path(ctypes.Structure):
+    _fields_ = [("states", ctypes.POINTER(_State)), ("n_states", ctypes.c_int32), ("status", ctypes.c_int32),
+                ("ln_viterbi", ctypes.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libaugx.so (built in-tree by ``__graft_entry__.build()``); fails loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("augustus_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`"
+                              % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.augx_last_error.restype = ctypes.c_char_p
+        L.augx_version.restype = ctypes.c_char_p
+        L.augx_model_tables.restype = ctypes.c_void_p
+        L.augx_model_tables.argtypes = [ctypes.c_void_p]
+        L.augx_model_option.restype = ctypes.c_char_p
+        L.augx_model_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.augx_model_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_decoder_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.augx_decoder_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_batch_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.augx_batch_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.augx_batch_sync.argtypes = [ctypes.c_void_p]
+        L.augx_batch_paths.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.augx_batch_cells.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.augx_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.augx_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_path_free.argtypes = [ctypes.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise AugxError(rc, lib().augx_last_error().decode(errors="replace"))
+
+
+class Model:
+    """Species model = option store + flat ln tables (``augx_model_load``)."""
+
+    def __init__(self, config_path, species, **opts):
+        L = lib()
+        self._h = ctypes.c_void_p()
+        names = (ctypes.c_char_p * len(opts))(*[k.encode() for k in opts])
+        vals = (ctypes.c_char_p * len(opts))(*[str(v).encode() for v in opts.values()])
+        _check(L.augx_model_load(config_path.encode(), species.encode(), len(opts), names, vals, ctypes.byref(self._h)))
+        self.species = species
+        self.config_path = config_path
+
+    @property
+    def tables_ptr(self):
+        return ctypes.c_void_p(lib().augx_model_tables(self._h))
+
+    @property
+    def n_states(self):
+        return ctypes.cast(self.tables_ptr, ctypes.POINTER(ctypes.c_int32))[0]
+
+    def option(self, name):
+        v = lib().augx_model_option(self._h, name.encode())
+        return None if v is None else v.decode()
+
+    def close(self):
+        if self._h:
+            lib().augx_model_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DecodedPiece:
+    __slots__ = ("status", "ln_viterbi", "states")
+
+    def __init__(self, status, lnv, states):
+        self.status, self.ln_viterbi, self.states = status, lnv, states  # states: [(begin, end, state, type)]
+
+
+class Batch:
+    """A batch of pieces resident in HBM (``augx_batch_create``); decode() may be repeated and timed."""
+
+    def __init__(self, decoder, seqs, init_kind=0, term_kind=0):
+        L = lib()
+        self.decoder = decoder
+        self.n = len(seqs)
+        self._keep = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+        self.lens = [len(s) for s in self._keep]
+        P = (_Piece * self.n)()
+        iks = init_kind if isinstance(init_kind, (list, tuple)) else [init_kind] * self.n
+        tks = term_kind if isinstance(term_kind, (list, tuple)) else [term_kind] * self.n
+        for i, s in enumerate(self._keep):
+            P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = s, len(s), iks[i], tks[i]
+        self._h = ctypes.c_void_p()
+        _check(L.augx_batch_create(decoder._h, P, self.n, ctypes.byref(self._h)))
+
+    def decode(self, sync=True):
+        _check(lib().augx_batch_decode(self.decoder._h, self._h))
+        if sync:
+            _check(lib().augx_batch_sync(self.decoder._h))
+
+    def kernel_ms(self):
+        a, b, c = ctypes.c_float(), ctypes.c_float(), ctypes.c_float()
+        _check(lib().augx_batch_kernel_ms(self.decoder._h, self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"prep_ms": a.value, "trellis_ms": b.value, "backtrace_ms": c.value}
+
+    def paths(self):
+        L = lib()
+        out = (_Path * self.n)()
+        _check(L.augx_batch_paths(self.decoder._h, self._h, out))
+        res = []
+        for i in range(self.n):
+            st = [(out[i].states[k].begin, out[i].states[k].end, out[i].states[k].state, out[i].states[k].type)
+                  for k in range(out[i].n_states)]
+            res.append(DecodedPiece(out[i].status, out[i].ln_viterbi, st))
+            L.augx_path_free(ctypes.byref(out[i]))
+        return res
+
+    def cells(self, piece):
+        import numpy as np
+        S = self.decoder.model.n_states
+        V = np.empty((self.lens[piece], S), dtype=np.float64)
+        _check(lib().augx_batch_cells(self.decoder._h, self._h, piece, V.ctypes.data_as(ctypes.c_void_p)))
+        return V
+
+    def close(self):
+        if self._h:
+            lib().augx_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Decoder:
+    """Device context (``augx_decoder_create``).  Raises AugxError(AUGX_E_NODEVICE) without a HIP device."""
+
+    def __init__(self, model, device=0):
+        self.model = model
+        self._h = ctypes.c_void_p()
+        _check(lib().augx_decoder_create(model._h, device, ctypes.byref(self._h)))
+
+    def decode(self, seqs, init_kind=0, term_kind=0):
+        b = Batch(self, seqs, init_kind, term_kind)
+        try:
+            b.decode()
+            return b.paths()
+        finally:
+            b.close()
+
+    def close(self):
+        if self._h:
+            lib().augx_decoder_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,455 @@
+// decoder.hip -- gfx950 kernels (thin __global__ wrappers around kernels.h), chunked prefix scans, and the
+// device half of the C ABI (augx_decoder_* / augx_batch_* / augx_decode_batch).
+//
+// Launch shapes (MI355X: 256 CUs, wave64):
+//   prep kernels : one thread per slot, 256-thread blocks, grid = N/256  (HBM-streaming, fully coalesced rows)
+//   scans        : grid (chunks x fields), 256 threads x 4 slots, rows of CHUNK=1024 contiguous uint64
+//   trellis      : one 64-lane wavefront (= one workgroup) per piece, ~87 KB LDS, position-sequential
+//   backtrace    : one wavefront per piece
+// There is no CPU fallback anywhere in this file: without a HIP device augx_decoder_create fails.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "kernels.h"
+#include "layout.h"
+#include "../capi_internal.h"
+
+using namespace augx;
+using namespace augx::dev;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            setLastError(std::string("HIP error: ") + hipGetErrorString(_e) + " in " #expr + " (" __FILE__ ":" + \
+                         std::to_string(__LINE__) + ")");                                               \
+            return AUGX_E_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) kEncode(BatchView B) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < B.N) k1Encode(B, g);
+}
+__global__ void __launch_bounds__(256) kSiteTerms(const DevTables *T, BatchView B) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < B.N) k1SiteTerms(*T, B, g);
+}
+__global__ void __launch_bounds__(256) kWindowClass(const DevTables *T, BatchView B) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int c = g < B.N ? k1WindowClass(*T, B, g) : -1;
+    // all slots of a block belong to one piece (pieces are CHUNK-aligned, 256 | CHUNK): reduce in the wave first
+    int mn = c >= 0 ? c : (1 << 30), mx = c;
+    for (int o = 32; o >= 1; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && mx >= 0) {
+        int p = B.chunkPiece[((int64_t)blockIdx.x * 256) / CHUNK];
+        atomicMin(&B.clsMinMax[2 * p], mn);
+        atomicMax(&B.clsMinMax[2 * p + 1], mx);
+    }
+}
+__global__ void kClassInit(BatchView B) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B.nPieces) { B.clsMinMax[2 * p] = 1 << 30; B.clsMinMax[2 * p + 1] = -1; }
+}
+__global__ void kClassFinal(BatchView B) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B.nPieces) B.cls[p] = B.clsMinMax[2 * p] == B.clsMinMax[2 * p + 1] ? B.clsMinMax[2 * p] : -1;
+}
+__global__ void __launch_bounds__(256) kFxTerms(const DevTables *T, BatchView B) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < B.N) k1FxTerms(*T, B, g);
+}
+__global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < B.N) k1Signals(*T, B, g);
+}
+
+// ---- chunked piece-local inclusive scans over rows [chunk][field][CHUNK] of uint64 (sum or max) ----
+template <bool MAX> __device__ inline uint64_t comb(uint64_t a, uint64_t b) { return MAX ? (a > b ? a : b) : a + b; }
+
+template <bool MAX> __global__ void __launch_bounds__(256) kScanTotals(const uint64_t *a, uint64_t *tot, int nf) {
+    const int chunk = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+    const uint64_t *row = a + ((int64_t)chunk * nf + f) * CHUNK;
+    uint64_t v = comb<MAX>(comb<MAX>(row[t * 4], row[t * 4 + 1]), comb<MAX>(row[t * 4 + 2], row[t * 4 + 3]));
+    for (int o = 32; o >= 1; o >>= 1) v = comb<MAX>(v, (uint64_t)__shfl_xor((unsigned long long)v, o, 64));
+    __shared__ uint64_t w[4];
+    if ((t & 63) == 0) w[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) tot[(int64_t)chunk * nf + f] = comb<MAX>(comb<MAX>(w[0], w[1]), comb<MAX>(w[2], w[3]));
+}
+// exclusive scan of the chunk totals inside each piece: one block per piece, one thread per field
+template <bool MAX> __global__ void kScanPieceOffsets(uint64_t *tot, BatchView B, int nf) {
+    const int p = blockIdx.x, f = threadIdx.x;
+    if (f >= nf) return;
+    uint64_t acc = 0;
+    for (int64_t ch = B.off[p] / CHUNK; ch < B.off[p + 1] / CHUNK; ch++) {
+        uint64_t v = tot[ch * nf + f];
+        tot[ch * nf + f] = acc;
+        acc = comb<MAX>(acc, v);
+    }
+}
+template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *a, const uint64_t *tot, int nf) {
+    const int chunk = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
+    uint64_t *row = a + ((int64_t)chunk * nf + f) * CHUNK;
+    uint64_t v0 = row[t * 4], v1 = comb<MAX>(v0, row[t * 4 + 1]), v2 = comb<MAX>(v1, row[t * 4 + 2]), v3 = comb<MAX>(v2, row[t * 4 + 3]);
+    // inclusive scan of the thread totals across the block
+    uint64_t inc = v3;
+    const int lane = t & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t up = (uint64_t)__shfl_up((unsigned long long)inc, o, 64);
+        if (lane >= o) inc = comb<MAX>(inc, up);
+    }
+    __shared__ uint64_t w[4];
+    if (lane == 63) w[t >> 6] = inc;
+    __syncthreads();
+    uint64_t pre = tot[(int64_t)chunk * nf + f];
+    for (int i = 0; i < (t >> 6); i++) pre = comb<MAX>(pre, w[i]);
+    uint64_t excl = (uint64_t)__shfl_up((unsigned long long)inc, 1, 64);
+    if (lane > 0) pre = comb<MAX>(pre, excl);
+    row[t * 4] = comb<MAX>(pre, v0);
+    row[t * 4 + 1] = comb<MAX>(pre, v1);
+    row[t * 4 + 2] = comb<MAX>(pre, v2);
+    row[t * 4 + 3] = comb<MAX>(pre, v3);
+}
+
+__global__ void __launch_bounds__(64) kTrellis(const DevTables *T, BatchView B) {
+    __shared__ TrellisLds lds;
+    trellisPiece(*T, B, lds, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) kBacktrace(const DevTables *T, BatchView B) { backtracePiece(*T, B, blockIdx.x); }
+
+// ---------------------------------------------------------------------------------------------------
+// host objects
+// ---------------------------------------------------------------------------------------------------
+struct augx_decoder {
+    const augx_model *model = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevTables hostT;          // scalars + DEVICE table pointers
+    DevTables *dT = nullptr;
+    std::vector<void *> tableBufs;
+    bool debugCells = false;
+};
+
+struct augx_batch {
+    augx_decoder *dec = nullptr;
+    BatchLayout L;
+    BatchView V;               // device pointers
+    std::vector<void *> bufs;
+    std::vector<const char *> hostSeq; // caller-owned sequences (used only by the GC-stairs fallback below)
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
+    bool decoded = false;
+};
+
+namespace {
+
+template <class T> int devAlloc(augx_batch *b, T **ptr, int64_t count) {
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+    b->bufs.push_back(p);
+    *ptr = (T *)p;
+    return 0;
+}
+
+// smoothed GC-content stairs of one piece on the host (reference ContentStairs::computeStairs,
+// src/motif.cc:543-616).  Only used for the rare piece whose window classes are not all equal; returns the
+// class if the smoothed stairs are constant, else -1 (multi-class pieces are not decoded by this version).
+int hostStairsClass(const augx_tables &t, const char *seq, int n) {
+    DevTables T;
+    fillDevTablesScalars(t, T);
+    std::vector<uint8_t> code(n);
+    for (int i = 0; i < n; i++) {
+        char c = seq[i];
+        c = (c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a') : c;
+        code[i] = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4;
+    }
+    std::vector<int> cls(n, -1);
+    int win = t.gc_win;
+    if (win > n || win < 1) win = n;
+    double cnt[4] = {0, 0, 0, 0};
+    for (int i = 0; i < win; i++)
+        if (code[i] < 4) cnt[code[i]] += 1;
+    int x = nearestClass(T, cnt);
+    for (int i = 0; i <= win / 2 && i < n; i++) cls[i] = x;
+    for (int i = win / 2 + 1; i <= n - (win + 1) / 2; i++) {
+        int add = i + (win + 1) / 2 - 1, sub = i - win / 2 - 1;
+        if (code[add] < 4) cnt[code[add]] += 1;
+        if (code[sub] < 4) cnt[code[sub]] -= 1;
+        cls[i] = x = nearestClass(T, cnt);
+    }
+    for (int i = n - (win + 1) / 2 + 1; i < n; i++) cls[i] = x;
+    x = -2;
+    int lastStep = 0;
+    for (int i = 0; i < n; i++)
+        if (cls[i] != x) {
+            if (i - lastStep < 1000 && lastStep > 0 && cls[lastStep - 1] == cls[i])
+                for (int j = lastStep; j < i; j++) cls[j] = cls[i];
+            lastStep = i;
+            x = cls[i];
+        }
+    for (int i = 1; i < n; i++)
+        if (cls[i] != cls[0]) return -1;
+    return cls[0];
+}
+
+template <bool MAX> int runScan(augx_batch *b, uint64_t *a, int nf) {
+    augx_decoder *d = b->dec;
+    dim3 grid(b->L.nChunks, nf);
+    hipLaunchKernelGGL((kScanTotals<MAX>), grid, dim3(256), 0, d->stream, a, b->V.chunkTot, nf);
+    hipLaunchKernelGGL((kScanPieceOffsets<MAX>), dim3(b->L.nPieces), dim3(32), 0, d->stream, b->V.chunkTot, b->V, nf);
+    hipLaunchKernelGGL((kScanApply<MAX>), grid, dim3(256), 0, d->stream, a, b->V.chunkTot, nf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
+    if (!m || !out) { setLastError("augx_decoder_create: NULL argument"); return AUGX_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        setLastError("augx_decoder_create: no HIP device available (this library has no CPU decode path)");
+        return AUGX_E_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) { setLastError("augx_decoder_create: bad device index"); return AUGX_E_ARG; }
+    const augx_tables &t = m->m.t;
+    try {
+        checkModelSupported(t);
+    } catch (std::exception &ex) {
+        setLastError(ex.what());
+        return AUGX_E_UNSUPPORTED;
+    }
+    HIP_TRY(hipSetDevice(device));
+    augx_decoder *d = new augx_decoder();
+    d->model = m;
+    d->device = device;
+    const char *dbg = getenv("AUGX_DEBUG_CELLS");
+    d->debugCells = dbg && atoi(dbg) != 0;
+    HIP_TRY(hipStreamCreate(&d->stream));
+    fillDevTablesScalars(t, d->hostT);
+    for (auto &sp : tableSpans(t, d->hostT)) {
+        void *p = nullptr;
+        size_t bytes = (size_t)(sp.count > 0 ? sp.count : 1) * sizeof(double);
+        HIP_TRY(hipMalloc(&p, bytes));
+        d->tableBufs.push_back(p);
+        if (sp.count > 0) HIP_TRY(hipMemcpy(p, sp.src, (size_t)sp.count * sizeof(double), hipMemcpyHostToDevice));
+        *sp.dst = (const double *)p;
+    }
+    HIP_TRY(hipMalloc((void **)&d->dT, sizeof(DevTables)));
+    HIP_TRY(hipMemcpy(d->dT, &d->hostT, sizeof(DevTables), hipMemcpyHostToDevice));
+    *out = d;
+    return AUGX_OK;
+}
+
+void augx_decoder_destroy(augx_decoder *d) {
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    for (void *p : d->tableBufs) (void)hipFree(p);
+    if (d->dT) (void)hipFree(d->dT);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+void augx_batch_destroy(augx_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->dec->device);
+    for (void *p : b->bufs) (void)hipFree(p);
+    for (auto &e : b->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_batch **out) {
+    if (!d || !pieces || n < 1 || !out) { setLastError("augx_batch_create: bad argument"); return AUGX_E_ARG; }
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(d->device));
+    augx_batch *b = new augx_batch();
+    b->dec = d;
+    try {
+        b->L.build(pieces, n);
+    } catch (std::exception &ex) {
+        setLastError(ex.what());
+        delete b;
+        return AUGX_E_ARG;
+    }
+    for (int p = 0; p < n; p++) b->hostSeq.push_back(pieces[p].seq);
+    const BatchLayout &L = b->L;
+    BatchSizes Z(L);
+    BatchView &V = b->V;
+    memset(&V, 0, sizeof V);
+    V.nPieces = n; V.N = L.N; V.nChunks = L.nChunks;
+    int rc = 0;
+#define DA(field, T, count) do { T *_p = nullptr; rc = devAlloc(b, &_p, (count)); if (rc) { augx_batch_destroy(b); return rc; } field = _p; } while (0)
+    int64_t *dOff; int32_t *dLen, *dIk, *dTk, *dCp; char *dRaw;
+    DA(dOff, int64_t, n + 1); DA(dLen, int32_t, n); DA(dIk, int32_t, n); DA(dTk, int32_t, n); DA(dCp, int32_t, L.nChunks);
+    DA(dRaw, char, Z.N);
+    V.off = dOff; V.len = dLen; V.initKind = dIk; V.termKind = dTk; V.chunkPiece = dCp; V.raw = dRaw;
+    DA(V.cls, int32_t, n); DA(V.clsMinMax, int32_t, 2 * n);
+    DA(V.code, uint8_t, Z.N);
+    DA(V.cnt, uint64_t, Z.N * NCNT);
+    DA(V.nsm, uint64_t, Z.N * 6);
+    DA(V.fx, uint64_t, Z.N * NFX);
+    DA(V.sig, double, Z.N * NSIG);
+    DA(V.gate, uint64_t, Z.N);
+    DA(V.site, int32_t, Z.N * NSITE);
+    DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
+    DA(V.bp, uint16_t, Z.N * SP);
+    if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
+    DA(V.vig, double, Z.N);
+    DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
+    DA(V.lrPos, int32_t, Z.listCap); DA(V.lrVal, double, Z.listCap * 3);
+    DA(V.ldPos, int32_t, Z.listCap); DA(V.ldVal, double, Z.listCap * 3);
+    DA(V.rdPos, int32_t, Z.listCap); DA(V.rdVal, double, Z.listCap * 3);
+    DA(V.atgPos, int32_t, Z.listCap);
+    DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
+    DA(V.pathRec, int32_t, Z.pathCap * 3);
+#undef DA
+    HIP_TRY(hipMemcpy(dOff, L.off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dLen, L.len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dIk, L.initKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dTk, L.termKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dCp, L.chunkPiece.data(), sizeof(int32_t) * L.nChunks, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dRaw, 'n', (size_t)Z.N));
+    for (int p = 0; p < n; p++)
+        HIP_TRY(hipMemcpy(dRaw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p], hipMemcpyHostToDevice));
+    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    *out = b;
+    return AUGX_OK;
+}
+
+int augx_batch_decode(augx_decoder *d, augx_batch *b) {
+    if (!d || !b) { setLastError("augx_batch_decode: NULL argument"); return AUGX_E_ARG; }
+    HIP_TRY(hipSetDevice(d->device));
+    const BatchView &V = b->V;
+    const int n = V.nPieces;
+    const unsigned gridN = (unsigned)((V.N + 255) / 256);
+    hipStream_t st = d->stream;
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    hipLaunchKernelGGL(kEncode, dim3(gridN), dim3(256), 0, st, V);
+    hipLaunchKernelGGL(kSiteTerms, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    int rc;
+    if ((rc = runScan<false>(b, V.cnt, NCNT))) return rc;
+    if ((rc = runScan<true>(b, V.nsm, 6))) return rc;
+    hipLaunchKernelGGL(kClassInit, dim3((n + 63) / 64), dim3(64), 0, st, V);
+    hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    hipLaunchKernelGGL(kClassFinal, dim3((n + 63) / 64), dim3(64), 0, st, V);
+    HIP_TRY(hipGetLastError());
+    {   // pieces whose 1-bp-shifted GC windows do not all agree: settle the smoothed stairs on the host
+        std::vector<int32_t> cls(n);
+        HIP_TRY(hipMemcpyAsync(cls.data(), V.cls, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool any = false;
+        for (int p = 0; p < n; p++)
+            if (cls[p] < 0) { cls[p] = hostStairsClass(d->model->m.t, b->hostSeq[p], b->L.len[p]); any = true; }
+        if (any) HIP_TRY(hipMemcpyAsync(V.cls, cls.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+        if (any) HIP_TRY(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(kFxTerms, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    if ((rc = runScan<false>(b, V.fx, NFX))) return rc;
+    hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    hipLaunchKernelGGL(kTrellis, dim3(n), dim3(64), 0, st, d->dT, V);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[2], st));
+    hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev[3], st));
+    b->decoded = true;
+    return AUGX_OK;
+}
+
+int augx_batch_sync(augx_decoder *d) {
+    if (!d) return AUGX_E_ARG;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return AUGX_OK;
+}
+
+int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *trellis_ms, float *back_ms) {
+    if (!d || !b || !b->decoded) return AUGX_E_ARG;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipEventSynchronize(b->ev[3]));
+    float a = 0, c = 0, e = 0;
+    HIP_TRY(hipEventElapsedTime(&a, b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&c, b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&e, b->ev[2], b->ev[3]));
+    if (prep_ms) *prep_ms = a;
+    if (trellis_ms) *trellis_ms = c;
+    if (back_ms) *back_ms = e;
+    return AUGX_OK;
+}
+
+int augx_batch_paths(augx_decoder *d, augx_batch *b, augx_path *out) {
+    if (!d || !b || !out || !b->decoded) { setLastError("augx_batch_paths: bad argument"); return AUGX_E_ARG; }
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    const BatchView &V = b->V;
+    const int n = V.nPieces;
+    std::vector<double> lnv(n);
+    std::vector<int32_t> status(n), count(n);
+    HIP_TRY(hipMemcpy(lnv.data(), V.lnv, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status.data(), V.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(count.data(), V.pathCount, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    const augx_tables &t = d->model->m.t;
+    for (int p = 0; p < n; p++) {
+        out[p].states = nullptr;
+        out[p].n_states = 0;
+        out[p].status = status[p];
+        out[p].ln_viterbi = lnv[p];
+        if (status[p] != 0) continue;
+        int cnt = count[p];
+        std::vector<int32_t> rec((size_t)cnt * 3 + 3);
+        int64_t po = b->L.off[p] / 8 + 64 * (int64_t)p;
+        if (cnt > 0) HIP_TRY(hipMemcpy(rec.data(), V.pathRec + po * 3, sizeof(int32_t) * 3 * (size_t)cnt, hipMemcpyDeviceToHost));
+        out[p].states = (augx_state *)malloc(sizeof(augx_state) * (size_t)(cnt > 0 ? cnt : 1));
+        out[p].n_states = cnt;
+        for (int i = 0; i < cnt; i++) {
+            const int32_t *r = &rec[(size_t)(cnt - 1 - i) * 3];
+            out[p].states[i].begin = r[0];
+            out[p].states[i].end = r[1];
+            out[p].states[i].state = (int16_t)r[2];
+            out[p].states[i].type = (int16_t)t.state_type[r[2]];
+        }
+    }
+    return AUGX_OK;
+}
+
+int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out) {
+    if (!d || !b || !out || piece < 0 || piece >= b->V.nPieces) return AUGX_E_ARG;
+    if (!b->V.cells) { setLastError("augx_batch_cells: decoder was not created with AUGX_DEBUG_CELLS=1"); return AUGX_E_ARG; }
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    const int S = d->hostT.S;
+    HIP_TRY(hipMemcpy(out, b->V.cells + (b->L.off[piece] + 1) * S, sizeof(double) * (size_t)b->L.len[piece] * S, hipMemcpyDeviceToHost));
+    return AUGX_OK;
+}
+
+int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out) {
+    augx_batch *b = nullptr;
+    int rc = augx_batch_create(d, pieces, n, &b);
+    if (rc) return rc;
+    rc = augx_batch_decode(d, b);
+    if (!rc) rc = augx_batch_paths(d, b, out);
+    augx_batch_destroy(b);
+    return rc;
+}
+
+void augx_path_free(augx_path *p) {
+    if (p && p->states) { free(p->states); p->states = nullptr; p->n_states = 0; }
+}
+}

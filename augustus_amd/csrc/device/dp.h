@@ -88,6 +88,9 @@ struct BatchView {
 };
 
 AUGX_HD int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
+// scan-field arrays (cnt, nsm, fx) are stored chunk-major, field-major inside a chunk: [chunk][field][CHUNK],
+// so that the prefix scans stream contiguous rows.  g = global slot, f = field, nf = fields per slot.
+AUGX_HD int64_t fidx(int64_t g, int f, int nf) { return ((g / CHUNK) * nf + f) * CHUNK + (g % CHUNK); }
 AUGX_HD int64_t listOff(const BatchView &B, int p) { return B.off[p] / 2; }
 AUGX_HD int64_t pathOff(const BatchView &B, int p) { return B.off[p] / 8 + 64 * (int64_t)p; }
 AUGX_HD int64_t pathCap(const BatchView &B, int p) { return (B.off[p + 1] - B.off[p]) / 8 + 64; }
@@ -96,9 +99,10 @@ AUGX_HD int64_t pathCap(const BatchView &B, int p) { return (B.off[p + 1] - B.of
 struct Piece {
     const DevTables *t;
     int n, c;                  // length, GC class
+    int64_t o;                 // slot offset of the piece: base q lives in slot o+1+q
     const uint8_t *code;       // code[q]
-    const uint64_t *fx;        // fx[(q+1)*NFX + f] = prefix sum up to and including q
-    const uint64_t *nsm;       // nsm[(q+1)*6 + r]
+    const uint64_t *fx;        // fx[fidx(o+1+q, f, NFX)] = prefix sum up to and including q
+    const uint64_t *nsm;       // nsm[fidx(o+1+q, r, 6)]
     const double *sig;         // sig[q*NSIG + i]
     AUGX_HD int b(int p) const { return (p >= 0 && p < n) ? code[p] : 4; }
     AUGX_HD bool is2(int p, int x, int y) const { return b(p) == x && b(p + 1) == y; }
@@ -134,13 +138,13 @@ struct Piece {
     // Markov-chain content of bases l..r from the fixed-point prefix field f
     AUGX_HD double seg(int f, int l, int r) const {
         if (l > r) return 0.0;
-        uint64_t hi = fx[(int64_t)(r + 1) * NFX + f], lo = fx[(int64_t)l * NFX + f];
+        uint64_t hi = fx[fidx(o + 1 + r, f, NFX)], lo = fx[fidx(o + l, f, NFX)];
         return (double)(int64_t)(hi - lo) * AUGX_FX_INV;
     }
     // nearest in-frame stop: reference OpenReadingFrame tables, src/exonmodel.cc:101-156
     AUGX_HD int nearestStop(int pos, bool fwd) const {
         if (n <= 5 && pos >= n - 2) return 0; // tables left unpatched by the reference for tiny inputs
-        return (int)nsm[(int64_t)(pos + 1) * 6 + (fwd ? 0 : 3) + pos % 3] - 1;
+        return (int)nsm[fidx(o + 1 + pos, (fwd ? 0 : 3) + pos % 3, 6)] - 1;
     }
     // reference OpenReadingFrame::leftmostExonBegin, src/exonmodel.cc:165-198
     AUGX_HD int leftmostExonBegin(int frame, int base, bool fwd) const {

@@ -62,9 +62,10 @@ AUGX_HD Piece makePiece(const DevTables &T, const BatchView &B, int p) {
     P.t = &T;
     P.n = B.len[p];
     P.c = B.cls[p];
+    P.o = o;
     P.code = B.code + o + 1;
-    P.fx = B.fx + o * NFX;
-    P.nsm = B.nsm + o * 6;
+    P.fx = B.fx;
+    P.nsm = B.nsm;
     P.sig = B.sig + (o + 1) * NSIG;
     return P;
 }
@@ -93,12 +94,11 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
     Piece P;
-    P.t = &T; P.n = B.len[p]; P.c = 0; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
-    uint64_t *cnt = B.cnt + g * NCNT;
-    uint64_t *ns = B.nsm + g * 6;
+    P.t = &T; P.n = B.len[p]; P.c = 0; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    uint64_t cnt[NCNT], ns[6];
     for (int i = 0; i < NCNT; i++) cnt[i] = 0;
     for (int i = 0; i < 6; i++) ns[i] = 0;
-    if (q < 0 || q >= P.n) return;
+    if (q >= 0 && q < P.n) {
     int c = P.b(q);
     if (c < 4) cnt[c] = 1;
     // start codon with positive probability at q (a of atg)
@@ -111,6 +111,9 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
         if (P.isStop(q)) ns[q % 3] = (uint64_t)q + 1;
         if (P.isRCStop(q)) ns[3 + q % 3] = (uint64_t)q + 1;
     }
+    }
+    for (int i = 0; i < NCNT; i++) B.cnt[fidx(g, i, NCNT)] = cnt[i];
+    for (int i = 0; i < 6; i++) B.nsm[fidx(g, i, 6)] = ns[i];
 }
 
 // GC class of the window starting at base s (one thread per slot; reference ContentStairs::computeStairs,
@@ -149,9 +152,8 @@ AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
     int win = T.gc_win;
     if (win > n || win < 1) win = n;
     if (s < 0 || s > n - win) return -1;
-    const uint64_t *lo = B.cnt + (o + s) * NCNT, *hi = B.cnt + (o + s + win) * NCNT;
     double cnt[4];
-    for (int i = 0; i < 4; i++) cnt[i] = (double)(hi[i] - lo[i]);
+    for (int i = 0; i < 4; i++) cnt[i] = (double)(B.cnt[fidx(o + s + win, i, NCNT)] - B.cnt[fidx(o + s, i, NCNT)]);
     return nearestClass(T, cnt);
 }
 
@@ -160,12 +162,11 @@ AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g) {
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
-    uint64_t *out = B.fx + g * NFX;
+    uint64_t out[NFX];
     for (int i = 0; i < NFX; i++) out[i] = 0;
-    if (q < 0 || q >= B.len[p]) return;
     Piece P;
-    P.t = &T; P.n = B.len[p]; P.c = B.cls[p]; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
-    if (P.c < 0) return;
+    P.t = &T; P.n = B.len[p]; P.c = B.cls[p]; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    if (q >= 0 && q < B.len[p] && P.c >= 0) {
     const int k = T.k, NP = T.NP, c = P.c;
     int pn = q >= k ? P.pat(q - k, k + 1) : -1;
     int rn = P.rcpat(q, k + 1);
@@ -181,6 +182,8 @@ AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g) {
     out[FX_INF] = toFx(pn >= 0 ? inE[pn] : T.ln_quarter);
     int rn2 = (q + k < P.n) ? rn : -1;
     out[FX_INR] = toFx(rn2 >= 0 ? inE[rn2] : T.ln_quarter);
+    }
+    for (int i = 0; i < NFX; i++) B.fx[fidx(g, i, NFX)] = out[i];
 }
 
 // per-base signal record + end-gate mask of the variable-length states
@@ -207,7 +210,8 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     sg[SIG_TISF] = tisFwd(P, q);
     sg[SIG_TISR] = tisRev(P, q);
     // list index of the site ending at q (prefix count - 1), -1 if q is not such a site
-    const uint64_t *cn = B.cnt + g * NCNT, *cp = B.cnt + (g - 1) * NCNT;
+    uint64_t cn[NCNT], cp[NCNT];
+    for (int i = CNT_ATG; i < NCNT; i++) { cn[i] = B.cnt[fidx(g, i, NCNT)]; cp[i] = B.cnt[fidx(g - 1, i, NCNT)]; }
     const int64_t lo = listOff(B, p);
     for (int i = 0; i < NSITE; i++)
         st[i] = cn[CNT_LA + i] != cp[CNT_LA + i] ? (int32_t)cn[CNT_LA + i] - 1 : -1;
@@ -281,7 +285,7 @@ struct TrellisCtx {
     AUGX_HD uint64_t cntAt(int q, int f) const { // number of sites of field f at bases <= q (q may be -1)
         if (q < 0) return 0;
         if (q > n - 1) q = n - 1;
-        return B.cnt[(o + 1 + q) * NCNT + f];
+        return B.cnt[fidx(o + 1 + q, f, NCNT)];
     }
 };
 
@@ -473,8 +477,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
     {   // ---- a piece without a single nucleotide is all intergenic (reference src/namgene.cc:205-226)
-        const uint64_t *last = B.cnt + (o + n) * NCNT;
-        if (last[0] + last[1] + last[2] + last[3] == 0) {
+        uint64_t nuc = 0;
+        for (int i = 0; i < 4; i++) nuc += B.cnt[fidx(o + n, i, NCNT)];
+        if (nuc == 0) {
             const int sy = T.synch;
             int selfAi = 0;
             for (int ai = 0; ai < T.n_anc[sy]; ai++)

@@ -23,9 +23,9 @@ template <bool MAX> void scanFields(uint64_t *a, int nf, const BatchLayout &L) {
         std::vector<uint64_t> acc(nf, 0);
         for (int64_t g = L.off[p]; g < L.off[p + 1]; g++)
             for (int f = 0; f < nf; f++) {
-                uint64_t v = a[g * nf + f];
+                uint64_t v = a[fidx(g, f, nf)];
                 acc[f] = MAX ? (v > acc[f] ? v : acc[f]) : acc[f] + v;
-                a[g * nf + f] = acc[f];
+                a[fidx(g, f, nf)] = acc[f];
             }
     }
 }

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Regenerates tests/golden/config_min.tar.gz: the minimal subset of the reference's species-parameter DATA
+# (config/, read-only input of the drop-in contract; not source code) needed to run the human and fly
+# ab-initio models where /root/reference does not exist (the GPU box).  Run in the build container.
+set -e
+REF=${REF:-/root/reference}
+OUT=$(cd "$(dirname "$0")" && pwd)/config_min.tar.gz
+tar -C "$REF" -czf "$OUT" \
+    config/species/human/human_parameters.cfg config/species/human/human_exon_probs.pbl \
+    config/species/human/human_intron_probs.pbl config/species/human/human_igenic_probs.pbl \
+    config/species/human/human_weightmatrix.txt config/species/human/human_utr_probs.pbl \
+    config/species/human/human_trans_shadow_partial_utr.pbl \
+    config/species/fly/fly_parameters.cfg config/species/fly/fly_exon_probs.pbl \
+    config/species/fly/fly_intron_probs.pbl config/species/fly/fly_igenic_probs.pbl \
+    config/species/fly/fly_weightmatrix.txt config/species/fly/fly_utr_probs.pbl \
+    config/model config/extrinsic/extrinsic.cfg config/parameters/aug_cmdln_parameters.json
+ls -la "$OUT"
