@@ -1,0 +1,341 @@
+// genes.cc -- see genes.h
+#include "genes.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace augx {
+
+static inline int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
+// type predicates, reference include/types.hh:520-640 (type ids: include/types.hh:492-512)
+static inline bool isInitialExon(int t) { return t >= 2 && t <= 4; }
+static inline bool isInternalExon(int t) { return t >= 5 && t <= 7; }
+static inline bool isRInternalExon(int t) { return t >= 38 && t <= 40; }
+static inline bool isRTerminalExon(int t) { return t >= 41 && t <= 43; }
+static inline bool isCodingExon(int t) { return (t >= 1 && t <= 8) || (t >= 36 && t <= 43); }
+static inline bool isCodingIntron(int t) { return (t >= 9 && t <= 23) || (t >= 44 && t <= 58); }
+static inline bool isIntron(int t) { return isCodingIntron(t) || t == TYPE_INTRON || t == TYPE_RINTRON; }
+static inline bool isOnFStrand(int t) { return !((t >= 36 && t <= 70) || t == TYPE_RINTRON || (t >= 80 && t <= 85)); }
+enum { T_SINGLE = 1, T_TERMINAL = 8, T_RSINGLE = 36, T_RINITIAL = 37 };
+
+int BioState::frame() const { return mod3(winOfType(type) + framemod); }
+
+// reference State::setTruncFlag, src/gene.cc:309-321
+static int truncFlag(int type, long begin, long end, long dnalen) {
+    int tr = 0;
+    long predEnd = begin - 1;
+    if (end == dnalen - 1 && (isInitialExon(type) || isInternalExon(type) || isRTerminalExon(type) || isRInternalExon(type) || isIntron(type)))
+        tr |= TRUNC_RIGHT;
+    if ((predEnd == -1 || predEnd == 0) &&
+        (isInternalExon(type) || type == T_TERMINAL || isRInternalExon(type) || type == T_RINITIAL || isIntron(type)))
+        tr |= TRUNC_LEFT;
+    return tr;
+}
+
+// reference State::getBiologicalState, src/gene.cc:176-300 (coding exons and introns only)
+static BioState bioState(const Model &m, long begin, long end, int type, int truncated) {
+    const augx_tables &t = m.t;
+    BioState b;
+    int beginShift = 0, endShift = 0;
+    if (type == T_SINGLE || isInitialExon(type)) beginShift = t.W;
+    else if (isInternalExon(type) || type == T_TERMINAL) { if (!(truncated & TRUNC_LEFT)) beginShift = -t.Ae; }
+    else if (isRInternalExon(type) || type == T_RINITIAL) { if (!(truncated & TRUNC_LEFT)) beginShift = -t.Ds; }
+    else if (type == TYPE_INTRON) beginShift = !(truncated & TRUNC_LEFT) ? t.Ds : -1;
+    else if (type == TYPE_RINTRON) beginShift = !(truncated & TRUNC_LEFT) ? t.Ae : -1;
+    if (type == T_RSINGLE || type == T_RINITIAL) endShift = -t.W;
+    else if (isInitialExon(type) || isInternalExon(type)) {
+        if (!(truncated & TRUNC_RIGHT)) endShift = t.Ds; else b.framemod = mod3(-t.Ds);
+    } else if (isRTerminalExon(type) || isRInternalExon(type)) {
+        if (!(truncated & TRUNC_RIGHT)) endShift = t.Ae; else b.framemod = mod3(t.Ae);
+    } else if (type == TYPE_INTRON) { if (!(truncated & TRUNC_RIGHT)) endShift = -t.Ae; }
+    else if (type == TYPE_RINTRON) { if (!(truncated & TRUNC_RIGHT)) endShift = -t.Ds; }
+    b.begin = begin + beginShift;
+    b.end = end + endShift;
+    b.type = type;
+    b.truncated = truncated;
+    return b;
+}
+
+bool Transcript::completeCDS() const { // reference Gene::completeCDS, src/gene.cc:1977-1988
+    if (exons.empty()) return false;
+    int ft = exons.front().type, lt = exons.back().type;
+    if (isInternalExon(ft) || isRInternalExon(ft) || isInternalExon(lt) || isRInternalExon(lt) || ft == T_TERMINAL ||
+        isRTerminalExon(lt) || ft == T_RINITIAL || isInitialExon(lt))
+        return false;
+    if ((exons.front().truncated & TRUNC_LEFT) || (exons.back().truncated & TRUNC_RIGHT)) return false;
+    return true;
+}
+void Transcript::shift(long d) {
+    for (auto &e : exons) { e.begin += d; e.end += d; }
+    for (auto &e : introns) { e.begin += d; e.end += d; }
+    if (transstart >= 0) transstart += d;
+    if (transend >= 0) transend += d;
+    codingstart += d;
+    codingend += d;
+}
+
+void OutputOptions::fromModel(const Model &m) { // reference Gene::init, src/gene.cc:2447-2459
+    const Options &o = m.opt;
+    print_start = o.getBool("start", true);
+    print_stop = o.getBool("stop", true);
+    print_introns = o.getBool("introns", false);
+    print_cds = o.getBool("cds", true);
+    print_exonnames = o.getBool("exonnames", false);
+    gff3 = o.getBool("gff3", false);
+    stopCodonExcludedFromCDS = o.getBool("stopCodonExcludedFromCDS", false);
+    protein = o.getBool("protein", true);
+    codingseq = o.getBool("codingseq", false);
+    uniqueGeneId = o.getBool("uniqueGeneId", false);
+    // "# Evidence for and against" is printed when the hints machinery is on, i.e. with softmasking (default true,
+    // reference src/types.cc:95, src/extrinsicinfo.cc:1722, src/gene.cc:3111) and printEvidence (default true)
+    evidence = o.getBool("softmasking", true) && o.getBool("printEvidence", true);
+}
+
+std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vector<PathState> &path, long dnalen) {
+    std::vector<Transcript> out;
+    size_t i = 0;
+    const size_t n = path.size();
+    int genenumber = 1;
+    bool haveGene = false;
+    Transcript g;
+    auto tr = [&](const PathState &s) { return truncFlag(s.type, s.begin, s.end, dnalen); };
+    // incomplete gene beginning with an intron in the CDS (src/gene.cc:403-417)
+    if (n > 0 && isCodingIntron(path[0].type)) {
+        long b = path[0].begin;
+        int trunc = tr(path[0]);
+        bool fwd = isOnFStrand(path[0].type);
+        while (i + 1 < n && isCodingIntron(path[i + 1].type)) i++;
+        trunc |= tr(path[i]);
+        g = Transcript();
+        haveGene = true;
+        g.introns.push_back(bioState(m, b, path[i].end, fwd ? TYPE_INTRON : TYPE_RINTRON, trunc));
+        g.transstart = g.introns.back().begin;
+        i++;
+    }
+    while (i < n) {
+        while (i < n && !isCodingExon(path[i].type)) i++;
+        if (i >= n) break;
+        if (!haveGene) { g = Transcript(); haveGene = true; }
+        const int ty = path[i].type;
+        g.plus = isOnFStrand(ty);
+        if (!g.plus) g.frame = 2;
+        if (ty == T_SINGLE || ty == T_RSINGLE) {
+            g.exons.push_back(bioState(m, path[i].begin, path[i].end, ty, tr(path[i])));
+            i++;
+        } else {
+            if (!isInitialExon(ty) && !isRTerminalExon(ty)) g.complete = false;
+            BioState first = bioState(m, path[i].begin, path[i].end, ty, tr(path[i]));
+            g.exons.push_back(first);
+            g.frame = g.plus ? mod3(first.frame() - first.length()) : mod3(first.frame() + first.length());
+            if (ty == T_TERMINAL || ty == T_RINITIAL) {
+                i++;
+            } else {
+                i++;
+                while (i < n && path[i].type != T_TERMINAL && path[i].type != T_RINITIAL) {
+                    int t2 = path[i].type;
+                    if (isIntron(t2)) {
+                        long b = path[i].begin;
+                        bool fwd = isOnFStrand(t2);
+                        while (i + 1 < n && isIntron(path[i + 1].type)) i++;
+                        g.introns.push_back(bioState(m, b, path[i].end, fwd ? TYPE_INTRON : TYPE_RINTRON, tr(path[i])));
+                        if (g.introns.back().end > g.transstart) g.transend = g.introns.back().end;
+                    } else if (isInternalExon(t2) || isRInternalExon(t2)) {
+                        g.exons.push_back(bioState(m, path[i].begin, path[i].end, t2, tr(path[i])));
+                    } else
+                        throw std::runtime_error("state path doesn't constitute a valid gene");
+                    i++;
+                }
+                if (i >= n)
+                    g.complete = false;
+                else {
+                    g.exons.push_back(bioState(m, path[i].begin, path[i].end, path[i].type, tr(path[i])));
+                    i++;
+                }
+            }
+        }
+        // finish construction of the gene (src/gene.cc:612-676)
+        g.clength = 0;
+        for (auto &e : g.exons) g.clength += e.length();
+        if (!g.plus) g.frame = mod3(g.frame - g.clength + 1);
+        g.codingstart = g.exons.front().begin;
+        g.codingend = g.exons.back().end;
+        if (g.codingend > g.transend) g.transend = -1;
+        if (g.codingstart >= 0 && g.codingstart < g.transstart) g.transstart = -1;
+        g.id = "g" + std::to_string(genenumber++);
+        out.push_back(g);
+        haveGene = false;
+    }
+    return out;
+}
+
+std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs) {
+    std::vector<Transcript> out;
+    for (const Transcript &g : txs) {
+        bool keep = true;
+        bool cc = g.completeCDS();
+        if ((g.clength < m.t.min_coding_len && cc) || (g.clength < 4 && g.clength < m.t.min_coding_len && !cc)) keep = false;
+        if (keep) out.push_back(g);
+    }
+    return out;
+}
+
+std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs) {
+    std::vector<GeneOut> genes;
+    for (const Transcript &t : txs) {
+        GeneOut ag;
+        ag.transcripts.push_back(t);
+        ag.plus = t.plus;
+        ag.mincodstart = t.codingstart;
+        ag.maxcodend = t.codingend;
+        ag.apostprob = 1.0; // Viterbi transcripts enter with apostprob 1 (src/namgene.cc:813-821, src/gene.cc:2706)
+        genes.push_back(ag);
+    }
+    std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
+    return genes;
+}
+
+static const char kTransTable1[] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+static int b2i(char c) {
+    switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1; case 'g': case 'G': return 2; case 't': case 'T': return 3; default: return -1; }
+}
+// reference getTranslation, src/gene.cc:2337-2354
+std::string translateCDS(const char *cs) {
+    std::string result;
+    while (cs[0] && cs[1] && cs[2]) {
+        int a = b2i(cs[0]), b = b2i(cs[1]), c = b2i(cs[2]);
+        char aa = (a < 0 || b < 0 || c < 0) ? 'X' : kTransTable1[a * 16 + b * 4 + c];
+        if (aa != '*') result.append(1, aa);
+        else if (cs[3]) result.append("X");
+        cs += 3;
+    }
+    return result;
+}
+static std::string exonicSequence(const Transcript &t, const char *seq) { // src/gene.cc:1400-1422
+    std::string s;
+    for (const BioState &e : t.exons) s.append(seq + e.begin, (size_t)e.length());
+    for (char &c : s) c = (char)tolower((unsigned char)c);
+    if (!t.plus) {
+        std::string r(s.rbegin(), s.rend());
+        for (char &c : r) c = c == 'a' ? 't' : c == 'c' ? 'g' : c == 'g' ? 'c' : c == 't' ? 'a' : c;
+        return r;
+    }
+    return s;
+}
+
+static void appendf(std::string &out, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static void appendf(std::string &out, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    int n = vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (n > 0) out.append(buf, (size_t)std::min<int>(n, (int)sizeof buf - 1));
+}
+
+// reference Gene::printGFF, src/gene.cc:1998-2313 (coding genes without UTR)
+static void printTranscriptGFF(std::string &out, const Transcript &t, const OutputOptions &o) {
+    const char *seqname = t.seqname.c_str();
+    const char *source = "AUGUSTUS";
+    const char strand = t.plus ? '+' : '-';
+    std::string transcript_id = t.geneid + "." + t.id;
+    std::string parentstr = o.gff3 ? ("Parent=" + transcript_id) : ("transcript_id \"" + transcript_id + "\"; gene_id \"" + t.geneid + "\";");
+    if (!t.exons.empty()) {
+        const BioState &f = t.exons.front();
+        if (o.print_start && t.plus && (isInitialExon(f.type) || f.type == T_SINGLE))
+            appendf(out, "%s\t%s\tstart_codon\t%ld\t%ld\t.\t+\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
+        if (o.print_stop && !t.plus && (f.type == T_TERMINAL || f.type == T_SINGLE || isRTerminalExon(f.type) || f.type == T_RSINGLE))
+            appendf(out, "%s\t%s\tstop_codon\t%ld\t%ld\t.\t-\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
+    }
+    auto frameCol = [&](const BioState &e) { return t.plus ? mod3(3 - (e.frame() - e.length())) : mod3(2 - e.frame()); };
+    if (o.print_exonnames && !o.gff3)
+        for (const BioState &e : t.exons) {
+            const char *nm = (e.type == T_SINGLE || e.type == T_RSINGLE) ? "single"
+                             : (isInitialExon(e.type) || e.type == T_RINITIAL) ? "initial"
+                             : (e.type == T_TERMINAL || isRTerminalExon(e.type)) ? "terminal" : "internal";
+            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t.\t%c\t%d\ttranscript_id \"%s.%s\"; gene_id \"%s\";\n", seqname, source, nm,
+                    e.begin + 1, e.end + 1, strand, frameCol(e), t.geneid.c_str(), t.id.c_str(), t.geneid.c_str());
+        }
+    if (o.print_introns)
+        for (const BioState &e : t.introns)
+            appendf(out, "%s\t%s\tintron\t%ld\t%ld\t.\t%c\t.\t%s\n", seqname, source, e.begin + 1, e.end + 1, strand, parentstr.c_str());
+    for (const BioState &e : t.exons) {
+        if (o.print_cds) {
+            int beginmod = 0, endmod = 0;
+            if (o.stopCodonExcludedFromCDS) {
+                if (e.type == T_TERMINAL || e.type == T_SINGLE) endmod = -3;
+                if (isRTerminalExon(e.type) || e.type == T_RSINGLE) beginmod = 3;
+            }
+            if (e.begin + 1 + beginmod <= e.end + 1 + endmod) {
+                appendf(out, "%s\t%s\tCDS\t%ld\t%ld\t.\t%c\t%d\t", seqname, source, e.begin + 1 + beginmod, e.end + 1 + endmod, strand, frameCol(e));
+                if (o.gff3) appendf(out, "ID=%s.%s.cds;", t.geneid.c_str(), t.id.c_str());
+                out += parentstr;
+                out += "\n";
+            }
+        }
+    }
+    if (!t.exons.empty()) {
+        const BioState &l = t.exons.back();
+        if (o.print_stop && t.plus && (l.type == T_TERMINAL || l.type == T_SINGLE))
+            appendf(out, "%s\t%s\tstop_codon\t%ld\t%ld\t.\t+\t0\t%s\n", seqname, source, l.end - 1, l.end + 1, parentstr.c_str());
+        if (o.print_start && !t.plus && (isInitialExon(l.type) || l.type == T_SINGLE || l.type == T_RINITIAL || l.type == T_RSINGLE))
+            appendf(out, "%s\t%s\tstart_codon\t%ld\t%ld\t.\t-\t0\t%s\n", seqname, source, l.end - 1, l.end + 1, parentstr.c_str());
+    }
+}
+
+void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o) {
+    (void)seqlen;
+    for (const GeneOut &g : genes) {
+        long minB = 0x7fffffffffffffffL, maxE = 0;
+        for (const Transcript &t : g.transcripts) { minB = std::min(minB, t.geneBegin()); maxE = std::max(maxE, t.geneEnd()); }
+        out += "# start gene " + g.id + "\n";
+        // gene line: AltGene::hasProbs is true after joinGenesFromPredRuns, apostprob = sum of transcript apostprobs
+        // (= 1 for the single Viterbi transcript), printed with setprecision(3)
+        char score[32];
+        snprintf(score, sizeof score, "%.3g", g.apostprob);
+        appendf(out, "%s\tAUGUSTUS\tgene\t%ld\t%ld\t%s\t%c\t.\t%s%s\n", g.seqname.c_str(), minB + 1, maxE + 1, score, g.plus ? '+' : '-',
+                o.gff3 ? "ID=" : "", g.id.c_str());
+        for (const Transcript &t : g.transcripts) {
+            appendf(out, "%s\tAUGUSTUS\ttranscript\t%ld\t%ld\t.\t%c\t.\t", g.seqname.c_str(), t.geneBegin() + 1, t.geneEnd() + 1, t.plus ? '+' : '-');
+            if (o.gff3) out += "ID=" + g.id + "." + t.id + ";Parent=" + g.id + "\n";
+            else out += g.id + "." + t.id + "\n";
+            printTranscriptGFF(out, t, o);
+            if (seq) {
+                std::string cds = exonicSequence(t, seq);
+                if (o.codingseq) { // reference Gene::printCodingSeq, src/gene.cc:2315-2334
+                    const int linelength = 100;
+                    int cur = 21;
+                    size_t offset = 0;
+                    out += "# coding sequence = [";
+                    while (offset < cds.size()) {
+                        out += cds.substr(offset, (size_t)(linelength - cur));
+                        offset += (size_t)(linelength - cur);
+                        if (offset < cds.size()) { out += "\n# "; cur = 2; }
+                    }
+                    out += "]\n";
+                }
+                if (o.protein) { // reference Gene::printProteinSeq, src/gene.cc:2356-2383
+                    const int linelength = 100;
+                    const std::string prefix = "# protein sequence = [";
+                    std::string trans = translateCDS(cds.c_str() + mod3(-t.frame));
+                    size_t i2 = linelength - prefix.size();
+                    out += prefix + trans.substr(0, i2);
+                    while (i2 < trans.size()) {
+                        out += "\n# " + trans.substr(i2, linelength - 2);
+                        i2 += linelength - 2;
+                    }
+                    out += "]\n";
+                }
+            }
+            if (o.evidence) { // reference Gene::printEvidence, src/gene.cc:2412-2445 (no hints: all counts 0)
+                out += "# Evidence for and against this transcript:\n";
+                out += "# % of transcript supported by hints (any source): 0\n";
+                appendf(out, "# CDS exons: 0/%zu\n# CDS introns: 0/%zu\n", t.exons.size(), t.introns.size());
+                out += "# 5'UTR exons and introns: 0/0\n# 3'UTR exons and introns: 0/0\n";
+                out += "# hint groups fully obeyed: 0\n# incompatible hint groups: 0\n";
+            }
+        }
+        out += "# end gene " + g.id + "\n###\n";
+    }
+}
+
+} // namespace augx

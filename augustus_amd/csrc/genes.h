@@ -1,0 +1,69 @@
+// genes.h -- state path -> transcripts -> genes -> GFF text (host side, after the device decode).
+// Restates the reference's post-processing for the ab-initio, non-UTR model:
+//   State::setTruncFlag / getBiologicalState      reference src/gene.cc:176-321
+//   StatePath::projectOntoGeneSequence            reference src/gene.cc:394-700
+//   filterGenePrediction / groupTranscriptsToGenes reference src/gene.cc:2465-2524, 3191-3240
+//   printGeneList / Gene::printGFF / printProteinSeq / printEvidence   reference src/gene.cc:3071-3120,1998-2313,2356-2445
+#pragma once
+#include <string>
+#include <vector>
+#include "model.h"
+
+namespace augx {
+
+enum { TRUNC_LEFT = 1, TRUNC_RIGHT = 2 };
+const int TYPE_INTRON = 71, TYPE_RINTRON = 72; // intron_type, rintron_type (reference include/types.hh:507)
+
+struct BioState {
+    long begin = 0, end = 0;
+    int type = -1;
+    int truncated = 0;
+    int framemod = 0;
+    int frame() const;
+    int length() const { return (int)(end - begin + 1); }
+};
+
+struct Transcript {
+    std::vector<BioState> exons, introns;
+    bool plus = true;
+    int frame = 0;
+    bool complete = true;
+    long transstart = -1, transend = -1, codingstart = -1, codingend = -1;
+    int clength = 0;
+    std::string id, geneid, seqname;
+    long geneBegin() const { return transstart >= 0 ? transstart : codingstart; }
+    long geneEnd() const { return transend >= 0 ? transend : codingend; }
+    bool completeCDS() const;
+    void shift(long d);
+};
+
+struct GeneOut {
+    std::vector<Transcript> transcripts;
+    std::string id, seqname;
+    bool plus = true;
+    long mincodstart = 0, maxcodend = 0;
+    double apostprob = 0;
+};
+
+struct OutputOptions {
+    bool print_start = true, print_stop = true, print_introns = false, print_cds = true, print_exonnames = false,
+         gff3 = false, stopCodonExcludedFromCDS = false, protein = true, codingseq = false, evidence = false,
+         uniqueGeneId = false;
+    void fromModel(const Model &m);
+};
+
+// raw decoded path of one piece (0-based HMM-state coordinates, 5'->3', chain states merged)
+struct PathState { long begin, end; int type; };
+
+// path -> list of (possibly partial) transcripts in piece coordinates
+std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vector<PathState> &path, long dnalen);
+// drop transcripts the reference's filterGenePrediction would drop (ab initio: CDS length rules only)
+std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs);
+// group into genes (one path => no overlaps => one transcript per gene), sorted by coding start
+std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs);
+// print the genes of one piece.  seq = the WHOLE input sequence (lower/upper case irrelevant), offset-free coordinates
+void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o);
+
+std::string translateCDS(const char *codingSeq);
+
+} // namespace augx
