@@ -1,0 +1,38 @@
+# Build of the MI355X (gfx950) product and of the test-side helpers.  `python -c "import __graft_entry__ as g; g.build()"`
+# drives this file.  hipcc cross-compiles gfx950 without a GPU.
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+# -ffp-contract=off: the decode path must round exactly like the CPU oracle (no FMA contraction)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
+CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
+SRC     = augustus_amd/csrc
+HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc
+DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/layout.h
+
+all: product oracle emu
+product: augustus_amd/libaugx.so augustus_amd/bin/augustus
+
+augustus_amd/libaugx.so: $(HOSTSRC) $(SRC)/device/decoder.hip $(DEVHDR) $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HOSTSRC) $(SRC)/device/decoder.hip
+
+augustus_amd/bin/augustus: $(SRC)/augustus_main.cc augustus_amd/libaugx.so
+	@mkdir -p augustus_amd/bin
+	$(HIPCC) -O2 -o $@ $(SRC)/augustus_main.cc -Laugustus_amd -laugx -Wl,-rpath,'$$ORIGIN/..'
+
+# ---- test infrastructure (never linked into the product) ----
+oracle: oracle/libghmm_twin.so
+oracle/libghmm_twin.so: oracle/ghmm_twin.cc include/augx.h
+	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/ghmm_twin.cc
+
+emu: build/libaugx_emu.so
+build/libaugx_emu.so: tests/emu/emu.cc $(DEVHDR)
+	@mkdir -p build
+	$(CXX) $(CXXFLAGS) -shared -o $@ tests/emu/emu.cc
+
+ref:
+	$(MAKE) -C oracle -j8
+
+clean:
+	rm -rf build augustus_amd/libaugx.so augustus_amd/bin oracle/libghmm_twin.so
+.PHONY: all product oracle emu ref clean

@@ -1,6 +1,7 @@
 // genes.cc -- see genes.h
 #include "genes.h"
 #include <algorithm>
+#include <cstdarg>
 #include <cstdio>
 #include <cstring>
 

@@ -168,6 +168,11 @@ void augx_batch_destroy(augx_batch *b);
  *      GFF on `out_fd`, diagnostics on `err_fd`; returns the process exit code ---- */
 int augx_main(int argc, const char *const *argv);
 
+/* ---- gene-structure + GFF stage on its own (replaces StatePath::projectOntoGeneSequence + filterGenePrediction +
+ *      printGeneList, reference src/gene.cc:394-700,2465-2524,3071-3120) for one record decoded as one piece ---- */
+int augx_format_gff(const augx_model *m, const char *name, const char *seq, int64_t len, const augx_state *states,
+                    int n_states, int first_gene_id, char *out, int64_t out_cap, int *n_genes);
+
 const char *augx_last_error(void);
 const char *augx_version(void);
 
