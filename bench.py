@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbp of DNA decoded per second (BASELINE.json metric), ab-initio human model, on N MI355X.
+
+One "step" = one pass of the hot path (prep -> trellis -> back-trace, all on the GPU) over one batch of synthetic
+input that is already resident in HBM: BASELINE.json configs[2], 100 contigs x 1 Mbp of upper-case uniform-random
+DNA per GPU (weak scaling: every rank decodes its own 100 contigs; contigs are independent, there is no data-path
+collective).  Launch:  python bench.py [--gpus N --steps K --warmup W]   (N>1 via torch.distributed.run).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def synth_contigs(n_contigs, length, seed0):
+    out = []
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(n_contigs):
+        rng = np.random.default_rng(seed0 + i)
+        out.append(lut[rng.integers(0, 4, size=length, dtype=np.uint8)].tobytes())
+    return out
+
+
+def cpu_baseline(cfg, sample_bp):
+    """The reference's own CPU path (oracle/_ref/augustus_ref, 1 thread) on a bounded sample of the same workload."""
+    from helpers import REF_AUGUSTUS, write_fasta, twin_decode
+    import tempfile
+    seq = synth_contigs(1, sample_bp, 999)[0].decode()
+    if os.path.exists(REF_AUGUSTUS):
+        with tempfile.TemporaryDirectory() as d:
+            fa = os.path.join(d, "s.fa")
+            write_fasta(fa, [("sample", seq)])
+            env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg)
+            t0 = time.time()
+            r = subprocess.run([REF_AUGUSTUS, "--species=human", fa], capture_output=True, env=env)
+            dt = time.time() - t0
+            if r.returncode == 0:
+                return {"value": sample_bp / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "reference",
+                        "sample": "1 contig x %d bp uniform-random DNA, --species=human, reference binary wall-clock incl. parameter load" % sample_bp}
+    import augustus_amd as ax
+    m = ax.Model(cfg, "human")
+    t0 = time.time()
+    twin_decode(m.tables_ptr, seq, m.n_states)
+    dt = time.time() - t0
+    return {"value": sample_bp / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
+            "sample": "1 contig x %d bp uniform-random DNA, oracle/ghmm_twin.cc" % sample_bp}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--contigs", type=int, default=100)
+    ap.add_argument("--contig-len", type=int, default=1000000)
+    ap.add_argument("--cpu-sample-bp", type=int, default=300000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the decode path has no CPU fallback)")
+    torch.cuda.set_device(local)
+
+    import augustus_amd as ax
+    from helpers import config_path
+    cfg = config_path()
+    model = ax.Model(cfg, "human")
+    dec = ax.Decoder(model, local)
+    S = model.n_states
+    seqs = synth_contigs(a.contigs, a.contig_len, 12345 + 1000 * rank)
+    batch = ax.Batch(dec, seqs)          # H2D upload: inputs are resident in HBM before the timed region
+    bases = a.contigs * a.contig_len
+
+    def sync():
+        dec_sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def dec_sync():
+        ax._check(ax.lib().augx_batch_sync(dec._h))
+
+    for _ in range(a.warmup):
+        batch.decode(sync=True)
+    sync()
+    t0 = time.perf_counter()
+    trellis_ms, prep_ms, back_ms = [], [], []
+    for _ in range(a.steps):
+        batch.decode(sync=False)
+        k = batch.kernel_ms()            # HIP events on the decoder's stream (also waits for the step)
+        trellis_ms.append(k["trellis_ms"]); prep_ms.append(k["prep_ms"]); back_ms.append(k["backtrace_ms"])
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # sanity: the decode produced feasible paths
+    res = batch.paths()
+    assert all(r.status == 0 for r in res), "decode failed"
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * bases * a.steps / dt / 1e6
+        # roofline of the dominant kernel (trellis): algorithmic bytes per bp = 0.25 + 20*S (SURVEY.md 8d / DESIGN.md)
+        alg_bytes = (0.25 + 20.0 * S) * bases
+        tr_s = float(np.mean(trellis_ms)) / 1e3
+        achieved = alg_bytes / tr_s / 1e9
+        out = {
+            "metric": "Mbp DNA decoded/sec (whole node), ab-initio human model",
+            "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic uniform-random DNA, %d contigs x %d bp per GPU, --species=human ab initio (47 states, sample=0)"
+                                   % (a.contigs, a.contig_len), "pieces_in_flight_per_gpu": a.contigs,
+                       "sharding": "contigs sharded over ranks, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                         "traffic": None, "kernel": "kTrellis", "kernel_ms": float(np.mean(trellis_ms)),
+                         "prep_ms": float(np.mean(prep_ms)), "backtrace_ms": float(np.mean(back_ms)),
+                         "positions_per_s_per_piece": a.contig_len / tr_s},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample_bp)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

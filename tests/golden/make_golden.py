@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Regenerates the golden vectors under tests/golden/ from the REAL reference (oracle/_ref, built by
+oracle/Makefile from /root/reference).  Run in the build container:  python tests/golden/make_golden.py
+
+Outputs
+  inputs.fa                 the fixed test inputs (examples/example.fa records + seeded synthetic/edge records)
+  golden_paths_<cfg>.json   per record: ln Viterbi score (%.17g) and the raw state path, from oracle/_ref/ref_harness
+  golden_<cfg>.gff          the reference binary's GFF for the same inputs (prediction part only)
+for cfg in {human, human_nosm, fly}.
+"""
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from helpers import *  # noqa
+
+CFGS = {
+    "human": ("human", []),
+    "human_nosm": ("human", ["--softmasking=0"]),
+    "fly": ("fly", ["--UTR=off", "--sample=0", "--softmasking=0"]),
+}
+
+
+def build_inputs():
+    recs = read_fasta("/root/reference/examples/example.fa")
+    ex = recs[0][1]
+    s = list(random_dna(40000, 5))
+    for st, ln in [(1000, 50), (5000, 1), (5003, 2), (9000, 700), (20000, 3000), (39990, 10)]:
+        for i in range(st, st + ln):
+            s[i] = "N"
+    recs += [
+        ("rand60k", random_dna(60000, 12345)),
+        ("rand20k_b", random_dna(20000, 777)),
+        ("withN", "".join(s)),
+        ("allN", "N" * 3000),
+        ("short7", random_dna(7, 3)),
+        ("short100", random_dna(100, 4)),
+        ("short600", random_dna(600, 6)),
+        ("iupac", random_dna(3000, 8) + "RYKMSW" + random_dna(3000, 9)),
+        ("trunc_left", ex[1500:6000]),
+        ("trunc_right", ex[500:4400]),
+        ("trunc_both", ex[2000:5300]),
+        ("revcomp", ex[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))),
+    ]
+    return recs
+
+
+def main():
+    recs = build_inputs()
+    fa = os.path.join(HERE, "inputs.fa")
+    write_fasta(fa, recs)
+    for cfg, (species, extra) in CFGS.items():
+        res, err = ref_harness(fa, species, extra, cfg="/root/reference/config/")
+        assert len(res) == len(recs), (cfg, err)
+        out = {"species": species, "extra": extra,
+               "records": [{"name": r["name"], "n": r["n"], "lnv": repr(r["lnv"]), "path": r["path"]} for r in res]}
+        json.dump(out, open(os.path.join(HERE, "golden_paths_%s.json" % cfg), "w"))
+        env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
+        txt = subprocess.run([REF_AUGUSTUS, "--species=" + species] + extra + [fa], capture_output=True, text=True, env=env)
+        assert txt.returncode == 0 and txt.stderr == "", txt.stderr
+        lines = txt.stdout.splitlines()
+        i0 = [k for k, l in enumerate(lines) if l.startswith("# ----- prediction")][0]
+        body = [l for l in lines[i0:] if not l.startswith("# command line")][:-1]
+        open(os.path.join(HERE, "golden_%s.gff" % cfg), "w").write("\n".join(body) + "\n")
+        print(cfg, len(res), "records", len(body), "gff lines")
+
+
+if __name__ == "__main__":
+    main()

@@ -117,3 +117,101 @@ def ref_harness(fasta, species, extra=(), cells_file=None, cfg=None):
         elif w[0] == "END":
             res.append(cur)
     return res, out.stderr
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors (tests/golden/make_golden.py) and the lane-loop emulator of the device kernels
+# ---------------------------------------------------------------------------------------------------
+import json
+
+GOLDEN_CFGS = {
+    "human": ("human", {}),
+    "human_nosm": ("human", {"softmasking": "0"}),
+    "fly": ("fly", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+}
+
+
+def golden_inputs():
+    return read_fasta(os.path.join(GOLDEN, "inputs.fa"))
+
+
+def golden_paths(cfg):
+    g = json.load(open(os.path.join(GOLDEN, "golden_paths_%s.json" % cfg)))
+    for r in g["records"]:
+        r["lnv"] = float(r["lnv"])
+        r["path"] = [tuple(p) for p in r["path"]]
+    return g
+
+
+def golden_gff(cfg):
+    return open(os.path.join(GOLDEN, "golden_%s.gff" % cfg)).read().splitlines()
+
+
+class _Piece(ctypes.Structure):
+    _fields_ = [("seq", ctypes.c_char_p), ("len", ctypes.c_int64), ("init_kind", ctypes.c_int32), ("term_kind", ctypes.c_int32)]
+
+
+_emu = None
+
+
+def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0):
+    """Run the device kernel bodies on the CPU (tests/emu/emu.cc).  Returns [(status, lnv, path, V, cls)]."""
+    global _emu
+    if _emu is None:
+        _emu = ctypes.CDLL(EMU_LIB)
+    n = len(seqs)
+    P = (_Piece * n)()
+    keep = [s.encode() if isinstance(s, str) else s for s in seqs]
+    for i, b in enumerate(keep):
+        P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = b, len(b), init_kind, term_kind
+    lnv = np.zeros(n)
+    st = np.zeros(n, dtype=np.int32)
+    cap = max(1024, max(len(s) for s in seqs) // 4 + 16)
+    po = np.zeros((n, cap, 3), dtype=np.int32)
+    pn = np.zeros(n, dtype=np.int32)
+    cls = np.zeros(n, dtype=np.int32)
+    tot = sum(len(s) for s in seqs)
+    C = np.zeros(tot * S) if cells else None
+    rc = _emu.emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
+                         po.ctypes.data_as(ctypes.c_void_p), cap, pn.ctypes.data_as(ctypes.c_void_p),
+                         C.ctypes.data_as(ctypes.c_void_p) if cells else None, cls.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    out, w = [], 0
+    for i, s in enumerate(seqs):
+        V = C[w:w + len(s) * S].reshape(len(s), S) if cells else None
+        w += len(s) * S
+        out.append((int(st[i]), float(lnv[i]), [tuple(int(x) for x in po[i, k]) for k in range(pn[i])], V, int(cls[i])))
+    return out
+
+
+def format_gff(model, recs, paths):
+    """GFF text of the product's gene-structure stage for externally supplied paths (augx_format_gff)."""
+    import augustus_amd as ax
+    L = ax.lib()
+    L.augx_format_gff.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p,
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int)]
+    out, gid = [], 1
+    for k, ((name, seq), path) in enumerate(zip(recs, paths)):
+        sts = (_St * max(1, len(path)))()
+        for i, (b, e, s, t) in enumerate(path):
+            sts[i].begin, sts[i].end, sts[i].state, sts[i].type = b, e, s, t
+        buf = ctypes.create_string_buffer(16 << 20)
+        ng = ctypes.c_int()
+        rc = L.augx_format_gff(model._h, name.encode(), seq.encode(), len(seq), sts, len(path), gid, buf, 16 << 20, ctypes.byref(ng))
+        assert rc == 0, L.augx_last_error()
+        out.append("# ----- prediction on sequence number %d (length = %d, name = %s) -----" % (k + 1, len(seq), name))
+        out.append("#")
+        out.append("# Predicted genes for sequence number %d on both strands" % (k + 1))
+        out += buf.value.decode().splitlines()
+        if ng.value == 0:
+            out.append("# (none)")
+        gid += ng.value
+        out.append("#")
+    return out[:-1]
+
+
+def gff_body(stdout_text):
+    """Prediction part of an augustus stdout, as the reference's own test filter does (tests/short/utils/aug_out_filter.py)."""
+    lines = stdout_text.splitlines()
+    i0 = [k for k, l in enumerate(lines) if l.startswith("# ----- prediction")][0]
+    return [l for l in lines[i0:] if not l.startswith("# command line")][:-1]

@@ -1,0 +1,43 @@
+"""C-ABI: libaugx.so loads, exports every symbol include/augx.h declares, loads models, and refuses to decode
+without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import augustus_amd as ax
+from helpers import *
+
+
+def test_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "augx.h")).read()
+    names = set(re.findall(r"\b(augx_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 18
+    L = ax.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), n
+
+
+def test_model_tables_human():
+    m = ax.Model(config_path(), "human")
+    assert m.n_states == 47
+    assert m.option("maxDNAPieceSize") == "2000000"
+
+
+def test_unsupported_features_fail_loudly():
+    for opts in ({"UTR": "on"}, {"singlestrand": "true"}, {"hintsfile": "x.gff"}, {"genemodel": "bacterium"}):
+        with pytest.raises(ax.AugxError) as e:
+            ax.Model(config_path(), "human", **opts)
+        assert e.value.code == ax.AUGX_E_UNSUPPORTED
+    with pytest.raises(ax.AugxError):
+        ax.Model(config_path(), "no_such_species")
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
+def test_no_cpu_fallback():
+    m = ax.Model(config_path(), "human")
+    with pytest.raises(ax.AugxError) as e:
+        ax.Decoder(m, 0)
+    assert e.value.code == ax.AUGX_E_NODEVICE
