@@ -15,14 +15,23 @@ namespace dev {
 #ifdef AUGX_EMU
 #define FOR_LANES(l) for (int l = 0; l < WAVE; ++l)
 #define LV(T, name) T name[WAVE]
+#define LV2(T, name, K) T name[K][WAVE]
+#define LI l
 #define LX(name) name[l]
 #define WAVE_SYNC() ((void)0)
+#define GLOBAL_SYNC() ((void)0)
 #define AUGX_KFN inline
 #else
 #define FOR_LANES(l) for (int l = (int)threadIdx.x, _once = 1; _once; _once = 0)
 #define LV(T, name) T name[1]
+#define LV2(T, name, K) T name[K][1]
+#define LI 0
 #define LX(name) name[0]
-#define WAVE_SYNC() __syncthreads()
+// One wavefront per workgroup: LDS instructions of a wave execute in issue order, so cross-lane LDS hand-offs only
+// need the compiler not to reorder (and the LDS queue drained); no s_barrier and no wait for global stores.
+#define WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
+// before re-reading global data this wave stored earlier (candidate lists, igenic column): drain the store queue
+#define GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define AUGX_KFN __device__ inline
 #endif
 
@@ -247,6 +256,15 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
 // =================================================================================================
 // K2  trellis: one wavefront per piece
 // =================================================================================================
+struct VarDesc {
+    int kind, win, nList, extra, total, listSel; // listSel: 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
+    int64_t i1;                                   // one past the newest list entry (piece-local index)
+    int eob, right, fOR, startMin;                // exon geometry
+    int eobi, cod0, cod1, cod2;                   // short intron: end of the biological intron, spliced-codon bases
+    double endP;
+    ExGeom g;
+};
+
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
     double longRing[6][LONG_RING];  // states consumed at lag dStateLen: rows 0..2 longdss_f, 3..5 rlongass_f
@@ -254,7 +272,10 @@ struct TrellisLds {
     uint64_t gate[WAVE];
     int32_t site[WAVE][NSITE];
     uint16_t bp[WAVE][SP];
-    double red_v[WAVE];             // scratch
+    VarDesc desc[SP];               // descriptors of the gated variable-length states of the current base
+    int itemBase[SP + 1];           // first item of each gated state (in gate-bit order); [SP] = total
+    double itVal[WAVE];             // one chunk of evaluated items
+    int itKey[WAVE], itAux[WAVE], itState[WAVE];
 };
 
 AUGX_HD int longRow(const DevTables &T, int s) {
@@ -289,182 +310,159 @@ struct TrellisCtx {
     }
 };
 
-// one variable-length state s ending at base j; all 64 lanes cooperate.  Returns the best (value, pred, eop).
-// The formulas are those of the reference loops (exon: src/exonmodel.cc:1059-1132; lessD: src/intronmodel.cc:585-629)
-AUGX_KFN void trellisVarState(TrellisCtx &X, int s, int j, double *outV, uint16_t *outBp) {
+// -------------------------------------------------------------------------------------------------
+// variable-length states (coding exons, short introns) whose end gate is open at base j.
+// All gated states of a position are evaluated together: one lane per state builds a descriptor (candidate
+// range + end-side constants), then all (state, candidate) items are spread over the 64 lanes, and finally one
+// lane per state reduces its items.  The formulas are those of the reference loops
+// (exon: src/exonmodel.cc:1059-1132; lessD: src/intronmodel.cc:585-629); the tie-break "larger key wins" is
+// the reference's descending loop with strict '>'.
+// -------------------------------------------------------------------------------------------------
+
+AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
     const DevTables &T = X.T;
-    const BatchView &B = X.B;
     const Piece &P = X.P;
-    const int kind = T.kind[s], win = T.win[s], c = X.c, n = X.n;
-    LV(double, bv);
-    LV(int, bkey);
-    LV(int, baux);
-    FOR_LANES(l) { LX(bv) = AUGX_NINF; LX(bkey) = -2147483647; LX(baux) = -1; }
+    const int kind = T.kind[s], win = T.win[s], n = X.n;
+    D.kind = kind; D.win = win; D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
+    D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cod0 = D.cod1 = D.cod2 = 4; D.endP = AUGX_NINF;
+    D.g = exGeom(T, AUGX_K_INTERNAL);
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
         const int eobi = fwd ? j + T.U + T.As + 2 : j + T.De + 2;
         const bool haveRight = eobi < n - 2;
-        int cod[3] = {4, 4, 4};
+        D.eobi = eobi;
         if (fwd) {
-            if (f == 1) { cod[1] = haveRight ? P.b(eobi + 1) : 4; cod[2] = haveRight ? P.b(eobi + 2) : 4; }
-            if (f == 2) { cod[2] = haveRight ? P.b(eobi + 1) : 4; }
+            if (f == 1) { D.cod1 = haveRight ? P.b(eobi + 1) : 4; D.cod2 = haveRight ? P.b(eobi + 2) : 4; }
+            if (f == 2) { D.cod2 = haveRight ? P.b(eobi + 1) : 4; }
         } else {
-            if (f == 0) cod[0] = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
+            if (f == 0) D.cod0 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
             if (f == 1) {
-                cod[0] = (haveRight && P.b(eobi + 2) <= 3) ? 3 - P.b(eobi + 2) : 4;
-                cod[1] = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
+                D.cod0 = (haveRight && P.b(eobi + 2) <= 3) ? 3 - P.b(eobi + 2) : 4;
+                D.cod1 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
             }
         }
         int left = j - T.dStateLen;
         if (left < 0) left = 0;
         const int fld = fwd ? CNT_LD : CNT_RD;
-        const int32_t *lpos = fwd ? B.ldPos : B.rdPos;
-        const double *lval = fwd ? B.ldVal : B.rdVal;
-        const int64_t i0 = (int64_t)X.cntAt(left - 1, fld), i1 = (int64_t)X.cntAt(j - 1, fld); // list indices [i0, i1)
-        const int a = T.anc[s][0]; // single ancestor (longdss_f / rlongass_f)
-        const double tr = lnT(T, c, a, s);
-        // candidate eop = 0 reads column 0 (initial probabilities); it is not a splice site, so not in the list
-        const int extra = (left == 0) ? 1 : 0;
-        const int64_t total = (i1 - i0) + extra;
-        for (int64_t base = 0; base < total; base += WAVE) {
-            FOR_LANES(l) {
-                int64_t idx = base + l;
-                if (idx < total) {
-                    int eop;
-                    double pv;
-                    if (idx < i1 - i0) {
-                        int64_t li = X.lo + (i1 - 1 - idx); // descending eop
-                        eop = lpos[li];
-                        pv = lval[li * 3 + f];
-                    } else {
-                        eop = 0;
-                        pv = (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF);
-                    }
-                    if (pv > AUGX_NINF) {
-                        int begin = eop + 1;
-                        int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
-                        bool ok = !(bobi >= 0 && !(fwd ? P.possDSS(bobi) : P.possRASS(bobi)));
-                        bool spliced = fwd ? (f != 0) : (f != 2);
-                        if (ok && spliced && bobi > 1) {
-                            int c0 = cod[0], c1 = cod[1], c2 = cod[2];
-                            if (fwd) {
-                                if (f == 1) c0 = P.b(bobi - 1);
-                                else { c0 = P.b(bobi - 2); c1 = P.b(bobi - 1); }
-                            } else {
-                                if (f == 0) { c1 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4; c2 = P.b(bobi - 2) <= 3 ? 3 - P.b(bobi - 2) : 4; }
-                                else c2 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4;
-                            }
-                            if (stopCodon3(c0, c1, c2)) ok = false;
-                        }
-                        int intronLength = eobi - bobi + 1;
-                        if (ok && intronLength <= T.d) {
-                            double restSeq = P.seg(fwd ? FX_INF : FX_INR, begin, j);
-                            double emi = T.len_intron[intronLength] + restSeq;
-                            if (emi > AUGX_NINF) {
-                                double val = pv + (tr + emi);
-                                if (better(val, eop, LX(bv), LX(bkey))) { LX(bv) = val; LX(bkey) = eop; LX(baux) = 0; }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    } else {
-        const ExGeom g = exGeom(T, kind);
-        const ExEnd e = exEnd(P, kind, win, j, g);
-        const double endP = exEndPart(P, kind, win, j, X.L.sig[j & 63][SIG_TISR]);
-        const bool fromIgenic = kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL || kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL;
-        if (endP > AUGX_NINF && e.right >= 0 && e.startMax >= e.startMin) {
-            if (fromIgenic) {
-                const int a = T.anc[s][0];
-                const double tr = lnT(T, c, a, s);
-                int64_t i0 = 0, total;
-                const bool viaAtg = kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL;
-                if (viaAtg) { // start codons with bob in [startMin-3, startMax-3]
-                    i0 = (int64_t)X.cntAt(e.startMin - 3 - 1, CNT_ATG);
-                    total = (int64_t)X.cntAt(e.startMax - 3, CNT_ATG) - i0;
-                } else
-                    total = 1; // single candidate bs = ORFleft+2 (src/exonmodel.cc:1044-1045)
-                for (int64_t base = 0; base < total; base += WAVE) {
-                    FOR_LANES(l) {
-                        int64_t idx = base + l;
-                        if (idx < total) {
-                            int bs;
-                            double tisF = AUGX_NINF;
-                            if (viaAtg) {
-                                int bob = B.atgPos[X.lo + i0 + (total - 1 - idx)];
-                                bs = bob + 3;
-                                tisF = P.sig[(int64_t)bob * NSIG + SIG_TISF];
-                            } else
-                                bs = e.startMin;
-                            int eop = bs - g.bpl - 1;
-                            // eop == j reads the igenic cell of the CURRENT column (already final: the reference
-                                // fills states in index order and igenic is state 0); later columns do not exist yet
-                                if (eop < n && eop <= j) {
-                                double pv = eop == j ? X.L.ring[j & 63][a] : B.vig[X.o + 1 + (eop >= 0 ? eop : 0)];
-                                if (eop <= 0) pv = (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF);
-                                if (pv > AUGX_NINF) {
-                                    double nep = exNotEndPart(P, kind, win, bs, e.right, e.fOR, g, tisF);
-                                    if (nep > AUGX_NINF) {
-                                        double te = (tr + endP) + nep;
-                                        double val = pv + te;
-                                        if (better(val, bs, LX(bv), LX(bkey))) { LX(bv) = val; LX(bkey) = bs; LX(baux) = 0; }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            } else {
-                // predecessors are the three longass_f (forward) or rlongdss_f (reverse) states, listed per splice site
-                const bool fwd = g.fwd;
-                const int fld = fwd ? CNT_LA : CNT_LR;
-                const int32_t *lpos = fwd ? B.laPos : B.lrPos;
-                const double *lval = fwd ? B.laVal : B.lrVal;
-                // eop = bs - 1 in [startMin-1, startMax-1]
-                const int64_t i0 = (int64_t)X.cntAt(e.startMin - 2, fld), i1 = (int64_t)X.cntAt(e.startMax - 1, fld);
-                const int extra = (e.startMin == 0) ? 1 : 0; // bs = 0: left-truncated exon, predecessor column 0
-                const int64_t total = (i1 - i0) + extra;
-                for (int64_t base = 0; base < total; base += WAVE) {
-                    FOR_LANES(l) {
-                        int64_t idx = base + l;
-                        if (idx < total) {
-                            int eop;
-                            int64_t li = -1;
-                            if (idx < i1 - i0) { li = X.lo + (i1 - 1 - idx); eop = lpos[li]; }
-                            else eop = -1;
-                            int bs = eop + 1;
-                            double nep = exNotEndPart(P, kind, win, bs, e.right, e.fOR, g, AUGX_NINF);
-                            if (nep > AUGX_NINF) {
-                                int bob = bs - g.ipo, len = e.eob - bob + 1;
-                                for (int ai = 0; ai < T.n_anc[s]; ai++) {
-                                    int a = T.anc[s][ai];
-                                    bool ok = win == mod3(fwd ? T.win[a] + len : T.win[a] - len);
-                                    if (!ok) continue;
-                                    double pv = li >= 0 ? lval[li * 3 + T.win[a]]
-                                                        : ((B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF));
-                                    if (!(pv > AUGX_NINF)) continue;
-                                    double te = (lnT(T, c, a, s) + endP) + nep;
-                                    double val = pv + te;
-                                    if (better(val, bs, LX(bv), LX(bkey))) { LX(bv) = val; LX(bkey) = bs; LX(baux) = ai; }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
+        const int64_t i0 = (int64_t)X.cntAt(left - 1, fld);
+        D.i1 = (int64_t)X.cntAt(j - 1, fld);
+        D.listSel = fwd ? 2 : 3;
+        D.nList = (int)(D.i1 - i0);
+        D.extra = left == 0 ? 1 : 0; // eop = 0 reads column 0 (initial probabilities); not a splice site, so not listed
+        D.total = D.nList + D.extra;
+        D.endP = 0.0;
+        return;
     }
-    Best b = waveArgMax(bv, bkey, baux);
-    *outV = b.v;
-    if (b.v > AUGX_NINF) {
+    D.g = exGeom(T, kind);
+    const ExEnd e = exEnd(P, kind, win, j, D.g);
+    D.eob = e.eob; D.right = e.right; D.fOR = e.fOR; D.startMin = e.startMin;
+    D.endP = exEndPart(P, kind, win, j, X.L.sig[j & 63][SIG_TISR]);
+    if (!(D.endP > AUGX_NINF) || e.right < 0 || e.startMax < e.startMin) return;
+    if (kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL) { // start codons with bob in [startMin-3, startMax-3]
+        const int64_t i0 = (int64_t)X.cntAt(e.startMin - 3 - 1, CNT_ATG);
+        D.i1 = (int64_t)X.cntAt(e.startMax - 3, CNT_ATG);
+        D.listSel = 4;
+        D.nList = (int)(D.i1 - i0);
+    } else if (kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) {
+        D.listSel = 5; // single candidate bs = ORFleft+2 (src/exonmodel.cc:1044-1045)
+        D.nList = 1;
+    } else {
+        const int fld = D.g.fwd ? CNT_LA : CNT_LR; // eop = bs - 1 in [startMin-1, startMax-1]
+        const int64_t i0 = (int64_t)X.cntAt(e.startMin - 2, fld);
+        D.i1 = (int64_t)X.cntAt(e.startMax - 1, fld);
+        D.listSel = D.g.fwd ? 0 : 1;
+        D.nList = (int)(D.i1 - i0);
+        D.extra = e.startMin == 0 ? 1 : 0; // bs = 0: left-truncated exon, predecessor column 0
+    }
+    D.total = D.nList + D.extra;
+}
+
+// candidate number idx (0 = newest) of the state described by D: value, tie-break key, predecessor index
+AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, int idx, double &val, int &key, int &aux) {
+    const DevTables &T = X.T;
+    const BatchView &B = X.B;
+    const Piece &P = X.P;
+    const int c = X.c, n = X.n, kind = D.kind, win = D.win;
+    val = AUGX_NINF; key = -2147483647; aux = -1;
+    auto col0 = [&](int a) { return (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF); };
+    if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
+        const bool fwd = kind == AUGX_K_LESSD;
+        const int f = win;
+        const int a = T.anc[s][0];
         int eop;
-        if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) eop = b.key;
-        else { ExGeom g = exGeom(T, kind); eop = b.key - g.bpl - 1; }
-        *outBp = bpVar(b.aux, j - eop);
-    } else
-        *outBp = BP_NONE;
+        double pv;
+        if (idx < D.nList) {
+            int64_t li = X.lo + (D.i1 - 1 - idx);
+            eop = (fwd ? B.ldPos : B.rdPos)[li];
+            pv = (fwd ? B.ldVal : B.rdVal)[li * 3 + f];
+        } else { eop = 0; pv = col0(a); }
+        if (!(pv > AUGX_NINF)) return;
+        int begin = eop + 1;
+        int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
+        if (bobi >= 0 && !(fwd ? P.possDSS(bobi) : P.possRASS(bobi))) return;
+        bool spliced = fwd ? (f != 0) : (f != 2);
+        if (spliced && bobi > 1) {
+            int c0 = D.cod0, c1 = D.cod1, c2 = D.cod2;
+            if (fwd) {
+                if (f == 1) c0 = P.b(bobi - 1);
+                else { c0 = P.b(bobi - 2); c1 = P.b(bobi - 1); }
+            } else {
+                if (f == 0) { c1 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4; c2 = P.b(bobi - 2) <= 3 ? 3 - P.b(bobi - 2) : 4; }
+                else c2 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4;
+            }
+            if (stopCodon3(c0, c1, c2)) return;
+        }
+        int intronLength = D.eobi - bobi + 1;
+        if (intronLength > T.d) return;
+        double restSeq = P.seg(fwd ? FX_INF : FX_INR, begin, j);
+        double emi = T.len_intron[intronLength] + restSeq;
+        if (!(emi > AUGX_NINF)) return;
+        val = pv + (lnT(T, c, a, s) + emi);
+        key = eop; aux = 0;
+        return;
+    }
+    if (D.listSel >= 4) { // predecessor is the igenic state
+        const int a = T.anc[s][0];
+        int bs;
+        double tisF = AUGX_NINF;
+        if (D.listSel == 4) {
+            int bob = B.atgPos[X.lo + (D.i1 - 1 - idx)];
+            bs = bob + 3;
+            tisF = P.sig[(int64_t)bob * NSIG + SIG_TISF];
+        } else
+            bs = D.startMin;
+        int eop = bs - D.g.bpl - 1;
+        // eop == j reads the igenic cell of the CURRENT column (already final: the reference fills states in index
+        // order and igenic is state 0); later columns do not exist yet
+        if (!(eop < n && eop <= j)) return;
+        double pv = eop == j ? X.L.ring[j & 63][a] : (eop <= 0 ? col0(a) : B.vig[X.o + 1 + eop]);
+        if (!(pv > AUGX_NINF)) return;
+        double nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
+        if (!(nep > AUGX_NINF)) return;
+        double te = (lnT(T, c, a, s) + D.endP) + nep;
+        val = pv + te;
+        key = bs; aux = 0;
+        return;
+    }
+    // predecessors are the three longass_f (forward) or rlongdss_f (reverse) states, listed per splice site
+    const bool fwd = D.g.fwd;
+    int eop;
+    int64_t li = -1;
+    if (idx < D.nList) { li = X.lo + (D.i1 - 1 - idx); eop = (fwd ? B.laPos : B.lrPos)[li]; }
+    else eop = -1;
+    int bs = eop + 1;
+    double nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
+    if (!(nep > AUGX_NINF)) return;
+    int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+    for (int ai = 0; ai < T.n_anc[s]; ai++) {
+        int a = T.anc[s][ai];
+        if (win != mod3(fwd ? T.win[a] + len : T.win[a] - len)) continue;
+        double pv = li >= 0 ? (fwd ? B.laVal : B.lrVal)[li * 3 + T.win[a]] : col0(a);
+        if (!(pv > AUGX_NINF)) continue;
+        double v2 = pv + ((lnT(T, c, a, s) + D.endP) + nep);
+        if (better(v2, bs, val, key)) { val = v2; key = bs; aux = ai; }
+    }
 }
 
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int p) {
@@ -514,6 +512,46 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
         }
     }
+    // ---- per-lane constants of the fixed-length states, hoisted out of the position loop (one GC class per piece)
+    LV(int, hLag);      // predecessor column lag, -1: not a fixed-length state
+    LV(int, hSig);      // index of the emission in the signal record
+    LV(int, hLong);     // predecessors are read from the long ring
+    LV(int, hNanc);
+    LV2(int, hAnc, 5);  // predecessor column index (state index, or long-ring row)
+    LV2(double, hTr, 5);
+    LV(int, hLrow);     // long-ring row this state is published to, -1 none
+    LV(int, hList);     // candidate list this state is published to (0 LA, 1 LR, 2 LD, 3 RD), -1 none
+    LV(int, hFrame);
+    LV(int, hIgenic);
+    FOR_LANES(l) {
+        LX(hLag) = -1; LX(hSig) = 0; LX(hLong) = 0; LX(hNanc) = 0; LX(hLrow) = -1; LX(hList) = -1; LX(hFrame) = 0; LX(hIgenic) = 0;
+        for (int i = 0; i < 5; i++) { hAnc[i][LI] = 0; hTr[i][LI] = AUGX_NINF; }
+        if (l < S && T.reachable[l]) {
+            const int kind = T.kind[l];
+            switch (kind) {
+            case AUGX_K_IGENIC: LX(hLag) = 1; LX(hSig) = SIG_EIG; break;
+            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: LX(hLag) = 1; LX(hSig) = SIG_EIN; break;
+            case AUGX_K_LONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSF; break;
+            case AUGX_K_RLONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSR; break;
+            case AUGX_K_LONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSF; break;
+            case AUGX_K_RLONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSR; break;
+            case AUGX_K_EQUALD: case AUGX_K_REQUALD: LX(hLag) = dL; LX(hSig) = SIG_EQD; LX(hLong) = dL >= WAVE; break;
+            default: break;
+            }
+            if (LX(hLag) > 0) {
+                LX(hNanc) = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
+                for (int ai = 0; ai < LX(hNanc); ai++) {
+                    int a = T.anc[l][ai];
+                    hAnc[ai][LI] = LX(hLong) ? longRow(T, a) : a;
+                    hTr[ai][LI] = lnT(T, c, a, l);
+                }
+            }
+            LX(hLrow) = longRow(T, l);
+            LX(hFrame) = T.win[l];
+            LX(hIgenic) = kind == AUGX_K_IGENIC;
+            LX(hList) = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
+        }
+    }
     WAVE_SYNC();
     for (int j0 = 0; j0 < n; j0 += WAVE) {
         // ---- load the tile of per-base records for bases j0..j0+63 (coalesced)
@@ -533,27 +571,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (l < SP) {
                     double best = AUGX_NINF;
                     uint16_t bp = BP_NONE;
-                    if (l < S && T.reachable[l]) {
-                        const int s = l, kind = T.kind[s];
-                        int lag = -1;
-                        double emi = AUGX_NINF;
-                        switch (kind) {
-                        case AUGX_K_IGENIC: lag = 1; emi = L.sig[col][SIG_EIG]; break;
-                        case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: lag = 1; emi = L.sig[col][SIG_EIN]; break;
-                        case AUGX_K_LONGDSS: lag = dssWhole; emi = L.sig[col][SIG_DSSF]; break;
-                        case AUGX_K_RLONGDSS: lag = dssWhole; emi = L.sig[col][SIG_DSSR]; break;
-                        case AUGX_K_LONGASS: lag = assLag; emi = L.sig[col][SIG_ASSF]; break;
-                        case AUGX_K_RLONGASS: lag = assLag; emi = L.sig[col][SIG_ASSR]; break;
-                        case AUGX_K_EQUALD: case AUGX_K_REQUALD: lag = dL; emi = L.sig[col][SIG_EQD]; break;
-                        default: break;
-                        }
-                        if (lag > 0 && j - lag >= 0 && emi > AUGX_NINF) {
-                            for (int ai = 0; ai < T.n_anc[s]; ai++) {
-                                int a = T.anc[s][ai];
-                                double pv = lag == dL && lag >= WAVE ? L.longRing[longRow(T, a)][(j - lag) & (LONG_RING - 1)]
-                                                                     : L.ring[(j - lag) & 63][a];
+                    const int lag = LX(hLag);
+                    if (lag > 0 && j - lag >= 0) {
+                        const double emi = L.sig[col][LX(hSig)];
+                        if (emi > AUGX_NINF) {
+                            const double *colp = LX(hLong) ? nullptr : &L.ring[(j - lag) & 63][0];
+                            const int lidx = (j - lag) & (LONG_RING - 1);
+                            for (int ai = 0; ai < LX(hNanc); ai++) {
+                                double pv = LX(hLong) ? L.longRing[hAnc[ai][LI]][lidx] : colp[hAnc[ai][LI]];
                                 if (!(pv > AUGX_NINF)) continue;
-                                double val = pv + (lnT(T, c, a, s) + emi);
+                                double val = pv + (hTr[ai][LI] + emi);
                                 if (val > best) { best = val; bp = bpFixed(ai); }
                             }
                         }
@@ -563,34 +590,82 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
             }
             WAVE_SYNC();
-            // ---- phase B: variable-length states whose end gate is open at j (wave-cooperative, one at a time)
-            uint64_t gate = L.gate[col];
-            while (gate) {
-                int s = 0;
-                { uint64_t gg = gate; while (!(gg & 1)) { gg >>= 1; s++; } }
-                gate &= gate - 1;
-                double v;
-                uint16_t bp;
-                trellisVarState(X, s, j, &v, &bp);
-                FOR_LANES(l) { if (l == 0) { L.ring[col][s] = v; L.bp[col][s] = bp; } }
+            // ---- phase B: variable-length states whose end gate is open at j, all together
+            const uint64_t gate = L.gate[col];
+            if (gate) {
+                GLOBAL_SYNC();
+                FOR_LANES(l) { // B1: one lane per gated state builds its descriptor
+                    if (l < SP && ((gate >> l) & 1)) varDescribe(X, l, j, L.desc[l]);
+                }
+                WAVE_SYNC();
+                int totalItems = 0;
+                FOR_LANES(l) { // B1b: item offsets (every lane computes the same prefix; cheap: <= 22 states)
+                    int acc = 0;
+                    for (int s2 = 0; s2 < S; s2++) {
+                        if (l == 0) L.itemBase[s2] = acc;
+                        if ((gate >> s2) & 1) acc += L.desc[s2].total;
+                    }
+                    if (l == 0) L.itemBase[SP] = acc;
+                    totalItems = acc;
+                }
+                WAVE_SYNC();
+                LV(double, rbv);
+                LV(int, rbk);
+                LV(int, rba);
+                FOR_LANES(l) { LX(rbv) = AUGX_NINF; LX(rbk) = -2147483647; LX(rba) = -1; }
+                for (int base = 0; base < totalItems; base += WAVE) {
+                    FOR_LANES(l) { // B2: evaluate one item per lane
+                        int it = base + l;
+                        L.itState[l] = -1;
+                        if (it < totalItems) {
+                            int s2 = 0;
+                            for (int q = 0; q < S; q++)
+                                if (((gate >> q) & 1) && L.itemBase[q] <= it) s2 = q;
+                            double v; int k2, a2;
+                            varEvalItem(X, s2, j, L.desc[s2], it - L.itemBase[s2], v, k2, a2);
+                            L.itVal[l] = v; L.itKey[l] = k2; L.itAux[l] = a2; L.itState[l] = s2;
+                        }
+                    }
+                    WAVE_SYNC();
+                    FOR_LANES(l) { // B3: the lane of each gated state folds the items of this chunk that belong to it
+                        if (l < SP && ((gate >> l) & 1)) {
+                            int lo2 = L.itemBase[l] - base, hi2 = lo2 + L.desc[l].total;
+                            if (lo2 < 0) lo2 = 0;
+                            if (hi2 > WAVE) hi2 = WAVE;
+                            for (int q = lo2; q < hi2; q++)
+                                if (better(L.itVal[q], L.itKey[q], LX(rbv), LX(rbk))) { LX(rbv) = L.itVal[q]; LX(rbk) = L.itKey[q]; LX(rba) = L.itAux[q]; }
+                        }
+                    }
+                    WAVE_SYNC();
+                }
+                FOR_LANES(l) {
+                    if (l < SP && ((gate >> l) & 1)) {
+                        uint16_t bp = BP_NONE;
+                        if (LX(rbv) > AUGX_NINF) {
+                            const int kind = L.desc[l].kind;
+                            int eop = (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) ? LX(rbk) : LX(rbk) - L.desc[l].g.bpl - 1;
+                            bp = bpVar(LX(rba), j - eop);
+                        }
+                        L.ring[col][l] = LX(rbv);
+                        L.bp[col][l] = bp;
+                    }
+                }
             }
             WAVE_SYNC();
             // ---- phase C: publish column j
             FOR_LANES(l) {
                 if (l < S) {
                     double v = L.ring[col][l];
-                    int lr = longRow(T, l);
-                    if (lr >= 0) L.longRing[lr][j & (LONG_RING - 1)] = v;
+                    if (LX(hLrow) >= 0) L.longRing[LX(hLrow)][j & (LONG_RING - 1)] = v;
                     if (B.cells) B.cells[(o + 1 + j) * S + l] = v;
-                    const int kind = T.kind[l], f = T.win[l];
-                    if (kind == AUGX_K_IGENIC) B.vig[o + 1 + j] = v;
-                    int si = -1;
-                    double *lval = nullptr;
-                    if (kind == AUGX_K_LONGASS) { si = L.site[col][0]; lval = B.laVal; }
-                    else if (kind == AUGX_K_RLONGDSS) { si = L.site[col][1]; lval = B.lrVal; }
-                    else if (kind == AUGX_K_LONGDSS) { si = L.site[col][2]; lval = B.ldVal; }
-                    else if (kind == AUGX_K_RLONGASS) { si = L.site[col][3]; lval = B.rdVal; }
-                    if (si >= 0) lval[(X.lo + si) * 3 + f] = v;
+                    if (LX(hIgenic)) B.vig[o + 1 + j] = v;
+                    if (LX(hList) >= 0) {
+                        int si = L.site[col][LX(hList)];
+                        if (si >= 0) {
+                            double *lval = LX(hList) == 0 ? B.laVal : LX(hList) == 1 ? B.lrVal : LX(hList) == 2 ? B.ldVal : B.rdVal;
+                            lval[(X.lo + si) * 3 + LX(hFrame)] = v;
+                        }
+                    }
                 }
             }
             WAVE_SYNC();
