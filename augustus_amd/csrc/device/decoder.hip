@@ -122,9 +122,9 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
     row[t * 4 + 3] = comb<MAX>(pre, v3);
 }
 
-__global__ void __launch_bounds__(64) kTrellis(const DevTables *T, BatchView B) {
+__global__ void __launch_bounds__(64) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
-    trellisPiece(*T, B, lds, blockIdx.x);
+    trellisPiece(*T, *B, lds, blockIdx.x);
 }
 __global__ void __launch_bounds__(64) kBacktrace(const DevTables *T, BatchView B) { backtracePiece(*T, B, blockIdx.x); }
 
@@ -145,6 +145,7 @@ struct augx_batch {
     augx_decoder *dec = nullptr;
     BatchLayout L;
     BatchView V;               // device pointers
+    BatchView *dV = nullptr;   // device copy of V (kernels with high register pressure take it by pointer)
     std::vector<void *> bufs;
     std::vector<const char *> hostSeq; // caller-owned sequences (used only by the GC-stairs fallback below)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
@@ -292,6 +293,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     BatchView &V = b->V;
     memset(&V, 0, sizeof V);
     V.nPieces = n; V.N = L.N; V.nChunks = L.nChunks;
+    { const char *df = getenv("AUGX_DBG_FLAGS"); V.dbgFlags = df ? atoi(df) : 0; }
     int rc = 0;
 #define DA(field, T, count) do { T *_p = nullptr; rc = devAlloc(b, &_p, (count)); if (rc) { augx_batch_destroy(b); return rc; } field = _p; } while (0)
     int64_t *dOff; int32_t *dLen, *dIk, *dTk, *dCp; char *dRaw;
@@ -326,6 +328,8 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     HIP_TRY(hipMemset(dRaw, 'n', (size_t)Z.N));
     for (int p = 0; p < n; p++)
         HIP_TRY(hipMemcpy(dRaw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p], hipMemcpyHostToDevice));
+    { void *pv = nullptr; HIP_TRY(hipMalloc(&pv, sizeof(BatchView))); b->bufs.push_back(pv); b->dV = (BatchView *)pv; }
+    HIP_TRY(hipMemcpy(b->dV, &V, sizeof(BatchView), hipMemcpyHostToDevice));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
     *out = b;
     return AUGX_OK;
@@ -363,7 +367,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], st));
-    hipLaunchKernelGGL(kTrellis, dim3(n), dim3(64), 0, st, d->dT, V);
+    hipLaunchKernelGGL(kTrellis, dim3(n), dim3(64), 0, st, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);

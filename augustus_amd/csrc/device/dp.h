@@ -16,7 +16,7 @@
 #define AUGX_HD inline
 #else
 #include <hip/hip_runtime.h>
-#define AUGX_HD __host__ __device__ inline
+#define AUGX_HD __host__ __device__ __forceinline__
 #endif
 
 namespace augx {
@@ -31,6 +31,7 @@ constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4
 constexpr int CHUNK = 1024;     // slots per scan chunk; every piece is padded to a multiple of CHUNK
 constexpr int LONG_RING = 1024; // ring depth for the states consumed at lag dStateLen (must exceed it)
 constexpr uint16_t BP_NONE = 0xFFFF;
+constexpr int CODE_WIN = 1024, NS_WIN = 128, CNT_WIN = 512, VIG_WIN = 512, LIST_WIN = 128; // LDS window sizes (powers of 2)
 
 #define AUGX_NINF (-INFINITY)
 
@@ -55,6 +56,7 @@ struct BatchView {
     int nPieces;
     int64_t N;                 // total slots
     int nChunks;
+    int dbgFlags;              // timing experiments only (AUGX_DBG_FLAGS): 1 skip phase B, 2 skip B2/B3, 4 skip phase C stores
     const int64_t *off;        // [nPieces+1]
     const int32_t *len;        // [nPieces]
     const int32_t *initKind, *termKind;
@@ -104,7 +106,15 @@ struct Piece {
     const uint64_t *fx;        // fx[fidx(o+1+q, f, NFX)] = prefix sum up to and including q
     const uint64_t *nsm;       // nsm[fidx(o+1+q, r, 6)]
     const double *sig;         // sig[q*NSIG + i]
-    AUGX_HD int b(int p) const { return (p >= 0 && p < n) ? code[p] : 4; }
+    // optional LDS windows (trellis kernel only): recent bases / stop tables are served from LDS, the rest from HBM
+    const uint8_t *wcode = nullptr;  // wcode[q & (CODE_WIN-1)] for q in [wcLo, wcHi)
+    int wcLo = 0, wcHi = 0;
+    const uint32_t *wns = nullptr;   // wns[(q & (NS_WIN-1))*6 + r] for q in [wnLo, wnHi)
+    int wnLo = 0, wnHi = 0;
+    AUGX_HD int b(int p) const {
+        if (p >= wcLo && p < wcHi) return wcode[p & (CODE_WIN - 1)];
+        return (p >= 0 && p < n) ? code[p] : 4;
+    }
     AUGX_HD bool is2(int p, int x, int y) const { return b(p) == x && b(p + 1) == y; }
     AUGX_HD int pat(int p, int len) const {
         int r = 0;
@@ -144,6 +154,7 @@ struct Piece {
     // nearest in-frame stop: reference OpenReadingFrame tables, src/exonmodel.cc:101-156
     AUGX_HD int nearestStop(int pos, bool fwd) const {
         if (n <= 5 && pos >= n - 2) return 0; // tables left unpatched by the reference for tiny inputs
+        if (pos >= wnLo && pos < wnHi) return (int)wns[(pos & (NS_WIN - 1)) * 6 + (fwd ? 0 : 3) + pos % 3] - 1;
         return (int)nsm[fidx(o + 1 + pos, (fwd ? 0 : 3) + pos % 3, 6)] - 1;
     }
     // reference OpenReadingFrame::leftmostExonBegin, src/exonmodel.cc:165-198

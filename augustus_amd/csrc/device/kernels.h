@@ -32,7 +32,7 @@ namespace dev {
 #define WAVE_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_wave_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
 // before re-reading global data this wave stored earlier (candidate lists, igenic column): drain the store queue
 #define GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
-#define AUGX_KFN __device__ inline
+#define AUGX_KFN __device__ __forceinline__
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -265,6 +265,31 @@ struct VarDesc {
     ExGeom g;
 };
 
+constexpr int BLK = 8;          // bases per block: smaller than every lag except the lag-1 chain states
+constexpr int MAXPAIR = WAVE;   // gated (base, state) pairs handled per round
+
+// wave-level bookkeeping primitives (device: cross-lane instructions; emulator: loops over the lane arrays)
+#ifdef AUGX_EMU
+inline void waveInclScan(int *v) { for (int l = 1; l < WAVE; l++) v[l] += v[l - 1]; }
+inline int waveRead(const int *v, int lane) { return v[lane]; }
+#else
+__device__ inline void waveInclScan(int *v) {
+    int x = v[0];
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
+    v[0] = x;
+}
+__device__ inline int waveRead(const int *v, int lane) { return __shfl(v[0], lane, 64); }
+#endif
+AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
+
+// per-state constants of the variable-length states (LDS copy: no table walks in the inner loops)
+struct VarConst {
+    int kind, win, nanc, anc[4], ancWin[4];
+    double tr[4];
+    ExGeom g;
+};
+
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
     double longRing[6][LONG_RING];  // states consumed at lag dStateLen: rows 0..2 longdss_f, 3..5 rlongass_f
@@ -272,10 +297,18 @@ struct TrellisLds {
     uint64_t gate[WAVE];
     int32_t site[WAVE][NSITE];
     uint16_t bp[WAVE][SP];
-    VarDesc desc[SP];               // descriptors of the gated variable-length states of the current base
-    int itemBase[SP + 1];           // first item of each gated state (in gate-bit order); [SP] = total
-    double itVal[WAVE];             // one chunk of evaluated items
-    int itKey[WAVE], itAux[WAVE], itState[WAVE];
+    // windows over recent bases (served from LDS; older data falls back to HBM)
+    uint8_t codew[CODE_WIN];
+    uint32_t nsw[NS_WIN * 6];
+    uint32_t cntw[CNT_WIN][5];      // site counts (ATG, LA, LR, LD, RD) at bases <= q
+    double vigw[VIG_WIN];           // igenic column
+    int32_t lcPos[4][LIST_WIN];     // newest LIST_WIN entries of the four splice-site candidate lists
+    double lcVal[4][LIST_WIN][3];
+    VarConst vc[SP];
+    VarDesc desc[MAXPAIR];          // descriptors of the gated (base, state) pairs of the current round
+    int pairJ[MAXPAIR], pairS[MAXPAIR];
+    double itVal[WAVE];             // one chunk of evaluated candidates
+    int itKey[WAVE], itAux[WAVE];
 };
 
 AUGX_HD int longRow(const DevTables &T, int s) {
@@ -297,35 +330,53 @@ struct TrellisCtx {
     int64_t o;      // slot offset of the piece
     int64_t lo;     // list offset
     int n, c, S;
+    int kwLo, kwHi; // cnt window
+    int vigLo;      // igenic ring holds bases > vigLo (and <= the newest chain base)
+    int listHi0, listHi1, listHi2, listHi3;  // newest published entry of each splice-site list (piece-local index), -1 none
+    AUGX_HD int listHi(int sel) const { return sel == 0 ? listHi0 : sel == 1 ? listHi1 : sel == 2 ? listHi2 : listHi3; }
     AUGX_HD TrellisCtx(const DevTables &t, const BatchView &b, TrellisLds &l, int pp) : T(t), B(b), L(l), p(pp) {
         P = makePiece(T, B, p);
         o = B.off[p];
         lo = listOff(B, p);
         n = P.n; c = P.c; S = T.S;
+        kwLo = kwHi = 0; vigLo = 0x7fffffff;
+        listHi0 = listHi1 = listHi2 = listHi3 = -1;
     }
     AUGX_HD uint64_t cntAt(int q, int f) const { // number of sites of field f at bases <= q (q may be -1)
         if (q < 0) return 0;
         if (q > n - 1) q = n - 1;
+        if (f >= CNT_ATG && q >= kwLo && q < kwHi) return L.cntw[q & (CNT_WIN - 1)][f - CNT_ATG];
         return B.cnt[fidx(o + 1 + q, f, NCNT)];
     }
+    AUGX_HD int listPos(int sel, int64_t li) const { // sel: 0 LA, 1 LR, 2 LD, 3 RD; li piece-local index
+        if (li <= listHi(sel) && li > listHi(sel) - LIST_WIN) return L.lcPos[sel][li & (LIST_WIN - 1)];
+        const int32_t *a = sel == 0 ? B.laPos : sel == 1 ? B.lrPos : sel == 2 ? B.ldPos : B.rdPos;
+        return a[lo + li];
+    }
+    AUGX_HD double listVal(int sel, int64_t li, int f) const {
+        if (li <= listHi(sel) && li > listHi(sel) - LIST_WIN) return L.lcVal[sel][li & (LIST_WIN - 1)][f];
+        const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+        return a[(lo + li) * 3 + f];
+    }
+    AUGX_HD double vigAt(int eop) const { return eop > vigLo ? L.vigw[eop & (VIG_WIN - 1)] : B.vig[o + 1 + eop]; }
 };
 
 // -------------------------------------------------------------------------------------------------
-// variable-length states (coding exons, short introns) whose end gate is open at base j.
-// All gated states of a position are evaluated together: one lane per state builds a descriptor (candidate
-// range + end-side constants), then all (state, candidate) items are spread over the 64 lanes, and finally one
-// lane per state reduces its items.  The formulas are those of the reference loops
+// variable-length states (coding exons, short introns) whose end gate is open.
+// All gated (base, state) pairs of a block are evaluated together: one lane per pair builds a descriptor
+// (candidate range + end-side constants), then all candidates are spread over the 64 lanes, and finally one
+// lane per pair reduces its candidates.  The formulas are those of the reference loops
 // (exon: src/exonmodel.cc:1059-1132; lessD: src/intronmodel.cc:585-629); the tie-break "larger key wins" is
 // the reference's descending loop with strict '>'.
 // -------------------------------------------------------------------------------------------------
-
 AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
     const DevTables &T = X.T;
     const Piece &P = X.P;
-    const int kind = T.kind[s], win = T.win[s], n = X.n;
+    const VarConst &VC = X.L.vc[s];
+    const int kind = VC.kind, win = VC.win, n = X.n;
     D.kind = kind; D.win = win; D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
     D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cod0 = D.cod1 = D.cod2 = 4; D.endP = AUGX_NINF;
-    D.g = exGeom(T, AUGX_K_INTERNAL);
+    D.g = VC.g;
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
@@ -354,7 +405,6 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
         D.endP = 0.0;
         return;
     }
-    D.g = exGeom(T, kind);
     const ExEnd e = exEnd(P, kind, win, j, D.g);
     D.eob = e.eob; D.right = e.right; D.fOR = e.fOR; D.startMin = e.startMin;
     D.endP = exEndPart(P, kind, win, j, X.L.sig[j & 63][SIG_TISR]);
@@ -383,19 +433,20 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
     const DevTables &T = X.T;
     const BatchView &B = X.B;
     const Piece &P = X.P;
-    const int c = X.c, n = X.n, kind = D.kind, win = D.win;
+    const VarConst &VC = X.L.vc[s];
+    const int n = X.n, kind = D.kind, win = D.win;
     val = AUGX_NINF; key = -2147483647; aux = -1;
     auto col0 = [&](int a) { return (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF); };
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
-        const int a = T.anc[s][0];
+        const int a = VC.anc[0];
         int eop;
         double pv;
         if (idx < D.nList) {
-            int64_t li = X.lo + (D.i1 - 1 - idx);
-            eop = (fwd ? B.ldPos : B.rdPos)[li];
-            pv = (fwd ? B.ldVal : B.rdVal)[li * 3 + f];
+            int64_t li = D.i1 - 1 - idx;
+            eop = X.listPos(D.listSel, li);
+            pv = X.listVal(D.listSel, li, f);
         } else { eop = 0; pv = col0(a); }
         if (!(pv > AUGX_NINF)) return;
         int begin = eop + 1;
@@ -418,12 +469,12 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         double restSeq = P.seg(fwd ? FX_INF : FX_INR, begin, j);
         double emi = T.len_intron[intronLength] + restSeq;
         if (!(emi > AUGX_NINF)) return;
-        val = pv + (lnT(T, c, a, s) + emi);
+        val = pv + (VC.tr[0] + emi);
         key = eop; aux = 0;
         return;
     }
     if (D.listSel >= 4) { // predecessor is the igenic state
-        const int a = T.anc[s][0];
+        const int a = VC.anc[0];
         int bs;
         double tisF = AUGX_NINF;
         if (D.listSel == 4) {
@@ -436,11 +487,11 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         // eop == j reads the igenic cell of the CURRENT column (already final: the reference fills states in index
         // order and igenic is state 0); later columns do not exist yet
         if (!(eop < n && eop <= j)) return;
-        double pv = eop == j ? X.L.ring[j & 63][a] : (eop <= 0 ? col0(a) : B.vig[X.o + 1 + eop]);
+        double pv = eop <= 0 ? col0(a) : X.vigAt(eop);
         if (!(pv > AUGX_NINF)) return;
         double nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
         if (!(nep > AUGX_NINF)) return;
-        double te = (lnT(T, c, a, s) + D.endP) + nep;
+        double te = (VC.tr[0] + D.endP) + nep;
         val = pv + te;
         key = bs; aux = 0;
         return;
@@ -449,19 +500,112 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
     const bool fwd = D.g.fwd;
     int eop;
     int64_t li = -1;
-    if (idx < D.nList) { li = X.lo + (D.i1 - 1 - idx); eop = (fwd ? B.laPos : B.lrPos)[li]; }
+    if (idx < D.nList) { li = D.i1 - 1 - idx; eop = X.listPos(D.listSel, li); }
     else eop = -1;
     int bs = eop + 1;
     double nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
     if (!(nep > AUGX_NINF)) return;
     int bob = bs - D.g.ipo, len = D.eob - bob + 1;
-    for (int ai = 0; ai < T.n_anc[s]; ai++) {
-        int a = T.anc[s][ai];
-        if (win != mod3(fwd ? T.win[a] + len : T.win[a] - len)) continue;
-        double pv = li >= 0 ? (fwd ? B.laVal : B.lrVal)[li * 3 + T.win[a]] : col0(a);
+    for (int ai = 0; ai < VC.nanc; ai++) {
+        if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
+        double pv = li >= 0 ? X.listVal(D.listSel, li, VC.ancWin[ai]) : col0(VC.anc[ai]);
         if (!(pv > AUGX_NINF)) continue;
-        double v2 = pv + ((lnT(T, c, a, s) + D.endP) + nep);
+        double v2 = pv + ((VC.tr[ai] + D.endP) + nep);
         if (better(v2, bs, val, key)) { val = v2; key = bs; aux = ai; }
+    }
+}
+
+// gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`
+AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask) {
+    const BatchView &B = X.B;
+    TrellisLds &L = X.L;
+    const int n = X.n, S = X.S;
+    uint64_t g[BLK];   // only ever indexed by fully unrolled loops: stays in registers
+    int off[BLK + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int dj = 0; dj < BLK; dj++) {
+        int j = jb + dj;
+        g[dj] = (j >= 1 && j < n) ? (L.gate[j & 63] & mask) : 0;
+        off[dj + 1] = off[dj] + popc64(g[dj]);
+    }
+    const int allPairs = off[BLK];
+    for (int done = 0; done < allPairs; done += MAXPAIR) {
+        const int nPairs = allPairs - done < MAXPAIR ? allPairs - done : MAXPAIR;
+        LV(int, pj);
+        LV(int, ps);
+        LV(int, tot);
+        FOR_LANES(l) { // one lane per pair: locate the pair, build its descriptor
+            LX(pj) = -1; LX(ps) = 0; LX(tot) = 0;
+            if (l < nPairs) {
+                int want = done + l, dj = 0, first = 0;
+                uint64_t gg = 0;
+#pragma unroll
+                for (int d2 = 0; d2 < BLK; d2++)
+                    if (off[d2] <= want && want < off[d2 + 1]) { dj = d2; gg = g[d2]; first = off[d2]; }
+                for (int k = want - first; k > 0; k--) gg &= gg - 1;
+                int s2 = 0;
+                while (!((gg >> s2) & 1)) s2++;
+                LX(pj) = jb + dj; LX(ps) = s2;
+                L.pairJ[l] = jb + dj; L.pairS[l] = s2;
+                varDescribe(X, s2, jb + dj, L.desc[l]);
+                LX(tot) = (B.dbgFlags & 2) ? 0 : L.desc[l].total;
+            }
+        }
+        WAVE_SYNC();
+        LV(int, ibase); // inclusive prefix of the candidate counts
+        FOR_LANES(l) { LX(ibase) = LX(tot); }
+        waveInclScan(ibase);
+        const int totalItems = waveRead(ibase, WAVE - 1);
+        LV(double, rbv);
+        LV(int, rbk);
+        LV(int, rba);
+        FOR_LANES(l) { LX(rbv) = AUGX_NINF; LX(rbk) = -2147483647; LX(rba) = -1; }
+        for (int base = 0; base < totalItems; base += WAVE) {
+            LV(int, myPair);
+            LV(int, myFirst);
+            FOR_LANES(l) { LX(myPair) = 0; LX(myFirst) = 0; }
+            for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
+                const int first = q == 0 ? 0 : waveRead(ibase, q - 1); // all lanes active here (cross-lane read)
+                FOR_LANES(l) { if (first <= base + l) { LX(myPair) = q; LX(myFirst) = first; } }
+            }
+            FOR_LANES(l) { // evaluate one candidate per lane
+                int it = base + l;
+                if (it < totalItems) {
+                    const int q = LX(myPair);
+                    const int first = LX(myFirst);
+                    double v; int k2, a2;
+                    varEvalItem(X, L.pairS[q], L.pairJ[q], L.desc[q], it - first, v, k2, a2);
+                    L.itVal[l] = v; L.itKey[l] = k2; L.itAux[l] = a2;
+                }
+            }
+            WAVE_SYNC();
+            FOR_LANES(l) { // the lane of each pair folds the candidates of this chunk that belong to it
+                if (l < nPairs) {
+                    int lo2 = (LX(ibase) - LX(tot)) - base, hi2 = LX(ibase) - base;
+                    if (lo2 < 0) lo2 = 0;
+                    if (hi2 > WAVE) hi2 = WAVE;
+                    for (int q = lo2; q < hi2; q++)
+                        if (better(L.itVal[q], L.itKey[q], LX(rbv), LX(rbk))) { LX(rbv) = L.itVal[q]; LX(rbk) = L.itKey[q]; LX(rba) = L.itAux[q]; }
+                }
+            }
+            WAVE_SYNC();
+        }
+        FOR_LANES(l) {
+            if (l < nPairs) {
+                const int j = LX(pj), s2 = LX(ps);
+                uint16_t bp = BP_NONE;
+                if (LX(rbv) > AUGX_NINF) {
+                    const int kind = L.vc[s2].kind;
+                    int eop = (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) ? LX(rbk) : LX(rbk) - L.vc[s2].g.bpl - 1;
+                    bp = bpVar(LX(rba), j - eop);
+                }
+                L.ring[j & 63][s2] = LX(rbv);
+                L.bp[j & 63][s2] = bp;
+                if (B.cells) B.cells[(X.o + 1 + j) * S + s2] = LX(rbv);
+            }
+        }
+        WAVE_SYNC();
     }
 }
 
@@ -497,50 +641,47 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             return;
         }
     }
-    // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
-    FOR_LANES(l) {
-        if (l < SP) {
-            double v = AUGX_NINF;
-            if (l < S) v = B.initKind[p] == 0 ? T.ln_init[l] : (l == T.synch ? 0.0 : AUGX_NINF);
-            L.ring[0][l] = v;
-            L.bp[0][l] = BP_NONE;
-            if (l < S) {
-                int lr = longRow(T, l);
-                if (lr >= 0) L.longRing[lr][0] = v;
-                if (B.cells) B.cells[(o + 1) * S + l] = v;
-                if (T.kind[l] == AUGX_K_IGENIC) B.vig[o + 1] = v;
-            }
-        }
-    }
-    // ---- per-lane constants of the fixed-length states, hoisted out of the position loop (one GC class per piece)
-    LV(int, hLag);      // predecessor column lag, -1: not a fixed-length state
-    LV(int, hSig);      // index of the emission in the signal record
-    LV(int, hLong);     // predecessors are read from the long ring
+    // ---- per-lane constants: lane l owns state l.  cls: 0 chain (lag 1), 1 fixed lag, 2 variable, 3 RTERMINAL, -1 off
+    LV(int, hCls);
+    LV(int, hLag);
+    LV(int, hSig);
+    LV(int, hLong);
     LV(int, hNanc);
-    LV2(int, hAnc, 5);  // predecessor column index (state index, or long-ring row)
+    LV2(int, hAnc, 5);
     LV2(double, hTr, 5);
-    LV(int, hLrow);     // long-ring row this state is published to, -1 none
-    LV(int, hList);     // candidate list this state is published to (0 LA, 1 LR, 2 LD, 3 RD), -1 none
+    LV(int, hLrow);
+    LV(int, hList);
     LV(int, hFrame);
     LV(int, hIgenic);
+    uint64_t maskVar = 0, maskRT = 0;
+    for (int s2 = 0; s2 < S; s2++) {
+        if (!T.reachable[s2]) continue;
+        const int kind = T.kind[s2];
+        if (kind == AUGX_K_RTERMINAL) maskRT |= 1ull << s2;
+        else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RINTERNAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) maskVar |= 1ull << s2;
+    }
     FOR_LANES(l) {
-        LX(hLag) = -1; LX(hSig) = 0; LX(hLong) = 0; LX(hNanc) = 0; LX(hLrow) = -1; LX(hList) = -1; LX(hFrame) = 0; LX(hIgenic) = 0;
+        LX(hCls) = -1; LX(hLag) = -1; LX(hSig) = 0; LX(hLong) = 0; LX(hNanc) = 0; LX(hLrow) = -1; LX(hList) = -1; LX(hFrame) = 0; LX(hIgenic) = 0;
+#pragma unroll
         for (int i = 0; i < 5; i++) { hAnc[i][LI] = 0; hTr[i][LI] = AUGX_NINF; }
         if (l < S && T.reachable[l]) {
             const int kind = T.kind[l];
+            LX(hCls) = kind == AUGX_K_RTERMINAL ? 3 : 2;
             switch (kind) {
-            case AUGX_K_IGENIC: LX(hLag) = 1; LX(hSig) = SIG_EIG; break;
-            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: LX(hLag) = 1; LX(hSig) = SIG_EIN; break;
-            case AUGX_K_LONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSF; break;
-            case AUGX_K_RLONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSR; break;
-            case AUGX_K_LONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSF; break;
-            case AUGX_K_RLONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSR; break;
-            case AUGX_K_EQUALD: case AUGX_K_REQUALD: LX(hLag) = dL; LX(hSig) = SIG_EQD; LX(hLong) = dL >= WAVE; break;
+            case AUGX_K_IGENIC: LX(hLag) = 1; LX(hSig) = SIG_EIG; LX(hCls) = 0; break;
+            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: LX(hLag) = 1; LX(hSig) = SIG_EIN; LX(hCls) = 0; break;
+            case AUGX_K_LONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSF; LX(hCls) = 1; break;
+            case AUGX_K_RLONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSR; LX(hCls) = 1; break;
+            case AUGX_K_LONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSF; LX(hCls) = 1; break;
+            case AUGX_K_RLONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSR; LX(hCls) = 1; break;
+            case AUGX_K_EQUALD: case AUGX_K_REQUALD: LX(hLag) = dL; LX(hSig) = SIG_EQD; LX(hLong) = dL >= WAVE; LX(hCls) = 1; break;
             default: break;
             }
             if (LX(hLag) > 0) {
                 LX(hNanc) = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
-                for (int ai = 0; ai < LX(hNanc); ai++) {
+#pragma unroll
+                for (int ai = 0; ai < 5; ai++) {
+                    if (ai >= LX(hNanc)) continue;
                     int a = T.anc[l][ai];
                     hAnc[ai][LI] = LX(hLong) ? longRow(T, a) : a;
                     hTr[ai][LI] = lnT(T, c, a, l);
@@ -550,125 +691,194 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             LX(hFrame) = T.win[l];
             LX(hIgenic) = kind == AUGX_K_IGENIC;
             LX(hList) = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
+            // LDS copy of the constants of the variable-length states
+            VarConst &VC = L.vc[l];
+            VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
+            for (int ai = 0; ai < 4; ai++) {
+                int a = ai < VC.nanc ? T.anc[l][ai] : 0;
+                VC.anc[ai] = a; VC.ancWin[ai] = T.win[a]; VC.tr[ai] = ai < VC.nanc ? lnT(T, c, a, l) : AUGX_NINF;
+            }
+            VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
         }
     }
+    // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
+    FOR_LANES(l) {
+        if (l < SP) {
+            double v = AUGX_NINF;
+            if (l < S) v = B.initKind[p] == 0 ? T.ln_init[l] : (l == T.synch ? 0.0 : AUGX_NINF);
+            L.ring[0][l] = v;
+            L.bp[0][l] = BP_NONE;
+            if (l < S) {
+                if (LX(hLrow) >= 0) L.longRing[LX(hLrow)][0] = v;
+                if (B.cells) B.cells[(o + 1) * S + l] = v;
+                if (LX(hIgenic)) { B.vig[o + 1] = v; L.vigw[0] = v; }
+            }
+        }
+    }
+    X.vigLo = -1;
+    X.P.wcode = L.codew;
+    X.P.wns = L.nsw;
     WAVE_SYNC();
     for (int j0 = 0; j0 < n; j0 += WAVE) {
-        // ---- load the tile of per-base records for bases j0..j0+63 (coalesced)
+        // ---- load the tile of per-base records for bases j0..j0+63 and advance the LDS windows (coalesced)
         FOR_LANES(l) {
             int q = j0 + l;
-            int64_t g = o + 1 + q;
-            for (int i = 0; i < NSIG; i++) L.sig[l][i] = B.sig[g * NSIG + i];
-            L.gate[l] = B.gate[g];
-            for (int i = 0; i < NSITE; i++) L.site[l][i] = B.site[g * NSITE + i];
+            int64_t gq = o + 1 + q;
+            for (int i = 0; i < NSIG; i++) L.sig[l][i] = B.sig[gq * NSIG + i];
+            L.gate[l] = B.gate[gq];
+            for (int i = 0; i < NSITE; i++) L.site[l][i] = B.site[gq * NSITE + i];
+            if (q != 0) for (int s2 = 0; s2 < SP; s2++) L.bp[l][s2] = BP_NONE;
+            // code window: bases [j0+64, j0+128) (first tile: also [0, 64))
+            for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
+                int qq = j0 + r * WAVE + l;
+                if (qq < n) L.codew[qq & (CODE_WIN - 1)] = B.code[o + 1 + qq];
+            }
+            // stop tables: bases [j0+16, j0+80) (first tile: also [0, 16))
+            for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
+                int qq = r == 0 ? l : j0 + 16 + l;
+                if (r == 0 && l >= 16) continue;
+                if (qq < n) for (int f = 0; f < 6; f++) L.nsw[(qq & (NS_WIN - 1)) * 6 + f] = (uint32_t)B.nsm[fidx(o + 1 + qq, f, 6)];
+            }
+            // site counts: bases [j0+64, j0+128) (first tile: also [0, 64))
+            for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
+                int qq = j0 + r * WAVE + l;
+                if (qq < n) for (int f = 0; f < 5; f++) L.cntw[qq & (CNT_WIN - 1)][f] = (uint32_t)B.cnt[fidx(o + 1 + qq, CNT_ATG + f, NCNT)];
+            }
+        }
+        {
+            int hi = j0 + 2 * WAVE < n ? j0 + 2 * WAVE : n;
+            X.P.wcHi = hi; X.P.wcLo = hi - CODE_WIN > 0 ? hi - CODE_WIN : 0;
+            X.kwHi = hi; X.kwLo = hi - CNT_WIN > 0 ? hi - CNT_WIN : 0;
+            int hn = j0 + 80 < n ? j0 + 80 : n;
+            X.P.wnHi = hn; X.P.wnLo = hn - NS_WIN > 0 ? hn - NS_WIN : 0;
         }
         WAVE_SYNC();
-        int jend = j0 + WAVE < n ? j0 + WAVE : n;
-        for (int j = (j0 == 0 ? 1 : j0); j < jend; j++) {
-            const int col = j & 63;
-            // ---- phase A: fixed-length states, one lane per state
+        for (int jb = j0; jb < j0 + WAVE && jb < n; jb += BLK) {
+            // ---- step 1: fixed-length states with lag > BLK: lane = state, BLK independent cells each
             FOR_LANES(l) {
-                if (l < SP) {
-                    double best = AUGX_NINF;
-                    uint16_t bp = BP_NONE;
-                    const int lag = LX(hLag);
-                    if (lag > 0 && j - lag >= 0) {
-                        const double emi = L.sig[col][LX(hSig)];
-                        if (emi > AUGX_NINF) {
-                            const double *colp = LX(hLong) ? nullptr : &L.ring[(j - lag) & 63][0];
-                            const int lidx = (j - lag) & (LONG_RING - 1);
-                            for (int ai = 0; ai < LX(hNanc); ai++) {
-                                double pv = LX(hLong) ? L.longRing[hAnc[ai][LI]][lidx] : colp[hAnc[ai][LI]];
-                                if (!(pv > AUGX_NINF)) continue;
-                                double val = pv + (hTr[ai][LI] + emi);
-                                if (val > best) { best = val; bp = bpFixed(ai); }
+                if (LX(hCls) == 1) {
+                    const int lag = LX(hLag), nanc = LX(hNanc);
+                    double emi[BLK], pv0[BLK], pv1[BLK];
+#pragma unroll
+                    for (int dj = 0; dj < BLK; dj++) { // independent LDS loads first
+                        const int j = jb + dj, jp = j - lag;
+                        emi[dj] = L.sig[j & 63][LX(hSig)];
+                        pv0[dj] = AUGX_NINF; pv1[dj] = AUGX_NINF;
+                        if (jp >= 0) {
+                            if (LX(hLong)) { pv0[dj] = L.longRing[hAnc[0][LI]][jp & (LONG_RING - 1)]; if (nanc > 1) pv1[dj] = L.longRing[hAnc[1][LI]][jp & (LONG_RING - 1)]; }
+                            else { pv0[dj] = L.ring[jp & 63][hAnc[0][LI]]; if (nanc > 1) pv1[dj] = L.ring[jp & 63][hAnc[1][LI]]; }
+                        }
+                    }
+#pragma unroll
+                    for (int dj = 0; dj < BLK; dj++) {
+                        const int j = jb + dj;
+                        if (j < 1 || j >= n) continue;
+                        double best = AUGX_NINF;
+                        uint16_t bp = BP_NONE;
+                        if (j - lag >= 0 && emi[dj] > AUGX_NINF) {
+                            if (pv0[dj] > AUGX_NINF) { best = pv0[dj] + (hTr[0][LI] + emi[dj]); bp = bpFixed(0); }
+                            if (nanc > 1 && pv1[dj] > AUGX_NINF) {
+                                double v2 = pv1[dj] + (hTr[1][LI] + emi[dj]);
+                                if (v2 > best) { best = v2; bp = bpFixed(1); }
+                            }
+                        }
+                        L.ring[j & 63][l] = best;
+                        L.bp[j & 63][l] = bp;
+                        if (LX(hLrow) >= 0) L.longRing[LX(hLrow)][j & (LONG_RING - 1)] = best;
+                        if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
+                        if (LX(hList) >= 0) {
+                            int si = L.site[j & 63][LX(hList)];
+                            if (si >= 0) {
+                                double *lval = LX(hList) == 0 ? B.laVal : LX(hList) == 1 ? B.lrVal : LX(hList) == 2 ? B.ldVal : B.rdVal;
+                                lval[(X.lo + si) * 3 + LX(hFrame)] = best;
+                                L.lcVal[LX(hList)][si & (LIST_WIN - 1)][LX(hFrame)] = best;
+                                if (LX(hFrame) == 0) L.lcPos[LX(hList)][si & (LIST_WIN - 1)] = j;
                             }
                         }
                     }
-                    L.ring[col][l] = best;
-                    L.bp[col][l] = bp;
                 }
             }
-            WAVE_SYNC();
-            // ---- phase B: variable-length states whose end gate is open at j, all together
-            const uint64_t gate = L.gate[col];
-            if (gate) {
-                GLOBAL_SYNC();
-                FOR_LANES(l) { // B1: one lane per gated state builds its descriptor
-                    if (l < SP && ((gate >> l) & 1)) varDescribe(X, l, j, L.desc[l]);
-                }
-                WAVE_SYNC();
-                int totalItems = 0;
-                FOR_LANES(l) { // B1b: item offsets (every lane computes the same prefix; cheap: <= 22 states)
-                    int acc = 0;
-                    for (int s2 = 0; s2 < S; s2++) {
-                        if (l == 0) L.itemBase[s2] = acc;
-                        if ((gate >> s2) & 1) acc += L.desc[s2].total;
-                    }
-                    if (l == 0) L.itemBase[SP] = acc;
-                    totalItems = acc;
-                }
-                WAVE_SYNC();
-                LV(double, rbv);
-                LV(int, rbk);
-                LV(int, rba);
-                FOR_LANES(l) { LX(rbv) = AUGX_NINF; LX(rbk) = -2147483647; LX(rba) = -1; }
-                for (int base = 0; base < totalItems; base += WAVE) {
-                    FOR_LANES(l) { // B2: evaluate one item per lane
-                        int it = base + l;
-                        L.itState[l] = -1;
-                        if (it < totalItems) {
-                            int s2 = 0;
-                            for (int q = 0; q < S; q++)
-                                if (((gate >> q) & 1) && L.itemBase[q] <= it) s2 = q;
-                            double v; int k2, a2;
-                            varEvalItem(X, s2, j, L.desc[s2], it - L.itemBase[s2], v, k2, a2);
-                            L.itVal[l] = v; L.itKey[l] = k2; L.itAux[l] = a2; L.itState[l] = s2;
-                        }
-                    }
-                    WAVE_SYNC();
-                    FOR_LANES(l) { // B3: the lane of each gated state folds the items of this chunk that belong to it
-                        if (l < SP && ((gate >> l) & 1)) {
-                            int lo2 = L.itemBase[l] - base, hi2 = lo2 + L.desc[l].total;
-                            if (lo2 < 0) lo2 = 0;
-                            if (hi2 > WAVE) hi2 = WAVE;
-                            for (int q = lo2; q < hi2; q++)
-                                if (better(L.itVal[q], L.itKey[q], LX(rbv), LX(rbk))) { LX(rbv) = L.itVal[q]; LX(rbk) = L.itKey[q]; LX(rba) = L.itAux[q]; }
-                        }
-                    }
-                    WAVE_SYNC();
-                }
-                FOR_LANES(l) {
-                    if (l < SP && ((gate >> l) & 1)) {
-                        uint16_t bp = BP_NONE;
-                        if (LX(rbv) > AUGX_NINF) {
-                            const int kind = L.desc[l].kind;
-                            int eop = (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) ? LX(rbk) : LX(rbk) - L.desc[l].g.bpl - 1;
-                            bp = bpVar(LX(rba), j - eop);
-                        }
-                        L.ring[col][l] = LX(rbv);
-                        L.bp[col][l] = bp;
-                    }
-                }
+            {   // newest published list entries = site counts at the last base of the block
+                int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
+                X.listHi0 = (int)X.cntAt(jl, CNT_LA) - 1;
+                X.listHi1 = (int)X.cntAt(jl, CNT_LR) - 1;
+                X.listHi2 = (int)X.cntAt(jl, CNT_LD) - 1;
+                X.listHi3 = (int)X.cntAt(jl, CNT_RD) - 1;
             }
             WAVE_SYNC();
-            // ---- phase C: publish column j
+            // ---- step 2: variable-length states (all but RTERMINAL): they depend on fixed-state cells (just published)
+            //      and on igenic cells at least BLK bases back
+            uint64_t anyVar = 0, anyRT = 0;
+            for (int dj = 0; dj < BLK; dj++) {
+                int j = jb + dj;
+                if (j >= 1 && j < n) { uint64_t gg = L.gate[j & 63]; anyVar |= gg & maskVar; anyRT |= gg & maskRT; }
+            }
+            // cells of variable-length states are absent unless their gate is open and a candidate survives
             FOR_LANES(l) {
-                if (l < S) {
-                    double v = L.ring[col][l];
-                    if (LX(hLrow) >= 0) L.longRing[LX(hLrow)][j & (LONG_RING - 1)] = v;
-                    if (B.cells) B.cells[(o + 1 + j) * S + l] = v;
-                    if (LX(hIgenic)) B.vig[o + 1 + j] = v;
-                    if (LX(hList) >= 0) {
-                        int si = L.site[col][LX(hList)];
-                        if (si >= 0) {
-                            double *lval = LX(hList) == 0 ? B.laVal : LX(hList) == 1 ? B.lrVal : LX(hList) == 2 ? B.ldVal : B.rdVal;
-                            lval[(X.lo + si) * 3 + LX(hFrame)] = v;
-                        }
+                if (LX(hCls) >= 2 || (l < SP && LX(hCls) < 0)) {
+                    for (int dj = 0; dj < BLK; dj++) {
+                        const int j = jb + dj;
+                        if (j < 1 || j >= n) continue;
+                        L.ring[j & 63][l] = AUGX_NINF;
+                        if (B.cells && l < S) B.cells[(o + 1 + j) * S + l] = AUGX_NINF;
                     }
                 }
             }
             WAVE_SYNC();
+            if (anyVar && !(B.dbgFlags & 1)) {
+                GLOBAL_SYNC();
+                trellisVarBlock(X, jb, maskVar);
+            }
+            // ---- step 3: the lag-1 chain states (igenic, geometric), one lane per state, BLK bases in sequence
+            FOR_LANES(l) {
+                if (LX(hCls) == 0) {
+                    const int nanc = LX(hNanc);
+                    double emi[BLK], pv[5][BLK];
+                    int selfAi = -1;
+#pragma unroll
+                    for (int ai = 0; ai < 5; ai++) if (ai < nanc && hAnc[ai][LI] == l) selfAi = ai;
+#pragma unroll
+                    for (int dj = 0; dj < BLK; dj++) { // independent LDS loads first
+                        const int j = jb + dj;
+                        emi[dj] = L.sig[j & 63][LX(hSig)];
+#pragma unroll
+                        for (int ai = 0; ai < 5; ai++) pv[ai][dj] = (ai < nanc && j >= 1) ? L.ring[(j - 1) & 63][hAnc[ai][LI]] : AUGX_NINF;
+                    }
+                    double prev = AUGX_NINF; // own value at j-1 once inside the block
+#pragma unroll
+                    for (int dj = 0; dj < BLK; dj++) {
+                        const int j = jb + dj;
+                        if (j < 1 || j >= n) continue;
+                        double best = AUGX_NINF;
+                        uint16_t bp = BP_NONE;
+                        if (emi[dj] > AUGX_NINF) {
+#pragma unroll
+                            for (int ai = 0; ai < 5; ai++) {
+                                if (ai >= nanc) continue;
+                                double pvv = (ai == selfAi && dj > 0 && j - 1 >= 1 && j - 1 >= jb) ? prev : pv[ai][dj];
+                                if (!(pvv > AUGX_NINF)) continue;
+                                double val = pvv + (hTr[ai][LI] + emi[dj]);
+                                if (val > best) { best = val; bp = bpFixed(ai); }
+                            }
+                        }
+                        prev = best;
+                        L.ring[j & 63][l] = best;
+                        L.bp[j & 63][l] = bp;
+                        if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
+                        if (LX(hIgenic)) { B.vig[o + 1 + j] = best; L.vigw[j & (VIG_WIN - 1)] = best; }
+                    }
+                }
+            }
+            {
+                int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
+                X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
+            }
+            WAVE_SYNC();
+            // ---- step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
+            if (anyRT && !(B.dbgFlags & 1)) {
+                GLOBAL_SYNC();
+                trellisVarBlock(X, jb, maskRT);
+            }
         }
         // ---- flush the back-pointer tile
         FOR_LANES(l) {
