@@ -73,6 +73,10 @@ __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B)
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1Signals(*T, B, g);
 }
+__global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView B) {
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < B.N) k1SiteConsts(*T, B, g);
+}
 
 // ---- chunked piece-local inclusive scans over rows [chunk][field][CHUNK] of uint64 (sum or max) ----
 template <bool MAX> __device__ inline uint64_t comb(uint64_t a, uint64_t b) { return MAX ? (a > b ? a : b) : a + b; }
@@ -312,11 +316,18 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.bp, uint16_t, Z.N * SP);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
     DA(V.vig, double, Z.N);
+    DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
     DA(V.lrPos, int32_t, Z.listCap); DA(V.lrVal, double, Z.listCap * 3);
     DA(V.ldPos, int32_t, Z.listCap); DA(V.ldVal, double, Z.listCap * 3);
     DA(V.rdPos, int32_t, Z.listCap); DA(V.rdVal, double, Z.listCap * 3);
     DA(V.atgPos, int32_t, Z.listCap);
+    DA(V.laPls, double, Z.listCap * 3); DA(V.laFx, uint64_t, Z.listCap * 3);
+    DA(V.lrEt, double, Z.listCap * 3); DA(V.lrFx, uint64_t, Z.listCap * 3);
+    DA(V.ldFx, uint64_t, Z.listCap); DA(V.rdFx, uint64_t, Z.listCap);
+    DA(V.atgD, double, Z.listCap * 3); DA(V.atgFx, uint64_t, Z.listCap);
+    DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap); DA(V.rsFx, uint64_t, Z.listCap * 3);
+    DA(V.plsR, double, Z.N * 3);
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
 #undef DA
@@ -365,6 +376,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kFxTerms, dim3(gridN), dim3(256), 0, st, d->dT, V);
     if ((rc = runScan<false>(b, V.fx, NFX))) return rc;
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    hipLaunchKernelGGL(kSiteConsts, dim3(gridN), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], st));
     hipLaunchKernelGGL(kTrellis, dim3(n), dim3(64), 0, st, d->dT, b->dV);

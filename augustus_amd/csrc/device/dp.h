@@ -26,12 +26,12 @@ constexpr int WAVE = 64;
 constexpr int SP = 48;          // column stride of the trellis storage (S <= SP)
 constexpr int NFX = 20;         // fixed-point prefix fields per slot: [strand 2][phase 3][table 3], inF, inR
 constexpr int FX_INF = 18, FX_INR = 19;
-constexpr int NSIG = 9;         // per-position signal record: eIg eIn dssF dssR assF assR tisF tisR eqD
-constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4, SIG_ASSR = 5, SIG_TISF = 6, SIG_TISR = 7, SIG_EQD = 8;
+constexpr int NSIG = 10;        // per-position signal record: eIg eIn dssF dssR assF assR tisF tisR eqD stopF
+constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4, SIG_ASSR = 5, SIG_TISF = 6, SIG_TISR = 7, SIG_EQD = 8, SIG_STOPF = 9;
 constexpr int CHUNK = 1024;     // slots per scan chunk; every piece is padded to a multiple of CHUNK
 constexpr int LONG_RING = 1024; // ring depth for the states consumed at lag dStateLen (must exceed it)
 constexpr uint16_t BP_NONE = 0xFFFF;
-constexpr int CODE_WIN = 1024, NS_WIN = 128, CNT_WIN = 512, VIG_WIN = 512, LIST_WIN = 128; // LDS window sizes (powers of 2)
+constexpr int CODE_WIN = 1024, NS_WIN = 128, CNT_WIN = 256, VIG_WIN = 512, LIST_WIN = 128, FX_WIN = 128, ATG_WIN = 64; // LDS window sizes (powers of 2)
 
 #define AUGX_NINF (-INFINITY)
 
@@ -76,11 +76,19 @@ struct BatchView {
     uint16_t *bp;              // [N][SP] back pointers
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
+    double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD
     int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]
     int32_t *lrPos; double *lrVal;   // reverse donor candidates     (rlongdss_f live)
     int32_t *ldPos; double *ldVal;   // forward short-intron starts  (longdss_f live)
     int32_t *rdPos; double *rdVal;   // reverse short-intron starts  (rlongass_f live)
     int32_t *atgPos;                 // start codons (position of the a of atg) [N/2]
+    // candidate-side constants of the list entries (independent of the Viterbi values: written by the prep kernels)
+    double *laPls; uint64_t *laFx;   // [cap][3] per phase a: ln P_ls of the first k bases; exon-content prefix at bs+k-1
+    double *lrEt; uint64_t *lrFx;    // [cap][3] per phase a: exon-terminal content of bs..bs+Le-1; exon-content prefix at bs+Le-1
+    uint64_t *ldFx, *rdFx;           // [cap] intron-content prefix at eop (forward pattern / reverse-complement pattern)
+    double *atgD; uint64_t *atgFx;   // [cap][3] (begin part, ln P_ls, initial content), [cap] exon-content prefix at bs+k-1+Li
+    int32_t *rsPos; double *rsBegin; uint64_t *rsFx; // reverse stop codons: position, ln stop prob, [cap][3] exon-content prefix at bs-1
+    double *plsR;                    // [N][3] reverse strand: ln P_ls of the k bases ending at this base, per frame
     // results
     double *lnv;               // [nPieces]
     int32_t *status;           // [nPieces]

@@ -82,8 +82,8 @@ AUGX_HD Piece makePiece(const DevTables &T, const BatchView &B, int p) {
 // =================================================================================================
 // K1  prep kernels (one thread per slot unless noted).  g = global slot index.
 // =================================================================================================
-constexpr int NCNT = 9; // prefix-count fields: a c g t | atg | ag(LA) | ac(LR) | gt(LD) | ct(RD)
-constexpr int CNT_ATG = 4, CNT_LA = 5, CNT_LR = 6, CNT_LD = 7, CNT_RD = 8;
+constexpr int NCNT = 10; // prefix-count fields: a c g t | atg | ag(LA) | ac(LR) | gt(LD) | ct(RD) | reverse stop codons
+constexpr int CNT_ATG = 4, CNT_LA = 5, CNT_LR = 6, CNT_LD = 7, CNT_RD = 8, CNT_RS = 9;
 
 AUGX_HD void k1Encode(const BatchView &B, int64_t g) {
     int p = B.chunkPiece[g / CHUNK];
@@ -118,7 +118,7 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
     if (P.possRASS(q - T.U - T.As - 2 + 1)) cnt[CNT_RD] = 1;        // rlongass may end at q  (:713)
     if (q <= P.n - 3) {
         if (P.isStop(q)) ns[q % 3] = (uint64_t)q + 1;
-        if (P.isRCStop(q)) ns[3 + q % 3] = (uint64_t)q + 1;
+        if (P.isRCStop(q)) { ns[3 + q % 3] = (uint64_t)q + 1; cnt[CNT_RS] = 1; }
     }
     }
     for (int i = 0; i < NCNT; i++) B.cnt[fidx(g, i, NCNT)] = cnt[i];
@@ -218,6 +218,7 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     if (q - assWhole - T.U >= 0 && P.possRASS(q - T.U - T.As - 2 + 1)) sg[SIG_ASSR] = assProb(P, q - assWhole - T.U + 1, false);
     sg[SIG_TISF] = tisFwd(P, q);
     sg[SIG_TISR] = tisRev(P, q);
+    sg[SIG_STOPF] = exEndPart(P, AUGX_K_TERMINAL, 0, q, AUGX_NINF); // ln P(stop codon ending at q), -inf if none
     // list index of the site ending at q (prefix count - 1), -1 if q is not such a site
     uint64_t cn[NCNT], cp[NCNT];
     for (int i = CNT_ATG; i < NCNT; i++) { cn[i] = B.cnt[fidx(g, i, NCNT)]; cp[i] = B.cnt[fidx(g - 1, i, NCNT)]; }
@@ -253,6 +254,65 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     B.gate[g] = gate;
 }
 
+// candidate-side constants of the list entries (everything a candidate contributes that does not depend on Viterbi
+// values).  Fast-path evaluation in the trellis combines them with end-side constants; the arithmetic is exactly that
+// of exNotEndPart (same prefix differences, same order of additions).
+AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
+    int p = B.chunkPiece[g / CHUNK];
+    int64_t o = B.off[p];
+    int q = (int)(g - o - 1);
+    if (q < 0 || q >= B.len[p]) return;
+    double *pr = B.plsR + g * 3;
+    pr[0] = pr[1] = pr[2] = AUGX_NINF;
+    if (B.cls[p] < 0) return;
+    Piece P = makePiece(T, B, p);
+    const int k = T.k, c = P.c, n = P.n;
+    const int64_t lo = listOff(B, p);
+    auto fxv = [&](int pos, int f) -> uint64_t { return pos < 0 ? 0 : P.fx[fidx(o + 1 + (pos < n ? pos : n - 1), f, NFX)]; };
+    auto plsK = [&](int pn, int frame) { return pn >= 0 ? T.ex_pls[(((int64_t)c * (k + 1) + (k - 1)) * 3 + frame) * T.NP + pn] : k * T.ln_n_coding; };
+    if (k > 0 && q - k + 1 >= 0) { // reverse strand initial pattern ending at q (src/exonmodel.cc:1598-1600)
+        int pn = P.rcpat(q - k + 1, k);
+        for (int fr = 0; fr < 3; fr++) pr[fr] = plsK(pn, fr);
+    }
+    uint64_t cn[NCNT], cp[NCNT];
+    for (int i = CNT_ATG; i < NCNT; i++) { cn[i] = B.cnt[fidx(g, i, NCNT)]; cp[i] = B.cnt[fidx(g - 1, i, NCNT)]; }
+    if (cn[CNT_LA] != cp[CNT_LA]) { // forward acceptor candidate ending (as longass state) at q: exon inner part starts at bs = q+1
+        int64_t idx = lo + (int64_t)cn[CNT_LA] - 1;
+        int bs = q + 1, eos = bs + k - 1, pn = P.pat(bs, k);
+        for (int a = 0; a < 3; a++) {
+            B.laPls[idx * 3 + a] = k == 0 ? 0.0 : plsK(pn, mod3(eos + a));
+            B.laFx[idx * 3 + a] = fxv(eos, (0 * 3 + a) * 3 + 0);
+        }
+    }
+    if (cn[CNT_LR] != cp[CNT_LR]) { // reverse donor candidate
+        int64_t idx = lo + (int64_t)cn[CNT_LR] - 1;
+        int bs = q + 1, eot = bs + T.Le - 1;
+        for (int a = 0; a < 3; a++) {
+            const int fb = (1 * 3 + a) * 3;
+            B.lrEt[idx * 3 + a] = (double)(int64_t)(fxv(eot, fb + 2) - fxv(bs - 1, fb + 2)) * AUGX_FX_INV;
+            if (eot < bs) B.lrEt[idx * 3 + a] = 0.0;
+            B.lrFx[idx * 3 + a] = fxv(eot, fb + 0);
+        }
+    }
+    if (cn[CNT_LD] != cp[CNT_LD]) B.ldFx[lo + (int64_t)cn[CNT_LD] - 1] = fxv(q, FX_INF);
+    if (cn[CNT_RD] != cp[CNT_RD]) B.rdFx[lo + (int64_t)cn[CNT_RD] - 1] = fxv(q, FX_INR);
+    if (cn[CNT_ATG] != cp[CNT_ATG]) { // start codon at q: bs = q+3, frame phase a = (-q) mod 3
+        int64_t idx = lo + (int64_t)cn[CNT_ATG] - 1;
+        int bs = q + 3, eos = bs + k - 1, eoi = eos + T.Li, a = mod3(-q);
+        const int fb = (0 * 3 + a) * 3;
+        B.atgD[idx * 3 + 0] = tisFwd(P, q);
+        B.atgD[idx * 3 + 1] = k == 0 ? 0.0 : plsK(P.pat(bs, k), mod3(eos + a));
+        B.atgD[idx * 3 + 2] = eoi > eos ? (double)(int64_t)(fxv(eoi, fb + 1) - fxv(eos, fb + 1)) * AUGX_FX_INV : 0.0;
+        B.atgFx[idx] = fxv(eoi, fb + 0);
+    }
+    if (cn[CNT_RS] != cp[CNT_RS]) { // reverse stop codon at q..q+2: bs = q+3
+        int64_t idx = lo + (int64_t)cn[CNT_RS] - 1;
+        B.rsPos[idx] = q;
+        B.rsBegin[idx] = (P.b(q) == 3 && P.b(q + 1) == 3) ? T.ln_stop_ochre : (P.b(q) == 1) ? T.ln_stop_amber : T.ln_stop_opal;
+        for (int a = 0; a < 3; a++) B.rsFx[idx * 3 + a] = fxv(q + 2, (1 * 3 + a) * 3 + 0);
+    }
+}
+
 // =================================================================================================
 // K2  trellis: one wavefront per piece
 // =================================================================================================
@@ -263,6 +323,11 @@ struct VarDesc {
     int eobi, cod0, cod1, cod2;                   // short intron: end of the biological intron, spliced-codon bases
     double endP;
     ExGeom g;
+    // end-side constants of the fast candidate evaluation (see k1SiteConsts)
+    int a;                  // phase of the content prefix fields
+    uint64_t eFx;           // content prefix at the end-side boundary
+    double eD0, plsEnd;     // end-side content term (exon-terminal fwd / initial-content rev), reverse-strand ln P_ls
+    const double *lenTab;   // length distribution of this exon type
 };
 
 constexpr int BLK = 8;          // bases per block: smaller than every lag except the lag-1 chain states
@@ -292,7 +357,7 @@ struct VarConst {
 
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
-    double longRing[6][LONG_RING];  // states consumed at lag dStateLen: rows 0..2 longdss_f, 3..5 rlongass_f
+    double eqPrev[WAVE][6];         // predecessor cells of the equalD states for the bases of the tile (lag dStateLen)
     double sig[WAVE][NSIG];         // tile of signal records for bases j0..j0+63
     uint64_t gate[WAVE];
     int32_t site[WAVE][NSITE];
@@ -300,10 +365,17 @@ struct TrellisLds {
     // windows over recent bases (served from LDS; older data falls back to HBM)
     uint8_t codew[CODE_WIN];
     uint32_t nsw[NS_WIN * 6];
-    uint32_t cntw[CNT_WIN][5];      // site counts (ATG, LA, LR, LD, RD) at bases <= q
+    uint32_t cntw[CNT_WIN][6];      // site counts (ATG, LA, LR, LD, RD, RS) at bases <= q
     double vigw[VIG_WIN];           // igenic column
+    uint64_t fxw[FX_WIN][NFX];      // content prefix sums of bases [j0-64, j0+64)
+    double plsRw[FX_WIN][3];
     int32_t lcPos[4][LIST_WIN];     // newest LIST_WIN entries of the four splice-site candidate lists
-    double lcVal[4][LIST_WIN][3];
+    double lcVal[4][LIST_WIN][3];   //   Viterbi values of the three frames
+    double lcC[2][LIST_WIN][3];     //   LA: ln P_ls; LR: exon-terminal content
+    uint64_t lcFx[4][LIST_WIN][3];  //   content prefix at the candidate-side boundary (LD/RD: [0] only)
+    int32_t aPos[ATG_WIN];          // newest start-codon entries
+    double aD[ATG_WIN][3];
+    uint64_t aFx[ATG_WIN];
     VarConst vc[SP];
     VarDesc desc[MAXPAIR];          // descriptors of the gated (base, state) pairs of the current round
     int pairJ[MAXPAIR], pairS[MAXPAIR];
@@ -331,6 +403,8 @@ struct TrellisCtx {
     int64_t lo;     // list offset
     int n, c, S;
     int kwLo, kwHi; // cnt window
+    int fwLo, fwHi; // content-prefix window
+    int atgHi;      // newest start-codon entry in the LDS cache
     int vigLo;      // igenic ring holds bases > vigLo (and <= the newest chain base)
     int listHi0, listHi1, listHi2, listHi3;  // newest published entry of each splice-site list (piece-local index), -1 none
     AUGX_HD int listHi(int sel) const { return sel == 0 ? listHi0 : sel == 1 ? listHi1 : sel == 2 ? listHi2 : listHi3; }
@@ -339,7 +413,7 @@ struct TrellisCtx {
         o = B.off[p];
         lo = listOff(B, p);
         n = P.n; c = P.c; S = T.S;
-        kwLo = kwHi = 0; vigLo = 0x7fffffff;
+        kwLo = kwHi = 0; fwLo = fwHi = 0; atgHi = -1; vigLo = 0x7fffffff;
         listHi0 = listHi1 = listHi2 = listHi3 = -1;
     }
     AUGX_HD uint64_t cntAt(int q, int f) const { // number of sites of field f at bases <= q (q may be -1)
@@ -359,6 +433,26 @@ struct TrellisCtx {
         return a[(lo + li) * 3 + f];
     }
     AUGX_HD double vigAt(int eop) const { return eop > vigLo ? L.vigw[eop & (VIG_WIN - 1)] : B.vig[o + 1 + eop]; }
+    AUGX_HD bool listCached(int sel, int64_t li) const { return li <= listHi(sel) && li > listHi(sel) - LIST_WIN; }
+    AUGX_HD double listC(int sel, int64_t li, int a) const { // LA: ln P_ls, LR: exon-terminal content
+        if (listCached(sel, li)) return L.lcC[sel][li & (LIST_WIN - 1)][a];
+        return (sel == 0 ? B.laPls : B.lrEt)[(lo + li) * 3 + a];
+    }
+    AUGX_HD uint64_t listFx(int sel, int64_t li, int a) const {
+        if (listCached(sel, li)) return L.lcFx[sel][li & (LIST_WIN - 1)][a];
+        if (sel == 0) return B.laFx[(lo + li) * 3 + a];
+        if (sel == 1) return B.lrFx[(lo + li) * 3 + a];
+        return (sel == 2 ? B.ldFx : B.rdFx)[lo + li];
+    }
+    AUGX_HD uint64_t fxAt(int q, int f) const { // content prefix field f up to and including base q (q < 0: empty)
+        if (q < 0) return 0;
+        if (q >= fwLo && q < fwHi) return L.fxw[q & (FX_WIN - 1)][f];
+        return B.fx[fidx(o + 1 + q, f, NFX)];
+    }
+    AUGX_HD double plsRAt(int q, int fr) const {
+        if (q >= fwLo && q < fwHi) return L.plsRw[q & (FX_WIN - 1)][fr];
+        return B.plsR[(o + 1 + q) * 3 + fr];
+    }
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -377,6 +471,7 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
     D.kind = kind; D.win = win; D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
     D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cod0 = D.cod1 = D.cod2 = 4; D.endP = AUGX_NINF;
     D.g = VC.g;
+    D.a = 0; D.eFx = 0; D.eD0 = 0.0; D.plsEnd = 0.0; D.lenTab = T.len_internal;
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
@@ -403,12 +498,44 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
         D.extra = left == 0 ? 1 : 0; // eop = 0 reads column 0 (initial probabilities); not a splice site, so not listed
         D.total = D.nList + D.extra;
         D.endP = 0.0;
+        D.eFx = X.fxAt(j, fwd ? FX_INF : FX_INR);
         return;
     }
     const ExEnd e = exEnd(P, kind, win, j, D.g);
     D.eob = e.eob; D.right = e.right; D.fOR = e.fOR; D.startMin = e.startMin;
-    D.endP = exEndPart(P, kind, win, j, X.L.sig[j & 63][SIG_TISR]);
+    D.endP = (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) ? X.L.sig[j & 63][SIG_STOPF]
+             : (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) ? X.L.sig[j & 63][SIG_TISR] : 0.0; // gate is open
     if (!(D.endP > AUGX_NINF) || e.right < 0 || e.startMax < e.startMin) return;
+    {   // end-side constants of the fast candidate evaluation
+        const int k = T.k, right = e.right;
+        const int a = D.g.fwd ? mod3(e.fOR - right) : mod3(e.fOR + right);
+        const int fb = ((D.g.fwd ? 0 : 1) * 3 + a) * 3;
+        D.a = a;
+        switch (kind) {
+        case AUGX_K_INTERNAL: case AUGX_K_INITIAL:
+            D.eFx = X.fxAt(right - T.Le, fb + 0);
+            D.eD0 = T.Le > 0 ? (double)(int64_t)(X.fxAt(right, fb + 2) - X.fxAt(right - T.Le, fb + 2)) * AUGX_FX_INV : 0.0;
+            D.lenTab = kind == AUGX_K_INTERNAL ? T.len_internal : T.len_initial;
+            break;
+        case AUGX_K_TERMINAL: case AUGX_K_SINGLE:
+            D.eFx = X.fxAt(right, fb + 0);
+            D.lenTab = kind == AUGX_K_TERMINAL ? T.len_terminal : T.len_single;
+            break;
+        default: {
+            const int boip = right - (k - 1);
+            D.plsEnd = (k > 0 && boip >= 0) ? X.plsRAt(right, mod3(e.fOR + right - boip)) : 0.0;
+            if (kind == AUGX_K_RINTERNAL || kind == AUGX_K_RTERMINAL) {
+                D.eFx = X.fxAt(boip - 1, fb + 0);
+                D.lenTab = kind == AUGX_K_RINTERNAL ? T.len_internal : T.len_terminal;
+            } else {
+                const int boi = boip - T.Li;
+                D.eFx = X.fxAt(boi - 1, fb + 0);
+                D.eD0 = T.Li > 0 ? (double)(int64_t)(X.fxAt(boip - 1, fb + 1) - X.fxAt(boi - 1, fb + 1)) * AUGX_FX_INV : 0.0;
+                D.lenTab = kind == AUGX_K_RINITIAL ? T.len_initial : T.len_single;
+            }
+        }
+        }
+    }
     if (kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL) { // start codons with bob in [startMin-3, startMax-3]
         const int64_t i0 = (int64_t)X.cntAt(e.startMin - 3 - 1, CNT_ATG);
         D.i1 = (int64_t)X.cntAt(e.startMax - 3, CNT_ATG);
@@ -466,7 +593,8 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         }
         int intronLength = D.eobi - bobi + 1;
         if (intronLength > T.d) return;
-        double restSeq = P.seg(fwd ? FX_INF : FX_INR, begin, j);
+        double restSeq = idx < D.nList ? (double)(int64_t)(D.eFx - X.listFx(D.listSel, D.i1 - 1 - idx, 0)) * AUGX_FX_INV
+                                       : P.seg(fwd ? FX_INF : FX_INR, begin, j);
         double emi = T.len_intron[intronLength] + restSeq;
         if (!(emi > AUGX_NINF)) return;
         val = pv + (VC.tr[0] + emi);
@@ -477,10 +605,18 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         const int a = VC.anc[0];
         int bs;
         double tisF = AUGX_NINF;
+        double cPls = 0.0, cInit = 0.0;
+        uint64_t cFxA = 0;
         if (D.listSel == 4) {
-            int bob = B.atgPos[X.lo + (D.i1 - 1 - idx)];
-            bs = bob + 3;
-            tisF = P.sig[(int64_t)bob * NSIG + SIG_TISF];
+            const int64_t ai2 = D.i1 - 1 - idx;
+            if (ai2 <= X.atgHi && ai2 > X.atgHi - ATG_WIN) {
+                const int sl = (int)(ai2 & (ATG_WIN - 1));
+                bs = X.L.aPos[sl] + 3; tisF = X.L.aD[sl][0]; cPls = X.L.aD[sl][1]; cInit = X.L.aD[sl][2]; cFxA = X.L.aFx[sl];
+            } else {
+                bs = B.atgPos[X.lo + ai2] + 3;
+                tisF = B.atgD[(X.lo + ai2) * 3 + 0]; cPls = B.atgD[(X.lo + ai2) * 3 + 1]; cInit = B.atgD[(X.lo + ai2) * 3 + 2];
+                cFxA = B.atgFx[X.lo + ai2];
+            }
         } else
             bs = D.startMin;
         int eop = bs - D.g.bpl - 1;
@@ -489,7 +625,39 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         if (!(eop < n && eop <= j)) return;
         double pv = eop <= 0 ? col0(a) : X.vigAt(eop);
         if (!(pv > AUGX_NINF)) return;
-        double nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
+        double nep;
+        const int m = D.right - bs, k = T.k;
+        const int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+        bool fast = false;
+        if (D.listSel == 4) {
+            const int eos = bs + k - 1, eoi = eos + T.Li;
+            const bool ok = m > k && mod3(-bob) == D.a && (kind == AUGX_K_SINGLE ? D.right >= eoi : D.right - T.Le >= eoi);
+            if (ok) {
+                fast = true;
+                double lenPart = AUGX_NINF;
+                if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_SINGLE ? len % 3 == 0 : (len % 3 == win && len > 2))) lenPart = D.lenTab[len];
+                if (!(lenPart > AUGX_NINF)) return;
+                double seg1 = (double)(int64_t)(D.eFx - cFxA) * AUGX_FX_INV;
+                double inner = kind == AUGX_K_SINGLE ? (cInit + seg1) : ((cInit + seg1) + D.eD0);
+                nep = (tisF + (cPls + inner)) + lenPart;
+            }
+        } else {
+            const int boip = D.right - (k - 1), boi = boip - T.Li;
+            // the candidate must start with a reverse stop codon at bob (ORFleft may also be the max-length clamp or 0)
+            const bool ok = m > k && (kind == AUGX_K_RTERMINAL || boi >= bs) && bob >= 0 &&
+                            X.cntAt(bob, CNT_RS) != X.cntAt(bob - 1, CNT_RS);
+            if (ok) {
+                fast = true;
+                double lenPart = AUGX_NINF;
+                if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RSINGLE ? len % 3 == 0 : mod3(2 - len) == win)) lenPart = D.lenTab[len];
+                if (!(lenPart > AUGX_NINF)) return;
+                const int64_t ri = (int64_t)X.cntAt(bob, CNT_RS) - 1; // the reverse stop codon at bob = bs-3
+                double seg1 = (double)(int64_t)(D.eFx - B.rsFx[(X.lo + ri) * 3 + D.a]) * AUGX_FX_INV;
+                double inner = kind == AUGX_K_RTERMINAL ? seg1 : (D.eD0 + seg1);
+                nep = (B.rsBegin[X.lo + ri] + (D.plsEnd + inner)) + lenPart;
+            }
+        }
+        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
         if (!(nep > AUGX_NINF)) return;
         double te = (VC.tr[0] + D.endP) + nep;
         val = pv + te;
@@ -503,9 +671,38 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
     if (idx < D.nList) { li = D.i1 - 1 - idx; eop = X.listPos(D.listSel, li); }
     else eop = -1;
     int bs = eop + 1;
-    double nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
-    if (!(nep > AUGX_NINF)) return;
     int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+    double nep;
+    {
+        const int m = D.right - bs, k = T.k;
+        bool fast = false;
+        if (li >= 0 && m > k) {
+            if (fwd) {
+                if (kind == AUGX_K_TERMINAL || m >= k + T.Le - 1) {
+                    fast = true;
+                    double lenPart = (len >= 1 && len <= T.max_exon_len) ? D.lenTab[len] : AUGX_NINF;
+                    if (!(lenPart > AUGX_NINF)) return;
+                    double seg1 = (double)(int64_t)(D.eFx - X.listFx(0, li, D.a)) * AUGX_FX_INV;
+                    double inner = kind == AUGX_K_TERMINAL ? seg1 : (seg1 + D.eD0);
+                    nep = (0.0 + (X.listC(0, li, D.a) + inner)) + lenPart;
+                }
+            } else {
+                const int boip = D.right - (k - 1), eot = bs + T.Le - 1, boi = boip - T.Li;
+                const bool ok = kind == AUGX_K_RINTERNAL ? (eot < boip) : (boi >= bs && eot < boi);
+                if (ok) {
+                    fast = true;
+                    double lenPart = (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RINTERNAL || len > 2)) ? D.lenTab[len] : AUGX_NINF;
+                    if (!(lenPart > AUGX_NINF)) return;
+                    double seg1 = (double)(int64_t)(D.eFx - X.listFx(1, li, D.a)) * AUGX_FX_INV;
+                    double cEt = X.listC(1, li, D.a);
+                    double inner = kind == AUGX_K_RINTERNAL ? (seg1 + cEt) : ((D.eD0 + seg1) + cEt);
+                    nep = (0.0 + (D.plsEnd + inner)) + lenPart;
+                }
+            }
+        }
+        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
+    }
+    if (!(nep > AUGX_NINF)) return;
     for (int ai = 0; ai < VC.nanc; ai++) {
         if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
         double pv = li >= 0 ? X.listVal(D.listSel, li, VC.ancWin[ai]) : col0(VC.anc[ai]);
@@ -709,7 +906,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             L.ring[0][l] = v;
             L.bp[0][l] = BP_NONE;
             if (l < S) {
-                if (LX(hLrow) >= 0) L.longRing[LX(hLrow)][0] = v;
+                if (LX(hLrow) >= 0) B.longV[(o + 1) * 6 + LX(hLrow)] = v;
                 if (B.cells) B.cells[(o + 1) * S + l] = v;
                 if (LX(hIgenic)) { B.vig[o + 1] = v; L.vigw[0] = v; }
             }
@@ -742,7 +939,37 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             // site counts: bases [j0+64, j0+128) (first tile: also [0, 64))
             for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
                 int qq = j0 + r * WAVE + l;
-                if (qq < n) for (int f = 0; f < 5; f++) L.cntw[qq & (CNT_WIN - 1)][f] = (uint32_t)B.cnt[fidx(o + 1 + qq, CNT_ATG + f, NCNT)];
+                if (qq < n) for (int f = 0; f < 6; f++) L.cntw[qq & (CNT_WIN - 1)][f] = (uint32_t)B.cnt[fidx(o + 1 + qq, CNT_ATG + f, NCNT)];
+            }
+            // content prefix sums and reverse P_ls terms of the bases of this tile
+            if (q < n) {
+                for (int f = 0; f < NFX; f++) L.fxw[q & (FX_WIN - 1)][f] = B.fx[fidx(gq, f, NFX)];
+                for (int f = 0; f < 3; f++) L.plsRw[q & (FX_WIN - 1)][f] = B.plsR[gq * 3 + f];
+            }
+            // predecessor cells of the equalD states (lag dStateLen >= 64: written long ago by this wavefront)
+            for (int f = 0; f < 6; f++) L.eqPrev[l][f] = (dL >= WAVE && q - dL >= 0 && q < n) ? B.longV[(gq - dL) * 6 + f] : AUGX_NINF;
+            // candidate-side constants of the list entries whose site lies in this tile
+            if (q < n) {
+                for (int sel = 0; sel < 4; sel++) {
+                    int si = L.site[l][sel];
+                    if (si < 0) continue;
+                    const int sl = si & (LIST_WIN - 1);
+                    L.lcPos[sel][sl] = q;
+                    for (int a = 0; a < 3; a++) {
+                        if (sel == 0) { L.lcC[0][sl][a] = B.laPls[(X.lo + si) * 3 + a]; L.lcFx[0][sl][a] = B.laFx[(X.lo + si) * 3 + a]; }
+                        if (sel == 1) { L.lcC[1][sl][a] = B.lrEt[(X.lo + si) * 3 + a]; L.lcFx[1][sl][a] = B.lrFx[(X.lo + si) * 3 + a]; }
+                    }
+                    if (sel == 2) L.lcFx[2][sl][0] = B.ldFx[X.lo + si];
+                    if (sel == 3) L.lcFx[3][sl][0] = B.rdFx[X.lo + si];
+                }
+                // start codons of this tile
+                uint32_t ac = (uint32_t)B.cnt[fidx(gq, CNT_ATG, NCNT)], ap = (uint32_t)B.cnt[fidx(gq - 1, CNT_ATG, NCNT)];
+                if (ac != ap) {
+                    const int ai2 = (int)ac - 1, sl = ai2 & (ATG_WIN - 1);
+                    L.aPos[sl] = q;
+                    for (int a = 0; a < 3; a++) L.aD[sl][a] = B.atgD[(X.lo + ai2) * 3 + a];
+                    L.aFx[sl] = B.atgFx[X.lo + ai2];
+                }
             }
         }
         {
@@ -751,7 +978,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             X.kwHi = hi; X.kwLo = hi - CNT_WIN > 0 ? hi - CNT_WIN : 0;
             int hn = j0 + 80 < n ? j0 + 80 : n;
             X.P.wnHi = hn; X.P.wnLo = hn - NS_WIN > 0 ? hn - NS_WIN : 0;
+            int hf = j0 + WAVE < n ? j0 + WAVE : n;
+            X.fwHi = hf; X.fwLo = hf - FX_WIN > 0 ? hf - FX_WIN : 0;
+            // list entries of sites up to the end of this tile are in the LDS caches (values follow as the trellis advances)
+            X.listHi0 = (int)X.cntAt(hf - 1, CNT_LA) - 1;
+            X.listHi1 = (int)X.cntAt(hf - 1, CNT_LR) - 1;
+            X.listHi2 = (int)X.cntAt(hf - 1, CNT_LD) - 1;
+            X.listHi3 = (int)X.cntAt(hf - 1, CNT_RD) - 1;
+            X.atgHi = (int)X.cntAt(hf - 1, CNT_ATG) - 1;
         }
+        GLOBAL_SYNC();
         WAVE_SYNC();
         for (int jb = j0; jb < j0 + WAVE && jb < n; jb += BLK) {
             // ---- step 1: fixed-length states with lag > BLK: lane = state, BLK independent cells each
@@ -765,7 +1001,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                         emi[dj] = L.sig[j & 63][LX(hSig)];
                         pv0[dj] = AUGX_NINF; pv1[dj] = AUGX_NINF;
                         if (jp >= 0) {
-                            if (LX(hLong)) { pv0[dj] = L.longRing[hAnc[0][LI]][jp & (LONG_RING - 1)]; if (nanc > 1) pv1[dj] = L.longRing[hAnc[1][LI]][jp & (LONG_RING - 1)]; }
+                            if (LX(hLong)) { pv0[dj] = L.eqPrev[j & 63][hAnc[0][LI]]; if (nanc > 1) pv1[dj] = L.eqPrev[j & 63][hAnc[1][LI]]; }
                             else { pv0[dj] = L.ring[jp & 63][hAnc[0][LI]]; if (nanc > 1) pv1[dj] = L.ring[jp & 63][hAnc[1][LI]]; }
                         }
                     }
@@ -784,7 +1020,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                         }
                         L.ring[j & 63][l] = best;
                         L.bp[j & 63][l] = bp;
-                        if (LX(hLrow) >= 0) L.longRing[LX(hLrow)][j & (LONG_RING - 1)] = best;
+                        if (LX(hLrow) >= 0) B.longV[(o + 1 + j) * 6 + LX(hLrow)] = best;
                         if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
                         if (LX(hList) >= 0) {
                             int si = L.site[j & 63][LX(hList)];
@@ -792,18 +1028,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                                 double *lval = LX(hList) == 0 ? B.laVal : LX(hList) == 1 ? B.lrVal : LX(hList) == 2 ? B.ldVal : B.rdVal;
                                 lval[(X.lo + si) * 3 + LX(hFrame)] = best;
                                 L.lcVal[LX(hList)][si & (LIST_WIN - 1)][LX(hFrame)] = best;
-                                if (LX(hFrame) == 0) L.lcPos[LX(hList)][si & (LIST_WIN - 1)] = j;
                             }
                         }
                     }
                 }
-            }
-            {   // newest published list entries = site counts at the last base of the block
-                int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
-                X.listHi0 = (int)X.cntAt(jl, CNT_LA) - 1;
-                X.listHi1 = (int)X.cntAt(jl, CNT_LR) - 1;
-                X.listHi2 = (int)X.cntAt(jl, CNT_LD) - 1;
-                X.listHi3 = (int)X.cntAt(jl, CNT_RD) - 1;
             }
             WAVE_SYNC();
             // ---- step 2: variable-length states (all but RTERMINAL): they depend on fixed-state cells (just published)
