@@ -4,7 +4,7 @@
 // Launch shapes (MI355X: 256 CUs, wave64):
 //   prep kernels : one thread per slot, 256-thread blocks, grid = N/256  (HBM-streaming, fully coalesced rows)
 //   scans        : grid (chunks x fields), 256 threads x 4 slots, rows of CHUNK=1024 contiguous uint64
-//   trellis      : one 64-lane wavefront (= one workgroup) per piece, ~87 KB LDS, position-sequential
+//   trellis      : one workgroup of 4 wavefronts per piece (one per SIMD of a CU), ~130 KB LDS, position-sequential
 //   backtrace    : one wavefront per piece
 // There is no CPU fallback anywhere in this file: without a HIP device augx_decoder_create fails.
 #include <hip/hip_runtime.h>
@@ -126,7 +126,7 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
     row[t * 4 + 3] = comb<MAX>(pre, v3);
 }
 
-__global__ void __launch_bounds__(64) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+__global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
     trellisPiece(*T, *B, lds, blockIdx.x);
 }
@@ -379,7 +379,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[1], st));
-    hipLaunchKernelGGL(kTrellis, dim3(n), dim3(64), 0, st, d->dT, b->dV);
+    hipLaunchKernelGGL(kTrellis, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);

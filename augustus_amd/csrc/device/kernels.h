@@ -21,6 +21,17 @@ namespace dev {
 #define WAVE_SYNC() ((void)0)
 #define GLOBAL_SYNC() ((void)0)
 #define AUGX_KFN inline
+// trellis kernel: NWAVES wavefronts per workgroup.  FOR_THREADS runs every thread of the workgroup, FOR_WAVES /
+// FOR_WLANES run "for each wavefront: its 64 lanes" (on the device each wavefront executes its own iteration only).
+#define FOR_THREADS(t) for (int t = 0; t < NT; ++t)
+#define FOR_WAVES(w) for (int w = 0; w < NWAVES; ++w)
+#define FOR_WLANES(t, w) for (int t = (w) * WAVE; t < (w) * WAVE + WAVE; ++t)
+#define TV(T, name) T name[NT]
+#define TV2(T, name, K) T name[K][NT]
+#define TI t
+#define TX(name) name[t]
+#define BLOCK_SYNC() ((void)0)
+#define BLOCK_GLOBAL_SYNC() ((void)0)
 #else
 #define FOR_LANES(l) for (int l = (int)threadIdx.x, _once = 1; _once; _once = 0)
 #define LV(T, name) T name[1]
@@ -33,7 +44,18 @@ namespace dev {
 // before re-reading global data this wave stored earlier (candidate lists, igenic column): drain the store queue
 #define GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define AUGX_KFN __device__ __forceinline__
+#define FOR_THREADS(t) for (int t = (int)threadIdx.x, _once = 1; _once; _once = 0)
+#define FOR_WAVES(w) for (int w = (int)(threadIdx.x >> 6), _oncew = 1; _oncew; _oncew = 0)
+#define FOR_WLANES(t, w) for (int t = (int)threadIdx.x, _once = 1; _once; _once = 0)
+#define TV(T, name) T name[1]
+#define TV2(T, name, K) T name[K][1]
+#define TI 0
+#define TX(name) name[0]
+// workgroup barrier that only orders LDS traffic (no wait for outstanding global stores)
+#define BLOCK_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
+#define BLOCK_GLOBAL_SYNC() __syncthreads()
 #endif
+constexpr int NWAVES = 4, NT = NWAVES * WAVE;
 
 // ------------------------------------------------------------------------------------------------
 // wave-wide argmax of (value, key): larger value wins, ties go to the larger key (= the candidate the
@@ -331,20 +353,21 @@ struct VarDesc {
 };
 
 constexpr int BLK = 8;          // bases per block: smaller than every lag except the lag-1 chain states
-constexpr int MAXPAIR = WAVE;   // gated (base, state) pairs handled per round
+constexpr int MAXPAIR = WAVE;   // gated (base, state) pairs handled per round (MAXPAIR / NWAVES per wavefront)
+constexpr int MAXPW = MAXPAIR / NWAVES;
 
 // wave-level bookkeeping primitives (device: cross-lane instructions; emulator: loops over the lane arrays)
 #ifdef AUGX_EMU
-inline void waveInclScan(int *v) { for (int l = 1; l < WAVE; l++) v[l] += v[l - 1]; }
-inline int waveRead(const int *v, int lane) { return v[lane]; }
+inline void waveInclScan(int *v, int w) { for (int l = 1; l < WAVE; l++) v[w * WAVE + l] += v[w * WAVE + l - 1]; }
+inline int waveRead(const int *v, int w, int lane) { return v[w * WAVE + lane]; }
 #else
-__device__ inline void waveInclScan(int *v) {
+__device__ inline void waveInclScan(int *v, int) {
     int x = v[0];
     const int lane = threadIdx.x & 63;
     for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
     v[0] = x;
 }
-__device__ inline int waveRead(const int *v, int lane) { return __shfl(v[0], lane, 64); }
+__device__ inline int waveRead(const int *v, int, int lane) { return __shfl(v[0], lane, 64); }
 #endif
 AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
@@ -379,8 +402,8 @@ struct TrellisLds {
     VarConst vc[SP];
     VarDesc desc[MAXPAIR];          // descriptors of the gated (base, state) pairs of the current round
     int pairJ[MAXPAIR], pairS[MAXPAIR];
-    double itVal[WAVE];             // one chunk of evaluated candidates
-    int itKey[WAVE], itAux[WAVE];
+    double itVal[NWAVES][WAVE];     // one chunk of evaluated candidates per wavefront
+    int itKey[NWAVES][WAVE], itAux[NWAVES][WAVE];
 };
 
 AUGX_HD int longRow(const DevTables &T, int s) {
@@ -713,7 +736,8 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
 }
 
 // gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`
-AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask) {
+// gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`; wavefront w takes every NWAVES-th pair
+AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w) {
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int n = X.n, S = X.S;
@@ -728,14 +752,17 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask) {
     }
     const int allPairs = off[BLK];
     for (int done = 0; done < allPairs; done += MAXPAIR) {
-        const int nPairs = allPairs - done < MAXPAIR ? allPairs - done : MAXPAIR;
-        LV(int, pj);
-        LV(int, ps);
-        LV(int, tot);
-        FOR_LANES(l) { // one lane per pair: locate the pair, build its descriptor
-            LX(pj) = -1; LX(ps) = 0; LX(tot) = 0;
+        const int roundPairs = allPairs - done < MAXPAIR ? allPairs - done : MAXPAIR;
+        const int nPairs = (roundPairs - w + NWAVES - 1) / NWAVES; // pairs done + w, done + w + NWAVES, ...
+        if (nPairs <= 0) continue;
+        TV(int, pj);
+        TV(int, ps);
+        TV(int, tot);
+        FOR_WLANES(t, w) { // one lane per pair: locate the pair, build its descriptor
+            const int l = t & 63;
+            TX(pj) = -1; TX(ps) = 0; TX(tot) = 0;
             if (l < nPairs) {
-                int want = done + l, dj = 0, first = 0;
+                int want = done + l * NWAVES + w, dj = 0, first = 0;
                 uint64_t gg = 0;
 #pragma unroll
                 for (int d2 = 0; d2 < BLK; d2++)
@@ -743,75 +770,79 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask) {
                 for (int k = want - first; k > 0; k--) gg &= gg - 1;
                 int s2 = 0;
                 while (!((gg >> s2) & 1)) s2++;
-                LX(pj) = jb + dj; LX(ps) = s2;
-                L.pairJ[l] = jb + dj; L.pairS[l] = s2;
-                varDescribe(X, s2, jb + dj, L.desc[l]);
-                LX(tot) = (B.dbgFlags & 2) ? 0 : L.desc[l].total;
+                TX(pj) = jb + dj; TX(ps) = s2;
+                L.pairJ[w * MAXPW + l] = jb + dj; L.pairS[w * MAXPW + l] = s2;
+                varDescribe(X, s2, jb + dj, L.desc[w * MAXPW + l]);
+                TX(tot) = (B.dbgFlags & 2) ? 0 : L.desc[w * MAXPW + l].total;
             }
         }
         WAVE_SYNC();
-        LV(int, ibase); // inclusive prefix of the candidate counts
-        FOR_LANES(l) { LX(ibase) = LX(tot); }
-        waveInclScan(ibase);
-        const int totalItems = waveRead(ibase, WAVE - 1);
-        LV(double, rbv);
-        LV(int, rbk);
-        LV(int, rba);
-        FOR_LANES(l) { LX(rbv) = AUGX_NINF; LX(rbk) = -2147483647; LX(rba) = -1; }
+        TV(int, ibase); // inclusive prefix of the candidate counts
+        FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
+        waveInclScan(ibase, w);
+        const int totalItems = waveRead(ibase, w, WAVE - 1);
+        TV(double, rbv);
+        TV(int, rbk);
+        TV(int, rba);
+        FOR_WLANES(t, w) { TX(rbv) = AUGX_NINF; TX(rbk) = -2147483647; TX(rba) = -1; }
         for (int base = 0; base < totalItems; base += WAVE) {
-            LV(int, myPair);
-            LV(int, myFirst);
-            FOR_LANES(l) { LX(myPair) = 0; LX(myFirst) = 0; }
+            TV(int, myPair);
+            TV(int, myFirst);
+            FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
             for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
-                const int first = q == 0 ? 0 : waveRead(ibase, q - 1); // all lanes active here (cross-lane read)
-                FOR_LANES(l) { if (first <= base + l) { LX(myPair) = q; LX(myFirst) = first; } }
+                const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
+                FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
             }
-            FOR_LANES(l) { // evaluate one candidate per lane
+            FOR_WLANES(t, w) { // evaluate one candidate per lane
+                const int l = t & 63;
                 int it = base + l;
                 if (it < totalItems) {
-                    const int q = LX(myPair);
-                    const int first = LX(myFirst);
+                    const int q = w * MAXPW + TX(myPair);
+                    const int first = TX(myFirst);
                     double v; int k2, a2;
                     varEvalItem(X, L.pairS[q], L.pairJ[q], L.desc[q], it - first, v, k2, a2);
-                    L.itVal[l] = v; L.itKey[l] = k2; L.itAux[l] = a2;
+                    L.itVal[w][l] = v; L.itKey[w][l] = k2; L.itAux[w][l] = a2;
                 }
             }
             WAVE_SYNC();
-            FOR_LANES(l) { // the lane of each pair folds the candidates of this chunk that belong to it
+            FOR_WLANES(t, w) { // the lane of each pair folds the candidates of this chunk that belong to it
+                const int l = t & 63;
                 if (l < nPairs) {
-                    int lo2 = (LX(ibase) - LX(tot)) - base, hi2 = LX(ibase) - base;
+                    int lo2 = (TX(ibase) - TX(tot)) - base, hi2 = TX(ibase) - base;
                     if (lo2 < 0) lo2 = 0;
                     if (hi2 > WAVE) hi2 = WAVE;
                     for (int q = lo2; q < hi2; q++)
-                        if (better(L.itVal[q], L.itKey[q], LX(rbv), LX(rbk))) { LX(rbv) = L.itVal[q]; LX(rbk) = L.itKey[q]; LX(rba) = L.itAux[q]; }
+                        if (better(L.itVal[w][q], L.itKey[w][q], TX(rbv), TX(rbk))) { TX(rbv) = L.itVal[w][q]; TX(rbk) = L.itKey[w][q]; TX(rba) = L.itAux[w][q]; }
                 }
             }
             WAVE_SYNC();
         }
-        FOR_LANES(l) {
+        FOR_WLANES(t, w) {
+            const int l = t & 63;
             if (l < nPairs) {
-                const int j = LX(pj), s2 = LX(ps);
+                const int j = TX(pj), s2 = TX(ps);
                 uint16_t bp = BP_NONE;
-                if (LX(rbv) > AUGX_NINF) {
+                if (TX(rbv) > AUGX_NINF) {
                     const int kind = L.vc[s2].kind;
-                    int eop = (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) ? LX(rbk) : LX(rbk) - L.vc[s2].g.bpl - 1;
-                    bp = bpVar(LX(rba), j - eop);
+                    int eop = (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) ? TX(rbk) : TX(rbk) - L.vc[s2].g.bpl - 1;
+                    bp = bpVar(TX(rba), j - eop);
                 }
-                L.ring[j & 63][s2] = LX(rbv);
+                L.ring[j & 63][s2] = TX(rbv);
                 L.bp[j & 63][s2] = bp;
-                if (B.cells) B.cells[(X.o + 1 + j) * S + s2] = LX(rbv);
+                if (B.cells) B.cells[(X.o + 1 + j) * S + s2] = TX(rbv);
             }
         }
         WAVE_SYNC();
     }
 }
 
+// One workgroup of NWAVES wavefronts per piece.  Thread t: st = t & 63 is "its" state, q4 = t >> 6 its quarter.
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int p) {
     TrellisCtx X(T, B, L, p);
     const int n = X.n, S = X.S, c = X.c;
     const int64_t o = X.o;
     if (c < 0) { // multi-class piece: not decoded by this version
-        FOR_LANES(l) { if (l == 0) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
+        FOR_THREADS(t) { if (t == 0) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
         return;
     }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
@@ -823,10 +854,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             int selfAi = 0;
             for (int ai = 0; ai < T.n_anc[sy]; ai++)
                 if (T.anc[sy][ai] == sy) selfAi = ai;
-            FOR_LANES(l) {
-                for (int q = l; q < n; q += WAVE)
+            FOR_THREADS(t) {
+                for (int q = t; q < n; q += NT)
                     for (int s2 = 0; s2 < SP; s2++) B.bp[(o + 1 + q) * SP + s2] = (s2 == sy && q >= 1) ? bpFixed(selfAi) : BP_NONE;
-                if (l == 0) {
+                if (t == 0) {
                     double v = B.initKind[p] == 0 ? T.ln_init[sy] : 0.0;
                     for (int q = 1; q < n; q++) v = v - T.ln4;
                     double tl = B.termKind[p] == 0 ? T.ln_term[sy] : 0.0;
@@ -838,18 +869,18 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             return;
         }
     }
-    // ---- per-lane constants: lane l owns state l.  cls: 0 chain (lag 1), 1 fixed lag, 2 variable, 3 RTERMINAL, -1 off
-    LV(int, hCls);
-    LV(int, hLag);
-    LV(int, hSig);
-    LV(int, hLong);
-    LV(int, hNanc);
-    LV2(int, hAnc, 5);
-    LV2(double, hTr, 5);
-    LV(int, hLrow);
-    LV(int, hList);
-    LV(int, hFrame);
-    LV(int, hIgenic);
+    // ---- per-thread constants of state st = t & 63.  cls: 0 chain (lag 1), 1 fixed lag, 2 variable, 3 RTERMINAL, -1 off
+    TV(int, hCls);
+    TV(int, hLag);
+    TV(int, hSig);
+    TV(int, hLong);
+    TV(int, hNanc);
+    TV2(int, hAnc, 5);
+    TV2(double, hTr, 5);
+    TV(int, hLrow);
+    TV(int, hList);
+    TV(int, hFrame);
+    TV(int, hIgenic);
     uint64_t maskVar = 0, maskRT = 0;
     for (int s2 = 0; s2 < S; s2++) {
         if (!T.reachable[s2]) continue;
@@ -857,121 +888,133 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         if (kind == AUGX_K_RTERMINAL) maskRT |= 1ull << s2;
         else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RINTERNAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) maskVar |= 1ull << s2;
     }
-    FOR_LANES(l) {
-        LX(hCls) = -1; LX(hLag) = -1; LX(hSig) = 0; LX(hLong) = 0; LX(hNanc) = 0; LX(hLrow) = -1; LX(hList) = -1; LX(hFrame) = 0; LX(hIgenic) = 0;
+    FOR_THREADS(t) {
+        const int l = t & 63;
+        TX(hCls) = -1; TX(hLag) = -1; TX(hSig) = 0; TX(hLong) = 0; TX(hNanc) = 0; TX(hLrow) = -1; TX(hList) = -1; TX(hFrame) = 0; TX(hIgenic) = 0;
 #pragma unroll
-        for (int i = 0; i < 5; i++) { hAnc[i][LI] = 0; hTr[i][LI] = AUGX_NINF; }
+        for (int i = 0; i < 5; i++) { hAnc[i][TI] = 0; hTr[i][TI] = AUGX_NINF; }
         if (l < S && T.reachable[l]) {
             const int kind = T.kind[l];
-            LX(hCls) = kind == AUGX_K_RTERMINAL ? 3 : 2;
+            TX(hCls) = kind == AUGX_K_RTERMINAL ? 3 : 2;
             switch (kind) {
-            case AUGX_K_IGENIC: LX(hLag) = 1; LX(hSig) = SIG_EIG; LX(hCls) = 0; break;
-            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: LX(hLag) = 1; LX(hSig) = SIG_EIN; LX(hCls) = 0; break;
-            case AUGX_K_LONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSF; LX(hCls) = 1; break;
-            case AUGX_K_RLONGDSS: LX(hLag) = dssWhole; LX(hSig) = SIG_DSSR; LX(hCls) = 1; break;
-            case AUGX_K_LONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSF; LX(hCls) = 1; break;
-            case AUGX_K_RLONGASS: LX(hLag) = assLag; LX(hSig) = SIG_ASSR; LX(hCls) = 1; break;
-            case AUGX_K_EQUALD: case AUGX_K_REQUALD: LX(hLag) = dL; LX(hSig) = SIG_EQD; LX(hLong) = dL >= WAVE; LX(hCls) = 1; break;
+            case AUGX_K_IGENIC: TX(hLag) = 1; TX(hSig) = SIG_EIG; TX(hCls) = 0; break;
+            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: TX(hLag) = 1; TX(hSig) = SIG_EIN; TX(hCls) = 0; break;
+            case AUGX_K_LONGDSS: TX(hLag) = dssWhole; TX(hSig) = SIG_DSSF; TX(hCls) = 1; break;
+            case AUGX_K_RLONGDSS: TX(hLag) = dssWhole; TX(hSig) = SIG_DSSR; TX(hCls) = 1; break;
+            case AUGX_K_LONGASS: TX(hLag) = assLag; TX(hSig) = SIG_ASSF; TX(hCls) = 1; break;
+            case AUGX_K_RLONGASS: TX(hLag) = assLag; TX(hSig) = SIG_ASSR; TX(hCls) = 1; break;
+            case AUGX_K_EQUALD: case AUGX_K_REQUALD: TX(hLag) = dL; TX(hSig) = SIG_EQD; TX(hLong) = dL >= WAVE; TX(hCls) = 1; break;
             default: break;
             }
-            if (LX(hLag) > 0) {
-                LX(hNanc) = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
+            if (TX(hLag) > 0) {
+                TX(hNanc) = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
 #pragma unroll
                 for (int ai = 0; ai < 5; ai++) {
-                    if (ai >= LX(hNanc)) continue;
+                    if (ai >= TX(hNanc)) continue;
                     int a = T.anc[l][ai];
-                    hAnc[ai][LI] = LX(hLong) ? longRow(T, a) : a;
-                    hTr[ai][LI] = lnT(T, c, a, l);
+                    hAnc[ai][TI] = TX(hLong) ? longRow(T, a) : a;
+                    hTr[ai][TI] = lnT(T, c, a, l);
                 }
             }
-            LX(hLrow) = longRow(T, l);
-            LX(hFrame) = T.win[l];
-            LX(hIgenic) = kind == AUGX_K_IGENIC;
-            LX(hList) = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
-            // LDS copy of the constants of the variable-length states
-            VarConst &VC = L.vc[l];
-            VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
-            for (int ai = 0; ai < 4; ai++) {
-                int a = ai < VC.nanc ? T.anc[l][ai] : 0;
-                VC.anc[ai] = a; VC.ancWin[ai] = T.win[a]; VC.tr[ai] = ai < VC.nanc ? lnT(T, c, a, l) : AUGX_NINF;
+            TX(hLrow) = longRow(T, l);
+            TX(hFrame) = T.win[l];
+            TX(hIgenic) = kind == AUGX_K_IGENIC;
+            TX(hList) = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
+            if (t < WAVE) { // LDS copy of the constants of the variable-length states
+                VarConst &VC = L.vc[l];
+                VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
+                for (int ai = 0; ai < 4; ai++) {
+                    int a = ai < VC.nanc ? T.anc[l][ai] : 0;
+                    VC.anc[ai] = a; VC.ancWin[ai] = T.win[a]; VC.tr[ai] = ai < VC.nanc ? lnT(T, c, a, l) : AUGX_NINF;
+                }
+                VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
             }
-            VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
         }
     }
     // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
-    FOR_LANES(l) {
-        if (l < SP) {
+    FOR_THREADS(t) {
+        if (t < SP) {
+            const int l = t;
             double v = AUGX_NINF;
             if (l < S) v = B.initKind[p] == 0 ? T.ln_init[l] : (l == T.synch ? 0.0 : AUGX_NINF);
             L.ring[0][l] = v;
             L.bp[0][l] = BP_NONE;
             if (l < S) {
-                if (LX(hLrow) >= 0) B.longV[(o + 1) * 6 + LX(hLrow)] = v;
+                if (TX(hLrow) >= 0) B.longV[(o + 1) * 6 + TX(hLrow)] = v;
                 if (B.cells) B.cells[(o + 1) * S + l] = v;
-                if (LX(hIgenic)) { B.vig[o + 1] = v; L.vigw[0] = v; }
+                if (TX(hIgenic)) { B.vig[o + 1] = v; L.vigw[0] = v; }
             }
         }
     }
     X.vigLo = -1;
     X.P.wcode = L.codew;
     X.P.wns = L.nsw;
-    WAVE_SYNC();
+    BLOCK_SYNC();
     for (int j0 = 0; j0 < n; j0 += WAVE) {
-        // ---- load the tile of per-base records for bases j0..j0+63 and advance the LDS windows (coalesced)
-        FOR_LANES(l) {
-            int q = j0 + l;
-            int64_t gq = o + 1 + q;
-            for (int i = 0; i < NSIG; i++) L.sig[l][i] = B.sig[gq * NSIG + i];
-            L.gate[l] = B.gate[gq];
-            for (int i = 0; i < NSITE; i++) L.site[l][i] = B.site[gq * NSITE + i];
-            if (q != 0) for (int s2 = 0; s2 < SP; s2++) L.bp[l][s2] = BP_NONE;
-            // code window: bases [j0+64, j0+128) (first tile: also [0, 64))
-            for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
-                int qq = j0 + r * WAVE + l;
-                if (qq < n) L.codew[qq & (CODE_WIN - 1)] = B.code[o + 1 + qq];
-            }
-            // stop tables: bases [j0+16, j0+80) (first tile: also [0, 16))
-            for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
-                int qq = r == 0 ? l : j0 + 16 + l;
-                if (r == 0 && l >= 16) continue;
-                if (qq < n) for (int f = 0; f < 6; f++) L.nsw[(qq & (NS_WIN - 1)) * 6 + f] = (uint32_t)B.nsm[fidx(o + 1 + qq, f, 6)];
-            }
-            // site counts: bases [j0+64, j0+128) (first tile: also [0, 64))
-            for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
-                int qq = j0 + r * WAVE + l;
-                if (qq < n) for (int f = 0; f < 6; f++) L.cntw[qq & (CNT_WIN - 1)][f] = (uint32_t)B.cnt[fidx(o + 1 + qq, CNT_ATG + f, NCNT)];
-            }
-            // content prefix sums and reverse P_ls terms of the bases of this tile
-            if (q < n) {
-                for (int f = 0; f < NFX; f++) L.fxw[q & (FX_WIN - 1)][f] = B.fx[fidx(gq, f, NFX)];
-                for (int f = 0; f < 3; f++) L.plsRw[q & (FX_WIN - 1)][f] = B.plsR[gq * 3 + f];
-            }
-            // predecessor cells of the equalD states (lag dStateLen >= 64: written long ago by this wavefront)
-            for (int f = 0; f < 6; f++) L.eqPrev[l][f] = (dL >= WAVE && q - dL >= 0 && q < n) ? B.longV[(gq - dL) * 6 + f] : AUGX_NINF;
-            // candidate-side constants of the list entries whose site lies in this tile
-            if (q < n) {
-                for (int sel = 0; sel < 4; sel++) {
-                    int si = L.site[l][sel];
-                    if (si < 0) continue;
-                    const int sl = si & (LIST_WIN - 1);
-                    L.lcPos[sel][sl] = q;
-                    for (int a = 0; a < 3; a++) {
-                        if (sel == 0) { L.lcC[0][sl][a] = B.laPls[(X.lo + si) * 3 + a]; L.lcFx[0][sl][a] = B.laFx[(X.lo + si) * 3 + a]; }
-                        if (sel == 1) { L.lcC[1][sl][a] = B.lrEt[(X.lo + si) * 3 + a]; L.lcFx[1][sl][a] = B.lrFx[(X.lo + si) * 3 + a]; }
-                    }
-                    if (sel == 2) L.lcFx[2][sl][0] = B.ldFx[X.lo + si];
-                    if (sel == 3) L.lcFx[3][sl][0] = B.rdFx[X.lo + si];
+        BLOCK_GLOBAL_SYNC(); // everything this workgroup stored to HBM so far is visible to its own later loads
+        // ---- load the tile of per-base records for bases j0..j0+63 and advance the LDS windows; the four
+        //      wavefronts share the work by record type (every row of 64 loads is coalesced)
+        FOR_THREADS(t) {
+            const int l = t & 63, q4 = t >> 6;
+            const int q = j0 + l;
+            const int64_t gq = o + 1 + q;
+            if (q4 == 0) {
+                for (int i = 0; i < NSIG; i++) L.sig[l][i] = B.sig[gq * NSIG + i];
+                L.gate[l] = B.gate[gq];
+                for (int i = 0; i < NSITE; i++) L.site[l][i] = B.site[gq * NSITE + i];
+                if (q != 0) for (int s2 = 0; s2 < SP; s2++) L.bp[l][s2] = BP_NONE;
+            } else if (q4 == 1) {
+                // code window: bases [j0+64, j0+128) (first tile: also [0, 64))
+                for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
+                    int qq = j0 + r * WAVE + l;
+                    if (qq < n) L.codew[qq & (CODE_WIN - 1)] = B.code[o + 1 + qq];
                 }
-                // start codons of this tile
-                uint32_t ac = (uint32_t)B.cnt[fidx(gq, CNT_ATG, NCNT)], ap = (uint32_t)B.cnt[fidx(gq - 1, CNT_ATG, NCNT)];
-                if (ac != ap) {
-                    const int ai2 = (int)ac - 1, sl = ai2 & (ATG_WIN - 1);
-                    L.aPos[sl] = q;
-                    for (int a = 0; a < 3; a++) L.aD[sl][a] = B.atgD[(X.lo + ai2) * 3 + a];
-                    L.aFx[sl] = B.atgFx[X.lo + ai2];
+                // stop tables: bases [j0+16, j0+80) (first tile: also [0, 16))
+                for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
+                    int qq = r == 0 ? l : j0 + 16 + l;
+                    if (r == 0 && l >= 16) continue;
+                    if (qq < n) for (int f = 0; f < 6; f++) L.nsw[(qq & (NS_WIN - 1)) * 6 + f] = (uint32_t)B.nsm[fidx(o + 1 + qq, f, 6)];
+                }
+                // site counts: bases [j0+64, j0+128) (first tile: also [0, 64))
+                for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
+                    int qq = j0 + r * WAVE + l;
+                    if (qq < n) for (int f = 0; f < 6; f++) L.cntw[qq & (CNT_WIN - 1)][f] = (uint32_t)B.cnt[fidx(o + 1 + qq, CNT_ATG + f, NCNT)];
+                }
+            } else if (q4 == 2) {
+                // content prefix sums and reverse P_ls terms of the bases of this tile
+                if (q < n) {
+                    for (int f = 0; f < NFX; f++) L.fxw[q & (FX_WIN - 1)][f] = B.fx[fidx(gq, f, NFX)];
+                    for (int f = 0; f < 3; f++) L.plsRw[q & (FX_WIN - 1)][f] = B.plsR[gq * 3 + f];
+                }
+            } else {
+                // predecessor cells of the equalD states (lag dStateLen >= 64: written long ago by this workgroup)
+                for (int f = 0; f < 6; f++) L.eqPrev[l][f] = (dL >= WAVE && q - dL >= 0 && q < n) ? B.longV[(gq - dL) * 6 + f] : AUGX_NINF;
+                // candidate-side constants of the list entries whose site lies in this tile
+                if (q < n) {
+                    for (int sel = 0; sel < 4; sel++) {
+                        int si = B.site[gq * NSITE + sel];
+                        if (si < 0) continue;
+                        const int sl = si & (LIST_WIN - 1);
+                        L.lcPos[sel][sl] = q;
+                        for (int a = 0; a < 3; a++) {
+                            if (sel == 0) { L.lcC[0][sl][a] = B.laPls[(X.lo + si) * 3 + a]; L.lcFx[0][sl][a] = B.laFx[(X.lo + si) * 3 + a]; }
+                            if (sel == 1) { L.lcC[1][sl][a] = B.lrEt[(X.lo + si) * 3 + a]; L.lcFx[1][sl][a] = B.lrFx[(X.lo + si) * 3 + a]; }
+                        }
+                        if (sel == 2) L.lcFx[2][sl][0] = B.ldFx[X.lo + si];
+                        if (sel == 3) L.lcFx[3][sl][0] = B.rdFx[X.lo + si];
+                    }
+                    // start codons of this tile
+                    uint32_t ac = (uint32_t)B.cnt[fidx(gq, CNT_ATG, NCNT)], ap = (uint32_t)B.cnt[fidx(gq - 1, CNT_ATG, NCNT)];
+                    if (ac != ap) {
+                        const int ai2 = (int)ac - 1, sl = ai2 & (ATG_WIN - 1);
+                        L.aPos[sl] = q;
+                        for (int a = 0; a < 3; a++) L.aD[sl][a] = B.atgD[(X.lo + ai2) * 3 + a];
+                        L.aFx[sl] = B.atgFx[X.lo + ai2];
+                    }
                 }
             }
         }
+        BLOCK_SYNC();
         {
             int hi = j0 + 2 * WAVE < n ? j0 + 2 * WAVE : n;
             X.P.wcHi = hi; X.P.wcLo = hi - CODE_WIN > 0 ? hi - CODE_WIN : 0;
@@ -987,90 +1030,90 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             X.listHi3 = (int)X.cntAt(hf - 1, CNT_RD) - 1;
             X.atgHi = (int)X.cntAt(hf - 1, CNT_ATG) - 1;
         }
-        GLOBAL_SYNC();
-        WAVE_SYNC();
         for (int jb = j0; jb < j0 + WAVE && jb < n; jb += BLK) {
-            // ---- step 1: fixed-length states with lag > BLK: lane = state, BLK independent cells each
-            FOR_LANES(l) {
-                if (LX(hCls) == 1) {
-                    const int lag = LX(hLag), nanc = LX(hNanc);
-                    double emi[BLK], pv0[BLK], pv1[BLK];
+            // ---- step 1: fixed-length states with lag > BLK: thread = (state, quarter of the block)
+            constexpr int CPT = BLK / NWAVES; // cells per thread
+            FOR_THREADS(t) {
+                const int l = t & 63, q4 = t >> 6;
+                if (TX(hCls) == 1) {
+                    const int lag = TX(hLag), nanc = TX(hNanc);
+                    double emi[CPT], pv0[CPT], pv1[CPT];
 #pragma unroll
-                    for (int dj = 0; dj < BLK; dj++) { // independent LDS loads first
-                        const int j = jb + dj, jp = j - lag;
-                        emi[dj] = L.sig[j & 63][LX(hSig)];
-                        pv0[dj] = AUGX_NINF; pv1[dj] = AUGX_NINF;
+                    for (int d = 0; d < CPT; d++) { // independent LDS loads first
+                        const int j = jb + q4 * CPT + d, jp = j - lag;
+                        emi[d] = L.sig[j & 63][TX(hSig)];
+                        pv0[d] = AUGX_NINF; pv1[d] = AUGX_NINF;
                         if (jp >= 0) {
-                            if (LX(hLong)) { pv0[dj] = L.eqPrev[j & 63][hAnc[0][LI]]; if (nanc > 1) pv1[dj] = L.eqPrev[j & 63][hAnc[1][LI]]; }
-                            else { pv0[dj] = L.ring[jp & 63][hAnc[0][LI]]; if (nanc > 1) pv1[dj] = L.ring[jp & 63][hAnc[1][LI]]; }
+                            if (TX(hLong)) { pv0[d] = L.eqPrev[j & 63][hAnc[0][TI]]; if (nanc > 1) pv1[d] = L.eqPrev[j & 63][hAnc[1][TI]]; }
+                            else { pv0[d] = L.ring[jp & 63][hAnc[0][TI]]; if (nanc > 1) pv1[d] = L.ring[jp & 63][hAnc[1][TI]]; }
                         }
                     }
 #pragma unroll
-                    for (int dj = 0; dj < BLK; dj++) {
-                        const int j = jb + dj;
+                    for (int d = 0; d < CPT; d++) {
+                        const int j = jb + q4 * CPT + d;
                         if (j < 1 || j >= n) continue;
                         double best = AUGX_NINF;
                         uint16_t bp = BP_NONE;
-                        if (j - lag >= 0 && emi[dj] > AUGX_NINF) {
-                            if (pv0[dj] > AUGX_NINF) { best = pv0[dj] + (hTr[0][LI] + emi[dj]); bp = bpFixed(0); }
-                            if (nanc > 1 && pv1[dj] > AUGX_NINF) {
-                                double v2 = pv1[dj] + (hTr[1][LI] + emi[dj]);
+                        if (j - lag >= 0 && emi[d] > AUGX_NINF) {
+                            if (pv0[d] > AUGX_NINF) { best = pv0[d] + (hTr[0][TI] + emi[d]); bp = bpFixed(0); }
+                            if (nanc > 1 && pv1[d] > AUGX_NINF) {
+                                double v2 = pv1[d] + (hTr[1][TI] + emi[d]);
                                 if (v2 > best) { best = v2; bp = bpFixed(1); }
                             }
                         }
                         L.ring[j & 63][l] = best;
                         L.bp[j & 63][l] = bp;
-                        if (LX(hLrow) >= 0) B.longV[(o + 1 + j) * 6 + LX(hLrow)] = best;
+                        if (TX(hLrow) >= 0) B.longV[(o + 1 + j) * 6 + TX(hLrow)] = best;
                         if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
-                        if (LX(hList) >= 0) {
-                            int si = L.site[j & 63][LX(hList)];
+                        if (TX(hList) >= 0) {
+                            int si = L.site[j & 63][TX(hList)];
                             if (si >= 0) {
-                                double *lval = LX(hList) == 0 ? B.laVal : LX(hList) == 1 ? B.lrVal : LX(hList) == 2 ? B.ldVal : B.rdVal;
-                                lval[(X.lo + si) * 3 + LX(hFrame)] = best;
-                                L.lcVal[LX(hList)][si & (LIST_WIN - 1)][LX(hFrame)] = best;
+                                double *lval = TX(hList) == 0 ? B.laVal : TX(hList) == 1 ? B.lrVal : TX(hList) == 2 ? B.ldVal : B.rdVal;
+                                lval[(X.lo + si) * 3 + TX(hFrame)] = best;
+                                L.lcVal[TX(hList)][si & (LIST_WIN - 1)][TX(hFrame)] = best;
                             }
                         }
                     }
-                }
-            }
-            WAVE_SYNC();
-            // ---- step 2: variable-length states (all but RTERMINAL): they depend on fixed-state cells (just published)
-            //      and on igenic cells at least BLK bases back
-            uint64_t anyVar = 0, anyRT = 0;
-            for (int dj = 0; dj < BLK; dj++) {
-                int j = jb + dj;
-                if (j >= 1 && j < n) { uint64_t gg = L.gate[j & 63]; anyVar |= gg & maskVar; anyRT |= gg & maskRT; }
-            }
-            // cells of variable-length states are absent unless their gate is open and a candidate survives
-            FOR_LANES(l) {
-                if (LX(hCls) >= 2 || (l < SP && LX(hCls) < 0)) {
-                    for (int dj = 0; dj < BLK; dj++) {
-                        const int j = jb + dj;
+                } else if (TX(hCls) >= 2 || (l < SP && TX(hCls) < 0)) {
+                    // cells of variable-length states are absent unless their gate is open and a candidate survives
+#pragma unroll
+                    for (int d = 0; d < CPT; d++) {
+                        const int j = jb + q4 * CPT + d;
                         if (j < 1 || j >= n) continue;
                         L.ring[j & 63][l] = AUGX_NINF;
                         if (B.cells && l < S) B.cells[(o + 1 + j) * S + l] = AUGX_NINF;
                     }
                 }
             }
-            WAVE_SYNC();
-            if (anyVar && !(B.dbgFlags & 1)) {
-                GLOBAL_SYNC();
-                trellisVarBlock(X, jb, maskVar);
+            BLOCK_SYNC();
+            // ---- step 2: variable-length states (all but RTERMINAL): they depend on fixed-state cells (just published)
+            //      and on igenic cells at least BLK bases back.  Pairs are dealt round-robin to the wavefronts.
+            uint64_t anyVar = 0, anyRT = 0;
+            for (int dj = 0; dj < BLK; dj++) {
+                int j = jb + dj;
+                if (j >= 1 && j < n) { uint64_t gg = L.gate[j & 63]; anyVar |= gg & maskVar; anyRT |= gg & maskRT; }
             }
-            // ---- step 3: the lag-1 chain states (igenic, geometric), one lane per state, BLK bases in sequence
-            FOR_LANES(l) {
-                if (LX(hCls) == 0) {
-                    const int nanc = LX(hNanc);
+            // (HBM re-reads only touch data at least one tile old -- the LDS caches cover 64 sites / 512 bases -- and
+            //  the store queue is drained at every tile boundary, so no wait is needed here)
+            if (anyVar && !(B.dbgFlags & 1)) {
+                FOR_WAVES(w) { trellisVarBlock(X, jb, maskVar, w); }
+                BLOCK_SYNC();
+            }
+            // ---- step 3: the lag-1 chain states (igenic, geometric), one lane of wavefront 0 per state, BLK bases in sequence
+            FOR_THREADS(t) {
+                const int l = t;
+                if (t < WAVE && TX(hCls) == 0) {
+                    const int nanc = TX(hNanc);
                     double emi[BLK], pv[5][BLK];
                     int selfAi = -1;
 #pragma unroll
-                    for (int ai = 0; ai < 5; ai++) if (ai < nanc && hAnc[ai][LI] == l) selfAi = ai;
+                    for (int ai = 0; ai < 5; ai++) if (ai < nanc && hAnc[ai][TI] == l) selfAi = ai;
 #pragma unroll
                     for (int dj = 0; dj < BLK; dj++) { // independent LDS loads first
                         const int j = jb + dj;
-                        emi[dj] = L.sig[j & 63][LX(hSig)];
+                        emi[dj] = L.sig[j & 63][TX(hSig)];
 #pragma unroll
-                        for (int ai = 0; ai < 5; ai++) pv[ai][dj] = (ai < nanc && j >= 1) ? L.ring[(j - 1) & 63][hAnc[ai][LI]] : AUGX_NINF;
+                        for (int ai = 0; ai < 5; ai++) pv[ai][dj] = (ai < nanc && j >= 1) ? L.ring[(j - 1) & 63][hAnc[ai][TI]] : AUGX_NINF;
                     }
                     double prev = AUGX_NINF; // own value at j-1 once inside the block
 #pragma unroll
@@ -1085,7 +1128,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                                 if (ai >= nanc) continue;
                                 double pvv = (ai == selfAi && dj > 0 && j - 1 >= 1 && j - 1 >= jb) ? prev : pv[ai][dj];
                                 if (!(pvv > AUGX_NINF)) continue;
-                                double val = pvv + (hTr[ai][LI] + emi[dj]);
+                                double val = pvv + (hTr[ai][TI] + emi[dj]);
                                 if (val > best) { best = val; bp = bpFixed(ai); }
                             }
                         }
@@ -1093,7 +1136,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                         L.ring[j & 63][l] = best;
                         L.bp[j & 63][l] = bp;
                         if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
-                        if (LX(hIgenic)) { B.vig[o + 1 + j] = best; L.vigw[j & (VIG_WIN - 1)] = best; }
+                        if (TX(hIgenic)) { B.vig[o + 1 + j] = best; L.vigw[j & (VIG_WIN - 1)] = best; }
                     }
                 }
             }
@@ -1101,25 +1144,26 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
                 X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
             }
-            WAVE_SYNC();
+            BLOCK_SYNC();
             // ---- step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
             if (anyRT && !(B.dbgFlags & 1)) {
-                GLOBAL_SYNC();
-                trellisVarBlock(X, jb, maskRT);
+                FOR_WAVES(w) { trellisVarBlock(X, jb, maskRT, w); }
+                BLOCK_SYNC();
             }
         }
         // ---- flush the back-pointer tile
-        FOR_LANES(l) {
-            for (int r = 0; r < WAVE; r++) {
+        FOR_THREADS(t) {
+            const int l = t & 63, q4 = t >> 6;
+            for (int r = q4; r < WAVE; r += NWAVES) {
                 int q = j0 + r;
                 if (q < n && l < SP) B.bp[(o + 1 + q) * SP + l] = L.bp[r][l];
             }
         }
-        WAVE_SYNC();
+        BLOCK_SYNC();
     }
     // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)
-    FOR_LANES(l) {
-        if (l == 0) {
+    FOR_THREADS(t) {
+        if (t == 0) {
             double maxV = AUGX_NINF;
             int state = -1;
             for (int i = 0; i < S; i++) {
