@@ -55,7 +55,7 @@ namespace dev {
 #define BLOCK_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
 #define BLOCK_GLOBAL_SYNC() __syncthreads()
 #endif
-constexpr int NWAVES = 4, NT = NWAVES * WAVE;
+constexpr int NWAVES = 8, NT = NWAVES * WAVE;
 
 // ------------------------------------------------------------------------------------------------
 // wave-wide argmax of (value, key): larger value wins, ties go to the larger key (= the candidate the
@@ -349,7 +349,7 @@ struct VarDesc {
     int a;                  // phase of the content prefix fields
     uint64_t eFx;           // content prefix at the end-side boundary
     double eD0, plsEnd;     // end-side content term (exon-terminal fwd / initial-content rev), reverse-strand ln P_ls
-    const double *lenTab;   // length distribution of this exon type
+    int lenSel;             // length distribution of this exon type: 0 single, 1 initial, 2 internal, 3 terminal
 };
 
 constexpr int BLK = 8;          // bases per block: smaller than every lag except the lag-1 chain states
@@ -389,6 +389,8 @@ struct TrellisLds {
     uint8_t codew[CODE_WIN];
     uint32_t nsw[NS_WIN * 6];
     uint32_t cntw[CNT_WIN][6];      // site counts (ATG, LA, LR, LD, RD, RS) at bases <= q
+    double lenw[4][LEN_WIN];        // ln(3 P(len)) of single / initial / internal / terminal exons, len < LEN_WIN
+    double leniw[LENI_MAX];         // ln P(len) of short introns
     double vigw[VIG_WIN];           // igenic column
     uint64_t fxw[FX_WIN][NFX];      // content prefix sums of bases [j0-64, j0+64)
     double plsRw[FX_WIN][3];
@@ -399,6 +401,10 @@ struct TrellisLds {
     int32_t aPos[ATG_WIN];          // newest start-codon entries
     double aD[ATG_WIN][3];
     uint64_t aFx[ATG_WIN];
+    int chainIds[8], nChain;         // the lag-1 chain states (igenic + geometric introns)
+    double chV[8][BLK][5];          // step 3 scratch: candidate value per (chain state, base, ancestor)
+    double chPs[8][BLK], chTe[8][BLK], chB[8][BLK][2];
+    int chA[8][BLK][2];
     VarConst vc[SP];
     VarDesc desc[MAXPAIR];          // descriptors of the gated (base, state) pairs of the current round
     int pairJ[MAXPAIR], pairS[MAXPAIR];
@@ -472,6 +478,11 @@ struct TrellisCtx {
         if (q >= fwLo && q < fwHi) return L.fxw[q & (FX_WIN - 1)][f];
         return B.fx[fidx(o + 1 + q, f, NFX)];
     }
+    AUGX_HD double lenAt(int sel, int len) const {
+        if (len < LEN_WIN) return L.lenw[sel][len];
+        return (sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
+    }
+    AUGX_HD double lenIAt(int len) const { return T.d < LENI_MAX ? L.leniw[len] : T.len_intron[len]; }
     AUGX_HD double plsRAt(int q, int fr) const {
         if (q >= fwLo && q < fwHi) return L.plsRw[q & (FX_WIN - 1)][fr];
         return B.plsR[(o + 1 + q) * 3 + fr];
@@ -494,7 +505,7 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
     D.kind = kind; D.win = win; D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
     D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cod0 = D.cod1 = D.cod2 = 4; D.endP = AUGX_NINF;
     D.g = VC.g;
-    D.a = 0; D.eFx = 0; D.eD0 = 0.0; D.plsEnd = 0.0; D.lenTab = T.len_internal;
+    D.a = 0; D.eFx = 0; D.eD0 = 0.0; D.plsEnd = 0.0; D.lenSel = 2;
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
@@ -538,23 +549,23 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
         case AUGX_K_INTERNAL: case AUGX_K_INITIAL:
             D.eFx = X.fxAt(right - T.Le, fb + 0);
             D.eD0 = T.Le > 0 ? (double)(int64_t)(X.fxAt(right, fb + 2) - X.fxAt(right - T.Le, fb + 2)) * AUGX_FX_INV : 0.0;
-            D.lenTab = kind == AUGX_K_INTERNAL ? T.len_internal : T.len_initial;
+            D.lenSel = kind == AUGX_K_INTERNAL ? 2 : 1;
             break;
         case AUGX_K_TERMINAL: case AUGX_K_SINGLE:
             D.eFx = X.fxAt(right, fb + 0);
-            D.lenTab = kind == AUGX_K_TERMINAL ? T.len_terminal : T.len_single;
+            D.lenSel = kind == AUGX_K_TERMINAL ? 3 : 0;
             break;
         default: {
             const int boip = right - (k - 1);
             D.plsEnd = (k > 0 && boip >= 0) ? X.plsRAt(right, mod3(e.fOR + right - boip)) : 0.0;
             if (kind == AUGX_K_RINTERNAL || kind == AUGX_K_RTERMINAL) {
                 D.eFx = X.fxAt(boip - 1, fb + 0);
-                D.lenTab = kind == AUGX_K_RINTERNAL ? T.len_internal : T.len_terminal;
+                D.lenSel = kind == AUGX_K_RINTERNAL ? 2 : 3;
             } else {
                 const int boi = boip - T.Li;
                 D.eFx = X.fxAt(boi - 1, fb + 0);
                 D.eD0 = T.Li > 0 ? (double)(int64_t)(X.fxAt(boip - 1, fb + 1) - X.fxAt(boi - 1, fb + 1)) * AUGX_FX_INV : 0.0;
-                D.lenTab = kind == AUGX_K_RINITIAL ? T.len_initial : T.len_single;
+                D.lenSel = kind == AUGX_K_RINITIAL ? 1 : 0;
             }
         }
         }
@@ -618,7 +629,7 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         if (intronLength > T.d) return;
         double restSeq = idx < D.nList ? (double)(int64_t)(D.eFx - X.listFx(D.listSel, D.i1 - 1 - idx, 0)) * AUGX_FX_INV
                                        : P.seg(fwd ? FX_INF : FX_INR, begin, j);
-        double emi = T.len_intron[intronLength] + restSeq;
+        double emi = X.lenIAt(intronLength) + restSeq;
         if (!(emi > AUGX_NINF)) return;
         val = pv + (VC.tr[0] + emi);
         key = eop; aux = 0;
@@ -658,7 +669,7 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
             if (ok) {
                 fast = true;
                 double lenPart = AUGX_NINF;
-                if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_SINGLE ? len % 3 == 0 : (len % 3 == win && len > 2))) lenPart = D.lenTab[len];
+                if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_SINGLE ? len % 3 == 0 : (len % 3 == win && len > 2))) lenPart = X.lenAt(D.lenSel, len);
                 if (!(lenPart > AUGX_NINF)) return;
                 double seg1 = (double)(int64_t)(D.eFx - cFxA) * AUGX_FX_INV;
                 double inner = kind == AUGX_K_SINGLE ? (cInit + seg1) : ((cInit + seg1) + D.eD0);
@@ -672,7 +683,7 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
             if (ok) {
                 fast = true;
                 double lenPart = AUGX_NINF;
-                if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RSINGLE ? len % 3 == 0 : mod3(2 - len) == win)) lenPart = D.lenTab[len];
+                if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RSINGLE ? len % 3 == 0 : mod3(2 - len) == win)) lenPart = X.lenAt(D.lenSel, len);
                 if (!(lenPart > AUGX_NINF)) return;
                 const int64_t ri = (int64_t)X.cntAt(bob, CNT_RS) - 1; // the reverse stop codon at bob = bs-3
                 double seg1 = (double)(int64_t)(D.eFx - B.rsFx[(X.lo + ri) * 3 + D.a]) * AUGX_FX_INV;
@@ -703,7 +714,7 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
             if (fwd) {
                 if (kind == AUGX_K_TERMINAL || m >= k + T.Le - 1) {
                     fast = true;
-                    double lenPart = (len >= 1 && len <= T.max_exon_len) ? D.lenTab[len] : AUGX_NINF;
+                    double lenPart = (len >= 1 && len <= T.max_exon_len) ? X.lenAt(D.lenSel, len) : AUGX_NINF;
                     if (!(lenPart > AUGX_NINF)) return;
                     double seg1 = (double)(int64_t)(D.eFx - X.listFx(0, li, D.a)) * AUGX_FX_INV;
                     double inner = kind == AUGX_K_TERMINAL ? seg1 : (seg1 + D.eD0);
@@ -714,7 +725,7 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
                 const bool ok = kind == AUGX_K_RINTERNAL ? (eot < boip) : (boi >= bs && eot < boi);
                 if (ok) {
                     fast = true;
-                    double lenPart = (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RINTERNAL || len > 2)) ? D.lenTab[len] : AUGX_NINF;
+                    double lenPart = (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RINTERNAL || len > 2)) ? X.lenAt(D.lenSel, len) : AUGX_NINF;
                     if (!(lenPart > AUGX_NINF)) return;
                     double seg1 = (double)(int64_t)(D.eFx - X.listFx(1, li, D.a)) * AUGX_FX_INV;
                     double cEt = X.listC(1, li, D.a);
@@ -737,7 +748,8 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
 
 // gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`
 // gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`; wavefront w takes every NWAVES-th pair
-AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w) {
+AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int stride) {
+    // stride == NWAVES: the pairs of `mask` are dealt round-robin to the wavefronts; stride == 1: this wavefront takes all
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int n = X.n, S = X.S;
@@ -751,9 +763,10 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w) {
         off[dj + 1] = off[dj] + popc64(g[dj]);
     }
     const int allPairs = off[BLK];
-    for (int done = 0; done < allPairs; done += MAXPAIR) {
-        const int roundPairs = allPairs - done < MAXPAIR ? allPairs - done : MAXPAIR;
-        const int nPairs = (roundPairs - w + NWAVES - 1) / NWAVES; // pairs done + w, done + w + NWAVES, ...
+    const int first0 = stride == 1 ? 0 : w, perRound = MAXPW * stride;
+    for (int done = 0; done < allPairs; done += perRound) {
+        const int roundPairs = allPairs - done < perRound ? allPairs - done : perRound;
+        const int nPairs = (roundPairs - first0 + stride - 1) / stride; // pairs done + first0, done + first0 + stride, ...
         if (nPairs <= 0) continue;
         TV(int, pj);
         TV(int, ps);
@@ -762,7 +775,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w) {
             const int l = t & 63;
             TX(pj) = -1; TX(ps) = 0; TX(tot) = 0;
             if (l < nPairs) {
-                int want = done + l * NWAVES + w, dj = 0, first = 0;
+                int want = done + l * stride + first0, dj = 0, first = 0;
                 uint64_t gg = 0;
 #pragma unroll
                 for (int d2 = 0; d2 < BLK; d2++)
@@ -881,13 +894,34 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     TV(int, hList);
     TV(int, hFrame);
     TV(int, hIgenic);
+    // each wavefront specialises on one family of variable-length states (its instruction stream then only runs the
+    // branches of that family): 0 internal/terminal, 1 initial/single, 2 short introns, 3 reverse exons but RTERMINAL
     uint64_t maskVar = 0, maskRT = 0;
+    uint64_t maskW[NWAVES];
+#pragma unroll
+    for (int i = 0; i < NWAVES; i++) maskW[i] = 0;
     for (int s2 = 0; s2 < S; s2++) {
         if (!T.reachable[s2]) continue;
         const int kind = T.kind[s2];
-        if (kind == AUGX_K_RTERMINAL) maskRT |= 1ull << s2;
-        else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RINTERNAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) maskVar |= 1ull << s2;
+        const uint64_t bit = 1ull << s2;
+        int fam = -1;
+        switch (kind) {
+        case AUGX_K_RTERMINAL: maskRT |= bit; break;
+        case AUGX_K_INTERNAL: fam = 0; break;
+        case AUGX_K_TERMINAL: fam = 1; break;
+        case AUGX_K_INITIAL: fam = 2; break;
+        case AUGX_K_SINGLE: case AUGX_K_RSINGLE: fam = 3; break;
+        case AUGX_K_LESSD: fam = 4; break;
+        case AUGX_K_RLESSD: fam = 5; break;
+        case AUGX_K_RINTERNAL: fam = 6; break;
+        case AUGX_K_RINITIAL: fam = 7; break;
+        default: break;
+        }
+#pragma unroll
+        for (int i = 0; i < NWAVES; i++) if (fam >= 0 && i == fam % NWAVES) maskW[i] |= bit;
     }
+#pragma unroll
+    for (int i = 0; i < NWAVES; i++) maskVar |= maskW[i];
     FOR_THREADS(t) {
         const int l = t & 63;
         TX(hCls) = -1; TX(hLag) = -1; TX(hSig) = 0; TX(hLong) = 0; TX(hNanc) = 0; TX(hLrow) = -1; TX(hList) = -1; TX(hFrame) = 0; TX(hIgenic) = 0;
@@ -931,6 +965,48 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
         }
     }
+    // ---- step-3 work items: one (chain state, ancestor, base of the block) triple per thread
+    FOR_THREADS(t) {
+        if (t == 0) {
+            int nc = 0;
+            for (int s2 = 0; s2 < S && nc < 8; s2++)
+                if (T.reachable[s2] && (T.kind[s2] == AUGX_K_IGENIC || T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC)) L.chainIds[nc++] = s2;
+            L.nChain = nc;
+        }
+    }
+    BLOCK_SYNC();
+    TV(int, ciCs);   // chain-state slot, -1: no item
+    TV(int, ciAi);
+    TV(int, ciDj);
+    TV(int, ciAnc);
+    TV(int, ciSig);
+    TV(int, ciSelf);
+    TV(double, ciTr);
+    const int nChain = L.nChain;
+    FOR_THREADS(t) {
+        TX(ciCs) = -1; TX(ciAi) = 0; TX(ciDj) = 0; TX(ciAnc) = 0; TX(ciSig) = 0; TX(ciSelf) = 0; TX(ciTr) = AUGX_NINF;
+        int base = 0;
+        for (int cs = 0; cs < nChain; cs++) {
+            const int s2 = L.chainIds[cs];
+            const int na = T.n_anc[s2] < 5 ? T.n_anc[s2] : 5;
+            if (t >= base && t < base + na * BLK) {
+                const int ai = (t - base) / BLK;
+                const int a = T.anc[s2][ai];
+                TX(ciCs) = cs; TX(ciAi) = ai; TX(ciDj) = (t - base) % BLK; TX(ciAnc) = a; TX(ciSelf) = a == s2;
+                TX(ciSig) = T.kind[s2] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
+                TX(ciTr) = lnT(T, c, a, s2);
+            }
+            base += na * BLK;
+        }
+    }
+    FOR_THREADS(t) { // length distributions into LDS
+        for (int i = t; i < LEN_WIN; i += NT) {
+            const bool in = i <= T.max_exon_len;
+            L.lenw[0][i] = in ? T.len_single[i] : AUGX_NINF; L.lenw[1][i] = in ? T.len_initial[i] : AUGX_NINF;
+            L.lenw[2][i] = in ? T.len_internal[i] : AUGX_NINF; L.lenw[3][i] = in ? T.len_terminal[i] : AUGX_NINF;
+        }
+        for (int i = t; i < LENI_MAX; i += NT) L.leniw[i] = i <= T.d ? T.len_intron[i] : AUGX_NINF;
+    }
     // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
     FOR_THREADS(t) {
         if (t < SP) {
@@ -955,7 +1031,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // ---- load the tile of per-base records for bases j0..j0+63 and advance the LDS windows; the four
         //      wavefronts share the work by record type (every row of 64 loads is coalesced)
         FOR_THREADS(t) {
-            const int l = t & 63, q4 = t >> 6;
+            const int l = t & 63, q4 = (B.dbgFlags & 64) ? 99 : (t >> 6);
             const int q = j0 + l;
             const int64_t gq = o + 1 + q;
             if (q4 == 0) {
@@ -986,7 +1062,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     for (int f = 0; f < NFX; f++) L.fxw[q & (FX_WIN - 1)][f] = B.fx[fidx(gq, f, NFX)];
                     for (int f = 0; f < 3; f++) L.plsRw[q & (FX_WIN - 1)][f] = B.plsR[gq * 3 + f];
                 }
-            } else {
+            } else if (q4 == 3) {
                 // predecessor cells of the equalD states (lag dStateLen >= 64: written long ago by this workgroup)
                 for (int f = 0; f < 6; f++) L.eqPrev[l][f] = (dL >= WAVE && q - dL >= 0 && q < n) ? B.longV[(gq - dL) * 6 + f] : AUGX_NINF;
                 // candidate-side constants of the list entries whose site lies in this tile
@@ -1035,7 +1111,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             constexpr int CPT = BLK / NWAVES; // cells per thread
             FOR_THREADS(t) {
                 const int l = t & 63, q4 = t >> 6;
-                if (TX(hCls) == 1) {
+                if (TX(hCls) == 1 && !(B.dbgFlags & 16)) {
                     const int lag = TX(hLag), nanc = TX(hNanc);
                     double emi[CPT], pv0[CPT], pv1[CPT];
 #pragma unroll
@@ -1096,49 +1172,96 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             // (HBM re-reads only touch data at least one tile old -- the LDS caches cover 64 sites / 512 bases -- and
             //  the store queue is drained at every tile boundary, so no wait is needed here)
             if (anyVar && !(B.dbgFlags & 1)) {
-                FOR_WAVES(w) { trellisVarBlock(X, jb, maskVar, w); }
+                FOR_WAVES(w) {
+                    uint64_t mw = 0;
+#pragma unroll
+                    for (int i = 0; i < NWAVES; i++) if (i == w) mw = maskW[i];
+                    trellisVarBlock(X, jb, mw, w, 1);
+                }
                 BLOCK_SYNC();
             }
-            // ---- step 3: the lag-1 chain states (igenic, geometric), one lane of wavefront 0 per state, BLK bases in sequence
+            // ---- step 3: the lag-1 chain states (igenic, geometric introns).  Three short phases:
+            //   3a  one thread per (state, ancestor, base): candidate value  V[j-1][a] + (t(a->s) + e_s(j))
+            //   3b  one thread per (state, base): best ancestor before / after the state itself, in ascending ancestor
+            //       order with strict '>' (reference src/igenicmodel.cc:247-255, src/intronmodel.cc:757-786)
+            //   3c  one thread per state: the sequential part, two additions and two compares per base
+            if (!(B.dbgFlags & 8)) {
             FOR_THREADS(t) {
-                const int l = t;
-                if (t < WAVE && TX(hCls) == 0) {
-                    const int nanc = TX(hNanc);
-                    double emi[BLK], pv[5][BLK];
-                    int selfAi = -1;
+                if (TX(ciCs) >= 0) {
+                    const int j = jb + TX(ciDj);
+                    const bool valid = j >= 1 && j < n;
+                    const double emi = valid ? L.sig[j & 63][TX(ciSig)] : AUGX_NINF;
+                    const double pv = L.ring[(j - 1) & 63][TX(ciAnc)];
+                    const double te = TX(ciTr) + emi;
+                    L.chV[TX(ciCs)][TX(ciDj)][TX(ciAi)] = TX(ciSelf) ? AUGX_NINF : pv + te;
+                    if (TX(ciSelf)) { L.chPs[TX(ciCs)][TX(ciDj)] = pv; L.chTe[TX(ciCs)][TX(ciDj)] = te; }
+                }
+            }
+            BLOCK_SYNC();
+            FOR_THREADS(t) {
+                if (t < nChain * BLK) {
+                    const int cs = t / BLK, dj = t % BLK, s2 = L.chainIds[cs];
+                    const int na = L.vc[s2].nanc; // (chain states have at most 5 ancestors; vc keeps 4, igenic's 5th read below)
+                    (void)na;
+                    double bB = AUGX_NINF, bA = AUGX_NINF;
+                    int aB = -1, aA = -1;
+                    bool seenSelf = false;
+                    const int nanc = T.n_anc[s2] < 5 ? T.n_anc[s2] : 5;
 #pragma unroll
-                    for (int ai = 0; ai < 5; ai++) if (ai < nanc && hAnc[ai][TI] == l) selfAi = ai;
-#pragma unroll
-                    for (int dj = 0; dj < BLK; dj++) { // independent LDS loads first
-                        const int j = jb + dj;
-                        emi[dj] = L.sig[j & 63][TX(hSig)];
-#pragma unroll
-                        for (int ai = 0; ai < 5; ai++) pv[ai][dj] = (ai < nanc && j >= 1) ? L.ring[(j - 1) & 63][hAnc[ai][TI]] : AUGX_NINF;
+                    for (int ai = 0; ai < 5; ai++) {
+                        if (ai >= nanc) continue;
+                        const bool self = T.anc[s2][ai] == s2;
+                        const double v = L.chV[cs][dj][ai];
+                        if (self) seenSelf = true;
+                        else if (!seenSelf) { if (v > bB) { bB = v; aB = ai; } }
+                        else { if (v > bA) { bA = v; aA = ai; } }
                     }
-                    double prev = AUGX_NINF; // own value at j-1 once inside the block
+                    L.chB[cs][dj][0] = bB; L.chB[cs][dj][1] = bA;
+                    L.chA[cs][dj][0] = aB; L.chA[cs][dj][1] = aA;
+                }
+            }
+            BLOCK_SYNC();
+            FOR_THREADS(t) {
+                if (t < nChain) {
+                    const int cs = t, l = L.chainIds[cs];
+                    int selfAi = 5;
+                    const int nanc = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
+#pragma unroll
+                    for (int ai = 0; ai < 5; ai++) if (ai < nanc && T.anc[l][ai] == l) selfAi = ai;
+                    double bB[BLK], bA[BLK], te[BLK], ps[BLK];
+                    int aB[BLK], aA[BLK];
+#pragma unroll
+                    for (int dj = 0; dj < BLK; dj++) {
+                        bB[dj] = L.chB[cs][dj][0]; bA[dj] = L.chB[cs][dj][1]; aB[dj] = L.chA[cs][dj][0]; aA[dj] = L.chA[cs][dj][1];
+                        te[dj] = L.chTe[cs][dj]; ps[dj] = L.chPs[cs][dj];
+                    }
+                    double res[BLK];
+                    int rai[BLK];
+                    double prev = AUGX_NINF;
+#pragma unroll
+                    for (int dj = 0; dj < BLK; dj++) {
+                        const int j = jb + dj;
+                        const double p0 = (dj == 0 || j - 1 < 1) ? ps[dj] : prev;
+                        const double vs = p0 + te[dj];
+                        double best = bB[dj];
+                        int bai = aB[dj];
+                        if (vs > best) { best = vs; bai = selfAi; }
+                        if (bA[dj] > best) { best = bA[dj]; bai = aA[dj]; }
+                        res[dj] = best; rai[dj] = bai;
+                        prev = best;
+                    }
+                    const bool isIg = T.kind[l] == AUGX_K_IGENIC;
 #pragma unroll
                     for (int dj = 0; dj < BLK; dj++) {
                         const int j = jb + dj;
                         if (j < 1 || j >= n) continue;
-                        double best = AUGX_NINF;
-                        uint16_t bp = BP_NONE;
-                        if (emi[dj] > AUGX_NINF) {
-#pragma unroll
-                            for (int ai = 0; ai < 5; ai++) {
-                                if (ai >= nanc) continue;
-                                double pvv = (ai == selfAi && dj > 0 && j - 1 >= 1 && j - 1 >= jb) ? prev : pv[ai][dj];
-                                if (!(pvv > AUGX_NINF)) continue;
-                                double val = pvv + (hTr[ai][TI] + emi[dj]);
-                                if (val > best) { best = val; bp = bpFixed(ai); }
-                            }
-                        }
-                        prev = best;
-                        L.ring[j & 63][l] = best;
-                        L.bp[j & 63][l] = bp;
-                        if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
-                        if (TX(hIgenic)) { B.vig[o + 1 + j] = best; L.vigw[j & (VIG_WIN - 1)] = best; }
+                        L.ring[j & 63][l] = res[dj];
+                        L.bp[j & 63][l] = res[dj] > AUGX_NINF ? bpFixed(rai[dj]) : BP_NONE;
+                        if (B.cells) B.cells[(o + 1 + j) * S + l] = res[dj];
+                        if (isIg) { B.vig[o + 1 + j] = res[dj]; L.vigw[j & (VIG_WIN - 1)] = res[dj]; }
                     }
                 }
+            }
             }
             {
                 int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
@@ -1147,14 +1270,14 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             BLOCK_SYNC();
             // ---- step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
             if (anyRT && !(B.dbgFlags & 1)) {
-                FOR_WAVES(w) { trellisVarBlock(X, jb, maskRT, w); }
+                FOR_WAVES(w) { trellisVarBlock(X, jb, maskRT, w, NWAVES); }
                 BLOCK_SYNC();
             }
         }
         // ---- flush the back-pointer tile
         FOR_THREADS(t) {
             const int l = t & 63, q4 = t >> 6;
-            for (int r = q4; r < WAVE; r += NWAVES) {
+            for (int r = q4; r < WAVE && !(B.dbgFlags & 32); r += NWAVES) {
                 int q = j0 + r;
                 if (q < n && l < SP) B.bp[(o + 1 + q) * SP + l] = L.bp[r][l];
             }
