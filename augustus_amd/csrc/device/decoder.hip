@@ -315,6 +315,9 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
+#ifdef AUGX_PROF
+    DA(V.prof, uint64_t, (int64_t)n * NWAVES * 16);
+#endif
     DA(V.vig, double, Z.N);
     DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
@@ -407,6 +410,21 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
     if (prep_ms) *prep_ms = a;
     if (trellis_ms) *trellis_ms = c;
     if (back_ms) *back_ms = e;
+#ifdef AUGX_PROF
+    {   // developer build: per-section cycle counters of the trellis kernel, averaged over pieces
+        std::vector<uint64_t> h((size_t)b->L.nPieces * NWAVES * 16);
+        HIP_TRY(hipMemcpy(h.data(), b->V.prof, h.size() * 8, hipMemcpyDeviceToHost));
+        for (int w = 0; w < NWAVES; w++) {
+            fprintf(stderr, "prof wave %d:", w);
+            for (int i = 0; i < 14; i++) {
+                double sum = 0;
+                for (int p = 0; p < b->L.nPieces; p++) sum += (double)h[((size_t)p * NWAVES + w) * 16 + i];
+                fprintf(stderr, " %d=%.1f", i, sum / b->L.nPieces / 1e6);
+            }
+            fprintf(stderr, " (Mcycles)\n");
+        }
+    }
+#endif
     return AUGX_OK;
 }
 

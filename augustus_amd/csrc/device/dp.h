@@ -77,6 +77,7 @@ struct BatchView {
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
+    uint64_t *prof;            // [nPieces][NWAVES][16] cycle counters (builds with -DAUGX_PROF only) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD
     int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]

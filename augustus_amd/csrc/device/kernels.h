@@ -422,7 +422,15 @@ AUGX_HD double lnT(const DevTables &T, int c, int a, int s) { return T.ln_trans[
 AUGX_HD uint16_t bpFixed(int ai) { return (uint16_t)ai; }
 AUGX_HD uint16_t bpVar(int ai, int dist) { return (uint16_t)((ai << 14) | (dist & 0x3FFF)); }
 
+#if defined(AUGX_PROF) && !defined(AUGX_EMU)
+#define PROF_MARK(X, sec) do { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } while (0)
+#else
+#define PROF_MARK(X, sec) do {} while (0)
+#endif
 struct TrellisCtx {
+#if defined(AUGX_PROF) && !defined(AUGX_EMU)
+    uint64_t pacc[16], plast;
+#endif
     const DevTables &T;
     const BatchView &B;
     TrellisLds &L;
@@ -781,8 +789,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
                 for (int d2 = 0; d2 < BLK; d2++)
                     if (off[d2] <= want && want < off[d2 + 1]) { dj = d2; gg = g[d2]; first = off[d2]; }
                 for (int k = want - first; k > 0; k--) gg &= gg - 1;
-                int s2 = 0;
-                while (!((gg >> s2) & 1)) s2++;
+                const int s2 = __builtin_ctzll(gg | (1ull << 63));
                 TX(pj) = jb + dj; TX(ps) = s2;
                 L.pairJ[w * MAXPW + l] = jb + dj; L.pairS[w * MAXPW + l] = s2;
                 varDescribe(X, s2, jb + dj, L.desc[w * MAXPW + l]);
@@ -790,6 +797,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
             }
         }
         WAVE_SYNC();
+        PROF_MARK(X, 2);
         TV(int, ibase); // inclusive prefix of the candidate counts
         FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
         waveInclScan(ibase, w);
@@ -798,6 +806,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
         TV(int, rbk);
         TV(int, rba);
         FOR_WLANES(t, w) { TX(rbv) = AUGX_NINF; TX(rbk) = -2147483647; TX(rba) = -1; }
+        PROF_MARK(X, 3);
         for (int base = 0; base < totalItems; base += WAVE) {
             TV(int, myPair);
             TV(int, myFirst);
@@ -806,6 +815,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
                 const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
                 FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
             }
+            PROF_MARK(X, 4);
             FOR_WLANES(t, w) { // evaluate one candidate per lane
                 const int l = t & 63;
                 int it = base + l;
@@ -818,6 +828,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
                 }
             }
             WAVE_SYNC();
+            PROF_MARK(X, 5);
             FOR_WLANES(t, w) { // the lane of each pair folds the candidates of this chunk that belong to it
                 const int l = t & 63;
                 if (l < nPairs) {
@@ -829,6 +840,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
                 }
             }
             WAVE_SYNC();
+            PROF_MARK(X, 6);
         }
         FOR_WLANES(t, w) {
             const int l = t & 63;
@@ -846,6 +858,7 @@ AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int s
             }
         }
         WAVE_SYNC();
+        PROF_MARK(X, 7);
     }
 }
 
@@ -1026,6 +1039,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     X.P.wcode = L.codew;
     X.P.wns = L.nsw;
     BLOCK_SYNC();
+#if defined(AUGX_PROF) && !defined(AUGX_EMU)
+    for (int i = 0; i < 16; i++) X.pacc[i] = 0;
+    X.plast = clock64();
+#endif
     for (int j0 = 0; j0 < n; j0 += WAVE) {
         BLOCK_GLOBAL_SYNC(); // everything this workgroup stored to HBM so far is visible to its own later loads
         // ---- load the tile of per-base records for bases j0..j0+63 and advance the LDS windows; the four
@@ -1106,6 +1123,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             X.listHi3 = (int)X.cntAt(hf - 1, CNT_RD) - 1;
             X.atgHi = (int)X.cntAt(hf - 1, CNT_ATG) - 1;
         }
+        PROF_MARK(X, 0);
         for (int jb = j0; jb < j0 + WAVE && jb < n; jb += BLK) {
             // ---- step 1: fixed-length states with lag > BLK: thread = (state, quarter of the block)
             constexpr int CPT = BLK / NWAVES; // cells per thread
@@ -1162,6 +1180,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
             }
             BLOCK_SYNC();
+            PROF_MARK(X, 1);
             // ---- step 2: variable-length states (all but RTERMINAL): they depend on fixed-state cells (just published)
             //      and on igenic cells at least BLK bases back.  Pairs are dealt round-robin to the wavefronts.
             uint64_t anyVar = 0, anyRT = 0;
@@ -1171,6 +1190,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
             // (HBM re-reads only touch data at least one tile old -- the LDS caches cover 64 sites / 512 bases -- and
             //  the store queue is drained at every tile boundary, so no wait is needed here)
+            PROF_MARK(X, 12);
             if (anyVar && !(B.dbgFlags & 1)) {
                 FOR_WAVES(w) {
                     uint64_t mw = 0;
@@ -1178,7 +1198,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     for (int i = 0; i < NWAVES; i++) if (i == w) mw = maskW[i];
                     trellisVarBlock(X, jb, mw, w, 1);
                 }
+                PROF_MARK(X, 13);
                 BLOCK_SYNC();
+                PROF_MARK(X, 8);
             }
             // ---- step 3: the lag-1 chain states (igenic, geometric introns).  Three short phases:
             //   3a  one thread per (state, ancestor, base): candidate value  V[j-1][a] + (t(a->s) + e_s(j))
@@ -1268,10 +1290,12 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
             }
             BLOCK_SYNC();
+            PROF_MARK(X, 9);
             // ---- step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
             if (anyRT && !(B.dbgFlags & 1)) {
                 FOR_WAVES(w) { trellisVarBlock(X, jb, maskRT, w, NWAVES); }
                 BLOCK_SYNC();
+                PROF_MARK(X, 10);
             }
         }
         // ---- flush the back-pointer tile
@@ -1283,7 +1307,12 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
         }
         BLOCK_SYNC();
+        PROF_MARK(X, 11);
     }
+#if defined(AUGX_PROF) && !defined(AUGX_EMU)
+    if ((threadIdx.x & 63) == 0 && B.prof)
+        for (int i = 0; i < 16; i++) B.prof[((int64_t)p * NWAVES + (threadIdx.x >> 6)) * 16 + i] = X.pacc[i];
+#endif
     // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)
     FOR_THREADS(t) {
         if (t == 0) {

@@ -122,6 +122,13 @@ def main():
         alg_bytes = (0.25 + 20.0 * S) * bases
         tr_s = float(np.mean(trellis_ms)) / 1e3
         achieved = alg_bytes / tr_s / 1e9
+        # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
+        # WRITE_SIZE in separate rocprofv3 runs, gfx950 correction applied; see profiles/r01_hbm_traffic.json)
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tj):
+            with open(tj) as fh:
+                traffic = json.load(fh)["kTrellis"]["traffic_bytes_per_bp"] * bases
         out = {
             "metric": "Mbp DNA decoded/sec (whole node), ab-initio human model",
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -131,7 +138,7 @@ def main():
                                    % (a.contigs, a.contig_len), "pieces_in_flight_per_gpu": a.contigs,
                        "sharding": "contigs sharded over ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "kernel": "kTrellis", "kernel_ms": float(np.mean(trellis_ms)),
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_hbm_traffic.json)", "kernel": "kTrellis", "kernel_ms": float(np.mean(trellis_ms)),
                          "prep_ms": float(np.mean(prep_ms)), "backtrace_ms": float(np.mean(back_ms)),
                          "positions_per_s_per_piece": a.contig_len / tr_s},
         }
