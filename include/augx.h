@@ -114,6 +114,12 @@ typedef struct augx_model augx_model;     /* host-side immutable model: tables +
 typedef struct augx_decoder augx_decoder; /* device-side context bound to one HIP device + stream       */
 
 /* one unit of work = one "piece" (reference src/namgene.cc:584-603) */
+/* values of augx_piece.init_kind / term_kind (reference src/namgene.cc:584-603) */
+#define AUGX_INIT_FILE 0
+#define AUGX_INIT_SYNCH 1
+#define AUGX_TERM_FILE 0
+#define AUGX_TERM_SYNCH 1
+
 typedef struct augx_piece {
     const char *seq;      /* ASCII nucleotides, any case; non-acgt = invalid (HOST pointer)               */
     int64_t len;
