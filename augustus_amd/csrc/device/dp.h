@@ -37,6 +37,17 @@ constexpr int LENI_MAX = 1024;  // intron length distribution cached in LDS when
 
 #define AUGX_NINF (-INFINITY)
 
+// one candidate of a variable-length state: everything but the predecessor's Viterbi value (kCandidates -> kTrellis)
+struct Item {
+    double te;      // ln(transition * emission) of the candidate, -inf if infeasible
+    uint32_t kp;    // [31:22] index of the (base, state) pair inside its block, [21:0] tie-break key (eop or bs)
+    uint32_t src;   // where the predecessor value lives: [31:30] tag, [29:28] ancestor index, [27:0] payload
+};
+constexpr int KEY_BITS = 22;                 // pieces on the device path are shorter than 2^22 bases
+constexpr uint32_t KEY_MASK = (1u << KEY_BITS) - 1;
+constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
+constexpr int BLK = 8;                       // bases per trellis block: smaller than every lag except the lag-1 chain states
+
 // flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
@@ -77,7 +88,6 @@ struct BatchView {
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
-    uint64_t *prof;            // [nPieces][NWAVES][16] cycle counters (builds with -DAUGX_PROF only) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD
     int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]
@@ -92,6 +102,15 @@ struct BatchView {
     double *atgD; uint64_t *atgFx;   // [cap][3] (begin part, ln P_ls, initial content), [cap] exon-content prefix at bs+k-1+Li
     int32_t *rsPos; double *rsBegin; uint64_t *rsFx; // reverse stop codons: position, ln stop prob, [cap][3] exon-content prefix at bs-1
     double *plsR;                    // [N][3] reverse strand: ln P_ls of the k bases ending at this base, per frame
+    // candidates of the variable-length states, grouped by block of BLK bases (block index = off[p]/BLK + j/BLK)
+    int64_t nBlk;                    // N / BLK
+    uint32_t *blkCnt;                // [nBlk][2] (pairs, items) of the block
+    uint32_t *blkSplit;              // [nBlk] items of the block that do not belong to RTERMINAL states (they come first)
+    uint64_t *blkOff;                // [nBlk+1][2] exclusive prefix of blkCnt
+    uint64_t *blkChunk;              // scan scratch [nBlk/1024 + 1][2]
+    uint16_t *pairRec;               // [pairs] (base offset in block << 8) | state
+    Item *items;                     // [items]
+    int64_t pairCap, itemCap;
     // results
     double *lnv;               // [nPieces]
     int32_t *status;           // [nPieces]

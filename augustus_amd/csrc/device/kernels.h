@@ -1,7 +1,8 @@
 // kernels.h -- bodies of the decode kernels, written once for gfx950 (hipcc) and for the lane-loop emulator
 // (-DAUGX_EMU, tests only).  See DESIGN.md for the kernel decomposition:
 //   K1  prep   : encode, site/stop/base-count prefix scans, GC class, fixed-point content prefix sums, signals
-//   K2  trellis: one 64-lane wavefront per piece, position-sequential, V columns in an LDS ring
+//   K2a candidates: transition * emission of every candidate of the variable-length states, parallel over blocks
+//   K2b trellis: one workgroup per piece, position-sequential, V columns in an LDS ring
 //   K3  back   : back-pointer chase, one wavefront per piece
 //
 // Lane discipline: a FOR_LANES block is executed by every lane (concurrently on the device, one after the other
@@ -53,9 +54,10 @@ namespace dev {
 #define TX(name) name[0]
 // workgroup barrier that only orders LDS traffic (no wait for outstanding global stores)
 #define BLOCK_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
-#define BLOCK_GLOBAL_SYNC() __syncthreads()
+// workgroup barrier after which everything the workgroup stored to HBM is visible to its later coherent loads
+#define BLOCK_GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); } while (0)
 #endif
-constexpr int NWAVES = 8, NT = NWAVES * WAVE;
+constexpr int NWAVES = 4, NT = NWAVES * WAVE;
 
 // ------------------------------------------------------------------------------------------------
 // wave-wide argmax of (value, key): larger value wins, ties go to the larger key (= the candidate the
@@ -336,7 +338,16 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
 }
 
 // =================================================================================================
-// K2  trellis: one wavefront per piece
+// K2a  candidates of the variable-length states (coding exons, short introns).
+//
+// A variable-length state s ending at base j has many possible predecessors: every feasible exon start / intron
+// start in a window that can be 15 kb long.  For each of them the score is
+//        V[eop][a]  +  ( ln t(a->s) + ln emission(eop+1 .. j | s) )
+// and only the first term depends on the trellis.  The second term ("te"), the tie-break key and the address of
+// the first term are computed HERE, fully parallel over blocks of BLK bases (one wavefront per block), and streamed
+// to the trellis kernel, which is left with one addition and one segmented arg-max per candidate.
+// The formulas are those of the reference loops (exon: src/exonmodel.cc:1059-1132; lessD:
+// src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
 // =================================================================================================
 struct VarDesc {
     int kind, win, nList, extra, total, listSel; // listSel: 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
@@ -351,10 +362,6 @@ struct VarDesc {
     double eD0, plsEnd;     // end-side content term (exon-terminal fwd / initial-content rev), reverse-strand ln P_ls
     int lenSel;             // length distribution of this exon type: 0 single, 1 initial, 2 internal, 3 terminal
 };
-
-constexpr int BLK = 8;          // bases per block: smaller than every lag except the lag-1 chain states
-constexpr int MAXPAIR = WAVE;   // gated (base, state) pairs handled per round (MAXPAIR / NWAVES per wavefront)
-constexpr int MAXPW = MAXPAIR / NWAVES;
 
 // wave-level bookkeeping primitives (device: cross-lane instructions; emulator: loops over the lane arrays)
 #ifdef AUGX_EMU
@@ -371,45 +378,11 @@ __device__ inline int waveRead(const int *v, int, int lane) { return __shfl(v[0]
 #endif
 AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
-// per-state constants of the variable-length states (LDS copy: no table walks in the inner loops)
+// per-state constants of the variable-length states
 struct VarConst {
     int kind, win, nanc, anc[4], ancWin[4];
     double tr[4];
     ExGeom g;
-};
-
-struct TrellisLds {
-    double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
-    double eqPrev[WAVE][6];         // predecessor cells of the equalD states for the bases of the tile (lag dStateLen)
-    double sig[WAVE][NSIG];         // tile of signal records for bases j0..j0+63
-    uint64_t gate[WAVE];
-    int32_t site[WAVE][NSITE];
-    uint16_t bp[WAVE][SP];
-    // windows over recent bases (served from LDS; older data falls back to HBM)
-    uint8_t codew[CODE_WIN];
-    uint32_t nsw[NS_WIN * 6];
-    uint32_t cntw[CNT_WIN][6];      // site counts (ATG, LA, LR, LD, RD, RS) at bases <= q
-    double lenw[4][LEN_WIN];        // ln(3 P(len)) of single / initial / internal / terminal exons, len < LEN_WIN
-    double leniw[LENI_MAX];         // ln P(len) of short introns
-    double vigw[VIG_WIN];           // igenic column
-    uint64_t fxw[FX_WIN][NFX];      // content prefix sums of bases [j0-64, j0+64)
-    double plsRw[FX_WIN][3];
-    int32_t lcPos[4][LIST_WIN];     // newest LIST_WIN entries of the four splice-site candidate lists
-    double lcVal[4][LIST_WIN][3];   //   Viterbi values of the three frames
-    double lcC[2][LIST_WIN][3];     //   LA: ln P_ls; LR: exon-terminal content
-    uint64_t lcFx[4][LIST_WIN][3];  //   content prefix at the candidate-side boundary (LD/RD: [0] only)
-    int32_t aPos[ATG_WIN];          // newest start-codon entries
-    double aD[ATG_WIN][3];
-    uint64_t aFx[ATG_WIN];
-    int chainIds[8], nChain;         // the lag-1 chain states (igenic + geometric introns)
-    double chV[8][BLK][5];          // step 3 scratch: candidate value per (chain state, base, ancestor)
-    double chPs[8][BLK], chTe[8][BLK], chB[8][BLK][2];
-    int chA[8][BLK][2];
-    VarConst vc[SP];
-    VarDesc desc[MAXPAIR];          // descriptors of the gated (base, state) pairs of the current round
-    int pairJ[MAXPAIR], pairS[MAXPAIR];
-    double itVal[NWAVES][WAVE];     // one chunk of evaluated candidates per wavefront
-    int itKey[NWAVES][WAVE], itAux[NWAVES][WAVE];
 };
 
 AUGX_HD int longRow(const DevTables &T, int s) {
@@ -421,94 +394,76 @@ AUGX_HD int longRow(const DevTables &T, int s) {
 AUGX_HD double lnT(const DevTables &T, int c, int a, int s) { return T.ln_trans[((int64_t)c * T.S + a) * T.S + s]; }
 AUGX_HD uint16_t bpFixed(int ai) { return (uint16_t)ai; }
 AUGX_HD uint16_t bpVar(int ai, int dist) { return (uint16_t)((ai << 14) | (dist & 0x3FFF)); }
+AUGX_HD uint32_t srcList(int ai, int sel, int frame, int64_t li) { return (SRC_LIST << 30) | ((uint32_t)ai << 28) | ((uint32_t)sel << 26) | ((uint32_t)frame << 24) | ((uint32_t)li & 0xFFFFFFu); }
+AUGX_HD uint32_t srcVig(int ai, int eop) { return (SRC_VIG << 30) | ((uint32_t)ai << 28) | ((uint32_t)eop & 0xFFFFFFu); }
+AUGX_HD uint32_t srcCol0(int ai, int a) { return (SRC_COL0 << 30) | ((uint32_t)ai << 28) | (uint32_t)a; }
 
-#if defined(AUGX_PROF) && !defined(AUGX_EMU)
-#define PROF_MARK(X, sec) do { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } while (0)
-#else
-#define PROF_MARK(X, sec) do {} while (0)
-#endif
-struct TrellisCtx {
-#if defined(AUGX_PROF) && !defined(AUGX_EMU)
-    uint64_t pacc[16], plast;
-#endif
+AUGX_HD void fillVarConst(const DevTables &T, int c, int l, VarConst &VC) {
+    const int kind = T.kind[l];
+    VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
+    for (int ai = 0; ai < 4; ai++) {
+        int a = ai < VC.nanc ? T.anc[l][ai] : 0;
+        VC.anc[ai] = a; VC.ancWin[ai] = T.win[a]; VC.tr[ai] = ai < VC.nanc ? lnT(T, c, a, l) : AUGX_NINF;
+    }
+    VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
+}
+
+struct CandLds {
+    VarConst vc[SP];
+    VarDesc desc[NWAVES][WAVE];     // descriptors of the (base, state) pairs of the current round, one per lane
+    int pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];
+};
+
+// read-only view of one piece for the candidate kernel (everything comes from HBM / L2)
+struct CandCtx {
     const DevTables &T;
     const BatchView &B;
-    TrellisLds &L;
+    const VarConst *vc;
     int p;
     Piece P;
     int64_t o;      // slot offset of the piece
     int64_t lo;     // list offset
     int n, c, S;
-    int kwLo, kwHi; // cnt window
-    int fwLo, fwHi; // content-prefix window
-    int atgHi;      // newest start-codon entry in the LDS cache
-    int vigLo;      // igenic ring holds bases > vigLo (and <= the newest chain base)
-    int listHi0, listHi1, listHi2, listHi3;  // newest published entry of each splice-site list (piece-local index), -1 none
-    AUGX_HD int listHi(int sel) const { return sel == 0 ? listHi0 : sel == 1 ? listHi1 : sel == 2 ? listHi2 : listHi3; }
-    AUGX_HD TrellisCtx(const DevTables &t, const BatchView &b, TrellisLds &l, int pp) : T(t), B(b), L(l), p(pp) {
+    AUGX_HD CandCtx(const DevTables &t, const BatchView &b, const VarConst *v, int pp) : T(t), B(b), vc(v), p(pp) {
         P = makePiece(T, B, p);
         o = B.off[p];
         lo = listOff(B, p);
         n = P.n; c = P.c; S = T.S;
-        kwLo = kwHi = 0; fwLo = fwHi = 0; atgHi = -1; vigLo = 0x7fffffff;
-        listHi0 = listHi1 = listHi2 = listHi3 = -1;
     }
     AUGX_HD uint64_t cntAt(int q, int f) const { // number of sites of field f at bases <= q (q may be -1)
         if (q < 0) return 0;
         if (q > n - 1) q = n - 1;
-        if (f >= CNT_ATG && q >= kwLo && q < kwHi) return L.cntw[q & (CNT_WIN - 1)][f - CNT_ATG];
         return B.cnt[fidx(o + 1 + q, f, NCNT)];
     }
     AUGX_HD int listPos(int sel, int64_t li) const { // sel: 0 LA, 1 LR, 2 LD, 3 RD; li piece-local index
-        if (li <= listHi(sel) && li > listHi(sel) - LIST_WIN) return L.lcPos[sel][li & (LIST_WIN - 1)];
         const int32_t *a = sel == 0 ? B.laPos : sel == 1 ? B.lrPos : sel == 2 ? B.ldPos : B.rdPos;
         return a[lo + li];
     }
-    AUGX_HD double listVal(int sel, int64_t li, int f) const {
-        if (li <= listHi(sel) && li > listHi(sel) - LIST_WIN) return L.lcVal[sel][li & (LIST_WIN - 1)][f];
-        const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
-        return a[(lo + li) * 3 + f];
-    }
-    AUGX_HD double vigAt(int eop) const { return eop > vigLo ? L.vigw[eop & (VIG_WIN - 1)] : B.vig[o + 1 + eop]; }
-    AUGX_HD bool listCached(int sel, int64_t li) const { return li <= listHi(sel) && li > listHi(sel) - LIST_WIN; }
     AUGX_HD double listC(int sel, int64_t li, int a) const { // LA: ln P_ls, LR: exon-terminal content
-        if (listCached(sel, li)) return L.lcC[sel][li & (LIST_WIN - 1)][a];
         return (sel == 0 ? B.laPls : B.lrEt)[(lo + li) * 3 + a];
     }
     AUGX_HD uint64_t listFx(int sel, int64_t li, int a) const {
-        if (listCached(sel, li)) return L.lcFx[sel][li & (LIST_WIN - 1)][a];
         if (sel == 0) return B.laFx[(lo + li) * 3 + a];
         if (sel == 1) return B.lrFx[(lo + li) * 3 + a];
         return (sel == 2 ? B.ldFx : B.rdFx)[lo + li];
     }
     AUGX_HD uint64_t fxAt(int q, int f) const { // content prefix field f up to and including base q (q < 0: empty)
         if (q < 0) return 0;
-        if (q >= fwLo && q < fwHi) return L.fxw[q & (FX_WIN - 1)][f];
         return B.fx[fidx(o + 1 + q, f, NFX)];
     }
     AUGX_HD double lenAt(int sel, int len) const {
-        if (len < LEN_WIN) return L.lenw[sel][len];
         return (sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
     }
-    AUGX_HD double lenIAt(int len) const { return T.d < LENI_MAX ? L.leniw[len] : T.len_intron[len]; }
-    AUGX_HD double plsRAt(int q, int fr) const {
-        if (q >= fwLo && q < fwHi) return L.plsRw[q & (FX_WIN - 1)][fr];
-        return B.plsR[(o + 1 + q) * 3 + fr];
-    }
+    AUGX_HD double lenIAt(int len) const { return T.len_intron[len]; }
+    AUGX_HD double plsRAt(int q, int fr) const { return B.plsR[(o + 1 + q) * 3 + fr]; }
+    AUGX_HD double sigAt(int q, int i) const { return B.sig[(o + 1 + q) * NSIG + i]; }
 };
 
-// -------------------------------------------------------------------------------------------------
-// variable-length states (coding exons, short introns) whose end gate is open.
-// All gated (base, state) pairs of a block are evaluated together: one lane per pair builds a descriptor
-// (candidate range + end-side constants), then all candidates are spread over the 64 lanes, and finally one
-// lane per pair reduces its candidates.  The formulas are those of the reference loops
-// (exon: src/exonmodel.cc:1059-1132; lessD: src/intronmodel.cc:585-629); the tie-break "larger key wins" is
-// the reference's descending loop with strict '>'.
-// -------------------------------------------------------------------------------------------------
-AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
+// descriptor of state s ending at base j: candidate range and end-side constants
+AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
     const DevTables &T = X.T;
     const Piece &P = X.P;
-    const VarConst &VC = X.L.vc[s];
+    const VarConst &VC = X.vc[s];
     const int kind = VC.kind, win = VC.win, n = X.n;
     D.kind = kind; D.win = win; D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
     D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cod0 = D.cod1 = D.cod2 = 4; D.endP = AUGX_NINF;
@@ -545,8 +500,8 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
     }
     const ExEnd e = exEnd(P, kind, win, j, D.g);
     D.eob = e.eob; D.right = e.right; D.fOR = e.fOR; D.startMin = e.startMin;
-    D.endP = (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) ? X.L.sig[j & 63][SIG_STOPF]
-             : (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) ? X.L.sig[j & 63][SIG_TISR] : 0.0; // gate is open
+    D.endP = (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) ? X.sigAt(j, SIG_STOPF)
+             : (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) ? X.sigAt(j, SIG_TISR) : 0.0; // gate is open
     if (!(D.endP > AUGX_NINF) || e.right < 0 || e.startMax < e.startMin) return;
     {   // end-side constants of the fast candidate evaluation
         const int k = T.k, right = e.right;
@@ -597,27 +552,25 @@ AUGX_KFN void varDescribe(const TrellisCtx &X, int s, int j, VarDesc &D) {
     D.total = D.nList + D.extra;
 }
 
-// candidate number idx (0 = newest) of the state described by D: value, tie-break key, predecessor index
-AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, int idx, double &val, int &key, int &aux) {
+// candidate number idx (0 = newest) of the state described by D: te = ln(transition * emission) (-inf: infeasible),
+// tie-break key, and the address of the predecessor's Viterbi value
+AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int idx, double &te, int &key, uint32_t &src) {
     const DevTables &T = X.T;
     const BatchView &B = X.B;
     const Piece &P = X.P;
-    const VarConst &VC = X.L.vc[s];
+    const VarConst &VC = X.vc[s];
     const int n = X.n, kind = D.kind, win = D.win;
-    val = AUGX_NINF; key = -2147483647; aux = -1;
-    auto col0 = [&](int a) { return (B.initKind[X.p] == 0) ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF); };
+    te = AUGX_NINF; key = 0; src = srcCol0(0, 0);
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
-        const int a = VC.anc[0];
         int eop;
-        double pv;
+        uint32_t sr;
         if (idx < D.nList) {
             int64_t li = D.i1 - 1 - idx;
             eop = X.listPos(D.listSel, li);
-            pv = X.listVal(D.listSel, li, f);
-        } else { eop = 0; pv = col0(a); }
-        if (!(pv > AUGX_NINF)) return;
+            sr = srcList(0, D.listSel, f, li);
+        } else { eop = 0; sr = srcCol0(0, VC.anc[0]); }
         int begin = eop + 1;
         int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
         if (bobi >= 0 && !(fwd ? P.possDSS(bobi) : P.possRASS(bobi))) return;
@@ -639,8 +592,8 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
                                        : P.seg(fwd ? FX_INF : FX_INR, begin, j);
         double emi = X.lenIAt(intronLength) + restSeq;
         if (!(emi > AUGX_NINF)) return;
-        val = pv + (VC.tr[0] + emi);
-        key = eop; aux = 0;
+        te = VC.tr[0] + emi;
+        key = eop; src = sr;
         return;
     }
     if (D.listSel >= 4) { // predecessor is the igenic state
@@ -651,22 +604,15 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         uint64_t cFxA = 0;
         if (D.listSel == 4) {
             const int64_t ai2 = D.i1 - 1 - idx;
-            if (ai2 <= X.atgHi && ai2 > X.atgHi - ATG_WIN) {
-                const int sl = (int)(ai2 & (ATG_WIN - 1));
-                bs = X.L.aPos[sl] + 3; tisF = X.L.aD[sl][0]; cPls = X.L.aD[sl][1]; cInit = X.L.aD[sl][2]; cFxA = X.L.aFx[sl];
-            } else {
-                bs = B.atgPos[X.lo + ai2] + 3;
-                tisF = B.atgD[(X.lo + ai2) * 3 + 0]; cPls = B.atgD[(X.lo + ai2) * 3 + 1]; cInit = B.atgD[(X.lo + ai2) * 3 + 2];
-                cFxA = B.atgFx[X.lo + ai2];
-            }
+            bs = B.atgPos[X.lo + ai2] + 3;
+            tisF = B.atgD[(X.lo + ai2) * 3 + 0]; cPls = B.atgD[(X.lo + ai2) * 3 + 1]; cInit = B.atgD[(X.lo + ai2) * 3 + 2];
+            cFxA = B.atgFx[X.lo + ai2];
         } else
             bs = D.startMin;
         int eop = bs - D.g.bpl - 1;
         // eop == j reads the igenic cell of the CURRENT column (already final: the reference fills states in index
         // order and igenic is state 0); later columns do not exist yet
         if (!(eop < n && eop <= j)) return;
-        double pv = eop <= 0 ? col0(a) : X.vigAt(eop);
-        if (!(pv > AUGX_NINF)) return;
         double nep;
         const int m = D.right - bs, k = T.k;
         const int bob = bs - D.g.ipo, len = D.eob - bob + 1;
@@ -701,9 +647,9 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         }
         if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
         if (!(nep > AUGX_NINF)) return;
-        double te = (VC.tr[0] + D.endP) + nep;
-        val = pv + te;
-        key = bs; aux = 0;
+        te = (VC.tr[0] + D.endP) + nep;
+        key = bs;
+        src = eop <= 0 ? srcCol0(0, a) : srcVig(0, eop);
         return;
     }
     // predecessors are the three longass_f (forward) or rlongdss_f (reverse) states, listed per splice site
@@ -745,124 +691,331 @@ AUGX_KFN void varEvalItem(const TrellisCtx &X, int s, int j, const VarDesc &D, i
         if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
     }
     if (!(nep > AUGX_NINF)) return;
+    // exactly one of the (up to three) ancestors has the reading frame that fits the exon length
     for (int ai = 0; ai < VC.nanc; ai++) {
         if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
-        double pv = li >= 0 ? X.listVal(D.listSel, li, VC.ancWin[ai]) : col0(VC.anc[ai]);
-        if (!(pv > AUGX_NINF)) continue;
-        double v2 = pv + ((VC.tr[ai] + D.endP) + nep);
-        if (better(v2, bs, val, key)) { val = v2; key = bs; aux = ai; }
+        te = (VC.tr[ai] + D.endP) + nep;
+        key = bs;
+        src = li >= 0 ? srcList(ai, D.listSel, VC.ancWin[ai], li) : srcCol0(ai, VC.anc[ai]);
+        break;
     }
 }
 
-// gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`
-// gated variable-length states of the bases [jb, jb+BLK) that belong to `mask`; wavefront w takes every NWAVES-th pair
-AUGX_KFN void trellisVarBlock(TrellisCtx &X, int jb, uint64_t mask, int w, int stride) {
-    // stride == NWAVES: the pairs of `mask` are dealt round-robin to the wavefronts; stride == 1: this wavefront takes all
+// masks of the variable-length states: all but RTERMINAL / RTERMINAL (whose candidate may read the igenic cell of
+// its own block and is therefore ordered after the chain states in the trellis)
+AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
+    maskVar = 0; maskRT = 0;
+    for (int s2 = 0; s2 < T.S; s2++) {
+        if (!T.reachable[s2]) continue;
+        const int kind = T.kind[s2];
+        if (kind == AUGX_K_RTERMINAL) maskRT |= 1ull << s2;
+        else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) maskVar |= 1ull << s2;
+    }
+}
+
+// candidates of block b (bases 8b .. 8b+7) of piece X.p, by wavefront w of the workgroup.
+// write == false: count pairs and items (blkCnt, blkSplit); write == true: emit pairRec / items at blkOff.
+AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, uint64_t maskVar, uint64_t maskRT) {
+    const BatchView &B = X.B;
+    const int n = X.n, jb = b * BLK;
+    const int64_t gblk = X.o / BLK + b;
+    uint64_t pairBase = 0, itemBase = 0;
+    if (write) { pairBase = B.blkOff[gblk * 2]; itemBase = B.blkOff[gblk * 2 + 1]; }
+    int pairsDone = 0;
+    uint32_t itemsDone = 0, split = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        const uint64_t mask = phase == 0 ? maskVar : maskRT;
+        uint64_t g[BLK];   // only ever indexed by fully unrolled loops: stays in registers
+        int off[BLK + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int dj = 0; dj < BLK; dj++) {
+            int j = jb + dj;
+            g[dj] = (j >= 1 && j < n) ? (B.gate[X.o + 1 + j] & mask) : 0;
+            off[dj + 1] = off[dj] + popc64(g[dj]);
+        }
+        const int allPairs = off[BLK];
+        for (int done = 0; done < allPairs; done += WAVE) {
+            const int nPairs = allPairs - done < WAVE ? allPairs - done : WAVE;
+            TV(int, tot);
+            FOR_WLANES(t, w) { // one lane per pair: locate the pair, build its descriptor
+                const int l = t & 63;
+                TX(tot) = 0;
+                if (l < nPairs) {
+                    int want = done + l, dj = 0, first = 0;
+                    uint64_t gg = 0;
+#pragma unroll
+                    for (int d2 = 0; d2 < BLK; d2++)
+                        if (off[d2] <= want && want < off[d2 + 1]) { dj = d2; gg = g[d2]; first = off[d2]; }
+                    for (int k = want - first; k > 0; k--) gg &= gg - 1;
+                    const int s2 = __builtin_ctzll(gg | (1ull << 63));
+                    L.pairJ[w][l] = jb + dj; L.pairS[w][l] = s2;
+                    varDescribe(X, s2, jb + dj, L.desc[w][l]);
+                    TX(tot) = L.desc[w][l].total;
+                    if (write) B.pairRec[pairBase + pairsDone + l] = (uint16_t)((dj << 8) | s2);
+                }
+            }
+            WAVE_SYNC();
+            TV(int, ibase); // inclusive prefix of the candidate counts
+            FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
+            waveInclScan(ibase, w);
+            const int totalItems = waveRead(ibase, w, WAVE - 1);
+            if (write) {
+                for (int base = 0; base < totalItems; base += WAVE) {
+                    TV(int, myPair);
+                    TV(int, myFirst);
+                    FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
+                    for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
+                        const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
+                        FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
+                    }
+                    FOR_WLANES(t, w) { // one candidate per lane
+                        const int l = t & 63;
+                        const int it = base + l;
+                        if (it < totalItems) {
+                            const int q = TX(myPair);
+                            double te; int key; uint32_t src;
+                            varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
+                            if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                            Item I;
+                            I.te = te; I.kp = ((uint32_t)(pairsDone + q) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+                            B.items[itemBase + itemsDone + it] = I;
+                        }
+                    }
+                }
+            }
+            WAVE_SYNC();
+            pairsDone += nPairs;
+            itemsDone += (uint32_t)totalItems;
+        }
+        if (phase == 0) split = itemsDone;
+    }
+    if (!write) {
+        FOR_WLANES(t, w) {
+            if ((t & 63) == 0) { B.blkCnt[gblk * 2] = (uint32_t)pairsDone; B.blkCnt[gblk * 2 + 1] = itemsDone; B.blkSplit[gblk] = split; }
+        }
+    }
+}
+
+// one workgroup = NWAVES consecutive blocks (they belong to one piece: a chunk of CHUNK slots never spans pieces)
+AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg, bool write) {
+    const int64_t gblk0 = wg * NWAVES;
+    if (gblk0 >= B.nBlk) return;
+    const int p = B.chunkPiece[gblk0 * BLK / CHUNK];
+    const int c = B.cls[p];
+    FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, c < 0 ? 0 : c, t, L.vc[t]); }
+    BLOCK_SYNC();
+    CandCtx X(T, B, L.vc, p);
+    uint64_t maskVar, maskRT;
+    varMasks(T, maskVar, maskRT);
+    FOR_WAVES(w) {
+        const int64_t gblk = gblk0 + w;
+        const int b = (int)(gblk - X.o / BLK);
+        candBlock(X, L, w, b, write, maskVar, maskRT);
+    }
+}
+
+// =================================================================================================
+// K2b  trellis: one workgroup of NWAVES wavefronts per piece.  Wavefront 0 walks the piece, block by block, with no
+// workgroup barrier inside a tile of 64 bases; the other wavefronts stage the next tile (signal records, candidates)
+// into the second half of the LDS buffers and flush the back pointers of the previous one.
+// =================================================================================================
+constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM)
+constexpr int PAIR_CAP = 512;
+
+struct TrellisLds {
+    double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
+    uint16_t bp[2][WAVE][SP];       // back pointers of the current / previous tile
+    double sig[2][WAVE][NSIG];      // signal records of the current / next tile
+    int32_t site[2][WAVE][NSITE];
+    double eqPrev[2][WAVE][6];      // predecessor cells of the equalD states (lag dStateLen)
+    uint64_t blkOff[2][BLK + 1][2]; // pair / item offsets of the blocks of the tile
+    uint32_t blkSplit[2][BLK];
+    int32_t listTop[2][BLK][4];     // newest entry of each candidate list at the end of each block
+    Item items[2][ITEM_CAP];
+    uint16_t pairRec[2][PAIR_CAP];
+    double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
+    double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
+    double col0[SP];                // column 0 (initial probabilities)
+    int bpAdj[SP];                  // eop = key - bpAdj[state]
+};
+
+// loads of data this kernel itself stored earlier (other wavefront, or long ago): bypass the per-CU vector cache
+#ifdef AUGX_EMU
+inline double ldCoherent(const double *p) { return *p; }
+#else
+__device__ inline double ldCoherent(const double *p) {
+    unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+#endif
+
+// cross-lane primitives of the trellis wavefront
+#ifdef AUGX_EMU
+// inclusive segmented arg-max scan: lanes with equal kp >> KEY_BITS form a segment (segments are contiguous)
+inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int w) {
+    for (int l = w * WAVE + 1; l < w * WAVE + WAVE; l++)
+        if ((kp[l - 1] >> KEY_BITS) == (kp[l] >> KEY_BITS) && better(val[l - 1], (int)kp[l - 1], val[l], (int)kp[l])) {
+            val[l] = val[l - 1]; kp[l] = kp[l - 1]; src[l] = src[l - 1];
+        }
+}
+inline void waveDown1(const uint32_t *in, uint32_t *out, int w, uint32_t fill) {
+    for (int l = w * WAVE; l < w * WAVE + WAVE; l++) out[l] = l + 1 < w * WAVE + WAVE ? in[l + 1] : fill;
+}
+inline double waveReadD(const double *v, int w, int lane) { return v[w * WAVE + lane]; }
+inline uint32_t waveReadU(const uint32_t *v, int w, int lane) { return v[w * WAVE + lane]; }
+#else
+__device__ inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int) {
+    double v = val[0];
+    uint32_t k = kp[0], s = src[0];
+    const int lane = threadIdx.x & 63;
+    const uint32_t seg = k >> KEY_BITS;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        double ov = __shfl_up(v, o, 64);
+        uint32_t ok = (uint32_t)__shfl_up((int)k, o, 64), os = (uint32_t)__shfl_up((int)s, o, 64);
+        if (lane >= o && (ok >> KEY_BITS) == seg && better(ov, (int)ok, v, (int)k)) { v = ov; k = ok; s = os; }
+    }
+    val[0] = v; kp[0] = k; src[0] = s;
+}
+__device__ inline void waveDown1(const uint32_t *in, uint32_t *out, int, uint32_t fill) {
+    uint32_t x = (uint32_t)__shfl_down((int)in[0], 1, 64);
+    out[0] = (threadIdx.x & 63) == 63 ? fill : x;
+}
+__device__ inline double waveReadD(const double *v, int, int lane) { return __shfl(v[0], lane, 64); }
+__device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return (uint32_t)__shfl((int)v[0], lane, 64); }
+#endif
+
+struct TrellisCtx {
+    const DevTables &T;
+    const BatchView &B;
+    TrellisLds &L;
+    int p;
+    int64_t o;      // slot offset of the piece
+    int64_t lo;     // list offset
+    int n, c, S;
+    int vigLo;      // the igenic window holds bases > vigLo (and <= the newest chain base)
+    AUGX_HD TrellisCtx(const DevTables &t, const BatchView &b, TrellisLds &l, int pp) : T(t), B(b), L(l), p(pp) {
+        o = B.off[p];
+        lo = listOff(B, p);
+        n = B.len[p]; c = B.cls[p]; S = T.S;
+        vigLo = -1;
+    }
+};
+
+// ---- staging of tile `tile` into LDS buffer `buf` by thread tid of nth (next tile: the loader wavefronts)
+AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth) {
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
-    const int n = X.n, S = X.S;
-    uint64_t g[BLK];   // only ever indexed by fully unrolled loops: stays in registers
-    int off[BLK + 1];
-    off[0] = 0;
-#pragma unroll
-    for (int dj = 0; dj < BLK; dj++) {
-        int j = jb + dj;
-        g[dj] = (j >= 1 && j < n) ? (L.gate[j & 63] & mask) : 0;
-        off[dj + 1] = off[dj] + popc64(g[dj]);
+    const int n = X.n, j0 = tile * WAVE, dL = X.T.dStateLen;
+    const int64_t o = X.o, g0 = o + 1 + j0;
+    for (int i = tid; i < WAVE * NSIG; i += nth) {
+        const int l = i / NSIG;
+        L.sig[buf][l][i % NSIG] = (j0 + l < n) ? B.sig[g0 * NSIG + i] : AUGX_NINF;
     }
-    const int allPairs = off[BLK];
-    const int first0 = stride == 1 ? 0 : w, perRound = MAXPW * stride;
-    for (int done = 0; done < allPairs; done += perRound) {
-        const int roundPairs = allPairs - done < perRound ? allPairs - done : perRound;
-        const int nPairs = (roundPairs - first0 + stride - 1) / stride; // pairs done + first0, done + first0 + stride, ...
-        if (nPairs <= 0) continue;
-        TV(int, pj);
-        TV(int, ps);
-        TV(int, tot);
-        FOR_WLANES(t, w) { // one lane per pair: locate the pair, build its descriptor
-            const int l = t & 63;
-            TX(pj) = -1; TX(ps) = 0; TX(tot) = 0;
-            if (l < nPairs) {
-                int want = done + l * stride + first0, dj = 0, first = 0;
-                uint64_t gg = 0;
-#pragma unroll
-                for (int d2 = 0; d2 < BLK; d2++)
-                    if (off[d2] <= want && want < off[d2 + 1]) { dj = d2; gg = g[d2]; first = off[d2]; }
-                for (int k = want - first; k > 0; k--) gg &= gg - 1;
-                const int s2 = __builtin_ctzll(gg | (1ull << 63));
-                TX(pj) = jb + dj; TX(ps) = s2;
-                L.pairJ[w * MAXPW + l] = jb + dj; L.pairS[w * MAXPW + l] = s2;
-                varDescribe(X, s2, jb + dj, L.desc[w * MAXPW + l]);
-                TX(tot) = (B.dbgFlags & 2) ? 0 : L.desc[w * MAXPW + l].total;
-            }
-        }
-        WAVE_SYNC();
-        PROF_MARK(X, 2);
-        TV(int, ibase); // inclusive prefix of the candidate counts
-        FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
-        waveInclScan(ibase, w);
-        const int totalItems = waveRead(ibase, w, WAVE - 1);
-        TV(double, rbv);
-        TV(int, rbk);
-        TV(int, rba);
-        FOR_WLANES(t, w) { TX(rbv) = AUGX_NINF; TX(rbk) = -2147483647; TX(rba) = -1; }
-        PROF_MARK(X, 3);
-        for (int base = 0; base < totalItems; base += WAVE) {
-            TV(int, myPair);
-            TV(int, myFirst);
-            FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
-            for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
-                const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
-                FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
-            }
-            PROF_MARK(X, 4);
-            FOR_WLANES(t, w) { // evaluate one candidate per lane
-                const int l = t & 63;
-                int it = base + l;
-                if (it < totalItems) {
-                    const int q = w * MAXPW + TX(myPair);
-                    const int first = TX(myFirst);
-                    double v; int k2, a2;
-                    varEvalItem(X, L.pairS[q], L.pairJ[q], L.desc[q], it - first, v, k2, a2);
-                    L.itVal[w][l] = v; L.itKey[w][l] = k2; L.itAux[w][l] = a2;
-                }
-            }
-            WAVE_SYNC();
-            PROF_MARK(X, 5);
-            FOR_WLANES(t, w) { // the lane of each pair folds the candidates of this chunk that belong to it
-                const int l = t & 63;
-                if (l < nPairs) {
-                    int lo2 = (TX(ibase) - TX(tot)) - base, hi2 = TX(ibase) - base;
-                    if (lo2 < 0) lo2 = 0;
-                    if (hi2 > WAVE) hi2 = WAVE;
-                    for (int q = lo2; q < hi2; q++)
-                        if (better(L.itVal[w][q], L.itKey[w][q], TX(rbv), TX(rbk))) { TX(rbv) = L.itVal[w][q]; TX(rbk) = L.itKey[w][q]; TX(rba) = L.itAux[w][q]; }
-                }
-            }
-            WAVE_SYNC();
-            PROF_MARK(X, 6);
-        }
-        FOR_WLANES(t, w) {
-            const int l = t & 63;
-            if (l < nPairs) {
-                const int j = TX(pj), s2 = TX(ps);
-                uint16_t bp = BP_NONE;
-                if (TX(rbv) > AUGX_NINF) {
-                    const int kind = L.vc[s2].kind;
-                    int eop = (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) ? TX(rbk) : TX(rbk) - L.vc[s2].g.bpl - 1;
-                    bp = bpVar(TX(rba), j - eop);
-                }
-                L.ring[j & 63][s2] = TX(rbv);
-                L.bp[j & 63][s2] = bp;
-                if (B.cells) B.cells[(X.o + 1 + j) * S + s2] = TX(rbv);
-            }
-        }
-        WAVE_SYNC();
-        PROF_MARK(X, 7);
+    for (int i = tid; i < WAVE * NSITE; i += nth) {
+        const int l = i / NSITE;
+        L.site[buf][l][i % NSITE] = (j0 + l < n) ? B.site[g0 * NSITE + i] : -1;
+    }
+    for (int i = tid; i < WAVE * 6; i += nth) {
+        const int l = i / 6, q = j0 + l;
+        L.eqPrev[buf][l][i % 6] = (dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
+    }
+    const int64_t gb0 = o / BLK + (int64_t)tile * BLK;
+    for (int i = tid; i < (BLK + 1) * 2; i += nth) {
+        int64_t gb = gb0 + i / 2;
+        if (gb > B.nBlk) gb = B.nBlk;
+        L.blkOff[buf][i / 2][i % 2] = B.blkOff[gb * 2 + i % 2];
+    }
+    for (int i = tid; i < BLK; i += nth) L.blkSplit[buf][i] = gb0 + i < B.nBlk ? B.blkSplit[gb0 + i] : 0;
+    for (int i = tid; i < BLK * 4; i += nth) {
+        int q = j0 + (i / 4) * BLK + BLK - 1;
+        if (q > n - 1) q = n - 1;
+        L.listTop[buf][i / 4][i % 4] = (int32_t)B.cnt[fidx(o + 1 + q, CNT_LA + i % 4, NCNT)] - 1;
+    }
+    int64_t gbE = gb0 + BLK;
+    if (gbE > B.nBlk) gbE = B.nBlk;
+    {
+        const uint64_t first = B.blkOff[gb0 * 2 + 1], last = B.blkOff[gbE * 2 + 1];
+        const int cnt = last - first < (uint64_t)ITEM_CAP ? (int)(last - first) : ITEM_CAP;
+        for (int i = tid; i < cnt; i += nth) L.items[buf][i] = B.items[first + i];
+    }
+    {
+        const uint64_t first = B.blkOff[gb0 * 2], last = B.blkOff[gbE * 2];
+        const int cnt = last - first < (uint64_t)PAIR_CAP ? (int)(last - first) : PAIR_CAP;
+        for (int i = tid; i < cnt; i += nth) L.pairRec[buf][i] = B.pairRec[first + i];
+    }
+}
+// write the back pointers of tile `tile` (LDS buffer buf) to HBM and reset the buffer
+AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int nth) {
+    const int j0 = tile * WAVE;
+    for (int i = tid; i < WAVE * SP; i += nth) {
+        const int r = i / SP;
+        if (j0 + r < X.n) X.B.bp[(X.o + 1 + j0) * SP + i] = X.L.bp[buf][r][i % SP];
+        X.L.bp[buf][r][i % SP] = BP_NONE;
     }
 }
 
-// One workgroup of NWAVES wavefronts per piece.  Thread t: st = t & 63 is "its" state, q4 = t >> 6 its quarter.
+// ---- candidates [lo, hi) of block blk (tile buffer buf) of the trellis wavefront: add the predecessor value, reduce
+//      per (base, state) pair, publish.  Candidates of one pair are contiguous; a pair may span several chunks of 64.
+AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, uint64_t lo, uint64_t hi) {
+    const BatchView &B = X.B;
+    TrellisLds &L = X.L;
+    const int S = X.S;
+    const uint64_t tileItem0 = L.blkOff[buf][0][1], tilePair0 = L.blkOff[buf][0][0], blkPair0 = L.blkOff[buf][blk][0];
+    double cv = AUGX_NINF;       // best of the last pair of the previous chunk (it may continue in this one)
+    uint32_t ckp = 0xFFFFFFFFu, csrc = 0;
+    for (uint64_t base = lo; base < hi; base += WAVE) {
+        TV(double, val);
+        TV(uint32_t, kp);
+        TV(uint32_t, src);
+        TV(uint32_t, nkp);
+        FOR_WLANES(t, 0) {
+            const int l = t & 63;
+            const uint64_t it = base + l;
+            TX(val) = AUGX_NINF; TX(kp) = 0xFFFFFFFFu; TX(src) = 0;
+            if (it < hi) {
+                const Item I = (it - tileItem0 < (uint64_t)ITEM_CAP) ? L.items[buf][it - tileItem0] : B.items[it];
+                const uint32_t sr = I.src, tag = sr >> 30;
+                double pv;
+                if (tag == SRC_LIST) {
+                    const int sel = (sr >> 26) & 3, fr = (sr >> 24) & 3, li = (int)(sr & 0xFFFFFFu);
+                    if (li > L.listTop[buf][blk][sel] - LIST_WIN) pv = L.lcVal[sel][li & (LIST_WIN - 1)][fr];
+                    else {
+                        const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                        pv = ldCoherent(&a[(X.lo + li) * 3 + fr]);
+                    }
+                } else if (tag == SRC_VIG) {
+                    const int eop = (int)(sr & 0xFFFFFFu);
+                    pv = eop > X.vigLo ? L.vigw[eop & (VIG_WIN - 1)] : ldCoherent(&B.vig[X.o + 1 + eop]);
+                } else
+                    pv = L.col0[sr & 0xFFu];
+                TX(val) = pv + I.te;
+                TX(kp) = I.kp; TX(src) = sr;
+            }
+            if (l == 0 && (ckp >> KEY_BITS) == (TX(kp) >> KEY_BITS) && better(cv, (int)ckp, TX(val), (int)TX(kp))) {
+                TX(val) = cv; TX(kp) = ckp; TX(src) = csrc;
+            }
+        }
+        waveSegScan(val, kp, src, 0);
+        waveDown1(kp, nkp, 0, 0xFFFFFFFFu);
+        FOR_WLANES(t, 0) { // the last lane of every segment publishes (a pair continuing in the next chunk is overwritten there)
+            const uint32_t k2 = TX(kp);
+            if (k2 != 0xFFFFFFFFu && (TX(nkp) >> KEY_BITS) != (k2 >> KEY_BITS) && TX(val) > AUGX_NINF) {
+                const uint64_t pi = blkPair0 + (k2 >> KEY_BITS);
+                const uint16_t pr = (pi - tilePair0 < (uint64_t)PAIR_CAP) ? L.pairRec[buf][pi - tilePair0] : B.pairRec[pi];
+                const int j = jb + (pr >> 8), s2 = pr & 0xFF;
+                const int eop = (int)(k2 & KEY_MASK) - L.bpAdj[s2];
+                L.ring[j & 63][s2] = TX(val);
+                L.bp[buf][j & 63][s2] = bpVar((int)((TX(src) >> 28) & 3), j - eop);
+                if (B.cells) B.cells[(X.o + 1 + j) * S + s2] = TX(val);
+            }
+        }
+        cv = waveReadD(val, 0, WAVE - 1); ckp = waveReadU(kp, 0, WAVE - 1); csrc = waveReadU(src, 0, WAVE - 1);
+        WAVE_SYNC();
+    }
+}
+
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int p) {
     TrellisCtx X(T, B, L, p);
     const int n = X.n, S = X.S, c = X.c;
@@ -895,424 +1048,252 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             return;
         }
     }
-    // ---- per-thread constants of state st = t & 63.  cls: 0 chain (lag 1), 1 fixed lag, 2 variable, 3 RTERMINAL, -1 off
-    TV(int, hCls);
-    TV(int, hLag);
-    TV(int, hSig);
-    TV(int, hLong);
-    TV(int, hNanc);
-    TV2(int, hAnc, 5);
-    TV2(double, hTr, 5);
-    TV(int, hLrow);
-    TV(int, hList);
-    TV(int, hFrame);
-    TV(int, hIgenic);
-    // each wavefront specialises on one family of variable-length states (its instruction stream then only runs the
-    // branches of that family): 0 internal/terminal, 1 initial/single, 2 short introns, 3 reverse exons but RTERMINAL
-    uint64_t maskVar = 0, maskRT = 0;
-    uint64_t maskW[NWAVES];
+    // ---- per-lane constants of the trellis wavefront.
+    //   fixed-lag states (longdss, longass, equalD): FR rounds of 64 cells, lane = (state slot, base of the block)
+    //   variable-length states: VR rounds of 64 cells to reset
+    //   chain states (igenic, geometric introns): lane = (chain slot, base of the block)
+    constexpr int FR = 3, VR = 4;
+    TV2(int, fS, FR); TV2(int, fLag, FR); TV2(int, fSig, FR); TV2(int, fLong, FR); TV2(int, fNanc, FR);
+    TV2(int, fAnc0, FR); TV2(int, fAnc1, FR); TV2(double, fTr0, FR); TV2(double, fTr1, FR);
+    TV2(int, fLrow, FR); TV2(int, fList, FR); TV2(int, fFrame, FR);
+    TV2(int, vS, VR);
+    TV(int, cS); TV(int, cSig); TV(int, cNanc); TV(int, cSelf); TV(int, cIsIg);
+    TV2(int, cAnc, 5); TV2(double, cTr, 5);
+    FOR_THREADS(t) {
+        const int l = t & 63, slot = l >> 3;
 #pragma unroll
-    for (int i = 0; i < NWAVES; i++) maskW[i] = 0;
-    for (int s2 = 0; s2 < S; s2++) {
-        if (!T.reachable[s2]) continue;
-        const int kind = T.kind[s2];
-        const uint64_t bit = 1ull << s2;
-        int fam = -1;
-        switch (kind) {
-        case AUGX_K_RTERMINAL: maskRT |= bit; break;
-        case AUGX_K_INTERNAL: fam = 0; break;
-        case AUGX_K_TERMINAL: fam = 1; break;
-        case AUGX_K_INITIAL: fam = 2; break;
-        case AUGX_K_SINGLE: case AUGX_K_RSINGLE: fam = 3; break;
-        case AUGX_K_LESSD: fam = 4; break;
-        case AUGX_K_RLESSD: fam = 5; break;
-        case AUGX_K_RINTERNAL: fam = 6; break;
-        case AUGX_K_RINITIAL: fam = 7; break;
-        default: break;
+        for (int r = 0; r < FR; r++) {
+            fS[r][TI] = -1; fLag[r][TI] = 1; fSig[r][TI] = 0; fLong[r][TI] = 0; fNanc[r][TI] = 0; fAnc0[r][TI] = 0; fAnc1[r][TI] = 0;
+            fTr0[r][TI] = AUGX_NINF; fTr1[r][TI] = AUGX_NINF; fLrow[r][TI] = -1; fList[r][TI] = -1; fFrame[r][TI] = 0;
         }
 #pragma unroll
-        for (int i = 0; i < NWAVES; i++) if (fam >= 0 && i == fam % NWAVES) maskW[i] |= bit;
-    }
+        for (int r = 0; r < VR; r++) vS[r][TI] = -1;
+        TX(cS) = -1; TX(cSig) = 0; TX(cNanc) = 0; TX(cSelf) = 5; TX(cIsIg) = 0;
 #pragma unroll
-    for (int i = 0; i < NWAVES; i++) maskVar |= maskW[i];
-    FOR_THREADS(t) {
-        const int l = t & 63;
-        TX(hCls) = -1; TX(hLag) = -1; TX(hSig) = 0; TX(hLong) = 0; TX(hNanc) = 0; TX(hLrow) = -1; TX(hList) = -1; TX(hFrame) = 0; TX(hIgenic) = 0;
-#pragma unroll
-        for (int i = 0; i < 5; i++) { hAnc[i][TI] = 0; hTr[i][TI] = AUGX_NINF; }
-        if (l < S && T.reachable[l]) {
-            const int kind = T.kind[l];
-            TX(hCls) = kind == AUGX_K_RTERMINAL ? 3 : 2;
+        for (int i = 0; i < 5; i++) { cAnc[i][TI] = 0; cTr[i][TI] = AUGX_NINF; }
+        int nf = 0, nv = 0, nc = 0;
+        for (int s2 = 0; s2 < S; s2++) {
+            if (!T.reachable[s2]) continue;
+            const int kind = T.kind[s2];
+            int lag = -1, sg = 0, lng = 0;
             switch (kind) {
-            case AUGX_K_IGENIC: TX(hLag) = 1; TX(hSig) = SIG_EIG; TX(hCls) = 0; break;
-            case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC: TX(hLag) = 1; TX(hSig) = SIG_EIN; TX(hCls) = 0; break;
-            case AUGX_K_LONGDSS: TX(hLag) = dssWhole; TX(hSig) = SIG_DSSF; TX(hCls) = 1; break;
-            case AUGX_K_RLONGDSS: TX(hLag) = dssWhole; TX(hSig) = SIG_DSSR; TX(hCls) = 1; break;
-            case AUGX_K_LONGASS: TX(hLag) = assLag; TX(hSig) = SIG_ASSF; TX(hCls) = 1; break;
-            case AUGX_K_RLONGASS: TX(hLag) = assLag; TX(hSig) = SIG_ASSR; TX(hCls) = 1; break;
-            case AUGX_K_EQUALD: case AUGX_K_REQUALD: TX(hLag) = dL; TX(hSig) = SIG_EQD; TX(hLong) = dL >= WAVE; TX(hCls) = 1; break;
+            case AUGX_K_LONGDSS: lag = dssWhole; sg = SIG_DSSF; break;
+            case AUGX_K_RLONGDSS: lag = dssWhole; sg = SIG_DSSR; break;
+            case AUGX_K_LONGASS: lag = assLag; sg = SIG_ASSF; break;
+            case AUGX_K_RLONGASS: lag = assLag; sg = SIG_ASSR; break;
+            case AUGX_K_EQUALD: case AUGX_K_REQUALD: lag = dL; sg = SIG_EQD; lng = dL >= WAVE; break;
             default: break;
             }
-            if (TX(hLag) > 0) {
-                TX(hNanc) = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
+            if (lag > 0) {
+                const int r = nf / 8;
+                if (r < FR && (nf & 7) == slot) {
 #pragma unroll
-                for (int ai = 0; ai < 5; ai++) {
-                    if (ai >= TX(hNanc)) continue;
-                    int a = T.anc[l][ai];
-                    hAnc[ai][TI] = TX(hLong) ? longRow(T, a) : a;
-                    hTr[ai][TI] = lnT(T, c, a, l);
+                    for (int rr = 0; rr < FR; rr++)
+                        if (rr == r) {
+                            fS[rr][TI] = s2; fLag[rr][TI] = lag; fSig[rr][TI] = sg; fLong[rr][TI] = lng;
+                            fNanc[rr][TI] = T.n_anc[s2] < 2 ? T.n_anc[s2] : 2;
+                            const int a0 = T.anc[s2][0], a1 = T.n_anc[s2] > 1 ? T.anc[s2][1] : 0;
+                            fAnc0[rr][TI] = lng ? longRow(T, a0) : a0; fAnc1[rr][TI] = lng ? longRow(T, a1) : a1;
+                            fTr0[rr][TI] = lnT(T, c, a0, s2); fTr1[rr][TI] = T.n_anc[s2] > 1 ? lnT(T, c, a1, s2) : AUGX_NINF;
+                            fLrow[rr][TI] = longRow(T, s2);
+                            fList[rr][TI] = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
+                            fFrame[rr][TI] = T.win[s2];
+                        }
                 }
-            }
-            TX(hLrow) = longRow(T, l);
-            TX(hFrame) = T.win[l];
-            TX(hIgenic) = kind == AUGX_K_IGENIC;
-            TX(hList) = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
-            if (t < WAVE) { // LDS copy of the constants of the variable-length states
-                VarConst &VC = L.vc[l];
-                VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
-                for (int ai = 0; ai < 4; ai++) {
-                    int a = ai < VC.nanc ? T.anc[l][ai] : 0;
-                    VC.anc[ai] = a; VC.ancWin[ai] = T.win[a]; VC.tr[ai] = ai < VC.nanc ? lnT(T, c, a, l) : AUGX_NINF;
+                nf++;
+            } else if (kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC) {
+                if (nc == slot) {
+                    TX(cS) = s2; TX(cSig) = kind == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN; TX(cIsIg) = kind == AUGX_K_IGENIC;
+                    TX(cNanc) = T.n_anc[s2] < 5 ? T.n_anc[s2] : 5;
+#pragma unroll
+                    for (int ai = 0; ai < 5; ai++)
+                        if (ai < TX(cNanc)) {
+                            cAnc[ai][TI] = T.anc[s2][ai]; cTr[ai][TI] = lnT(T, c, T.anc[s2][ai], s2);
+                            if (T.anc[s2][ai] == s2) TX(cSelf) = ai;
+                        }
                 }
-                VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
+                nc++;
+            } else {
+                const int r = nv / 8;
+                if (r < VR && (nv & 7) == slot) {
+#pragma unroll
+                    for (int rr = 0; rr < VR; rr++) if (rr == r) vS[rr][TI] = s2;
+                }
+                nv++;
             }
         }
-    }
-    // ---- step-3 work items: one (chain state, ancestor, base of the block) triple per thread
-    FOR_THREADS(t) {
-        if (t == 0) {
-            int nc = 0;
-            for (int s2 = 0; s2 < S && nc < 8; s2++)
-                if (T.reachable[s2] && (T.kind[s2] == AUGX_K_IGENIC || T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC)) L.chainIds[nc++] = s2;
-            L.nChain = nc;
+        // LDS tables
+        if (t < SP) {
+            double v = AUGX_NINF;
+            if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
+            L.col0[t] = v;
+            int adj = 0;
+            if (t < S) {
+                const int kind = T.kind[t];
+                if (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) adj = exGeom(T, kind).bpl + 1;
+            }
+            L.bpAdj[t] = adj;
+        }
+        for (int i = t; i < WAVE * SP; i += NT) {
+            L.ring[i / SP][i % SP] = AUGX_NINF;
+            L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
         }
     }
     BLOCK_SYNC();
-    TV(int, ciCs);   // chain-state slot, -1: no item
-    TV(int, ciAi);
-    TV(int, ciDj);
-    TV(int, ciAnc);
-    TV(int, ciSig);
-    TV(int, ciSelf);
-    TV(double, ciTr);
-    const int nChain = L.nChain;
-    FOR_THREADS(t) {
-        TX(ciCs) = -1; TX(ciAi) = 0; TX(ciDj) = 0; TX(ciAnc) = 0; TX(ciSig) = 0; TX(ciSelf) = 0; TX(ciTr) = AUGX_NINF;
-        int base = 0;
-        for (int cs = 0; cs < nChain; cs++) {
-            const int s2 = L.chainIds[cs];
-            const int na = T.n_anc[s2] < 5 ? T.n_anc[s2] : 5;
-            if (t >= base && t < base + na * BLK) {
-                const int ai = (t - base) / BLK;
-                const int a = T.anc[s2][ai];
-                TX(ciCs) = cs; TX(ciAi) = ai; TX(ciDj) = (t - base) % BLK; TX(ciAnc) = a; TX(ciSelf) = a == s2;
-                TX(ciSig) = T.kind[s2] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
-                TX(ciTr) = lnT(T, c, a, s2);
-            }
-            base += na * BLK;
-        }
-    }
-    FOR_THREADS(t) { // length distributions into LDS
-        for (int i = t; i < LEN_WIN; i += NT) {
-            const bool in = i <= T.max_exon_len;
-            L.lenw[0][i] = in ? T.len_single[i] : AUGX_NINF; L.lenw[1][i] = in ? T.len_initial[i] : AUGX_NINF;
-            L.lenw[2][i] = in ? T.len_internal[i] : AUGX_NINF; L.lenw[3][i] = in ? T.len_terminal[i] : AUGX_NINF;
-        }
-        for (int i = t; i < LENI_MAX; i += NT) L.leniw[i] = i <= T.d ? T.len_intron[i] : AUGX_NINF;
-    }
     // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
     FOR_THREADS(t) {
-        if (t < SP) {
-            const int l = t;
-            double v = AUGX_NINF;
-            if (l < S) v = B.initKind[p] == 0 ? T.ln_init[l] : (l == T.synch ? 0.0 : AUGX_NINF);
-            L.ring[0][l] = v;
-            L.bp[0][l] = BP_NONE;
-            if (l < S) {
-                if (TX(hLrow) >= 0) B.longV[(o + 1) * 6 + TX(hLrow)] = v;
-                if (B.cells) B.cells[(o + 1) * S + l] = v;
-                if (TX(hIgenic)) { B.vig[o + 1] = v; L.vigw[0] = v; }
-            }
+        if (t < S) {
+            const double v = L.col0[t];
+            L.ring[0][t] = v;
+            const int lr = longRow(T, t);
+            if (lr >= 0) B.longV[(o + 1) * 6 + lr] = v;
+            if (B.cells) B.cells[(o + 1) * S + t] = v;
+            if (T.kind[t] == AUGX_K_IGENIC) { B.vig[o + 1] = v; L.vigw[0] = v; }
         }
+        loadTileThread(X, 0, 0, t, NT);
     }
-    X.vigLo = -1;
-    X.P.wcode = L.codew;
-    X.P.wns = L.nsw;
-    BLOCK_SYNC();
-#if defined(AUGX_PROF) && !defined(AUGX_EMU)
-    for (int i = 0; i < 16; i++) X.pacc[i] = 0;
-    X.plast = clock64();
-#endif
-    for (int j0 = 0; j0 < n; j0 += WAVE) {
-        BLOCK_GLOBAL_SYNC(); // everything this workgroup stored to HBM so far is visible to its own later loads
-        // ---- load the tile of per-base records for bases j0..j0+63 and advance the LDS windows; the four
-        //      wavefronts share the work by record type (every row of 64 loads is coalesced)
-        FOR_THREADS(t) {
-            const int l = t & 63, q4 = (B.dbgFlags & 64) ? 99 : (t >> 6);
-            const int q = j0 + l;
-            const int64_t gq = o + 1 + q;
-            if (q4 == 0) {
-                for (int i = 0; i < NSIG; i++) L.sig[l][i] = B.sig[gq * NSIG + i];
-                L.gate[l] = B.gate[gq];
-                for (int i = 0; i < NSITE; i++) L.site[l][i] = B.site[gq * NSITE + i];
-                if (q != 0) for (int s2 = 0; s2 < SP; s2++) L.bp[l][s2] = BP_NONE;
-            } else if (q4 == 1) {
-                // code window: bases [j0+64, j0+128) (first tile: also [0, 64))
-                for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
-                    int qq = j0 + r * WAVE + l;
-                    if (qq < n) L.codew[qq & (CODE_WIN - 1)] = B.code[o + 1 + qq];
+    const int nTiles = (n + WAVE - 1) / WAVE;
+    BLOCK_GLOBAL_SYNC();
+    for (int tile = 0; tile < nTiles; tile++) {
+        const int buf = tile & 1, j0 = tile * WAVE;
+        FOR_WAVES(w) {
+            if (w != 0) {
+                // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
+                FOR_WLANES(t, w) {
+                    if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - WAVE, NT - WAVE);
+                    if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - WAVE, NT - WAVE);
                 }
-                // stop tables: bases [j0+16, j0+80) (first tile: also [0, 16))
-                for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
-                    int qq = r == 0 ? l : j0 + 16 + l;
-                    if (r == 0 && l >= 16) continue;
-                    if (qq < n) for (int f = 0; f < 6; f++) L.nsw[(qq & (NS_WIN - 1)) * 6 + f] = (uint32_t)B.nsm[fidx(o + 1 + qq, f, 6)];
-                }
-                // site counts: bases [j0+64, j0+128) (first tile: also [0, 64))
-                for (int r = (j0 == 0 ? 0 : 1); r < 2; r++) {
-                    int qq = j0 + r * WAVE + l;
-                    if (qq < n) for (int f = 0; f < 6; f++) L.cntw[qq & (CNT_WIN - 1)][f] = (uint32_t)B.cnt[fidx(o + 1 + qq, CNT_ATG + f, NCNT)];
-                }
-            } else if (q4 == 2) {
-                // content prefix sums and reverse P_ls terms of the bases of this tile
-                if (q < n) {
-                    for (int f = 0; f < NFX; f++) L.fxw[q & (FX_WIN - 1)][f] = B.fx[fidx(gq, f, NFX)];
-                    for (int f = 0; f < 3; f++) L.plsRw[q & (FX_WIN - 1)][f] = B.plsR[gq * 3 + f];
-                }
-            } else if (q4 == 3) {
-                // predecessor cells of the equalD states (lag dStateLen >= 64: written long ago by this workgroup)
-                for (int f = 0; f < 6; f++) L.eqPrev[l][f] = (dL >= WAVE && q - dL >= 0 && q < n) ? B.longV[(gq - dL) * 6 + f] : AUGX_NINF;
-                // candidate-side constants of the list entries whose site lies in this tile
-                if (q < n) {
-                    for (int sel = 0; sel < 4; sel++) {
-                        int si = B.site[gq * NSITE + sel];
-                        if (si < 0) continue;
-                        const int sl = si & (LIST_WIN - 1);
-                        L.lcPos[sel][sl] = q;
-                        for (int a = 0; a < 3; a++) {
-                            if (sel == 0) { L.lcC[0][sl][a] = B.laPls[(X.lo + si) * 3 + a]; L.lcFx[0][sl][a] = B.laFx[(X.lo + si) * 3 + a]; }
-                            if (sel == 1) { L.lcC[1][sl][a] = B.lrEt[(X.lo + si) * 3 + a]; L.lcFx[1][sl][a] = B.lrFx[(X.lo + si) * 3 + a]; }
-                        }
-                        if (sel == 2) L.lcFx[2][sl][0] = B.ldFx[X.lo + si];
-                        if (sel == 3) L.lcFx[3][sl][0] = B.rdFx[X.lo + si];
-                    }
-                    // start codons of this tile
-                    uint32_t ac = (uint32_t)B.cnt[fidx(gq, CNT_ATG, NCNT)], ap = (uint32_t)B.cnt[fidx(gq - 1, CNT_ATG, NCNT)];
-                    if (ac != ap) {
-                        const int ai2 = (int)ac - 1, sl = ai2 & (ATG_WIN - 1);
-                        L.aPos[sl] = q;
-                        for (int a = 0; a < 3; a++) L.aD[sl][a] = B.atgD[(X.lo + ai2) * 3 + a];
-                        L.aFx[sl] = B.atgFx[X.lo + ai2];
-                    }
-                }
-            }
-        }
-        BLOCK_SYNC();
-        {
-            int hi = j0 + 2 * WAVE < n ? j0 + 2 * WAVE : n;
-            X.P.wcHi = hi; X.P.wcLo = hi - CODE_WIN > 0 ? hi - CODE_WIN : 0;
-            X.kwHi = hi; X.kwLo = hi - CNT_WIN > 0 ? hi - CNT_WIN : 0;
-            int hn = j0 + 80 < n ? j0 + 80 : n;
-            X.P.wnHi = hn; X.P.wnLo = hn - NS_WIN > 0 ? hn - NS_WIN : 0;
-            int hf = j0 + WAVE < n ? j0 + WAVE : n;
-            X.fwHi = hf; X.fwLo = hf - FX_WIN > 0 ? hf - FX_WIN : 0;
-            // list entries of sites up to the end of this tile are in the LDS caches (values follow as the trellis advances)
-            X.listHi0 = (int)X.cntAt(hf - 1, CNT_LA) - 1;
-            X.listHi1 = (int)X.cntAt(hf - 1, CNT_LR) - 1;
-            X.listHi2 = (int)X.cntAt(hf - 1, CNT_LD) - 1;
-            X.listHi3 = (int)X.cntAt(hf - 1, CNT_RD) - 1;
-            X.atgHi = (int)X.cntAt(hf - 1, CNT_ATG) - 1;
-        }
-        PROF_MARK(X, 0);
-        for (int jb = j0; jb < j0 + WAVE && jb < n; jb += BLK) {
-            // ---- step 1: fixed-length states with lag > BLK: thread = (state, quarter of the block)
-            constexpr int CPT = BLK / NWAVES; // cells per thread
-            FOR_THREADS(t) {
-                const int l = t & 63, q4 = t >> 6;
-                if (TX(hCls) == 1 && !(B.dbgFlags & 16)) {
-                    const int lag = TX(hLag), nanc = TX(hNanc);
-                    double emi[CPT], pv0[CPT], pv1[CPT];
+            } else {
+                // ---- trellis wavefront
+                for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
+                    const int jb = j0 + blk * BLK;
+                    // step 1: fixed-lag states (lag > BLK): all loads first, then the two-way max
+                    FOR_WLANES(t, 0) {
+                        const int l = t & 63, dj = l & 7, j = jb + dj;
+                        double emi[FR], pv0[FR], pv1[FR];
 #pragma unroll
-                    for (int d = 0; d < CPT; d++) { // independent LDS loads first
-                        const int j = jb + q4 * CPT + d, jp = j - lag;
-                        emi[d] = L.sig[j & 63][TX(hSig)];
-                        pv0[d] = AUGX_NINF; pv1[d] = AUGX_NINF;
-                        if (jp >= 0) {
-                            if (TX(hLong)) { pv0[d] = L.eqPrev[j & 63][hAnc[0][TI]]; if (nanc > 1) pv1[d] = L.eqPrev[j & 63][hAnc[1][TI]]; }
-                            else { pv0[d] = L.ring[jp & 63][hAnc[0][TI]]; if (nanc > 1) pv1[d] = L.ring[jp & 63][hAnc[1][TI]]; }
-                        }
-                    }
-#pragma unroll
-                    for (int d = 0; d < CPT; d++) {
-                        const int j = jb + q4 * CPT + d;
-                        if (j < 1 || j >= n) continue;
-                        double best = AUGX_NINF;
-                        uint16_t bp = BP_NONE;
-                        if (j - lag >= 0 && emi[d] > AUGX_NINF) {
-                            if (pv0[d] > AUGX_NINF) { best = pv0[d] + (hTr[0][TI] + emi[d]); bp = bpFixed(0); }
-                            if (nanc > 1 && pv1[d] > AUGX_NINF) {
-                                double v2 = pv1[d] + (hTr[1][TI] + emi[d]);
-                                if (v2 > best) { best = v2; bp = bpFixed(1); }
+                        for (int r = 0; r < FR; r++) {
+                            const int jp = j - fLag[r][TI];
+                            emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
+                            pv0[r] = AUGX_NINF; pv1[r] = AUGX_NINF;
+                            if (fS[r][TI] >= 0 && jp >= 0) {
+                                if (fLong[r][TI]) { pv0[r] = L.eqPrev[buf][j & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.eqPrev[buf][j & 63][fAnc1[r][TI]]; }
+                                else { pv0[r] = L.ring[jp & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.ring[jp & 63][fAnc1[r][TI]]; }
                             }
                         }
-                        L.ring[j & 63][l] = best;
-                        L.bp[j & 63][l] = bp;
-                        if (TX(hLrow) >= 0) B.longV[(o + 1 + j) * 6 + TX(hLrow)] = best;
-                        if (B.cells) B.cells[(o + 1 + j) * S + l] = best;
-                        if (TX(hList) >= 0) {
-                            int si = L.site[j & 63][TX(hList)];
-                            if (si >= 0) {
-                                double *lval = TX(hList) == 0 ? B.laVal : TX(hList) == 1 ? B.lrVal : TX(hList) == 2 ? B.ldVal : B.rdVal;
-                                lval[(X.lo + si) * 3 + TX(hFrame)] = best;
-                                L.lcVal[TX(hList)][si & (LIST_WIN - 1)][TX(hFrame)] = best;
+#pragma unroll
+                        for (int r = 0; r < FR; r++) {
+                            const int s2 = fS[r][TI];
+                            if (s2 < 0 || j < 1 || j >= n) continue;
+                            double best = AUGX_NINF;
+                            uint16_t bp = BP_NONE;
+                            if (j - fLag[r][TI] >= 0 && emi[r] > AUGX_NINF) {
+                                if (pv0[r] > AUGX_NINF) { best = pv0[r] + (fTr0[r][TI] + emi[r]); bp = bpFixed(0); }
+                                if (fNanc[r][TI] > 1 && pv1[r] > AUGX_NINF) {
+                                    double v2 = pv1[r] + (fTr1[r][TI] + emi[r]);
+                                    if (v2 > best) { best = v2; bp = bpFixed(1); }
+                                }
+                            }
+                            L.ring[j & 63][s2] = best;
+                            L.bp[buf][j & 63][s2] = bp;
+                            if (fLrow[r][TI] >= 0) B.longV[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
+                            if (B.cells) B.cells[(o + 1 + j) * S + s2] = best;
+                            if (fList[r][TI] >= 0) {
+                                const int si = L.site[buf][j & 63][fList[r][TI]];
+                                if (si >= 0) {
+                                    double *lval = fList[r][TI] == 0 ? B.laVal : fList[r][TI] == 1 ? B.lrVal : fList[r][TI] == 2 ? B.ldVal : B.rdVal;
+                                    lval[(X.lo + si) * 3 + fFrame[r][TI]] = best;
+                                    L.lcVal[fList[r][TI]][si & (LIST_WIN - 1)][fFrame[r][TI]] = best;
+                                }
+                            }
+                        }
+                        // cells of variable-length states are absent unless a candidate survives
+#pragma unroll
+                        for (int r = 0; r < VR; r++) {
+                            const int s2 = vS[r][TI];
+                            if (s2 < 0 || j < 1 || j >= n) continue;
+                            L.ring[j & 63][s2] = AUGX_NINF;
+                            if (B.cells) B.cells[(o + 1 + j) * S + s2] = AUGX_NINF;
+                        }
+                    }
+                    WAVE_SYNC();
+                    // step 2: variable-length states but RTERMINAL
+                    const uint64_t it0 = L.blkOff[buf][blk][1], it1 = L.blkOff[buf][blk + 1][1], itS = it0 + L.blkSplit[buf][blk];
+                    if (itS > it0) trellisItems(X, buf, blk, jb, it0, itS);
+                    // step 3: the lag-1 chain states.  Lane (slot, dj): best ancestor before / after the state itself in
+                    // ascending ancestor order with strict '>' (reference src/igenicmodel.cc:247-255,
+                    // src/intronmodel.cc:757-786); then the 8-step recurrence along the block, one lane per base.
+                    TV(double, res);
+                    TV(double, prevRes);
+                    FOR_WLANES(t, 0) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
+                    TV(double, bB); TV(double, bA); TV(double, teS); TV(double, psS);
+                    TV(int, aB); TV(int, aA); TV(int, rai);
+                    FOR_WLANES(t, 0) {
+                        const int l = t & 63, dj = l & 7, j = jb + dj;
+                        TX(bB) = AUGX_NINF; TX(bA) = AUGX_NINF; TX(aB) = -1; TX(aA) = -1; TX(teS) = AUGX_NINF; TX(psS) = AUGX_NINF; TX(rai) = -1;
+                        if (TX(cS) >= 0) {
+                            const bool valid = j >= 1 && j < n;
+                            const double emi = valid ? L.sig[buf][j & 63][TX(cSig)] : AUGX_NINF;
+                            double pv[5];
+#pragma unroll
+                            for (int ai = 0; ai < 5; ai++) pv[ai] = L.ring[(j - 1) & 63][cAnc[ai][TI]];
+#pragma unroll
+                            for (int ai = 0; ai < 5; ai++) {
+                                if (ai >= TX(cNanc)) continue;
+                                const double te = cTr[ai][TI] + emi;
+                                if (ai == TX(cSelf)) { TX(teS) = te; TX(psS) = pv[ai]; }
+                                else {
+                                    const double v = pv[ai] + te;
+                                    if (ai < TX(cSelf)) { if (v > TX(bB)) { TX(bB) = v; TX(aB) = ai; } }
+                                    else { if (v > TX(bA)) { TX(bA) = v; TX(aA) = ai; } }
+                                }
                             }
                         }
                     }
-                } else if (TX(hCls) >= 2 || (l < SP && TX(hCls) < 0)) {
-                    // cells of variable-length states are absent unless their gate is open and a candidate survives
 #pragma unroll
-                    for (int d = 0; d < CPT; d++) {
-                        const int j = jb + q4 * CPT + d;
-                        if (j < 1 || j >= n) continue;
-                        L.ring[j & 63][l] = AUGX_NINF;
-                        if (B.cells && l < S) B.cells[(o + 1 + j) * S + l] = AUGX_NINF;
-                    }
-                }
-            }
-            BLOCK_SYNC();
-            PROF_MARK(X, 1);
-            // ---- step 2: variable-length states (all but RTERMINAL): they depend on fixed-state cells (just published)
-            //      and on igenic cells at least BLK bases back.  Pairs are dealt round-robin to the wavefronts.
-            uint64_t anyVar = 0, anyRT = 0;
-            for (int dj = 0; dj < BLK; dj++) {
-                int j = jb + dj;
-                if (j >= 1 && j < n) { uint64_t gg = L.gate[j & 63]; anyVar |= gg & maskVar; anyRT |= gg & maskRT; }
-            }
-            // (HBM re-reads only touch data at least one tile old -- the LDS caches cover 64 sites / 512 bases -- and
-            //  the store queue is drained at every tile boundary, so no wait is needed here)
-            PROF_MARK(X, 12);
-            if (anyVar && !(B.dbgFlags & 1)) {
-                FOR_WAVES(w) {
-                    uint64_t mw = 0;
-#pragma unroll
-                    for (int i = 0; i < NWAVES; i++) if (i == w) mw = maskW[i];
-                    trellisVarBlock(X, jb, mw, w, 1);
-                }
-                PROF_MARK(X, 13);
-                BLOCK_SYNC();
-                PROF_MARK(X, 8);
-            }
-            // ---- step 3: the lag-1 chain states (igenic, geometric introns).  Three short phases:
-            //   3a  one thread per (state, ancestor, base): candidate value  V[j-1][a] + (t(a->s) + e_s(j))
-            //   3b  one thread per (state, base): best ancestor before / after the state itself, in ascending ancestor
-            //       order with strict '>' (reference src/igenicmodel.cc:247-255, src/intronmodel.cc:757-786)
-            //   3c  one thread per state: the sequential part, two additions and two compares per base
-            if (!(B.dbgFlags & 8)) {
-            FOR_THREADS(t) {
-                if (TX(ciCs) >= 0) {
-                    const int j = jb + TX(ciDj);
-                    const bool valid = j >= 1 && j < n;
-                    const double emi = valid ? L.sig[j & 63][TX(ciSig)] : AUGX_NINF;
-                    const double pv = L.ring[(j - 1) & 63][TX(ciAnc)];
-                    const double te = TX(ciTr) + emi;
-                    L.chV[TX(ciCs)][TX(ciDj)][TX(ciAi)] = TX(ciSelf) ? AUGX_NINF : pv + te;
-                    if (TX(ciSelf)) { L.chPs[TX(ciCs)][TX(ciDj)] = pv; L.chTe[TX(ciCs)][TX(ciDj)] = te; }
-                }
-            }
-            BLOCK_SYNC();
-            FOR_THREADS(t) {
-                if (t < nChain * BLK) {
-                    const int cs = t / BLK, dj = t % BLK, s2 = L.chainIds[cs];
-                    const int na = L.vc[s2].nanc; // (chain states have at most 5 ancestors; vc keeps 4, igenic's 5th read below)
-                    (void)na;
-                    double bB = AUGX_NINF, bA = AUGX_NINF;
-                    int aB = -1, aA = -1;
-                    bool seenSelf = false;
-                    const int nanc = T.n_anc[s2] < 5 ? T.n_anc[s2] : 5;
-#pragma unroll
-                    for (int ai = 0; ai < 5; ai++) {
-                        if (ai >= nanc) continue;
-                        const bool self = T.anc[s2][ai] == s2;
-                        const double v = L.chV[cs][dj][ai];
-                        if (self) seenSelf = true;
-                        else if (!seenSelf) { if (v > bB) { bB = v; aB = ai; } }
-                        else { if (v > bA) { bA = v; aA = ai; } }
-                    }
-                    L.chB[cs][dj][0] = bB; L.chB[cs][dj][1] = bA;
-                    L.chA[cs][dj][0] = aB; L.chA[cs][dj][1] = aA;
-                }
-            }
-            BLOCK_SYNC();
-            FOR_THREADS(t) {
-                if (t < nChain) {
-                    const int cs = t, l = L.chainIds[cs];
-                    int selfAi = 5;
-                    const int nanc = T.n_anc[l] < 5 ? T.n_anc[l] : 5;
-#pragma unroll
-                    for (int ai = 0; ai < 5; ai++) if (ai < nanc && T.anc[l][ai] == l) selfAi = ai;
-                    double bB[BLK], bA[BLK], te[BLK], ps[BLK];
-                    int aB[BLK], aA[BLK];
-#pragma unroll
-                    for (int dj = 0; dj < BLK; dj++) {
-                        bB[dj] = L.chB[cs][dj][0]; bA[dj] = L.chB[cs][dj][1]; aB[dj] = L.chA[cs][dj][0]; aA[dj] = L.chA[cs][dj][1];
-                        te[dj] = L.chTe[cs][dj]; ps[dj] = L.chPs[cs][dj];
-                    }
-                    double res[BLK];
-                    int rai[BLK];
-                    double prev = AUGX_NINF;
-#pragma unroll
-                    for (int dj = 0; dj < BLK; dj++) {
-                        const int j = jb + dj;
-                        const double p0 = (dj == 0 || j - 1 < 1) ? ps[dj] : prev;
-                        const double vs = p0 + te[dj];
-                        double best = bB[dj];
-                        int bai = aB[dj];
-                        if (vs > best) { best = vs; bai = selfAi; }
-                        if (bA[dj] > best) { best = bA[dj]; bai = aA[dj]; }
-                        res[dj] = best; rai[dj] = bai;
-                        prev = best;
-                    }
-                    const bool isIg = T.kind[l] == AUGX_K_IGENIC;
-#pragma unroll
-                    for (int dj = 0; dj < BLK; dj++) {
-                        const int j = jb + dj;
-                        if (j < 1 || j >= n) continue;
-                        L.ring[j & 63][l] = res[dj];
-                        L.bp[j & 63][l] = res[dj] > AUGX_NINF ? bpFixed(rai[dj]) : BP_NONE;
-                        if (B.cells) B.cells[(o + 1 + j) * S + l] = res[dj];
-                        if (isIg) { B.vig[o + 1 + j] = res[dj]; L.vigw[j & (VIG_WIN - 1)] = res[dj]; }
-                    }
-                }
-            }
-            }
-            {
-                int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
-                X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
-            }
-            BLOCK_SYNC();
-            PROF_MARK(X, 9);
-            // ---- step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
-            if (anyRT && !(B.dbgFlags & 1)) {
-                FOR_WAVES(w) { trellisVarBlock(X, jb, maskRT, w, NWAVES); }
-                BLOCK_SYNC();
-                PROF_MARK(X, 10);
-            }
-        }
-        // ---- flush the back-pointer tile
-        FOR_THREADS(t) {
-            const int l = t & 63, q4 = t >> 6;
-            for (int r = q4; r < WAVE && !(B.dbgFlags & 32); r += NWAVES) {
-                int q = j0 + r;
-                if (q < n && l < SP) B.bp[(o + 1 + q) * SP + l] = L.bp[r][l];
-            }
-        }
-        BLOCK_SYNC();
-        PROF_MARK(X, 11);
-    }
-#if defined(AUGX_PROF) && !defined(AUGX_EMU)
-    if ((threadIdx.x & 63) == 0 && B.prof)
-        for (int i = 0; i < 16; i++) B.prof[((int64_t)p * NWAVES + (threadIdx.x >> 6)) * 16 + i] = X.pacc[i];
+                    for (int d = 0; d < BLK; d++) {
+#ifdef AUGX_EMU
+                        FOR_WLANES(t, 0) { TX(prevRes) = (t & 63) > 0 ? res[t - 1] : AUGX_NINF; }
+#else
+                        prevRes[0] = __shfl_up(res[0], 1, 64);
 #endif
+                        FOR_WLANES(t, 0) {
+                            const int l = t & 63, dj = l & 7, j = jb + dj;
+                            if (dj == d && TX(cS) >= 0) {
+                                const double p0 = (d == 0 || j - 1 < 1) ? TX(psS) : TX(prevRes);
+                                const double vs = p0 + TX(teS);
+                                double best = TX(bB);
+                                int bai = TX(aB);
+                                if (vs > best) { best = vs; bai = TX(cSelf); }
+                                if (TX(bA) > best) { best = TX(bA); bai = TX(aA); }
+                                TX(res) = best; TX(rai) = bai;
+                            }
+                        }
+                    }
+                    FOR_WLANES(t, 0) {
+                        const int l = t & 63, dj = l & 7, j = jb + dj;
+                        if (TX(cS) >= 0 && j >= 1 && j < n) {
+                            const int s2 = TX(cS);
+                            L.ring[j & 63][s2] = TX(res);
+                            L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
+                            if (B.cells) B.cells[(o + 1 + j) * S + s2] = TX(res);
+                            if (TX(cIsIg)) { B.vig[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
+                        }
+                    }
+                    {
+                        int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
+                        X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
+                    }
+                    WAVE_SYNC();
+                    // step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
+                    if (it1 > itS) trellisItems(X, buf, blk, jb, itS, it1);
+                }
+            }
+        }
+        BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
+    }
+    // ---- back pointers of the last tile
+    FOR_THREADS(t) { flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT); }
     // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)
     FOR_THREADS(t) {
         if (t == 0) {

@@ -21,7 +21,7 @@ struct BatchLayout {
         off.assign(n + 1, 0);
         len.resize(n); initKind.resize(n); termKind.resize(n);
         for (int p = 0; p < n; p++) {
-            if (pieces[p].len < 1 || pieces[p].len > 0x3fffffff) throw std::runtime_error("augx: piece length out of range");
+            if (pieces[p].len < 1 || pieces[p].len >= (1 << KEY_BITS) - 64) throw std::runtime_error("augx: piece length out of range (device pieces are shorter than 4 Mbp; lower --maxDNAPieceSize)");
             len[p] = (int32_t)pieces[p].len;
             initKind[p] = pieces[p].init_kind;
             termKind[p] = pieces[p].term_kind;
@@ -50,18 +50,34 @@ struct BatchSizes {
 inline void checkModelSupported(const augx_tables &t) {
     if (t.S > SP) throw std::runtime_error("augx: model has more than 48 states (UTR/nc models are not on the device path yet)");
     int dL = t.d - 2 - t.De - t.As - 2 - t.U;
-    if (dL >= LONG_RING || dL < 1) throw std::runtime_error("augx: intron d out of the supported range");
+    if (dL >= LONG_RING || dL <= BLK || (dL > WAVE - BLK && dL < WAVE)) throw std::runtime_error("augx: intron d out of the supported range");
+    if (t.Ds + 2 + t.De <= BLK || t.As + 2 + t.Ae + t.U <= BLK) throw std::runtime_error("augx: splice-site windows shorter than a trellis block");
     if (t.As + 2 + t.Ae + t.U > 63 || t.Ds + 2 + t.De > 63) throw std::runtime_error("augx: splice-site windows too long");
     if (t.max_exon_len + t.W + 64 > 0x3FFF) throw std::runtime_error("augx: maxexonlength too large for 14-bit back pointers");
     if (t.d > 0x3FFF) throw std::runtime_error("augx: intron d too large");
+    int nFixed = 0, nVar = 0, nChain = 0;
     for (int s = 0; s < t.S; s++) {
         int kind = t.state_kind[s];
+        if (t.reachable[s]) {
+            bool fixedLag = kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS || kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS ||
+                            kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD;
+            bool chain = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC;
+            if (fixedLag) { nFixed++; if (t.n_anc[s] > 2) throw std::runtime_error("augx: fixed-length intron state with more than 2 ancestors"); }
+            else if (chain) { nChain++; if (t.n_anc[s] > 5) throw std::runtime_error("augx: single-base state with more than 5 ancestors"); }
+            else nVar++;
+        }
         bool var3 = kind == AUGX_K_INTERNAL || kind == AUGX_K_TERMINAL || kind == AUGX_K_RINTERNAL || kind == AUGX_K_RINITIAL;
-        if (var3 && t.n_anc[s] > 4) throw std::runtime_error("augx: exon state with more than 4 ancestors");
+        if (var3 && t.n_anc[s] > 3) throw std::runtime_error("augx: exon state with more than 3 ancestors");
+        if (var3)
+            for (int a = 0; a < t.n_anc[s]; a++)
+                for (int b2 = 0; b2 < a; b2++)
+                    if (t.state_win[t.anc[s][a]] == t.state_win[t.anc[s][b2]])
+                        throw std::runtime_error("augx: exon state with two ancestors of the same reading frame");
         if ((kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD || kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL ||
              kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) && t.n_anc[s] != 1)
             throw std::runtime_error("augx: unexpected ancestor count (non-standard transition file)");
     }
+    if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
 }
 
 // fill the scalar part of DevTables; the caller sets the table pointers (device or host)

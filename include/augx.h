@@ -35,7 +35,8 @@ enum {
     AUGX_E_NODEVICE = -3,   /* no HIP device / kernel image: the product path has no CPU fallback       */
     AUGX_E_HIP = -4,        /* HIP runtime error                                                        */
     AUGX_E_UNSUPPORTED = -5,/* model feature outside the implemented hot path (fails loudly)            */
-    AUGX_E_NOPATH = -6      /* "No feasible path found in HMM" (reference src/namgene.cc:455-457)       */
+    AUGX_E_NOPATH = -6,     /* "No feasible path found in HMM" (reference src/namgene.cc:455-457)       */
+    AUGX_E_NOMEM = -7       /* device memory exhausted (decode fewer bases per batch)                   */
 };
 
 /* state kinds of the GHMM (derived from the reference's StateType, include/types.hh:492-512) */

@@ -105,7 +105,24 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     scanFields<false>(B.fx, NFX, L);
     for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
     for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g);
-    // ---- K2, K3
+    // ---- K2a: count, scan, emit
+    B.nBlk = B.N / BLK;
+    B.blkCnt = zalloc<uint32_t>(B.nBlk * 2);
+    B.blkSplit = zalloc<uint32_t>(B.nBlk);
+    B.blkOff = zalloc<uint64_t>((B.nBlk + 1) * 2);
+    CandLds *cl = new CandLds();
+    const int64_t nWg = (B.nBlk + NWAVES - 1) / NWAVES;
+    for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg, false);
+    for (int64_t i = 0; i < B.nBlk; i++) {
+        B.blkOff[(i + 1) * 2] = B.blkOff[i * 2] + B.blkCnt[i * 2];
+        B.blkOff[(i + 1) * 2 + 1] = B.blkOff[i * 2 + 1] + B.blkCnt[i * 2 + 1];
+    }
+    B.pairCap = (int64_t)B.blkOff[B.nBlk * 2]; B.itemCap = (int64_t)B.blkOff[B.nBlk * 2 + 1];
+    B.pairRec = zalloc<uint16_t>(B.pairCap + 1);
+    B.items = zalloc<Item>(B.itemCap + 1);
+    for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg, true);
+    delete cl;
+    // ---- K2b, K3
     TrellisLds *lds = new TrellisLds();
     for (int p = 0; p < n; p++) {
         trellisPiece(T, B, *lds, p);
@@ -132,6 +149,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             w += (int64_t)L.len[p] * t->S;
         }
     }
+    free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.pairRec); free(B.items);
     free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
     free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldPos); free(B.ldVal);
     free(B.rdPos); free(B.rdVal); free(B.atgPos); free(B.pathRec);
