@@ -389,6 +389,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
+    if (getenv("AUGX_PROF")) DA(V.prof, uint64_t, (int64_t)n * 8);
     DA(V.vig, double, Z.N);
     DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
@@ -520,6 +521,17 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
     if (prep_ms) *prep_ms = a;
     if (trellis_ms) *trellis_ms = c;
     if (back_ms) *back_ms = e;
+    if (b->V.prof) { // developer aid (AUGX_PROF=1): cycle counters of the trellis wavefront, averaged over pieces
+        std::vector<uint64_t> h((size_t)b->L.nPieces * 8);
+        HIP_TRY(hipMemcpy(h.data(), b->V.prof, h.size() * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "trellis wavefront Mcycles/piece:");
+        for (int i = 0; i < 8; i++) {
+            double sum = 0;
+            for (int p = 0; p < b->L.nPieces; p++) sum += (double)h[(size_t)p * 8 + i];
+            fprintf(stderr, " [%d]=%.2f", i, sum / b->L.nPieces / 1e6);
+        }
+        fprintf(stderr, "  (0 tile wait, 1 fixed, 2+7 items, 3 chain, 4 item load, 5 scan, 6 publish)\n");
+    }
     return AUGX_OK;
 }
 

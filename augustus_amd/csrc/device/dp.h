@@ -40,11 +40,12 @@ constexpr int LENI_MAX = 1024;  // intron length distribution cached in LDS when
 // one candidate of a variable-length state: everything but the predecessor's Viterbi value (kCandidates -> kTrellis)
 struct Item {
     double te;      // ln(transition * emission) of the candidate, -inf if infeasible
-    uint32_t kp;    // [31:22] index of the (base, state) pair inside its block, [21:0] tie-break key (eop or bs)
+    uint32_t kp;    // [31:22] index of the (base, state) pair inside its block, [21:0] tie-break key = eop + KEY_BIAS
     uint32_t src;   // where the predecessor value lives: [31:30] tag, [29:28] ancestor index, [27:0] payload
 };
 constexpr int KEY_BITS = 22;                 // pieces on the device path are shorter than 2^22 bases
 constexpr uint32_t KEY_MASK = (1u << KEY_BITS) - 1;
+constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >= -(3 + W) - 1 for a left-truncated initial exon)
 constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
 constexpr int BLK = 8;                       // bases per trellis block: smaller than every lag except the lag-1 chain states
 
@@ -88,6 +89,7 @@ struct BatchView {
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
+    uint64_t *prof;            // [nPieces][16] cycle counters of the trellis wavefront (AUGX_PROF=1) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD
     int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]

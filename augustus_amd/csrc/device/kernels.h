@@ -59,6 +59,28 @@ namespace dev {
 #endif
 constexpr int NWAVES = 4, NT = NWAVES * WAVE;
 
+// pointers loaded from the BatchView are generic to the compiler; the hot loops re-type them as global so that their
+// loads and stores do not count against the LDS wait counter (flat instructions do)
+#ifdef AUGX_EMU
+template <class T> inline T *gp(T *p) { return p; }
+inline Item ldItem(const Item *p) { return *p; }
+#else
+#define AUGX_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ AUGX_GLOBAL T *gp(T *p) { return (AUGX_GLOBAL T *)p; }
+__device__ __forceinline__ Item ldItem(const Item *p) { // one 16-byte global load
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i r = *(const AUGX_GLOBAL v4i *)p;
+    Item I;
+    I.te = __hiloint2double(r.y, r.x); I.kp = (uint32_t)r.z; I.src = (uint32_t)r.w;
+    return I;
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ int dppMov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xf, false); }
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dppMovD(double old, double x) {
+    int lo = dppMov<CTRL, ROWMASK>(__double2loint(old), __double2loint(x)), hi = dppMov<CTRL, ROWMASK>(__double2hiint(old), __double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // wave-wide argmax of (value, key): larger value wins, ties go to the larger key (= the candidate the
 // reference's descending loop with strict '>' meets first: src/exonmodel.cc:1059,1115, src/intronmodel.cc:589,623)
@@ -593,7 +615,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         double emi = X.lenIAt(intronLength) + restSeq;
         if (!(emi > AUGX_NINF)) return;
         te = VC.tr[0] + emi;
-        key = eop; src = sr;
+        key = eop + KEY_BIAS; src = sr;
         return;
     }
     if (D.listSel >= 4) { // predecessor is the igenic state
@@ -648,7 +670,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
         if (!(nep > AUGX_NINF)) return;
         te = (VC.tr[0] + D.endP) + nep;
-        key = bs;
+        key = eop + KEY_BIAS;
         src = eop <= 0 ? srcCol0(0, a) : srcVig(0, eop);
         return;
     }
@@ -695,7 +717,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     for (int ai = 0; ai < VC.nanc; ai++) {
         if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
         te = (VC.tr[ai] + D.endP) + nep;
-        key = bs;
+        key = bs - D.g.bpl - 1 + KEY_BIAS;
         src = li >= 0 ? srcList(ai, D.listSel, VC.ancWin[ai], li) : srcCol0(ai, VC.anc[ai]);
         break;
     }
@@ -837,7 +859,6 @@ struct TrellisLds {
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
-    int bpAdj[SP];                  // eop = key - bpAdj[state]
 };
 
 // loads of data this kernel itself stored earlier (other wavefront, or long ago): bypass the per-CU vector cache
@@ -845,7 +866,7 @@ struct TrellisLds {
 inline double ldCoherent(const double *p) { return *p; }
 #else
 __device__ inline double ldCoherent(const double *p) {
-    unsigned long long u = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long u = __hip_atomic_load((const AUGX_GLOBAL unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return __longlong_as_double((long long)u);
 }
 #endif
@@ -868,25 +889,41 @@ inline uint32_t waveReadU(const uint32_t *v, int w, int lane) { return v[w * WAV
 __device__ inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int) {
     double v = val[0];
     uint32_t k = kp[0], s = src[0];
-    const int lane = threadIdx.x & 63;
     const uint32_t seg = k >> KEY_BITS;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        double ov = __shfl_up(v, o, 64);
-        uint32_t ok = (uint32_t)__shfl_up((int)k, o, 64), os = (uint32_t)__shfl_up((int)s, o, 64);
-        if (lane >= o && (ok >> KEY_BITS) == seg && better(ov, (int)ok, v, (int)k)) { v = ov; k = ok; s = os; }
-    }
+    // row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast 15 / 31 across the rows (lanes that receive nothing
+    // see their own value, which never beats itself)
+#define AUGX_SEG_STEP(CTRL, ROWMASK) { \
+        const double ov = dppMovD<CTRL, ROWMASK>(v, v); \
+        const uint32_t ok = (uint32_t)dppMov<CTRL, ROWMASK>((int)k, (int)k), os = (uint32_t)dppMov<CTRL, ROWMASK>((int)s, (int)s); \
+        const bool tk = (ok >> KEY_BITS) == seg && better(ov, (int)ok, v, (int)k); \
+        v = tk ? ov : v; k = tk ? ok : k; s = tk ? os : s; }
+    AUGX_SEG_STEP(0x111, 0xf)
+    AUGX_SEG_STEP(0x112, 0xf)
+    AUGX_SEG_STEP(0x114, 0xf)
+    AUGX_SEG_STEP(0x118, 0xf)
+    AUGX_SEG_STEP(0x142, 0xa)
+    AUGX_SEG_STEP(0x143, 0xc)
+#undef AUGX_SEG_STEP
     val[0] = v; kp[0] = k; src[0] = s;
 }
 __device__ inline void waveDown1(const uint32_t *in, uint32_t *out, int, uint32_t fill) {
-    uint32_t x = (uint32_t)__shfl_down((int)in[0], 1, 64);
-    out[0] = (threadIdx.x & 63) == 63 ? fill : x;
+    out[0] = (uint32_t)dppMov<0x130, 0xf>((int)fill, (int)in[0]); // wave_shl:1, lane 63 keeps the fill value
 }
-__device__ inline double waveReadD(const double *v, int, int lane) { return __shfl(v[0], lane, 64); }
-__device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return (uint32_t)__shfl((int)v[0], lane, 64); }
+__device__ inline double waveReadD(const double *v, int, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[0]), lane), __builtin_amdgcn_readlane(__double2loint(v[0]), lane));
+}
+__device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v[0], lane); }
 #endif
 
+#ifdef AUGX_EMU
+#define PROF_MARK(X, sec) do {} while (0)
+#else
+#define PROF_MARK(X, sec) do { if ((X).B.prof) { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } } while (0)
+#endif
 struct TrellisCtx {
+#ifndef AUGX_EMU
+    uint64_t pacc[8], plast;
+#endif
     const DevTables &T;
     const BatchView &B;
     TrellisLds &L;
@@ -911,11 +948,11 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     const int64_t o = X.o, g0 = o + 1 + j0;
     for (int i = tid; i < WAVE * NSIG; i += nth) {
         const int l = i / NSIG;
-        L.sig[buf][l][i % NSIG] = (j0 + l < n) ? B.sig[g0 * NSIG + i] : AUGX_NINF;
+        L.sig[buf][l][i % NSIG] = (j0 + l < n) ? gp(B.sig)[g0 * NSIG + i] : AUGX_NINF;
     }
     for (int i = tid; i < WAVE * NSITE; i += nth) {
         const int l = i / NSITE;
-        L.site[buf][l][i % NSITE] = (j0 + l < n) ? B.site[g0 * NSITE + i] : -1;
+        L.site[buf][l][i % NSITE] = (j0 + l < n) ? gp(B.site)[g0 * NSITE + i] : -1;
     }
     for (int i = tid; i < WAVE * 6; i += nth) {
         const int l = i / 6, q = j0 + l;
@@ -925,25 +962,33 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     for (int i = tid; i < (BLK + 1) * 2; i += nth) {
         int64_t gb = gb0 + i / 2;
         if (gb > B.nBlk) gb = B.nBlk;
-        L.blkOff[buf][i / 2][i % 2] = B.blkOff[gb * 2 + i % 2];
+        L.blkOff[buf][i / 2][i % 2] = gp(B.blkOff)[gb * 2 + i % 2];
     }
-    for (int i = tid; i < BLK; i += nth) L.blkSplit[buf][i] = gb0 + i < B.nBlk ? B.blkSplit[gb0 + i] : 0;
+    for (int i = tid; i < BLK; i += nth) L.blkSplit[buf][i] = gb0 + i < B.nBlk ? gp(B.blkSplit)[gb0 + i] : 0;
     for (int i = tid; i < BLK * 4; i += nth) {
         int q = j0 + (i / 4) * BLK + BLK - 1;
         if (q > n - 1) q = n - 1;
-        L.listTop[buf][i / 4][i % 4] = (int32_t)B.cnt[fidx(o + 1 + q, CNT_LA + i % 4, NCNT)] - 1;
+        L.listTop[buf][i / 4][i % 4] = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + i % 4, NCNT)] - 1;
     }
     int64_t gbE = gb0 + BLK;
     if (gbE > B.nBlk) gbE = B.nBlk;
     {
-        const uint64_t first = B.blkOff[gb0 * 2 + 1], last = B.blkOff[gbE * 2 + 1];
+        const uint64_t first = gp(B.blkOff)[gb0 * 2 + 1], last = gp(B.blkOff)[gbE * 2 + 1];
         const int cnt = last - first < (uint64_t)ITEM_CAP ? (int)(last - first) : ITEM_CAP;
-        for (int i = tid; i < cnt; i += nth) L.items[buf][i] = B.items[first + i];
+        const Item *gi = B.items + first;
+        for (int i = tid; i < cnt; i += 4 * nth) { // four loads in flight per thread
+            const Item r0 = ldItem(gi + i), r1 = ldItem(gi + (i + nth < cnt ? i + nth : i)), r2 = ldItem(gi + (i + 2 * nth < cnt ? i + 2 * nth : i)),
+                       r3 = ldItem(gi + (i + 3 * nth < cnt ? i + 3 * nth : i));
+            L.items[buf][i] = r0;
+            if (i + nth < cnt) L.items[buf][i + nth] = r1;
+            if (i + 2 * nth < cnt) L.items[buf][i + 2 * nth] = r2;
+            if (i + 3 * nth < cnt) L.items[buf][i + 3 * nth] = r3;
+        }
     }
     {
-        const uint64_t first = B.blkOff[gb0 * 2], last = B.blkOff[gbE * 2];
+        const uint64_t first = gp(B.blkOff)[gb0 * 2], last = gp(B.blkOff)[gbE * 2];
         const int cnt = last - first < (uint64_t)PAIR_CAP ? (int)(last - first) : PAIR_CAP;
-        for (int i = tid; i < cnt; i += nth) L.pairRec[buf][i] = B.pairRec[first + i];
+        for (int i = tid; i < cnt; i += nth) L.pairRec[buf][i] = gp(B.pairRec)[first + i];
     }
 }
 // write the back pointers of tile `tile` (LDS buffer buf) to HBM and reset the buffer
@@ -951,68 +996,78 @@ AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int
     const int j0 = tile * WAVE;
     for (int i = tid; i < WAVE * SP; i += nth) {
         const int r = i / SP;
-        if (j0 + r < X.n) X.B.bp[(X.o + 1 + j0) * SP + i] = X.L.bp[buf][r][i % SP];
+        if (j0 + r < X.n) gp(X.B.bp)[(X.o + 1 + j0) * SP + i] = X.L.bp[buf][r][i % SP];
         X.L.bp[buf][r][i % SP] = BP_NONE;
     }
 }
 
-// ---- candidates [lo, hi) of block blk (tile buffer buf) of the trellis wavefront: add the predecessor value, reduce
-//      per (base, state) pair, publish.  Candidates of one pair are contiguous; a pair may span several chunks of 64.
-AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, uint64_t lo, uint64_t hi) {
+// ---- candidates [lo, hi) (indices relative to the first candidate of the tile) of block blk of the trellis
+//      wavefront: add the predecessor value, reduce per (base, state) pair, publish.  Candidates of one pair are
+//      contiguous; a pair may span several chunks of 64.  Written branch-light: one LDS read per candidate.
+AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, int lo, int hi) {
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int S = X.S;
-    const uint64_t tileItem0 = L.blkOff[buf][0][1], tilePair0 = L.blkOff[buf][0][0], blkPair0 = L.blkOff[buf][blk][0];
+    const uint64_t tileItem0 = L.blkOff[buf][0][1], tilePair0 = L.blkOff[buf][0][0];
+    const int prBase = (int)(L.blkOff[buf][blk][0] - tilePair0);
+    const int top0 = L.listTop[buf][blk][0] - LIST_WIN, top1 = L.listTop[buf][blk][1] - LIST_WIN,
+              top2 = L.listTop[buf][blk][2] - LIST_WIN, top3 = L.listTop[buf][blk][3] - LIST_WIN;
+    const bool wantCells = B.cells != nullptr;
     double cv = AUGX_NINF;       // best of the last pair of the previous chunk (it may continue in this one)
     uint32_t ckp = 0xFFFFFFFFu, csrc = 0;
-    for (uint64_t base = lo; base < hi; base += WAVE) {
+    PROF_MARK(X, 7);
+    for (int base = lo; base < hi; base += WAVE) {
         TV(double, val);
         TV(uint32_t, kp);
         TV(uint32_t, src);
         TV(uint32_t, nkp);
+        const bool inLds = base + WAVE <= ITEM_CAP;
         FOR_WLANES(t, 0) {
-            const int l = t & 63;
-            const uint64_t it = base + l;
-            TX(val) = AUGX_NINF; TX(kp) = 0xFFFFFFFFu; TX(src) = 0;
-            if (it < hi) {
-                const Item I = (it - tileItem0 < (uint64_t)ITEM_CAP) ? L.items[buf][it - tileItem0] : B.items[it];
-                const uint32_t sr = I.src, tag = sr >> 30;
-                double pv;
+            const int l = t & 63, it = base + l;
+            const bool valid = it < hi;
+            Item I;
+            if (inLds) I = L.items[buf][it];
+            else if (valid) I = ldItem(B.items + tileItem0 + it);
+            else { I.te = AUGX_NINF; I.kp = 0; I.src = srcCol0(0, 0); }
+            const uint32_t sr = I.src, tag = sr >> 30;
+            const int sel = (sr >> 26) & 3, fr = (sr >> 24) & 3, pay = (int)(sr & 0xFFFFFFu);
+            const int top = sel == 0 ? top0 : sel == 1 ? top1 : sel == 2 ? top2 : top3;
+            const double *ptr = tag == SRC_LIST ? &L.lcVal[sel][pay & (LIST_WIN - 1)][fr]
+                                : tag == SRC_VIG ? &L.vigw[pay & (VIG_WIN - 1)] : &L.col0[sr & 0x3Fu];
+            double pv = *ptr;
+            const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= X.vigLo));
+            if (slow) { // the value left the LDS windows long ago: read it back from HBM
                 if (tag == SRC_LIST) {
-                    const int sel = (sr >> 26) & 3, fr = (sr >> 24) & 3, li = (int)(sr & 0xFFFFFFu);
-                    if (li > L.listTop[buf][blk][sel] - LIST_WIN) pv = L.lcVal[sel][li & (LIST_WIN - 1)][fr];
-                    else {
-                        const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
-                        pv = ldCoherent(&a[(X.lo + li) * 3 + fr]);
-                    }
-                } else if (tag == SRC_VIG) {
-                    const int eop = (int)(sr & 0xFFFFFFu);
-                    pv = eop > X.vigLo ? L.vigw[eop & (VIG_WIN - 1)] : ldCoherent(&B.vig[X.o + 1 + eop]);
+                    const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                    pv = ldCoherent(&a[(X.lo + pay) * 3 + fr]);
                 } else
-                    pv = L.col0[sr & 0xFFu];
-                TX(val) = pv + I.te;
-                TX(kp) = I.kp; TX(src) = sr;
+                    pv = ldCoherent(&B.vig[X.o + 1 + pay]);
             }
-            if (l == 0 && (ckp >> KEY_BITS) == (TX(kp) >> KEY_BITS) && better(cv, (int)ckp, TX(val), (int)TX(kp))) {
-                TX(val) = cv; TX(kp) = ckp; TX(src) = csrc;
-            }
+            double v = valid ? pv + I.te : AUGX_NINF;
+            uint32_t k = valid ? I.kp : 0xFFFFFFFFu, s2 = sr;
+            const bool takeCarry = l == 0 && (ckp >> KEY_BITS) == (k >> KEY_BITS) && better(cv, (int)ckp, v, (int)k);
+            v = takeCarry ? cv : v; k = takeCarry ? ckp : k; s2 = takeCarry ? csrc : s2;
+            TX(val) = v; TX(kp) = k; TX(src) = s2;
         }
+        PROF_MARK(X, 4);
         waveSegScan(val, kp, src, 0);
         waveDown1(kp, nkp, 0, 0xFFFFFFFFu);
+        PROF_MARK(X, 5);
         FOR_WLANES(t, 0) { // the last lane of every segment publishes (a pair continuing in the next chunk is overwritten there)
             const uint32_t k2 = TX(kp);
             if (k2 != 0xFFFFFFFFu && (TX(nkp) >> KEY_BITS) != (k2 >> KEY_BITS) && TX(val) > AUGX_NINF) {
-                const uint64_t pi = blkPair0 + (k2 >> KEY_BITS);
-                const uint16_t pr = (pi - tilePair0 < (uint64_t)PAIR_CAP) ? L.pairRec[buf][pi - tilePair0] : B.pairRec[pi];
-                const int j = jb + (pr >> 8), s2 = pr & 0xFF;
-                const int eop = (int)(k2 & KEY_MASK) - L.bpAdj[s2];
-                L.ring[j & 63][s2] = TX(val);
-                L.bp[buf][j & 63][s2] = bpVar((int)((TX(src) >> 28) & 3), j - eop);
-                if (B.cells) B.cells[(X.o + 1 + j) * S + s2] = TX(val);
+                const int pi = prBase + (int)(k2 >> KEY_BITS);
+                const uint16_t pr = pi < PAIR_CAP ? L.pairRec[buf][pi] : gp(B.pairRec)[tilePair0 + pi];
+                const int j = jb + (pr >> 8), st = pr & 0xFF;
+                const int eop = (int)(k2 & KEY_MASK) - KEY_BIAS;
+                L.ring[j & 63][st] = TX(val);
+                L.bp[buf][j & 63][st] = bpVar((int)((TX(src) >> 28) & 3), j - eop);
+                if (wantCells) gp(B.cells)[(X.o + 1 + j) * S + st] = TX(val);
             }
         }
         cv = waveReadD(val, 0, WAVE - 1); ckp = waveReadU(kp, 0, WAVE - 1); csrc = waveReadU(src, 0, WAVE - 1);
         WAVE_SYNC();
+        PROF_MARK(X, 6);
     }
 }
 
@@ -1127,12 +1182,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             double v = AUGX_NINF;
             if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
             L.col0[t] = v;
-            int adj = 0;
-            if (t < S) {
-                const int kind = T.kind[t];
-                if (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) adj = exGeom(T, kind).bpl + 1;
-            }
-            L.bpAdj[t] = adj;
         }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
@@ -1153,21 +1202,29 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         loadTileThread(X, 0, 0, t, NT);
     }
     const int nTiles = (n + WAVE - 1) / WAVE;
+    const bool wantCells = B.cells != nullptr;
     BLOCK_GLOBAL_SYNC();
+#ifndef AUGX_EMU
+    for (int i = 0; i < 8; i++) X.pacc[i] = 0;
+    X.plast = clock64();
+#endif
     for (int tile = 0; tile < nTiles; tile++) {
         const int buf = tile & 1, j0 = tile * WAVE;
         FOR_WAVES(w) {
             if (w != 0) {
                 // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
                 FOR_WLANES(t, w) {
+                    if (B.dbgFlags & 8) continue;
                     if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - WAVE, NT - WAVE);
                     if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - WAVE, NT - WAVE);
                 }
             } else {
                 // ---- trellis wavefront
+                PROF_MARK(X, 0);
                 for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
                     const int jb = j0 + blk * BLK;
                     // step 1: fixed-lag states (lag > BLK): all loads first, then the two-way max
+                    if (!(B.dbgFlags & 4))
                     FOR_WLANES(t, 0) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
                         double emi[FR], pv0[FR], pv1[FR];
@@ -1196,13 +1253,13 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             }
                             L.ring[j & 63][s2] = best;
                             L.bp[buf][j & 63][s2] = bp;
-                            if (fLrow[r][TI] >= 0) B.longV[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
-                            if (B.cells) B.cells[(o + 1 + j) * S + s2] = best;
+                            if (fLrow[r][TI] >= 0) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
+                            if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = best;
                             if (fList[r][TI] >= 0) {
                                 const int si = L.site[buf][j & 63][fList[r][TI]];
                                 if (si >= 0) {
                                     double *lval = fList[r][TI] == 0 ? B.laVal : fList[r][TI] == 1 ? B.lrVal : fList[r][TI] == 2 ? B.ldVal : B.rdVal;
-                                    lval[(X.lo + si) * 3 + fFrame[r][TI]] = best;
+                                    gp(lval)[(X.lo + si) * 3 + fFrame[r][TI]] = best;
                                     L.lcVal[fList[r][TI]][si & (LIST_WIN - 1)][fFrame[r][TI]] = best;
                                 }
                             }
@@ -1213,16 +1270,20 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             const int s2 = vS[r][TI];
                             if (s2 < 0 || j < 1 || j >= n) continue;
                             L.ring[j & 63][s2] = AUGX_NINF;
-                            if (B.cells) B.cells[(o + 1 + j) * S + s2] = AUGX_NINF;
+                            if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
                         }
                     }
                     WAVE_SYNC();
+                    PROF_MARK(X, 1);
                     // step 2: variable-length states but RTERMINAL
-                    const uint64_t it0 = L.blkOff[buf][blk][1], it1 = L.blkOff[buf][blk + 1][1], itS = it0 + L.blkSplit[buf][blk];
-                    if (itS > it0) trellisItems(X, buf, blk, jb, it0, itS);
+                    const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]), it1 = (int)(L.blkOff[buf][blk + 1][1] - L.blkOff[buf][0][1]),
+                              itS = it0 + (int)L.blkSplit[buf][blk];
+                    if (itS > it0 && !(B.dbgFlags & 1)) trellisItems(X, buf, blk, jb, it0, itS);
+                    PROF_MARK(X, 2);
                     // step 3: the lag-1 chain states.  Lane (slot, dj): best ancestor before / after the state itself in
                     // ascending ancestor order with strict '>' (reference src/igenicmodel.cc:247-255,
                     // src/intronmodel.cc:757-786); then the 8-step recurrence along the block, one lane per base.
+                    if (!(B.dbgFlags & 2)) {
                     TV(double, res);
                     TV(double, prevRes);
                     FOR_WLANES(t, 0) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
@@ -1255,7 +1316,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #ifdef AUGX_EMU
                         FOR_WLANES(t, 0) { TX(prevRes) = (t & 63) > 0 ? res[t - 1] : AUGX_NINF; }
 #else
-                        prevRes[0] = __shfl_up(res[0], 1, 64);
+                        prevRes[0] = dppMovD<0x111, 0xf>(res[0], res[0]); // row_shr:1 (the 8 bases of a chain state share a row)
 #endif
                         FOR_WLANES(t, 0) {
                             const int l = t & 63, dj = l & 7, j = jb + dj;
@@ -1276,22 +1337,28 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             const int s2 = TX(cS);
                             L.ring[j & 63][s2] = TX(res);
                             L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
-                            if (B.cells) B.cells[(o + 1 + j) * S + s2] = TX(res);
-                            if (TX(cIsIg)) { B.vig[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
+                            if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = TX(res);
+                            if (TX(cIsIg)) { gp(B.vig)[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
                         }
+                    }
                     }
                     {
                         int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
                         X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
                     }
                     WAVE_SYNC();
+                    PROF_MARK(X, 3);
                     // step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
-                    if (it1 > itS) trellisItems(X, buf, blk, jb, itS, it1);
+                    if (it1 > itS && !(B.dbgFlags & 1)) trellisItems(X, buf, blk, jb, itS, it1);
                 }
             }
         }
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
     }
+#ifndef AUGX_EMU
+    if (B.prof && threadIdx.x == 0)
+        for (int i = 0; i < 8; i++) B.prof[(int64_t)p * 8 + i] = X.pacc[i];
+#endif
     // ---- back pointers of the last tile
     FOR_THREADS(t) { flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT); }
     // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)

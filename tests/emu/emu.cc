@@ -122,6 +122,12 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg, true);
     delete cl;
+    if (getenv("AUGX_EMU_STATS")) {
+        int64_t dead = 0, byTag[3] = {0, 0, 0};
+        for (int64_t i = 0; i < B.itemCap; i++) { if (!(B.items[i].te > AUGX_NINF)) dead++; else byTag[B.items[i].src >> 30]++; }
+        fprintf(stderr, "emu stats: N=%lld pairs=%lld items=%lld dead=%lld live list=%lld vig=%lld col0=%lld\n", (long long)B.N, (long long)B.pairCap,
+                (long long)B.itemCap, (long long)dead, (long long)byTag[0], (long long)byTag[1], (long long)byTag[2]);
+    }
     // ---- K2b, K3
     TrellisLds *lds = new TrellisLds();
     for (int p = 0; p < n; p++) {
