@@ -89,7 +89,7 @@ struct BatchView {
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
-    uint64_t *prof;            // [nPieces][16] cycle counters of the trellis wavefront (AUGX_PROF=1) or NULL
+    uint64_t *prof;            // [nPieces][4][8] cycle counters of the trellis wavefronts (AUGX_PROF=1) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD
     int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]
@@ -107,7 +107,7 @@ struct BatchView {
     // candidates of the variable-length states, grouped by block of BLK bases (block index = off[p]/BLK + j/BLK)
     int64_t nBlk;                    // N / BLK
     uint32_t *blkCnt;                // [nBlk][2] (pairs, items) of the block
-    uint32_t *blkSplit;              // [nBlk] items of the block that do not belong to RTERMINAL states (they come first)
+    uint32_t *blkSplit;              // [nBlk][3] items of the block up to the pair boundaries near 1/3 and 2/3 / of all states but RTERMINAL (they come first)
     uint64_t *blkOff;                // [nBlk+1][2] exclusive prefix of blkCnt
     uint64_t *blkChunk;              // scan scratch [nBlk/1024 + 1][2]
     uint16_t *pairRec;               // [pairs] (base offset in block << 8) | state

@@ -57,7 +57,7 @@ namespace dev {
 // workgroup barrier after which everything the workgroup stored to HBM is visible to its later coherent loads
 #define BLOCK_GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); } while (0)
 #endif
-constexpr int NWAVES = 4, NT = NWAVES * WAVE;
+constexpr int NWAVES = 8, NT = NWAVES * WAVE;
 
 // pointers loaded from the BatchView are generic to the compiler; the hot loops re-type them as global so that their
 // loads and stores do not count against the LDS wait counter (flat instructions do)
@@ -744,7 +744,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
     uint64_t pairBase = 0, itemBase = 0;
     if (write) { pairBase = B.blkOff[gblk * 2]; itemBase = B.blkOff[gblk * 2 + 1]; }
     int pairsDone = 0;
-    uint32_t itemsDone = 0, split = 0;
+    uint32_t itemsDone = 0, split = 0, mid1 = 0, mid2 = 0;
     for (int phase = 0; phase < 2; phase++) {
         const uint64_t mask = phase == 0 ? maskVar : maskRT;
         uint64_t g[BLK];   // only ever indexed by fully unrolled loops: stays in registers
@@ -782,6 +782,16 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
             FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
             waveInclScan(ibase, w);
             const int totalItems = waveRead(ibase, w, WAVE - 1);
+            if (!write && phase == 0 && done == 0) { // pair boundaries closest to 1/3 and 2/3 of the candidates (three trellis wavefronts share them)
+                const int t1 = totalItems / 3, t2 = 2 * totalItems / 3;
+                int best1 = 0x7fffffff, best2 = 0x7fffffff;
+                for (int q = 0; q < nPairs; q++) {
+                    const int bnd = waveRead(ibase, w, q), d1 = bnd > t1 ? bnd - t1 : t1 - bnd, d2 = bnd > t2 ? bnd - t2 : t2 - bnd;
+                    if (d1 < best1) { best1 = d1; mid1 = (uint32_t)bnd; }
+                    if (d2 < best2) { best2 = d2; mid2 = (uint32_t)bnd; }
+                }
+                if (mid2 < mid1) mid2 = mid1;
+            }
             if (write) {
                 for (int base = 0; base < totalItems; base += WAVE) {
                     TV(int, myPair);
@@ -814,7 +824,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
     }
     if (!write) {
         FOR_WLANES(t, w) {
-            if ((t & 63) == 0) { B.blkCnt[gblk * 2] = (uint32_t)pairsDone; B.blkCnt[gblk * 2 + 1] = itemsDone; B.blkSplit[gblk] = split; }
+            if ((t & 63) == 0) { B.blkCnt[gblk * 2] = (uint32_t)pairsDone; B.blkCnt[gblk * 2 + 1] = itemsDone; B.blkSplit[gblk * 3] = mid1; B.blkSplit[gblk * 3 + 1] = mid2; B.blkSplit[gblk * 3 + 2] = split; }
         }
     }
 }
@@ -842,6 +852,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // workgroup barrier inside a tile of 64 bases; the other wavefronts stage the next tile (signal records, candidates)
 // into the second half of the LDS buffers and flush the back pointers of the previous one.
 // =================================================================================================
+constexpr int NWORK = 3, W_C = 3, W_LOAD = 4; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4.. loaders
 constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM)
 constexpr int PAIR_CAP = 512;
 
@@ -852,13 +863,15 @@ struct TrellisLds {
     int32_t site[2][WAVE][NSITE];
     double eqPrev[2][WAVE][6];      // predecessor cells of the equalD states (lag dStateLen)
     uint64_t blkOff[2][BLK + 1][2]; // pair / item offsets of the blocks of the tile
-    uint32_t blkSplit[2][BLK];
+    uint32_t blkSplit[2][BLK][3];   // candidates: end of the first / second third, end of all states but RTERMINAL
     int32_t listTop[2][BLK][4];     // newest entry of each candidate list at the end of each block
     Item items[2][ITEM_CAP];
     uint16_t pairRec[2][PAIR_CAP];
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
+    int flagF[NWORK], flagI[NWORK], flagL, flagC; // blocks completed by the trellis wavefronts (see trellisPiece)
+    int abortFlag;
 };
 
 // loads of data this kernel itself stored earlier (other wavefront, or long ago): bypass the per-CU vector cache
@@ -915,9 +928,31 @@ __device__ inline double waveReadD(const double *v, int, int lane) {
 __device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v[0], lane); }
 #endif
 
+// progress flags between the trellis wavefronts of one workgroup (all resident on one CU: spinning is safe)
+#ifdef AUGX_EMU
+inline void waitFlag(TrellisLds &L, const int *f, int target) { if (*f < target) { fprintf(stderr, "emu: trellis wavefront dependency violated\n"); abort(); } (void)L; }
+inline void setFlag(int *f, int v) { *f = v; }
+#else
+__device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
+    int spins = 0;
+    while (*(const volatile int *)f < target && !*(const volatile int *)&L.abortFlag) {
+        if (++spins > (1 << 22)) *(volatile int *)&L.abortFlag = 1; // never expected: turns a logic error into an error status
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __asm__ volatile("" ::: "memory");
+}
+__device__ inline void setFlag(int *f, int v) {
+    __builtin_amdgcn_s_waitcnt(0xc07f); // the LDS writes of this wavefront have been performed
+    __asm__ volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) *(volatile int *)f = v;
+}
+#endif
+
 #ifdef AUGX_EMU
 #define PROF_MARK(X, sec) do {} while (0)
+#define PROF_STAMP(X, gbk, slot) do {} while (0)
 #else
+#define PROF_STAMP(X, gbk, slot) do { if ((X).B.prof && (gbk) == 1000 && (threadIdx.x & 63) == 0) (X).B.prof[(int64_t)(X).B.nPieces * 32 + (int64_t)(X).p * 16 + (slot)] = clock64(); } while (0)
 #define PROF_MARK(X, sec) do { if ((X).B.prof) { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } } while (0)
 #endif
 struct TrellisCtx {
@@ -964,7 +999,7 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         if (gb > B.nBlk) gb = B.nBlk;
         L.blkOff[buf][i / 2][i % 2] = gp(B.blkOff)[gb * 2 + i % 2];
     }
-    for (int i = tid; i < BLK; i += nth) L.blkSplit[buf][i] = gb0 + i < B.nBlk ? gp(B.blkSplit)[gb0 + i] : 0;
+    for (int i = tid; i < BLK * 3; i += nth) L.blkSplit[buf][i / 3][i % 3] = gb0 + i / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + i / 3) * 3 + i % 3] : 0;
     for (int i = tid; i < BLK * 4; i += nth) {
         int q = j0 + (i / 4) * BLK + BLK - 1;
         if (q > n - 1) q = n - 1;
@@ -1004,7 +1039,7 @@ AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int
 // ---- candidates [lo, hi) (indices relative to the first candidate of the tile) of block blk of the trellis
 //      wavefront: add the predecessor value, reduce per (base, state) pair, publish.  Candidates of one pair are
 //      contiguous; a pair may span several chunks of 64.  Written branch-light: one LDS read per candidate.
-AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, int lo, int hi) {
+AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int lo, int hi, int vigLo) {
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int S = X.S;
@@ -1022,7 +1057,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, int lo, int 
         TV(uint32_t, src);
         TV(uint32_t, nkp);
         const bool inLds = base + WAVE <= ITEM_CAP;
-        FOR_WLANES(t, 0) {
+        FOR_WLANES(t, w) {
             const int l = t & 63, it = base + l;
             const bool valid = it < hi;
             Item I;
@@ -1035,7 +1070,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, int lo, int 
             const double *ptr = tag == SRC_LIST ? &L.lcVal[sel][pay & (LIST_WIN - 1)][fr]
                                 : tag == SRC_VIG ? &L.vigw[pay & (VIG_WIN - 1)] : &L.col0[sr & 0x3Fu];
             double pv = *ptr;
-            const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= X.vigLo));
+            const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= vigLo));
             if (slow) { // the value left the LDS windows long ago: read it back from HBM
                 if (tag == SRC_LIST) {
                     const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
@@ -1050,10 +1085,10 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, int lo, int 
             TX(val) = v; TX(kp) = k; TX(src) = s2;
         }
         PROF_MARK(X, 4);
-        waveSegScan(val, kp, src, 0);
-        waveDown1(kp, nkp, 0, 0xFFFFFFFFu);
+        waveSegScan(val, kp, src, w);
+        waveDown1(kp, nkp, w, 0xFFFFFFFFu);
         PROF_MARK(X, 5);
-        FOR_WLANES(t, 0) { // the last lane of every segment publishes (a pair continuing in the next chunk is overwritten there)
+        FOR_WLANES(t, w) { // the last lane of every segment publishes (a pair continuing in the next chunk is overwritten there)
             const uint32_t k2 = TX(kp);
             if (k2 != 0xFFFFFFFFu && (TX(nkp) >> KEY_BITS) != (k2 >> KEY_BITS) && TX(val) > AUGX_NINF) {
                 const int pi = prBase + (int)(k2 >> KEY_BITS);
@@ -1065,7 +1100,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int buf, int blk, int jb, int lo, int 
                 if (wantCells) gp(B.cells)[(X.o + 1 + j) * S + st] = TX(val);
             }
         }
-        cv = waveReadD(val, 0, WAVE - 1); ckp = waveReadU(kp, 0, WAVE - 1); csrc = waveReadU(src, 0, WAVE - 1);
+        cv = waveReadD(val, w, WAVE - 1); ckp = waveReadU(kp, w, WAVE - 1); csrc = waveReadU(src, w, WAVE - 1);
         WAVE_SYNC();
         PROF_MARK(X, 6);
     }
@@ -1110,7 +1145,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     constexpr int FR = 3, VR = 4;
     TV2(int, fS, FR); TV2(int, fLag, FR); TV2(int, fSig, FR); TV2(int, fLong, FR); TV2(int, fNanc, FR);
     TV2(int, fAnc0, FR); TV2(int, fAnc1, FR); TV2(double, fTr0, FR); TV2(double, fTr1, FR);
-    TV2(int, fLrow, FR); TV2(int, fList, FR); TV2(int, fFrame, FR);
+    TV2(int, fLrow, FR); TV2(int, fList, FR); TV2(int, fFrame, FR); TV2(int, fLate, FR);
     TV2(int, vS, VR);
     TV(int, cS); TV(int, cSig); TV(int, cNanc); TV(int, cSelf); TV(int, cIsIg);
     TV2(int, cAnc, 5); TV2(double, cTr, 5);
@@ -1119,7 +1154,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #pragma unroll
         for (int r = 0; r < FR; r++) {
             fS[r][TI] = -1; fLag[r][TI] = 1; fSig[r][TI] = 0; fLong[r][TI] = 0; fNanc[r][TI] = 0; fAnc0[r][TI] = 0; fAnc1[r][TI] = 0;
-            fTr0[r][TI] = AUGX_NINF; fTr1[r][TI] = AUGX_NINF; fLrow[r][TI] = -1; fList[r][TI] = -1; fFrame[r][TI] = 0;
+            fTr0[r][TI] = AUGX_NINF; fTr1[r][TI] = AUGX_NINF; fLrow[r][TI] = -1; fList[r][TI] = -1; fFrame[r][TI] = 0; fLate[r][TI] = 0;
         }
 #pragma unroll
         for (int r = 0; r < VR; r++) vS[r][TI] = -1;
@@ -1153,6 +1188,14 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             fLrow[rr][TI] = longRow(T, s2);
                             fList[rr][TI] = kind == AUGX_K_LONGASS ? 0 : kind == AUGX_K_RLONGDSS ? 1 : kind == AUGX_K_LONGDSS ? 2 : kind == AUGX_K_RLONGASS ? 3 : -1;
                             fFrame[rr][TI] = T.win[s2];
+                            // a short-lag state fed by a chain state needs the chain cells of the previous block: it is
+                            // computed by the chain wavefront (rlongdss <- rgeometric at lag dss_whole)
+                            bool chainAnc = false;
+                            for (int ai = 0; ai < T.n_anc[s2] && ai < 2; ai++) {
+                                const int ak = T.kind[T.anc[s2][ai]];
+                                if (ak == AUGX_K_IGENIC || ak == AUGX_K_GEOMETRIC || ak == AUGX_K_RGEOMETRIC) chainAnc = true;
+                            }
+                            fLate[rr][TI] = lag < 2 * BLK && chainAnc;
                         }
                 }
                 nf++;
@@ -1183,6 +1226,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
             L.col0[t] = v;
         }
+        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.abortFlag = 0; }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
@@ -1204,6 +1248,49 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     const int nTiles = (n + WAVE - 1) / WAVE;
     const bool wantCells = B.cells != nullptr;
     BLOCK_GLOBAL_SYNC();
+    // fixed-lag states of block jb (all loads first, then the two-way max); late selects the states described at fLate
+    auto fixedStep = [&](int w, int buf, int jb, int late, int rsel) {
+        FOR_WLANES(t, w) {
+            const int l = t & 63, dj = l & 7, j = jb + dj;
+            double emi[FR], pv0[FR], pv1[FR];
+#pragma unroll
+            for (int r = 0; r < FR; r++) {
+                const int jp = j - fLag[r][TI];
+                emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
+                pv0[r] = AUGX_NINF; pv1[r] = AUGX_NINF;
+                if (fS[r][TI] >= 0 && jp >= 0) {
+                    if (fLong[r][TI]) { pv0[r] = L.eqPrev[buf][j & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.eqPrev[buf][j & 63][fAnc1[r][TI]]; }
+                    else { pv0[r] = L.ring[jp & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.ring[jp & 63][fAnc1[r][TI]]; }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < FR; r++) {
+                const int s2 = fS[r][TI];
+                if (s2 < 0 || j < 1 || j >= n || fLate[r][TI] != late || (rsel >= 0 && r != rsel)) continue;
+                double best = AUGX_NINF;
+                uint16_t bp = BP_NONE;
+                if (j - fLag[r][TI] >= 0 && emi[r] > AUGX_NINF) {
+                    if (pv0[r] > AUGX_NINF) { best = pv0[r] + (fTr0[r][TI] + emi[r]); bp = bpFixed(0); }
+                    if (fNanc[r][TI] > 1 && pv1[r] > AUGX_NINF) {
+                        double v2 = pv1[r] + (fTr1[r][TI] + emi[r]);
+                        if (v2 > best) { best = v2; bp = bpFixed(1); }
+                    }
+                }
+                L.ring[j & 63][s2] = best;
+                L.bp[buf][j & 63][s2] = bp;
+                if (fLrow[r][TI] >= 0) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
+                if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = best;
+                if (fList[r][TI] >= 0) {
+                    const int si = L.site[buf][j & 63][fList[r][TI]];
+                    if (si >= 0) {
+                        double *lval = fList[r][TI] == 0 ? B.laVal : fList[r][TI] == 1 ? B.lrVal : fList[r][TI] == 2 ? B.ldVal : B.rdVal;
+                        gp(lval)[(X.lo + si) * 3 + fFrame[r][TI]] = best;
+                        L.lcVal[fList[r][TI]][si & (LIST_WIN - 1)][fFrame[r][TI]] = best;
+                    }
+                }
+            }
+        }
+    };
 #ifndef AUGX_EMU
     for (int i = 0; i < 8; i++) X.pacc[i] = 0;
     X.plast = clock64();
@@ -1211,85 +1298,86 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     for (int tile = 0; tile < nTiles; tile++) {
         const int buf = tile & 1, j0 = tile * WAVE;
         FOR_WAVES(w) {
-            if (w != 0) {
+            if (w >= W_LOAD) {
                 // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
                 FOR_WLANES(t, w) {
-                    if (B.dbgFlags & 8) continue;
-                    if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - WAVE, NT - WAVE);
-                    if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - WAVE, NT - WAVE);
+                    if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
+                    if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
-            } else {
-                // ---- trellis wavefront
-                PROF_MARK(X, 0);
-                for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
-                    const int jb = j0 + blk * BLK;
-                    // step 1: fixed-lag states (lag > BLK): all loads first, then the two-way max
-                    if (!(B.dbgFlags & 4))
-                    FOR_WLANES(t, 0) {
+            }
+        }
+        // ---- the trellis wavefronts walk the blocks of the tile, each at its own pace (progress flags in LDS):
+        //   workers 0..2: (a) one third of the fixed-lag states of block b and of the cell resets, after all candidates
+        //                     of block b-1 (exon cells at lag >= 9);
+        //                 (b) one third of the candidates of block b, after (a) of all workers (list values) and the
+        //                     late fixed-lag states of block b (chain wavefront)
+        //   chain wavefront: late fixed-lag states of block b; then, after (b) of all workers, chain states + RTERMINAL
+        PROF_MARK(X, 0);
+        for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
+            const int jb = j0 + blk * BLK, gbk = tile * BLK + blk;
+            const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]), it1 = (int)(L.blkOff[buf][blk + 1][1] - L.blkOff[buf][0][1]),
+                      itA = it0 + (int)L.blkSplit[buf][blk][0], itB = it0 + (int)L.blkSplit[buf][blk][1], itS = it0 + (int)L.blkSplit[buf][blk][2];
+            FOR_WAVES(w) {
+                if (w == W_C) { // the late fixed-lag states need the chain cells of block b-1 (this wavefront's previous iteration)
+                    PROF_STAMP(X, gbk, 6);
+                    fixedStep(w, buf, jb, 1, -1);
+                    setFlag(&L.flagL, gbk + 1);
+                    PROF_STAMP(X, gbk, 7);
+                }
+            }
+            FOR_WAVES(w) {
+                if (w < NWORK) {
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
+                    PROF_MARK(X, 1);
+                    if (w == 0) PROF_STAMP(X, gbk, 0);
+                    // step 1: fixed-lag states (lag > BLK) but the late ones; reset of the variable-length cells
+                    fixedStep(w, buf, jb, 0, w);
+                    FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
-                        double emi[FR], pv0[FR], pv1[FR];
-#pragma unroll
-                        for (int r = 0; r < FR; r++) {
-                            const int jp = j - fLag[r][TI];
-                            emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
-                            pv0[r] = AUGX_NINF; pv1[r] = AUGX_NINF;
-                            if (fS[r][TI] >= 0 && jp >= 0) {
-                                if (fLong[r][TI]) { pv0[r] = L.eqPrev[buf][j & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.eqPrev[buf][j & 63][fAnc1[r][TI]]; }
-                                else { pv0[r] = L.ring[jp & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.ring[jp & 63][fAnc1[r][TI]]; }
-                            }
-                        }
-#pragma unroll
-                        for (int r = 0; r < FR; r++) {
-                            const int s2 = fS[r][TI];
-                            if (s2 < 0 || j < 1 || j >= n) continue;
-                            double best = AUGX_NINF;
-                            uint16_t bp = BP_NONE;
-                            if (j - fLag[r][TI] >= 0 && emi[r] > AUGX_NINF) {
-                                if (pv0[r] > AUGX_NINF) { best = pv0[r] + (fTr0[r][TI] + emi[r]); bp = bpFixed(0); }
-                                if (fNanc[r][TI] > 1 && pv1[r] > AUGX_NINF) {
-                                    double v2 = pv1[r] + (fTr1[r][TI] + emi[r]);
-                                    if (v2 > best) { best = v2; bp = bpFixed(1); }
-                                }
-                            }
-                            L.ring[j & 63][s2] = best;
-                            L.bp[buf][j & 63][s2] = bp;
-                            if (fLrow[r][TI] >= 0) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
-                            if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = best;
-                            if (fList[r][TI] >= 0) {
-                                const int si = L.site[buf][j & 63][fList[r][TI]];
-                                if (si >= 0) {
-                                    double *lval = fList[r][TI] == 0 ? B.laVal : fList[r][TI] == 1 ? B.lrVal : fList[r][TI] == 2 ? B.ldVal : B.rdVal;
-                                    gp(lval)[(X.lo + si) * 3 + fFrame[r][TI]] = best;
-                                    L.lcVal[fList[r][TI]][si & (LIST_WIN - 1)][fFrame[r][TI]] = best;
-                                }
-                            }
-                        }
+                        (void)l;
                         // cells of variable-length states are absent unless a candidate survives
 #pragma unroll
                         for (int r = 0; r < VR; r++) {
                             const int s2 = vS[r][TI];
-                            if (s2 < 0 || j < 1 || j >= n) continue;
+                            if (s2 < 0 || j < 1 || j >= n || r % NWORK != w) continue;
                             L.ring[j & 63][s2] = AUGX_NINF;
                             if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
                         }
                     }
-                    WAVE_SYNC();
-                    PROF_MARK(X, 1);
-                    // step 2: variable-length states but RTERMINAL
-                    const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]), it1 = (int)(L.blkOff[buf][blk + 1][1] - L.blkOff[buf][0][1]),
-                              itS = it0 + (int)L.blkSplit[buf][blk];
-                    if (itS > it0 && !(B.dbgFlags & 1)) trellisItems(X, buf, blk, jb, it0, itS);
+                    setFlag(&L.flagF[w], gbk + 1);
+                    if (w == 0) PROF_STAMP(X, gbk, 1);
                     PROF_MARK(X, 2);
+                }
+            }
+            FOR_WAVES(w) {
+                if (w < NWORK) {
+                    // step 2: variable-length states but RTERMINAL
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagF[i], gbk + 1);
+                    waitFlag(L, &L.flagL, gbk + 1);
+                    PROF_MARK(X, 1);
+                    if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 2 : 4);
+                    const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
+                    const int lo2 = w == 0 ? it0 : w == 1 ? itA : itB, hi2 = w == 0 ? itA : w == 1 ? itB : itS;
+                    if (hi2 > lo2) trellisItems(X, w, buf, blk, jb, lo2, hi2, vigLo);
+                    setFlag(&L.flagI[w], gbk + 1);
+                    if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 3 : 5);
+                    PROF_MARK(X, 2);
+                }
+            }
+            FOR_WAVES(w) {
+                if (w == W_C) {
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk + 1);
+                    PROF_MARK(X, 1);
+                    PROF_STAMP(X, gbk, 8);
                     // step 3: the lag-1 chain states.  Lane (slot, dj): best ancestor before / after the state itself in
                     // ascending ancestor order with strict '>' (reference src/igenicmodel.cc:247-255,
                     // src/intronmodel.cc:757-786); then the 8-step recurrence along the block, one lane per base.
-                    if (!(B.dbgFlags & 2)) {
                     TV(double, res);
                     TV(double, prevRes);
-                    FOR_WLANES(t, 0) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
+                    FOR_WLANES(t, w) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
                     TV(double, bB); TV(double, bA); TV(double, teS); TV(double, psS);
                     TV(int, aB); TV(int, aA); TV(int, rai);
-                    FOR_WLANES(t, 0) {
+                    FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
                         TX(bB) = AUGX_NINF; TX(bA) = AUGX_NINF; TX(aB) = -1; TX(aA) = -1; TX(teS) = AUGX_NINF; TX(psS) = AUGX_NINF; TX(rai) = -1;
                         if (TX(cS) >= 0) {
@@ -1314,11 +1402,11 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #pragma unroll
                     for (int d = 0; d < BLK; d++) {
 #ifdef AUGX_EMU
-                        FOR_WLANES(t, 0) { TX(prevRes) = (t & 63) > 0 ? res[t - 1] : AUGX_NINF; }
+                        FOR_WLANES(t, w) { TX(prevRes) = (t & 63) > 0 ? res[t - 1] : AUGX_NINF; }
 #else
                         prevRes[0] = dppMovD<0x111, 0xf>(res[0], res[0]); // row_shr:1 (the 8 bases of a chain state share a row)
 #endif
-                        FOR_WLANES(t, 0) {
+                        FOR_WLANES(t, w) {
                             const int l = t & 63, dj = l & 7, j = jb + dj;
                             if (dj == d && TX(cS) >= 0) {
                                 const double p0 = (d == 0 || j - 1 < 1) ? TX(psS) : TX(prevRes);
@@ -1331,7 +1419,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             }
                         }
                     }
-                    FOR_WLANES(t, 0) {
+                    FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
                         if (TX(cS) >= 0 && j >= 1 && j < n) {
                             const int s2 = TX(cS);
@@ -1341,23 +1429,24 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             if (TX(cIsIg)) { gp(B.vig)[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
                         }
                     }
-                    }
-                    {
-                        int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
-                        X.vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
-                    }
                     WAVE_SYNC();
                     PROF_MARK(X, 3);
                     // step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
-                    if (it1 > itS && !(B.dbgFlags & 1)) trellisItems(X, buf, blk, jb, itS, it1);
+                    if (it1 > itS) {
+                        const int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
+                        trellisItems(X, w, buf, blk, jb, itS, it1, jl - VIG_WIN > -1 ? jl - VIG_WIN : -1);
+                    }
+                    setFlag(&L.flagC, gbk + 1);
+                    PROF_STAMP(X, gbk, 9);
+                    PROF_MARK(X, 2);
                 }
             }
         }
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
     }
 #ifndef AUGX_EMU
-    if (B.prof && threadIdx.x == 0)
-        for (int i = 0; i < 8; i++) B.prof[(int64_t)p * 8 + i] = X.pacc[i];
+    if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 4 * WAVE)
+        for (int i = 0; i < 8; i++) B.prof[((int64_t)p * 4 + (threadIdx.x >> 6)) * 8 + i] = X.pacc[i];
 #endif
     // ---- back pointers of the last tile
     FOR_THREADS(t) { flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT); }
@@ -1373,7 +1462,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
             B.lnv[p] = maxV;
             B.finalState[p] = state;
-            B.status[p] = state >= 0 ? 0 : AUGX_E_NOPATH;
+            B.status[p] = L.abortFlag ? AUGX_E_HIP : state >= 0 ? 0 : AUGX_E_NOPATH;
         }
     }
 }

@@ -108,7 +108,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     // ---- K2a: count, scan, emit
     B.nBlk = B.N / BLK;
     B.blkCnt = zalloc<uint32_t>(B.nBlk * 2);
-    B.blkSplit = zalloc<uint32_t>(B.nBlk);
+    B.blkSplit = zalloc<uint32_t>(B.nBlk * 3);
     B.blkOff = zalloc<uint64_t>((B.nBlk + 1) * 2);
     CandLds *cl = new CandLds();
     const int64_t nWg = (B.nBlk + NWAVES - 1) / NWAVES;
