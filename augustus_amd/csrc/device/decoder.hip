@@ -126,74 +126,10 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
     row[t * 4 + 3] = comb<MAX>(pre, v3);
 }
 
-// ---- candidates: count / emit, and the exclusive scan of the per-block counts in between ----
-__global__ void __launch_bounds__(NT) kCandCount(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+// ---- candidates of the variable-length states: one workgroup per tile of 64 bases (count, reserve, emit) ----
+__global__ void __launch_bounds__(NT) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ CandLds lds;
-    candWorkgroup(*T, *B, lds, blockIdx.x, false);
-}
-__global__ void __launch_bounds__(NT) kCandWrite(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
-    __shared__ CandLds lds;
-    candWorkgroup(*T, *B, lds, blockIdx.x, true);
-}
-__device__ inline uint64_t blockSum256(uint64_t v, uint64_t *sh) { // sum over the 256 threads of the workgroup
-    for (int o = 32; o >= 1; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-// exclusive prefix over the 256 threads; *total receives the workgroup sum
-__device__ inline uint64_t blockExcl256(uint64_t v, uint64_t *sh, uint64_t *total) {
-    uint64_t inc = v;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint64_t up = (uint64_t)__shfl_up((unsigned long long)inc, o, 64);
-        if (lane >= o) inc += up;
-    }
-    __syncthreads();
-    if (lane == 63) sh[wv] = inc;
-    __syncthreads();
-    uint64_t pre = 0;
-    for (int i = 0; i < wv; i++) pre += sh[i];
-    *total = sh[0] + sh[1] + sh[2] + sh[3];
-    return pre + inc - v;
-}
-__global__ void __launch_bounds__(256) kBlkSum(BatchView B) {
-    __shared__ uint64_t sh[4];
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    for (int f = 0; f < 2; f++) {
-        uint64_t v = 0;
-        for (int k = 0; k < 4; k++)
-            if (i0 + k < B.nBlk) v += B.blkCnt[(i0 + k) * 2 + f];
-        uint64_t tsum = blockSum256(v, sh);
-        if (threadIdx.x == 0) B.blkChunk[(int64_t)blockIdx.x * 2 + f] = tsum;
-    }
-}
-__global__ void __launch_bounds__(256) kBlkChunkScan(BatchView B, int64_t nChunks2) {
-    __shared__ uint64_t sh[4];
-    const int64_t per = (nChunks2 + 255) / 256, a = threadIdx.x * per, e = a + per < nChunks2 ? a + per : nChunks2;
-    for (int f = 0; f < 2; f++) {
-        uint64_t v = 0;
-        for (int64_t i = a; i < e; i++) v += B.blkChunk[i * 2 + f];
-        uint64_t total;
-        uint64_t pre = blockExcl256(v, sh, &total);
-        for (int64_t i = a; i < e; i++) { uint64_t x = B.blkChunk[i * 2 + f]; B.blkChunk[i * 2 + f] = pre; pre += x; }
-        if (threadIdx.x == 0) B.blkOff[B.nBlk * 2 + f] = total;
-    }
-}
-__global__ void __launch_bounds__(256) kBlkApply(BatchView B) {
-    __shared__ uint64_t sh[4];
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    for (int f = 0; f < 2; f++) {
-        uint64_t x[4], v = 0;
-        for (int k = 0; k < 4; k++) { x[k] = i0 + k < B.nBlk ? B.blkCnt[(i0 + k) * 2 + f] : 0; v += x[k]; }
-        uint64_t total;
-        uint64_t pre = B.blkChunk[(int64_t)blockIdx.x * 2 + f] + blockExcl256(v, sh, &total);
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < B.nBlk) B.blkOff[(i0 + k) * 2 + f] = pre;
-            pre += x[k];
-        }
-    }
+    candWorkgroup(*T, *B, lds, blockIdx.x);
 }
 
 __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
@@ -404,8 +340,8 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap); DA(V.rsFx, uint64_t, Z.listCap * 3);
     DA(V.plsR, double, Z.N * 3);
     V.nBlk = Z.N / BLK;
-    DA(V.blkCnt, uint32_t, V.nBlk * 2); DA(V.blkSplit, uint32_t, V.nBlk * 3); DA(V.blkOff, uint64_t, (V.nBlk + 1) * 2);
-    DA(V.blkChunk, uint64_t, (V.nBlk / 1024 + 2) * 2);
+    DA(V.blkCnt, uint32_t, V.nBlk * 2); DA(V.blkSplit, uint32_t, V.nBlk * 3); DA(V.blkOff, uint64_t, V.nBlk * 2);
+    DA(V.candAlloc, CandAlloc, 1);
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
 #undef DA
@@ -456,41 +392,45 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
-    {   // candidates of the variable-length states: count per block, scan, size the buffers, emit
+    {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn
+        // out too small (first decode of a batch, unusual sequence), it reports the size needed and is run again.
         BatchView &W = b->V;
         const unsigned nWg = (unsigned)((W.nBlk + NWAVES - 1) / NWAVES);
-        const int64_t nChunks2 = (W.nBlk + 1023) / 1024;
-        hipLaunchKernelGGL(kCandCount, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-        hipLaunchKernelGGL(kBlkSum, dim3((unsigned)nChunks2), dim3(256), 0, st, W);
-        hipLaunchKernelGGL(kBlkChunkScan, dim3(1), dim3(256), 0, st, W, nChunks2);
-        hipLaunchKernelGGL(kBlkApply, dim3((unsigned)nChunks2), dim3(256), 0, st, W);
-        HIP_TRY(hipGetLastError());
-        uint64_t tot[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(tot, W.blkOff + W.nBlk * 2, sizeof tot, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if ((int64_t)tot[0] > W.pairCap || !b->pairBuf) {
-            if (b->pairBuf) HIP_TRY(hipFree(b->pairBuf));
-            b->pairBuf = nullptr;
-            W.pairCap = (int64_t)tot[0] + 64;
+        if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
+            W.pairCap = W.N * 2 + 4096; W.itemCap = W.N * 18 + 65536;
             HIP_TRY(hipMalloc(&b->pairBuf, (size_t)W.pairCap * sizeof(uint16_t)));
-            W.pairRec = (uint16_t *)b->pairBuf;
-        }
-        if ((int64_t)tot[1] > W.itemCap || !b->itemBuf) {
-            if (b->itemBuf) HIP_TRY(hipFree(b->itemBuf));
-            b->itemBuf = nullptr;
-            W.itemCap = (int64_t)tot[1] + 64;
-            hipError_t me = hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item));
-            if (me != hipSuccess) {
+            if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
                 (void)hipGetLastError();
-                setLastError("augx_batch_decode: out of device memory for the candidate buffer (" + std::to_string(tot[1]) + " candidates); decode fewer bases per batch");
+                b->itemBuf = nullptr;
+                setLastError("augx_batch_decode: out of device memory for the candidate buffer; decode fewer bases per batch");
                 return AUGX_E_NOMEM;
             }
-            W.items = (Item *)b->itemBuf;
+            W.pairRec = (uint16_t *)b->pairBuf; W.items = (Item *)b->itemBuf;
+            HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
-        HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(kCandWrite, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-        HIP_TRY(hipGetLastError());
-        b->nItems = tot[1]; b->nPairs = tot[0];
+        for (int attempt = 0;; attempt++) {
+            HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
+            hipLaunchKernelGGL(kCand, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+            HIP_TRY(hipGetLastError());
+            CandAlloc tot;
+            HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            b->nPairs = tot.pairs; b->nItems = tot.items;
+            if ((int64_t)tot.pairs <= W.pairCap && (int64_t)tot.items <= W.itemCap) break;
+            if (attempt > 0) { setLastError("augx_batch_decode: candidate buffers overflowed twice"); return AUGX_E_HIP; }
+            HIP_TRY(hipFree(b->pairBuf)); HIP_TRY(hipFree(b->itemBuf));
+            b->pairBuf = b->itemBuf = nullptr;
+            W.pairCap = (int64_t)tot.pairs + 64; W.itemCap = (int64_t)tot.items + 64;
+            HIP_TRY(hipMalloc(&b->pairBuf, (size_t)W.pairCap * sizeof(uint16_t)));
+            if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
+                (void)hipGetLastError();
+                b->itemBuf = nullptr;
+                setLastError("augx_batch_decode: out of device memory for the candidate buffer (" + std::to_string(tot.items) + " candidates); decode fewer bases per batch");
+                return AUGX_E_NOMEM;
+            }
+            W.pairRec = (uint16_t *)b->pairBuf; W.items = (Item *)b->itemBuf;
+            HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
+        }
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     hipLaunchKernelGGL(kTrellis, dim3(n), dim3(NT), 0, st, d->dT, b->dV);

@@ -49,6 +49,7 @@ constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >
 constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
 constexpr int BLK = 8;                       // bases per trellis block: smaller than every lag except the lag-1 chain states
 
+struct CandAlloc;
 // flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
@@ -108,8 +109,8 @@ struct BatchView {
     int64_t nBlk;                    // N / BLK
     uint32_t *blkCnt;                // [nBlk][2] (pairs, items) of the block
     uint32_t *blkSplit;              // [nBlk][3] items of the block up to the pair boundaries near 1/3 and 2/3 / of all states but RTERMINAL (they come first)
-    uint64_t *blkOff;                // [nBlk+1][2] exclusive prefix of blkCnt
-    uint64_t *blkChunk;              // scan scratch [nBlk/1024 + 1][2]
+    uint64_t *blkOff;                // [nBlk][2] first pair / first item of the block (the blocks of a tile are contiguous)
+    struct CandAlloc *candAlloc;     // running totals of pairs / items handed out to tiles
     uint16_t *pairRec;               // [pairs] (base offset in block << 8) | state
     Item *items;                     // [items]
     int64_t pairCap, itemCap;

@@ -434,6 +434,9 @@ struct CandLds {
     VarConst vc[SP];
     VarDesc desc[NWAVES][WAVE];     // descriptors of the (base, state) pairs of the current round, one per lane
     int pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];
+    uint32_t cntW[NWAVES][5];
+    unsigned long long preW[NWAVES][2], baseW[2];
+    int fits;
 };
 
 // read-only view of one piece for the candidate kernel (everything comes from HBM / L2)
@@ -735,102 +738,114 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
     }
 }
 
-// candidates of block b (bases 8b .. 8b+7) of piece X.p, by wavefront w of the workgroup.
-// write == false: count pairs and items (blkCnt, blkSplit); write == true: emit pairRec / items at blkOff.
-AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, uint64_t maskVar, uint64_t maskRT) {
+// candidates of block b (bases 8b .. 8b+7) of piece X.p, by wavefront w of the workgroup.  The pairs are ordered: all
+// states but RTERMINAL (by base, then state), then RTERMINAL.  Rounds of 64 pairs (one block rarely has more).
+//   write == false: describe + count; results in cnt[] = {pairs, items, items of non-RTERMINAL pairs, mid1, mid2}
+//   write == true : emit pairRec / items at pairBase / itemBase.  If the block had a single round, the descriptors
+//                   left in LDS by the counting call are reused.
+AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, uint64_t maskVar, uint64_t maskRT, uint64_t pairBase,
+                        uint64_t itemBase, uint32_t *cnt) {
     const BatchView &B = X.B;
     const int n = X.n, jb = b * BLK;
-    const int64_t gblk = X.o / BLK + b;
-    uint64_t pairBase = 0, itemBase = 0;
-    if (write) { pairBase = B.blkOff[gblk * 2]; itemBase = B.blkOff[gblk * 2 + 1]; }
-    int pairsDone = 0;
-    uint32_t itemsDone = 0, split = 0, mid1 = 0, mid2 = 0;
-    for (int phase = 0; phase < 2; phase++) {
-        const uint64_t mask = phase == 0 ? maskVar : maskRT;
-        uint64_t g[BLK];   // only ever indexed by fully unrolled loops: stays in registers
-        int off[BLK + 1];
-        off[0] = 0;
+    uint64_t g0[BLK], g1[BLK];   // only ever indexed by fully unrolled loops: stay in registers
+    int off0[BLK + 1], off1[BLK + 1];
+    off0[0] = 0; off1[0] = 0;
 #pragma unroll
-        for (int dj = 0; dj < BLK; dj++) {
-            int j = jb + dj;
-            g[dj] = (j >= 1 && j < n) ? (B.gate[X.o + 1 + j] & mask) : 0;
-            off[dj + 1] = off[dj] + popc64(g[dj]);
-        }
-        const int allPairs = off[BLK];
-        for (int done = 0; done < allPairs; done += WAVE) {
-            const int nPairs = allPairs - done < WAVE ? allPairs - done : WAVE;
-            TV(int, tot);
-            FOR_WLANES(t, w) { // one lane per pair: locate the pair, build its descriptor
-                const int l = t & 63;
-                TX(tot) = 0;
-                if (l < nPairs) {
+    for (int dj = 0; dj < BLK; dj++) {
+        const int j = jb + dj;
+        const uint64_t gt = (j >= 1 && j < n) ? B.gate[X.o + 1 + j] : 0;
+        g0[dj] = gt & maskVar; g1[dj] = gt & maskRT;
+        off0[dj + 1] = off0[dj] + popc64(g0[dj]);
+        off1[dj + 1] = off1[dj] + popc64(g1[dj]);
+    }
+    const int nP0 = off0[BLK], allPairs = nP0 + off1[BLK];
+    const bool reuse = write && allPairs <= WAVE;
+    uint32_t itemsDone = 0, split = 0, mid1 = 0, mid2 = 0;
+    for (int done = 0; done < allPairs; done += WAVE) {
+        const int nPairs = allPairs - done < WAVE ? allPairs - done : WAVE;
+        TV(int, tot);
+        FOR_WLANES(t, w) { // one lane per pair: locate the pair, build its descriptor
+            const int l = t & 63;
+            TX(tot) = 0;
+            if (l < nPairs) {
+                if (reuse) TX(tot) = L.desc[w][l].total;
+                else {
                     int want = done + l, dj = 0, first = 0;
                     uint64_t gg = 0;
+                    if (want < nP0) {
 #pragma unroll
-                    for (int d2 = 0; d2 < BLK; d2++)
-                        if (off[d2] <= want && want < off[d2 + 1]) { dj = d2; gg = g[d2]; first = off[d2]; }
+                        for (int d2 = 0; d2 < BLK; d2++)
+                            if (off0[d2] <= want && want < off0[d2 + 1]) { dj = d2; gg = g0[d2]; first = off0[d2]; }
+                    } else {
+                        want -= nP0;
+#pragma unroll
+                        for (int d2 = 0; d2 < BLK; d2++)
+                            if (off1[d2] <= want && want < off1[d2 + 1]) { dj = d2; gg = g1[d2]; first = off1[d2]; }
+                    }
                     for (int k = want - first; k > 0; k--) gg &= gg - 1;
                     const int s2 = __builtin_ctzll(gg | (1ull << 63));
                     L.pairJ[w][l] = jb + dj; L.pairS[w][l] = s2;
                     varDescribe(X, s2, jb + dj, L.desc[w][l]);
                     TX(tot) = L.desc[w][l].total;
-                    if (write) B.pairRec[pairBase + pairsDone + l] = (uint16_t)((dj << 8) | s2);
                 }
+                if (write) B.pairRec[pairBase + done + l] = (uint16_t)(((L.pairJ[w][l] - jb) << 8) | L.pairS[w][l]);
             }
-            WAVE_SYNC();
-            TV(int, ibase); // inclusive prefix of the candidate counts
-            FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
-            waveInclScan(ibase, w);
-            const int totalItems = waveRead(ibase, w, WAVE - 1);
-            if (!write && phase == 0 && done == 0) { // pair boundaries closest to 1/3 and 2/3 of the candidates (three trellis wavefronts share them)
-                const int t1 = totalItems / 3, t2 = 2 * totalItems / 3;
+        }
+        WAVE_SYNC();
+        TV(int, ibase); // inclusive prefix of the candidate counts
+        FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
+        waveInclScan(ibase, w);
+        const int totalItems = waveRead(ibase, w, WAVE - 1);
+        if (!write) {
+            // candidates of the pairs before the first RTERMINAL pair
+            if (nP0 > done) split = itemsDone + (uint32_t)(nP0 - done >= nPairs ? totalItems : waveRead(ibase, w, nP0 - done - 1));
+            if (done == 0) { // pair boundaries closest to 1/3 and 2/3 of the non-RTERMINAL candidates (three trellis wavefronts share them)
+                const int np = nP0 < nPairs ? nP0 : nPairs;
+                const int tot0 = np > 0 ? waveRead(ibase, w, np - 1) : 0, t1 = tot0 / 3, t2 = 2 * tot0 / 3;
                 int best1 = 0x7fffffff, best2 = 0x7fffffff;
-                for (int q = 0; q < nPairs; q++) {
+                for (int q = 0; q < np; q++) {
                     const int bnd = waveRead(ibase, w, q), d1 = bnd > t1 ? bnd - t1 : t1 - bnd, d2 = bnd > t2 ? bnd - t2 : t2 - bnd;
                     if (d1 < best1) { best1 = d1; mid1 = (uint32_t)bnd; }
                     if (d2 < best2) { best2 = d2; mid2 = (uint32_t)bnd; }
                 }
                 if (mid2 < mid1) mid2 = mid1;
             }
-            if (write) {
-                for (int base = 0; base < totalItems; base += WAVE) {
-                    TV(int, myPair);
-                    TV(int, myFirst);
-                    FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
-                    for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
-                        const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
-                        FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
-                    }
-                    FOR_WLANES(t, w) { // one candidate per lane
-                        const int l = t & 63;
-                        const int it = base + l;
-                        if (it < totalItems) {
-                            const int q = TX(myPair);
-                            double te; int key; uint32_t src;
-                            varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
-                            if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
-                            Item I;
-                            I.te = te; I.kp = ((uint32_t)(pairsDone + q) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
-                            B.items[itemBase + itemsDone + it] = I;
-                        }
+        } else {
+            for (int base = 0; base < totalItems; base += WAVE) {
+                TV(int, myPair);
+                TV(int, myFirst);
+                FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
+                for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
+                    const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
+                    FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
+                }
+                FOR_WLANES(t, w) { // one candidate per lane
+                    const int l = t & 63;
+                    const int it = base + l;
+                    if (it < totalItems) {
+                        const int q = TX(myPair);
+                        double te; int key; uint32_t src;
+                        varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
+                        if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                        Item I;
+                        I.te = te; I.kp = ((uint32_t)(done + q) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+                        B.items[itemBase + itemsDone + it] = I;
                     }
                 }
             }
-            WAVE_SYNC();
-            pairsDone += nPairs;
-            itemsDone += (uint32_t)totalItems;
         }
-        if (phase == 0) split = itemsDone;
+        WAVE_SYNC();
+        itemsDone += (uint32_t)totalItems;
     }
-    if (!write) {
-        FOR_WLANES(t, w) {
-            if ((t & 63) == 0) { B.blkCnt[gblk * 2] = (uint32_t)pairsDone; B.blkCnt[gblk * 2 + 1] = itemsDone; B.blkSplit[gblk * 3] = mid1; B.blkSplit[gblk * 3 + 1] = mid2; B.blkSplit[gblk * 3 + 2] = split; }
-        }
-    }
+    if (!write) { cnt[0] = (uint32_t)allPairs; cnt[1] = itemsDone; cnt[2] = nP0 == 0 ? 0 : split; cnt[3] = mid1; cnt[4] = mid2; }
 }
 
-// one workgroup = NWAVES consecutive blocks (they belong to one piece: a chunk of CHUNK slots never spans pieces)
-AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg, bool write) {
+// global allocation state of the candidate buffers (one per batch)
+struct CandAlloc { unsigned long long pairs, items; };
+
+// one workgroup = the NWAVES = BLK consecutive blocks of one tile of 64 bases (they belong to one piece: a chunk of
+// CHUNK slots never spans pieces).  Count, reserve a contiguous range for the tile, emit.
+AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg) {
     const int64_t gblk0 = wg * NWAVES;
     if (gblk0 >= B.nBlk) return;
     const int p = B.chunkPiece[gblk0 * BLK / CHUNK];
@@ -841,9 +856,40 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
     uint64_t maskVar, maskRT;
     varMasks(T, maskVar, maskRT);
     FOR_WAVES(w) {
+        const int b = (int)(gblk0 + w - X.o / BLK);
+        uint32_t cnt[5];
+        candBlock(X, L, w, b, false, maskVar, maskRT, 0, 0, cnt);
+        FOR_WLANES(t, w) { if ((t & 63) == 0) for (int i = 0; i < 5; i++) L.cntW[w][i] = cnt[i]; }
+    }
+    BLOCK_SYNC();
+    FOR_THREADS(t) {
+        if (t == 0) {
+            unsigned long long np = 0, ni = 0;
+            for (int w = 0; w < NWAVES; w++) { L.preW[w][0] = np; L.preW[w][1] = ni; np += L.cntW[w][0]; ni += L.cntW[w][1]; }
+#ifdef AUGX_EMU
+            const unsigned long long bp0 = B.candAlloc->pairs, bi0 = B.candAlloc->items;
+            B.candAlloc->pairs += np; B.candAlloc->items += ni;
+#else
+            const unsigned long long bp0 = atomicAdd(&B.candAlloc->pairs, np), bi0 = atomicAdd(&B.candAlloc->items, ni);
+#endif
+            L.baseW[0] = bp0; L.baseW[1] = bi0;
+            L.fits = (bp0 + np <= (unsigned long long)B.pairCap && bi0 + ni <= (unsigned long long)B.itemCap) ? 1 : 0;
+        }
+    }
+    BLOCK_SYNC();
+    if (!L.fits) return; // the host re-runs the kernel with buffers of the size the counters report
+    FOR_WAVES(w) {
         const int64_t gblk = gblk0 + w;
         const int b = (int)(gblk - X.o / BLK);
-        candBlock(X, L, w, b, write, maskVar, maskRT);
+        const uint64_t pairBase = L.baseW[0] + L.preW[w][0], itemBase = L.baseW[1] + L.preW[w][1];
+        FOR_WLANES(t, w) {
+            if ((t & 63) == 0) {
+                B.blkOff[gblk * 2] = pairBase; B.blkOff[gblk * 2 + 1] = itemBase;
+                B.blkCnt[gblk * 2] = L.cntW[w][0]; B.blkCnt[gblk * 2 + 1] = L.cntW[w][1];
+                B.blkSplit[gblk * 3] = L.cntW[w][3]; B.blkSplit[gblk * 3 + 1] = L.cntW[w][4]; B.blkSplit[gblk * 3 + 2] = L.cntW[w][2];
+            }
+        }
+        if (L.cntW[w][0] > 0) candBlock(X, L, w, b, true, maskVar, maskRT, pairBase, itemBase, nullptr);
     }
 }
 
@@ -994,10 +1040,10 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         L.eqPrev[buf][l][i % 6] = (dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
     }
     const int64_t gb0 = o / BLK + (int64_t)tile * BLK;
-    for (int i = tid; i < (BLK + 1) * 2; i += nth) {
-        int64_t gb = gb0 + i / 2;
-        if (gb > B.nBlk) gb = B.nBlk;
-        L.blkOff[buf][i / 2][i % 2] = gp(B.blkOff)[gb * 2 + i % 2];
+    for (int i = tid; i < (BLK + 1) * 2; i += nth) { // offsets of the blocks (a tile is contiguous); [BLK] = end of the tile
+        int64_t gb = gb0 + i / 2, extra = 0;
+        if (i / 2 == BLK || gb >= B.nBlk) { gb = (gb0 + BLK - 1 < B.nBlk ? gb0 + BLK - 1 : B.nBlk - 1); extra = gp(B.blkCnt)[gb * 2 + i % 2]; }
+        L.blkOff[buf][i / 2][i % 2] = gp(B.blkOff)[gb * 2 + i % 2] + extra;
     }
     for (int i = tid; i < BLK * 3; i += nth) L.blkSplit[buf][i / 3][i % 3] = gb0 + i / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + i / 3) * 3 + i % 3] : 0;
     for (int i = tid; i < BLK * 4; i += nth) {
@@ -1005,10 +1051,9 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         if (q > n - 1) q = n - 1;
         L.listTop[buf][i / 4][i % 4] = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + i % 4, NCNT)] - 1;
     }
-    int64_t gbE = gb0 + BLK;
-    if (gbE > B.nBlk) gbE = B.nBlk;
+    const int64_t gbL = gb0 + BLK - 1 < B.nBlk ? gb0 + BLK - 1 : B.nBlk - 1; // last block of the tile
     {
-        const uint64_t first = gp(B.blkOff)[gb0 * 2 + 1], last = gp(B.blkOff)[gbE * 2 + 1];
+        const uint64_t first = gp(B.blkOff)[gb0 * 2 + 1], last = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
         const int cnt = last - first < (uint64_t)ITEM_CAP ? (int)(last - first) : ITEM_CAP;
         const Item *gi = B.items + first;
         for (int i = tid; i < cnt; i += 4 * nth) { // four loads in flight per thread
@@ -1021,7 +1066,7 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         }
     }
     {
-        const uint64_t first = gp(B.blkOff)[gb0 * 2], last = gp(B.blkOff)[gbE * 2];
+        const uint64_t first = gp(B.blkOff)[gb0 * 2], last = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
         const int cnt = last - first < (uint64_t)PAIR_CAP ? (int)(last - first) : PAIR_CAP;
         for (int i = tid; i < cnt; i += nth) L.pairRec[buf][i] = gp(B.pairRec)[first + i];
     }

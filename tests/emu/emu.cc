@@ -105,26 +105,31 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     scanFields<false>(B.fx, NFX, L);
     for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
     for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g);
-    // ---- K2a: count, scan, emit
+    // ---- K2a: candidates, tile by tile (first with buffers that are too small, to exercise the re-run path)
     B.nBlk = B.N / BLK;
     B.blkCnt = zalloc<uint32_t>(B.nBlk * 2);
     B.blkSplit = zalloc<uint32_t>(B.nBlk * 3);
-    B.blkOff = zalloc<uint64_t>((B.nBlk + 1) * 2);
+    B.blkOff = zalloc<uint64_t>(B.nBlk * 2);
+    CandAlloc ca;
+    B.candAlloc = &ca;
     CandLds *cl = new CandLds();
     const int64_t nWg = (B.nBlk + NWAVES - 1) / NWAVES;
-    for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg, false);
-    for (int64_t i = 0; i < B.nBlk; i++) {
-        B.blkOff[(i + 1) * 2] = B.blkOff[i * 2] + B.blkCnt[i * 2];
-        B.blkOff[(i + 1) * 2 + 1] = B.blkOff[i * 2 + 1] + B.blkCnt[i * 2 + 1];
-    }
-    B.pairCap = (int64_t)B.blkOff[B.nBlk * 2]; B.itemCap = (int64_t)B.blkOff[B.nBlk * 2 + 1];
+    B.pairCap = 16; B.itemCap = 64;
     B.pairRec = zalloc<uint16_t>(B.pairCap + 1);
     B.items = zalloc<Item>(B.itemCap + 1);
-    for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg, true);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ca.pairs = 0; ca.items = 0;
+        for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg);
+        if ((int64_t)ca.pairs <= B.pairCap && (int64_t)ca.items <= B.itemCap) break;
+        free(B.pairRec); free(B.items);
+        B.pairCap = (int64_t)ca.pairs; B.itemCap = (int64_t)ca.items;
+        B.pairRec = zalloc<uint16_t>(B.pairCap + 1);
+        B.items = zalloc<Item>(B.itemCap + 1);
+    }
     delete cl;
     if (getenv("AUGX_EMU_STATS")) {
         int64_t dead = 0, byTag[3] = {0, 0, 0};
-        for (int64_t i = 0; i < B.itemCap; i++) { if (!(B.items[i].te > AUGX_NINF)) dead++; else byTag[B.items[i].src >> 30]++; }
+        for (int64_t i = 0; i < (int64_t)ca.items; i++) { if (!(B.items[i].te > AUGX_NINF)) dead++; else byTag[B.items[i].src >> 30]++; }
         fprintf(stderr, "emu stats: N=%lld pairs=%lld items=%lld dead=%lld live list=%lld vig=%lld col0=%lld\n", (long long)B.N, (long long)B.pairCap,
                 (long long)B.itemCap, (long long)dead, (long long)byTag[0], (long long)byTag[1], (long long)byTag[2]);
     }
