@@ -371,6 +371,9 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
 // The formulas are those of the reference loops (exon: src/exonmodel.cc:1059-1132; lessD:
 // src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
 // =================================================================================================
+#ifdef AUGX_EMU
+static long long g_emuSlowA = 0, g_emuSlowB = 0; // emulator statistics: candidates taking the general evaluation path
+#endif
 struct VarDesc {
     int kind, win, nList, extra, total, listSel; // listSel: 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
     int64_t i1;                                   // one past the newest list entry (piece-local index)
@@ -435,6 +438,8 @@ struct CandLds {
     VarDesc desc[NWAVES][WAVE];     // descriptors of the (base, state) pairs of the current round, one per lane
     int pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];
     uint32_t cntW[NWAVES][5];
+    uint8_t plD[NWAVES][BLK * 32], plS[NWAVES][BLK * 32]; // pair list of each wavefront's block: base offset, state
+    int plN[NWAVES][2];                                 // pairs but RTERMINAL / all pairs
     unsigned long long preW[NWAVES][2], baseW[2];
     int fits;
 };
@@ -587,38 +592,44 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     const int n = X.n, kind = D.kind, win = D.win;
     te = AUGX_NINF; key = 0; src = srcCol0(0, 0);
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
+        // written without early exits so that the loads of one candidate are all in flight together: the list entry
+        // first, then the four sequence bytes, the content prefix and the length term
         const bool fwd = kind == AUGX_K_LESSD;
         const int f = win;
-        int eop;
-        uint32_t sr;
-        if (idx < D.nList) {
-            int64_t li = D.i1 - 1 - idx;
-            eop = X.listPos(D.listSel, li);
-            sr = srcList(0, D.listSel, f, li);
-        } else { eop = 0; sr = srcCol0(0, VC.anc[0]); }
-        int begin = eop + 1;
-        int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
-        if (bobi >= 0 && !(fwd ? P.possDSS(bobi) : P.possRASS(bobi))) return;
-        bool spliced = fwd ? (f != 0) : (f != 2);
+        const bool listed = idx < D.nList;
+        const int64_t li = listed ? D.i1 - 1 - idx : 0;
+        const int eop = listed ? X.listPos(D.listSel, li) : 0;
+        const uint32_t sr = listed ? srcList(0, D.listSel, f, li) : srcCol0(0, VC.anc[0]);
+        const int begin = eop + 1;
+        const int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
+        const int bA = P.b(bobi), bB = P.b(bobi + 1), bM1 = P.b(bobi - 1), bM2 = P.b(bobi - 2);
+        const uint64_t cFx = listed ? X.listFx(D.listSel, li, 0) : 0;
+        int intronLength = D.eobi - bobi + 1;
+        const bool lenOk = intronLength <= T.d;
+        if (intronLength > T.d || intronLength < 0) intronLength = 0;
+        const double lenI = X.lenIAt(intronLength);
+        // splice-site dinucleotide at the intron start (reference isPossibleDSS / isPossibleRASS)
+        const bool siteOk = bobi < 0 || (bobi >= 1 && bobi <= n - 2 && (fwd ? (bA == 2 && bB == 3) : (bA == 1 && bB == 3)));
+        // stop codon across the splice (reference src/intronmodel.cc:935-958)
+        const bool spliced = fwd ? (f != 0) : (f != 2);
+        bool veto = false;
         if (spliced && bobi > 1) {
             int c0 = D.cod0, c1 = D.cod1, c2 = D.cod2;
             if (fwd) {
-                if (f == 1) c0 = P.b(bobi - 1);
-                else { c0 = P.b(bobi - 2); c1 = P.b(bobi - 1); }
+                if (f == 1) c0 = bM1;
+                else { c0 = bM2; c1 = bM1; }
             } else {
-                if (f == 0) { c1 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4; c2 = P.b(bobi - 2) <= 3 ? 3 - P.b(bobi - 2) : 4; }
-                else c2 = P.b(bobi - 1) <= 3 ? 3 - P.b(bobi - 1) : 4;
+                if (f == 0) { c1 = bM1 <= 3 ? 3 - bM1 : 4; c2 = bM2 <= 3 ? 3 - bM2 : 4; }
+                else c2 = bM1 <= 3 ? 3 - bM1 : 4;
             }
-            if (stopCodon3(c0, c1, c2)) return;
+            veto = stopCodon3(c0, c1, c2);
         }
-        int intronLength = D.eobi - bobi + 1;
-        if (intronLength > T.d) return;
-        double restSeq = idx < D.nList ? (double)(int64_t)(D.eFx - X.listFx(D.listSel, D.i1 - 1 - idx, 0)) * AUGX_FX_INV
-                                       : P.seg(fwd ? FX_INF : FX_INR, begin, j);
-        double emi = X.lenIAt(intronLength) + restSeq;
-        if (!(emi > AUGX_NINF)) return;
-        te = VC.tr[0] + emi;
-        key = eop + KEY_BIAS; src = sr;
+        const double restSeq = listed ? (double)(int64_t)(D.eFx - cFx) * AUGX_FX_INV : P.seg(fwd ? FX_INF : FX_INR, begin, j);
+        const double emi = lenI + restSeq;
+        if (siteOk && !veto && lenOk && emi > AUGX_NINF) {
+            te = VC.tr[0] + emi;
+            key = eop + KEY_BIAS; src = sr;
+        }
         return;
     }
     if (D.listSel >= 4) { // predecessor is the igenic state
@@ -641,6 +652,11 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         double nep;
         const int m = D.right - bs, k = T.k;
         const int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+        // length and reading-frame constraints first (reference src/exonmodel.cc:1716-1762 applies them last; a candidate
+        // that fails them is infeasible whatever its content score): two of three start codons are out of frame
+        if (len < 1 || len > T.max_exon_len) return;
+        if ((kind == AUGX_K_SINGLE || kind == AUGX_K_RSINGLE) ? len % 3 != 0
+            : kind == AUGX_K_INITIAL ? (len % 3 != win || len <= 2) : mod3(2 - len) != win) return;
         bool fast = false;
         if (D.listSel == 4) {
             const int eos = bs + k - 1, eoi = eos + T.Li;
@@ -670,7 +686,10 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                 nep = (B.rsBegin[X.lo + ri] + (D.plsEnd + inner)) + lenPart;
             }
         }
-        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
+#ifdef AUGX_EMU
+        if (!fast) g_emuSlowA++;
+#endif
+        if (!fast) nep = (B.dbgFlags & 16) ? AUGX_NINF : exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
         if (!(nep > AUGX_NINF)) return;
         te = (VC.tr[0] + D.endP) + nep;
         key = eop + KEY_BIAS;
@@ -685,6 +704,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     else eop = -1;
     int bs = eop + 1;
     int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+    if (len < 1 || len > T.max_exon_len || (kind == AUGX_K_RINITIAL && len <= 2)) return;
     double nep;
     {
         const int m = D.right - bs, k = T.k;
@@ -713,7 +733,10 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                 }
             }
         }
-        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
+#ifdef AUGX_EMU
+        if (!fast) g_emuSlowB++;
+#endif
+        if (!fast) nep = (B.dbgFlags & 16) ? AUGX_NINF : exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
     }
     if (!(nep > AUGX_NINF)) return;
     // exactly one of the (up to three) ancestors has the reading frame that fits the exon length
@@ -747,18 +770,42 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                         uint64_t itemBase, uint32_t *cnt) {
     const BatchView &B = X.B;
     const int n = X.n, jb = b * BLK;
-    uint64_t g0[BLK], g1[BLK];   // only ever indexed by fully unrolled loops: stay in registers
-    int off0[BLK + 1], off1[BLK + 1];
-    off0[0] = 0; off1[0] = 0;
-#pragma unroll
-    for (int dj = 0; dj < BLK; dj++) {
-        const int j = jb + dj;
-        const uint64_t gt = (j >= 1 && j < n) ? B.gate[X.o + 1 + j] : 0;
-        g0[dj] = gt & maskVar; g1[dj] = gt & maskRT;
-        off0[dj + 1] = off0[dj] + popc64(g0[dj]);
-        off1[dj + 1] = off1[dj] + popc64(g1[dj]);
+    // three groups of pairs, in this order: short introns (most candidates; their chunks then run the short-intron
+    // code only), exons but RTERMINAL, RTERMINAL
+    uint64_t maskLess = 0;
+    for (int s2 = 0; s2 < X.S; s2++)
+        if (X.vc[s2].kind == AUGX_K_LESSD || X.vc[s2].kind == AUGX_K_RLESSD) maskLess |= 1ull << s2;
+    maskLess &= maskVar;
+    // pair list of the block in LDS (lane dj < BLK owns base jb + dj); the counting call builds it, the emitting call reuses it
+    int nP0, allPairs;
+    if (!write) {
+        TV(int, nA); TV(int, nB); TV(int, nC);
+        TV(uint64_t, gA); TV(uint64_t, gB); TV(uint64_t, gC);
+        FOR_WLANES(t, w) {
+            const int l = t & 63, j = jb + l;
+            const uint64_t gt = (l < BLK && j >= 1 && j < n) ? B.gate[X.o + 1 + j] : 0;
+            TX(gA) = gt & maskLess; TX(gB) = gt & maskVar & ~maskLess; TX(gC) = gt & maskRT;
+            TX(nA) = popc64(TX(gA)); TX(nB) = popc64(TX(gB)); TX(nC) = popc64(TX(gC));
+        }
+        TV(int, iA); TV(int, iB); TV(int, iC);
+        FOR_WLANES(t, w) { TX(iA) = TX(nA); TX(iB) = TX(nB); TX(iC) = TX(nC); }
+        waveInclScan(iA, w); waveInclScan(iB, w); waveInclScan(iC, w);
+        const int totA = waveRead(iA, w, WAVE - 1), totB = waveRead(iB, w, WAVE - 1), totC = waveRead(iC, w, WAVE - 1);
+        FOR_WLANES(t, w) {
+            const int l = t & 63;
+            if (l < BLK) {
+                int pos = TX(iA) - TX(nA);
+                for (uint64_t gg = TX(gA); gg; gg &= gg - 1) { L.plD[w][pos] = (uint8_t)l; L.plS[w][pos] = (uint8_t)__builtin_ctzll(gg); pos++; }
+                pos = totA + TX(iB) - TX(nB);
+                for (uint64_t gg = TX(gB); gg; gg &= gg - 1) { L.plD[w][pos] = (uint8_t)l; L.plS[w][pos] = (uint8_t)__builtin_ctzll(gg); pos++; }
+                pos = totA + totB + TX(iC) - TX(nC);
+                for (uint64_t gg = TX(gC); gg; gg &= gg - 1) { L.plD[w][pos] = (uint8_t)l; L.plS[w][pos] = (uint8_t)__builtin_ctzll(gg); pos++; }
+            }
+            if (l == 0) { L.plN[w][0] = totA + totB; L.plN[w][1] = totA + totB + totC; }
+        }
+        WAVE_SYNC();
     }
-    const int nP0 = off0[BLK], allPairs = nP0 + off1[BLK];
+    nP0 = L.plN[w][0]; allPairs = L.plN[w][1];
     const bool reuse = write && allPairs <= WAVE;
     uint32_t itemsDone = 0, split = 0, mid1 = 0, mid2 = 0;
     for (int done = 0; done < allPairs; done += WAVE) {
@@ -770,20 +817,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
             if (l < nPairs) {
                 if (reuse) TX(tot) = L.desc[w][l].total;
                 else {
-                    int want = done + l, dj = 0, first = 0;
-                    uint64_t gg = 0;
-                    if (want < nP0) {
-#pragma unroll
-                        for (int d2 = 0; d2 < BLK; d2++)
-                            if (off0[d2] <= want && want < off0[d2 + 1]) { dj = d2; gg = g0[d2]; first = off0[d2]; }
-                    } else {
-                        want -= nP0;
-#pragma unroll
-                        for (int d2 = 0; d2 < BLK; d2++)
-                            if (off1[d2] <= want && want < off1[d2 + 1]) { dj = d2; gg = g1[d2]; first = off1[d2]; }
-                    }
-                    for (int k = want - first; k > 0; k--) gg &= gg - 1;
-                    const int s2 = __builtin_ctzll(gg | (1ull << 63));
+                    const int dj = L.plD[w][done + l], s2 = L.plS[w][done + l];
                     L.pairJ[w][l] = jb + dj; L.pairS[w][l] = s2;
                     varDescribe(X, s2, jb + dj, L.desc[w][l]);
                     TX(tot) = L.desc[w][l].total;
@@ -825,7 +859,8 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                     if (it < totalItems) {
                         const int q = TX(myPair);
                         double te; int key; uint32_t src;
-                        varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
+                        if (B.dbgFlags & 32) { te = AUGX_NINF; key = 0; src = 0; }
+                        else varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
                         if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
                         Item I;
                         I.te = te; I.kp = ((uint32_t)(done + q) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;

@@ -132,6 +132,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         for (int64_t i = 0; i < (int64_t)ca.items; i++) { if (!(B.items[i].te > AUGX_NINF)) dead++; else byTag[B.items[i].src >> 30]++; }
         fprintf(stderr, "emu stats: N=%lld pairs=%lld items=%lld dead=%lld live list=%lld vig=%lld col0=%lld\n", (long long)B.N, (long long)B.pairCap,
                 (long long)B.itemCap, (long long)dead, (long long)byTag[0], (long long)byTag[1], (long long)byTag[2]);
+        fprintf(stderr, "emu stats: general-path evaluations: igenic-pred %lld, list exon %lld\n", g_emuSlowA, g_emuSlowB);
     }
     // ---- K2b, K3
     TrellisLds *lds = new TrellisLds();
