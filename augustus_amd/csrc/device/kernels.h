@@ -1332,40 +1332,41 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     auto fixedStep = [&](int w, int buf, int jb, int late, int rsel) {
         FOR_WLANES(t, w) {
             const int l = t & 63, dj = l & 7, j = jb + dj;
+            // written branch-light: every load of the selected rounds is issued before anything is computed
             double emi[FR], pv0[FR], pv1[FR];
+            int si[FR];
 #pragma unroll
             for (int r = 0; r < FR; r++) {
+                emi[r] = AUGX_NINF; pv0[r] = AUGX_NINF; pv1[r] = AUGX_NINF; si[r] = -1;
+                if (rsel >= 0 && r != rsel) continue;
                 const int jp = j - fLag[r][TI];
+                const bool lg = fLong[r][TI] != 0;
+                const double *p0 = lg ? &L.eqPrev[buf][j & 63][fAnc0[r][TI]] : &L.ring[jp & 63][fAnc0[r][TI]];
+                const double *p1 = lg ? &L.eqPrev[buf][j & 63][fAnc1[r][TI]] : &L.ring[jp & 63][fAnc1[r][TI]];
                 emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
-                pv0[r] = AUGX_NINF; pv1[r] = AUGX_NINF;
-                if (fS[r][TI] >= 0 && jp >= 0) {
-                    if (fLong[r][TI]) { pv0[r] = L.eqPrev[buf][j & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.eqPrev[buf][j & 63][fAnc1[r][TI]]; }
-                    else { pv0[r] = L.ring[jp & 63][fAnc0[r][TI]]; if (fNanc[r][TI] > 1) pv1[r] = L.ring[jp & 63][fAnc1[r][TI]]; }
-                }
+                pv0[r] = *p0; pv1[r] = *p1;
+                si[r] = L.site[buf][j & 63][fList[r][TI] & 3];
             }
 #pragma unroll
             for (int r = 0; r < FR; r++) {
+                if (rsel >= 0 && r != rsel) continue;
                 const int s2 = fS[r][TI];
-                if (s2 < 0 || j < 1 || j >= n || fLate[r][TI] != late || (rsel >= 0 && r != rsel)) continue;
-                double best = AUGX_NINF;
-                uint16_t bp = BP_NONE;
-                if (j - fLag[r][TI] >= 0 && emi[r] > AUGX_NINF) {
-                    if (pv0[r] > AUGX_NINF) { best = pv0[r] + (fTr0[r][TI] + emi[r]); bp = bpFixed(0); }
-                    if (fNanc[r][TI] > 1 && pv1[r] > AUGX_NINF) {
-                        double v2 = pv1[r] + (fTr1[r][TI] + emi[r]);
-                        if (v2 > best) { best = v2; bp = bpFixed(1); }
-                    }
-                }
-                L.ring[j & 63][s2] = best;
-                L.bp[buf][j & 63][s2] = bp;
-                if (fLrow[r][TI] >= 0) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
-                if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = best;
-                if (fList[r][TI] >= 0) {
-                    const int si = L.site[buf][j & 63][fList[r][TI]];
-                    if (si >= 0) {
+                const bool ok = j - fLag[r][TI] >= 0 && emi[r] > AUGX_NINF;
+                const bool c0 = ok && pv0[r] > AUGX_NINF, c1 = ok && fNanc[r][TI] > 1 && pv1[r] > AUGX_NINF;
+                const double v0 = pv0[r] + (fTr0[r][TI] + emi[r]), v1 = pv1[r] + (fTr1[r][TI] + emi[r]);
+                double best = c0 ? v0 : AUGX_NINF;
+                const bool take1 = c1 && v1 > best;
+                best = take1 ? v1 : best;
+                const uint16_t bp = take1 ? bpFixed(1) : c0 ? bpFixed(0) : BP_NONE;
+                if (s2 >= 0 && j >= 1 && j < n && fLate[r][TI] == late) {
+                    L.ring[j & 63][s2] = best;
+                    L.bp[buf][j & 63][s2] = bp;
+                    if (fLrow[r][TI] >= 0) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
+                    if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = best;
+                    if (fList[r][TI] >= 0 && si[r] >= 0) {
                         double *lval = fList[r][TI] == 0 ? B.laVal : fList[r][TI] == 1 ? B.lrVal : fList[r][TI] == 2 ? B.ldVal : B.rdVal;
-                        gp(lval)[(X.lo + si) * 3 + fFrame[r][TI]] = best;
-                        L.lcVal[fList[r][TI]][si & (LIST_WIN - 1)][fFrame[r][TI]] = best;
+                        gp(lval)[(X.lo + si[r]) * 3 + fFrame[r][TI]] = best;
+                        L.lcVal[fList[r][TI]][si[r] & (LIST_WIN - 1)][fFrame[r][TI]] = best;
                     }
                 }
             }
@@ -1439,6 +1440,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
                     const int lo2 = w == 0 ? it0 : w == 1 ? itA : itB, hi2 = w == 0 ? itA : w == 1 ? itB : itS;
                     if (hi2 > lo2) trellisItems(X, w, buf, blk, jb, lo2, hi2, vigLo);
+                    if (w == NWORK - 1 && blk > 0) { // RTERMINAL candidates of the previous block (nothing reads them before lag >= 16)
+                        const int rt0 = (int)(L.blkOff[buf][blk - 1][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][blk - 1][2];
+                        if (it0 > rt0) trellisItems(X, w, buf, blk - 1, jb - BLK, rt0, it0, vigLo);
+                    }
                     setFlag(&L.flagI[w], gbk + 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 3 : 5);
                     PROF_MARK(X, 2);
@@ -1460,25 +1465,49 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
                         TX(bB) = AUGX_NINF; TX(bA) = AUGX_NINF; TX(aB) = -1; TX(aA) = -1; TX(teS) = AUGX_NINF; TX(psS) = AUGX_NINF; TX(rai) = -1;
-                        if (TX(cS) >= 0) {
-                            const bool valid = j >= 1 && j < n;
-                            const double emi = valid ? L.sig[buf][j & 63][TX(cSig)] : AUGX_NINF;
-                            double pv[5];
+                        {
+                            const bool valid = TX(cS) >= 0 && j >= 1 && j < n;
+                            const double emiL = L.sig[buf][j & 63][TX(cSig)];
+                            double pv[5], v[5], te[5];
 #pragma unroll
                             for (int ai = 0; ai < 5; ai++) pv[ai] = L.ring[(j - 1) & 63][cAnc[ai][TI]];
+                            const double emi = valid ? emiL : AUGX_NINF;
+                            const int self = TX(cSelf);
 #pragma unroll
-                            for (int ai = 0; ai < 5; ai++) {
-                                if (ai >= TX(cNanc)) continue;
-                                const double te = cTr[ai][TI] + emi;
-                                if (ai == TX(cSelf)) { TX(teS) = te; TX(psS) = pv[ai]; }
-                                else {
-                                    const double v = pv[ai] + te;
-                                    if (ai < TX(cSelf)) { if (v > TX(bB)) { TX(bB) = v; TX(aB) = ai; } }
-                                    else { if (v > TX(bA)) { TX(bA) = v; TX(aA) = ai; } }
-                                }
+                            for (int ai = 0; ai < 5; ai++) { te[ai] = cTr[ai][TI] + emi; v[ai] = pv[ai] + te[ai]; } // cTr = -inf beyond the last ancestor
+                            TX(teS) = self == 0 ? te[0] : self == 1 ? te[1] : self == 2 ? te[2] : self == 3 ? te[3] : self == 4 ? te[4] : AUGX_NINF;
+                            TX(psS) = self == 0 ? pv[0] : self == 1 ? pv[1] : self == 2 ? pv[2] : self == 3 ? pv[3] : self == 4 ? pv[4] : AUGX_NINF;
+                            // first-wins arg-max (strict '>' in ascending order) of the ancestors before / after the state itself, as trees
+                            double vb[5], va[5];
+#pragma unroll
+                            for (int ai = 0; ai < 5; ai++) { vb[ai] = ai < self ? v[ai] : AUGX_NINF; va[ai] = ai > self ? v[ai] : AUGX_NINF; }
+                            {
+                                const bool t01 = vb[1] > vb[0], t23 = vb[3] > vb[2];
+                                const double m01 = t01 ? vb[1] : vb[0], m23 = t23 ? vb[3] : vb[2];
+                                const int i01 = t01 ? 1 : 0, i23 = t23 ? 3 : 2;
+                                const bool tq = m23 > m01;
+                                const double mq = tq ? m23 : m01;
+                                const int iq = tq ? i23 : i01;
+                                const bool t4 = vb[4] > mq;
+                                TX(bB) = t4 ? vb[4] : mq;
+                                TX(aB) = TX(bB) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
+                            }
+                            {
+                                const bool t01 = va[1] > va[0], t23 = va[3] > va[2];
+                                const double m01 = t01 ? va[1] : va[0], m23 = t23 ? va[3] : va[2];
+                                const int i01 = t01 ? 1 : 0, i23 = t23 ? 3 : 2;
+                                const bool tq = m23 > m01;
+                                const double mq = tq ? m23 : m01;
+                                const int iq = tq ? i23 : i01;
+                                const bool t4 = va[4] > mq;
+                                TX(bA) = t4 ? va[4] : mq;
+                                TX(aA) = TX(bA) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
                             }
                         }
                     }
+                    PROF_MARK(X, 4);
+                    TV(double, mBA);
+                    FOR_WLANES(t, w) { TX(mBA) = TX(bB) > TX(bA) ? TX(bB) : TX(bA); }
 #pragma unroll
                     for (int d = 0; d < BLK; d++) {
 #ifdef AUGX_EMU
@@ -1488,16 +1517,22 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #endif
                         FOR_WLANES(t, w) {
                             const int l = t & 63, dj = l & 7, j = jb + dj;
-                            if (dj == d && TX(cS) >= 0) {
+                            if (dj == d) {
                                 const double p0 = (d == 0 || j - 1 < 1) ? TX(psS) : TX(prevRes);
                                 const double vs = p0 + TX(teS);
-                                double best = TX(bB);
-                                int bai = TX(aB);
-                                if (vs > best) { best = vs; bai = TX(cSelf); }
-                                if (TX(bA) > best) { best = TX(bA); bai = TX(aA); }
-                                TX(res) = best; TX(rai) = bai;
+                                TX(psS) = p0;
+                                TX(res) = vs > TX(mBA) ? vs : TX(mBA);
                             }
                         }
+                    }
+                    PROF_MARK(X, 5);
+                    FOR_WLANES(t, w) {
+                        const double vs = TX(psS) + TX(teS);
+                        double best = TX(bB);
+                        int bai = TX(aB);
+                        if (vs > best) { best = vs; bai = TX(cSelf); }
+                        if (TX(bA) > best) { best = TX(bA); bai = TX(aA); }
+                        TX(rai) = bai;
                     }
                     FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
@@ -1512,7 +1547,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     WAVE_SYNC();
                     PROF_MARK(X, 3);
                     // step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
-                    if (it1 > itS) {
+                    if (it1 > itS && (blk == BLK - 1 || jb + BLK >= n)) { // last block of the tile (the others: see the workers)
                         const int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
                         trellisItems(X, w, buf, blk, jb, itS, it1, jl - VIG_WIN > -1 ? jl - VIG_WIN : -1);
                     }

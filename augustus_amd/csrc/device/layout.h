@@ -77,6 +77,16 @@ inline void checkModelSupported(const augx_tables &t) {
              kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) && t.n_anc[s] != 1)
             throw std::runtime_error("augx: unexpected ancestor count (non-standard transition file)");
     }
+    // the trellis kernel finishes the RTERMINAL cells of a block while the next block is under way: their readers must
+    // be fixed-lag states more than two blocks away
+    for (int s = 0; s < t.S; s++)
+        for (int a = 0; a < t.n_anc[s]; a++)
+            if (t.reachable[s] && t.state_kind[t.anc[s][a]] == AUGX_K_RTERMINAL) {
+                int kind = t.state_kind[s];
+                int lag = (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? t.As + 2 + t.Ae + t.U
+                          : (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? t.Ds + 2 + t.De : 0;
+                if (lag <= 2 * BLK) throw std::runtime_error("augx: unexpected successor of the reverse terminal exon state");
+            }
     if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
 }
 
