@@ -325,7 +325,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
-    if (getenv("AUGX_PROF")) DA(V.prof, uint64_t, (int64_t)n * 48);
+    if (getenv("AUGX_PROF")) DA(V.prof, uint64_t, (int64_t)n * 56);
     DA(V.vig, double, Z.N);
     DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
@@ -462,20 +462,20 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
     if (trellis_ms) *trellis_ms = c;
     if (back_ms) *back_ms = e;
     if (b->V.prof) { // developer aid (AUGX_PROF=1): cycle counters of the four trellis wavefronts, averaged over pieces
-        std::vector<uint64_t> h((size_t)b->L.nPieces * 48);
+        std::vector<uint64_t> h((size_t)b->L.nPieces * 56);
         HIP_TRY(hipMemcpy(h.data(), b->V.prof, h.size() * 8, hipMemcpyDeviceToHost));
-        static const char *role[4] = {"work0", "work1", "work2", "chain"};
-        for (int w = 0; w < 4; w++) {
+        static const char *role[5] = {"work0", "work1", "work2", "chain", "far"};
+        for (int w = 0; w < 5; w++) {
             fprintf(stderr, "trellis %-6s Mcycles/piece:", role[w]);
             for (int i = 0; i < 8; i++) {
                 double sum = 0;
-                for (int p = 0; p < b->L.nPieces; p++) sum += (double)h[((size_t)p * 4 + w) * 8 + i];
+                for (int p = 0; p < b->L.nPieces; p++) sum += (double)h[((size_t)p * 5 + w) * 8 + i];
                 fprintf(stderr, " [%d]=%.2f", i, sum / b->L.nPieces / 1e6);
             }
             fprintf(stderr, "  (0 tile wait, 1 flag wait, 2 role work, 3 chain, 4 item load, 5 scan, 6 publish, 7 item setup)\n");
         }
         {   // time stamps of block 1000 of piece 0, relative to the start of its fixed-lag step
-            const uint64_t *ts = &h[(size_t)b->L.nPieces * 32];
+            const uint64_t *ts = &h[(size_t)b->L.nPieces * 40];
             fprintf(stderr, "block 1000 of piece 0 (cycles): F %lld..%lld  I1 %lld..%lld  I2 %lld..%lld  late %lld..%lld  chain %lld..%lld\n",
                     0LL, (long long)(ts[1] - ts[0]), (long long)(ts[2] - ts[0]), (long long)(ts[3] - ts[0]), (long long)(ts[4] - ts[0]),
                     (long long)(ts[5] - ts[0]), (long long)(ts[6] - ts[0]), (long long)(ts[7] - ts[0]), (long long)(ts[8] - ts[0]), (long long)(ts[9] - ts[0]));

@@ -933,7 +933,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // workgroup barrier inside a tile of 64 bases; the other wavefronts stage the next tile (signal records, candidates)
 // into the second half of the LDS buffers and flush the back pointers of the previous one.
 // =================================================================================================
-constexpr int NWORK = 3, W_C = 3, W_LOAD = 4; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4.. loaders
+constexpr int NWORK = 3, W_C = 3, W_X = 4, W_LOAD = 5; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4 far fixed-lag states, 5.. loaders
 constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM)
 constexpr int PAIR_CAP = 512;
 
@@ -951,7 +951,7 @@ struct TrellisLds {
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
-    int flagF[NWORK], flagI[NWORK], flagL, flagC; // blocks completed by the trellis wavefronts (see trellisPiece)
+    int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN; // blocks completed by the trellis wavefronts (see trellisPiece)
     int abortFlag;
 };
 
@@ -1033,7 +1033,7 @@ __device__ inline void setFlag(int *f, int v) {
 #define PROF_MARK(X, sec) do {} while (0)
 #define PROF_STAMP(X, gbk, slot) do {} while (0)
 #else
-#define PROF_STAMP(X, gbk, slot) do { if ((X).B.prof && (gbk) == 1000 && (threadIdx.x & 63) == 0) (X).B.prof[(int64_t)(X).B.nPieces * 32 + (int64_t)(X).p * 16 + (slot)] = clock64(); } while (0)
+#define PROF_STAMP(X, gbk, slot) do { if ((X).B.prof && (gbk) == 1000 && (threadIdx.x & 63) == 0) (X).B.prof[(int64_t)(X).B.nPieces * 40 + (int64_t)(X).p * 16 + (slot)] = clock64(); } while (0)
 #define PROF_MARK(X, sec) do { if ((X).B.prof) { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } } while (0)
 #endif
 struct TrellisCtx {
@@ -1125,8 +1125,11 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     const int S = X.S;
     const uint64_t tileItem0 = L.blkOff[buf][0][1], tilePair0 = L.blkOff[buf][0][0];
     const int prBase = (int)(L.blkOff[buf][blk][0] - tilePair0);
-    const int top0 = L.listTop[buf][blk][0] - LIST_WIN, top1 = L.listTop[buf][blk][1] - LIST_WIN,
-              top2 = L.listTop[buf][blk][2] - LIST_WIN, top3 = L.listTop[buf][blk][3] - LIST_WIN;
+    // list entries at or below topK have (or may have: the far fixed-lag wavefront runs up to two blocks = LIST_AHEAD
+    // entries ahead) left the LDS cache of the newest LIST_WIN entries
+    constexpr int LIST_AHEAD = 32;
+    const int top0 = L.listTop[buf][blk][0] - (LIST_WIN - LIST_AHEAD), top1 = L.listTop[buf][blk][1] - (LIST_WIN - LIST_AHEAD),
+              top2 = L.listTop[buf][blk][2] - (LIST_WIN - LIST_AHEAD), top3 = L.listTop[buf][blk][3] - (LIST_WIN - LIST_AHEAD);
     const bool wantCells = B.cells != nullptr;
     double cv = AUGX_NINF;       // best of the last pair of the previous chunk (it may continue in this one)
     uint32_t ckp = 0xFFFFFFFFu, csrc = 0;
@@ -1275,7 +1278,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                                 const int ak = T.kind[T.anc[s2][ai]];
                                 if (ak == AUGX_K_IGENIC || ak == AUGX_K_GEOMETRIC || ak == AUGX_K_RGEOMETRIC) chainAnc = true;
                             }
-                            fLate[rr][TI] = lag < 2 * BLK && chainAnc;
+                            fLate[rr][TI] = (lag < 2 * BLK && chainAnc) ? 1 : lag >= 3 * BLK ? 2 : 0; // 0 near, 1 late, 2 far (reads blocks <= b-3 only)
                         }
                 }
                 nf++;
@@ -1306,7 +1309,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
             L.col0[t] = v;
         }
-        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.abortFlag = 0; }
+        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.abortFlag = 0; }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
@@ -1372,6 +1375,105 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
         }
     };
+    // one pass over the lag-1 chain states (reference src/igenicmodel.cc:247-255, src/intronmodel.cc:757-786): igenic on the
+    // block starting at jbIg, the geometric intron states on the block starting at jbGeo (-1: not in this pass).
+    // Lane (slot, dj): tree arg-max over the ancestors before / after the state itself (ascending order, strict '>'),
+    // then the 8-step recurrence along the block, one lane per base.
+    auto chainPass = [&](int w, int buf, int jbIg, int jbGeo) {
+        TV(double, res);
+        TV(double, prevRes);
+        FOR_WLANES(t, w) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
+        TV(double, bB); TV(double, bA); TV(double, teS); TV(double, psS);
+        TV(int, aB); TV(int, aA); TV(int, rai); TV(int, jj);
+        FOR_WLANES(t, w) {
+            const int l = t & 63, dj = l & 7;
+            const int jbL = TX(cIsIg) ? jbIg : jbGeo;
+            const int j = jbL >= 0 ? jbL + dj : -1;
+            TX(jj) = j;
+            TX(bB) = AUGX_NINF; TX(bA) = AUGX_NINF; TX(aB) = -1; TX(aA) = -1; TX(teS) = AUGX_NINF; TX(psS) = AUGX_NINF; TX(rai) = -1;
+            {
+                const bool valid = TX(cS) >= 0 && j >= 1 && j < n;
+                const double emiL = L.sig[buf][j & 63][TX(cSig)];
+                double pv[5], v[5], te[5];
+#pragma unroll
+                for (int ai = 0; ai < 5; ai++) pv[ai] = L.ring[(j - 1) & 63][cAnc[ai][TI]];
+                const double emi = valid ? emiL : AUGX_NINF;
+                const int self = TX(cSelf);
+#pragma unroll
+                for (int ai = 0; ai < 5; ai++) { te[ai] = cTr[ai][TI] + emi; v[ai] = pv[ai] + te[ai]; } // cTr = -inf beyond the last ancestor
+                TX(teS) = self == 0 ? te[0] : self == 1 ? te[1] : self == 2 ? te[2] : self == 3 ? te[3] : self == 4 ? te[4] : AUGX_NINF;
+                TX(psS) = self == 0 ? pv[0] : self == 1 ? pv[1] : self == 2 ? pv[2] : self == 3 ? pv[3] : self == 4 ? pv[4] : AUGX_NINF;
+                double vb[5], va[5];
+#pragma unroll
+                for (int ai = 0; ai < 5; ai++) { vb[ai] = ai < self ? v[ai] : AUGX_NINF; va[ai] = ai > self ? v[ai] : AUGX_NINF; }
+                {
+                    const bool t01 = vb[1] > vb[0], t23 = vb[3] > vb[2];
+                    const double m01 = t01 ? vb[1] : vb[0], m23 = t23 ? vb[3] : vb[2];
+                    const int i01 = t01 ? 1 : 0, i23 = t23 ? 3 : 2;
+                    const bool tq = m23 > m01;
+                    const double mq = tq ? m23 : m01;
+                    const int iq = tq ? i23 : i01;
+                    const bool t4 = vb[4] > mq;
+                    TX(bB) = t4 ? vb[4] : mq;
+                    TX(aB) = TX(bB) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
+                }
+                {
+                    const bool t01 = va[1] > va[0], t23 = va[3] > va[2];
+                    const double m01 = t01 ? va[1] : va[0], m23 = t23 ? va[3] : va[2];
+                    const int i01 = t01 ? 1 : 0, i23 = t23 ? 3 : 2;
+                    const bool tq = m23 > m01;
+                    const double mq = tq ? m23 : m01;
+                    const int iq = tq ? i23 : i01;
+                    const bool t4 = va[4] > mq;
+                    TX(bA) = t4 ? va[4] : mq;
+                    TX(aA) = TX(bA) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
+                }
+            }
+        }
+        // the value recurrence is one addition and one max per base (max(bB, self, bA) is what the three strict
+        // comparisons leave); which ancestor won is decided afterwards, for all bases at once
+        TV(double, mBA);
+        FOR_WLANES(t, w) { TX(mBA) = TX(bB) > TX(bA) ? TX(bB) : TX(bA); }
+#pragma unroll
+        for (int d = 0; d < BLK; d++) {
+#ifdef AUGX_EMU
+            FOR_WLANES(t, w) { TX(prevRes) = (t & 63) > 0 ? res[t - 1] : AUGX_NINF; }
+#else
+            prevRes[0] = dppMovD<0x111, 0xf>(res[0], res[0]); // row_shr:1 (the 8 bases of a chain state share a row)
+#endif
+            FOR_WLANES(t, w) {
+                const int l = t & 63, dj = l & 7, j = TX(jj);
+                if (dj == d) {
+                    const double p0 = (d == 0 || j - 1 < 1) ? TX(psS) : TX(prevRes);
+                    const double vs = p0 + TX(teS);
+                    TX(psS) = p0;
+                    TX(res) = vs > TX(mBA) ? vs : TX(mBA);
+                }
+            }
+        }
+        FOR_WLANES(t, w) {
+            const double vs = TX(psS) + TX(teS);
+            double best = TX(bB);
+            int bai = TX(aB);
+            if (vs > best) { best = vs; bai = TX(cSelf); }
+            if (TX(bA) > best) { best = TX(bA); bai = TX(aA); }
+            TX(rai) = bai;
+        }
+        FOR_WLANES(t, w) {
+            const int j = TX(jj);
+            if (TX(cS) >= 0 && j >= 1 && j < n) {
+                const int s2 = TX(cS);
+                L.ring[j & 63][s2] = TX(res);
+                L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
+                if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = TX(res);
+                if (TX(cIsIg)) { gp(B.vig)[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
+            }
+        }
+        WAVE_SYNC();
+    };
+    // candidates read igenic cells at least igSlack bases back; with two blocks of slack igenic may lag one block
+    const int igSlackI = T.W + T.min_exon_len - T.Ds, igSlack = igSlackI < T.W ? igSlackI : T.W;
+    const bool safeIg = igSlack < 2 * BLK;
 #ifndef AUGX_EMU
     for (int i = 0; i < 8; i++) X.pacc[i] = 0;
     X.plast = clock64();
@@ -1387,32 +1489,30 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
             }
         }
-        // ---- the trellis wavefronts walk the blocks of the tile, each at its own pace (progress flags in LDS):
-        //   workers 0..2: (a) one third of the fixed-lag states of block b and of the cell resets, after all candidates
-        //                     of block b-1 (exon cells at lag >= 9);
-        //                 (b) one third of the candidates of block b, after (a) of all workers (list values) and the
-        //                     late fixed-lag states of block b (chain wavefront)
-        //   chain wavefront: late fixed-lag states of block b; then, after (b) of all workers, chain states + RTERMINAL
+        // ---- the trellis wavefronts walk the blocks of the tile, each at its own pace (progress flags in LDS).  Block b:
+        //   far wavefront    (0) fixed-lag states that read blocks <= b-3 only (lag >= 24, equalD) and the cell resets of b;
+        //                        runs up to two blocks ahead of the workers
+        //   chain wavefront  (1) late fixed-lag states of b          after the candidates of b-1
+        //   worker 0         (2) near fixed-lag states of b (longdss: exon cells at lag 9), after the candidates of b-1
+        //   chain wavefront  (3) one pass over the chain states: geometric introns of b (after (0): they are fed by equalD
+        //                        only) and igenic of b-1 (fed by the exon cells of b-1) -- igenic lags one block because
+        //                        no candidate reads an igenic cell less than igSlack >= 2 blocks back (else: safe mode)
+        //   workers 0..2     (4) a third each of the candidates of b, after (0), (1) and (2); the last worker also does the
+        //                        RTERMINAL candidates of b-2 (they may start at an igenic cell of their own block)
+        // so that the cycle is candidates(b) -> fixed-lag(b+1) -> candidates(b+1), with the chain states off it.
         PROF_MARK(X, 0);
+        int nb = 0;
         for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
+            nb = blk + 1;
             const int jb = j0 + blk * BLK, gbk = tile * BLK + blk;
-            const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]), it1 = (int)(L.blkOff[buf][blk + 1][1] - L.blkOff[buf][0][1]),
+            const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]),
                       itA = it0 + (int)L.blkSplit[buf][blk][0], itB = it0 + (int)L.blkSplit[buf][blk][1], itS = it0 + (int)L.blkSplit[buf][blk][2];
             FOR_WAVES(w) {
-                if (w == W_C) { // the late fixed-lag states need the chain cells of block b-1 (this wavefront's previous iteration)
-                    PROF_STAMP(X, gbk, 6);
-                    fixedStep(w, buf, jb, 1, -1);
-                    setFlag(&L.flagL, gbk + 1);
-                    PROF_STAMP(X, gbk, 7);
-                }
-            }
-            FOR_WAVES(w) {
-                if (w < NWORK) {
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
+                if (w == W_X) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk - 2);
                     PROF_MARK(X, 1);
-                    if (w == 0) PROF_STAMP(X, gbk, 0);
-                    // step 1: fixed-lag states (lag > BLK) but the late ones; reset of the variable-length cells
-                    fixedStep(w, buf, jb, 0, w);
+                    fixedStep(w, buf, jb, 2, -1);
+                    PROF_MARK(X, 4);
                     FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
                         (void)l;
@@ -1420,148 +1520,93 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #pragma unroll
                         for (int r = 0; r < VR; r++) {
                             const int s2 = vS[r][TI];
-                            if (s2 < 0 || j < 1 || j >= n || r % NWORK != w) continue;
+                            if (s2 < 0 || j < 1 || j >= n) continue;
                             L.ring[j & 63][s2] = AUGX_NINF;
                             if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
                         }
                     }
-                    setFlag(&L.flagF[w], gbk + 1);
-                    if (w == 0) PROF_STAMP(X, gbk, 1);
+                    setFlag(&L.flagN, gbk + 1);
                     PROF_MARK(X, 2);
                 }
             }
             FOR_WAVES(w) {
-                if (w < NWORK) {
-                    // step 2: variable-length states but RTERMINAL
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagF[i], gbk + 1);
+                if (w == W_C) { // (1)
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
+                    PROF_MARK(X, 1);
+                    PROF_STAMP(X, gbk, 6);
+                    fixedStep(w, buf, jb, 1, -1);
+                    setFlag(&L.flagL, gbk + 1);
+                    PROF_STAMP(X, gbk, 7);
+                    PROF_MARK(X, 2);
+                }
+            }
+            FOR_WAVES(w) {
+                if (w == 0) { // (2) near fixed-lag states (longdss: exon cells at lag 9)
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
+                    PROF_MARK(X, 1);
+                    PROF_STAMP(X, gbk, 0);
+                    fixedStep(w, buf, jb, 0, -1);
+                    setFlag(&L.flagF[0], gbk + 1);
+                    PROF_STAMP(X, gbk, 1);
+                    PROF_MARK(X, 2);
+                }
+            }
+            FOR_WAVES(w) {
+                if (w == W_C) { // (3)
+                    waitFlag(L, &L.flagN, gbk + 1);
+                    PROF_MARK(X, 1);
+                    PROF_STAMP(X, gbk, 8);
+                    chainPass(w, buf, blk > 0 ? jb - BLK : -1, jb);
+                    setFlag(&L.flagC, gbk); // igenic is complete up to block b-1
+                    PROF_STAMP(X, gbk, 9);
+                    PROF_MARK(X, 3);
+                }
+            }
+            FOR_WAVES(w) {
+                if (w < NWORK) { // (4)
+                    waitFlag(L, &L.flagF[0], gbk + 1);
+                    waitFlag(L, &L.flagN, gbk + 1);
                     waitFlag(L, &L.flagL, gbk + 1);
+                    if (safeIg) waitFlag(L, &L.flagC, gbk);
                     PROF_MARK(X, 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 2 : 4);
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
                     const int lo2 = w == 0 ? it0 : w == 1 ? itA : itB, hi2 = w == 0 ? itA : w == 1 ? itB : itS;
                     if (hi2 > lo2) trellisItems(X, w, buf, blk, jb, lo2, hi2, vigLo);
-                    if (w == NWORK - 1 && blk > 0) { // RTERMINAL candidates of the previous block (nothing reads them before lag >= 16)
-                        const int rt0 = (int)(L.blkOff[buf][blk - 1][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][blk - 1][2];
-                        if (it0 > rt0) trellisItems(X, w, buf, blk - 1, jb - BLK, rt0, it0, vigLo);
+                    if (w == NWORK - 1 && blk >= 2) { // RTERMINAL candidates of block b-2 (nothing reads them before lag > 2 blocks)
+                        const int rt0 = (int)(L.blkOff[buf][blk - 2][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][blk - 2][2],
+                                  rt1 = (int)(L.blkOff[buf][blk - 1][1] - L.blkOff[buf][0][1]);
+                        if (rt1 > rt0) trellisItems(X, w, buf, blk - 2, jb - 2 * BLK, rt0, rt1, vigLo);
                     }
                     setFlag(&L.flagI[w], gbk + 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 3 : 5);
                     PROF_MARK(X, 2);
                 }
             }
-            FOR_WAVES(w) {
-                if (w == W_C) {
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk + 1);
-                    PROF_MARK(X, 1);
-                    PROF_STAMP(X, gbk, 8);
-                    // step 3: the lag-1 chain states.  Lane (slot, dj): best ancestor before / after the state itself in
-                    // ascending ancestor order with strict '>' (reference src/igenicmodel.cc:247-255,
-                    // src/intronmodel.cc:757-786); then the 8-step recurrence along the block, one lane per base.
-                    TV(double, res);
-                    TV(double, prevRes);
-                    FOR_WLANES(t, w) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
-                    TV(double, bB); TV(double, bA); TV(double, teS); TV(double, psS);
-                    TV(int, aB); TV(int, aA); TV(int, rai);
-                    FOR_WLANES(t, w) {
-                        const int l = t & 63, dj = l & 7, j = jb + dj;
-                        TX(bB) = AUGX_NINF; TX(bA) = AUGX_NINF; TX(aB) = -1; TX(aA) = -1; TX(teS) = AUGX_NINF; TX(psS) = AUGX_NINF; TX(rai) = -1;
-                        {
-                            const bool valid = TX(cS) >= 0 && j >= 1 && j < n;
-                            const double emiL = L.sig[buf][j & 63][TX(cSig)];
-                            double pv[5], v[5], te[5];
-#pragma unroll
-                            for (int ai = 0; ai < 5; ai++) pv[ai] = L.ring[(j - 1) & 63][cAnc[ai][TI]];
-                            const double emi = valid ? emiL : AUGX_NINF;
-                            const int self = TX(cSelf);
-#pragma unroll
-                            for (int ai = 0; ai < 5; ai++) { te[ai] = cTr[ai][TI] + emi; v[ai] = pv[ai] + te[ai]; } // cTr = -inf beyond the last ancestor
-                            TX(teS) = self == 0 ? te[0] : self == 1 ? te[1] : self == 2 ? te[2] : self == 3 ? te[3] : self == 4 ? te[4] : AUGX_NINF;
-                            TX(psS) = self == 0 ? pv[0] : self == 1 ? pv[1] : self == 2 ? pv[2] : self == 3 ? pv[3] : self == 4 ? pv[4] : AUGX_NINF;
-                            // first-wins arg-max (strict '>' in ascending order) of the ancestors before / after the state itself, as trees
-                            double vb[5], va[5];
-#pragma unroll
-                            for (int ai = 0; ai < 5; ai++) { vb[ai] = ai < self ? v[ai] : AUGX_NINF; va[ai] = ai > self ? v[ai] : AUGX_NINF; }
-                            {
-                                const bool t01 = vb[1] > vb[0], t23 = vb[3] > vb[2];
-                                const double m01 = t01 ? vb[1] : vb[0], m23 = t23 ? vb[3] : vb[2];
-                                const int i01 = t01 ? 1 : 0, i23 = t23 ? 3 : 2;
-                                const bool tq = m23 > m01;
-                                const double mq = tq ? m23 : m01;
-                                const int iq = tq ? i23 : i01;
-                                const bool t4 = vb[4] > mq;
-                                TX(bB) = t4 ? vb[4] : mq;
-                                TX(aB) = TX(bB) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
-                            }
-                            {
-                                const bool t01 = va[1] > va[0], t23 = va[3] > va[2];
-                                const double m01 = t01 ? va[1] : va[0], m23 = t23 ? va[3] : va[2];
-                                const int i01 = t01 ? 1 : 0, i23 = t23 ? 3 : 2;
-                                const bool tq = m23 > m01;
-                                const double mq = tq ? m23 : m01;
-                                const int iq = tq ? i23 : i01;
-                                const bool t4 = va[4] > mq;
-                                TX(bA) = t4 ? va[4] : mq;
-                                TX(aA) = TX(bA) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
-                            }
-                        }
-                    }
-                    PROF_MARK(X, 4);
-                    TV(double, mBA);
-                    FOR_WLANES(t, w) { TX(mBA) = TX(bB) > TX(bA) ? TX(bB) : TX(bA); }
-#pragma unroll
-                    for (int d = 0; d < BLK; d++) {
-#ifdef AUGX_EMU
-                        FOR_WLANES(t, w) { TX(prevRes) = (t & 63) > 0 ? res[t - 1] : AUGX_NINF; }
-#else
-                        prevRes[0] = dppMovD<0x111, 0xf>(res[0], res[0]); // row_shr:1 (the 8 bases of a chain state share a row)
-#endif
-                        FOR_WLANES(t, w) {
-                            const int l = t & 63, dj = l & 7, j = jb + dj;
-                            if (dj == d) {
-                                const double p0 = (d == 0 || j - 1 < 1) ? TX(psS) : TX(prevRes);
-                                const double vs = p0 + TX(teS);
-                                TX(psS) = p0;
-                                TX(res) = vs > TX(mBA) ? vs : TX(mBA);
-                            }
-                        }
-                    }
-                    PROF_MARK(X, 5);
-                    FOR_WLANES(t, w) {
-                        const double vs = TX(psS) + TX(teS);
-                        double best = TX(bB);
-                        int bai = TX(aB);
-                        if (vs > best) { best = vs; bai = TX(cSelf); }
-                        if (TX(bA) > best) { best = TX(bA); bai = TX(aA); }
-                        TX(rai) = bai;
-                    }
-                    FOR_WLANES(t, w) {
-                        const int l = t & 63, dj = l & 7, j = jb + dj;
-                        if (TX(cS) >= 0 && j >= 1 && j < n) {
-                            const int s2 = TX(cS);
-                            L.ring[j & 63][s2] = TX(res);
-                            L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
-                            if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = TX(res);
-                            if (TX(cIsIg)) { gp(B.vig)[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
-                        }
-                    }
-                    WAVE_SYNC();
-                    PROF_MARK(X, 3);
-                    // step 4: RTERMINAL exons (their single candidate may start at an igenic cell of this very block)
-                    if (it1 > itS && (blk == BLK - 1 || jb + BLK >= n)) { // last block of the tile (the others: see the workers)
-                        const int jl = jb + BLK - 1 < n - 1 ? jb + BLK - 1 : n - 1;
-                        trellisItems(X, w, buf, blk, jb, itS, it1, jl - VIG_WIN > -1 ? jl - VIG_WIN : -1);
-                    }
-                    setFlag(&L.flagC, gbk + 1);
-                    PROF_STAMP(X, gbk, 9);
-                    PROF_MARK(X, 2);
+        }
+        // ---- end of the tile: igenic of the last block, then the RTERMINAL candidates of the last two blocks
+        FOR_WAVES(w) {
+            if (w == W_C && nb > 0) {
+                const int gLast = tile * BLK + nb - 1, jbLast = j0 + (nb - 1) * BLK;
+                for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gLast + 1);
+                PROF_MARK(X, 1);
+                chainPass(w, buf, jbLast, -1);
+                setFlag(&L.flagC, gLast + 1);
+                const int jl = jbLast + BLK - 1 < n - 1 ? jbLast + BLK - 1 : n - 1;
+                const int vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
+                for (int bq = nb >= 2 ? nb - 2 : 0; bq < nb; bq++) {
+                    const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
+                              rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
+                    if (rt1 > rt0) trellisItems(X, w, buf, bq, j0 + bq * BLK, rt0, rt1, vigLo);
                 }
+                PROF_MARK(X, 3);
             }
         }
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
     }
 #ifndef AUGX_EMU
-    if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 4 * WAVE)
-        for (int i = 0; i < 8; i++) B.prof[((int64_t)p * 4 + (threadIdx.x >> 6)) * 8 + i] = X.pacc[i];
+    if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)
+        for (int i = 0; i < 8; i++) B.prof[((int64_t)p * 5 + (threadIdx.x >> 6)) * 8 + i] = X.pacc[i];
 #endif
     // ---- back pointers of the last tile
     FOR_THREADS(t) { flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT); }

@@ -87,6 +87,28 @@ inline void checkModelSupported(const augx_tables &t) {
                           : (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? t.Ds + 2 + t.De : 0;
                 if (lag <= 2 * BLK) throw std::runtime_error("augx: unexpected successor of the reverse terminal exon state");
             }
+    // scheduling assumptions of the trellis kernel (device/kernels.h, trellisPiece)
+    {
+        auto isChain = [&](int k) { return k == AUGX_K_IGENIC || k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC; };
+        auto isFixed = [&](int k) { return k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS || k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS || k == AUGX_K_EQUALD || k == AUGX_K_REQUALD; };
+        for (int s = 0; s < t.S; s++) {
+            if (!t.reachable[s]) continue;
+            const int kind = t.state_kind[s];
+            for (int a = 0; a < t.n_anc[s]; a++) {
+                const int ak = t.state_kind[t.anc[s][a]];
+                // igenic lags one block behind: no fixed-lag state may read it; the geometric states run ahead of the
+                // candidates of their block: they may only be fed by fixed-lag states
+                if (isFixed(kind) && ak == AUGX_K_IGENIC) throw std::runtime_error("augx: fixed-length intron state fed by the intergenic state");
+                if ((kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC) && t.anc[s][a] != s && !isFixed(ak))
+                    throw std::runtime_error("augx: geometric intron state fed by a state that is not a fixed-length intron state");
+                if (kind == AUGX_K_IGENIC && isChain(ak) && t.anc[s][a] != s) throw std::runtime_error("augx: intergenic state fed by an intron state");
+            }
+        }
+        // single / initial exons reach back to an igenic cell at least this far (reference src/exonmodel.cc:1042-1054)
+        int slack = t.W + t.min_exon_len - t.Ds;
+        if (t.W < slack) slack = t.W;
+        if (slack < BLK) throw std::runtime_error("augx: trans_init_window too short for the block size of the trellis kernel (species not supported yet)");
+    }
     if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
 }
 
