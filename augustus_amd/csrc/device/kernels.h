@@ -943,6 +943,7 @@ struct TrellisLds {
     double sig[2][WAVE][NSIG];      // signal records of the current / next tile
     int32_t site[2][WAVE][NSITE];
     double eqPrev[2][WAVE][6];      // predecessor cells of the equalD states (lag dStateLen)
+    double longW[2][WAVE][6];       // cells of the states equalD reads back at lag dStateLen (flushed to HBM tile by tile)
     uint64_t blkOff[2][BLK + 1][2]; // pair / item offsets of the blocks of the tile
     uint32_t blkSplit[2][BLK][3];   // candidates: end of the first / second third, end of all states but RTERMINAL
     int32_t listTop[2][BLK][4];     // newest entry of each candidate list at the end of each block
@@ -1057,7 +1058,7 @@ struct TrellisCtx {
 };
 
 // ---- staging of tile `tile` into LDS buffer `buf` by thread tid of nth (next tile: the loader wavefronts)
-AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth) {
+AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth, bool flushOld) {
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int n = X.n, j0 = tile * WAVE, dL = X.T.dStateLen;
@@ -1067,8 +1068,16 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         L.sig[buf][l][i % NSIG] = (j0 + l < n) ? gp(B.sig)[g0 * NSIG + i] : AUGX_NINF;
     }
     for (int i = tid; i < WAVE * NSITE; i += nth) {
-        const int l = i / NSITE;
-        L.site[buf][l][i % NSITE] = (j0 + l < n) ? gp(B.site)[g0 * NSITE + i] : -1;
+        const int l = i / NSITE, sel = i % NSITE;
+        if (flushOld) { // the buffer still holds the site indices of tile - 2: retire the list values of those sites to HBM
+            const int si = L.site[buf][l][sel];
+            if (si >= 0) {
+                double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+#pragma unroll
+                for (int f = 0; f < 3; f++) gp(a)[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
+            }
+        }
+        L.site[buf][l][sel] = (j0 + l < n) ? gp(B.site)[g0 * NSITE + i] : -1;
     }
     for (int i = tid; i < WAVE * 6; i += nth) {
         const int l = i / 6, q = j0 + l;
@@ -1107,6 +1116,7 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     }
 }
 // write the back pointers of tile `tile` (LDS buffer buf) to HBM and reset the buffer
+// (the trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles)
 AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int nth) {
     const int j0 = tile * WAVE;
     for (int i = tid; i < WAVE * SP; i += nth) {
@@ -1114,6 +1124,10 @@ AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int
         if (j0 + r < X.n) gp(X.B.bp)[(X.o + 1 + j0) * SP + i] = X.L.bp[buf][r][i % SP];
         X.L.bp[buf][r][i % SP] = BP_NONE;
     }
+    for (int i = tid; i < WAVE; i += nth) // igenic column
+        if (j0 + i >= 1 && j0 + i < X.n) gp(X.B.vig)[X.o + 1 + j0 + i] = X.L.vigw[(j0 + i) & (VIG_WIN - 1)];
+    for (int i = tid; i < WAVE * 6; i += nth) // cells read back at lag dStateLen
+        if (j0 + i / 6 >= 1 && j0 + i / 6 < X.n) gp(X.B.longV)[(X.o + 1 + j0) * 6 + i] = X.L.longW[buf][i / 6][i % 6];
 }
 
 // ---- candidates [lo, hi) (indices relative to the first candidate of the tile) of block blk of the trellis
@@ -1322,14 +1336,15 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             const double v = L.col0[t];
             L.ring[0][t] = v;
             const int lr = longRow(T, t);
-            if (lr >= 0) B.longV[(o + 1) * 6 + lr] = v;
+            if (lr >= 0) { B.longV[(o + 1) * 6 + lr] = v; L.longW[0][0][lr] = v; }
             if (B.cells) B.cells[(o + 1) * S + t] = v;
             if (T.kind[t] == AUGX_K_IGENIC) { B.vig[o + 1] = v; L.vigw[0] = v; }
         }
-        loadTileThread(X, 0, 0, t, NT);
+        loadTileThread(X, 0, 0, t, NT, false);
     }
     const int nTiles = (n + WAVE - 1) / WAVE;
     const bool wantCells = B.cells != nullptr;
+    const bool directLong = dL < 4 * WAVE; // short dStateLen: equalD would read a cell before its tile has been flushed
     BLOCK_GLOBAL_SYNC();
     // fixed-lag states of block jb (all loads first, then the two-way max); late selects the states described at fLate
     auto fixedStep = [&](int w, int buf, int jb, int late, int rsel) {
@@ -1364,11 +1379,12 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (s2 >= 0 && j >= 1 && j < n && fLate[r][TI] == late) {
                     L.ring[j & 63][s2] = best;
                     L.bp[buf][j & 63][s2] = bp;
-                    if (fLrow[r][TI] >= 0) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best;
+                    if (fLrow[r][TI] >= 0) {
+                        L.longW[buf][j & 63][fLrow[r][TI]] = best;
+                        if (directLong) gp(B.longV)[(o + 1 + j) * 6 + fLrow[r][TI]] = best; // short dStateLen: the tile-wise flush would come too late
+                    }
                     if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = best;
                     if (fList[r][TI] >= 0 && si[r] >= 0) {
-                        double *lval = fList[r][TI] == 0 ? B.laVal : fList[r][TI] == 1 ? B.lrVal : fList[r][TI] == 2 ? B.ldVal : B.rdVal;
-                        gp(lval)[(X.lo + si[r]) * 3 + fFrame[r][TI]] = best;
                         L.lcVal[fList[r][TI]][si[r] & (LIST_WIN - 1)][fFrame[r][TI]] = best;
                     }
                 }
@@ -1466,7 +1482,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 L.ring[j & 63][s2] = TX(res);
                 L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
                 if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = TX(res);
-                if (TX(cIsIg)) { gp(B.vig)[o + 1 + j] = TX(res); L.vigw[j & (VIG_WIN - 1)] = TX(res); }
+                if (TX(cIsIg)) L.vigw[j & (VIG_WIN - 1)] = TX(res); // (HBM copy: flushed with the tile)
             }
         }
         WAVE_SYNC();
@@ -1484,7 +1500,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (w >= W_LOAD) {
                 // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
                 FOR_WLANES(t, w) {
-                    if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
+                    if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= 1);
                     if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
             }
