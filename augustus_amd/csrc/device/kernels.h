@@ -1014,6 +1014,7 @@ __device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return 
 #ifdef AUGX_EMU
 inline void waitFlag(TrellisLds &L, const int *f, int target) { if (*f < target) { fprintf(stderr, "emu: trellis wavefront dependency violated\n"); abort(); } (void)L; }
 inline void setFlag(int *f, int v) { *f = v; }
+inline int readFlag(const int *f) { return *f; }
 #else
 __device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
     int spins = 0;
@@ -1022,6 +1023,11 @@ __device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
         __builtin_amdgcn_s_sleep(1);
     }
     __asm__ volatile("" ::: "memory");
+}
+__device__ inline int readFlag(const int *f) {
+    const int v = *(const volatile int *)f;
+    __asm__ volatile("" ::: "memory");
+    return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ inline void setFlag(int *f, int v) {
     __builtin_amdgcn_s_waitcnt(0xc07f); // the LDS writes of this wavefront have been performed
@@ -1376,7 +1382,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const bool take1 = c1 && v1 > best;
                 best = take1 ? v1 : best;
                 const uint16_t bp = take1 ? bpFixed(1) : c0 ? bpFixed(0) : BP_NONE;
-                if (s2 >= 0 && j >= 1 && j < n && fLate[r][TI] == late) {
+                if (s2 >= 0 && j >= 1 && j < n && ((late >> fLate[r][TI]) & 1)) {
                     L.ring[j & 63][s2] = best;
                     L.bp[buf][j & 63][s2] = bp;
                     if (fLrow[r][TI] >= 0) {
@@ -1490,6 +1496,20 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     // candidates read igenic cells at least igSlack bases back; with two blocks of slack igenic may lag one block
     const int igSlackI = T.W + T.min_exon_len - T.Ds, igSlack = igSlackI < T.W ? igSlackI : T.W;
     const bool safeIg = igSlack < 2 * BLK;
+    // RTERMINAL candidates (their single predecessor may be an igenic cell of their own block; nothing reads their cells
+    // before lag > 2 blocks): done by the far wavefront for every block whose igenic cells are complete
+    int rtNext = 0; // next block (global index) whose RTERMINAL candidates are due
+    auto rtCatchUp = [&](int w, int buf, int tile, int igDone, int jbNow) { // jbNow: no igenic cell at or beyond it exists yet
+        if (rtNext < tile * BLK) rtNext = tile * BLK;
+        for (; rtNext < igDone; rtNext++) {
+            const int bq = rtNext - tile * BLK, jq = rtNext * BLK;
+            if (bq >= BLK || jq >= n) break;
+            const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
+                      rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
+            const int vigLo = jbNow - 1 - VIG_WIN > -1 ? jbNow - 1 - VIG_WIN : -1;
+            if (rt1 > rt0) trellisItems(X, w, buf, bq, jq, rt0, rt1, vigLo);
+        }
+    };
 #ifndef AUGX_EMU
     for (int i = 0; i < 8; i++) X.pacc[i] = 0;
     X.plast = clock64();
@@ -1508,14 +1528,15 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // ---- the trellis wavefronts walk the blocks of the tile, each at its own pace (progress flags in LDS).  Block b:
         //   far wavefront    (0) fixed-lag states that read blocks <= b-3 only (lag >= 24, equalD) and the cell resets of b;
         //                        runs up to two blocks ahead of the workers
-        //   chain wavefront  (1) late fixed-lag states of b          after the candidates of b-1
-        //   worker 0         (2) near fixed-lag states of b (longdss: exon cells at lag 9), after the candidates of b-1
+        //   chain wavefront  (1) near and late fixed-lag states of b (longdss: exon cells at lag 9; rlongdss: also a chain
+        //                        state at lag 9), after the candidates of b-1
         //   chain wavefront  (3) one pass over the chain states: geometric introns of b (after (0): they are fed by equalD
         //                        only) and igenic of b-1 (fed by the exon cells of b-1) -- igenic lags one block because
         //                        no candidate reads an igenic cell less than igSlack >= 2 blocks back (else: safe mode)
-        //   workers 0..2     (4) a third each of the candidates of b, after (0), (1) and (2); the last worker also does the
-        //                        RTERMINAL candidates of b-2 (they may start at an igenic cell of their own block)
-        // so that the cycle is candidates(b) -> fixed-lag(b+1) -> candidates(b+1), with the chain states off it.
+        //   workers 0..2     (4) a third each of the candidates of b, after (0) and (1)
+        //   far wavefront        also does the RTERMINAL candidates (they may start at an igenic cell of their own block)
+        //                        of every block whose igenic cells are complete
+        // so that the cycle is candidates(b) -> near/late fixed-lag(b+1) -> candidates(b+1), with the chain states off it.
         PROF_MARK(X, 0);
         int nb = 0;
         for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
@@ -1527,7 +1548,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (w == W_X) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
                     for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk - 2);
                     PROF_MARK(X, 1);
-                    fixedStep(w, buf, jb, 2, -1);
+                    rtCatchUp(w, buf, tile, readFlag(&L.flagC), jb); // RTERMINAL candidates of the blocks whose igenic cells are complete (at least b-5)
+                    PROF_MARK(X, 3);
+                    fixedStep(w, buf, jb, 4, -1); // far states (class 2)
                     PROF_MARK(X, 4);
                     FOR_WLANES(t, w) {
                         const int l = t & 63, dj = l & 7, j = jb + dj;
@@ -1550,20 +1573,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 6);
-                    fixedStep(w, buf, jb, 1, -1);
+                    fixedStep(w, buf, jb, 3, -1); // near (class 0) and late (class 1) states
                     setFlag(&L.flagL, gbk + 1);
                     PROF_STAMP(X, gbk, 7);
-                    PROF_MARK(X, 2);
-                }
-            }
-            FOR_WAVES(w) {
-                if (w == 0) { // (2) near fixed-lag states (longdss: exon cells at lag 9)
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
-                    PROF_MARK(X, 1);
-                    PROF_STAMP(X, gbk, 0);
-                    fixedStep(w, buf, jb, 0, -1);
-                    setFlag(&L.flagF[0], gbk + 1);
-                    PROF_STAMP(X, gbk, 1);
                     PROF_MARK(X, 2);
                 }
             }
@@ -1580,7 +1592,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
             FOR_WAVES(w) {
                 if (w < NWORK) { // (4)
-                    waitFlag(L, &L.flagF[0], gbk + 1);
                     waitFlag(L, &L.flagN, gbk + 1);
                     waitFlag(L, &L.flagL, gbk + 1);
                     if (safeIg) waitFlag(L, &L.flagC, gbk);
@@ -1589,11 +1600,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
                     const int lo2 = w == 0 ? it0 : w == 1 ? itA : itB, hi2 = w == 0 ? itA : w == 1 ? itB : itS;
                     if (hi2 > lo2) trellisItems(X, w, buf, blk, jb, lo2, hi2, vigLo);
-                    if (w == NWORK - 1 && blk >= 2) { // RTERMINAL candidates of block b-2 (nothing reads them before lag > 2 blocks)
-                        const int rt0 = (int)(L.blkOff[buf][blk - 2][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][blk - 2][2],
-                                  rt1 = (int)(L.blkOff[buf][blk - 1][1] - L.blkOff[buf][0][1]);
-                        if (rt1 > rt0) trellisItems(X, w, buf, blk - 2, jb - 2 * BLK, rt0, rt1, vigLo);
-                    }
                     setFlag(&L.flagI[w], gbk + 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 3 : 5);
                     PROF_MARK(X, 2);
@@ -1608,14 +1614,13 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 PROF_MARK(X, 1);
                 chainPass(w, buf, jbLast, -1);
                 setFlag(&L.flagC, gLast + 1);
-                const int jl = jbLast + BLK - 1 < n - 1 ? jbLast + BLK - 1 : n - 1;
-                const int vigLo = jl - VIG_WIN > -1 ? jl - VIG_WIN : -1;
-                for (int bq = nb >= 2 ? nb - 2 : 0; bq < nb; bq++) {
-                    const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
-                              rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
-                    if (rt1 > rt0) trellisItems(X, w, buf, bq, j0 + bq * BLK, rt0, rt1, vigLo);
-                }
                 PROF_MARK(X, 3);
+            }
+        }
+        FOR_WAVES(w) {
+            if (w == W_X && nb > 0) { // the remaining RTERMINAL candidates of the tile (their back pointers live in this tile's buffer)
+                waitFlag(L, &L.flagC, tile * BLK + nb);
+                rtCatchUp(w, buf, tile, tile * BLK + nb, j0 + nb * BLK);
             }
         }
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
