@@ -36,3 +36,18 @@ def test_emulated_interior_piece_kinds():
         rc, lnv2, path2, V2, _ = twin_decode(m.tables_ptr, seq, S, cells=True, init_kind=ik, term_kind=tk)
         assert st == 0 and lnv == lnv2 and np.array_equal(V, V2)
         assert path == [(b, e, s) for b, e, s, t in path2]
+
+
+@pytest.mark.parametrize("species", ["human", "fly"])
+def test_emulated_ragged_lengths(species):
+    """Edge lengths around the tile (64) and block (8) sizes, a one-base piece, and a ragged batch."""
+    m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
+    S = m.n_states
+    seqs = [random_dna(n, 100 + n) for n in (1, 2, 7, 8, 9, 63, 64, 65, 127, 129, 600, 1031)]
+    res = emu_decode(m.tables_ptr, seqs, S, cells=True)
+    for seq, (st, lnv, path, V, cls) in zip(seqs, res):
+        rc, lnv2, path2, V2, _ = twin_decode(m.tables_ptr, seq, S, cells=True)
+        assert st == rc or (st == ax.AUGX_E_NOPATH and rc != 0), len(seq)
+        if rc == 0:
+            assert lnv == lnv2 and np.array_equal(V, V2), len(seq)
+            assert path == [(b, e, s) for b, e, s, t in path2], len(seq)

@@ -109,3 +109,18 @@ def test_cli_piece_cutting_matches_reference(tmp_path):
     ours = subprocess.run([exe] + args, capture_output=True, text=True, env=env)
     assert ref.returncode == 0 and ours.returncode == 0, ours.stderr
     assert gff_body(ours.stdout) == gff_body(ref.stdout)
+
+
+@pytest.mark.parametrize("species", ["human", "fly"])
+def test_gpu_ragged_lengths(species):
+    """Edge lengths around the tile (64) and block (8) sizes, a one-base piece, ragged batch: bit-identical to the oracle."""
+    m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
+    d = ax.Decoder(m)
+    seqs = [random_dna(n, 100 + n) for n in (1, 2, 7, 8, 9, 63, 64, 65, 127, 129, 600, 1031, 4099)]
+    res = d.decode(seqs)
+    for seq, r in zip(seqs, res):
+        rc, lnv, path, _, _ = twin_decode(m.tables_ptr, seq, m.n_states)
+        if rc == 0:
+            assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, len(seq)
+        else:
+            assert r.status != 0, len(seq)
