@@ -60,6 +60,8 @@ def lib():
         L.augx_model_destroy.argtypes = [ctypes.c_void_p]
         L.augx_decoder_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.augx_decoder_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_decoder_batch_capacity.restype = ctypes.c_int64
+        L.augx_decoder_batch_capacity.argtypes = [ctypes.c_void_p]
         L.augx_batch_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.augx_batch_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.augx_batch_sync.argtypes = [ctypes.c_void_p]

@@ -268,6 +268,16 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     return AUGX_OK;
 }
 
+int64_t augx_decoder_batch_capacity(augx_decoder *d) {
+    if (!d) return 0;
+    size_t freeB = 0, totalB = 0;
+    if (hipSetDevice(d->device) != hipSuccess || hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 16L * 1000 * 1000;
+    int64_t cap = (int64_t)(freeB / 1700); // ~1.1 KB of per-base arrays + ~0.3 KB of candidates, with head room
+    if (cap > 128L * 1000 * 1000) cap = 128L * 1000 * 1000;
+    if (cap < 1000 * 1000) cap = 1000 * 1000;
+    return cap;
+}
+
 void augx_decoder_destroy(augx_decoder *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);

@@ -279,7 +279,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     // ---- phase 2: decode all pieces in batches bounded by a slot budget
     std::vector<Decoded> decoded(allPieces.size());
     {
-        long budget = 48L * 1000 * 1000; // bases per batch (~0.6 KB of HBM per base)
+        long budget = (long)augx_decoder_batch_capacity(S.dec); // bases per batch: what the free HBM holds, at most 128 Mbp
         if (const char *e = getenv("AUGX_BATCH_BASES")) budget = atol(e);
         size_t i = 0;
         while (i < allPieces.size()) {

@@ -153,6 +153,8 @@ void augx_model_destroy(augx_model *m);
 /* ---- decoder (device) ---- */
 int augx_decoder_create(const augx_model *m, int device, augx_decoder **out);
 void augx_decoder_destroy(augx_decoder *d);
+/* bases one batch should hold at most: what fits the free device memory (about 1.5 KB per base), capped at 128 Mbp */
+int64_t augx_decoder_batch_capacity(augx_decoder *d);
 
 /* replaces viterbiAndForward + getViterbiPath for a batch of independent pieces */
 int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
