@@ -489,6 +489,8 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
             fprintf(stderr, "block 1000 of piece 0 (cycles): F %lld..%lld  I1 %lld..%lld  I2 %lld..%lld  late %lld..%lld  chain %lld..%lld\n",
                     0LL, (long long)(ts[1] - ts[0]), (long long)(ts[2] - ts[0]), (long long)(ts[3] - ts[0]), (long long)(ts[4] - ts[0]),
                     (long long)(ts[5] - ts[0]), (long long)(ts[6] - ts[0]), (long long)(ts[7] - ts[0]), (long long)(ts[8] - ts[0]), (long long)(ts[9] - ts[0]));
+            fprintf(stderr, "end of tile 124 (cycles after worker 0 left its last block): igenic tail %lld..%lld  worker-0 tail done %lld  far tail done %lld  barrier passed %lld  (block 1000: late starts %lld)\n",
+                    (long long)(ts[11] - ts[10]), (long long)(ts[12] - ts[10]), (long long)(ts[13] - ts[10]), (long long)(ts[14] - ts[10]), (long long)(ts[15] - ts[10]), (long long)(ts[6] - ts[10]));
         }
     }
     return AUGX_OK;

@@ -952,7 +952,7 @@ struct TrellisLds {
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
-    int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN; // blocks completed by the trellis wavefronts (see trellisPiece)
+    int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     int abortFlag;
 };
 
@@ -1014,7 +1014,9 @@ __device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return 
 #ifdef AUGX_EMU
 inline void waitFlag(TrellisLds &L, const int *f, int target) { if (*f < target) { fprintf(stderr, "emu: trellis wavefront dependency violated\n"); abort(); } (void)L; }
 inline void setFlag(int *f, int v) { *f = v; }
+inline void drainStores() {}
 inline int readFlag(const int *f) { return *f; }
+inline void addFlag(int *f) { *f += 1; }
 #else
 __device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
     int spins = 0;
@@ -1029,6 +1031,12 @@ __device__ inline int readFlag(const int *f) {
     __asm__ volatile("" ::: "memory");
     return __builtin_amdgcn_readfirstlane(v);
 }
+__device__ inline void drainStores() { __builtin_amdgcn_s_waitcnt(0x0070); } // vmcnt(0) lgkmcnt(0): this wavefront's global stores are done
+__device__ inline void addFlag(int *f) { // one count per wavefront, after everything it loaded has landed in LDS
+    __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) lgkmcnt(0)
+    __asm__ volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ inline void setFlag(int *f, int v) {
     __builtin_amdgcn_s_waitcnt(0xc07f); // the LDS writes of this wavefront have been performed
     __asm__ volatile("" ::: "memory");
@@ -1039,8 +1047,10 @@ __device__ inline void setFlag(int *f, int v) {
 #ifdef AUGX_EMU
 #define PROF_MARK(X, sec) do {} while (0)
 #define PROF_STAMP(X, gbk, slot) do {} while (0)
+#define PROF_TSTAMP(X, cond, slot) do {} while (0)
 #else
 #define PROF_STAMP(X, gbk, slot) do { if ((X).B.prof && (gbk) == 1000 && (threadIdx.x & 63) == 0) (X).B.prof[(int64_t)(X).B.nPieces * 40 + (int64_t)(X).p * 16 + (slot)] = clock64(); } while (0)
+#define PROF_TSTAMP(X, cond, slot) do { if ((X).B.prof && (cond) && (threadIdx.x & 63) == 0) (X).B.prof[(int64_t)(X).B.nPieces * 40 + (int64_t)(X).p * 16 + (slot)] = clock64(); } while (0)
 #define PROF_MARK(X, sec) do { if ((X).B.prof) { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } } while (0)
 #endif
 struct TrellisCtx {
@@ -1065,70 +1075,116 @@ struct TrellisCtx {
 
 // ---- staging of tile `tile` into LDS buffer `buf` by thread tid of nth (next tile: the loader wavefronts)
 AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth, bool flushOld) {
+    // written in two phases -- every global load of the thread is issued before the first result is consumed -- so that a
+    // tile costs the loaders a few memory round trips, not one per element (nth >= 192: the unroll bounds below)
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int n = X.n, j0 = tile * WAVE, dL = X.T.dStateLen;
     const int64_t o = X.o, g0 = o + 1 + j0;
-    for (int i = tid; i < WAVE * NSIG; i += nth) {
-        const int l = i / NSIG;
-        L.sig[buf][l][i % NSIG] = (j0 + l < n) ? gp(B.sig)[g0 * NSIG + i] : AUGX_NINF;
-    }
-    for (int i = tid; i < WAVE * NSITE; i += nth) {
-        const int l = i / NSITE, sel = i % NSITE;
-        if (flushOld) { // the buffer still holds the site indices of tile - 2: retire the list values of those sites to HBM
-            const int si = L.site[buf][l][sel];
-            if (si >= 0) {
-                double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
-#pragma unroll
-                for (int f = 0; f < 3; f++) gp(a)[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
-            }
-        }
-        L.site[buf][l][sel] = (j0 + l < n) ? gp(B.site)[g0 * NSITE + i] : -1;
-    }
-    for (int i = tid; i < WAVE * 6; i += nth) {
-        const int l = i / 6, q = j0 + l;
-        L.eqPrev[buf][l][i % 6] = (dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
-    }
     const int64_t gb0 = o / BLK + (int64_t)tile * BLK;
-    for (int i = tid; i < (BLK + 1) * 2; i += nth) { // offsets of the blocks (a tile is contiguous); [BLK] = end of the tile
-        int64_t gb = gb0 + i / 2, extra = 0;
-        if (i / 2 == BLK || gb >= B.nBlk) { gb = (gb0 + BLK - 1 < B.nBlk ? gb0 + BLK - 1 : B.nBlk - 1); extra = gp(B.blkCnt)[gb * 2 + i % 2]; }
-        L.blkOff[buf][i / 2][i % 2] = gp(B.blkOff)[gb * 2 + i % 2] + extra;
-    }
-    for (int i = tid; i < BLK * 3; i += nth) L.blkSplit[buf][i / 3][i % 3] = gb0 + i / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + i / 3) * 3 + i % 3] : 0;
-    for (int i = tid; i < BLK * 4; i += nth) {
-        int q = j0 + (i / 4) * BLK + BLK - 1;
-        if (q > n - 1) q = n - 1;
-        L.listTop[buf][i / 4][i % 4] = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + i % 4, NCNT)] - 1;
-    }
     const int64_t gbL = gb0 + BLK - 1 < B.nBlk ? gb0 + BLK - 1 : B.nBlk - 1; // last block of the tile
+    constexpr int KSIG = (WAVE * NSIG + 191) / 192, KSITE = (WAVE * NSITE + 191) / 192, KEQ = (WAVE * 6 + 191) / 192;
+    double vSig[KSIG], vEq[KEQ];
+    int vSite[KSITE];
+#pragma unroll
+    for (int k = 0; k < KSIG; k++) {
+        const int i = tid + k * nth;
+        vSig[k] = (i < WAVE * NSIG && j0 + i / NSIG < n) ? gp(B.sig)[g0 * NSIG + i] : AUGX_NINF;
+    }
+#pragma unroll
+    for (int k = 0; k < KSITE; k++) {
+        const int i = tid + k * nth;
+        vSite[k] = (i < WAVE * NSITE && j0 + i / NSITE < n) ? gp(B.site)[g0 * NSITE + i] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < KEQ; k++) {
+        const int i = tid + k * nth, q = j0 + i / 6;
+        vEq[k] = (i < WAVE * 6 && dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
+    }
+    // block tables: thread i < 18 the pair / item offset of block i/2 ([BLK] = end of the tile: a tile is contiguous),
+    // i < 24 the split points, i < 32 the newest list entries
+    uint64_t vOff = 0;
+    uint32_t vSplit = 0;
+    int32_t vTop = 0;
+    if (tid < (BLK + 1) * 2) {
+        int64_t gb = gb0 + tid / 2;
+        uint64_t extra = 0;
+        if (tid / 2 == BLK || gb >= B.nBlk) { gb = gbL; extra = gp(B.blkCnt)[gb * 2 + tid % 2]; }
+        vOff = gp(B.blkOff)[gb * 2 + tid % 2] + extra;
+    }
+    if (tid < BLK * 3) vSplit = gb0 + tid / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + tid / 3) * 3 + tid % 3] : 0;
+    if (tid < BLK * 4) {
+        int q = j0 + (tid / 4) * BLK + BLK - 1;
+        if (q > n - 1) q = n - 1;
+        vTop = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + tid % 4, NCNT)] - 1;
+    }
+    const uint64_t firstI = gp(B.blkOff)[gb0 * 2 + 1], lastI = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
+    const uint64_t firstP = gp(B.blkOff)[gb0 * 2], lastP = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
+    // ---- second phase
+#pragma unroll
+    for (int k = 0; k < KSIG; k++) {
+        const int i = tid + k * nth;
+        if (i < WAVE * NSIG) L.sig[buf][i / NSIG][i % NSIG] = vSig[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KSITE; k++) {
+        const int i = tid + k * nth;
+        if (i < WAVE * NSITE) {
+            const int l = i / NSITE, sel = i % NSITE;
+            if (flushOld) { // the buffer still holds the site indices of tile - 2: retire the list values of those sites to HBM
+                const int si = L.site[buf][l][sel];
+                if (si >= 0) {
+                    double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+#pragma unroll
+                    for (int f = 0; f < 3; f++) gp(a)[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
+                }
+            }
+            L.site[buf][l][sel] = vSite[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KEQ; k++) {
+        const int i = tid + k * nth;
+        if (i < WAVE * 6) L.eqPrev[buf][i / 6][i % 6] = vEq[k];
+    }
+    if (tid < (BLK + 1) * 2) L.blkOff[buf][tid / 2][tid % 2] = vOff;
+    if (tid < BLK * 3) L.blkSplit[buf][tid / 3][tid % 3] = vSplit;
+    if (tid < BLK * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
     {
-        const uint64_t first = gp(B.blkOff)[gb0 * 2 + 1], last = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
-        const int cnt = last - first < (uint64_t)ITEM_CAP ? (int)(last - first) : ITEM_CAP;
-        const Item *gi = B.items + first;
-        for (int i = tid; i < cnt; i += 4 * nth) { // four loads in flight per thread
-            const Item r0 = ldItem(gi + i), r1 = ldItem(gi + (i + nth < cnt ? i + nth : i)), r2 = ldItem(gi + (i + 2 * nth < cnt ? i + 2 * nth : i)),
-                       r3 = ldItem(gi + (i + 3 * nth < cnt ? i + 3 * nth : i));
-            L.items[buf][i] = r0;
-            if (i + nth < cnt) L.items[buf][i + nth] = r1;
-            if (i + 2 * nth < cnt) L.items[buf][i + 2 * nth] = r2;
-            if (i + 3 * nth < cnt) L.items[buf][i + 3 * nth] = r3;
+        const int cnt = lastI - firstI < (uint64_t)ITEM_CAP ? (int)(lastI - firstI) : ITEM_CAP;
+        const Item *gi = B.items + firstI;
+        constexpr int KI = 6; // loads in flight per thread (ITEM_CAP / 192 = 11: two rounds at most)
+        for (int base = 0; base < cnt; base += KI * nth) {
+            Item r[KI];
+#pragma unroll
+            for (int k = 0; k < KI; k++) { const int i = base + tid + k * nth; r[k] = ldItem(gi + (i < cnt ? i : 0)); }
+#pragma unroll
+            for (int k = 0; k < KI; k++) { const int i = base + tid + k * nth; if (i < cnt) L.items[buf][i] = r[k]; }
         }
     }
     {
-        const uint64_t first = gp(B.blkOff)[gb0 * 2], last = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
-        const int cnt = last - first < (uint64_t)PAIR_CAP ? (int)(last - first) : PAIR_CAP;
-        for (int i = tid; i < cnt; i += nth) L.pairRec[buf][i] = gp(B.pairRec)[first + i];
+        const int cnt = lastP - firstP < (uint64_t)PAIR_CAP ? (int)(lastP - firstP) : PAIR_CAP;
+        uint16_t r[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = tid + k * nth; r[k] = i < cnt ? gp(B.pairRec)[firstP + i] : (uint16_t)0; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int i = tid + k * nth; if (i < cnt) L.pairRec[buf][i] = r[k]; }
     }
 }
-// write the back pointers of tile `tile` (LDS buffer buf) to HBM and reset the buffer
-// (the trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles)
+// retire tile `tile` (LDS buffer buf) to HBM: back pointers (and reset of their buffer), igenic column, long-lag cells.
+// (The trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles.)
 AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int nth) {
     const int j0 = tile * WAVE;
-    for (int i = tid; i < WAVE * SP; i += nth) {
-        const int r = i / SP;
-        if (j0 + r < X.n) gp(X.B.bp)[(X.o + 1 + j0) * SP + i] = X.L.bp[buf][r][i % SP];
-        X.L.bp[buf][r][i % SP] = BP_NONE;
+    {   // the 64 x SP back pointers are contiguous in LDS and in HBM: move them as 64-bit words
+        const uint64_t *src = (const uint64_t *)&X.L.bp[buf][0][0];
+        uint64_t *srcW = (uint64_t *)&X.L.bp[buf][0][0];
+        uint64_t *dst = (uint64_t *)(X.B.bp + (X.o + 1 + j0) * SP);
+        constexpr int WPR = SP / 4; // words per row
+        const uint64_t none = 0x0001000100010001ull * (uint64_t)BP_NONE;
+        for (int i = tid; i < WAVE * WPR; i += nth) {
+            if (j0 + i / WPR < X.n) gp(dst)[i] = src[i];
+            srcW[i] = none;
+        }
     }
     for (int i = tid; i < WAVE; i += nth) // igenic column
         if (j0 + i >= 1 && j0 + i < X.n) gp(X.B.vig)[X.o + 1 + j0 + i] = X.L.vigw[(j0 + i) & (VIG_WIN - 1)];
@@ -1329,7 +1385,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
             L.col0[t] = v;
         }
-        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.abortFlag = 0; }
+        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.flagR = 0; L.staged = 0; L.rtPub = 0; L.abortFlag = 0; }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
@@ -1498,16 +1554,32 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     const bool safeIg = igSlack < 2 * BLK;
     // RTERMINAL candidates (their single predecessor may be an igenic cell of their own block; nothing reads their cells
     // before lag > 2 blocks): done by the far wavefront for every block whose igenic cells are complete
-    int rtNext = 0; // next block (global index) whose RTERMINAL candidates are due
-    auto rtCatchUp = [&](int w, int buf, int tile, int igDone, int jbNow) { // jbNow: no igenic cell at or beyond it exists yet
+    int rtNext = 0;  // (far wavefront) next block, global index, whose RTERMINAL candidates are due
+    int farPre = 0;  // (far wavefront) blocks below this index already have their far step (pre-run across the tile boundary)
+    auto doRT = [&](int w, int buf, int tile, int k, int jbNow) { // jbNow: no igenic cell at or beyond it exists yet
+        const int bq = k - tile * BLK;
+        const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
+                  rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
+        const int vigLo = jbNow - 1 - VIG_WIN > -1 ? jbNow - 1 - VIG_WIN : -1;
+        if (rt1 > rt0) trellisItems(X, w, buf, bq, k * BLK, rt0, rt1, vigLo);
+    };
+    auto rtCatchUp = [&](int w, int buf, int tile, int igDone, int jbNow) {
         if (rtNext < tile * BLK) rtNext = tile * BLK;
-        for (; rtNext < igDone; rtNext++) {
-            const int bq = rtNext - tile * BLK, jq = rtNext * BLK;
-            if (bq >= BLK || jq >= n) break;
-            const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
-                      rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
-            const int vigLo = jbNow - 1 - VIG_WIN > -1 ? jbNow - 1 - VIG_WIN : -1;
-            if (rt1 > rt0) trellisItems(X, w, buf, bq, jq, rt0, rt1, vigLo);
+        for (; rtNext < igDone && rtNext < (tile + 1) * BLK && rtNext * BLK < n; rtNext++) doRT(w, buf, tile, rtNext, jbNow);
+    };
+    auto farStep = [&](int w, int buf, int jb) { // far fixed-lag states (class 2) and cell resets of the block starting at jb
+        fixedStep(w, buf, jb, 4, -1);
+        FOR_WLANES(t, w) {
+            const int l = t & 63, dj = l & 7, j = jb + dj;
+            (void)l;
+            // cells of variable-length states are absent unless a candidate survives
+#pragma unroll
+            for (int r = 0; r < VR; r++) {
+                const int s2 = vS[r][TI];
+                if (s2 < 0 || j < 1 || j >= n) continue;
+                L.ring[j & 63][s2] = AUGX_NINF;
+                if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
+            }
         }
     };
 #ifndef AUGX_EMU
@@ -1523,6 +1595,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= 1);
                     if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
+                addFlag(&L.staged); // (NWAVES - W_LOAD) counts per tile: the next tile is staged, its buffers are retired
             }
         }
         // ---- the trellis wavefronts walk the blocks of the tile, each at its own pace (progress flags in LDS).  Block b:
@@ -1545,26 +1618,13 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]),
                       itA = it0 + (int)L.blkSplit[buf][blk][0], itB = it0 + (int)L.blkSplit[buf][blk][1], itS = it0 + (int)L.blkSplit[buf][blk][2];
             FOR_WAVES(w) {
-                if (w == W_X) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
+                if (w == W_X && gbk >= farPre) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
                     for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk - 2);
                     PROF_MARK(X, 1);
                     rtCatchUp(w, buf, tile, readFlag(&L.flagC), jb); // RTERMINAL candidates of the blocks whose igenic cells are complete (at least b-5)
                     PROF_MARK(X, 3);
-                    fixedStep(w, buf, jb, 4, -1); // far states (class 2)
-                    PROF_MARK(X, 4);
-                    FOR_WLANES(t, w) {
-                        const int l = t & 63, dj = l & 7, j = jb + dj;
-                        (void)l;
-                        // cells of variable-length states are absent unless a candidate survives
-#pragma unroll
-                        for (int r = 0; r < VR; r++) {
-                            const int s2 = vS[r][TI];
-                            if (s2 < 0 || j < 1 || j >= n) continue;
-                            L.ring[j & 63][s2] = AUGX_NINF;
-                            if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
-                        }
-                    }
-                    setFlag(&L.flagN, gbk + 1);
+                    farStep(w, buf, jb);
+                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagN, gbk + 1);
                     PROF_MARK(X, 2);
                 }
             }
@@ -1574,7 +1634,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 6);
                     fixedStep(w, buf, jb, 3, -1); // near (class 0) and late (class 1) states
-                    setFlag(&L.flagL, gbk + 1);
+                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagL, gbk + 1);
                     PROF_STAMP(X, gbk, 7);
                     PROF_MARK(X, 2);
                 }
@@ -1585,7 +1645,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 8);
                     chainPass(w, buf, blk > 0 ? jb - BLK : -1, jb);
-                    setFlag(&L.flagC, gbk); // igenic is complete up to block b-1
+                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagC, gbk); // igenic is complete up to block b-1
                     PROF_STAMP(X, gbk, 9);
                     PROF_MARK(X, 3);
                 }
@@ -1600,30 +1660,67 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
                     const int lo2 = w == 0 ? it0 : w == 1 ? itA : itB, hi2 = w == 0 ? itA : w == 1 ? itB : itS;
                     if (hi2 > lo2) trellisItems(X, w, buf, blk, jb, lo2, hi2, vigLo);
-                    setFlag(&L.flagI[w], gbk + 1);
+                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagI[w], gbk + 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 3 : 5);
                     PROF_MARK(X, 2);
                 }
             }
         }
+        FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 10); }
         // ---- end of the tile: igenic of the last block, then the RTERMINAL candidates of the last two blocks
         FOR_WAVES(w) {
             if (w == W_C && nb > 0) {
                 const int gLast = tile * BLK + nb - 1, jbLast = j0 + (nb - 1) * BLK;
                 for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gLast + 1);
                 PROF_MARK(X, 1);
+                PROF_TSTAMP(X, tile == 124, 11);
                 chainPass(w, buf, jbLast, -1);
-                setFlag(&L.flagC, gLast + 1);
+                if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagC, gLast + 1);
+                PROF_TSTAMP(X, tile == 124, 12);
                 PROF_MARK(X, 3);
             }
         }
+        // the remaining RTERMINAL candidates of the tile (their back pointers live in this tile's buffer) are shared by
+        // the workers and the far wavefront; before that the far wavefront already does its step for the first block of
+        // the next tile, as soon as the loaders have staged it
         FOR_WAVES(w) {
-            if (w == W_X && nb > 0) { // the remaining RTERMINAL candidates of the tile (their back pointers live in this tile's buffer)
-                waitFlag(L, &L.flagC, tile * BLK + nb);
-                rtCatchUp(w, buf, tile, tile * BLK + nb, j0 + nb * BLK);
+            if (w == W_X && nb > 0) {
+                const int gN = (tile + 1) * BLK, jbN = j0 + WAVE;
+                if (tile + 1 < nTiles && jbN < n) {
+                    waitFlag(L, &L.staged, (NWAVES - W_LOAD) * (tile + 1));
+                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gN - 2);
+                    rtCatchUp(w, buf, tile, readFlag(&L.flagC), j0 + nb * BLK); // the far states read RTERMINAL cells 5 blocks back
+                    farStep(w, buf ^ 1, jbN);
+                    if (wantCells) drainStores();
+                    setFlag(&L.flagN, gN + 1);
+                    farPre = gN + 1;
+                }
+                if (rtNext < tile * BLK) rtNext = tile * BLK;
+                FOR_WLANES(t, w) { if ((t & 63) == 0) L.rtPub = rtNext; }
+                if (wantCells) drainStores();
+                setFlag(&L.flagR, tile + 1);
+            }
+        }
+        FOR_WAVES(w) {
+            if (w < NWORK && nb > 0) {
+                const int gEnd = tile * BLK + nb;
+                waitFlag(L, &L.flagR, tile + 1);
+                const int k = readFlag(&L.rtPub) + w;
+                if (k < gEnd) { waitFlag(L, &L.flagC, gEnd); doRT(w, buf, tile, k, j0 + nb * BLK); }
+                if (w == 0) PROF_TSTAMP(X, tile == 124, 13);
+            }
+        }
+        FOR_WAVES(w) {
+            if (w == W_X && nb > 0) {
+                const int gEnd = tile * BLK + nb;
+                waitFlag(L, &L.flagC, gEnd);
+                for (int k = rtNext + NWORK; k < gEnd; k++) doRT(w, buf, tile, k, j0 + nb * BLK);
+                rtNext = gEnd;
+                PROF_TSTAMP(X, tile == 124, 14);
             }
         }
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
+        FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 15); }
     }
 #ifndef AUGX_EMU
     if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)

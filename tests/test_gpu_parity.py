@@ -43,13 +43,19 @@ def test_gpu_cells_bit_identical_to_oracle(monkeypatch):
     m = ax.Model(config_path(), "human")
     d = ax.Decoder(m, 0)
     S = m.n_states
-    seqs = [s for _, s in golden_inputs()[:2]] + [random_dna(30000, 1), random_dna(5000, 2).lower(), random_dna(100, 3)]
+    # every golden input (real genes on both strands, truncated genes, N runs, IUPAC codes) plus random pieces: the
+    # path alone can hide a wrong cell, so all S x n cells are compared
+    seqs = [s for _, s in golden_inputs()] + [random_dna(30000, 1), random_dna(5000, 2).lower(), random_dna(100, 3)]
     b = ax.Batch(d, seqs)
     b.decode()
     for i, (s, r) in enumerate(zip(seqs, b.paths())):
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
-        assert r.status == 0 and r.ln_viterbi == lnv and r.states == path
-        assert np.array_equal(b.cells(i), V)
+        if r.status == ax.AUGX_E_UNSUPPORTED:  # multi-GC-class piece: not decoded by this version (fails loudly)
+            assert len(set(gc.tolist())) > 1
+            continue
+        assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, i
+        if set(s.upper()) != {"N"}:
+            assert np.array_equal(b.cells(i), V), i
 
 
 def test_gpu_interior_piece_kinds(human):
