@@ -54,8 +54,9 @@ namespace dev {
 #define TX(name) name[0]
 // workgroup barrier that only orders LDS traffic (no wait for outstanding global stores)
 #define BLOCK_SYNC() do { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); __asm__ volatile("" ::: "memory"); } while (0)
-// workgroup barrier after which everything the workgroup stored to HBM is visible to its later coherent loads
-#define BLOCK_GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __syncthreads(); } while (0)
+// workgroup barrier after which everything the workgroup stored to HBM is visible to its own later loads: producer and
+// consumer share the CU's vector cache and L2, so waiting for the stores is enough (no L2 write-back)
+#define BLOCK_GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); } while (0)
 #endif
 constexpr int NWAVES = 8, NT = NWAVES * WAVE;
 
@@ -956,12 +957,13 @@ struct TrellisLds {
     int abortFlag;
 };
 
-// loads of data this kernel itself stored earlier (other wavefront, or long ago): bypass the per-CU vector cache
+// loads of data this workgroup itself stored earlier (other wavefront, at least one tile barrier ago): workgroup-scope
+// atomic loads, so that the compiler neither caches nor reorders them
 #ifdef AUGX_EMU
 inline double ldCoherent(const double *p) { return *p; }
 #else
 __device__ inline double ldCoherent(const double *p) {
-    unsigned long long u = __hip_atomic_load((const AUGX_GLOBAL unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long u = __hip_atomic_load((const AUGX_GLOBAL unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __longlong_as_double((long long)u);
 }
 #endif
@@ -1083,6 +1085,9 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     const int64_t o = X.o, g0 = o + 1 + j0;
     const int64_t gb0 = o / BLK + (int64_t)tile * BLK;
     const int64_t gbL = gb0 + BLK - 1 < B.nBlk ? gb0 + BLK - 1 : B.nBlk - 1; // last block of the tile
+    // (the candidate / pair ranges first: the loads that depend on them then overlap with everything else)
+    const uint64_t firstI = gp(B.blkOff)[gb0 * 2 + 1], lastI = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
+    const uint64_t firstP = gp(B.blkOff)[gb0 * 2], lastP = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
     constexpr int KSIG = (WAVE * NSIG + 191) / 192, KSITE = (WAVE * NSITE + 191) / 192, KEQ = (WAVE * 6 + 191) / 192;
     double vSig[KSIG], vEq[KEQ];
     int vSite[KSITE];
@@ -1118,8 +1123,18 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         if (q > n - 1) q = n - 1;
         vTop = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + tid % 4, NCNT)] - 1;
     }
-    const uint64_t firstI = gp(B.blkOff)[gb0 * 2 + 1], lastI = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
-    const uint64_t firstP = gp(B.blkOff)[gb0 * 2], lastP = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
+    constexpr int KI = (ITEM_CAP + 191) / 192, KP = (PAIR_CAP + 191) / 192;
+    const int cntI = lastI - firstI < (uint64_t)ITEM_CAP ? (int)(lastI - firstI) : ITEM_CAP;
+    const int cntP = lastP - firstP < (uint64_t)PAIR_CAP ? (int)(lastP - firstP) : PAIR_CAP;
+    Item vItem[KI];
+    uint16_t vPair[KP];
+    {
+        const Item *gi = B.items + firstI;
+#pragma unroll
+        for (int k = 0; k < KI; k++) { const int i = tid + k * nth; vItem[k] = ldItem(gi + (i < cntI ? i : 0)); }
+#pragma unroll
+        for (int k = 0; k < KP; k++) { const int i = tid + k * nth; vPair[k] = i < cntP ? gp(B.pairRec)[firstP + i] : (uint16_t)0; }
+    }
     // ---- second phase
 #pragma unroll
     for (int k = 0; k < KSIG; k++) {
@@ -1150,26 +1165,10 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     if (tid < (BLK + 1) * 2) L.blkOff[buf][tid / 2][tid % 2] = vOff;
     if (tid < BLK * 3) L.blkSplit[buf][tid / 3][tid % 3] = vSplit;
     if (tid < BLK * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
-    {
-        const int cnt = lastI - firstI < (uint64_t)ITEM_CAP ? (int)(lastI - firstI) : ITEM_CAP;
-        const Item *gi = B.items + firstI;
-        constexpr int KI = 6; // loads in flight per thread (ITEM_CAP / 192 = 11: two rounds at most)
-        for (int base = 0; base < cnt; base += KI * nth) {
-            Item r[KI];
 #pragma unroll
-            for (int k = 0; k < KI; k++) { const int i = base + tid + k * nth; r[k] = ldItem(gi + (i < cnt ? i : 0)); }
+    for (int k = 0; k < KI; k++) { const int i = tid + k * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
 #pragma unroll
-            for (int k = 0; k < KI; k++) { const int i = base + tid + k * nth; if (i < cnt) L.items[buf][i] = r[k]; }
-        }
-    }
-    {
-        const int cnt = lastP - firstP < (uint64_t)PAIR_CAP ? (int)(lastP - firstP) : PAIR_CAP;
-        uint16_t r[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const int i = tid + k * nth; r[k] = i < cnt ? gp(B.pairRec)[firstP + i] : (uint16_t)0; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { const int i = tid + k * nth; if (i < cnt) L.pairRec[buf][i] = r[k]; }
-    }
+    for (int k = 0; k < KP; k++) { const int i = tid + k * nth; if (i < cntP) L.pairRec[buf][i] = vPair[k]; }
 }
 // retire tile `tile` (LDS buffer buf) to HBM: back pointers (and reset of their buffer), igenic column, long-lag cells.
 // (The trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles.)
