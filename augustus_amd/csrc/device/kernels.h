@@ -1301,6 +1301,15 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     //   variable-length states: VR rounds of 64 cells to reset
     //   chain states (igenic, geometric introns): lane = (chain slot, base of the block)
     constexpr int FR = 3, VR = 4;
+    int nNearStates = 0; // fixed-lag states with lag < 3 blocks (near, late); they occupy the rounds [0, nearRounds)
+    for (int s2 = 0; s2 < S; s2++) {
+        if (!T.reachable[s2]) continue;
+        const int kind = T.kind[s2];
+        if (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) nNearStates += dssWhole < 3 * BLK;
+        else if (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) nNearStates += assLag < 3 * BLK;
+        else if (kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD) nNearStates += dL < 3 * BLK;
+    }
+    const int nearRounds = (nNearStates + 7) / 8, farBase = nearRounds * 8;
     TV2(int, fS, FR); TV2(int, fLag, FR); TV2(int, fSig, FR); TV2(int, fLong, FR); TV2(int, fNanc, FR);
     TV2(int, fAnc0, FR); TV2(int, fAnc1, FR); TV2(double, fTr0, FR); TV2(double, fTr1, FR);
     TV2(int, fLrow, FR); TV2(int, fList, FR); TV2(int, fFrame, FR); TV2(int, fLate, FR);
@@ -1319,7 +1328,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         TX(cS) = -1; TX(cSig) = 0; TX(cNanc) = 0; TX(cSelf) = 5; TX(cIsIg) = 0;
 #pragma unroll
         for (int i = 0; i < 5; i++) { cAnc[i][TI] = 0; cTr[i][TI] = AUGX_NINF; }
-        int nf = 0, nv = 0, nc = 0;
+        int nfNear = 0, nfFar = 0, nv = 0, nc = 0;
         for (int s2 = 0; s2 < S; s2++) {
             if (!T.reachable[s2]) continue;
             const int kind = T.kind[s2];
@@ -1333,6 +1342,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             default: break;
             }
             if (lag > 0) {
+                // the near / late states (lag < 3 blocks) fill the first round(s), the far states the rest: each step of the
+                // block loop then only runs its own rounds
+                const int nf = lag < 3 * BLK ? nfNear++ : farBase + nfFar++;
                 const int r = nf / 8;
                 if (r < FR && (nf & 7) == slot) {
 #pragma unroll
@@ -1356,7 +1368,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             fLate[rr][TI] = (lag < 2 * BLK && chainAnc) ? 1 : lag >= 3 * BLK ? 2 : 0; // 0 near, 1 late, 2 far (reads blocks <= b-3 only)
                         }
                 }
-                nf++;
             } else if (kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC) {
                 if (nc == slot) {
                     TX(cS) = s2; TX(cSig) = kind == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN; TX(cIsIg) = kind == AUGX_K_IGENIC;
@@ -1408,7 +1419,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     const bool directLong = dL < 4 * WAVE; // short dStateLen: equalD would read a cell before its tile has been flushed
     BLOCK_GLOBAL_SYNC();
     // fixed-lag states of block jb (all loads first, then the two-way max); late selects the states described at fLate
-    auto fixedStep = [&](int w, int buf, int jb, int late, int rsel) {
+    auto fixedStep = [&](int w, int buf, int jb, int late, int rlo, int rhi) { // classes in mask `late`, rounds [rlo, rhi)
         FOR_WLANES(t, w) {
             const int l = t & 63, dj = l & 7, j = jb + dj;
             // written branch-light: every load of the selected rounds is issued before anything is computed
@@ -1417,7 +1428,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #pragma unroll
             for (int r = 0; r < FR; r++) {
                 emi[r] = AUGX_NINF; pv0[r] = AUGX_NINF; pv1[r] = AUGX_NINF; si[r] = -1;
-                if (rsel >= 0 && r != rsel) continue;
+                if (r < rlo || r >= rhi) continue;
                 const int jp = j - fLag[r][TI];
                 const bool lg = fLong[r][TI] != 0;
                 const double *p0 = lg ? &L.eqPrev[buf][j & 63][fAnc0[r][TI]] : &L.ring[jp & 63][fAnc0[r][TI]];
@@ -1428,7 +1439,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
 #pragma unroll
             for (int r = 0; r < FR; r++) {
-                if (rsel >= 0 && r != rsel) continue;
+                if (r < rlo || r >= rhi) continue;
                 const int s2 = fS[r][TI];
                 const bool ok = j - fLag[r][TI] >= 0 && emi[r] > AUGX_NINF;
                 const bool c0 = ok && pv0[r] > AUGX_NINF, c1 = ok && fNanc[r][TI] > 1 && pv1[r] > AUGX_NINF;
@@ -1567,7 +1578,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         for (; rtNext < igDone && rtNext < (tile + 1) * BLK && rtNext * BLK < n; rtNext++) doRT(w, buf, tile, rtNext, jbNow);
     };
     auto farStep = [&](int w, int buf, int jb) { // far fixed-lag states (class 2) and cell resets of the block starting at jb
-        fixedStep(w, buf, jb, 4, -1);
+        fixedStep(w, buf, jb, 4, nearRounds, FR);
         FOR_WLANES(t, w) {
             const int l = t & 63, dj = l & 7, j = jb + dj;
             (void)l;
@@ -1632,7 +1643,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 6);
-                    fixedStep(w, buf, jb, 3, -1); // near (class 0) and late (class 1) states
+                    fixedStep(w, buf, jb, 3, 0, nearRounds); // near (class 0) and late (class 1) states
                     if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagL, gbk + 1);
                     PROF_STAMP(X, gbk, 7);
                     PROF_MARK(X, 2);

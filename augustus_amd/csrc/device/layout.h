@@ -109,6 +109,18 @@ inline void checkModelSupported(const augx_tables &t) {
         if (t.W < slack) slack = t.W;
         if (slack < BLK) throw std::runtime_error("augx: trans_init_window too short for the block size of the trellis kernel (species not supported yet)");
     }
+    {   // the fixed-lag states are laid out in rounds of 8: near / late states (lag < 3 blocks) first, then the far ones
+        int nNear = 0, nFar = 0;
+        for (int s = 0; s < t.S; s++) {
+            if (!t.reachable[s]) continue;
+            int kind = t.state_kind[s];
+            int lag = (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? t.As + 2 + t.Ae + t.U
+                      : (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? t.Ds + 2 + t.De
+                      : (kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD) ? dL : 0;
+            if (lag > 0) (lag < 3 * BLK ? nNear : nFar)++;
+        }
+        if ((nNear + 7) / 8 + (nFar + 7) / 8 > 3) throw std::runtime_error("augx: too many fixed-length intron states for the trellis wavefront layout");
+    }
     if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
 }
 
