@@ -340,12 +340,11 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
     DA(V.lrPos, int32_t, Z.listCap); DA(V.lrVal, double, Z.listCap * 3);
-    DA(V.ldPos, int32_t, Z.listCap); DA(V.ldVal, double, Z.listCap * 3);
-    DA(V.rdPos, int32_t, Z.listCap); DA(V.rdVal, double, Z.listCap * 3);
+    DA(V.ldEnt, IntronStart, Z.listCap); DA(V.ldVal, double, Z.listCap * 3);
+    DA(V.rdEnt, IntronStart, Z.listCap); DA(V.rdVal, double, Z.listCap * 3);
     DA(V.atgPos, int32_t, Z.listCap);
     DA(V.laPls, double, Z.listCap * 3); DA(V.laFx, uint64_t, Z.listCap * 3);
     DA(V.lrEt, double, Z.listCap * 3); DA(V.lrFx, uint64_t, Z.listCap * 3);
-    DA(V.ldFx, uint64_t, Z.listCap); DA(V.rdFx, uint64_t, Z.listCap);
     DA(V.atgD, double, Z.listCap * 3); DA(V.atgFx, uint64_t, Z.listCap);
     DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap); DA(V.rsFx, uint64_t, Z.listCap * 3);
     DA(V.plsR, double, Z.N * 3);

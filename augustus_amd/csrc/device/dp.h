@@ -50,6 +50,9 @@ constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payloa
 constexpr int BLK = 8;                       // bases per trellis block: smaller than every lag except the lag-1 chain states
 
 struct CandAlloc;
+// one possible start of a short intron (entry of the LD / RD candidate lists): everything a lessD candidate needs of it,
+// in one 16-byte record (position, the two bases before the splice site, intron-content prefix at the position)
+struct IntronStart { int32_t pos; uint32_t ctx; uint64_t fx; };
 // flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
@@ -95,13 +98,12 @@ struct BatchView {
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD
     int32_t *laPos; double *laVal;   // forward acceptor candidates  (longass_f live):  [N/2] , [N/2][3]
     int32_t *lrPos; double *lrVal;   // reverse donor candidates     (rlongdss_f live)
-    int32_t *ldPos; double *ldVal;   // forward short-intron starts  (longdss_f live)
-    int32_t *rdPos; double *rdVal;   // reverse short-intron starts  (rlongass_f live)
+    struct IntronStart *ldEnt; double *ldVal;   // forward short-intron starts  (longdss_f live)
+    struct IntronStart *rdEnt; double *rdVal;   // reverse short-intron starts  (rlongass_f live)
     int32_t *atgPos;                 // start codons (position of the a of atg) [N/2]
     // candidate-side constants of the list entries (independent of the Viterbi values: written by the prep kernels)
     double *laPls; uint64_t *laFx;   // [cap][3] per phase a: ln P_ls of the first k bases; exon-content prefix at bs+k-1
     double *lrEt; uint64_t *lrFx;    // [cap][3] per phase a: exon-terminal content of bs..bs+Le-1; exon-content prefix at bs+Le-1
-    uint64_t *ldFx, *rdFx;           // [cap] intron-content prefix at eop (forward pattern / reverse-complement pattern)
     double *atgD; uint64_t *atgFx;   // [cap][3] (begin part, ln P_ls, initial content), [cap] exon-content prefix at bs+k-1+Li
     int32_t *rsPos; double *rsBegin; uint64_t *rsFx; // reverse stop codons: position, ln stop prob, [cap][3] exon-content prefix at bs-1
     double *plsR;                    // [N][3] reverse strand: ln P_ls of the k bases ending at this base, per frame

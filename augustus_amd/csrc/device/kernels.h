@@ -65,6 +65,7 @@ constexpr int NWAVES = 8, NT = NWAVES * WAVE;
 #ifdef AUGX_EMU
 template <class T> inline T *gp(T *p) { return p; }
 inline Item ldItem(const Item *p) { return *p; }
+inline IntronStart ldIntronStart(const IntronStart *p) { return *p; }
 #else
 #define AUGX_GLOBAL __attribute__((address_space(1)))
 template <class T> __device__ __forceinline__ AUGX_GLOBAL T *gp(T *p) { return (AUGX_GLOBAL T *)p; }
@@ -74,6 +75,13 @@ __device__ __forceinline__ Item ldItem(const Item *p) { // one 16-byte global lo
     Item I;
     I.te = __hiloint2double(r.y, r.x); I.kp = (uint32_t)r.z; I.src = (uint32_t)r.w;
     return I;
+}
+__device__ __forceinline__ IntronStart ldIntronStart(const IntronStart *p) { // one 16-byte global load
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i r = *(const AUGX_GLOBAL v4i *)p;
+    IntronStart e;
+    e.pos = r.x; e.ctx = (uint32_t)r.y; e.fx = ((uint64_t)(uint32_t)r.w << 32) | (uint32_t)r.z;
+    return e;
 }
 template <int CTRL, int ROWMASK> __device__ __forceinline__ int dppMov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROWMASK, 0xf, false); }
 template <int CTRL, int ROWMASK> __device__ __forceinline__ double dppMovD(double old, double x) {
@@ -275,8 +283,8 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     // the candidate lists are indexed by site; positions are known here, the trellis fills in the values
     if (st[0] >= 0) B.laPos[lo + st[0]] = q;
     if (st[1] >= 0) B.lrPos[lo + st[1]] = q;
-    if (st[2] >= 0) B.ldPos[lo + st[2]] = q;
-    if (st[3] >= 0) B.rdPos[lo + st[3]] = q;
+    if (st[2] >= 0) B.ldEnt[lo + st[2]].pos = q;
+    if (st[3] >= 0) B.rdEnt[lo + st[3]].pos = q;
     if (cn[CNT_ATG] != cp[CNT_ATG]) B.atgPos[lo + cn[CNT_ATG] - 1] = q;
     // emission of the equalD states ending at q (reference IntronModel::seqProb, src/intronmodel.cc:1087-1107)
     if (q - T.dStateLen >= 0) sg[SIG_EQD] = P.seg(FX_INF, q - T.dStateLen + 1, q);
@@ -341,8 +349,17 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
             B.lrFx[idx * 3 + a] = fxv(eot, fb + 0);
         }
     }
-    if (cn[CNT_LD] != cp[CNT_LD]) B.ldFx[lo + (int64_t)cn[CNT_LD] - 1] = fxv(q, FX_INF);
-    if (cn[CNT_RD] != cp[CNT_RD]) B.rdFx[lo + (int64_t)cn[CNT_RD] - 1] = fxv(q, FX_INR);
+    // short-intron starts: content prefix at q and the two bases before the biological intron (spliced-codon check)
+    if (cn[CNT_LD] != cp[CNT_LD]) {
+        IntronStart &e = B.ldEnt[lo + (int64_t)cn[CNT_LD] - 1];
+        const int bobi = q + 1 - T.De - 2;
+        e.fx = fxv(q, FX_INF); e.ctx = (uint32_t)P.b(bobi - 1) | ((uint32_t)P.b(bobi - 2) << 4);
+    }
+    if (cn[CNT_RD] != cp[CNT_RD]) {
+        IntronStart &e = B.rdEnt[lo + (int64_t)cn[CNT_RD] - 1];
+        const int bobi = q + 1 - (T.U + T.As + 2);
+        e.fx = fxv(q, FX_INR); e.ctx = (uint32_t)P.b(bobi - 1) | ((uint32_t)P.b(bobi - 2) << 4);
+    }
     if (cn[CNT_ATG] != cp[CNT_ATG]) { // start codon at q: bs = q+3, frame phase a = (-q) mod 3
         int64_t idx = lo + (int64_t)cn[CNT_ATG] - 1;
         int bs = q + 3, eos = bs + k - 1, eoi = eos + T.Li, a = mod3(-q);
@@ -467,8 +484,8 @@ struct CandCtx {
         return B.cnt[fidx(o + 1 + q, f, NCNT)];
     }
     AUGX_HD int listPos(int sel, int64_t li) const { // sel: 0 LA, 1 LR, 2 LD, 3 RD; li piece-local index
-        const int32_t *a = sel == 0 ? B.laPos : sel == 1 ? B.lrPos : sel == 2 ? B.ldPos : B.rdPos;
-        return a[lo + li];
+        if (sel >= 2) return (sel == 2 ? B.ldEnt : B.rdEnt)[lo + li].pos;
+        return (sel == 0 ? B.laPos : B.lrPos)[lo + li];
     }
     AUGX_HD double listC(int sel, int64_t li, int a) const { // LA: ln P_ls, LR: exon-terminal content
         return (sel == 0 ? B.laPls : B.lrEt)[(lo + li) * 3 + a];
@@ -476,7 +493,7 @@ struct CandCtx {
     AUGX_HD uint64_t listFx(int sel, int64_t li, int a) const {
         if (sel == 0) return B.laFx[(lo + li) * 3 + a];
         if (sel == 1) return B.lrFx[(lo + li) * 3 + a];
-        return (sel == 2 ? B.ldFx : B.rdFx)[lo + li];
+        return (sel == 2 ? B.ldEnt : B.rdEnt)[lo + li].fx;
     }
     AUGX_HD uint64_t fxAt(int q, int f) const { // content prefix field f up to and including base q (q < 0: empty)
         if (q < 0) return 0;
@@ -599,18 +616,27 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         const int f = win;
         const bool listed = idx < D.nList;
         const int64_t li = listed ? D.i1 - 1 - idx : 0;
-        const int eop = listed ? X.listPos(D.listSel, li) : 0;
+        // a listed candidate is one 16-byte record: position, the two bases before the splice site, content prefix
+        // (its splice-site dinucleotide is what put it on the list)
+        IntronStart e;
+        e.pos = 0; e.ctx = 0x44; e.fx = 0;
+        if (listed) e = ldIntronStart((D.listSel == 2 ? B.ldEnt : B.rdEnt) + X.lo + li);
+        const int eop = e.pos;
         const uint32_t sr = listed ? srcList(0, D.listSel, f, li) : srcCol0(0, VC.anc[0]);
         const int begin = eop + 1;
         const int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
-        const int bA = P.b(bobi), bB = P.b(bobi + 1), bM1 = P.b(bobi - 1), bM2 = P.b(bobi - 2);
-        const uint64_t cFx = listed ? X.listFx(D.listSel, li, 0) : 0;
+        int bM1 = (int)(e.ctx & 15), bM2 = (int)((e.ctx >> 4) & 15);
+        bool siteOk = true;
+        if (!listed) { // eop = 0 (column 0): not a splice site; the reference still applies its gate (src/intronmodel.cc:595-600)
+            const int bA = P.b(bobi), bB = P.b(bobi + 1);
+            bM1 = P.b(bobi - 1); bM2 = P.b(bobi - 2);
+            siteOk = bobi < 0 || (bobi >= 1 && bobi <= n - 2 && (fwd ? (bA == 2 && bB == 3) : (bA == 1 && bB == 3)));
+        }
+        const uint64_t cFx = e.fx;
         int intronLength = D.eobi - bobi + 1;
         const bool lenOk = intronLength <= T.d;
         if (intronLength > T.d || intronLength < 0) intronLength = 0;
         const double lenI = X.lenIAt(intronLength);
-        // splice-site dinucleotide at the intron start (reference isPossibleDSS / isPossibleRASS)
-        const bool siteOk = bobi < 0 || (bobi >= 1 && bobi <= n - 2 && (fwd ? (bA == 2 && bB == 3) : (bA == 1 && bB == 3)));
         // stop codon across the splice (reference src/intronmodel.cc:935-958)
         const bool spliced = fwd ? (f != 0) : (f != 2);
         bool veto = false;
@@ -701,8 +727,15 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     const bool fwd = D.g.fwd;
     int eop;
     int64_t li = -1;
-    if (idx < D.nList) { li = D.i1 - 1 - idx; eop = X.listPos(D.listSel, li); }
-    else eop = -1;
+    // (the three loads of a listed candidate are issued together: position, content prefix and begin-side constant)
+    uint64_t cFxL = 0;
+    double cCL = 0.0;
+    if (idx < D.nList) {
+        li = D.i1 - 1 - idx;
+        eop = X.listPos(D.listSel, li);
+        cFxL = X.listFx(D.listSel, li, D.a);
+        cCL = X.listC(D.listSel, li, D.a);
+    } else eop = -1;
     int bs = eop + 1;
     int bob = bs - D.g.ipo, len = D.eob - bob + 1;
     if (len < 1 || len > T.max_exon_len || (kind == AUGX_K_RINITIAL && len <= 2)) return;
@@ -716,9 +749,9 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                     fast = true;
                     double lenPart = (len >= 1 && len <= T.max_exon_len) ? X.lenAt(D.lenSel, len) : AUGX_NINF;
                     if (!(lenPart > AUGX_NINF)) return;
-                    double seg1 = (double)(int64_t)(D.eFx - X.listFx(0, li, D.a)) * AUGX_FX_INV;
+                    double seg1 = (double)(int64_t)(D.eFx - cFxL) * AUGX_FX_INV;
                     double inner = kind == AUGX_K_TERMINAL ? seg1 : (seg1 + D.eD0);
-                    nep = (0.0 + (X.listC(0, li, D.a) + inner)) + lenPart;
+                    nep = (0.0 + (cCL + inner)) + lenPart;
                 }
             } else {
                 const int boip = D.right - (k - 1), eot = bs + T.Le - 1, boi = boip - T.Li;
@@ -727,8 +760,8 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                     fast = true;
                     double lenPart = (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RINTERNAL || len > 2)) ? X.lenAt(D.lenSel, len) : AUGX_NINF;
                     if (!(lenPart > AUGX_NINF)) return;
-                    double seg1 = (double)(int64_t)(D.eFx - X.listFx(1, li, D.a)) * AUGX_FX_INV;
-                    double cEt = X.listC(1, li, D.a);
+                    double seg1 = (double)(int64_t)(D.eFx - cFxL) * AUGX_FX_INV;
+                    double cEt = cCL;
                     double inner = kind == AUGX_K_RINTERNAL ? (seg1 + cEt) : ((D.eD0 + seg1) + cEt);
                     nep = (0.0 + (D.plsEnd + inner)) + lenPart;
                 }

@@ -72,12 +72,11 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.longV = zalloc<double>(Z.N * 6);
     B.laPos = zalloc<int32_t>(Z.listCap); B.laVal = zalloc<double>(Z.listCap * 3);
     B.lrPos = zalloc<int32_t>(Z.listCap); B.lrVal = zalloc<double>(Z.listCap * 3);
-    B.ldPos = zalloc<int32_t>(Z.listCap); B.ldVal = zalloc<double>(Z.listCap * 3);
-    B.rdPos = zalloc<int32_t>(Z.listCap); B.rdVal = zalloc<double>(Z.listCap * 3);
+    B.ldEnt = zalloc<IntronStart>(Z.listCap); B.ldVal = zalloc<double>(Z.listCap * 3);
+    B.rdEnt = zalloc<IntronStart>(Z.listCap); B.rdVal = zalloc<double>(Z.listCap * 3);
     B.atgPos = zalloc<int32_t>(Z.listCap);
     B.laPls = zalloc<double>(Z.listCap * 3); B.laFx = zalloc<uint64_t>(Z.listCap * 3);
     B.lrEt = zalloc<double>(Z.listCap * 3); B.lrFx = zalloc<uint64_t>(Z.listCap * 3);
-    B.ldFx = zalloc<uint64_t>(Z.listCap); B.rdFx = zalloc<uint64_t>(Z.listCap);
     B.atgD = zalloc<double>(Z.listCap * 3); B.atgFx = zalloc<uint64_t>(Z.listCap);
     B.rsPos = zalloc<int32_t>(Z.listCap); B.rsBegin = zalloc<double>(Z.listCap); B.rsFx = zalloc<uint64_t>(Z.listCap * 3);
     B.plsR = zalloc<double>(Z.N * 3);
@@ -163,9 +162,9 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     }
     free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.pairRec); free(B.items);
     free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
-    free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldPos); free(B.ldVal);
-    free(B.rdPos); free(B.rdVal); free(B.atgPos); free(B.pathRec);
-    free(B.laPls); free(B.laFx); free(B.lrEt); free(B.lrFx); free(B.ldFx); free(B.rdFx); free(B.atgD); free(B.atgFx); free(B.rsPos); free(B.rsBegin); free(B.rsFx); free(B.plsR);
+    free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldEnt); free(B.ldVal);
+    free(B.rdEnt); free(B.rdVal); free(B.atgPos); free(B.pathRec);
+    free(B.laPls); free(B.laFx); free(B.lrEt); free(B.lrFx); free(B.atgD); free(B.atgFx); free(B.rsPos); free(B.rsBegin); free(B.rsFx); free(B.plsR);
     return 0;
 }
 }
