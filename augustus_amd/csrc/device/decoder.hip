@@ -127,14 +127,14 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
 }
 
 // ---- candidates of the variable-length states: one workgroup per tile of 64 bases (count, reserve, emit) ----
-__global__ void __launch_bounds__(NT) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+template <int BLK> __global__ void __launch_bounds__(NT) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ CandLds lds;
-    candWorkgroup(*T, *B, lds, blockIdx.x);
+    candWorkgroup<BLK>(*T, *B, lds, blockIdx.x);
 }
 
-__global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+template <int BLK> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
-    trellisPiece(*T, *B, lds, blockIdx.x);
+    trellisPiece<BLK>(*T, *B, lds, blockIdx.x);
 }
 __global__ void __launch_bounds__(64) kBacktrace(const DevTables *T, BatchView B) { backtracePiece(*T, B, blockIdx.x); }
 
@@ -149,6 +149,7 @@ struct augx_decoder {
     DevTables *dT = nullptr;
     std::vector<void *> tableBufs;
     bool debugCells = false;
+    int blk = 8;              // block size of the candidate / trellis kernels for this model (layout.h: chooseBlockSize)
 };
 
 struct augx_batch {
@@ -240,8 +241,9 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     }
     if (device < 0 || device >= ndev) { setLastError("augx_decoder_create: bad device index"); return AUGX_E_ARG; }
     const augx_tables &t = m->m.t;
+    int blk = 8;
     try {
-        checkModelSupported(t);
+        blk = chooseBlockSize(t);
     } catch (std::exception &ex) {
         setLastError(ex.what());
         return AUGX_E_UNSUPPORTED;
@@ -250,6 +252,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     augx_decoder *d = new augx_decoder();
     d->model = m;
     d->device = device;
+    d->blk = blk;
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
     HIP_TRY(hipStreamCreate(&d->stream));
@@ -348,7 +351,8 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.atgD, double, Z.listCap * 3); DA(V.atgFx, uint64_t, Z.listCap);
     DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap); DA(V.rsFx, uint64_t, Z.listCap * 3);
     DA(V.plsR, double, Z.N * 3);
-    V.nBlk = Z.N / BLK;
+    V.blk = d->blk;
+    V.nBlk = Z.N / V.blk;
     DA(V.blkCnt, uint32_t, V.nBlk * 2); DA(V.blkSplit, uint32_t, V.nBlk * 3); DA(V.blkOff, uint64_t, V.nBlk * 2);
     DA(V.candAlloc, CandAlloc, 1);
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
@@ -404,7 +408,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn
         // out too small (first decode of a batch, unusual sequence), it reports the size needed and is run again.
         BatchView &W = b->V;
-        const unsigned nWg = (unsigned)((W.nBlk + NWAVES - 1) / NWAVES);
+        const unsigned nWg = (unsigned)(W.N / WAVE); // one workgroup per tile of 64 bases
         if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
             W.pairCap = W.N * 2 + 4096; W.itemCap = W.N * 18 + 65536;
             HIP_TRY(hipMalloc(&b->pairBuf, (size_t)W.pairCap * sizeof(uint16_t)));
@@ -419,7 +423,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         }
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
-            hipLaunchKernelGGL(kCand, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+            if (d->blk == 8) hipLaunchKernelGGL(kCand<8>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+            else hipLaunchKernelGGL(kCand<4>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
             HIP_TRY(hipGetLastError());
             CandAlloc tot;
             HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));
@@ -442,7 +447,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         }
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
-    hipLaunchKernelGGL(kTrellis, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+    if (d->blk == 8) hipLaunchKernelGGL(kTrellis<8>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+    else hipLaunchKernelGGL(kTrellis<4>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);

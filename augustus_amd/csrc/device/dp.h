@@ -47,7 +47,9 @@ constexpr int KEY_BITS = 22;                 // pieces on the device path are sh
 constexpr uint32_t KEY_MASK = (1u << KEY_BITS) - 1;
 constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >= -(3 + W) - 1 for a left-truncated initial exon)
 constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
-constexpr int BLK = 8;                       // bases per trellis block: smaller than every lag except the lag-1 chain states
+// bases per trellis block (template parameter BLK of the candidate and trellis kernels): smaller than every lag of the
+// model except the lag-1 chain states.  8 where the species' windows allow it, else 4 (layout.h: chooseBlockSize)
+constexpr int MAXNB = 16;                    // blocks per tile of 64 bases at the smallest block size
 
 struct CandAlloc;
 // one possible start of a short intron (entry of the LD / RD candidate lists): everything a lessD candidate needs of it,
@@ -108,7 +110,8 @@ struct BatchView {
     int32_t *rsPos; double *rsBegin; uint64_t *rsFx; // reverse stop codons: position, ln stop prob, [cap][3] exon-content prefix at bs-1
     double *plsR;                    // [N][3] reverse strand: ln P_ls of the k bases ending at this base, per frame
     // candidates of the variable-length states, grouped by block of BLK bases (block index = off[p]/BLK + j/BLK)
-    int64_t nBlk;                    // N / BLK
+    int blk;                         // block size of this batch (8 or 4)
+    int64_t nBlk;                    // N / blk
     uint32_t *blkCnt;                // [nBlk][2] (pairs, items) of the block
     uint32_t *blkSplit;              // [nBlk][3] items of the block up to the pair boundaries near 1/3 and 2/3 / of all states but RTERMINAL (they come first)
     uint64_t *blkOff;                // [nBlk][2] first pair / first item of the block (the blocks of a tile are contiguous)

@@ -384,7 +384,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
 // start in a window that can be 15 kb long.  For each of them the score is
 //        V[eop][a]  +  ( ln t(a->s) + ln emission(eop+1 .. j | s) )
 // and only the first term depends on the trellis.  The second term ("te"), the tie-break key and the address of
-// the first term are computed HERE, fully parallel over blocks of BLK bases (one wavefront per block), and streamed
+// the first term are computed HERE, fully parallel over blocks of 8 (or 4) bases (one or two blocks per wavefront), and streamed
 // to the trellis kernel, which is left with one addition and one segmented arg-max per candidate.
 // The formulas are those of the reference loops (exon: src/exonmodel.cc:1059-1132; lessD:
 // src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
@@ -455,10 +455,10 @@ struct CandLds {
     VarConst vc[SP];
     VarDesc desc[NWAVES][WAVE];     // descriptors of the (base, state) pairs of the current round, one per lane
     int pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];
-    uint32_t cntW[NWAVES][5];
-    uint8_t plD[NWAVES][BLK * 32], plS[NWAVES][BLK * 32]; // pair list of each wavefront's block: base offset, state
+    uint32_t cntW[MAXNB][5];        // per block of the tile: pairs, items, items but RTERMINAL, split points
+    uint8_t plD[NWAVES][256], plS[NWAVES][256];         // pair list of the wavefront's current block: base offset, state
     int plN[NWAVES][2];                                 // pairs but RTERMINAL / all pairs
-    unsigned long long preW[NWAVES][2], baseW[2];
+    unsigned long long preW[MAXNB][2], baseW[2];
     int fits;
 };
 
@@ -800,7 +800,8 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
 //   write == false: describe + count; results in cnt[] = {pairs, items, items of non-RTERMINAL pairs, mid1, mid2}
 //   write == true : emit pairRec / items at pairBase / itemBase.  If the block had a single round, the descriptors
 //                   left in LDS by the counting call are reused.
-AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, uint64_t maskVar, uint64_t maskRT, uint64_t pairBase,
+template <int BLK>
+AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, bool mayReuse, uint64_t maskVar, uint64_t maskRT, uint64_t pairBase,
                         uint64_t itemBase, uint32_t *cnt) {
     const BatchView &B = X.B;
     const int n = X.n, jb = b * BLK;
@@ -812,7 +813,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
     maskLess &= maskVar;
     // pair list of the block in LDS (lane dj < BLK owns base jb + dj); the counting call builds it, the emitting call reuses it
     int nP0, allPairs;
-    if (!write) {
+    if (!write || !mayReuse) {
         TV(int, nA); TV(int, nB); TV(int, nC);
         TV(uint64_t, gA); TV(uint64_t, gB); TV(uint64_t, gC);
         FOR_WLANES(t, w) {
@@ -840,7 +841,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
         WAVE_SYNC();
     }
     nP0 = L.plN[w][0]; allPairs = L.plN[w][1];
-    const bool reuse = write && allPairs <= WAVE;
+    const bool reuse = write && mayReuse && allPairs <= WAVE;
     uint32_t itemsDone = 0, split = 0, mid1 = 0, mid2 = 0;
     for (int done = 0; done < allPairs; done += WAVE) {
         const int nPairs = allPairs - done < WAVE ? allPairs - done : WAVE;
@@ -912,10 +913,13 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
 // global allocation state of the candidate buffers (one per batch)
 struct CandAlloc { unsigned long long pairs, items; };
 
-// one workgroup = the NWAVES = BLK consecutive blocks of one tile of 64 bases (they belong to one piece: a chunk of
-// CHUNK slots never spans pieces).  Count, reserve a contiguous range for the tile, emit.
+// one workgroup = the WAVE / BLK consecutive blocks of one tile of 64 bases (they belong to one piece: a chunk of
+// CHUNK slots never spans pieces), one or two blocks per wavefront.  Count, reserve a contiguous range for the tile, emit.
+template <int BLK>
 AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg) {
-    const int64_t gblk0 = wg * NWAVES;
+    constexpr int NB = WAVE / BLK, BPW = NB / NWAVES; // blocks per tile, blocks per wavefront
+    static_assert(NB % NWAVES == 0 && NB <= MAXNB, "block size");
+    const int64_t gblk0 = wg * NB;
     if (gblk0 >= B.nBlk) return;
     const int p = B.chunkPiece[gblk0 * BLK / CHUNK];
     const int c = B.cls[p];
@@ -925,16 +929,19 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
     uint64_t maskVar, maskRT;
     varMasks(T, maskVar, maskRT);
     FOR_WAVES(w) {
-        const int b = (int)(gblk0 + w - X.o / BLK);
-        uint32_t cnt[5];
-        candBlock(X, L, w, b, false, maskVar, maskRT, 0, 0, cnt);
-        FOR_WLANES(t, w) { if ((t & 63) == 0) for (int i = 0; i < 5; i++) L.cntW[w][i] = cnt[i]; }
+        for (int q = 0; q < BPW; q++) {
+            const int bi = w * BPW + q;
+            const int b = (int)(gblk0 + bi - X.o / BLK);
+            uint32_t cnt[5];
+            candBlock<BLK>(X, L, w, b, false, BPW == 1, maskVar, maskRT, 0, 0, cnt);
+            FOR_WLANES(t, w) { if ((t & 63) == 0) for (int i = 0; i < 5; i++) L.cntW[bi][i] = cnt[i]; }
+        }
     }
     BLOCK_SYNC();
     FOR_THREADS(t) {
         if (t == 0) {
             unsigned long long np = 0, ni = 0;
-            for (int w = 0; w < NWAVES; w++) { L.preW[w][0] = np; L.preW[w][1] = ni; np += L.cntW[w][0]; ni += L.cntW[w][1]; }
+            for (int bi = 0; bi < NB; bi++) { L.preW[bi][0] = np; L.preW[bi][1] = ni; np += L.cntW[bi][0]; ni += L.cntW[bi][1]; }
 #ifdef AUGX_EMU
             const unsigned long long bp0 = B.candAlloc->pairs, bi0 = B.candAlloc->items;
             B.candAlloc->pairs += np; B.candAlloc->items += ni;
@@ -948,17 +955,20 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
     BLOCK_SYNC();
     if (!L.fits) return; // the host re-runs the kernel with buffers of the size the counters report
     FOR_WAVES(w) {
-        const int64_t gblk = gblk0 + w;
-        const int b = (int)(gblk - X.o / BLK);
-        const uint64_t pairBase = L.baseW[0] + L.preW[w][0], itemBase = L.baseW[1] + L.preW[w][1];
-        FOR_WLANES(t, w) {
-            if ((t & 63) == 0) {
-                B.blkOff[gblk * 2] = pairBase; B.blkOff[gblk * 2 + 1] = itemBase;
-                B.blkCnt[gblk * 2] = L.cntW[w][0]; B.blkCnt[gblk * 2 + 1] = L.cntW[w][1];
-                B.blkSplit[gblk * 3] = L.cntW[w][3]; B.blkSplit[gblk * 3 + 1] = L.cntW[w][4]; B.blkSplit[gblk * 3 + 2] = L.cntW[w][2];
+        for (int q = 0; q < BPW; q++) {
+            const int bi = w * BPW + q;
+            const int64_t gblk = gblk0 + bi;
+            const int b = (int)(gblk - X.o / BLK);
+            const uint64_t pairBase = L.baseW[0] + L.preW[bi][0], itemBase = L.baseW[1] + L.preW[bi][1];
+            FOR_WLANES(t, w) {
+                if ((t & 63) == 0) {
+                    B.blkOff[gblk * 2] = pairBase; B.blkOff[gblk * 2 + 1] = itemBase;
+                    B.blkCnt[gblk * 2] = L.cntW[bi][0]; B.blkCnt[gblk * 2 + 1] = L.cntW[bi][1];
+                    B.blkSplit[gblk * 3] = L.cntW[bi][3]; B.blkSplit[gblk * 3 + 1] = L.cntW[bi][4]; B.blkSplit[gblk * 3 + 2] = L.cntW[bi][2];
+                }
             }
+            if (L.cntW[bi][0] > 0) candBlock<BLK>(X, L, w, b, true, BPW == 1, maskVar, maskRT, pairBase, itemBase, nullptr);
         }
-        if (L.cntW[w][0] > 0) candBlock(X, L, w, b, true, maskVar, maskRT, pairBase, itemBase, nullptr);
     }
 }
 
@@ -978,9 +988,9 @@ struct TrellisLds {
     int32_t site[2][WAVE][NSITE];
     double eqPrev[2][WAVE][6];      // predecessor cells of the equalD states (lag dStateLen)
     double longW[2][WAVE][6];       // cells of the states equalD reads back at lag dStateLen (flushed to HBM tile by tile)
-    uint64_t blkOff[2][BLK + 1][2]; // pair / item offsets of the blocks of the tile
-    uint32_t blkSplit[2][BLK][3];   // candidates: end of the first / second third, end of all states but RTERMINAL
-    int32_t listTop[2][BLK][4];     // newest entry of each candidate list at the end of each block
+    uint64_t blkOff[2][MAXNB + 1][2]; // pair / item offsets of the blocks of the tile
+    uint32_t blkSplit[2][MAXNB][3]; // candidates: end of the first / second third, end of all states but RTERMINAL
+    int32_t listTop[2][MAXNB][4];   // newest entry of each candidate list at the end of each block
     Item items[2][ITEM_CAP];
     uint16_t pairRec[2][PAIR_CAP];
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
@@ -1109,15 +1119,17 @@ struct TrellisCtx {
 };
 
 // ---- staging of tile `tile` into LDS buffer `buf` by thread tid of nth (next tile: the loader wavefronts)
+template <int BLK>
 AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth, bool flushOld) {
+    constexpr int NB = WAVE / BLK; // blocks per tile
     // written in two phases -- every global load of the thread is issued before the first result is consumed -- so that a
     // tile costs the loaders a few memory round trips, not one per element (nth >= 192: the unroll bounds below)
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int n = X.n, j0 = tile * WAVE, dL = X.T.dStateLen;
     const int64_t o = X.o, g0 = o + 1 + j0;
-    const int64_t gb0 = o / BLK + (int64_t)tile * BLK;
-    const int64_t gbL = gb0 + BLK - 1 < B.nBlk ? gb0 + BLK - 1 : B.nBlk - 1; // last block of the tile
+    const int64_t gb0 = o / BLK + (int64_t)tile * NB;
+    const int64_t gbL = gb0 + NB - 1 < B.nBlk ? gb0 + NB - 1 : B.nBlk - 1; // last block of the tile
     // (the candidate / pair ranges first: the loads that depend on them then overlap with everything else)
     const uint64_t firstI = gp(B.blkOff)[gb0 * 2 + 1], lastI = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
     const uint64_t firstP = gp(B.blkOff)[gb0 * 2], lastP = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
@@ -1139,19 +1151,19 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         const int i = tid + k * nth, q = j0 + i / 6;
         vEq[k] = (i < WAVE * 6 && dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
     }
-    // block tables: thread i < 18 the pair / item offset of block i/2 ([BLK] = end of the tile: a tile is contiguous),
-    // i < 24 the split points, i < 32 the newest list entries
+    // block tables: thread i < 2 (NB + 1) the pair / item offset of block i/2 ([NB] = end of the tile: a tile is contiguous),
+    // i < 3 NB the split points, i < 4 NB the newest list entries
     uint64_t vOff = 0;
     uint32_t vSplit = 0;
     int32_t vTop = 0;
-    if (tid < (BLK + 1) * 2) {
+    if (tid < (NB + 1) * 2) {
         int64_t gb = gb0 + tid / 2;
         uint64_t extra = 0;
-        if (tid / 2 == BLK || gb >= B.nBlk) { gb = gbL; extra = gp(B.blkCnt)[gb * 2 + tid % 2]; }
+        if (tid / 2 == NB || gb >= B.nBlk) { gb = gbL; extra = gp(B.blkCnt)[gb * 2 + tid % 2]; }
         vOff = gp(B.blkOff)[gb * 2 + tid % 2] + extra;
     }
-    if (tid < BLK * 3) vSplit = gb0 + tid / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + tid / 3) * 3 + tid % 3] : 0;
-    if (tid < BLK * 4) {
+    if (tid < NB * 3) vSplit = gb0 + tid / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + tid / 3) * 3 + tid % 3] : 0;
+    if (tid < NB * 4) {
         int q = j0 + (tid / 4) * BLK + BLK - 1;
         if (q > n - 1) q = n - 1;
         vTop = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + tid % 4, NCNT)] - 1;
@@ -1195,9 +1207,9 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         const int i = tid + k * nth;
         if (i < WAVE * 6) L.eqPrev[buf][i / 6][i % 6] = vEq[k];
     }
-    if (tid < (BLK + 1) * 2) L.blkOff[buf][tid / 2][tid % 2] = vOff;
-    if (tid < BLK * 3) L.blkSplit[buf][tid / 3][tid % 3] = vSplit;
-    if (tid < BLK * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
+    if (tid < (NB + 1) * 2) L.blkOff[buf][tid / 2][tid % 2] = vOff;
+    if (tid < NB * 3) L.blkSplit[buf][tid / 3][tid % 3] = vSplit;
+    if (tid < NB * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
 #pragma unroll
     for (int k = 0; k < KI; k++) { const int i = tid + k * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
 #pragma unroll
@@ -1297,7 +1309,10 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     }
 }
 
+template <int BLK>
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int p) {
+    constexpr int NB = WAVE / BLK;  // blocks per tile
+    constexpr int SPR = WAVE / BLK; // state slots per round of 64 lanes: lane = (slot, base of the block)
     TrellisCtx X(T, B, L, p);
     const int n = X.n, S = X.S, c = X.c;
     const int64_t o = X.o;
@@ -1342,7 +1357,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         else if (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) nNearStates += assLag < 3 * BLK;
         else if (kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD) nNearStates += dL < 3 * BLK;
     }
-    const int nearRounds = (nNearStates + 7) / 8, farBase = nearRounds * 8;
+    const int nearRounds = (nNearStates + SPR - 1) / SPR, farBase = nearRounds * SPR;
     TV2(int, fS, FR); TV2(int, fLag, FR); TV2(int, fSig, FR); TV2(int, fLong, FR); TV2(int, fNanc, FR);
     TV2(int, fAnc0, FR); TV2(int, fAnc1, FR); TV2(double, fTr0, FR); TV2(double, fTr1, FR);
     TV2(int, fLrow, FR); TV2(int, fList, FR); TV2(int, fFrame, FR); TV2(int, fLate, FR);
@@ -1350,7 +1365,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     TV(int, cS); TV(int, cSig); TV(int, cNanc); TV(int, cSelf); TV(int, cIsIg);
     TV2(int, cAnc, 5); TV2(double, cTr, 5);
     FOR_THREADS(t) {
-        const int l = t & 63, slot = l >> 3;
+        const int l = t & 63, slot = l / BLK;
 #pragma unroll
         for (int r = 0; r < FR; r++) {
             fS[r][TI] = -1; fLag[r][TI] = 1; fSig[r][TI] = 0; fLong[r][TI] = 0; fNanc[r][TI] = 0; fAnc0[r][TI] = 0; fAnc1[r][TI] = 0;
@@ -1378,8 +1393,8 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 // the near / late states (lag < 3 blocks) fill the first round(s), the far states the rest: each step of the
                 // block loop then only runs its own rounds
                 const int nf = lag < 3 * BLK ? nfNear++ : farBase + nfFar++;
-                const int r = nf / 8;
-                if (r < FR && (nf & 7) == slot) {
+                const int r = nf / SPR;
+                if (r < FR && nf % SPR == slot) {
 #pragma unroll
                     for (int rr = 0; rr < FR; rr++)
                         if (rr == r) {
@@ -1414,8 +1429,8 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
                 nc++;
             } else {
-                const int r = nv / 8;
-                if (r < VR && (nv & 7) == slot) {
+                const int r = nv / SPR;
+                if (r < VR && nv % SPR == slot) {
 #pragma unroll
                     for (int rr = 0; rr < VR; rr++) if (rr == r) vS[rr][TI] = s2;
                 }
@@ -1445,7 +1460,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (B.cells) B.cells[(o + 1) * S + t] = v;
             if (T.kind[t] == AUGX_K_IGENIC) { B.vig[o + 1] = v; L.vigw[0] = v; }
         }
-        loadTileThread(X, 0, 0, t, NT, false);
+        loadTileThread<BLK>(X, 0, 0, t, NT, false);
     }
     const int nTiles = (n + WAVE - 1) / WAVE;
     const bool wantCells = B.cells != nullptr;
@@ -1454,7 +1469,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     // fixed-lag states of block jb (all loads first, then the two-way max); late selects the states described at fLate
     auto fixedStep = [&](int w, int buf, int jb, int late, int rlo, int rhi) { // classes in mask `late`, rounds [rlo, rhi)
         FOR_WLANES(t, w) {
-            const int l = t & 63, dj = l & 7, j = jb + dj;
+            const int l = t & 63, dj = l % BLK, j = jb + dj;
             // written branch-light: every load of the selected rounds is issued before anything is computed
             double emi[FR], pv0[FR], pv1[FR];
             int si[FR];
@@ -1507,7 +1522,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         TV(double, bB); TV(double, bA); TV(double, teS); TV(double, psS);
         TV(int, aB); TV(int, aA); TV(int, rai); TV(int, jj);
         FOR_WLANES(t, w) {
-            const int l = t & 63, dj = l & 7;
+            const int l = t & 63, dj = l % BLK;
             const int jbL = TX(cIsIg) ? jbIg : jbGeo;
             const int j = jbL >= 0 ? jbL + dj : -1;
             TX(jj) = j;
@@ -1563,7 +1578,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             prevRes[0] = dppMovD<0x111, 0xf>(res[0], res[0]); // row_shr:1 (the 8 bases of a chain state share a row)
 #endif
             FOR_WLANES(t, w) {
-                const int l = t & 63, dj = l & 7, j = TX(jj);
+                const int l = t & 63, dj = l % BLK, j = TX(jj);
                 if (dj == d) {
                     const double p0 = (d == 0 || j - 1 < 1) ? TX(psS) : TX(prevRes);
                     const double vs = p0 + TX(teS);
@@ -1600,20 +1615,20 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     int rtNext = 0;  // (far wavefront) next block, global index, whose RTERMINAL candidates are due
     int farPre = 0;  // (far wavefront) blocks below this index already have their far step (pre-run across the tile boundary)
     auto doRT = [&](int w, int buf, int tile, int k, int jbNow) { // jbNow: no igenic cell at or beyond it exists yet
-        const int bq = k - tile * BLK;
+        const int bq = k - tile * NB;
         const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
                   rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
         const int vigLo = jbNow - 1 - VIG_WIN > -1 ? jbNow - 1 - VIG_WIN : -1;
         if (rt1 > rt0) trellisItems(X, w, buf, bq, k * BLK, rt0, rt1, vigLo);
     };
     auto rtCatchUp = [&](int w, int buf, int tile, int igDone, int jbNow) {
-        if (rtNext < tile * BLK) rtNext = tile * BLK;
-        for (; rtNext < igDone && rtNext < (tile + 1) * BLK && rtNext * BLK < n; rtNext++) doRT(w, buf, tile, rtNext, jbNow);
+        if (rtNext < tile * NB) rtNext = tile * NB;
+        for (; rtNext < igDone && rtNext < (tile + 1) * NB && rtNext * BLK < n; rtNext++) doRT(w, buf, tile, rtNext, jbNow);
     };
     auto farStep = [&](int w, int buf, int jb) { // far fixed-lag states (class 2) and cell resets of the block starting at jb
         fixedStep(w, buf, jb, 4, nearRounds, FR);
         FOR_WLANES(t, w) {
-            const int l = t & 63, dj = l & 7, j = jb + dj;
+            const int l = t & 63, dj = l % BLK, j = jb + dj;
             (void)l;
             // cells of variable-length states are absent unless a candidate survives
 #pragma unroll
@@ -1635,7 +1650,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (w >= W_LOAD) {
                 // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
                 FOR_WLANES(t, w) {
-                    if (tile + 1 < nTiles) loadTileThread(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= 1);
+                    if (tile + 1 < nTiles) loadTileThread<BLK>(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= 1);
                     if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
                 addFlag(&L.staged); // (NWAVES - W_LOAD) counts per tile: the next tile is staged, its buffers are retired
@@ -1655,9 +1670,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // so that the cycle is candidates(b) -> near/late fixed-lag(b+1) -> candidates(b+1), with the chain states off it.
         PROF_MARK(X, 0);
         int nb = 0;
-        for (int blk = 0; blk < BLK && j0 + blk * BLK < n; blk++) {
+        for (int blk = 0; blk < NB && j0 + blk * BLK < n; blk++) {
             nb = blk + 1;
-            const int jb = j0 + blk * BLK, gbk = tile * BLK + blk;
+            const int jb = j0 + blk * BLK, gbk = tile * NB + blk;
             const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]),
                       itA = it0 + (int)L.blkSplit[buf][blk][0], itB = it0 + (int)L.blkSplit[buf][blk][1], itS = it0 + (int)L.blkSplit[buf][blk][2];
             FOR_WAVES(w) {
@@ -1713,7 +1728,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // ---- end of the tile: igenic of the last block, then the RTERMINAL candidates of the last two blocks
         FOR_WAVES(w) {
             if (w == W_C && nb > 0) {
-                const int gLast = tile * BLK + nb - 1, jbLast = j0 + (nb - 1) * BLK;
+                const int gLast = tile * NB + nb - 1, jbLast = j0 + (nb - 1) * BLK;
                 for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gLast + 1);
                 PROF_MARK(X, 1);
                 PROF_TSTAMP(X, tile == 124, 11);
@@ -1728,7 +1743,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // the next tile, as soon as the loaders have staged it
         FOR_WAVES(w) {
             if (w == W_X && nb > 0) {
-                const int gN = (tile + 1) * BLK, jbN = j0 + WAVE;
+                const int gN = (tile + 1) * NB, jbN = j0 + WAVE;
                 if (tile + 1 < nTiles && jbN < n) {
                     waitFlag(L, &L.staged, (NWAVES - W_LOAD) * (tile + 1));
                     for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gN - 2);
@@ -1738,7 +1753,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     setFlag(&L.flagN, gN + 1);
                     farPre = gN + 1;
                 }
-                if (rtNext < tile * BLK) rtNext = tile * BLK;
+                if (rtNext < tile * NB) rtNext = tile * NB;
                 FOR_WLANES(t, w) { if ((t & 63) == 0) L.rtPub = rtNext; }
                 if (wantCells) drainStores();
                 setFlag(&L.flagR, tile + 1);
@@ -1746,7 +1761,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         }
         FOR_WAVES(w) {
             if (w < NWORK && nb > 0) {
-                const int gEnd = tile * BLK + nb;
+                const int gEnd = tile * NB + nb;
                 waitFlag(L, &L.flagR, tile + 1);
                 const int k = readFlag(&L.rtPub) + w;
                 if (k < gEnd) { waitFlag(L, &L.flagC, gEnd); doRT(w, buf, tile, k, j0 + nb * BLK); }
@@ -1755,7 +1770,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         }
         FOR_WAVES(w) {
             if (w == W_X && nb > 0) {
-                const int gEnd = tile * BLK + nb;
+                const int gEnd = tile * NB + nb;
                 waitFlag(L, &L.flagC, gEnd);
                 for (int k = rtNext + NWORK; k < gEnd; k++) doRT(w, buf, tile, k, j0 + nb * BLK);
                 rtNext = gEnd;

@@ -1,6 +1,7 @@
 // layout.h -- host-side helpers shared by the HIP decoder and the test emulator: slot layout of a batch,
 // DevTables construction from augx_tables, buffer size bookkeeping.
 #pragma once
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -47,7 +48,7 @@ struct BatchSizes {
     }
 };
 
-inline void checkModelSupported(const augx_tables &t) {
+inline void checkModelSupported(const augx_tables &t, int BLK) {
     if (t.S > SP) throw std::runtime_error("augx: model has more than 48 states (UTR/nc models are not on the device path yet)");
     int dL = t.d - 2 - t.De - t.As - 2 - t.U;
     if (dL >= LONG_RING || dL <= BLK || (dL > WAVE - BLK && dL < WAVE)) throw std::runtime_error("augx: intron d out of the supported range");
@@ -107,7 +108,7 @@ inline void checkModelSupported(const augx_tables &t) {
         // single / initial exons reach back to an igenic cell at least this far (reference src/exonmodel.cc:1042-1054)
         int slack = t.W + t.min_exon_len - t.Ds;
         if (t.W < slack) slack = t.W;
-        if (slack < BLK) throw std::runtime_error("augx: trans_init_window too short for the block size of the trellis kernel (species not supported yet)");
+        if (slack < BLK) throw std::runtime_error("augx: trans_init_window too short for the block size of the trellis kernel");
     }
     {   // the fixed-lag states are laid out in rounds of 8: near / late states (lag < 3 blocks) first, then the far ones
         int nNear = 0, nFar = 0;
@@ -122,6 +123,24 @@ inline void checkModelSupported(const augx_tables &t) {
         if ((nNear + 7) / 8 + (nFar + 7) / 8 > 3) throw std::runtime_error("augx: too many fixed-length intron states for the trellis wavefront layout");
     }
     if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
+}
+
+// block size of the candidate / trellis kernels for this model: 8 where the species' windows allow it, else 4
+// (override for tests: AUGX_BLK=4).  Throws what checkModelSupported throws for the smallest size.
+inline int chooseBlockSize(const augx_tables &t) {
+    if (const char *e = getenv("AUGX_BLK")) {
+        const int b = atoi(e);
+        if (b != 8 && b != 4) throw std::runtime_error("augx: AUGX_BLK must be 8 or 4");
+        checkModelSupported(t, b);
+        return b;
+    }
+    try {
+        checkModelSupported(t, 8);
+        return 8;
+    } catch (std::exception &) {
+    }
+    checkModelSupported(t, 4);
+    return 4;
 }
 
 // fill the scalar part of DevTables; the caller sets the table pointers (device or host)

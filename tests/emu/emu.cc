@@ -37,8 +37,9 @@ extern "C" {
 // the dense ln V matrices piece after piece (len*S doubles each).
 int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *lnv, int32_t *status, int32_t *path_out,
                int32_t path_cap, int32_t *path_n, double *cells_out, int32_t *cls_out) {
+    int blk = 8;
     try {
-        checkModelSupported(*t);
+        blk = chooseBlockSize(*t);
     } catch (std::exception &e) {
         fprintf(stderr, "emu: %s\n", e.what());
         return AUGX_E_UNSUPPORTED;
@@ -105,20 +106,21 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
     for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g);
     // ---- K2a: candidates, tile by tile (first with buffers that are too small, to exercise the re-run path)
-    B.nBlk = B.N / BLK;
+    B.blk = blk;
+    B.nBlk = B.N / blk;
     B.blkCnt = zalloc<uint32_t>(B.nBlk * 2);
     B.blkSplit = zalloc<uint32_t>(B.nBlk * 3);
     B.blkOff = zalloc<uint64_t>(B.nBlk * 2);
     CandAlloc ca;
     B.candAlloc = &ca;
     CandLds *cl = new CandLds();
-    const int64_t nWg = (B.nBlk + NWAVES - 1) / NWAVES;
+    const int64_t nWg = B.N / WAVE; // one workgroup per tile of 64 bases
     B.pairCap = 16; B.itemCap = 64;
     B.pairRec = zalloc<uint16_t>(B.pairCap + 1);
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int attempt = 0; attempt < 2; attempt++) {
         ca.pairs = 0; ca.items = 0;
-        for (int64_t wg = 0; wg < nWg; wg++) candWorkgroup(T, B, *cl, wg);
+        for (int64_t wg = 0; wg < nWg; wg++) { if (blk == 8) candWorkgroup<8>(T, B, *cl, wg); else candWorkgroup<4>(T, B, *cl, wg); }
         if ((int64_t)ca.pairs <= B.pairCap && (int64_t)ca.items <= B.itemCap) break;
         free(B.pairRec); free(B.items);
         B.pairCap = (int64_t)ca.pairs; B.itemCap = (int64_t)ca.items;
@@ -136,7 +138,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     // ---- K2b, K3
     TrellisLds *lds = new TrellisLds();
     for (int p = 0; p < n; p++) {
-        trellisPiece(T, B, *lds, p);
+        if (blk == 8) trellisPiece<8>(T, B, *lds, p); else trellisPiece<4>(T, B, *lds, p);
         backtracePiece(T, B, p);
     }
     delete lds;
