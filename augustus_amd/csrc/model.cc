@@ -516,6 +516,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
             r.need(tag);
             r.need("[P_ls]");
             r.comment();
+            std::vector<double> plsK[3]; // order-k pattern probabilities (old-format files derive the emissions from them)
+            for (int f = 0; f < 3; f++) plsK[f].assign(NP, 0.0);
             for (int l = 0; l <= k; l++) {
                 r.comment();
                 (void)r.readInt();
@@ -524,8 +526,11 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
                     r.comment();
                     int pn = r.readPattern(l + 1);
                     if (pn != j) throw ConfigError("ExonModel::readProbabilities: Error reading file " + r.path() + " at P_ls");
-                    for (int f = 0; f < 3; f++)
-                        ex_pls[(((size_t)c * (k + 1) + l) * 3 + f) * NP + j] = lnp(r.readDouble());
+                    for (int f = 0; f < 3; f++) {
+                        const double pr = r.readDouble();
+                        ex_pls[(((size_t)c * (k + 1) + l) * 3 + f) * NP + j] = lnp(pr);
+                        if (l == k) plsK[f][j] = pr;
+                    }
                 }
             }
             r.need("[TRANSINIT]");
@@ -545,17 +550,25 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
                 r.seek(sp1);
             size_t sp2 = r.tell();
             if (!r.gotoLineAfter("[EMISSION]")) {
+                // old parameter files: the emissions are the order-k pattern probabilities normalised over the last base
+                // (reference StateModel::computeEmiFromPat, src/statemodel.cc:175-190; src/exonmodel.cc:730-737)
                 r.seek(sp2);
-                throw UnsupportedError("exon parameter file without [EMISSION] section (old format) not supported");
-            }
-            r.comment(); (void)r.readInt();
-            r.comment(); (void)r.readInt();
-            r.comment(); (void)r.readDouble();
-            for (int i = 0; i < NP; i++) {
-                r.comment();
-                int pn = r.readPattern(k + 1);
-                if (pn != i) throw ConfigError("ExonModel::readProbabilities: Error reading file " + r.path() + " at EMISSION");
-                for (int f = 0; f < 3; f++) ex_emi[((size_t)c * 3 + f) * NP + i] = lnp(r.readDouble());
+                for (int f = 0; f < 3; f++)
+                    for (int i = 0; i < NP; i += 4) {
+                        const double sum = plsK[f][i] + plsK[f][i + 1] + plsK[f][i + 2] + plsK[f][i + 3];
+                        for (int nuk = 0; nuk < 4; nuk++)
+                            ex_emi[((size_t)c * 3 + f) * NP + i + nuk] = lnp(k > 0 ? plsK[f][i + nuk] / sum : plsK[f][i + nuk]);
+                    }
+            } else {
+                r.comment(); (void)r.readInt();
+                r.comment(); (void)r.readInt();
+                r.comment(); (void)r.readDouble();
+                for (int i = 0; i < NP; i++) {
+                    r.comment();
+                    int pn = r.readPattern(k + 1);
+                    if (pn != i) throw ConfigError("ExonModel::readProbabilities: Error reading file " + r.path() + " at EMISSION");
+                    for (int f = 0; f < 3; f++) ex_emi[((size_t)c * 3 + f) * NP + i] = lnp(r.readDouble());
+                }
             }
             auto readSparse = [&](const char *sec, std::vector<double> &dst) {
                 r.need(sec);
@@ -705,16 +718,20 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
                 }
             }
             size_t sp = r.tell();
-            if (!r.gotoLineAfter("[EMISSION]")) {
+            if (!r.gotoLineAfter("[EMISSION]")) { // old parameter files (reference src/igenicmodel.cc:196-204, computeEmiFromPat)
                 r.seek(sp);
-                throw UnsupportedError("igenic parameter file without [EMISSION] section (old format) not supported");
-            }
-            r.comment(); (void)r.readInt();
-            for (int j = 0; j < NP; j++) {
-                r.comment();
-                int pn = r.readPattern(k + 1);
-                if (pn != j) throw ConfigError("IgenicModel::readProbabilities: Error reading file " + r.path() + " at EMISSION");
-                ig_emi[(size_t)c * NP + j] = lnp(r.readDouble());
+                for (int i = 0; i < NP; i += 4) {
+                    const double sum = pls[k][i] + pls[k][i + 1] + pls[k][i + 2] + pls[k][i + 3];
+                    for (int nuk = 0; nuk < 4; nuk++) ig_emi[(size_t)c * NP + i + nuk] = lnp(k > 0 ? pls[k][i + nuk] / sum : pls[k][i + nuk]);
+                }
+            } else {
+                r.comment(); (void)r.readInt();
+                for (int j = 0; j < NP; j++) {
+                    r.comment();
+                    int pn = r.readPattern(k + 1);
+                    if (pn != j) throw ConfigError("IgenicModel::readProbabilities: Error reading file " + r.path() + " at EMISSION");
+                    ig_emi[(size_t)c * NP + j] = lnp(r.readDouble());
+                }
             }
             if (tie) // reference IGenicModel::updateToLocalGC, src/igenicmodel.cc:69-81
                 for (int j = 0; j < NP; j++) ig_emi[(size_t)c * NP + j] = in_emi[(size_t)c * NP + j];

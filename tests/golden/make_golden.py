@@ -6,7 +6,7 @@ Outputs
   inputs.fa                 the fixed test inputs (examples/example.fa records + seeded synthetic/edge records)
   golden_paths_<cfg>.json   per record: ln Viterbi score (%.17g) and the raw state path, from oracle/_ref/ref_harness
   golden_<cfg>.gff          the reference binary's GFF for the same inputs (prediction part only)
-for cfg in {human, human_nosm, fly}.
+for cfg in {human, human_nosm, fly, arabidopsis}.
 """
 import json
 import os
@@ -21,6 +21,8 @@ CFGS = {
     "human": ("human", []),
     "human_nosm": ("human", ["--softmasking=0"]),
     "fly": ("fly", ["--UTR=off", "--sample=0", "--softmasking=0"]),
+    # old parameter-file format (no [EMISSION] sections) and a donor window of 8 bases: block size 4 on the device
+    "arabidopsis": ("arabidopsis", ["--UTR=off", "--sample=0", "--softmasking=0"]),
 }
 
 

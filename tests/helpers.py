@@ -26,7 +26,8 @@ def config_path():
     """AUGUSTUS_CONFIG_PATH-style directory: extracted from the committed fixture (works on the GPU box)."""
     global _cfg_dir
     if _cfg_dir is None:
-        d = os.path.join(tempfile.gettempdir(), "augx_config_%d" % os.getuid())
+        tar = os.path.join(GOLDEN, "config_min.tar.gz")
+        d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d" % (os.getuid(), os.path.getsize(tar)))
         marker = os.path.join(d, "config", "model", "states_shadow.cfg")
         if not os.path.exists(marker):
             os.makedirs(d, exist_ok=True)
@@ -128,6 +129,7 @@ GOLDEN_CFGS = {
     "human": ("human", {}),
     "human_nosm": ("human", {"softmasking": "0"}),
     "fly": ("fly", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+    "arabidopsis": ("arabidopsis", {"UTR": "off", "sample": "0", "softmasking": "0"}),
 }
 
 

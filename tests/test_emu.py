@@ -38,7 +38,7 @@ def test_emulated_interior_piece_kinds():
         assert path == [(b, e, s) for b, e, s, t in path2]
 
 
-@pytest.mark.parametrize("species", ["human", "fly"])
+@pytest.mark.parametrize("species", ["human", "fly", "arabidopsis"])
 def test_emulated_ragged_lengths(species):
     """Edge lengths around the tile (64) and block (8) sizes, a one-base piece, and a ragged batch."""
     m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])

@@ -117,7 +117,7 @@ def test_cli_piece_cutting_matches_reference(tmp_path):
     assert gff_body(ours.stdout) == gff_body(ref.stdout)
 
 
-@pytest.mark.parametrize("species", ["human", "fly"])
+@pytest.mark.parametrize("species", ["human", "fly", "arabidopsis"])
 def test_gpu_ragged_lengths(species):
     """Edge lengths around the tile (64) and block (8) sizes, a one-base piece, ragged batch: bit-identical to the oracle."""
     m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
