@@ -424,7 +424,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
             if (d->blk == 8) hipLaunchKernelGGL(kCand<8>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-            else hipLaunchKernelGGL(kCand<4>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+            else if (d->blk == 4) hipLaunchKernelGGL(kCand<4>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+            else hipLaunchKernelGGL(kCand<2>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
             HIP_TRY(hipGetLastError());
             CandAlloc tot;
             HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));
@@ -448,7 +449,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     if (d->blk == 8) hipLaunchKernelGGL(kTrellis<8>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-    else hipLaunchKernelGGL(kTrellis<4>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+    else if (d->blk == 4) hipLaunchKernelGGL(kTrellis<4>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+    else hipLaunchKernelGGL(kTrellis<2>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);

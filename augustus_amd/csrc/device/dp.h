@@ -48,8 +48,8 @@ constexpr uint32_t KEY_MASK = (1u << KEY_BITS) - 1;
 constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >= -(3 + W) - 1 for a left-truncated initial exon)
 constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
 // bases per trellis block (template parameter BLK of the candidate and trellis kernels): smaller than every lag of the
-// model except the lag-1 chain states.  8 where the species' windows allow it, else 4 (layout.h: chooseBlockSize)
-constexpr int MAXNB = 16;                    // blocks per tile of 64 bases at the smallest block size
+// model except the lag-1 chain states.  8 where the species' windows allow it, else 4 or 2 (layout.h: chooseBlockSize)
+constexpr int MAXNB = 32;                    // blocks per tile of 64 bases at the smallest block size (2)
 
 struct CandAlloc;
 // one possible start of a short intron (entry of the LD / RD candidate lists): everything a lessD candidate needs of it,

@@ -125,22 +125,24 @@ inline void checkModelSupported(const augx_tables &t, int BLK) {
     if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
 }
 
-// block size of the candidate / trellis kernels for this model: 8 where the species' windows allow it, else 4
+// block size of the candidate / trellis kernels for this model: 8 where the species' windows allow it, else 4 or 2
 // (override for tests: AUGX_BLK=4).  Throws what checkModelSupported throws for the smallest size.
 inline int chooseBlockSize(const augx_tables &t) {
     if (const char *e = getenv("AUGX_BLK")) {
         const int b = atoi(e);
-        if (b != 8 && b != 4) throw std::runtime_error("augx: AUGX_BLK must be 8 or 4");
+        if (b != 8 && b != 4 && b != 2) throw std::runtime_error("augx: AUGX_BLK must be 8, 4 or 2");
         checkModelSupported(t, b);
         return b;
     }
-    try {
-        checkModelSupported(t, 8);
-        return 8;
-    } catch (std::exception &) {
+    for (int b = 8; b > 2; b /= 2) {
+        try {
+            checkModelSupported(t, b);
+            return b;
+        } catch (std::exception &) {
+        }
     }
-    checkModelSupported(t, 4);
-    return 4;
+    checkModelSupported(t, 2);
+    return 2;
 }
 
 // fill the scalar part of DevTables; the caller sets the table pointers (device or host)

@@ -120,7 +120,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int attempt = 0; attempt < 2; attempt++) {
         ca.pairs = 0; ca.items = 0;
-        for (int64_t wg = 0; wg < nWg; wg++) { if (blk == 8) candWorkgroup<8>(T, B, *cl, wg); else candWorkgroup<4>(T, B, *cl, wg); }
+        for (int64_t wg = 0; wg < nWg; wg++) { if (blk == 8) candWorkgroup<8>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4>(T, B, *cl, wg); else candWorkgroup<2>(T, B, *cl, wg); }
         if ((int64_t)ca.pairs <= B.pairCap && (int64_t)ca.items <= B.itemCap) break;
         free(B.pairRec); free(B.items);
         B.pairCap = (int64_t)ca.pairs; B.itemCap = (int64_t)ca.items;
@@ -138,7 +138,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     // ---- K2b, K3
     TrellisLds *lds = new TrellisLds();
     for (int p = 0; p < n; p++) {
-        if (blk == 8) trellisPiece<8>(T, B, *lds, p); else trellisPiece<4>(T, B, *lds, p);
+        if (blk == 8) trellisPiece<8>(T, B, *lds, p); else if (blk == 4) trellisPiece<4>(T, B, *lds, p); else trellisPiece<2>(T, B, *lds, p);
         backtracePiece(T, B, p);
     }
     delete lds;
