@@ -26,7 +26,7 @@ oracle/libghmm_twin.so: oracle/ghmm_twin.cc include/augx.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/ghmm_twin.cc
 
 emu: build/libaugx_emu.so
-build/libaugx_emu.so: tests/emu/emu.cc $(DEVHDR)
+build/libaugx_emu.so: tests/emu/emu.cc $(DEVHDR) include/augx.h
 	@mkdir -p build
 	$(CXX) $(CXXFLAGS) -shared -o $@ tests/emu/emu.cc
 

@@ -21,7 +21,7 @@ extern "C" {
 
 #define AUGX_MAX_STATES 80
 #define AUGX_MAX_ANC 8
-#define AUGX_MAX_CLASSES 8
+#define AUGX_MAX_CLASSES 16
 /* Markov-chain content sums are accumulated in fixed point (ln p * 2^40 rounded to int64, wrap-around
  * uint64 adds): exactly associative, so device scans of any shape give bit-identical prefix differences. */
 #define AUGX_FX_SHIFT 40
