@@ -320,7 +320,6 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     BatchView &V = b->V;
     memset(&V, 0, sizeof V);
     V.nPieces = n; V.N = L.N; V.nChunks = L.nChunks;
-    { const char *df = getenv("AUGX_DBG_FLAGS"); V.dbgFlags = df ? atoi(df) : 0; }
     int rc = 0;
 #define DA(field, T, count) do { T *_p = nullptr; rc = devAlloc(b, &_p, (count)); if (rc) { augx_batch_destroy(b); return rc; } field = _p; } while (0)
     int64_t *dOff; int32_t *dLen, *dIk, *dTk, *dCp; char *dRaw;

@@ -76,7 +76,6 @@ struct BatchView {
     int nPieces;
     int64_t N;                 // total slots
     int nChunks;
-    int dbgFlags;              // timing experiments only (AUGX_DBG_FLAGS): 1 skip phase B, 2 skip B2/B3, 4 skip phase C stores
     const int64_t *off;        // [nPieces+1]
     const int32_t *len;        // [nPieces]
     const int32_t *initKind, *termKind;

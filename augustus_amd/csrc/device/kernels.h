@@ -716,7 +716,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
 #ifdef AUGX_EMU
         if (!fast) g_emuSlowA++;
 #endif
-        if (!fast) nep = (B.dbgFlags & 16) ? AUGX_NINF : exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
+        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
         if (!(nep > AUGX_NINF)) return;
         te = (VC.tr[0] + D.endP) + nep;
         key = eop + KEY_BIAS;
@@ -770,7 +770,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
 #ifdef AUGX_EMU
         if (!fast) g_emuSlowB++;
 #endif
-        if (!fast) nep = (B.dbgFlags & 16) ? AUGX_NINF : exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
+        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
     }
     if (!(nep > AUGX_NINF)) return;
     // exactly one of the (up to three) ancestors has the reading frame that fits the exon length
@@ -894,8 +894,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                     if (it < totalItems) {
                         const int q = TX(myPair);
                         double te; int key; uint32_t src;
-                        if (B.dbgFlags & 32) { te = AUGX_NINF; key = 0; src = 0; }
-                        else varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
+                        varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
                         if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
                         Item I;
                         I.te = te; I.kp = ((uint32_t)(done + q) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
@@ -973,9 +972,11 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 }
 
 // =================================================================================================
-// K2b  trellis: one workgroup of NWAVES wavefronts per piece.  Wavefront 0 walks the piece, block by block, with no
-// workgroup barrier inside a tile of 64 bases; the other wavefronts stage the next tile (signal records, candidates)
-// into the second half of the LDS buffers and flush the back pointers of the previous one.
+// K2b  trellis: one workgroup of NWAVES wavefronts per piece.  Five wavefronts (three candidate workers, the chain
+// wavefront, the far wavefront) walk the piece block by block, synchronised by progress counters in LDS, with no
+// workgroup barrier inside a tile of 64 bases; the loader wavefronts stage the next tile (signal records, candidates)
+// into the second half of the LDS buffers and retire the previous one (back pointers, igenic column, long-lag cells,
+// list values) to HBM.  See trellisPiece for the schedule and DESIGN.md section 5 for the reasoning.
 // =================================================================================================
 constexpr int NWORK = 3, W_C = 3, W_X = 4, W_LOAD = 5; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4 far fixed-lag states, 5.. loaders
 constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM)
