@@ -142,7 +142,7 @@ def main():
                          "prep_ms": float(np.mean(prep_ms)), "backtrace_ms": float(np.mean(back_ms)),
                          "positions_per_s_per_piece": a.contig_len / tr_s},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:  # the reference's CPU path, timed beside it (rank 0, N = 1 only)
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample_bp)
         print(json.dumps(out))
     if dist is not None:
