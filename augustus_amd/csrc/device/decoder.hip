@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B)
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1Signals(*T, B, g);
 }
+__global__ void __launch_bounds__(256) kSiteSignals(const DevTables *T, BatchView B) {
+    k1SiteSignals(*T, B, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
+}
 __global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView B) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1SiteConsts(*T, B, g);
@@ -402,6 +405,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kFxTerms, dim3(gridN), dim3(256), 0, st, d->dT, V);
     if ((rc = runScan<false>(b, V.fx, NFX))) return rc;
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.N / 2 + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn

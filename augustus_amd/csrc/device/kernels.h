@@ -267,11 +267,10 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     sg[SIG_EIG] = q >= 1 ? eIg(P, q) : AUGX_NINF;
     sg[SIG_EIN] = eIn(P, q);
     // fixed-length intron states ending at q: gate && emission (reference src/intronmodel.cc:690-717,861-923)
-    if (q - dssWhole >= 0 && P.possDSS(q - T.De - 2 + 1)) sg[SIG_DSSF] = dssProb(P, q - dssWhole + 1, true);
-    if (q - dssWhole >= 0 && P.possRDSS(q - T.Ds)) sg[SIG_DSSR] = dssProb(P, q - dssWhole + 1, false);
-    if (q - assWhole - T.U >= 0 && P.possASS(q - T.Ae)) sg[SIG_ASSF] = assProb(P, q - assWhole - T.U + 1, true);
-    if (q - assWhole - T.U >= 0 && P.possRASS(q - T.U - T.As - 2 + 1)) sg[SIG_ASSR] = assProb(P, q - assWhole - T.U + 1, false);
-    sg[SIG_TISF] = tisFwd(P, q);
+    // (the splice-site records SIG_DSSF/DSSR/ASSF/ASSR are filled by k1SiteSignals, one thread per site instead of one
+    //  per base: their motif loops would otherwise run with one lane in sixteen active.  SIG_TISF is not used: the
+    //  start-codon records carry the translation-initiation term, see k1SiteConsts)
+    (void)dssWhole; (void)assWhole;
     sg[SIG_TISR] = tisRev(P, q);
     sg[SIG_STOPF] = exEndPart(P, AUGX_K_TERMINAL, 0, q, AUGX_NINF); // ln P(stop codon ending at q), -inf if none
     // list index of the site ending at q (prefix count - 1), -1 if q is not such a site
@@ -307,6 +306,26 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
             if (open) gate |= 1ull << s;
         }
     B.gate[g] = gate;
+}
+
+// splice-site signal records: one thread per entry t of the four candidate lists (sel: 0 forward acceptor, 1 reverse
+// donor, 2 forward donor, 3 reverse acceptor); reference IntronModel::aSSProb / dSSProb via emiProbUnderModel,
+// src/intronmodel.cc:690-717,861-923.  Runs after k1Signals (which has reset the records and filled the positions).
+AUGX_HD void k1SiteSignals(const DevTables &T, const BatchView &B, int64_t t, int sel) {
+    if (t >= B.N / 2) return;
+    const int p = B.chunkPiece[(2 * t) / CHUNK];
+    if (B.cls[p] < 0) return;
+    const int64_t o = B.off[p], lo = listOff(B, p), li = t - lo;
+    const int n = B.len[p];
+    if (li < 0 || li >= (int64_t)B.cnt[fidx(o + n, CNT_LA + sel, NCNT)]) return;
+    Piece P = makePiece(T, B, p);
+    const int q = sel == 0 ? B.laPos[lo + li] : sel == 1 ? B.lrPos[lo + li] : sel == 2 ? B.ldEnt[lo + li].pos : B.rdEnt[lo + li].pos;
+    const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
+    double *sg = B.sig + (o + 1 + q) * NSIG;
+    if (sel == 2) { if (q - dssWhole >= 0) sg[SIG_DSSF] = dssProb(P, q - dssWhole + 1, true); }
+    else if (sel == 1) { if (q - dssWhole >= 0) sg[SIG_DSSR] = dssProb(P, q - dssWhole + 1, false); }
+    else if (sel == 0) { if (q - assWhole - T.U >= 0) sg[SIG_ASSF] = assProb(P, q - assWhole - T.U + 1, true); }
+    else { if (q - assWhole - T.U >= 0) sg[SIG_ASSR] = assProb(P, q - assWhole - T.U + 1, false); }
 }
 
 // candidate-side constants of the list entries (everything a candidate contributes that does not depend on Viterbi

@@ -104,6 +104,8 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     for (int64_t g = 0; g < B.N; g++) k1FxTerms(T, B, g);
     scanFields<false>(B.fx, NFX, L);
     for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
+    for (int sel = 0; sel < 4; sel++)
+        for (int64_t t2 = 0; t2 < B.N / 2; t2++) k1SiteSignals(T, B, t2, sel);
     for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g);
     // ---- K2a: candidates, tile by tile (first with buffers that are too small, to exercise the re-run path)
     B.blk = blk;
