@@ -164,7 +164,7 @@ struct augx_batch {
     std::vector<const char *> hostSeq; // caller-owned sequences (used only by the GC-stairs fallback below)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
     uint64_t nItems = 0, nPairs = 0;
-    void *pairBuf = nullptr, *itemBuf = nullptr; // candidate buffers, sized per decode (kept while large enough)
+    void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
     bool decoded = false;
 };
 
@@ -297,7 +297,6 @@ void augx_batch_destroy(augx_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->dec->device);
     for (void *p : b->bufs) (void)hipFree(p);
-    if (b->pairBuf) (void)hipFree(b->pairBuf);
     if (b->itemBuf) (void)hipFree(b->itemBuf);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
@@ -413,15 +412,14 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         BatchView &W = b->V;
         const unsigned nWg = (unsigned)(W.N / WAVE); // one workgroup per tile of 64 bases
         if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
-            W.pairCap = W.N * 2 + 4096; W.itemCap = W.N * 18 + 65536;
-            HIP_TRY(hipMalloc(&b->pairBuf, (size_t)W.pairCap * sizeof(uint16_t)));
+            W.itemCap = W.N * 18 + 65536;
             if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
                 (void)hipGetLastError();
                 b->itemBuf = nullptr;
                 setLastError("augx_batch_decode: out of device memory for the candidate buffer; decode fewer bases per batch");
                 return AUGX_E_NOMEM;
             }
-            W.pairRec = (uint16_t *)b->pairBuf; W.items = (Item *)b->itemBuf;
+            W.items = (Item *)b->itemBuf;
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
         for (int attempt = 0;; attempt++) {
@@ -434,19 +432,18 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             b->nPairs = tot.pairs; b->nItems = tot.items;
-            if ((int64_t)tot.pairs <= W.pairCap && (int64_t)tot.items <= W.itemCap) break;
+            if ((int64_t)tot.items <= W.itemCap) break;
             if (attempt > 0) { setLastError("augx_batch_decode: candidate buffers overflowed twice"); return AUGX_E_HIP; }
-            HIP_TRY(hipFree(b->pairBuf)); HIP_TRY(hipFree(b->itemBuf));
-            b->pairBuf = b->itemBuf = nullptr;
-            W.pairCap = (int64_t)tot.pairs + 64; W.itemCap = (int64_t)tot.items + 64;
-            HIP_TRY(hipMalloc(&b->pairBuf, (size_t)W.pairCap * sizeof(uint16_t)));
+            HIP_TRY(hipFree(b->itemBuf));
+            b->itemBuf = nullptr;
+            W.itemCap = (int64_t)tot.items + 64;
             if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
                 (void)hipGetLastError();
                 b->itemBuf = nullptr;
                 setLastError("augx_batch_decode: out of device memory for the candidate buffer (" + std::to_string(tot.items) + " candidates); decode fewer bases per batch");
                 return AUGX_E_NOMEM;
             }
-            W.pairRec = (uint16_t *)b->pairBuf; W.items = (Item *)b->itemBuf;
+            W.items = (Item *)b->itemBuf;
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
     }

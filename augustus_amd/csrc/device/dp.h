@@ -40,7 +40,7 @@ constexpr int LENI_MAX = 1024;  // intron length distribution cached in LDS when
 // one candidate of a variable-length state: everything but the predecessor's Viterbi value (kCandidates -> kTrellis)
 struct Item {
     double te;      // ln(transition * emission) of the candidate, -inf if infeasible
-    uint32_t kp;    // [31:22] index of the (base, state) pair inside its block, [21:0] tie-break key = eop + KEY_BIAS
+    uint32_t kp;    // [31:22] the (base, state) pair: (base offset in the block << 6) | state, [21:0] tie-break key = eop + KEY_BIAS
     uint32_t src;   // where the predecessor value lives: [31:30] tag, [29:28] ancestor index, [27:0] payload
 };
 constexpr int KEY_BITS = 22;                 // pieces on the device path are shorter than 2^22 bases
@@ -115,9 +115,8 @@ struct BatchView {
     uint32_t *blkSplit;              // [nBlk][3] items of the block up to the pair boundaries near 1/3 and 2/3 / of all states but RTERMINAL (they come first)
     uint64_t *blkOff;                // [nBlk][2] first pair / first item of the block (the blocks of a tile are contiguous)
     struct CandAlloc *candAlloc;     // running totals of pairs / items handed out to tiles
-    uint16_t *pairRec;               // [pairs] (base offset in block << 8) | state
     Item *items;                     // [items]
-    int64_t pairCap, itemCap;
+    int64_t itemCap;
     // results
     double *lnv;               // [nPieces]
     int32_t *status;           // [nPieces]

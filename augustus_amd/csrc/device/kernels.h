@@ -817,7 +817,7 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
 // candidates of block b (bases 8b .. 8b+7) of piece X.p, by wavefront w of the workgroup.  The pairs are ordered: all
 // states but RTERMINAL (by base, then state), then RTERMINAL.  Rounds of 64 pairs (one block rarely has more).
 //   write == false: describe + count; results in cnt[] = {pairs, items, items of non-RTERMINAL pairs, mid1, mid2}
-//   write == true : emit pairRec / items at pairBase / itemBase.  If the block had a single round, the descriptors
+//   write == true : emit the items at itemBase.  If the block had a single round, the descriptors
 //                   left in LDS by the counting call are reused.
 template <int BLK>
 AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, bool mayReuse, uint64_t maskVar, uint64_t maskRT, uint64_t pairBase,
@@ -876,7 +876,6 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                     varDescribe(X, s2, jb + dj, L.desc[w][l]);
                     TX(tot) = L.desc[w][l].total;
                 }
-                if (write) B.pairRec[pairBase + done + l] = (uint16_t)(((L.pairJ[w][l] - jb) << 8) | L.pairS[w][l]);
             }
         }
         WAVE_SYNC();
@@ -916,7 +915,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                         varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
                         if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
                         Item I;
-                        I.te = te; I.kp = ((uint32_t)(done + q) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+                        I.te = te; I.kp = ((uint32_t)(((L.pairJ[w][q] - jb) << 6) | L.pairS[w][q]) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
                         B.items[itemBase + itemsDone + it] = I;
                     }
                 }
@@ -967,7 +966,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
             const unsigned long long bp0 = atomicAdd(&B.candAlloc->pairs, np), bi0 = atomicAdd(&B.candAlloc->items, ni);
 #endif
             L.baseW[0] = bp0; L.baseW[1] = bi0;
-            L.fits = (bp0 + np <= (unsigned long long)B.pairCap && bi0 + ni <= (unsigned long long)B.itemCap) ? 1 : 0;
+            L.fits = bi0 + ni <= (unsigned long long)B.itemCap ? 1 : 0;
         }
     }
     BLOCK_SYNC();
@@ -999,7 +998,6 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // =================================================================================================
 constexpr int NWORK = 3, W_C = 3, W_X = 4, W_LOAD = 5; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4 far fixed-lag states, 5.. loaders
 constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM)
-constexpr int PAIR_CAP = 512;
 
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
@@ -1012,7 +1010,6 @@ struct TrellisLds {
     uint32_t blkSplit[2][MAXNB][3]; // candidates: end of the first / second third, end of all states but RTERMINAL
     int32_t listTop[2][MAXNB][4];   // newest entry of each candidate list at the end of each block
     Item items[2][ITEM_CAP];
-    uint16_t pairRec[2][PAIR_CAP];
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
@@ -1152,7 +1149,6 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     const int64_t gbL = gb0 + NB - 1 < B.nBlk ? gb0 + NB - 1 : B.nBlk - 1; // last block of the tile
     // (the candidate / pair ranges first: the loads that depend on them then overlap with everything else)
     const uint64_t firstI = gp(B.blkOff)[gb0 * 2 + 1], lastI = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
-    const uint64_t firstP = gp(B.blkOff)[gb0 * 2], lastP = gp(B.blkOff)[gbL * 2] + gp(B.blkCnt)[gbL * 2];
     constexpr int KSIG = (WAVE * NSIG + 191) / 192, KSITE = (WAVE * NSITE + 191) / 192, KEQ = (WAVE * 6 + 191) / 192;
     double vSig[KSIG], vEq[KEQ];
     int vSite[KSITE];
@@ -1188,17 +1184,13 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         if (q > n - 1) q = n - 1;
         vTop = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + tid % 4, NCNT)] - 1;
     }
-    constexpr int KI = (ITEM_CAP + 191) / 192, KP = (PAIR_CAP + 191) / 192;
+    constexpr int KI = (ITEM_CAP + 191) / 192;
     const int cntI = lastI - firstI < (uint64_t)ITEM_CAP ? (int)(lastI - firstI) : ITEM_CAP;
-    const int cntP = lastP - firstP < (uint64_t)PAIR_CAP ? (int)(lastP - firstP) : PAIR_CAP;
     Item vItem[KI];
-    uint16_t vPair[KP];
     {
         const Item *gi = B.items + firstI;
 #pragma unroll
         for (int k = 0; k < KI; k++) { const int i = tid + k * nth; vItem[k] = ldItem(gi + (i < cntI ? i : 0)); }
-#pragma unroll
-        for (int k = 0; k < KP; k++) { const int i = tid + k * nth; vPair[k] = i < cntP ? gp(B.pairRec)[firstP + i] : (uint16_t)0; }
     }
     // ---- second phase
 #pragma unroll
@@ -1232,8 +1224,6 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     if (tid < NB * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
 #pragma unroll
     for (int k = 0; k < KI; k++) { const int i = tid + k * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
-#pragma unroll
-    for (int k = 0; k < KP; k++) { const int i = tid + k * nth; if (i < cntP) L.pairRec[buf][i] = vPair[k]; }
 }
 // retire tile `tile` (LDS buffer buf) to HBM: back pointers (and reset of their buffer), igenic column, long-lag cells.
 // (The trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles.)
@@ -1263,8 +1253,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int S = X.S;
-    const uint64_t tileItem0 = L.blkOff[buf][0][1], tilePair0 = L.blkOff[buf][0][0];
-    const int prBase = (int)(L.blkOff[buf][blk][0] - tilePair0);
+    const uint64_t tileItem0 = L.blkOff[buf][0][1];
     // list entries at or below topK have (or may have: the far fixed-lag wavefront runs up to two blocks = LIST_AHEAD
     // entries ahead) left the LDS cache of the newest LIST_WIN entries
     constexpr int LIST_AHEAD = 32;
@@ -1314,9 +1303,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
         FOR_WLANES(t, w) { // the last lane of every segment publishes (a pair continuing in the next chunk is overwritten there)
             const uint32_t k2 = TX(kp);
             if (k2 != 0xFFFFFFFFu && (TX(nkp) >> KEY_BITS) != (k2 >> KEY_BITS) && TX(val) > AUGX_NINF) {
-                const int pi = prBase + (int)(k2 >> KEY_BITS);
-                const uint16_t pr = pi < PAIR_CAP ? L.pairRec[buf][pi] : gp(B.pairRec)[tilePair0 + pi];
-                const int j = jb + (pr >> 8), st = pr & 0xFF;
+                const int j = jb + (int)(k2 >> (KEY_BITS + 6)), st = (int)(k2 >> KEY_BITS) & 63; // the pair id is (base offset, state)
                 const int eop = (int)(k2 & KEY_MASK) - KEY_BIAS;
                 L.ring[j & 63][st] = TX(val);
                 L.bp[buf][j & 63][st] = bpVar((int)((TX(src) >> 28) & 3), j - eop);

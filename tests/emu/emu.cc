@@ -117,23 +117,21 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.candAlloc = &ca;
     CandLds *cl = new CandLds();
     const int64_t nWg = B.N / WAVE; // one workgroup per tile of 64 bases
-    B.pairCap = 16; B.itemCap = 64;
-    B.pairRec = zalloc<uint16_t>(B.pairCap + 1);
+    B.itemCap = 64;
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int attempt = 0; attempt < 2; attempt++) {
         ca.pairs = 0; ca.items = 0;
         for (int64_t wg = 0; wg < nWg; wg++) { if (blk == 8) candWorkgroup<8>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4>(T, B, *cl, wg); else candWorkgroup<2>(T, B, *cl, wg); }
-        if ((int64_t)ca.pairs <= B.pairCap && (int64_t)ca.items <= B.itemCap) break;
-        free(B.pairRec); free(B.items);
-        B.pairCap = (int64_t)ca.pairs; B.itemCap = (int64_t)ca.items;
-        B.pairRec = zalloc<uint16_t>(B.pairCap + 1);
+        if ((int64_t)ca.items <= B.itemCap) break;
+        free(B.items);
+        B.itemCap = (int64_t)ca.items;
         B.items = zalloc<Item>(B.itemCap + 1);
     }
     delete cl;
     if (getenv("AUGX_EMU_STATS")) {
         int64_t dead = 0, byTag[3] = {0, 0, 0};
         for (int64_t i = 0; i < (int64_t)ca.items; i++) { if (!(B.items[i].te > AUGX_NINF)) dead++; else byTag[B.items[i].src >> 30]++; }
-        fprintf(stderr, "emu stats: N=%lld pairs=%lld items=%lld dead=%lld live list=%lld vig=%lld col0=%lld\n", (long long)B.N, (long long)B.pairCap,
+        fprintf(stderr, "emu stats: N=%lld pairs=%lld items=%lld dead=%lld live list=%lld vig=%lld col0=%lld\n", (long long)B.N, (long long)ca.pairs,
                 (long long)B.itemCap, (long long)dead, (long long)byTag[0], (long long)byTag[1], (long long)byTag[2]);
         fprintf(stderr, "emu stats: general-path evaluations: igenic-pred %lld, list exon %lld\n", g_emuSlowA, g_emuSlowB);
     }
@@ -164,7 +162,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             w += (int64_t)L.len[p] * t->S;
         }
     }
-    free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.pairRec); free(B.items);
+    free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.items);
     free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
     free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldEnt); free(B.ldVal);
     free(B.rdEnt); free(B.rdVal); free(B.atgPos); free(B.pathRec);
