@@ -1006,7 +1006,8 @@ struct TrellisLds {
     int32_t site[2][WAVE][NSITE];
     double eqPrev[2][WAVE][6];      // predecessor cells of the equalD states (lag dStateLen)
     double longW[2][WAVE][6];       // cells of the states equalD reads back at lag dStateLen (flushed to HBM tile by tile)
-    uint64_t blkOff[2][MAXNB + 1][2]; // pair / item offsets of the blocks of the tile
+    uint64_t tileItem0[2];            // first candidate of the tile (index into the batch's candidate buffer)
+    int32_t blkItem[2][MAXNB + 1];    // first candidate of each block relative to the tile ([NB] = end of the tile)
     uint32_t blkSplit[2][MAXNB][3]; // candidates: end of the first / second third, end of all states but RTERMINAL
     int32_t listTop[2][MAXNB][4];   // newest entry of each candidate list at the end of each block
     Item items[2][ITEM_CAP];
@@ -1167,16 +1168,15 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         const int i = tid + k * nth, q = j0 + i / 6;
         vEq[k] = (i < WAVE * 6 && dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
     }
-    // block tables: thread i < 2 (NB + 1) the pair / item offset of block i/2 ([NB] = end of the tile: a tile is contiguous),
-    // i < 3 NB the split points, i < 4 NB the newest list entries
-    uint64_t vOff = 0;
+    // block tables: thread i <= NB the first candidate of block i, i < 3 NB the split points, i < 4 NB the newest list entries
+    int32_t vOff = 0;
     uint32_t vSplit = 0;
     int32_t vTop = 0;
-    if (tid < (NB + 1) * 2) {
-        int64_t gb = gb0 + tid / 2;
+    if (tid < NB + 1) { // first candidate of block tid relative to the tile (a tile is contiguous); [NB] = end of the tile
+        int64_t gb = gb0 + tid;
         uint64_t extra = 0;
-        if (tid / 2 == NB || gb >= B.nBlk) { gb = gbL; extra = gp(B.blkCnt)[gb * 2 + tid % 2]; }
-        vOff = gp(B.blkOff)[gb * 2 + tid % 2] + extra;
+        if (tid == NB || gb >= B.nBlk) { gb = gbL; extra = gp(B.blkCnt)[gb * 2 + 1]; }
+        vOff = (int32_t)(gp(B.blkOff)[gb * 2 + 1] + extra - firstI);
     }
     if (tid < NB * 3) vSplit = gb0 + tid / 3 < B.nBlk ? gp(B.blkSplit)[(gb0 + tid / 3) * 3 + tid % 3] : 0;
     if (tid < NB * 4) {
@@ -1219,7 +1219,8 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         const int i = tid + k * nth;
         if (i < WAVE * 6) L.eqPrev[buf][i / 6][i % 6] = vEq[k];
     }
-    if (tid < (NB + 1) * 2) L.blkOff[buf][tid / 2][tid % 2] = vOff;
+    if (tid < NB + 1) L.blkItem[buf][tid] = vOff;
+    if (tid == 0) L.tileItem0[buf] = firstI;
     if (tid < NB * 3) L.blkSplit[buf][tid / 3][tid % 3] = vSplit;
     if (tid < NB * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
 #pragma unroll
@@ -1253,7 +1254,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int S = X.S;
-    const uint64_t tileItem0 = L.blkOff[buf][0][1];
+    const uint64_t tileItem0 = L.tileItem0[buf];
     // list entries at or below topK have (or may have: the far fixed-lag wavefront runs up to two blocks = LIST_AHEAD
     // entries ahead) left the LDS cache of the newest LIST_WIN entries
     constexpr int LIST_AHEAD = 32;
@@ -1623,8 +1624,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     int farPre = 0;  // (far wavefront) blocks below this index already have their far step (pre-run across the tile boundary)
     auto doRT = [&](int w, int buf, int tile, int k, int jbNow) { // jbNow: no igenic cell at or beyond it exists yet
         const int bq = k - tile * NB;
-        const int rt0 = (int)(L.blkOff[buf][bq][1] - L.blkOff[buf][0][1]) + (int)L.blkSplit[buf][bq][2],
-                  rt1 = (int)(L.blkOff[buf][bq + 1][1] - L.blkOff[buf][0][1]);
+        const int rt0 = L.blkItem[buf][bq] + (int)L.blkSplit[buf][bq][2], rt1 = L.blkItem[buf][bq + 1];
         const int vigLo = jbNow - 1 - VIG_WIN > -1 ? jbNow - 1 - VIG_WIN : -1;
         if (rt1 > rt0) trellisItems(X, w, buf, bq, k * BLK, rt0, rt1, vigLo);
     };
@@ -1680,7 +1680,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         for (int blk = 0; blk < NB && j0 + blk * BLK < n; blk++) {
             nb = blk + 1;
             const int jb = j0 + blk * BLK, gbk = tile * NB + blk;
-            const int it0 = (int)(L.blkOff[buf][blk][1] - L.blkOff[buf][0][1]),
+            const int it0 = L.blkItem[buf][blk],
                       itA = it0 + (int)L.blkSplit[buf][blk][0], itB = it0 + (int)L.blkSplit[buf][blk][1], itS = it0 + (int)L.blkSplit[buf][blk][2];
             FOR_WAVES(w) {
                 if (w == W_X && gbk >= farPre) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
