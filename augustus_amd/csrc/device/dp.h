@@ -59,6 +59,8 @@ struct IntronStart { int32_t pos; uint32_t ctx; uint64_t fx; };
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
     int tis_n, tis_k, ass_n, ass_k, tis_nbins, tis_mem, synch, gc_win, gc_weighing_type;
+    int soft;                  // soft-masking: lower-case bases carry lnSoft on igenic and intron states
+    double lnSoft;
     int kind[AUGX_MAX_STATES], win[AUGX_MAX_STATES], type[AUGX_MAX_STATES], reachable[AUGX_MAX_STATES];
     int n_anc[AUGX_MAX_STATES], anc[AUGX_MAX_STATES][AUGX_MAX_ANC];
     double ln_init[AUGX_MAX_STATES], ln_term[AUGX_MAX_STATES];

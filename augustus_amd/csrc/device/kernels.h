@@ -137,8 +137,8 @@ AUGX_HD Piece makePiece(const DevTables &T, const BatchView &B, int p) {
 // =================================================================================================
 // K1  prep kernels (one thread per slot unless noted).  g = global slot index.
 // =================================================================================================
-constexpr int NCNT = 10; // prefix-count fields: a c g t | atg | ag(LA) | ac(LR) | gt(LD) | ct(RD) | reverse stop codons
-constexpr int CNT_ATG = 4, CNT_LA = 5, CNT_LR = 6, CNT_LD = 7, CNT_RD = 8, CNT_RS = 9;
+constexpr int NCNT = 11; // prefix-count fields: a c g t | atg | ag(LA) | ac(LR) | gt(LD) | ct(RD) | reverse stop codons | soft-masked
+constexpr int CNT_ATG = 4, CNT_LA = 5, CNT_LR = 6, CNT_LD = 7, CNT_RD = 8, CNT_RS = 9, CNT_SOFT = 10;
 
 AUGX_HD void k1Encode(const BatchView &B, int64_t g) {
     int p = B.chunkPiece[g / CHUNK];
@@ -165,6 +165,7 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
     if (q >= 0 && q < P.n) {
     int c = P.b(q);
     if (c < 4) cnt[c] = 1;
+    if (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') cnt[CNT_SOFT] = 1; // lower-case base = nonexonpart hint (src/extrinsicinfo.cc:1703-1720)
     // start codon with positive probability at q (a of atg)
     if (q < P.n - 2) { int pn = P.pat(q, 3); if (pn >= 0 && T.ln_startcodon[pn] > AUGX_NINF) cnt[CNT_ATG] = 1; }
     if (P.possASS(q - T.Ae)) cnt[CNT_LA] = 1;                       // longass may end at q   (src/intronmodel.cc:705)
@@ -243,9 +244,11 @@ AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g) {
             out[(1 * 3 + a) * 3 + tb] = toFx(rn >= 0 ? tabs[tb][mod3(a - q) * NP + rn] : T.ln_n_coding);
         }
     const double *inE = T.in_emi + (int64_t)c * NP;
-    out[FX_INF] = toFx(pn >= 0 ? inE[pn] : T.ln_quarter);
+    // (intron content; a soft-masked base adds the nonexonpart bonus, reference src/intronmodel.cc:1011-1036)
+    const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0;
+    out[FX_INF] = toFx((pn >= 0 ? inE[pn] : T.ln_quarter) + softB);
     int rn2 = (q + k < P.n) ? rn : -1;
-    out[FX_INR] = toFx(rn2 >= 0 ? inE[rn2] : T.ln_quarter);
+    out[FX_INR] = toFx((rn2 >= 0 ? inE[rn2] : T.ln_quarter) + softB);
     }
     for (int i = 0; i < NFX; i++) B.fx[fidx(g, i, NFX)] = out[i];
 }
@@ -264,8 +267,9 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     if (q < 0 || q >= B.len[p] || B.cls[p] < 0) return;
     Piece P = makePiece(T, B, p);
     const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
-    sg[SIG_EIG] = q >= 1 ? eIg(P, q) : AUGX_NINF;
-    sg[SIG_EIN] = eIn(P, q);
+    const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0; // (src/igenicmodel.cc:306-326)
+    sg[SIG_EIG] = q >= 1 ? eIg(P, q) + softB : AUGX_NINF;
+    sg[SIG_EIN] = eIn(P, q) + softB;
     // fixed-length intron states ending at q: gate && emission (reference src/intronmodel.cc:690-717,861-923)
     // (the splice-site records SIG_DSSF/DSSR/ASSF/ASSR are filled by k1SiteSignals, one thread per site instead of one
     //  per base: their motif loops would otherwise run with one lane in sixteen active.  SIG_TISF is not used: the
@@ -322,10 +326,18 @@ AUGX_HD void k1SiteSignals(const DevTables &T, const BatchView &B, int64_t t, in
     const int q = sel == 0 ? B.laPos[lo + li] : sel == 1 ? B.lrPos[lo + li] : sel == 2 ? B.ldEnt[lo + li].pos : B.rdEnt[lo + li].pos;
     const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
     double *sg = B.sig + (o + 1 + q) * NSIG;
-    if (sel == 2) { if (q - dssWhole >= 0) sg[SIG_DSSF] = dssProb(P, q - dssWhole + 1, true); }
-    else if (sel == 1) { if (q - dssWhole >= 0) sg[SIG_DSSR] = dssProb(P, q - dssWhole + 1, false); }
-    else if (sel == 0) { if (q - assWhole - T.U >= 0) sg[SIG_ASSF] = assProb(P, q - assWhole - T.U + 1, true); }
-    else { if (q - assWhole - T.U >= 0) sg[SIG_ASSR] = assProb(P, q - assWhole - T.U + 1, false); }
+    // soft-masked bases inside the intronic part of the state's window [a, b] (reference src/intronmodel.cc:872-924,1011-1036)
+    auto softIn = [&](int a, int b2) -> double {
+        if (!T.soft) return 0.0;
+        if (a < 0) a = 0;
+        if (b2 < a) return 0.0;
+        const uint64_t hi = B.cnt[fidx(o + 1 + b2, CNT_SOFT, NCNT)], lo2 = B.cnt[fidx(o + a, CNT_SOFT, NCNT)];
+        return (double)(int64_t)(hi - lo2) * T.lnSoft;
+    };
+    if (sel == 2) { if (q - dssWhole >= 0) sg[SIG_DSSF] = dssProb(P, q - dssWhole + 1, true) + softIn(q - 2 - T.De + 1, q); }
+    else if (sel == 1) { if (q - dssWhole >= 0) sg[SIG_DSSR] = dssProb(P, q - dssWhole + 1, false) + softIn(q - dssWhole + 1, q - T.Ds); }
+    else if (sel == 0) { if (q - assWhole - T.U >= 0) sg[SIG_ASSF] = assProb(P, q - assWhole - T.U + 1, true) + softIn(q - assWhole - T.U + 1, q - T.Ae); }
+    else { if (q - assWhole - T.U >= 0) sg[SIG_ASSR] = assProb(P, q - assWhole - T.U + 1, false) + softIn(q - assWhole - T.U + 1 + T.Ae, q); }
 }
 
 // candidate-side constants of the list entries (everything a candidate contributes that does not depend on Viterbi

@@ -154,6 +154,7 @@ inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
     D.max_exon_len = t.max_exon_len; D.min_exon_len = t.min_exon_len;
     D.tis_n = t.tis_n; D.tis_k = t.tis_k; D.ass_n = t.ass_n; D.ass_k = t.ass_k; D.tis_nbins = t.tis_nbins; D.tis_mem = t.tis_mem;
     D.synch = t.synch_state; D.gc_win = t.gc_win; D.gc_weighing_type = t.gc_weighing_type;
+    D.soft = t.softmasking; D.lnSoft = t.ln_soft_bonus;
     for (int s = 0; s < t.S; s++) {
         D.kind[s] = t.state_kind[s]; D.win[s] = t.state_win[s]; D.type[s] = t.state_type[s]; D.reachable[s] = t.reachable[s];
         D.n_anc[s] = t.n_anc[s];

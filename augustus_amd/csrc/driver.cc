@@ -166,10 +166,6 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     if (M.opt.getInt("sample", 0) > 0)
         return fail("sampling (--sample>0: forward algorithm + posterior probabilities) is not implemented on the MI355X path yet; "
                     "run with --sample=0 (the human default).");
-    if (M.opt.getBool("softmasking", true)) {
-        // the soft-masking bonus (nonexonpart 1.15 on lower-case runs, reference src/extrinsicinfo.cc:1696-1724) is a
-        // no-op on upper-case input; lower-case input must be run with --softmasking=0 until the bonus is implemented
-    }
     // redirect output if requested (reference src/augustus.cc:503-520)
     std::ofstream outfile, errfile;
     std::streambuf *coutbuf = std::cout.rdbuf(), *cerrbuf = std::cerr.rdbuf();

@@ -89,7 +89,8 @@ void OutputOptions::fromModel(const Model &m) { // reference Gene::init, src/gen
     uniqueGeneId = o.getBool("uniqueGeneId", false);
     // "# Evidence for and against" is printed when the hints machinery is on, i.e. with softmasking (default true,
     // reference src/types.cc:95, src/extrinsicinfo.cc:1722, src/gene.cc:3111) and printEvidence (default true)
-    evidence = o.getBool("softmasking", true) && o.getBool("printEvidence", true);
+    softmasking = o.getBool("softmasking", true);
+    evidence = softmasking && o.getBool("printEvidence", true);
 }
 
 std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vector<PathState> &path, long dnalen) {
@@ -284,7 +285,18 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
 }
 
 void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o) {
-    (void)seqlen;
+    // soft-masked runs of the input sequence = the hint groups of the evidence block
+    std::vector<std::pair<long, long>> rmRuns;
+    if (o.evidence && o.softmasking && seq && !genes.empty())
+        for (long i = 0; i < seqlen;) {
+            if (seq[i] >= 'a' && seq[i] <= 'z') {
+                long e = i;
+                while (e + 1 < seqlen && seq[e + 1] >= 'a' && seq[e + 1] <= 'z') e++;
+                rmRuns.push_back({i, e});
+                i = e + 1;
+            } else
+                i++;
+        }
     for (const GeneOut &g : genes) {
         long minB = 0x7fffffffffffffffL, maxE = 0;
         for (const Transcript &t : g.transcripts) { minB = std::min(minB, t.geneBegin()); maxE = std::max(maxE, t.geneEnd()); }
@@ -327,12 +339,27 @@ void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const ch
                     out += "]\n";
                 }
             }
-            if (o.evidence) { // reference Gene::printEvidence, src/gene.cc:2412-2445 (no hints: all counts 0)
+            if (o.evidence) { // reference Gene::printEvidence, src/gene.cc:2412-2445
+                // the only hints of this path are the soft-masked runs (one nonexonpart hint group of source RM each,
+                // reference src/extrinsicinfo.cc:1696-1724); a group that overlaps the transcript is obeyed when it lies
+                // inside one intron (Gene::supportingFraction, src/gene.cc:1696-1720), else incompatible.  No hint
+                // type that could support an exon or intron exists, so those counts stay 0.
+                int obeyed = 0, incompatible = 0;
+                for (const auto &run : rmRuns) {
+                    if (run.second < t.geneBegin() || run.first > t.geneEnd()) continue;
+                    bool inIntron = false;
+                    for (const BioState &in : t.introns)
+                        if (run.first >= in.begin && run.second <= in.end) inIntron = true;
+                    (inIntron ? obeyed : incompatible)++;
+                }
                 out += "# Evidence for and against this transcript:\n";
                 out += "# % of transcript supported by hints (any source): 0\n";
                 appendf(out, "# CDS exons: 0/%zu\n# CDS introns: 0/%zu\n", t.exons.size(), t.introns.size());
                 out += "# 5'UTR exons and introns: 0/0\n# 3'UTR exons and introns: 0/0\n";
-                out += "# hint groups fully obeyed: 0\n# incompatible hint groups: 0\n";
+                appendf(out, "# hint groups fully obeyed: %d\n", obeyed);
+                if (obeyed) appendf(out, "# %6s:%4d \n", "RM", obeyed);
+                appendf(out, "# incompatible hint groups: %d\n", incompatible);
+                if (incompatible) appendf(out, "# %6s:%4d \n", "RM", incompatible);
             }
         }
         out += "# end gene " + g.id + "\n###\n";

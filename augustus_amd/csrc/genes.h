@@ -48,7 +48,7 @@ struct GeneOut {
 struct OutputOptions {
     bool print_start = true, print_stop = true, print_introns = false, print_cds = true, print_exonnames = false,
          gff3 = false, stopCodonExcludedFromCDS = false, protein = true, codingseq = false, evidence = false,
-         uniqueGeneId = false;
+         uniqueGeneId = false, softmasking = true;
     void fromModel(const Model &m);
 };
 

@@ -346,6 +346,38 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     t.d = opt.getInt("/IntronModel/d", 0);
     t.tis_mem = opt.getInt("/ExonModel/tis_motif_memory", 3);
     t.gc_win = opt.getInt("GCwinsize", 10000);
+    // soft-masking: lower-case runs are nonexonpart hints of source RM (reference src/extrinsicinfo.cc:1696-1724); their bonus
+    // comes from the extrinsic configuration.  Only the shipped shape of that file is supported: every bonus / malus 1
+    // but the RM grade quotient of nonexonpart.
+    t.softmasking = opt.getBool("softmasking", true) ? 1 : 0;
+    t.ln_soft_bonus = 0.0;
+    if (t.softmasking) {
+        if (opt.has("extrinsicCfgFile")) throw UnsupportedError("--extrinsicCfgFile is outside the MI355X ab-initio hot path");
+        const std::string ecfg = configPath + "extrinsic/extrinsic.cfg";
+        std::ifstream ef(ecfg.c_str());
+        if (!ef) throw ConfigError("Could not find the extrinsic config file " + ecfg + " (needed with --softmasking=1).");
+        std::string line;
+        bool general = false, found = false;
+        while (std::getline(ef, line)) {
+            std::istringstream ls(line);
+            std::vector<std::string> w;
+            for (std::string x; ls >> x;) w.push_back(x);
+            if (w.empty() || w[0][0] == '#') continue;
+            if (w[0][0] == '[') { general = w[0] == "[GENERAL]"; continue; }
+            if (!general || w.size() < 3) continue;
+            const double bonus = atof(w[1].c_str()), malus = atof(w[2].c_str());
+            double rm = 1.0;
+            for (size_t i = 3; i + 2 < w.size(); i++)
+                if (w[i] == "RM") { // source columns: name, number of score classes, boundaries, grade quotients
+                    if (atoi(w[i + 1].c_str()) != 1) throw UnsupportedError("extrinsic.cfg: more than one score class for source RM");
+                    rm = atof(w[i + 2].c_str());
+                }
+            if (bonus != 1.0 || malus != 1.0 || (w[0] != "nonexonpart" && rm != 1.0))
+                throw UnsupportedError("extrinsic.cfg with bonus/malus values other than the soft-masking nonexonpart bonus is outside the MI355X ab-initio hot path");
+            if (w[0] == "nonexonpart") { t.ln_soft_bonus = std::log(bonus * rm); found = true; }
+        }
+        if (!found) throw ConfigError("extrinsic.cfg: no nonexonpart line in [GENERAL]");
+    }
     double probNinCoding = opt.getDouble("/Constant/probNinCoding", 0.23);
     double opal = opt.getDouble("/Constant/opalprob", 0.333), amber = opt.getDouble("/Constant/amberprob", 0.333),
            ochre = opt.getDouble("/Constant/ochreprob", 0.333);

@@ -109,6 +109,10 @@ typedef struct augx_tables {
     int32_t gc_weighing_type;       /* 1 equal, 2 gcContentClasses, 3 multiNormalKernel                  */
     int32_t n_anc[AUGX_MAX_STATES];
     int32_t anc[AUGX_MAX_STATES][AUGX_MAX_ANC];  /* ancestors in ascending state index (tie-break order) */
+    /* soft-masking (reference SequenceFeatureCollection::prepare, src/extrinsicinfo.cc:1696-1724): every lower-case
+       base is a nonexonpart hint of source RM; igenic and intron states get its bonus per covered base */
+    int32_t softmasking;            /* 0/1: --softmasking                                                */
+    double ln_soft_bonus;           /* ln(bonus), 1.15 in config/extrinsic/extrinsic.cfg                  */
 } augx_tables;
 
 typedef struct augx_model augx_model;     /* host-side immutable model: tables + option values          */

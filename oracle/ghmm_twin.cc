@@ -65,6 +65,23 @@ struct Twin {
             code[i] = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4; // src/extrinsicinfo.cc:1726
         }
         ca.resize(t.n_classes);
+        // soft-masking: lower-case bases are nonexonpart hints (reference src/extrinsicinfo.cc:1696-1724)
+        soft.assign(n + 1, 0);
+        softCnt.assign(n + 2, 0);
+        for (int i = 0; i < n; i++) {
+            soft[i] = (t.softmasking && seq[i] >= 'a' && seq[i] <= 'z') ? 1 : 0;
+            softCnt[i + 1] = softCnt[i] + soft[i];
+        }
+    }
+    std::vector<uint8_t> soft;   // soft-masked base?
+    std::vector<int64_t> softCnt; // prefix count, softCnt[p+1] = number of soft-masked bases in [0, p]
+    inline double softB(int p) const { return soft[p] ? t.ln_soft_bonus : 0.0; }
+    // bonus of the soft-masked bases in [a, b] (reference src/intronmodel.cc:1011-1036: one factor per covered base)
+    inline double softIn(int a, int b2) const {
+        if (!t.softmasking) return 0.0;
+        if (a < 0) a = 0;
+        if (b2 < a) return 0.0;
+        return (double)(softCnt[b2 + 1] - softCnt[a]) * t.ln_soft_bonus;
     }
     inline int b(int p) const { return (p >= 0 && p < n) ? code[p] : 4; }
     inline bool is2(int p, int x, int y) const { return b(p) == x && b(p + 1) == y; }
@@ -200,10 +217,10 @@ struct Twin {
         for (int p = 0; p < n; p++) {
             // forward: reference IntronModel::seqProb src/intronmodel.cc:1090-1101 / SnippetProbs fwd src/statemodel.cc:287-297
             int pn = p >= k ? pat(p - k, k + 1) : -1;
-            A.inF[p + 1] = A.inF[p] + fx(pn >= 0 ? inE[pn] : t.ln_quarter);
+            A.inF[p + 1] = A.inF[p] + fx((pn >= 0 ? inE[pn] : t.ln_quarter) + softB(p));
             // reverse snippet (rlessD only): src/statemodel.cc:298-309
             int rn = (p + k < n) ? rcpat(p, k + 1) : -1;
-            A.inR[p + 1] = A.inR[p] + fx(rn >= 0 ? inE[rn] : t.ln_quarter);
+            A.inR[p + 1] = A.inR[p] + fx((rn >= 0 ? inE[rn] : t.ln_quarter) + softB(p));
         }
         const double *tabs[3] = {t.ex_emi + (size_t)c * 3 * NP, t.ex_init + (size_t)c * 3 * NP, t.ex_et + (size_t)c * 3 * NP};
         for (int tb = 0; tb < 3; tb++)
@@ -620,12 +637,12 @@ struct Twin {
             case AUGX_K_LONGDSS:
                 eop = j - dssWhole;
                 if (eop < 0 || !possDSS(j - t.De - 2 + 1)) return;
-                emi = dssProb(j - dssWhole + 1, true);
+                emi = dssProb(j - dssWhole + 1, true) + softIn(j - 2 - t.De + 1, j);
                 break;
             case AUGX_K_RLONGDSS:
                 eop = j - dssWhole;
                 if (eop < 0 || !possRDSS(j - t.Ds)) return;
-                emi = dssProb(j - dssWhole + 1, false);
+                emi = dssProb(j - dssWhole + 1, false) + softIn(j - dssWhole + 1, j - t.Ds);
                 break;
             case AUGX_K_EQUALD: case AUGX_K_REQUALD:
                 eop = j - dStateLen;
@@ -634,17 +651,17 @@ struct Twin {
                 break;
             case AUGX_K_GEOMETRIC: case AUGX_K_RGEOMETRIC:
                 eop = j - 1;
-                emi = eIn(c, j);
+                emi = eIn(c, j) + softB(j);
                 break;
             case AUGX_K_LONGASS:
                 eop = j - assWhole - t.U;
                 if (eop < 0 || !possASS(j - t.Ae)) return;
-                emi = assProb(c, j - assWhole - t.U + 1, true);
+                emi = assProb(c, j - assWhole - t.U + 1, true) + softIn(j - assWhole - t.U + 1, j - t.Ae);
                 break;
             default: // RLONGASS
                 eop = j - assWhole - t.U;
                 if (eop < 0 || !possRASS(j - t.U - t.As - 2 + 1)) return;
-                emi = assProb(c, j - assWhole - t.U + 1, false);
+                emi = assProb(c, j - assWhole - t.U + 1, false) + softIn(j - assWhole - t.U + 1 + t.Ae, j);
             }
             if (emi == NINF) return;
             for (int ai = 0; ai < t.n_anc[s]; ai++) {
@@ -660,7 +677,7 @@ struct Twin {
     // reference IGenicModel::viterbiForwardAndSampling, src/igenicmodel.cc:231-287
     void igenicCell(int s, int j) {
         const int c = cls[j];
-        double e = eIg(c, j), best = NINF;
+        double e = eIg(c, j) + softB(j), best = NINF;
         int ba = t.n_anc[s] ? t.anc[s][0] : -1;
         for (int ai = 0; ai < t.n_anc[s]; ai++) {
             int a = t.anc[s][ai];

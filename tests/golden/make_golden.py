@@ -47,6 +47,14 @@ def build_inputs():
         ("trunc_both", ex[2000:5300]),
         ("revcomp", ex[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))),
     ]
+    # soft-masked records (lower-case runs = nonexonpart hints with default flags): real gene with masked intron and
+    # exon parts, random DNA with short and long masked runs, an all-lower-case record
+    sm = ex[:1200] + ex[1200:2500].lower() + ex[2500:6000] + ex[6000:6400].lower() + ex[6400:]
+    r = list(random_dna(30000, 99))
+    for a, b in [(100, 160), (5000, 7000), (12000, 12010), (20000, 26000), (29900, 30000)]:
+        for i in range(a, b):
+            r[i] = r[i].lower()
+    recs += [("softmask_gene", sm), ("softmask_rand", "".join(r)), ("softmask_all", random_dna(8000, 5).lower())]
     return recs
 
 
