@@ -212,8 +212,33 @@ extern "C" int augx_main(int argc, const char *const *argv) {
 
     const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
     if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); return 1; }
-    long predStart = M.opt.getInt("predictionStart", -1), predEnd = M.opt.getInt("predictionEnd", -1);
-    if (predStart >= 0 || predEnd >= 0) { restore(); return fail("--predictionStart/--predictionEnd are not implemented on the MI355X path yet"); }
+    // --predictionStart / --predictionEnd: predict on a piece of the first sequence only and shift the printed coordinates
+    // (reference cutRelevantPiece, src/augustus.cc:552-602)
+    if ((M.opt.has("predictionStart") || M.opt.has("predictionEnd")) && !recs.empty()) {
+        const long seqlen = (long)recs[0].seq.size();
+        long ps = M.opt.has("predictionStart") ? M.opt.getInt("predictionStart", 1) - 1 : 0;
+        long pe = M.opt.has("predictionEnd") ? M.opt.getInt("predictionEnd", 1) - 1 : seqlen - 1;
+        if ((ps != 0 || pe != seqlen - 1) && !(pe < 0 && ps < 0)) {
+            if (ps < 0) ps = 0;
+            if (pe > seqlen - 1) pe = seqlen - 1;
+            if (ps >= seqlen) {
+                restore();
+                return fail("predictionStart (" + std::to_string(ps + 1) + ") is larger than sequence length (" + std::to_string(seqlen) + "). No predictions made.");
+            }
+            if (pe < ps) {
+                restore();
+                return fail("predictionEnd (" + std::to_string(pe + 1) + ") is smaller than predictionStart (" + std::to_string(ps + 1) + "). No predictions made!");
+            }
+            if (recs.size() > 1) {
+                std::cerr << "Warning: predictionStart or predictionEnd set but input consists of more than one sequence." << std::endl
+                          << "Prediction will be made only on first sequence." << std::endl;
+                recs.resize(1);
+            }
+            recs[0].seq = recs[0].seq.substr((size_t)ps, (size_t)(pe - ps + 1));
+            S.oo.offset = ps;
+        } else if (ps < 0 && pe < 0 && pe == ps)
+            S.oo.offset = -ps - 1;
+    }
 
     // ---- phase 1: find the cut points of all records (serial chain per record, reference src/namgene.cc:973-1133)
     struct PieceRef { int rec; long begin, end; int initKind, termKind; };
@@ -307,7 +332,11 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         if (verbosity)
             std::cout << "#\n# ----- prediction on sequence number " << (r + 1) << " (length = " << rec.seq.size()
                       << ", name = " << rec.name << ") -----" << std::endl << "#" << std::endl;
-        std::cout << "# Predicted genes for sequence number " << (r + 1) << " on both strands" << std::endl;
+        {
+            const std::string st = M.opt.get("strand", "both");
+            const bool fw = st == "forward", bw = st == "backward"; // (other values fall back to both, see genes.cc)
+            std::cout << "# Predicted genes for sequence number " << (r + 1) << " on " << (fw ? "forward strand" : bw ? "reverse strand" : "both strands") << std::endl;
+        }
         bool any = false;
         std::string errmsg;
         for (; pi < allPieces.size() && allPieces[pi].rec == (int)r; pi++) {

@@ -172,8 +172,12 @@ std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vecto
 
 std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs) {
     std::vector<Transcript> out;
+    // --strand (reference src/augustus.cc:177-191, filterGenePrediction src/gene.cc:2474-2475).  Only the values listed as
+    // possible_values in aug_cmdln_parameters.json reach the reference's parser: anything but forward / backward means both
+    const std::string st = m.opt.get("strand", "both");
+    const int want = st == "forward" ? 1 : st == "backward" ? -1 : 0;
     for (const Transcript &g : txs) {
-        bool keep = true;
+        bool keep = !(want == 1 && !g.plus) && !(want == -1 && g.plus);
         bool cc = g.completeCDS();
         if ((g.clength < m.t.min_coding_len && cc) || (g.clength < 4 && g.clength < m.t.min_coding_len && !cc)) keep = false;
         if (keep) out.push_back(g);
@@ -305,13 +309,17 @@ void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const ch
         // (= 1 for the single Viterbi transcript), printed with setprecision(3)
         char score[32];
         snprintf(score, sizeof score, "%.3g", g.apostprob);
-        appendf(out, "%s\tAUGUSTUS\tgene\t%ld\t%ld\t%s\t%c\t.\t%s%s\n", g.seqname.c_str(), minB + 1, maxE + 1, score, g.plus ? '+' : '-',
+        appendf(out, "%s\tAUGUSTUS\tgene\t%ld\t%ld\t%s\t%c\t.\t%s%s\n", g.seqname.c_str(), minB + 1 + o.offset, maxE + 1 + o.offset, score, g.plus ? '+' : '-',
                 o.gff3 ? "ID=" : "", g.id.c_str());
         for (const Transcript &t : g.transcripts) {
-            appendf(out, "%s\tAUGUSTUS\ttranscript\t%ld\t%ld\t.\t%c\t.\t", g.seqname.c_str(), t.geneBegin() + 1, t.geneEnd() + 1, t.plus ? '+' : '-');
+            appendf(out, "%s\tAUGUSTUS\ttranscript\t%ld\t%ld\t.\t%c\t.\t", g.seqname.c_str(), t.geneBegin() + 1 + o.offset, t.geneEnd() + 1 + o.offset, t.plus ? '+' : '-');
             if (o.gff3) out += "ID=" + g.id + "." + t.id + ";Parent=" + g.id + "\n";
             else out += g.id + "." + t.id + "\n";
-            printTranscriptGFF(out, t, o);
+            { // printed coordinates are shifted by the offset of --predictionStart (reference AnnoSequence::offset)
+                Transcript tp = t;
+                tp.shift(o.offset);
+                printTranscriptGFF(out, tp, o);
+            }
             if (seq) {
                 std::string cds = exonicSequence(t, seq);
                 if (o.codingseq) { // reference Gene::printCodingSeq, src/gene.cc:2315-2334

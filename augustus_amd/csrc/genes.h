@@ -49,6 +49,7 @@ struct OutputOptions {
     bool print_start = true, print_stop = true, print_introns = false, print_cds = true, print_exonnames = false,
          gff3 = false, stopCodonExcludedFromCDS = false, protein = true, codingseq = false, evidence = false,
          uniqueGeneId = false, softmasking = true;
+    long offset = 0; // added to every printed coordinate (--predictionStart)
     void fromModel(const Model &m);
 };
 

@@ -322,6 +322,18 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     if (opt.has("hintsfile")) throw UnsupportedError("--hintsfile (extrinsic evidence) is outside the MI355X ab-initio hot path");
     if (opt.has("proteinprofile")) throw UnsupportedError("--proteinprofile (PPX) is outside the MI355X ab-initio hot path");
     if (opt.getBool("mea", false)) throw UnsupportedError("--mea=1 is outside the MI355X ab-initio hot path");
+    // options that would change the prediction or the output and are not implemented here: fail loudly instead of
+    // silently printing something else than the reference
+    if (!opt.getBool("contentmodels", true)) throw UnsupportedError("--contentmodels=false is outside the MI355X hot path");
+    if (opt.getBool("alternatives-from-sampling", false))
+        throw UnsupportedError("--alternatives-from-sampling=true needs posterior sampling, which is not implemented on the MI355X path yet");
+    if (opt.getBool("noInFrameStop", false)) throw UnsupportedError("--noInFrameStop=true is not implemented on the MI355X path yet");
+    for (const char *o2 : {"emiprobs", "exoncands", "printHints", "printSampled", "printOEs", "printGeneRangesBED", "printGeneRangesGFF",
+                           "print_blocks", "printMEA"})
+        if (opt.getBool(o2, false)) throw UnsupportedError(std::string("--") + o2 + " (extra output) is not implemented on the MI355X path");
+    for (const char *o2 : {"speciesfilenames", "alnfile", "treefile", "dbaccess", "dbhints", "referenceFile", "refSpecies", "optCfgFile",
+                           "codonAlignmentFile", "trainFeatureFile"})
+        if (opt.has(o2)) throw UnsupportedError(std::string("--") + o2 + " (comparative / training mode) is outside the MI355X ab-initio hot path");
     std::string strandName = "shadow";
     std::string transFile = "trans_" + strandName + "_" + genemodel + ".pbl";
     opt.set("/NAMGene/TransFile", transFile);

@@ -117,6 +117,27 @@ def test_cli_piece_cutting_matches_reference(tmp_path):
     assert gff_body(ours.stdout) == gff_body(ref.stdout)
 
 
+@pytest.mark.parametrize("extra", [["--strand=forward"], ["--strand=backward"], ["--predictionStart=2001", "--predictionEnd=8000"],
+                                   ["--predictionStart=3000"], ["--gff3=on", "--introns=on", "--strand=minus"], ["--gff3=on", "--introns=on", "--strand=backward"],
+                                   ["--softmasking=0", "--codingseq=on", "--exonnames=on"]])
+def test_cli_options_match_reference(tmp_path, extra):
+    """command-line options of the path (strand filter, prediction range with coordinate offset, output variants):
+    stdout of the prediction part byte-identical to the reference binary, empty stderr"""
+    exe = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
+    if not os.path.exists(REF_AUGUSTUS):
+        pytest.skip("oracle/_ref not present")
+    recs = golden_inputs()
+    byname = dict(recs)
+    fa = str(tmp_path / "opt.fa")
+    write_fasta(fa, [("HS04636", byname["HS04636"]), ("softmask_gene", byname["softmask_gene"]), ("revcomp", byname["revcomp"])])
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    args = ["--species=human"] + extra + [fa]
+    ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
+    ours = subprocess.run([exe] + args, capture_output=True, text=True, env=env)
+    assert ref.returncode == 0 and ours.returncode == 0, ours.stderr
+    assert gff_body(ours.stdout) == gff_body(ref.stdout)
+    assert ours.stderr == ref.stderr
+
 @pytest.mark.parametrize("species", ["human", "fly", "arabidopsis"])
 def test_gpu_ragged_lengths(species):
     """Edge lengths around the tile (64) and block (8) sizes, a one-base piece, ragged batch: bit-identical to the oracle."""
