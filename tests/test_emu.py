@@ -51,3 +51,36 @@ def test_emulated_ragged_lengths(species):
         if rc == 0:
             assert lnv == lnv2 and np.array_equal(V, V2), len(seq)
             assert path == [(b, e, s) for b, e, s, t in path2], len(seq)
+
+
+def adversarial_cases():
+    """dense splice sites (more candidates per tile than the LDS staging holds), 20 kb open reading frames on both strands
+    (exon candidates far outside every LDS window), start-codon repeats, purine / pyrimidine tracts"""
+    rng8, rng9 = np.random.default_rng(8), np.random.default_rng(9)
+    return {
+        "aggt": "AGGT" * 3000,
+        "gtag_rand": random_dna(2000, 1) + "GTAG" * 1500 + random_dna(2000, 2),
+        "polyGCC": random_dna(1000, 3) + "ATG" + "GCC" * 7000 + "TAA" + random_dna(1000, 4),
+        "polyGGC_rev": random_dna(1000, 5) + "TTA" + "GGC" * 7000 + "CAT" + random_dna(1000, 6),
+        "atg_rep": "ATG" * 4000 + random_dna(3000, 7),
+        "ag_rich": "".join(rng8.choice(list("AG"), size=20000)),
+        "ct_rich": "".join(rng9.choice(list("CT"), size=20000)),
+    }
+
+
+@pytest.mark.parametrize("species", ["human", "fly"])
+def test_emulated_adversarial_sequences(species):
+    m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
+    S = m.n_states
+    cases = adversarial_cases()
+    res = emu_decode(m.tables_ptr, list(cases.values()), S, cells=True)
+    decoded = 0
+    for (name, seq), (st, lnv, path, V, cls) in zip(cases.items(), res):
+        rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, S, cells=True)
+        if st == ax.AUGX_E_UNSUPPORTED:  # multi-GC-class piece (human model, GC-rich insert)
+            assert len(set(gc.tolist())) > 1, name
+            continue
+        decoded += 1
+        assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
+        assert path == [(b, e, s) for b, e, s, t in path2], name
+    assert decoded >= 4

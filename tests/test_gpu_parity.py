@@ -151,3 +151,28 @@ def test_gpu_ragged_lengths(species):
             assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, len(seq)
         else:
             assert r.status != 0, len(seq)
+
+
+@pytest.mark.parametrize("species", ["human", "fly"])
+def test_gpu_adversarial_sequences(species):
+    """dense splice sites, 20 kb open reading frames, repeats (see tests/test_emu.py): cells, score and path bit-identical"""
+    from test_emu import adversarial_cases
+    os.environ["AUGX_DEBUG_CELLS"] = "1"
+    try:
+        m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
+        d = ax.Decoder(m, 0)
+        cases = adversarial_cases()
+        b = ax.Batch(d, list(cases.values()))
+        b.decode()
+        decoded = 0
+        for i, ((name, seq), r) in enumerate(zip(cases.items(), b.paths())):
+            rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+            if r.status == ax.AUGX_E_UNSUPPORTED:
+                assert len(set(gc.tolist())) > 1, name
+                continue
+            decoded += 1
+            assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, name
+            assert np.array_equal(b.cells(i), V), name
+        assert decoded >= 4
+    finally:
+        del os.environ["AUGX_DEBUG_CELLS"]
