@@ -63,11 +63,15 @@ __global__ void kClassInit(BatchView B) {
 }
 __global__ void kClassFinal(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < B.nPieces) B.cls[p] = B.clsMinMax[2 * p] == B.clsMinMax[2 * p + 1] ? B.clsMinMax[2 * p] : -1;
+    if (p < B.nPieces) {
+        B.cls[p] = B.clsMinMax[2 * p] == B.clsMinMax[2 * p + 1] ? B.clsMinMax[2 * p] : -1;
+        B.nPlanes[p] = 1;
+        B.planeCls[p * MAXPL] = B.cls[p];
+    }
 }
-__global__ void __launch_bounds__(256) kFxTerms(const DevTables *T, BatchView B) {
+__global__ void __launch_bounds__(256) kFxTerms(const DevTables *T, BatchView B) { // grid.y = plane
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < B.N) k1FxTerms(*T, B, g);
+    if (g < B.N) k1FxTerms(*T, B, g, blockIdx.y);
 }
 __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -76,9 +80,9 @@ __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B)
 __global__ void __launch_bounds__(256) kSiteSignals(const DevTables *T, BatchView B) {
     k1SiteSignals(*T, B, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
-__global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView B) {
+__global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView B) { // grid.y = plane
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < B.N) k1SiteConsts(*T, B, g);
+    if (g < B.N) k1SiteConsts(*T, B, g, blockIdx.y);
 }
 
 // ---- chunked piece-local inclusive scans over rows [chunk][field][CHUNK] of uint64 (sum or max) ----
@@ -130,9 +134,11 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
 }
 
 // ---- candidates of the variable-length states: one workgroup per tile of 64 bases (count, reserve, emit) ----
-template <int BLK> __global__ void __launch_bounds__(NT) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+// (MULTI: some piece of the batch has more than one GC class -- the plane of every class-dependent array is then chosen per
+//  end base; batches without such a piece run the variant with the plane folded away)
+template <int BLK, bool MULTI> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ CandLds lds;
-    candWorkgroup<BLK>(*T, *B, lds, blockIdx.x);
+    candWorkgroup<BLK, MULTI>(*T, *B, lds, blockIdx.x);
 }
 
 template <int BLK> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
@@ -161,7 +167,8 @@ struct augx_batch {
     BatchView V;               // device pointers
     BatchView *dV = nullptr;   // device copy of V (kernels with high register pressure take it by pointer)
     std::vector<void *> bufs;
-    std::vector<const char *> hostSeq; // caller-owned sequences (used only by the GC-stairs fallback below)
+    int nPlAlloc = 0;          // planes the class-dependent arrays are allocated for (0: not yet)
+    void *planeBufs[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
     uint64_t nItems = 0, nPairs = 0;
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
@@ -178,45 +185,34 @@ template <class T> int devAlloc(augx_batch *b, T **ptr, int64_t count) {
     return 0;
 }
 
-// smoothed GC-content stairs of one piece on the host (reference ContentStairs::computeStairs,
-// src/motif.cc:543-616).  Only used for the rare piece whose window classes are not all equal; returns the
-// class if the smoothed stairs are constant, else -1 (multi-class pieces are not decoded by this version).
-int hostStairsClass(const augx_tables &t, const char *seq, int n) {
-    DevTables T;
-    fillDevTablesScalars(t, T);
-    std::vector<uint8_t> code(n);
-    for (int i = 0; i < n; i++) {
-        char c = seq[i];
-        c = (c >= 'A' && c <= 'Z') ? (char)(c - 'A' + 'a') : c;
-        code[i] = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : 4;
-    }
-    std::vector<int> cls(n, -1);
-    int win = t.gc_win;
-    if (win > n || win < 1) win = n;
-    double cnt[4] = {0, 0, 0, 0};
-    for (int i = 0; i < win; i++)
-        if (code[i] < 4) cnt[code[i]] += 1;
-    int x = nearestClass(T, cnt);
-    for (int i = 0; i <= win / 2 && i < n; i++) cls[i] = x;
-    for (int i = win / 2 + 1; i <= n - (win + 1) / 2; i++) {
-        int add = i + (win + 1) / 2 - 1, sub = i - win / 2 - 1;
-        if (code[add] < 4) cnt[code[add]] += 1;
-        if (code[sub] < 4) cnt[code[sub]] -= 1;
-        cls[i] = x = nearestClass(T, cnt);
-    }
-    for (int i = n - (win + 1) / 2 + 1; i < n; i++) cls[i] = x;
-    x = -2;
-    int lastStep = 0;
-    for (int i = 0; i < n; i++)
-        if (cls[i] != x) {
-            if (i - lastStep < 1000 && lastStep > 0 && cls[lastStep - 1] == cls[i])
-                for (int j = lastStep; j < i; j++) cls[j] = cls[i];
-            lastStep = i;
-            x = cls[i];
+// the class-dependent arrays of a batch ([nPl][...], see BatchView): allocated for one plane when the batch is created, and
+// again, larger, by the first decode that meets a piece with more GC classes
+int ensurePlanes(augx_batch *b, int nPl) {
+    if (nPl <= b->nPlAlloc) return 0;
+    BatchView &V = b->V;
+    BatchSizes Z(b->L);
+    struct Slot { void **field; size_t elem; int64_t count; };
+    const Slot slots[11] = {
+        {(void **)&V.fx, sizeof(uint64_t), Z.N * NFX},         {(void **)&V.plsR, sizeof(double), Z.N * 3},
+        {(void **)&V.ldEnt, sizeof(IntronStart), Z.listCap},   {(void **)&V.rdEnt, sizeof(IntronStart), Z.listCap},
+        {(void **)&V.laPls, sizeof(double), Z.listCap * 3},    {(void **)&V.laFx, sizeof(uint64_t), Z.listCap * 3},
+        {(void **)&V.lrEt, sizeof(double), Z.listCap * 3},     {(void **)&V.lrFx, sizeof(uint64_t), Z.listCap * 3},
+        {(void **)&V.atgD, sizeof(double), Z.listCap * 3},     {(void **)&V.atgFx, sizeof(uint64_t), Z.listCap},
+        {(void **)&V.rsFx, sizeof(uint64_t), Z.listCap * 3}};
+    for (int i = 0; i < 11; i++) {
+        if (b->planeBufs[i]) { HIP_TRY(hipFree(b->planeBufs[i])); b->planeBufs[i] = nullptr; *slots[i].field = nullptr; }
+        void *p = nullptr;
+        if (hipMalloc(&p, (size_t)nPl * (size_t)slots[i].count * slots[i].elem) != hipSuccess) {
+            (void)hipGetLastError();
+            b->nPlAlloc = 0;
+            setLastError("augx: out of device memory for the per-GC-class arrays (" + std::to_string(nPl) + " classes in one piece); decode fewer bases per batch");
+            return AUGX_E_NOMEM;
         }
-    for (int i = 1; i < n; i++)
-        if (cls[i] != cls[0]) return -1;
-    return cls[0];
+        b->planeBufs[i] = p;
+        *slots[i].field = p;
+    }
+    b->nPlAlloc = nPl;
+    return 0;
 }
 
 template <bool MAX> int runScan(augx_batch *b, uint64_t *a, int nf) {
@@ -278,7 +274,9 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     if (!d) return 0;
     size_t freeB = 0, totalB = 0;
     if (hipSetDevice(d->device) != hipSuccess || hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 16L * 1000 * 1000;
-    int64_t cap = (int64_t)(freeB / 1700); // ~1.1 KB of per-base arrays + ~0.3 KB of candidates, with head room
+    // ~1.1 KB of per-base arrays + ~0.3 KB of candidates, with head room; a model with several GC classes may need the
+    // class-dependent arrays (~0.28 KB per base) once more per extra class met inside one piece: room for two extra
+    int64_t cap = (int64_t)(freeB / (d->model->m.t.n_classes > 1 ? 2300 : 1700));
     if (cap > 128L * 1000 * 1000) cap = 128L * 1000 * 1000;
     if (cap < 1000 * 1000) cap = 1000 * 1000;
     return cap;
@@ -297,6 +295,8 @@ void augx_batch_destroy(augx_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->dec->device);
     for (void *p : b->bufs) (void)hipFree(p);
+    for (void *p : b->planeBufs)
+        if (p) (void)hipFree(p);
     if (b->itemBuf) (void)hipFree(b->itemBuf);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
@@ -316,7 +316,6 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
         delete b;
         return AUGX_E_ARG;
     }
-    for (int p = 0; p < n; p++) b->hostSeq.push_back(pieces[p].seq);
     const BatchLayout &L = b->L;
     BatchSizes Z(L);
     BatchView &V = b->V;
@@ -329,10 +328,12 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(dRaw, char, Z.N);
     V.off = dOff; V.len = dLen; V.initKind = dIk; V.termKind = dTk; V.chunkPiece = dCp; V.raw = dRaw;
     DA(V.cls, int32_t, n); DA(V.clsMinMax, int32_t, 2 * n);
+    DA(V.nPlanes, int32_t, n); DA(V.planeCls, int32_t, (int64_t)n * MAXPL);
+    DA(V.gcRaw, uint8_t, Z.N); DA(V.gcPlane, uint8_t, Z.N);
+    V.nPl = 1; V.listCap = Z.listCap;
     DA(V.code, uint8_t, Z.N);
     DA(V.cnt, uint64_t, Z.N * NCNT);
     DA(V.nsm, uint64_t, Z.N * 6);
-    DA(V.fx, uint64_t, Z.N * NFX);
     DA(V.sig, double, Z.N * NSIG);
     DA(V.gate, uint64_t, Z.N);
     DA(V.site, int32_t, Z.N * NSITE);
@@ -344,14 +345,11 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
     DA(V.lrPos, int32_t, Z.listCap); DA(V.lrVal, double, Z.listCap * 3);
-    DA(V.ldEnt, IntronStart, Z.listCap); DA(V.ldVal, double, Z.listCap * 3);
-    DA(V.rdEnt, IntronStart, Z.listCap); DA(V.rdVal, double, Z.listCap * 3);
+    DA(V.ldVal, double, Z.listCap * 3);
+    DA(V.rdVal, double, Z.listCap * 3);
     DA(V.atgPos, int32_t, Z.listCap);
-    DA(V.laPls, double, Z.listCap * 3); DA(V.laFx, uint64_t, Z.listCap * 3);
-    DA(V.lrEt, double, Z.listCap * 3); DA(V.lrFx, uint64_t, Z.listCap * 3);
-    DA(V.atgD, double, Z.listCap * 3); DA(V.atgFx, uint64_t, Z.listCap);
-    DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap); DA(V.rsFx, uint64_t, Z.listCap * 3);
-    DA(V.plsR, double, Z.N * 3);
+    DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap);
+    if ((rc = ensurePlanes(b, 1))) { augx_batch_destroy(b); return rc; }
     V.blk = d->blk;
     V.nBlk = Z.N / V.blk;
     DA(V.blkCnt, uint32_t, V.nBlk * 2); DA(V.blkSplit, uint32_t, V.nBlk * 3); DA(V.blkOff, uint64_t, V.nBlk * 2);
@@ -365,6 +363,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     HIP_TRY(hipMemcpy(dTk, L.termKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dCp, L.chunkPiece.data(), sizeof(int32_t) * L.nChunks, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(dRaw, 'n', (size_t)Z.N));
+    HIP_TRY(hipMemset(V.gcPlane, 0, (size_t)Z.N));
     for (int p = 0; p < n; p++)
         HIP_TRY(hipMemcpy(dRaw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p], hipMemcpyHostToDevice));
     { void *pv = nullptr; HIP_TRY(hipMalloc(&pv, sizeof(BatchView))); b->bufs.push_back(pv); b->dV = (BatchView *)pv; }
@@ -391,21 +390,48 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kClassFinal, dim3((n + 63) / 64), dim3(64), 0, st, V);
     HIP_TRY(hipGetLastError());
-    {   // pieces whose 1-bp-shifted GC windows do not all agree: settle the smoothed stairs on the host
+    {   // pieces whose 1-bp-shifted GC windows do not all agree: the smoothed content stairs are settled on the host from
+        // the window classes (1 byte per base; reference ContentStairs::computeStairs, src/motif.cc:543-616), and the
+        // classes of the piece become planes of the class-dependent arrays
+        BatchView &W = b->V;
         std::vector<int32_t> cls(n);
         HIP_TRY(hipMemcpyAsync(cls.data(), V.cls, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        int nPl = 1;
         bool any = false;
-        for (int p = 0; p < n; p++)
-            if (cls[p] < 0) { cls[p] = hostStairsClass(d->model->m.t, b->hostSeq[p], b->L.len[p]); any = true; }
-        if (any) HIP_TRY(hipMemcpyAsync(V.cls, cls.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-        if (any) HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int32_t> nPlanes(n, 1), planeCls((size_t)n * MAXPL, 0);
+        std::vector<uint8_t> wc, plane;
+        for (int p = 0; p < n; p++) {
+            planeCls[(size_t)p * MAXPL] = cls[p];
+            if (cls[p] >= 0) continue; // (gcPlane is all zero for such a piece: set when the batch was created)
+            const int len = b->L.len[p];
+            any = true;
+            wc.resize((size_t)len);
+            HIP_TRY(hipMemcpy(wc.data(), V.gcRaw + b->L.off[p] + 1, (size_t)len, hipMemcpyDeviceToHost));
+            const int np = stairsPlanes(wc.data(), len, d->model->m.t.gc_win, plane, &planeCls[(size_t)p * MAXPL]);
+            if (np < 0) continue; // more than MAXPL classes: the piece reports AUGX_E_UNSUPPORTED
+            cls[p] = planeCls[(size_t)p * MAXPL];
+            nPlanes[p] = np;
+            if (np > nPl) nPl = np;
+            if (np > 1) HIP_TRY(hipMemcpy(V.gcPlane + b->L.off[p] + 1, plane.data(), (size_t)len, hipMemcpyHostToDevice));
+        }
+        if (any) {
+            HIP_TRY(hipMemcpy(V.cls, cls.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(V.nPlanes, nPlanes.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(V.planeCls, planeCls.data(), sizeof(int32_t) * n * MAXPL, hipMemcpyHostToDevice));
+        }
+        if ((rc = ensurePlanes(b, nPl))) return rc;
+        if (W.nPl != nPl) { // (the planes of a batch are a property of its sequences: this happens in its first decode only)
+            W.nPl = nPl;
+            HIP_TRY(hipMemcpy(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice));
+        }
     }
-    hipLaunchKernelGGL(kFxTerms, dim3(gridN), dim3(256), 0, st, d->dT, V);
-    if ((rc = runScan<false>(b, V.fx, NFX))) return rc;
+    hipLaunchKernelGGL(kFxTerms, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);
+    for (int pl = 0; pl < V.nPl; pl++)
+        if ((rc = runScan<false>(b, V.fx + (int64_t)pl * V.N * NFX, NFX))) return rc;
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.N / 2 + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
-    hipLaunchKernelGGL(kSiteConsts, dim3(gridN), dim3(256), 0, st, d->dT, V);
+    hipLaunchKernelGGL(kSiteConsts, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn
         // out too small (first decode of a batch, unusual sequence), it reports the size needed and is run again.
@@ -424,9 +450,13 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         }
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
-            if (d->blk == 8) hipLaunchKernelGGL(kCand<8>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-            else if (d->blk == 4) hipLaunchKernelGGL(kCand<4>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-            else hipLaunchKernelGGL(kCand<2>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+            const bool multi = W.nPl > 1;
+#define AUGX_LAUNCH_CAND(BLK_) do { if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, b->dV); \
+                                    else hipLaunchKernelGGL((kCand<BLK_, false>), dim3(nWg), dim3(NT), 0, st, d->dT, b->dV); } while (0)
+            if (d->blk == 8) AUGX_LAUNCH_CAND(8);
+            else if (d->blk == 4) AUGX_LAUNCH_CAND(4);
+            else AUGX_LAUNCH_CAND(2);
+#undef AUGX_LAUNCH_CAND
             HIP_TRY(hipGetLastError());
             CandAlloc tot;
             HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));

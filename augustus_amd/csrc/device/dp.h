@@ -49,6 +49,7 @@ constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >
 constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
 // bases per trellis block (template parameter BLK of the candidate and trellis kernels): smaller than every lag of the
 // model except the lag-1 chain states.  8 where the species' windows allow it, else 4 or 2 (layout.h: chooseBlockSize)
+constexpr int MAXPL = 8;                     // GC-content classes decoded inside one piece
 constexpr int MAXNB = 32;                    // blocks per tile of 64 bases at the smallest block size (2)
 
 struct CandAlloc;
@@ -82,8 +83,18 @@ struct BatchView {
     const int32_t *len;        // [nPieces]
     const int32_t *initKind, *termKind;
     const int32_t *chunkPiece; // [nChunks]
-    int32_t *cls;              // [nPieces] GC class of the piece (single class per piece in this version)
+    int32_t *cls;              // [nPieces] GC class of plane 0 of the piece (-1: more than MAXPL classes, not decoded)
     int32_t *clsMinMax;        // [nPieces][2]
+    // GC-content classes inside a piece (reference NAMGene::viterbiAndForward switches all class-dependent tables at every
+    // step of the content stairs, src/namgene.cc:245-248: a state ENDING at base j is scored with the tables of class(j)).
+    // The classes of a piece are numbered by first appearance ("planes"); every class-dependent prefix / list array exists
+    // once per plane ([nPl][...], plane-major), and the end base of a state selects the plane.
+    int nPl;                   // planes allocated in this batch (1: no multi-class piece)
+    int64_t listCap;           // entries per plane of the candidate-side list arrays
+    uint8_t *gcRaw;            // [N] class of the GC window STARTING at this base (unsmoothed; input of the stairs)
+    uint8_t *gcPlane;          // [N] plane of the base
+    int32_t *nPlanes;          // [nPieces]
+    int32_t *planeCls;         // [nPieces][MAXPL] class of each plane
     const char *raw;           // [N] ASCII (slot layout)
     uint8_t *code;             // [N] 0..3 acgt, 4 invalid / padding
     uint64_t *cnt;             // [N][4] prefix base counts

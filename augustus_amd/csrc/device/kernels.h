@@ -133,6 +133,15 @@ AUGX_HD Piece makePiece(const DevTables &T, const BatchView &B, int p) {
     P.sig = B.sig + (o + 1) * NSIG;
     return P;
 }
+// the same piece seen through plane pl: tables of that plane's GC class, content prefix sums of that plane
+AUGX_HD Piece makePieceAt(const DevTables &T, const BatchView &B, int p, int pl) {
+    Piece P = makePiece(T, B, p);
+    if (pl > 0) {
+        P.c = B.planeCls[p * MAXPL + pl];
+        P.fx = B.fx + (int64_t)pl * B.N * NFX;
+    }
+    return P;
+}
 
 // =================================================================================================
 // K1  prep kernels (one thread per slot unless noted).  g = global slot index.
@@ -168,8 +177,11 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
     if (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') cnt[CNT_SOFT] = 1; // lower-case base = nonexonpart hint (src/extrinsicinfo.cc:1703-1720)
     // start codon with positive probability at q (a of atg)
     if (q < P.n - 2) { int pn = P.pat(q, 3); if (pn >= 0 && T.ln_startcodon[pn] > AUGX_NINF) cnt[CNT_ATG] = 1; }
-    if (P.possASS(q - T.Ae)) cnt[CNT_LA] = 1;                       // longass may end at q   (src/intronmodel.cc:705)
-    if (P.possRDSS(q - T.Ds)) cnt[CNT_LR] = 1;                      // rlongdss may end at q  (:709)
+    // (base 0 is also listed when an exon may begin right after it without a splice site: the reference asks for the
+    //  site only if the biological exon begins at base >= 2 (src/exonmodel.cc:1468, 1522), and such a candidate then
+    //  continues from column 0 -- the initial probabilities of the longass / rlongdss states)
+    if (P.possASS(q - T.Ae) || (q == 0 && T.Ae <= 1)) cnt[CNT_LA] = 1;   // longass may end at q   (src/intronmodel.cc:705)
+    if (P.possRDSS(q - T.Ds) || (q == 0 && T.Ds <= 1)) cnt[CNT_LR] = 1;  // rlongdss may end at q  (:709)
     if (P.possDSS(q - T.De - 2 + 1)) cnt[CNT_LD] = 1;               // longdss may end at q   (:693)
     if (P.possRASS(q - T.U - T.As - 2 + 1)) cnt[CNT_RD] = 1;        // rlongass may end at q  (:713)
     if (q <= P.n - 3) {
@@ -219,18 +231,21 @@ AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
     if (s < 0 || s > n - win) return -1;
     double cnt[4];
     for (int i = 0; i < 4; i++) cnt[i] = (double)(B.cnt[fidx(o + s + win, i, NCNT)] - B.cnt[fidx(o + s, i, NCNT)]);
-    return nearestClass(T, cnt);
+    const int c = nearestClass(T, cnt);
+    B.gcRaw[g] = (uint8_t)c; // input of the content stairs, should the windows of the piece disagree (layout.h: stairsPlanes)
+    return c;
 }
 
 // fixed-point terms of the 20 content prefix fields
-AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g) {
+AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g, int pl) {
     int p = B.chunkPiece[g / CHUNK];
+    if (pl > 0 && pl >= B.nPlanes[p]) return; // (this piece has no such plane)
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
     uint64_t out[NFX];
     for (int i = 0; i < NFX; i++) out[i] = 0;
     Piece P;
-    P.t = &T; P.n = B.len[p]; P.c = B.cls[p]; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    P.t = &T; P.n = B.len[p]; P.c = B.cls[p] < 0 ? -1 : B.planeCls[p * MAXPL + pl]; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
     if (q >= 0 && q < B.len[p] && P.c >= 0) {
     const int k = T.k, NP = T.NP, c = P.c;
     int pn = q >= k ? P.pat(q - k, k + 1) : -1;
@@ -250,7 +265,8 @@ AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g) {
     int rn2 = (q + k < P.n) ? rn : -1;
     out[FX_INR] = toFx((rn2 >= 0 ? inE[rn2] : T.ln_quarter) + softB);
     }
-    for (int i = 0; i < NFX; i++) B.fx[fidx(g, i, NFX)] = out[i];
+    uint64_t *fx = B.fx + (int64_t)pl * B.N * NFX;
+    for (int i = 0; i < NFX; i++) fx[fidx(g, i, NFX)] = out[i];
 }
 
 // per-base signal record + end-gate mask of the variable-length states
@@ -265,7 +281,7 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     int32_t *st = B.site + g * NSITE;
     for (int i = 0; i < NSITE; i++) st[i] = -1;
     if (q < 0 || q >= B.len[p] || B.cls[p] < 0) return;
-    Piece P = makePiece(T, B, p);
+    Piece P = makePieceAt(T, B, p, B.gcPlane[g]); // everything ending at q is scored with the class of q
     const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
     const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0; // (src/igenicmodel.cc:306-326)
     sg[SIG_EIG] = q >= 1 ? eIg(P, q) + softB : AUGX_NINF;
@@ -322,8 +338,8 @@ AUGX_HD void k1SiteSignals(const DevTables &T, const BatchView &B, int64_t t, in
     const int64_t o = B.off[p], lo = listOff(B, p), li = t - lo;
     const int n = B.len[p];
     if (li < 0 || li >= (int64_t)B.cnt[fidx(o + n, CNT_LA + sel, NCNT)]) return;
-    Piece P = makePiece(T, B, p);
     const int q = sel == 0 ? B.laPos[lo + li] : sel == 1 ? B.lrPos[lo + li] : sel == 2 ? B.ldEnt[lo + li].pos : B.rdEnt[lo + li].pos;
+    Piece P = makePieceAt(T, B, p, B.gcPlane[o + 1 + q]);
     const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
     double *sg = B.sig + (o + 1 + q) * NSIG;
     // soft-masked bases inside the intronic part of the state's window [a, b] (reference src/intronmodel.cc:872-924,1011-1036)
@@ -343,15 +359,18 @@ AUGX_HD void k1SiteSignals(const DevTables &T, const BatchView &B, int64_t t, in
 // candidate-side constants of the list entries (everything a candidate contributes that does not depend on Viterbi
 // values).  Fast-path evaluation in the trellis combines them with end-side constants; the arithmetic is exactly that
 // of exNotEndPart (same prefix differences, same order of additions).
-AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
+// One set of constants per plane (GC class) of the piece -- the END of the candidate's state selects the plane: pl = plane.
+AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int pl) {
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
     if (q < 0 || q >= B.len[p]) return;
-    double *pr = B.plsR + g * 3;
+    if (pl > 0 && (B.cls[p] < 0 || pl >= B.nPlanes[p])) return; // (this piece has no such plane)
+    const int64_t pN = (int64_t)pl * B.N, pL = (int64_t)pl * B.listCap;
+    double *pr = B.plsR + (pN + g) * 3;
     pr[0] = pr[1] = pr[2] = AUGX_NINF;
     if (B.cls[p] < 0) return;
-    Piece P = makePiece(T, B, p);
+    Piece P = makePieceAt(T, B, p, pl);
     const int k = T.k, c = P.c, n = P.n;
     const int64_t lo = listOff(B, p);
     auto fxv = [&](int pos, int f) -> uint64_t { return pos < 0 ? 0 : P.fx[fidx(o + 1 + (pos < n ? pos : n - 1), f, NFX)]; };
@@ -363,7 +382,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
     uint64_t cn[NCNT], cp[NCNT];
     for (int i = CNT_ATG; i < NCNT; i++) { cn[i] = B.cnt[fidx(g, i, NCNT)]; cp[i] = B.cnt[fidx(g - 1, i, NCNT)]; }
     if (cn[CNT_LA] != cp[CNT_LA]) { // forward acceptor candidate ending (as longass state) at q: exon inner part starts at bs = q+1
-        int64_t idx = lo + (int64_t)cn[CNT_LA] - 1;
+        int64_t idx = pL + lo + (int64_t)cn[CNT_LA] - 1;
         int bs = q + 1, eos = bs + k - 1, pn = P.pat(bs, k);
         for (int a = 0; a < 3; a++) {
             B.laPls[idx * 3 + a] = k == 0 ? 0.0 : plsK(pn, mod3(eos + a));
@@ -371,7 +390,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
         }
     }
     if (cn[CNT_LR] != cp[CNT_LR]) { // reverse donor candidate
-        int64_t idx = lo + (int64_t)cn[CNT_LR] - 1;
+        int64_t idx = pL + lo + (int64_t)cn[CNT_LR] - 1;
         int bs = q + 1, eot = bs + T.Le - 1;
         for (int a = 0; a < 3; a++) {
             const int fb = (1 * 3 + a) * 3;
@@ -382,17 +401,17 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
     }
     // short-intron starts: content prefix at q and the two bases before the biological intron (spliced-codon check)
     if (cn[CNT_LD] != cp[CNT_LD]) {
-        IntronStart &e = B.ldEnt[lo + (int64_t)cn[CNT_LD] - 1];
+        IntronStart &e = B.ldEnt[pL + lo + (int64_t)cn[CNT_LD] - 1];
         const int bobi = q + 1 - T.De - 2;
-        e.fx = fxv(q, FX_INF); e.ctx = (uint32_t)P.b(bobi - 1) | ((uint32_t)P.b(bobi - 2) << 4);
+        e.pos = q; e.fx = fxv(q, FX_INF); e.ctx = (uint32_t)P.b(bobi - 1) | ((uint32_t)P.b(bobi - 2) << 4);
     }
     if (cn[CNT_RD] != cp[CNT_RD]) {
-        IntronStart &e = B.rdEnt[lo + (int64_t)cn[CNT_RD] - 1];
+        IntronStart &e = B.rdEnt[pL + lo + (int64_t)cn[CNT_RD] - 1];
         const int bobi = q + 1 - (T.U + T.As + 2);
-        e.fx = fxv(q, FX_INR); e.ctx = (uint32_t)P.b(bobi - 1) | ((uint32_t)P.b(bobi - 2) << 4);
+        e.pos = q; e.fx = fxv(q, FX_INR); e.ctx = (uint32_t)P.b(bobi - 1) | ((uint32_t)P.b(bobi - 2) << 4);
     }
     if (cn[CNT_ATG] != cp[CNT_ATG]) { // start codon at q: bs = q+3, frame phase a = (-q) mod 3
-        int64_t idx = lo + (int64_t)cn[CNT_ATG] - 1;
+        int64_t idx = pL + lo + (int64_t)cn[CNT_ATG] - 1;
         int bs = q + 3, eos = bs + k - 1, eoi = eos + T.Li, a = mod3(-q);
         const int fb = (0 * 3 + a) * 3;
         B.atgD[idx * 3 + 0] = tisFwd(P, q);
@@ -402,9 +421,11 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
     }
     if (cn[CNT_RS] != cp[CNT_RS]) { // reverse stop codon at q..q+2: bs = q+3
         int64_t idx = lo + (int64_t)cn[CNT_RS] - 1;
-        B.rsPos[idx] = q;
-        B.rsBegin[idx] = (P.b(q) == 3 && P.b(q + 1) == 3) ? T.ln_stop_ochre : (P.b(q) == 1) ? T.ln_stop_amber : T.ln_stop_opal;
-        for (int a = 0; a < 3; a++) B.rsFx[idx * 3 + a] = fxv(q + 2, (1 * 3 + a) * 3 + 0);
+        if (pl == 0) {
+            B.rsPos[idx] = q;
+            B.rsBegin[idx] = (P.b(q) == 3 && P.b(q + 1) == 3) ? T.ln_stop_ochre : (P.b(q) == 1) ? T.ln_stop_amber : T.ln_stop_opal;
+        }
+        for (int a = 0; a < 3; a++) B.rsFx[(pL + idx) * 3 + a] = fxv(q + 2, (1 * 3 + a) * 3 + 0);
     }
 }
 
@@ -423,18 +444,19 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g) {
 #ifdef AUGX_EMU
 static long long g_emuSlowA = 0, g_emuSlowB = 0; // emulator statistics: candidates taking the general evaluation path
 #endif
-struct VarDesc {
-    int kind, win, nList, extra, total, listSel; // listSel: 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
+struct VarDesc { // (kind, frame and geometry of the state are per-state constants: VarConst)
+    int pl;                                       // plane (GC class) of the end base j: selects every class-dependent array
+    int nList, extra, total, listSel;             // listSel: 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
+    int a;                                        // phase of the content prefix fields
+    int lenSel;                                   // length distribution of this exon type: 0 single, 1 initial, 2 internal, 3 terminal
+    int cods;                                     // short intron: spliced-codon bases on the end side, 4 bits each (cod0 | cod1 << 4 | cod2 << 8)
     int64_t i1;                                   // one past the newest list entry (piece-local index)
     int eob, right, fOR, startMin;                // exon geometry
-    int eobi, cod0, cod1, cod2;                   // short intron: end of the biological intron, spliced-codon bases
+    int eobi;                                     // short intron: end of the biological intron
     double endP;
-    ExGeom g;
     // end-side constants of the fast candidate evaluation (see k1SiteConsts)
-    int a;                  // phase of the content prefix fields
     uint64_t eFx;           // content prefix at the end-side boundary
     double eD0, plsEnd;     // end-side content term (exon-terminal fwd / initial-content rev), reverse-strand ln P_ls
-    int lenSel;             // length distribution of this exon type: 0 single, 1 initial, 2 internal, 3 terminal
 };
 
 // wave-level bookkeeping primitives (device: cross-lane instructions; emulator: loops over the lane arrays)
@@ -455,7 +477,7 @@ AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 // per-state constants of the variable-length states
 struct VarConst {
     int kind, win, nanc, anc[4], ancWin[4];
-    double tr[4];
+    double tr[MAXPL][4];   // ln transition probability from each ancestor, per plane of the piece
     ExGeom g;
 };
 
@@ -472,12 +494,15 @@ AUGX_HD uint32_t srcList(int ai, int sel, int frame, int64_t li) { return (SRC_L
 AUGX_HD uint32_t srcVig(int ai, int eop) { return (SRC_VIG << 30) | ((uint32_t)ai << 28) | ((uint32_t)eop & 0xFFFFFFu); }
 AUGX_HD uint32_t srcCol0(int ai, int a) { return (SRC_COL0 << 30) | ((uint32_t)ai << 28) | (uint32_t)a; }
 
-AUGX_HD void fillVarConst(const DevTables &T, int c, int l, VarConst &VC) {
+AUGX_HD void fillVarConst(const DevTables &T, const BatchView &B, int p, int l, VarConst &VC) {
     const int kind = T.kind[l];
     VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
+    const int nPl = B.cls[p] < 0 ? 0 : B.nPlanes[p];
     for (int ai = 0; ai < 4; ai++) {
         int a = ai < VC.nanc ? T.anc[l][ai] : 0;
-        VC.anc[ai] = a; VC.ancWin[ai] = T.win[a]; VC.tr[ai] = ai < VC.nanc ? lnT(T, c, a, l) : AUGX_NINF;
+        VC.anc[ai] = a; VC.ancWin[ai] = T.win[a];
+        VC.tr[0][ai] = AUGX_NINF;
+        for (int pl = 0; pl < nPl; pl++) VC.tr[pl][ai] = ai < VC.nanc ? lnT(T, B.planeCls[p * MAXPL + pl], a, l) : AUGX_NINF; // (planes >= nPl are never read)
     }
     VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
 }
@@ -518,35 +543,45 @@ struct CandCtx {
         if (sel >= 2) return (sel == 2 ? B.ldEnt : B.rdEnt)[lo + li].pos;
         return (sel == 0 ? B.laPos : B.lrPos)[lo + li];
     }
-    AUGX_HD double listC(int sel, int64_t li, int a) const { // LA: ln P_ls, LR: exon-terminal content
-        return (sel == 0 ? B.laPls : B.lrEt)[(lo + li) * 3 + a];
+    // class-dependent arrays: plane pl of [nPl][...]
+    AUGX_HD int64_t pL(int pl) const { return (int64_t)pl * B.listCap + lo; }
+    AUGX_HD double listC(int pl, int sel, int64_t li, int a) const { // LA: ln P_ls, LR: exon-terminal content
+        return (sel == 0 ? B.laPls : B.lrEt)[(pL(pl) + li) * 3 + a];
     }
-    AUGX_HD uint64_t listFx(int sel, int64_t li, int a) const {
-        if (sel == 0) return B.laFx[(lo + li) * 3 + a];
-        if (sel == 1) return B.lrFx[(lo + li) * 3 + a];
-        return (sel == 2 ? B.ldEnt : B.rdEnt)[lo + li].fx;
+    AUGX_HD uint64_t listFx(int pl, int sel, int64_t li, int a) const {
+        if (sel == 0) return B.laFx[(pL(pl) + li) * 3 + a];
+        if (sel == 1) return B.lrFx[(pL(pl) + li) * 3 + a];
+        return (sel == 2 ? B.ldEnt : B.rdEnt)[pL(pl) + li].fx;
     }
-    AUGX_HD uint64_t fxAt(int q, int f) const { // content prefix field f up to and including base q (q < 0: empty)
+    AUGX_HD uint64_t fxAt(int pl, int q, int f) const { // content prefix field f up to and including base q (q < 0: empty)
         if (q < 0) return 0;
-        return B.fx[fidx(o + 1 + q, f, NFX)];
+        return B.fx[(int64_t)pl * B.N * NFX + fidx(o + 1 + q, f, NFX)];
+    }
+    AUGX_HD Piece pieceAt(int pl) const { // the piece seen through plane pl (general evaluation paths)
+        Piece Q = P;
+        if (pl > 0) { Q.c = B.planeCls[p * MAXPL + pl]; Q.fx = B.fx + (int64_t)pl * B.N * NFX; }
+        return Q;
     }
     AUGX_HD double lenAt(int sel, int len) const {
         return (sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
     }
     AUGX_HD double lenIAt(int len) const { return T.len_intron[len]; }
-    AUGX_HD double plsRAt(int q, int fr) const { return B.plsR[(o + 1 + q) * 3 + fr]; }
+    AUGX_HD double plsRAt(int pl, int q, int fr) const { return B.plsR[((int64_t)pl * B.N + o + 1 + q) * 3 + fr]; }
     AUGX_HD double sigAt(int q, int i) const { return B.sig[(o + 1 + q) * NSIG + i]; }
 };
 
 // descriptor of state s ending at base j: candidate range and end-side constants
+template <bool MULTI>
 AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
     const DevTables &T = X.T;
-    const Piece &P = X.P;
+    const Piece &P = X.P; // (sequence, stop tables and signal records only: nothing class-dependent is read through it here)
     const VarConst &VC = X.vc[s];
     const int kind = VC.kind, win = VC.win, n = X.n;
-    D.kind = kind; D.win = win; D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
-    D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cod0 = D.cod1 = D.cod2 = 4; D.endP = AUGX_NINF;
-    D.g = VC.g;
+    const int pl = MULTI ? X.B.gcPlane[X.o + 1 + j] : 0; // (MULTI: the batch has a piece with more than one GC class)
+    D.pl = pl;
+    D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
+    D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cods = 0x444; D.endP = AUGX_NINF;
+    const ExGeom &Dg = VC.g;
     D.a = 0; D.eFx = 0; D.eD0 = 0.0; D.plsEnd = 0.0; D.lenSel = 2;
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         const bool fwd = kind == AUGX_K_LESSD;
@@ -554,16 +589,18 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         const int eobi = fwd ? j + T.U + T.As + 2 : j + T.De + 2;
         const bool haveRight = eobi < n - 2;
         D.eobi = eobi;
+        int cod0 = 4, cod1 = 4, cod2 = 4;
         if (fwd) {
-            if (f == 1) { D.cod1 = haveRight ? P.b(eobi + 1) : 4; D.cod2 = haveRight ? P.b(eobi + 2) : 4; }
-            if (f == 2) { D.cod2 = haveRight ? P.b(eobi + 1) : 4; }
+            if (f == 1) { cod1 = haveRight ? P.b(eobi + 1) : 4; cod2 = haveRight ? P.b(eobi + 2) : 4; }
+            if (f == 2) { cod2 = haveRight ? P.b(eobi + 1) : 4; }
         } else {
-            if (f == 0) D.cod0 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
+            if (f == 0) cod0 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
             if (f == 1) {
-                D.cod0 = (haveRight && P.b(eobi + 2) <= 3) ? 3 - P.b(eobi + 2) : 4;
-                D.cod1 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
+                cod0 = (haveRight && P.b(eobi + 2) <= 3) ? 3 - P.b(eobi + 2) : 4;
+                cod1 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
             }
         }
+        D.cods = cod0 | (cod1 << 4) | (cod2 << 8);
         int left = j - T.dStateLen;
         if (left < 0) left = 0;
         const int fld = fwd ? CNT_LD : CNT_RD;
@@ -574,39 +611,39 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         D.extra = left == 0 ? 1 : 0; // eop = 0 reads column 0 (initial probabilities); not a splice site, so not listed
         D.total = D.nList + D.extra;
         D.endP = 0.0;
-        D.eFx = X.fxAt(j, fwd ? FX_INF : FX_INR);
+        D.eFx = X.fxAt(pl, j, fwd ? FX_INF : FX_INR);
         return;
     }
-    const ExEnd e = exEnd(P, kind, win, j, D.g);
+    const ExEnd e = exEnd(P, kind, win, j, Dg);
     D.eob = e.eob; D.right = e.right; D.fOR = e.fOR; D.startMin = e.startMin;
     D.endP = (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) ? X.sigAt(j, SIG_STOPF)
              : (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) ? X.sigAt(j, SIG_TISR) : 0.0; // gate is open
     if (!(D.endP > AUGX_NINF) || e.right < 0 || e.startMax < e.startMin) return;
     {   // end-side constants of the fast candidate evaluation
         const int k = T.k, right = e.right;
-        const int a = D.g.fwd ? mod3(e.fOR - right) : mod3(e.fOR + right);
-        const int fb = ((D.g.fwd ? 0 : 1) * 3 + a) * 3;
+        const int a = Dg.fwd ? mod3(e.fOR - right) : mod3(e.fOR + right);
+        const int fb = ((Dg.fwd ? 0 : 1) * 3 + a) * 3;
         D.a = a;
         switch (kind) {
         case AUGX_K_INTERNAL: case AUGX_K_INITIAL:
-            D.eFx = X.fxAt(right - T.Le, fb + 0);
-            D.eD0 = T.Le > 0 ? (double)(int64_t)(X.fxAt(right, fb + 2) - X.fxAt(right - T.Le, fb + 2)) * AUGX_FX_INV : 0.0;
+            D.eFx = X.fxAt(pl, right - T.Le, fb + 0);
+            D.eD0 = T.Le > 0 ? (double)(int64_t)(X.fxAt(pl, right, fb + 2) - X.fxAt(pl, right - T.Le, fb + 2)) * AUGX_FX_INV : 0.0;
             D.lenSel = kind == AUGX_K_INTERNAL ? 2 : 1;
             break;
         case AUGX_K_TERMINAL: case AUGX_K_SINGLE:
-            D.eFx = X.fxAt(right, fb + 0);
+            D.eFx = X.fxAt(pl, right, fb + 0);
             D.lenSel = kind == AUGX_K_TERMINAL ? 3 : 0;
             break;
         default: {
             const int boip = right - (k - 1);
-            D.plsEnd = (k > 0 && boip >= 0) ? X.plsRAt(right, mod3(e.fOR + right - boip)) : 0.0;
+            D.plsEnd = (k > 0 && boip >= 0) ? X.plsRAt(pl, right, mod3(e.fOR + right - boip)) : 0.0;
             if (kind == AUGX_K_RINTERNAL || kind == AUGX_K_RTERMINAL) {
-                D.eFx = X.fxAt(boip - 1, fb + 0);
+                D.eFx = X.fxAt(pl, boip - 1, fb + 0);
                 D.lenSel = kind == AUGX_K_RINTERNAL ? 2 : 3;
             } else {
                 const int boi = boip - T.Li;
-                D.eFx = X.fxAt(boi - 1, fb + 0);
-                D.eD0 = T.Li > 0 ? (double)(int64_t)(X.fxAt(boip - 1, fb + 1) - X.fxAt(boi - 1, fb + 1)) * AUGX_FX_INV : 0.0;
+                D.eFx = X.fxAt(pl, boi - 1, fb + 0);
+                D.eD0 = T.Li > 0 ? (double)(int64_t)(X.fxAt(pl, boip - 1, fb + 1) - X.fxAt(pl, boi - 1, fb + 1)) * AUGX_FX_INV : 0.0;
                 D.lenSel = kind == AUGX_K_RINITIAL ? 1 : 0;
             }
         }
@@ -621,10 +658,10 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         D.listSel = 5; // single candidate bs = ORFleft+2 (src/exonmodel.cc:1044-1045)
         D.nList = 1;
     } else {
-        const int fld = D.g.fwd ? CNT_LA : CNT_LR; // eop = bs - 1 in [startMin-1, startMax-1]
+        const int fld = Dg.fwd ? CNT_LA : CNT_LR; // eop = bs - 1 in [startMin-1, startMax-1]
         const int64_t i0 = (int64_t)X.cntAt(e.startMin - 2, fld);
         D.i1 = (int64_t)X.cntAt(e.startMax - 1, fld);
-        D.listSel = D.g.fwd ? 0 : 1;
+        D.listSel = Dg.fwd ? 0 : 1;
         D.nList = (int)(D.i1 - i0);
         D.extra = e.startMin == 0 ? 1 : 0; // bs = 0: left-truncated exon, predecessor column 0
     }
@@ -633,12 +670,15 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
 
 // candidate number idx (0 = newest) of the state described by D: te = ln(transition * emission) (-inf: infeasible),
 // tie-break key, and the address of the predecessor's Viterbi value
+template <bool MULTI>
 AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int idx, double &te, int &key, uint32_t &src) {
     const DevTables &T = X.T;
     const BatchView &B = X.B;
-    const Piece &P = X.P;
     const VarConst &VC = X.vc[s];
-    const int n = X.n, kind = D.kind, win = D.win;
+    const int n = X.n, kind = VC.kind, win = VC.win, pl = MULTI ? D.pl : 0;
+    const Piece P = X.pieceAt(pl); // (class-dependent reads of the general paths go through the plane of the end base)
+    const ExGeom &Dg = VC.g;
+    const double *trPl = VC.tr[pl];
     te = AUGX_NINF; key = 0; src = srcCol0(0, 0);
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         // written without early exits so that the loads of one candidate are all in flight together: the list entry
@@ -651,7 +691,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         // (its splice-site dinucleotide is what put it on the list)
         IntronStart e;
         e.pos = 0; e.ctx = 0x44; e.fx = 0;
-        if (listed) e = ldIntronStart((D.listSel == 2 ? B.ldEnt : B.rdEnt) + X.lo + li);
+        if (listed) e = ldIntronStart((D.listSel == 2 ? B.ldEnt : B.rdEnt) + X.pL(pl) + li);
         const int eop = e.pos;
         const uint32_t sr = listed ? srcList(0, D.listSel, f, li) : srcCol0(0, VC.anc[0]);
         const int begin = eop + 1;
@@ -672,7 +712,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         const bool spliced = fwd ? (f != 0) : (f != 2);
         bool veto = false;
         if (spliced && bobi > 1) {
-            int c0 = D.cod0, c1 = D.cod1, c2 = D.cod2;
+            int c0 = D.cods & 15, c1 = (D.cods >> 4) & 15, c2 = (D.cods >> 8) & 15;
             if (fwd) {
                 if (f == 1) c0 = bM1;
                 else { c0 = bM2; c1 = bM1; }
@@ -685,7 +725,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         const double restSeq = listed ? (double)(int64_t)(D.eFx - cFx) * AUGX_FX_INV : P.seg(fwd ? FX_INF : FX_INR, begin, j);
         const double emi = lenI + restSeq;
         if (siteOk && !veto && lenOk && emi > AUGX_NINF) {
-            te = VC.tr[0] + emi;
+            te = trPl[0] + emi;
             key = eop + KEY_BIAS; src = sr;
         }
         return;
@@ -699,17 +739,18 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         if (D.listSel == 4) {
             const int64_t ai2 = D.i1 - 1 - idx;
             bs = B.atgPos[X.lo + ai2] + 3;
-            tisF = B.atgD[(X.lo + ai2) * 3 + 0]; cPls = B.atgD[(X.lo + ai2) * 3 + 1]; cInit = B.atgD[(X.lo + ai2) * 3 + 2];
-            cFxA = B.atgFx[X.lo + ai2];
+            const int64_t ap = X.pL(pl) + ai2;
+            tisF = B.atgD[ap * 3 + 0]; cPls = B.atgD[ap * 3 + 1]; cInit = B.atgD[ap * 3 + 2];
+            cFxA = B.atgFx[ap];
         } else
             bs = D.startMin;
-        int eop = bs - D.g.bpl - 1;
+        int eop = bs - Dg.bpl - 1;
         // eop == j reads the igenic cell of the CURRENT column (already final: the reference fills states in index
         // order and igenic is state 0); later columns do not exist yet
         if (!(eop < n && eop <= j)) return;
         double nep;
         const int m = D.right - bs, k = T.k;
-        const int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+        const int bob = bs - Dg.ipo, len = D.eob - bob + 1;
         // length and reading-frame constraints first (reference src/exonmodel.cc:1716-1762 applies them last; a candidate
         // that fails them is infeasible whatever its content score): two of three start codons are out of frame
         if (len < 1 || len > T.max_exon_len) return;
@@ -739,7 +780,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                 if (len >= 1 && len <= T.max_exon_len && (kind == AUGX_K_RSINGLE ? len % 3 == 0 : mod3(2 - len) == win)) lenPart = X.lenAt(D.lenSel, len);
                 if (!(lenPart > AUGX_NINF)) return;
                 const int64_t ri = (int64_t)X.cntAt(bob, CNT_RS) - 1; // the reverse stop codon at bob = bs-3
-                double seg1 = (double)(int64_t)(D.eFx - B.rsFx[(X.lo + ri) * 3 + D.a]) * AUGX_FX_INV;
+                double seg1 = (double)(int64_t)(D.eFx - B.rsFx[(X.pL(pl) + ri) * 3 + D.a]) * AUGX_FX_INV;
                 double inner = kind == AUGX_K_RTERMINAL ? seg1 : (D.eD0 + seg1);
                 nep = (B.rsBegin[X.lo + ri] + (D.plsEnd + inner)) + lenPart;
             }
@@ -747,15 +788,15 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
 #ifdef AUGX_EMU
         if (!fast) g_emuSlowA++;
 #endif
-        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, tisF);
+        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, Dg, tisF);
         if (!(nep > AUGX_NINF)) return;
-        te = (VC.tr[0] + D.endP) + nep;
+        te = (trPl[0] + D.endP) + nep;
         key = eop + KEY_BIAS;
         src = eop <= 0 ? srcCol0(0, a) : srcVig(0, eop);
         return;
     }
     // predecessors are the three longass_f (forward) or rlongdss_f (reverse) states, listed per splice site
-    const bool fwd = D.g.fwd;
+    const bool fwd = Dg.fwd;
     int eop;
     int64_t li = -1;
     // (the three loads of a listed candidate are issued together: position, content prefix and begin-side constant)
@@ -764,11 +805,11 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     if (idx < D.nList) {
         li = D.i1 - 1 - idx;
         eop = X.listPos(D.listSel, li);
-        cFxL = X.listFx(D.listSel, li, D.a);
-        cCL = X.listC(D.listSel, li, D.a);
+        cFxL = X.listFx(pl, D.listSel, li, D.a);
+        cCL = X.listC(pl, D.listSel, li, D.a);
     } else eop = -1;
     int bs = eop + 1;
-    int bob = bs - D.g.ipo, len = D.eob - bob + 1;
+    int bob = bs - Dg.ipo, len = D.eob - bob + 1;
     if (len < 1 || len > T.max_exon_len || (kind == AUGX_K_RINITIAL && len <= 2)) return;
     double nep;
     {
@@ -801,14 +842,14 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
 #ifdef AUGX_EMU
         if (!fast) g_emuSlowB++;
 #endif
-        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, D.g, AUGX_NINF);
+        if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, Dg, AUGX_NINF);
     }
     if (!(nep > AUGX_NINF)) return;
     // exactly one of the (up to three) ancestors has the reading frame that fits the exon length
     for (int ai = 0; ai < VC.nanc; ai++) {
         if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
-        te = (VC.tr[ai] + D.endP) + nep;
-        key = bs - D.g.bpl - 1 + KEY_BIAS;
+        te = (trPl[ai] + D.endP) + nep;
+        key = bs - Dg.bpl - 1 + KEY_BIAS;
         src = li >= 0 ? srcList(ai, D.listSel, VC.ancWin[ai], li) : srcCol0(ai, VC.anc[ai]);
         break;
     }
@@ -831,7 +872,7 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
 //   write == false: describe + count; results in cnt[] = {pairs, items, items of non-RTERMINAL pairs, mid1, mid2}
 //   write == true : emit the items at itemBase.  If the block had a single round, the descriptors
 //                   left in LDS by the counting call are reused.
-template <int BLK>
+template <int BLK, bool MULTI>
 AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, bool mayReuse, uint64_t maskVar, uint64_t maskRT, uint64_t pairBase,
                         uint64_t itemBase, uint32_t *cnt) {
     const BatchView &B = X.B;
@@ -885,7 +926,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                 else {
                     const int dj = L.plD[w][done + l], s2 = L.plS[w][done + l];
                     L.pairJ[w][l] = jb + dj; L.pairS[w][l] = s2;
-                    varDescribe(X, s2, jb + dj, L.desc[w][l]);
+                    varDescribe<MULTI>(X, s2, jb + dj, L.desc[w][l]);
                     TX(tot) = L.desc[w][l].total;
                 }
             }
@@ -924,7 +965,7 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
                     if (it < totalItems) {
                         const int q = TX(myPair);
                         double te; int key; uint32_t src;
-                        varEvalItem(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
+                        varEvalItem<MULTI>(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
                         if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
                         Item I;
                         I.te = te; I.kp = ((uint32_t)(((L.pairJ[w][q] - jb) << 6) | L.pairS[w][q]) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
@@ -944,15 +985,14 @@ struct CandAlloc { unsigned long long pairs, items; };
 
 // one workgroup = the WAVE / BLK consecutive blocks of one tile of 64 bases (they belong to one piece: a chunk of
 // CHUNK slots never spans pieces), one or two blocks per wavefront.  Count, reserve a contiguous range for the tile, emit.
-template <int BLK>
+template <int BLK, bool MULTI>
 AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg) {
     constexpr int NB = WAVE / BLK, BPW = NB / NWAVES; // blocks per tile, blocks per wavefront
     static_assert(NB % NWAVES == 0 && NB <= MAXNB, "block size");
     const int64_t gblk0 = wg * NB;
     if (gblk0 >= B.nBlk) return;
     const int p = B.chunkPiece[gblk0 * BLK / CHUNK];
-    const int c = B.cls[p];
-    FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, c < 0 ? 0 : c, t, L.vc[t]); }
+    FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, B, p, t, L.vc[t]); }
     BLOCK_SYNC();
     CandCtx X(T, B, L.vc, p);
     uint64_t maskVar, maskRT;
@@ -962,7 +1002,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
             const int bi = w * BPW + q;
             const int b = (int)(gblk0 + bi - X.o / BLK);
             uint32_t cnt[5];
-            candBlock<BLK>(X, L, w, b, false, BPW == 1, maskVar, maskRT, 0, 0, cnt);
+            candBlock<BLK, MULTI>(X, L, w, b, false, BPW == 1, maskVar, maskRT, 0, 0, cnt);
             FOR_WLANES(t, w) { if ((t & 63) == 0) for (int i = 0; i < 5; i++) L.cntW[bi][i] = cnt[i]; }
         }
     }
@@ -996,7 +1036,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
                     B.blkSplit[gblk * 3] = L.cntW[bi][3]; B.blkSplit[gblk * 3 + 1] = L.cntW[bi][4]; B.blkSplit[gblk * 3 + 2] = L.cntW[bi][2];
                 }
             }
-            if (L.cntW[bi][0] > 0) candBlock<BLK>(X, L, w, b, true, BPW == 1, maskVar, maskRT, pairBase, itemBase, nullptr);
+            if (L.cntW[bi][0] > 0) candBlock<BLK, MULTI>(X, L, w, b, true, BPW == 1, maskVar, maskRT, pairBase, itemBase, nullptr);
         }
     }
 }
@@ -1026,6 +1066,7 @@ struct TrellisLds {
     double vigw[VIG_WIN];           // igenic column, newest VIG_WIN bases
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
+    uint8_t gcw[2][WAVE];           // plane (GC class) of the bases of the current / next tile (multi-class pieces only)
     int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     int abortFlag;
 };
@@ -1140,11 +1181,13 @@ struct TrellisCtx {
     int64_t lo;     // list offset
     int n, c, S;
     int vigLo;      // the igenic window holds bases > vigLo (and <= the newest chain base)
+    bool multi;     // the piece has more than one GC class: transition terms follow the plane of the base
     AUGX_HD TrellisCtx(const DevTables &t, const BatchView &b, TrellisLds &l, int pp) : T(t), B(b), L(l), p(pp) {
         o = B.off[p];
         lo = listOff(B, p);
         n = B.len[p]; c = B.cls[p]; S = T.S;
         vigLo = -1;
+        multi = c >= 0 && B.nPlanes[p] > 1;
     }
 };
 
@@ -1196,6 +1239,8 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
         if (q > n - 1) q = n - 1;
         vTop = (int32_t)gp(B.cnt)[fidx(o + 1 + q, CNT_LA + tid % 4, NCNT)] - 1;
     }
+    uint8_t vGc = 0;
+    if (X.multi && tid < WAVE) vGc = gp(B.gcPlane)[g0 + (j0 + tid < n ? tid : n - 1 - j0)];
     constexpr int KI = (ITEM_CAP + 191) / 192;
     const int cntI = lastI - firstI < (uint64_t)ITEM_CAP ? (int)(lastI - firstI) : ITEM_CAP;
     Item vItem[KI];
@@ -1235,6 +1280,7 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     if (tid == 0) L.tileItem0[buf] = firstI;
     if (tid < NB * 3) L.blkSplit[buf][tid / 3][tid % 3] = vSplit;
     if (tid < NB * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
+    if (tid < WAVE) L.gcw[buf][tid] = vGc;
 #pragma unroll
     for (int k = 0; k < KI; k++) { const int i = tid + k * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
 }
@@ -1384,8 +1430,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     TV2(int, vS, VR);
     TV(int, cS); TV(int, cSig); TV(int, cNanc); TV(int, cSelf); TV(int, cIsIg);
     TV2(int, cAnc, 5); TV2(double, cTr, 5);
+    TV(int, fPl); TV(int, cPl); // plane (GC class) the transition terms of the lane currently belong to
     FOR_THREADS(t) {
         const int l = t & 63, slot = l / BLK;
+        TX(fPl) = 0; TX(cPl) = 0;
 #pragma unroll
         for (int r = 0; r < FR; r++) {
             fS[r][TI] = -1; fLag[r][TI] = 1; fSig[r][TI] = 0; fLong[r][TI] = 0; fNanc[r][TI] = 0; fAnc0[r][TI] = 0; fAnc1[r][TI] = 0;
@@ -1479,6 +1527,12 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (lr >= 0) { B.longV[(o + 1) * 6 + lr] = v; L.longW[0][0][lr] = v; }
             if (B.cells) B.cells[(o + 1) * S + t] = v;
             if (T.kind[t] == AUGX_K_IGENIC) { B.vig[o + 1] = v; L.vigw[0] = v; }
+            // base 0 as a list entry (k1SiteTerms): its values are the initial probabilities
+            const int sel0 = T.kind[t] == AUGX_K_LONGASS ? 0 : T.kind[t] == AUGX_K_RLONGDSS ? 1 : -1;
+            if (sel0 >= 0) {
+                const int si = B.site[(o + 1) * NSITE + sel0];
+                if (si >= 0) L.lcVal[sel0][si & (LIST_WIN - 1)][T.win[t]] = v;
+            }
         }
         loadTileThread<BLK>(X, 0, 0, t, NT, false);
     }
@@ -1490,6 +1544,20 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     auto fixedStep = [&](int w, int buf, int jb, int late, int rlo, int rhi) { // classes in mask `late`, rounds [rlo, rhi)
         FOR_WLANES(t, w) {
             const int l = t & 63, dj = l % BLK, j = jb + dj;
+            if (X.multi) { // a step of the content stairs: the transitions into the lane's states change with the class of base j
+                const int pl = L.gcw[buf][j & 63];
+                if (pl != TX(fPl)) {
+                    TX(fPl) = pl;
+                    const int cc = B.planeCls[p * MAXPL + pl];
+#pragma unroll
+                    for (int r = 0; r < FR; r++) {
+                        const int s2 = fS[r][TI];
+                        if (s2 < 0) continue;
+                        fTr0[r][TI] = lnT(T, cc, T.anc[s2][0], s2);
+                        fTr1[r][TI] = T.n_anc[s2] > 1 ? lnT(T, cc, T.anc[s2][1], s2) : AUGX_NINF;
+                    }
+                }
+            }
             // written branch-light: every load of the selected rounds is issued before anything is computed
             double emi[FR], pv0[FR], pv1[FR];
             int si[FR];
@@ -1546,6 +1614,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             const int jbL = TX(cIsIg) ? jbIg : jbGeo;
             const int j = jbL >= 0 ? jbL + dj : -1;
             TX(jj) = j;
+            if (X.multi && j >= 0 && TX(cS) >= 0) {
+                const int pl = L.gcw[buf][j & 63];
+                if (pl != TX(cPl)) {
+                    TX(cPl) = pl;
+                    const int cc = B.planeCls[p * MAXPL + pl];
+#pragma unroll
+                    for (int ai = 0; ai < 5; ai++)
+                        if (ai < TX(cNanc)) cTr[ai][TI] = lnT(T, cc, cAnc[ai][TI], TX(cS));
+                }
+            }
             TX(bB) = AUGX_NINF; TX(bA) = AUGX_NINF; TX(aB) = -1; TX(aA) = -1; TX(teS) = AUGX_NINF; TX(psS) = AUGX_NINF; TX(rai) = -1;
             {
                 const bool valid = TX(cS) >= 0 && j >= 1 && j < n;

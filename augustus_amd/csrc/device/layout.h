@@ -38,6 +38,43 @@ struct BatchLayout {
     }
 };
 
+// smoothed GC-content stairs of one piece from the classes of its windows (reference ContentStairs::computeStairs,
+// src/motif.cc:543-616): wc[s] = class of the window of `win` bases starting at base s, s in [0, n - win] (win already
+// clamped to n).  Base i has the class of the window centred on it, the ends that of the first / last window; a step
+// shorter than 1000 bases that returns to the class before it is removed.  The classes are then numbered by first
+// appearance (planes).  Returns the number of planes (plane[] filled, planeCls[k] = class of plane k), or -1 if the
+// piece has more than MAXPL classes.
+inline int stairsPlanes(const uint8_t *wc, int n, int win, std::vector<uint8_t> &plane, int32_t planeCls[MAXPL]) {
+    if (win > n || win < 1) win = n;
+    std::vector<uint8_t> cls((size_t)n);
+    const int half = win / 2, last = n - win;
+    for (int i = 0; i < n; i++) {
+        int s = i - half;
+        cls[i] = wc[s < 0 ? 0 : s > last ? last : s];
+    }
+    int x = -2, lastStep = 0;
+    for (int i = 0; i < n; i++)
+        if (cls[i] != x) {
+            if (i - lastStep < 1000 && lastStep > 0 && cls[lastStep - 1] == cls[i])
+                for (int j = lastStep; j < i; j++) cls[j] = cls[i];
+            lastStep = i;
+            x = cls[i];
+        }
+    int nPl = 0, map[256];
+    for (int i = 0; i < 256; i++) map[i] = -1;
+    plane.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        int &m = map[cls[i]];
+        if (m < 0) {
+            if (nPl >= MAXPL) return -1;
+            planeCls[nPl] = cls[i];
+            m = nPl++;
+        }
+        plane[i] = (uint8_t)m;
+    }
+    return nPl;
+}
+
 // element counts of every device buffer of a batch (bytes = count * sizeof(element))
 struct BatchSizes {
     int64_t N, nChunks, nPieces, listCap, pathCap;

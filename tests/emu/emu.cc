@@ -63,7 +63,6 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.code = zalloc<uint8_t>(Z.N);
     B.cnt = zalloc<uint64_t>(Z.N * NCNT);
     B.nsm = zalloc<uint64_t>(Z.N * 6);
-    B.fx = zalloc<uint64_t>(Z.N * NFX);
     B.sig = zalloc<double>(Z.N * NSIG);
     B.gate = zalloc<uint64_t>(Z.N);
     B.site = zalloc<int32_t>(Z.N * NSITE);
@@ -73,14 +72,14 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.longV = zalloc<double>(Z.N * 6);
     B.laPos = zalloc<int32_t>(Z.listCap); B.laVal = zalloc<double>(Z.listCap * 3);
     B.lrPos = zalloc<int32_t>(Z.listCap); B.lrVal = zalloc<double>(Z.listCap * 3);
-    B.ldEnt = zalloc<IntronStart>(Z.listCap); B.ldVal = zalloc<double>(Z.listCap * 3);
-    B.rdEnt = zalloc<IntronStart>(Z.listCap); B.rdVal = zalloc<double>(Z.listCap * 3);
+    B.ldVal = zalloc<double>(Z.listCap * 3);
+    B.rdVal = zalloc<double>(Z.listCap * 3);
     B.atgPos = zalloc<int32_t>(Z.listCap);
-    B.laPls = zalloc<double>(Z.listCap * 3); B.laFx = zalloc<uint64_t>(Z.listCap * 3);
-    B.lrEt = zalloc<double>(Z.listCap * 3); B.lrFx = zalloc<uint64_t>(Z.listCap * 3);
-    B.atgD = zalloc<double>(Z.listCap * 3); B.atgFx = zalloc<uint64_t>(Z.listCap);
-    B.rsPos = zalloc<int32_t>(Z.listCap); B.rsBegin = zalloc<double>(Z.listCap); B.rsFx = zalloc<uint64_t>(Z.listCap * 3);
-    B.plsR = zalloc<double>(Z.N * 3);
+    B.rsPos = zalloc<int32_t>(Z.listCap); B.rsBegin = zalloc<double>(Z.listCap);
+    B.gcRaw = zalloc<uint8_t>(Z.N); B.gcPlane = zalloc<uint8_t>(Z.N);
+    std::vector<int32_t> nPlanes(n, 1), planeCls((size_t)n * MAXPL, 0);
+    B.nPlanes = nPlanes.data(); B.planeCls = planeCls.data();
+    B.listCap = Z.listCap; B.nPl = 1;
     std::vector<double> lnvv(n);
     std::vector<int32_t> st(n), fin(n), pc(n);
     B.lnv = lnvv.data(); B.status = st.data(); B.finalState = fin.data(); B.pathCount = pc.data();
@@ -100,13 +99,37 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             if (c > clsMM[2 * p + 1]) clsMM[2 * p + 1] = c;
         }
     }
-    for (int p = 0; p < n; p++) cls[p] = clsMM[2 * p] == clsMM[2 * p + 1] ? clsMM[2 * p] : -1;
-    for (int64_t g = 0; g < B.N; g++) k1FxTerms(T, B, g);
-    scanFields<false>(B.fx, NFX, L);
+    for (int p = 0; p < n; p++) {
+        cls[p] = clsMM[2 * p] == clsMM[2 * p + 1] ? clsMM[2 * p] : -1;
+        planeCls[(size_t)p * MAXPL] = cls[p];
+        if (cls[p] < 0) { // the windows disagree: content stairs of the piece, classes -> planes (as augx_batch_decode does)
+            std::vector<uint8_t> plane;
+            const int np = stairsPlanes(B.gcRaw + L.off[p] + 1, L.len[p], t->gc_win, plane, &planeCls[(size_t)p * MAXPL]);
+            if (np < 0) continue;
+            cls[p] = planeCls[(size_t)p * MAXPL];
+            nPlanes[p] = np;
+            if (np > 1) memcpy(B.gcPlane + L.off[p] + 1, plane.data(), (size_t)L.len[p]);
+            if (np > B.nPl) B.nPl = np;
+        }
+    }
+    // class-dependent arrays: one plane per class of the most varied piece
+    const int64_t nPl = B.nPl;
+    B.fx = zalloc<uint64_t>(nPl * Z.N * NFX);
+    B.plsR = zalloc<double>(nPl * Z.N * 3);
+    B.ldEnt = zalloc<IntronStart>(nPl * Z.listCap); B.rdEnt = zalloc<IntronStart>(nPl * Z.listCap);
+    B.laPls = zalloc<double>(nPl * Z.listCap * 3); B.laFx = zalloc<uint64_t>(nPl * Z.listCap * 3);
+    B.lrEt = zalloc<double>(nPl * Z.listCap * 3); B.lrFx = zalloc<uint64_t>(nPl * Z.listCap * 3);
+    B.atgD = zalloc<double>(nPl * Z.listCap * 3); B.atgFx = zalloc<uint64_t>(nPl * Z.listCap);
+    B.rsFx = zalloc<uint64_t>(nPl * Z.listCap * 3);
+    for (int pl = 0; pl < nPl; pl++) {
+        for (int64_t g = 0; g < B.N; g++) k1FxTerms(T, B, g, pl);
+        scanFields<false>(B.fx + (int64_t)pl * Z.N * NFX, NFX, L);
+    }
     for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
     for (int sel = 0; sel < 4; sel++)
         for (int64_t t2 = 0; t2 < B.N / 2; t2++) k1SiteSignals(T, B, t2, sel);
-    for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g);
+    for (int pl = 0; pl < B.nPl; pl++)
+        for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g, pl);
     // ---- K2a: candidates, tile by tile (first with buffers that are too small, to exercise the re-run path)
     B.blk = blk;
     B.nBlk = B.N / blk;
@@ -121,7 +144,10 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int attempt = 0; attempt < 2; attempt++) {
         ca.pairs = 0; ca.items = 0;
-        for (int64_t wg = 0; wg < nWg; wg++) { if (blk == 8) candWorkgroup<8>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4>(T, B, *cl, wg); else candWorkgroup<2>(T, B, *cl, wg); }
+        for (int64_t wg = 0; wg < nWg; wg++) {
+            if (B.nPl > 1) { if (blk == 8) candWorkgroup<8, true>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4, true>(T, B, *cl, wg); else candWorkgroup<2, true>(T, B, *cl, wg); }
+            else { if (blk == 8) candWorkgroup<8, false>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4, false>(T, B, *cl, wg); else candWorkgroup<2, false>(T, B, *cl, wg); }
+        }
         if ((int64_t)ca.items <= B.itemCap) break;
         free(B.items);
         B.itemCap = (int64_t)ca.items;
@@ -166,7 +192,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
     free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldEnt); free(B.ldVal);
     free(B.rdEnt); free(B.rdVal); free(B.atgPos); free(B.pathRec);
-    free(B.laPls); free(B.laFx); free(B.lrEt); free(B.lrFx); free(B.atgD); free(B.atgFx); free(B.rsPos); free(B.rsBegin); free(B.rsFx); free(B.plsR);
+    free(B.laPls); free(B.laFx); free(B.lrEt); free(B.lrFx); free(B.atgD); free(B.atgFx); free(B.rsPos); free(B.rsBegin); free(B.rsFx); free(B.plsR); free(B.gcRaw); free(B.gcPlane);
     return 0;
 }
 }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates tests/golden/config_min.tar.gz: the minimal subset of the reference's species-parameter DATA
-# (config/, read-only input of the drop-in contract; not source code) needed to run the human, fly and arabidopsis
-# (old parameter-file format, short donor window: block size 4) ab-initio models where /root/reference does not exist (the GPU box).  Run in the build container.
+# (config/, read-only input of the drop-in contract; not source code) needed to run the human, fly, arabidopsis
+# (old parameter-file format, short donor window: block size 4) and saccharomyces (3 GC classes, ass_end 0) ab-initio models where /root/reference does not exist (the GPU box).  Run in the build container.
 set -e
 REF=${REF:-/root/reference}
 OUT=$(cd "$(dirname "$0")" && pwd)/config_min.tar.gz
@@ -16,5 +16,8 @@ tar -C "$REF" -czf "$OUT" \
     config/species/arabidopsis/arabidopsis_parameters.cfg config/species/arabidopsis/arabidopsis_exon_probs.pbl \
     config/species/arabidopsis/arabidopsis_intron_probs.pbl config/species/arabidopsis/arabidopsis_igenic_probs.pbl \
     config/species/arabidopsis/arabidopsis_weightmatrix.txt \
+    config/species/saccharomyces/saccharomyces_parameters.cfg config/species/saccharomyces/saccharomyces_exon_probs.pbl \
+    config/species/saccharomyces/saccharomyces_intron_probs.pbl config/species/saccharomyces/saccharomyces_igenic_probs.pbl \
+    config/species/saccharomyces/saccharomyces_weightmatrix.txt \
     config/model config/extrinsic/extrinsic.cfg config/parameters/aug_cmdln_parameters.json
 ls -la "$OUT"

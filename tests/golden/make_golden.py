@@ -6,7 +6,7 @@ Outputs
   inputs.fa                 the fixed test inputs (examples/example.fa records + seeded synthetic/edge records)
   golden_paths_<cfg>.json   per record: ln Viterbi score (%.17g) and the raw state path, from oracle/_ref/ref_harness
   golden_<cfg>.gff          the reference binary's GFF for the same inputs (prediction part only)
-for cfg in {human, human_nosm, fly, arabidopsis}.
+for cfg in {human, human_nosm, fly, arabidopsis, saccharomyces}.
 """
 import json
 import os
@@ -23,6 +23,9 @@ CFGS = {
     "fly": ("fly", ["--UTR=off", "--sample=0", "--softmasking=0"]),
     # old parameter-file format (no [EMISSION] sections) and a donor window of 8 bases: block size 4 on the device
     "arabidopsis": ("arabidopsis", ["--UTR=off", "--sample=0", "--softmasking=0"]),
+    # 3 GC classes (the multigc_* records have up to three of them in one piece) and ass_end = 0 (an exon may follow base 0
+    # without an acceptor site)
+    "saccharomyces": ("saccharomyces", ["--UTR=off", "--sample=0", "--softmasking=0"]),
 }
 
 
@@ -55,6 +58,21 @@ def build_inputs():
         for i in range(a, b):
             r[i] = r[i].lower()
     recs += [("softmask_gene", sm), ("softmask_rand", "".join(r)), ("softmask_all", random_dna(8000, 5).lower())]
+    # records whose GC content changes along the sequence: more than one GC class inside one piece for the human model
+    # (2 classes, windows of 3000 bases); the class-dependent tables switch at the steps (src/namgene.cc:245-248)
+    import random
+
+    def gc_dna(n, gc, seed):
+        rng = random.Random(seed)
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(n))
+
+    rc = ex[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+    recs += [
+        ("multigc_gene", gc_dna(8000, 0.33, 1) + ex + gc_dna(9000, 0.62, 2)),
+        ("multigc_two", gc_dna(6000, 0.62, 3) + rc + gc_dna(7000, 0.30, 4) + ex),
+        ("multigc_rand", gc_dna(9000, 0.35, 5) + gc_dna(9000, 0.6, 6) + gc_dna(9000, 0.35, 7)),
+        ("multigc_levels", gc_dna(6000, 0.25, 8) + gc_dna(6000, 0.38, 9) + ex + gc_dna(6000, 0.48, 10) + gc_dna(6000, 0.58, 11) + gc_dna(6000, 0.7, 12)),
+    ]
     return recs
 
 

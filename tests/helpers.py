@@ -130,6 +130,7 @@ GOLDEN_CFGS = {
     "human_nosm": ("human", {"softmasking": "0"}),
     "fly": ("fly", {"UTR": "off", "sample": "0", "softmasking": "0"}),
     "arabidopsis": ("arabidopsis", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+    "saccharomyces": ("saccharomyces", {"UTR": "off", "sample": "0", "softmasking": "0"}),
 }
 
 

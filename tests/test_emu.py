@@ -15,16 +15,17 @@ def test_emulated_kernels_bit_identical_to_oracle(cfg):
     S = m.n_states
     recs = golden_inputs()
     res = emu_decode(m.tables_ptr, [s for _, s in recs], S, cells=True)
+    most_classes = 0
     for (name, seq), (st, lnv, path, V, cls) in zip(recs, res):
         rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, S, cells=True)
-        if st == ax.AUGX_E_UNSUPPORTED:  # multi-GC-class piece: not decoded by this version (fails loudly)
-            assert len(set(gc.tolist())) > 1 or cls == -1
-            continue
+        most_classes = max(most_classes, len(set(gc.tolist())))
         assert st == 0 and rc == 0, name
         assert lnv == lnv2, name
         assert path == [(b, e, s) for b, e, s, t in path2], name
         if set(seq.upper()) != {"N"}:
             assert np.array_equal(V, V2), name  # -inf == -inf holds, no NaNs are produced
+    # the multigc_* records switch GC class inside the piece (class-dependent tables follow the end base of each state)
+    assert most_classes >= {"human": 2, "human_nosm": 2, "saccharomyces": 3}.get(cfg, 1)
 
 
 def test_emulated_interior_piece_kinds():
@@ -77,10 +78,7 @@ def test_emulated_adversarial_sequences(species):
     decoded = 0
     for (name, seq), (st, lnv, path, V, cls) in zip(cases.items(), res):
         rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, S, cells=True)
-        if st == ax.AUGX_E_UNSUPPORTED:  # multi-GC-class piece (human model, GC-rich insert)
-            assert len(set(gc.tolist())) > 1, name
-            continue
         decoded += 1
         assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
         assert path == [(b, e, s) for b, e, s, t in path2], name
-    assert decoded >= 4
+    assert decoded == len(cases)

@@ -29,30 +29,27 @@ def test_gpu_matches_golden_reference(cfg):
     res = d.decode([s for _, s in recs])
     n_checked = 0
     for (name, seq), r, g in zip(recs, res, gold):
-        if r.status == ax.AUGX_E_UNSUPPORTED:
-            continue  # multi-GC-class piece (fails loudly, never silently differs)
         assert r.status == 0, name
         assert abs(r.ln_viterbi - g["lnv"]) <= 1e-9 * abs(g["lnv"]), name
         assert [(b, e, t) for b, e, s, t in r.states] == g["path"], name
         n_checked += 1
-    assert n_checked >= len(recs) - 1
+    assert n_checked == len(recs)
 
 
-def test_gpu_cells_bit_identical_to_oracle(monkeypatch):
+@pytest.mark.parametrize("cfg", ["human", "saccharomyces"])
+def test_gpu_cells_bit_identical_to_oracle(monkeypatch, cfg):
     monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
-    m = ax.Model(config_path(), "human")
+    m = ax.Model(config_path(), GOLDEN_CFGS[cfg][0], **GOLDEN_CFGS[cfg][1])
     d = ax.Decoder(m, 0)
     S = m.n_states
-    # every golden input (real genes on both strands, truncated genes, N runs, IUPAC codes) plus random pieces: the
-    # path alone can hide a wrong cell, so all S x n cells are compared
+    # every golden input (real genes on both strands, truncated genes, N runs, IUPAC codes, records with two (human) or
+    # three (saccharomyces) GC classes inside the piece) plus random pieces: the path alone can hide a wrong cell, so all
+    # S x n cells are compared
     seqs = [s for _, s in golden_inputs()] + [random_dna(30000, 1), random_dna(5000, 2).lower(), random_dna(100, 3)]
     b = ax.Batch(d, seqs)
     b.decode()
     for i, (s, r) in enumerate(zip(seqs, b.paths())):
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
-        if r.status == ax.AUGX_E_UNSUPPORTED:  # multi-GC-class piece: not decoded by this version (fails loudly)
-            assert len(set(gc.tolist())) > 1
-            continue
         assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, i
         if set(s.upper()) != {"N"}:
             assert np.array_equal(b.cells(i), V), i
@@ -167,12 +164,9 @@ def test_gpu_adversarial_sequences(species):
         decoded = 0
         for i, ((name, seq), r) in enumerate(zip(cases.items(), b.paths())):
             rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
-            if r.status == ax.AUGX_E_UNSUPPORTED:
-                assert len(set(gc.tolist())) > 1, name
-                continue
             decoded += 1
             assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, name
             assert np.array_equal(b.cells(i), V), name
-        assert decoded >= 4
+        assert decoded == len(cases)
     finally:
         del os.environ["AUGX_DEBUG_CELLS"]
