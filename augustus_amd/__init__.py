@@ -15,8 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaugx.so")
 
 AUGX_E_NODEVICE = -3
+AUGX_E_HIP = -4
 AUGX_E_UNSUPPORTED = -5
 AUGX_E_NOPATH = -6
+AUGX_E_NOMEM = -7
 
 
 class AugxError(RuntimeError):
