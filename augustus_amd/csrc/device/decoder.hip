@@ -340,7 +340,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
-    if (getenv("AUGX_PROF")) DA(V.prof, uint64_t, (int64_t)n * 56);
+    if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); HIP_TRY(hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8)); }
     DA(V.vig, double, Z.N);
     DA(V.longV, double, Z.N * 6);
     DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
@@ -436,7 +436,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn
         // out too small (first decode of a batch, unusual sequence), it reports the size needed and is run again.
         BatchView &W = b->V;
-        const unsigned nWg = (unsigned)(W.N / WAVE); // one workgroup per tile of 64 bases
+        const unsigned nWg = (unsigned)(W.N / (WAVE * NWAVES)); // one wavefront per tile of 64 bases, NWAVES tiles per workgroup
         if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
             W.itemCap = W.N * 18 + 65536;
             if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
@@ -509,7 +509,7 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
     if (trellis_ms) *trellis_ms = c;
     if (back_ms) *back_ms = e;
     if (b->V.prof) { // developer aid (AUGX_PROF=1): cycle counters of the four trellis wavefronts, averaged over pieces
-        std::vector<uint64_t> h((size_t)b->L.nPieces * 56);
+        std::vector<uint64_t> h((size_t)b->L.nPieces * 56 + 64);
         HIP_TRY(hipMemcpy(h.data(), b->V.prof, h.size() * 8, hipMemcpyDeviceToHost));
         static const char *role[5] = {"work0", "work1", "work2", "chain", "far"};
         for (int w = 0; w < 5; w++) {
@@ -520,6 +520,11 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
                 fprintf(stderr, " [%d]=%.2f", i, sum / b->L.nPieces / 1e6);
             }
             fprintf(stderr, "  (0 tile wait, 1 flag wait, 2 role work, 3 chain, 4 item load, 5 scan, 6 publish, 7 item setup)\n");
+        }
+        {
+            const uint64_t *cp = &h[(size_t)b->L.nPieces * 56];
+            const double nw = (double)(cp[4] ? cp[4] : 1);
+            fprintf(stderr, "kCand cycles per wavefront (= tile; avg over %.0f): %.0f\n", nw, cp[0] / nw);
         }
         {   // time stamps of block 1000 of piece 0, relative to the start of its fixed-lag step
             const uint64_t *ts = &h[(size_t)b->L.nPieces * 40];

@@ -444,20 +444,22 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
 #ifdef AUGX_EMU
 static long long g_emuSlowA = 0, g_emuSlowB = 0; // emulator statistics: candidates taking the general evaluation path
 #endif
-struct VarDesc { // (kind, frame and geometry of the state are per-state constants: VarConst)
-    int pl;                                       // plane (GC class) of the end base j: selects every class-dependent array
-    int nList, extra, total, listSel;             // listSel: 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
-    int a;                                        // phase of the content prefix fields
-    int lenSel;                                   // length distribution of this exon type: 0 single, 1 initial, 2 internal, 3 terminal
-    int cods;                                     // short intron: spliced-codon bases on the end side, 4 bits each (cod0 | cod1 << 4 | cod2 << 8)
-    int64_t i1;                                   // one past the newest list entry (piece-local index)
-    int eob, right, fOR, startMin;                // exon geometry
-    int eobi;                                     // short intron: end of the biological intron
+struct VarDesc { // 64 bytes (kind, frame and geometry of the state are per-state constants: VarConst)
+    int8_t pl;              // plane (GC class) of the end base j: selects every class-dependent array
+    int8_t listSel;         // 0 LA, 1 LR, 2 LD, 3 RD, 4 ATG, 5 single reverse-stop candidate
+    int8_t a;               // phase of the content prefix fields
+    int8_t lenSel;          // length distribution of this exon type: 0 single, 1 initial, 2 internal, 3 terminal
+    int8_t extra, fOR;
+    int16_t cods;           // short intron: spliced-codon bases on the end side, 4 bits each (cod0 | cod1 << 4 | cod2 << 8)
+    int32_t nList, total;
+    int32_t i1;             // one past the newest list entry (piece-local index)
+    int32_t eob, right, startMin; // exon geometry
     double endP;
     // end-side constants of the fast candidate evaluation (see k1SiteConsts)
     uint64_t eFx;           // content prefix at the end-side boundary
     double eD0, plsEnd;     // end-side content term (exon-terminal fwd / initial-content rev), reverse-strand ln P_ls
 };
+static_assert(sizeof(VarDesc) == 64, "VarDesc layout");
 
 // wave-level bookkeeping primitives (device: cross-lane instructions; emulator: loops over the lane arrays)
 #ifdef AUGX_EMU
@@ -507,15 +509,15 @@ AUGX_HD void fillVarConst(const DevTables &T, const BatchView &B, int p, int l, 
     VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
 }
 
+constexpr int DCAP = 96; // descriptors of a tile that stay in LDS between the counting and the emitting pass (>= WAVE)
 struct CandLds {
     VarConst vc[SP];
-    VarDesc desc[NWAVES][WAVE];     // descriptors of the (base, state) pairs of the current round, one per lane
-    int pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];
-    uint32_t cntW[MAXNB][5];        // per block of the tile: pairs, items, items but RTERMINAL, split points
-    uint8_t plD[NWAVES][256], plS[NWAVES][256];         // pair list of the wavefront's current block: base offset, state
-    int plN[NWAVES][2];                                 // pairs but RTERMINAL / all pairs
-    unsigned long long preW[MAXNB][2], baseW[2];
-    int fits;
+    VarDesc desc[NWAVES][DCAP];                          // per wavefront (= tile): descriptors of its (base, state) pairs
+    uint8_t pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];    // the pairs of the current round: base offset in the tile, state
+    int scan[NWAVES][3][WAVE];                           // inclusive lane scans of the pair counts of the three groups
+    uint32_t cntItems[NWAVES][MAXNB], cntNonRT[NWAVES][MAXNB]; // per block: candidates (then: first candidate), candidates but RTERMINAL
+    unsigned long long bestMid[NWAVES][MAXNB][2];        // per block: (distance << 32 | position) of the pair boundaries nearest 1/3 and 2/3
+    unsigned long long baseW[NWAVES][2];                 // first pair / first candidate of the tile in the batch's buffers
 };
 
 // read-only view of one piece for the candidate kernel (everything comes from HBM / L2)
@@ -580,7 +582,7 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
     const int pl = MULTI ? X.B.gcPlane[X.o + 1 + j] : 0; // (MULTI: the batch has a piece with more than one GC class)
     D.pl = pl;
     D.nList = 0; D.extra = 0; D.total = 0; D.listSel = 0; D.i1 = 0;
-    D.eob = D.right = D.fOR = D.startMin = 0; D.eobi = 0; D.cods = 0x444; D.endP = AUGX_NINF;
+    D.eob = D.right = D.startMin = 0; D.fOR = 0; D.cods = 0x444; D.endP = AUGX_NINF;
     const ExGeom &Dg = VC.g;
     D.a = 0; D.eFx = 0; D.eD0 = 0.0; D.plsEnd = 0.0; D.lenSel = 2;
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
@@ -588,7 +590,6 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         const int f = win;
         const int eobi = fwd ? j + T.U + T.As + 2 : j + T.De + 2;
         const bool haveRight = eobi < n - 2;
-        D.eobi = eobi;
         int cod0 = 4, cod1 = 4, cod2 = 4;
         if (fwd) {
             if (f == 1) { cod1 = haveRight ? P.b(eobi + 1) : 4; cod2 = haveRight ? P.b(eobi + 2) : 4; }
@@ -600,14 +601,14 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
                 cod1 = (haveRight && P.b(eobi + 1) <= 3) ? 3 - P.b(eobi + 1) : 4;
             }
         }
-        D.cods = cod0 | (cod1 << 4) | (cod2 << 8);
+        D.cods = (int16_t)(cod0 | (cod1 << 4) | (cod2 << 8));
         int left = j - T.dStateLen;
         if (left < 0) left = 0;
         const int fld = fwd ? CNT_LD : CNT_RD;
         const int64_t i0 = (int64_t)X.cntAt(left - 1, fld);
-        D.i1 = (int64_t)X.cntAt(j - 1, fld);
+        D.i1 = (int32_t)X.cntAt(j - 1, fld);
         D.listSel = fwd ? 2 : 3;
-        D.nList = (int)(D.i1 - i0);
+        D.nList = (int)((int64_t)D.i1 - i0);
         D.extra = left == 0 ? 1 : 0; // eop = 0 reads column 0 (initial probabilities); not a splice site, so not listed
         D.total = D.nList + D.extra;
         D.endP = 0.0;
@@ -615,7 +616,7 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         return;
     }
     const ExEnd e = exEnd(P, kind, win, j, Dg);
-    D.eob = e.eob; D.right = e.right; D.fOR = e.fOR; D.startMin = e.startMin;
+    D.eob = e.eob; D.right = e.right; D.fOR = (int8_t)e.fOR; D.startMin = e.startMin;
     D.endP = (kind == AUGX_K_SINGLE || kind == AUGX_K_TERMINAL) ? X.sigAt(j, SIG_STOPF)
              : (kind == AUGX_K_RSINGLE || kind == AUGX_K_RINITIAL) ? X.sigAt(j, SIG_TISR) : 0.0; // gate is open
     if (!(D.endP > AUGX_NINF) || e.right < 0 || e.startMax < e.startMin) return;
@@ -623,7 +624,7 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         const int k = T.k, right = e.right;
         const int a = Dg.fwd ? mod3(e.fOR - right) : mod3(e.fOR + right);
         const int fb = ((Dg.fwd ? 0 : 1) * 3 + a) * 3;
-        D.a = a;
+        D.a = (int8_t)a;
         switch (kind) {
         case AUGX_K_INTERNAL: case AUGX_K_INITIAL:
             D.eFx = X.fxAt(pl, right - T.Le, fb + 0);
@@ -651,18 +652,18 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
     }
     if (kind == AUGX_K_SINGLE || kind == AUGX_K_INITIAL) { // start codons with bob in [startMin-3, startMax-3]
         const int64_t i0 = (int64_t)X.cntAt(e.startMin - 3 - 1, CNT_ATG);
-        D.i1 = (int64_t)X.cntAt(e.startMax - 3, CNT_ATG);
+        D.i1 = (int32_t)X.cntAt(e.startMax - 3, CNT_ATG);
         D.listSel = 4;
-        D.nList = (int)(D.i1 - i0);
+        D.nList = (int)((int64_t)D.i1 - i0);
     } else if (kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) {
         D.listSel = 5; // single candidate bs = ORFleft+2 (src/exonmodel.cc:1044-1045)
         D.nList = 1;
     } else {
         const int fld = Dg.fwd ? CNT_LA : CNT_LR; // eop = bs - 1 in [startMin-1, startMax-1]
         const int64_t i0 = (int64_t)X.cntAt(e.startMin - 2, fld);
-        D.i1 = (int64_t)X.cntAt(e.startMax - 1, fld);
+        D.i1 = (int32_t)X.cntAt(e.startMax - 1, fld);
         D.listSel = Dg.fwd ? 0 : 1;
-        D.nList = (int)(D.i1 - i0);
+        D.nList = (int)((int64_t)D.i1 - i0);
         D.extra = e.startMin == 0 ? 1 : 0; // bs = 0: left-truncated exon, predecessor column 0
     }
     D.total = D.nList + D.extra;
@@ -704,7 +705,8 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
             siteOk = bobi < 0 || (bobi >= 1 && bobi <= n - 2 && (fwd ? (bA == 2 && bB == 3) : (bA == 1 && bB == 3)));
         }
         const uint64_t cFx = e.fx;
-        int intronLength = D.eobi - bobi + 1;
+        const int eobi = fwd ? j + T.U + T.As + 2 : j + T.De + 2; // end of the biological intron
+        int intronLength = eobi - bobi + 1;
         const bool lenOk = intronLength <= T.d;
         if (intronLength > T.d || intronLength < 0) intronLength = 0;
         const double lenI = X.lenIAt(intronLength);
@@ -867,68 +869,139 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
     }
 }
 
-// candidates of block b (bases 8b .. 8b+7) of piece X.p, by wavefront w of the workgroup.  The pairs are ordered: all
-// states but RTERMINAL (by base, then state), then RTERMINAL.  Rounds of 64 pairs (one block rarely has more).
-//   write == false: describe + count; results in cnt[] = {pairs, items, items of non-RTERMINAL pairs, mid1, mid2}
-//   write == true : emit the items at itemBase.  If the block had a single round, the descriptors
-//                   left in LDS by the counting call are reused.
+// LDS accumulators shared by the lanes of one wavefront
+#ifdef AUGX_EMU
+inline void ldsAdd(uint32_t *p, uint32_t v) { *p += v; }
+inline void ldsMin64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
+#else
+__device__ inline void ldsAdd(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ inline void ldsMin64(unsigned long long *p, unsigned long long v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+
+// global allocation state of the candidate buffer (one per batch)
+struct CandAlloc { unsigned long long pairs, items; };
+
+// Candidates of one tile of 64 bases (first base j0, first block gblk0 in the batch's block tables) of piece X.p, by ONE
+// wavefront: lane = base while the pairs are collected, lane = pair while they are described, lane = candidate while
+// they are evaluated.  The (base, state) pairs of a block are ordered: short introns, exons but RTERMINAL, RTERMINAL
+// (each by base, then state); the candidates of the tile are contiguous in the batch's buffer, block after block.
+//   pass 1: describe every pair (descriptors of the first DCAP pairs stay in LDS), count the candidates per block
+//   reserve: one atomic add per tile hands out the range; the per-block tables (first candidate, counts) are written
+//   pass 2: evaluate and store the candidates, 64 at a time; note the pair boundaries nearest to 1/3 and 2/3 of each
+//           block's candidates (three trellis wavefronts share them)
 template <int BLK, bool MULTI>
-AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, bool mayReuse, uint64_t maskVar, uint64_t maskRT, uint64_t pairBase,
-                        uint64_t itemBase, uint32_t *cnt) {
+AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk0, uint64_t maskLess, uint64_t maskVar, uint64_t maskRT) {
+    constexpr int NB = WAVE / BLK;
+    static_assert(NB <= MAXNB && DCAP >= WAVE, "tile layout");
     const BatchView &B = X.B;
-    const int n = X.n, jb = b * BLK;
-    // three groups of pairs, in this order: short introns (most candidates; their chunks then run the short-intron
-    // code only), exons but RTERMINAL, RTERMINAL
-    uint64_t maskLess = 0;
-    for (int s2 = 0; s2 < X.S; s2++)
-        if (X.vc[s2].kind == AUGX_K_LESSD || X.vc[s2].kind == AUGX_K_RLESSD) maskLess |= 1ull << s2;
-    maskLess &= maskVar;
-    // pair list of the block in LDS (lane dj < BLK owns base jb + dj); the counting call builds it, the emitting call reuses it
-    int nP0, allPairs;
-    if (!write || !mayReuse) {
-        TV(int, nA); TV(int, nB); TV(int, nC);
-        TV(uint64_t, gA); TV(uint64_t, gB); TV(uint64_t, gC);
-        FOR_WLANES(t, w) {
-            const int l = t & 63, j = jb + l;
-            const uint64_t gt = (l < BLK && j >= 1 && j < n) ? B.gate[X.o + 1 + j] : 0;
-            TX(gA) = gt & maskLess; TX(gB) = gt & maskVar & ~maskLess; TX(gC) = gt & maskRT;
-            TX(nA) = popc64(TX(gA)); TX(nB) = popc64(TX(gB)); TX(nC) = popc64(TX(gC));
-        }
-        TV(int, iA); TV(int, iB); TV(int, iC);
-        FOR_WLANES(t, w) { TX(iA) = TX(nA); TX(iB) = TX(nB); TX(iC) = TX(nC); }
-        waveInclScan(iA, w); waveInclScan(iB, w); waveInclScan(iC, w);
-        const int totA = waveRead(iA, w, WAVE - 1), totB = waveRead(iB, w, WAVE - 1), totC = waveRead(iC, w, WAVE - 1);
+    const int n = X.n;
+    TV(uint64_t, gA); TV(uint64_t, gB); TV(uint64_t, gC);
+    TV(int, nA); TV(int, nB); TV(int, nC);
+    TV(int, iA); TV(int, iB); TV(int, iC);
+    FOR_WLANES(t, w) {
+        const int l = t & 63, j = j0 + l;
+        const uint64_t gt = (j >= 1 && j < n) ? B.gate[X.o + 1 + j] : 0;
+        TX(gA) = gt & maskLess; TX(gB) = gt & maskVar & ~maskLess; TX(gC) = gt & maskRT;
+        TX(nA) = popc64(TX(gA)); TX(nB) = popc64(TX(gB)); TX(nC) = popc64(TX(gC));
+        TX(iA) = TX(nA); TX(iB) = TX(nB); TX(iC) = TX(nC);
+        if (l < NB) { L.cntItems[w][l] = 0; L.cntNonRT[w][l] = 0; L.bestMid[w][l][0] = ~0ull; L.bestMid[w][l][1] = ~0ull; }
+    }
+    waveInclScan(iA, w); waveInclScan(iB, w); waveInclScan(iC, w);
+    FOR_WLANES(t, w) { const int l = t & 63; L.scan[w][0][l] = TX(iA); L.scan[w][1][l] = TX(iB); L.scan[w][2][l] = TX(iC); }
+    WAVE_SYNC();
+    const int totalPairs = waveRead(iA, w, WAVE - 1) + waveRead(iB, w, WAVE - 1) + waveRead(iC, w, WAVE - 1);
+    // position (in the tile's pair order) of the first pair of each group of this lane's base
+    TV(int, posA); TV(int, posB); TV(int, posC);
+    FOR_WLANES(t, w) {
+        const int l = t & 63, fb = (l / BLK) * BLK, lb = fb + BLK - 1;
+        const int a0 = fb > 0 ? L.scan[w][0][fb - 1] : 0, a1 = L.scan[w][0][lb];
+        const int b0 = fb > 0 ? L.scan[w][1][fb - 1] : 0, b1 = L.scan[w][1][lb];
+        const int c0 = fb > 0 ? L.scan[w][2][fb - 1] : 0;
+        const int P0 = a0 + b0 + c0;
+        TX(posA) = P0 + (TX(iA) - TX(nA) - a0);
+        TX(posB) = P0 + (a1 - a0) + (TX(iB) - TX(nB) - b0);
+        TX(posC) = P0 + (a1 - a0) + (b1 - b0) + (TX(iC) - TX(nC) - c0);
+    }
+    // the pairs r0 .. r0+63 of the tile -> pairJ / pairS (every base scatters its own)
+    auto expand = [&](int r0) {
         FOR_WLANES(t, w) {
             const int l = t & 63;
-            if (l < BLK) {
-                int pos = TX(iA) - TX(nA);
-                for (uint64_t gg = TX(gA); gg; gg &= gg - 1) { L.plD[w][pos] = (uint8_t)l; L.plS[w][pos] = (uint8_t)__builtin_ctzll(gg); pos++; }
-                pos = totA + TX(iB) - TX(nB);
-                for (uint64_t gg = TX(gB); gg; gg &= gg - 1) { L.plD[w][pos] = (uint8_t)l; L.plS[w][pos] = (uint8_t)__builtin_ctzll(gg); pos++; }
-                pos = totA + totB + TX(iC) - TX(nC);
-                for (uint64_t gg = TX(gC); gg; gg &= gg - 1) { L.plD[w][pos] = (uint8_t)l; L.plS[w][pos] = (uint8_t)__builtin_ctzll(gg); pos++; }
+            int pos = TX(posA) - r0;
+            for (uint64_t gg = TX(gA); gg; gg &= gg - 1, pos++)
+                if (pos >= 0 && pos < WAVE) { L.pairJ[w][pos] = (uint8_t)l; L.pairS[w][pos] = (uint8_t)__builtin_ctzll(gg); }
+            pos = TX(posB) - r0;
+            for (uint64_t gg = TX(gB); gg; gg &= gg - 1, pos++)
+                if (pos >= 0 && pos < WAVE) { L.pairJ[w][pos] = (uint8_t)l; L.pairS[w][pos] = (uint8_t)__builtin_ctzll(gg); }
+            pos = TX(posC) - r0;
+            for (uint64_t gg = TX(gC); gg; gg &= gg - 1, pos++)
+                if (pos >= 0 && pos < WAVE) { L.pairJ[w][pos] = (uint8_t)l; L.pairS[w][pos] = (uint8_t)__builtin_ctzll(gg); }
+        }
+        WAVE_SYNC();
+    };
+    // ---- pass 1: describe and count
+    for (int r0 = 0; r0 < totalPairs; r0 += WAVE) {
+        expand(r0);
+        const int nPr = totalPairs - r0 < WAVE ? totalPairs - r0 : WAVE;
+        FOR_WLANES(t, w) {
+            const int l = t & 63;
+            if (l < nPr) {
+                const int dj = L.pairJ[w][l], s2 = L.pairS[w][l];
+                VarDesc D;
+                varDescribe<MULTI>(X, s2, j0 + dj, D);
+                if (r0 + l < DCAP) L.desc[w][r0 + l] = D;
+                ldsAdd(&L.cntItems[w][dj / BLK], (uint32_t)D.total);
+                if (!((maskRT >> s2) & 1)) ldsAdd(&L.cntNonRT[w][dj / BLK], (uint32_t)D.total);
             }
-            if (l == 0) { L.plN[w][0] = totA + totB; L.plN[w][1] = totA + totB + totC; }
         }
         WAVE_SYNC();
     }
-    nP0 = L.plN[w][0]; allPairs = L.plN[w][1];
-    const bool reuse = write && mayReuse && allPairs <= WAVE;
-    uint32_t itemsDone = 0, split = 0, mid1 = 0, mid2 = 0;
-    for (int done = 0; done < allPairs; done += WAVE) {
-        const int nPairs = allPairs - done < WAVE ? allPairs - done : WAVE;
+    // ---- reserve the tile's range; per-block tables
+    TV(int, bItems); TV(int, bInc);
+    FOR_WLANES(t, w) { const int l = t & 63; TX(bItems) = l < NB ? (int)L.cntItems[w][l] : 0; TX(bInc) = TX(bItems); }
+    waveInclScan(bInc, w);
+    const int tileItems = waveRead(bInc, w, WAVE - 1);
+    FOR_WLANES(t, w) {
+        if ((t & 63) == 0) {
+#ifdef AUGX_EMU
+            const unsigned long long bp0 = B.candAlloc->pairs, bi0 = B.candAlloc->items;
+            B.candAlloc->pairs += (unsigned long long)totalPairs; B.candAlloc->items += (unsigned long long)tileItems;
+#else
+            const unsigned long long bp0 = atomicAdd(&B.candAlloc->pairs, (unsigned long long)totalPairs), bi0 = atomicAdd(&B.candAlloc->items, (unsigned long long)tileItems);
+#endif
+            L.baseW[w][0] = bp0; L.baseW[w][1] = bi0;
+        }
+    }
+    WAVE_SYNC();
+    const uint64_t pairBase = L.baseW[w][0], itemBase = L.baseW[w][1];
+    if (itemBase + (uint64_t)tileItems > (uint64_t)B.itemCap) return; // the host re-runs the kernel with a buffer of the size the counters report
+    FOR_WLANES(t, w) {
+        const int l = t & 63;
+        if (l < NB) {
+            const int fb = l * BLK, lb = fb + BLK - 1;
+            const int p0 = fb > 0 ? L.scan[w][0][fb - 1] + L.scan[w][1][fb - 1] + L.scan[w][2][fb - 1] : 0;
+            const int p1 = L.scan[w][0][lb] + L.scan[w][1][lb] + L.scan[w][2][lb];
+            const int64_t gblk = gblk0 + l;
+            B.blkOff[gblk * 2] = pairBase + (uint64_t)p0; B.blkOff[gblk * 2 + 1] = itemBase + (uint64_t)(TX(bInc) - TX(bItems));
+            B.blkCnt[gblk * 2] = (uint32_t)(p1 - p0); B.blkCnt[gblk * 2 + 1] = (uint32_t)TX(bItems);
+            B.blkSplit[gblk * 3 + 2] = L.cntNonRT[w][l];
+            L.cntItems[w][l] = (uint32_t)(TX(bInc) - TX(bItems)); // from here on: first candidate of the block, relative to the tile
+        }
+    }
+    WAVE_SYNC();
+    // ---- pass 2: evaluate and store
+    uint32_t itemsDone = 0;
+    for (int r0 = 0; r0 < totalPairs; r0 += WAVE) {
+        if (totalPairs > WAVE) expand(r0); // (a single round: pairJ / pairS still hold it)
+        const int nPr = totalPairs - r0 < WAVE ? totalPairs - r0 : WAVE;
+        // descriptor slot of pair r0 + q: the first DCAP pairs kept theirs, later ones are described again into the slots
+        // of pairs already done
         TV(int, tot);
-        FOR_WLANES(t, w) { // one lane per pair: locate the pair, build its descriptor
+        FOR_WLANES(t, w) {
             const int l = t & 63;
             TX(tot) = 0;
-            if (l < nPairs) {
-                if (reuse) TX(tot) = L.desc[w][l].total;
-                else {
-                    const int dj = L.plD[w][done + l], s2 = L.plS[w][done + l];
-                    L.pairJ[w][l] = jb + dj; L.pairS[w][l] = s2;
-                    varDescribe<MULTI>(X, s2, jb + dj, L.desc[w][l]);
-                    TX(tot) = L.desc[w][l].total;
-                }
+            if (l < nPr) {
+                if (r0 + l >= DCAP) varDescribe<MULTI>(X, L.pairS[w][l], j0 + L.pairJ[w][l], L.desc[w][l]);
+                TX(tot) = L.desc[w][r0 + l < DCAP ? r0 + l : l].total;
             }
         }
         WAVE_SYNC();
@@ -936,109 +1009,86 @@ AUGX_KFN void candBlock(const CandCtx &X, CandLds &L, int w, int b, bool write, 
         FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
         waveInclScan(ibase, w);
         const int totalItems = waveRead(ibase, w, WAVE - 1);
-        if (!write) {
-            // candidates of the pairs before the first RTERMINAL pair
-            if (nP0 > done) split = itemsDone + (uint32_t)(nP0 - done >= nPairs ? totalItems : waveRead(ibase, w, nP0 - done - 1));
-            if (done == 0) { // pair boundaries closest to 1/3 and 2/3 of the non-RTERMINAL candidates (three trellis wavefronts share them)
-                const int np = nP0 < nPairs ? nP0 : nPairs;
-                const int tot0 = np > 0 ? waveRead(ibase, w, np - 1) : 0, t1 = tot0 / 3, t2 = 2 * tot0 / 3;
-                int best1 = 0x7fffffff, best2 = 0x7fffffff;
-                for (int q = 0; q < np; q++) {
-                    const int bnd = waveRead(ibase, w, q), d1 = bnd > t1 ? bnd - t1 : t1 - bnd, d2 = bnd > t2 ? bnd - t2 : t2 - bnd;
-                    if (d1 < best1) { best1 = d1; mid1 = (uint32_t)bnd; }
-                    if (d2 < best2) { best2 = d2; mid2 = (uint32_t)bnd; }
-                }
-                if (mid2 < mid1) mid2 = mid1;
+        FOR_WLANES(t, w) { // pair boundaries nearest to 1/3 and 2/3 of the block's candidates (RTERMINAL pairs come last and are not shared)
+            const int l = t & 63;
+            if (l < nPr && !((maskRT >> L.pairS[w][l]) & 1)) {
+                const int blk = L.pairJ[w][l] / BLK;
+                const uint32_t loc = itemsDone + (uint32_t)TX(ibase) - L.cntItems[w][blk], nr = L.cntNonRT[w][blk];
+                const uint32_t t1 = nr / 3, t2 = 2 * nr / 3, d1 = loc > t1 ? loc - t1 : t1 - loc, d2 = loc > t2 ? loc - t2 : t2 - loc;
+                ldsMin64(&L.bestMid[w][blk][0], ((unsigned long long)d1 << 32) | loc);
+                ldsMin64(&L.bestMid[w][blk][1], ((unsigned long long)d2 << 32) | loc);
             }
-        } else {
-            for (int base = 0; base < totalItems; base += WAVE) {
-                TV(int, myPair);
-                TV(int, myFirst);
-                FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
-                for (int q = 0; q < nPairs; q++) { // pair of item `base + lane`: last pair whose first item is <= it
-                    const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
-                    FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
-                }
-                FOR_WLANES(t, w) { // one candidate per lane
-                    const int l = t & 63;
-                    const int it = base + l;
-                    if (it < totalItems) {
-                        const int q = TX(myPair);
-                        double te; int key; uint32_t src;
-                        varEvalItem<MULTI>(X, L.pairS[w][q], L.pairJ[w][q], L.desc[w][q], it - TX(myFirst), te, key, src);
-                        if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
-                        Item I;
-                        I.te = te; I.kp = ((uint32_t)(((L.pairJ[w][q] - jb) << 6) | L.pairS[w][q]) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
-                        B.items[itemBase + itemsDone + it] = I;
-                    }
+        }
+        for (int base = 0; base < totalItems; base += WAVE) {
+            TV(int, myPair);
+            TV(int, myFirst);
+            FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
+            for (int q = 0; q < nPr; q++) { // pair of candidate `base + lane`: last pair whose first candidate is <= it
+                const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
+                if (first >= base + WAVE) break;
+                FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
+            }
+            FOR_WLANES(t, w) { // one candidate per lane
+                const int l = t & 63;
+                const int it = base + l;
+                if (it < totalItems) {
+                    const int q = TX(myPair);
+                    const int dj = L.pairJ[w][q], s2 = L.pairS[w][q];
+                    double te; int key; uint32_t src;
+                    varEvalItem<MULTI>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - TX(myFirst), te, key, src);
+                    if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                    Item I;
+                    I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+                    B.items[itemBase + itemsDone + it] = I;
                 }
             }
         }
         WAVE_SYNC();
         itemsDone += (uint32_t)totalItems;
     }
-    if (!write) { cnt[0] = (uint32_t)allPairs; cnt[1] = itemsDone; cnt[2] = nP0 == 0 ? 0 : split; cnt[3] = mid1; cnt[4] = mid2; }
+    FOR_WLANES(t, w) {
+        const int l = t & 63;
+        if (l < NB) {
+            const unsigned long long m1 = L.bestMid[w][l][0], m2 = L.bestMid[w][l][1];
+            uint32_t mid1 = m1 == ~0ull ? 0 : (uint32_t)m1, mid2 = m2 == ~0ull ? 0 : (uint32_t)m2;
+            if (mid2 < mid1) mid2 = mid1;
+            B.blkSplit[(gblk0 + l) * 3] = mid1; B.blkSplit[(gblk0 + l) * 3 + 1] = mid2;
+        }
+    }
 }
 
-// global allocation state of the candidate buffers (one per batch)
-struct CandAlloc { unsigned long long pairs, items; };
-
-// one workgroup = the WAVE / BLK consecutive blocks of one tile of 64 bases (they belong to one piece: a chunk of
-// CHUNK slots never spans pieces), one or two blocks per wavefront.  Count, reserve a contiguous range for the tile, emit.
+// one workgroup = NWAVES consecutive tiles of 64 bases (they belong to one piece: a chunk of CHUNK slots never spans
+// pieces), one tile per wavefront; the wavefronts share the per-state constants and nothing else
 template <int BLK, bool MULTI>
 AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg) {
-    constexpr int NB = WAVE / BLK, BPW = NB / NWAVES; // blocks per tile, blocks per wavefront
-    static_assert(NB % NWAVES == 0 && NB <= MAXNB, "block size");
-    const int64_t gblk0 = wg * NB;
-    if (gblk0 >= B.nBlk) return;
-    const int p = B.chunkPiece[gblk0 * BLK / CHUNK];
+    constexpr int NB = WAVE / BLK;
+    static_assert(CHUNK % (NWAVES * WAVE) == 0, "tiles of a workgroup lie in one chunk");
+    const int64_t gtile0 = wg * NWAVES;
+    if (gtile0 * WAVE >= B.N) return;
+    const int p = B.chunkPiece[gtile0 * WAVE / CHUNK];
+#ifndef AUGX_EMU
+    uint64_t cp0 = clock64(), cp1;
+#endif
     FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, B, p, t, L.vc[t]); }
     BLOCK_SYNC();
     CandCtx X(T, B, L.vc, p);
     uint64_t maskVar, maskRT;
     varMasks(T, maskVar, maskRT);
+    uint64_t maskLess = 0;
+    for (int s2 = 0; s2 < X.S; s2++)
+        if (L.vc[s2].kind == AUGX_K_LESSD || L.vc[s2].kind == AUGX_K_RLESSD) maskLess |= 1ull << s2;
+    maskLess &= maskVar;
     FOR_WAVES(w) {
-        for (int q = 0; q < BPW; q++) {
-            const int bi = w * BPW + q;
-            const int b = (int)(gblk0 + bi - X.o / BLK);
-            uint32_t cnt[5];
-            candBlock<BLK, MULTI>(X, L, w, b, false, BPW == 1, maskVar, maskRT, 0, 0, cnt);
-            FOR_WLANES(t, w) { if ((t & 63) == 0) for (int i = 0; i < 5; i++) L.cntW[bi][i] = cnt[i]; }
-        }
+        const int64_t gtile = gtile0 + w;
+        candTile<BLK, MULTI>(X, L, w, (int)(gtile * WAVE - X.o), gtile * NB, maskLess, maskVar, maskRT);
     }
-    BLOCK_SYNC();
-    FOR_THREADS(t) {
-        if (t == 0) {
-            unsigned long long np = 0, ni = 0;
-            for (int bi = 0; bi < NB; bi++) { L.preW[bi][0] = np; L.preW[bi][1] = ni; np += L.cntW[bi][0]; ni += L.cntW[bi][1]; }
-#ifdef AUGX_EMU
-            const unsigned long long bp0 = B.candAlloc->pairs, bi0 = B.candAlloc->items;
-            B.candAlloc->pairs += np; B.candAlloc->items += ni;
-#else
-            const unsigned long long bp0 = atomicAdd(&B.candAlloc->pairs, np), bi0 = atomicAdd(&B.candAlloc->items, ni);
+#ifndef AUGX_EMU
+    cp1 = clock64();
+    if (B.prof && (threadIdx.x & 63) == 0) {
+        unsigned long long *pp = (unsigned long long *)B.prof + (int64_t)B.nPieces * 56;
+        atomicAdd(pp + 0, cp1 - cp0); atomicAdd(pp + 4, 1ull);
+    }
 #endif
-            L.baseW[0] = bp0; L.baseW[1] = bi0;
-            L.fits = bi0 + ni <= (unsigned long long)B.itemCap ? 1 : 0;
-        }
-    }
-    BLOCK_SYNC();
-    if (!L.fits) return; // the host re-runs the kernel with buffers of the size the counters report
-    FOR_WAVES(w) {
-        for (int q = 0; q < BPW; q++) {
-            const int bi = w * BPW + q;
-            const int64_t gblk = gblk0 + bi;
-            const int b = (int)(gblk - X.o / BLK);
-            const uint64_t pairBase = L.baseW[0] + L.preW[bi][0], itemBase = L.baseW[1] + L.preW[bi][1];
-            FOR_WLANES(t, w) {
-                if ((t & 63) == 0) {
-                    B.blkOff[gblk * 2] = pairBase; B.blkOff[gblk * 2 + 1] = itemBase;
-                    B.blkCnt[gblk * 2] = L.cntW[bi][0]; B.blkCnt[gblk * 2 + 1] = L.cntW[bi][1];
-                    B.blkSplit[gblk * 3] = L.cntW[bi][3]; B.blkSplit[gblk * 3 + 1] = L.cntW[bi][4]; B.blkSplit[gblk * 3 + 2] = L.cntW[bi][2];
-                }
-            }
-            if (L.cntW[bi][0] > 0) candBlock<BLK, MULTI>(X, L, w, b, true, BPW == 1, maskVar, maskRT, pairBase, itemBase, nullptr);
-        }
-    }
 }
 
 // =================================================================================================

@@ -139,7 +139,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     CandAlloc ca;
     B.candAlloc = &ca;
     CandLds *cl = new CandLds();
-    const int64_t nWg = B.N / WAVE; // one workgroup per tile of 64 bases
+    const int64_t nWg = B.N / (WAVE * NWAVES); // one wavefront per tile of 64 bases
     B.itemCap = 64;
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int attempt = 0; attempt < 2; attempt++) {
