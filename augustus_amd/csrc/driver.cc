@@ -240,64 +240,88 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             S.oo.offset = -ps - 1;
     }
 
-    // ---- phase 1: find the cut points of all records (serial chain per record, reference src/namgene.cc:973-1133)
+    // ---- phase 1: find the cut points of all records (reference src/namgene.cc:973-1133).  Inside a record the cuts are a
+    //      serial chain (the next exam window starts where the last piece ended), but records are independent: every round
+    //      decodes the pending exam window of EVERY unfinished record in one batch.
     struct PieceRef { int rec; long begin, end; int initKind, termKind; };
-    std::vector<PieceRef> allPieces;
-    for (size_t r = 0; r < recs.size(); r++) {
-        const std::string &dna = recs[r].seq;
-        const long seqlen = (long)dna.size();
+    struct CutState {
         long beginPos = 0;
         int prevInit = 0, prevTerm = 0; // init/term kinds in effect while the exam window is decoded (state leak, src/namgene.cc:576 vs 594-603)
-        do {
-            long endPos;
-            long restlen = seqlen - beginPos;
-            if (restlen <= maxstep)
-                endPos = beginPos + restlen - 1;
-            else {
-                long examChunk = 50000;
-                if (examChunk < 0.2 * maxstep) examChunk = (long)(0.2 * maxstep);
-                if (examChunk > 150000) examChunk = 150000;
-                const long gapStart = 1, gapEnd = seqlen;
-                long cut = -1;
-                std::vector<PathState> lastPath;
-                long es = 0, ee = 0;
-                for (int attempt = 0; attempt < 2 && cut == -1; attempt++) {
-                    if (attempt == 1) { examChunk *= 2; if (examChunk > maxstep) examChunk = maxstep; }
-                    long center = (gapEnd - gapStart < examChunk) ? (gapEnd + gapStart) / 2 : gapEnd - examChunk / 2;
-                    if (attempt == 0 && examChunk > maxstep) { es = beginPos; ee = beginPos + maxstep - 1; }
-                    else {
-                        es = center - examChunk / 2;
-                        ee = center + examChunk / 2;
-                        if (ee >= beginPos + maxstep) { es -= (ee - (beginPos + maxstep - 1)); ee = beginPos + maxstep - 1; }
-                        if (es < beginPos) { ee += beginPos - es; es = beginPos; }
-                    }
-                    std::vector<augx_piece> ex(1);
-                    ex[0].seq = dna.data() + es; ex[0].len = ee - es + 1; ex[0].init_kind = prevInit; ex[0].term_kind = prevTerm;
-                    std::vector<Decoded> dd;
-                    if (!S.decode(ex, dd)) { restore(); return fail(S.err); }
-                    if (dd[0].status != 0) { restore(); return fail("No feasible path found in HMM"); }
-                    lastPath = dd[0].path;
-                    cut = tryFindCutEndPoint(lastPath, es, ee, true, gapStart, gapEnd, true);
-                }
-                if (cut == -1) {
-                    cut = tryFindCutEndPoint(lastPath, es, ee, true, gapStart, gapEnd, false);
-                    if (cut == -1) cut = tryFindCutEndPoint(lastPath, es, ee, false, 0, 0, false);
-                    if (cut == -1) cut = beginPos + maxstep - 1;
-                }
-                if (cut <= beginPos + 0.05 * maxstep || cut <= beginPos + 5000) cut = beginPos + maxstep - 1;
-                endPos = cut;
-            }
+        int attempt = 0;
+        long examChunk = 0, es = 0, ee = 0;
+        bool done = false;
+    };
+    std::vector<std::vector<PieceRef>> recPieces(recs.size());
+    {
+        std::vector<CutState> cs(recs.size());
+        auto pushPiece = [&](size_t r, long endPos) {
+            const long seqlen = (long)recs[r].seq.size();
+            CutState &c = cs[r];
             PieceRef pr;
-            pr.rec = (int)r; pr.begin = beginPos; pr.end = endPos;
-            pr.initKind = beginPos == 0 ? 0 : 1;
+            pr.rec = (int)r; pr.begin = c.beginPos; pr.end = endPos;
+            pr.initKind = c.beginPos == 0 ? 0 : 1;
             pr.termKind = endPos == seqlen - 1 ? 0 : 1;
-            allPieces.push_back(pr);
-            prevInit = pr.initKind; prevTerm = pr.termKind;
-            beginPos = endPos + 1;
-        } while (beginPos < seqlen);
+            recPieces[r].push_back(pr);
+            c.prevInit = pr.initKind; c.prevTerm = pr.termKind;
+            c.beginPos = endPos + 1;
+            c.attempt = 0;
+            if (c.beginPos >= seqlen) c.done = true;
+        };
+        for (;;) {
+            std::vector<augx_piece> ex;
+            std::vector<size_t> who;
+            for (size_t r = 0; r < recs.size(); r++) {
+                CutState &c = cs[r];
+                const long seqlen = (long)recs[r].seq.size();
+                while (!c.done && seqlen - c.beginPos <= maxstep) pushPiece(r, seqlen - 1); // the rest fits one piece
+                if (c.done) continue;
+                if (c.attempt == 0) {
+                    c.examChunk = 50000;
+                    if (c.examChunk < 0.2 * maxstep) c.examChunk = (long)(0.2 * maxstep);
+                    if (c.examChunk > 150000) c.examChunk = 150000;
+                } else { c.examChunk *= 2; if (c.examChunk > maxstep) c.examChunk = maxstep; }
+                const long gapStart = 1, gapEnd = seqlen;
+                const long center = (gapEnd - gapStart < c.examChunk) ? (gapEnd + gapStart) / 2 : gapEnd - c.examChunk / 2;
+                if (c.attempt == 0 && c.examChunk > maxstep) { c.es = c.beginPos; c.ee = c.beginPos + maxstep - 1; }
+                else {
+                    c.es = center - c.examChunk / 2;
+                    c.ee = center + c.examChunk / 2;
+                    if (c.ee >= c.beginPos + maxstep) { c.es -= (c.ee - (c.beginPos + maxstep - 1)); c.ee = c.beginPos + maxstep - 1; }
+                    if (c.es < c.beginPos) { c.ee += c.beginPos - c.es; c.es = c.beginPos; }
+                }
+                augx_piece p;
+                p.seq = recs[r].seq.data() + c.es; p.len = c.ee - c.es + 1; p.init_kind = c.prevInit; p.term_kind = c.prevTerm;
+                ex.push_back(p);
+                who.push_back(r);
+            }
+            if (ex.empty()) break;
+            std::vector<Decoded> dd;
+            if (!S.decode(ex, dd)) { restore(); return fail(S.err); }
+            for (size_t k = 0; k < who.size(); k++) {
+                const size_t r = who[k];
+                CutState &c = cs[r];
+                const long seqlen = (long)recs[r].seq.size();
+                const long gapStart = 1, gapEnd = seqlen;
+                if (dd[k].status != 0) { restore(); return fail("No feasible path found in HMM"); }
+                long cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, true, gapStart, gapEnd, true);
+                if (cut == -1 && c.attempt == 0) { c.attempt = 1; continue; } // once more with a window twice as long
+                if (cut == -1) {
+                    cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, true, gapStart, gapEnd, false);
+                    if (cut == -1) cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, false, 0, 0, false);
+                    if (cut == -1) cut = c.beginPos + maxstep - 1;
+                }
+                if (cut <= c.beginPos + 0.05 * maxstep || cut <= c.beginPos + 5000) cut = c.beginPos + maxstep - 1;
+                pushPiece(r, cut);
+            }
+        }
     }
+    std::vector<PieceRef> allPieces;
+    for (auto &v : recPieces) allPieces.insert(allPieces.end(), v.begin(), v.end());
 
-    // ---- phase 2: decode all pieces in batches bounded by a slot budget
+    // ---- phase 2: decode all pieces in batches bounded by a slot budget.  (Taking the batches in turn on two decoders /
+    //      HIP streams, as bench.py does with its resident batches, was measured here and does not pay: genome pieces are
+    //      maxDNAPieceSize long, the trellis kernel's time is set by the piece length, and two half-size batches in flight
+    //      keep no more compute units busy than one full-size batch.)
     std::vector<Decoded> decoded(allPieces.size());
     {
         long budget = (long)augx_decoder_batch_capacity(S.dec); // bases per batch: what the free HBM holds, at most 128 Mbp
