@@ -46,31 +46,41 @@ struct BatchLayout {
 // piece has more than MAXPL classes.
 inline int stairsPlanes(const uint8_t *wc, int n, int win, std::vector<uint8_t> &plane, int32_t planeCls[MAXPL]) {
     if (win > n || win < 1) win = n;
-    std::vector<uint8_t> cls((size_t)n);
     const int half = win / 2, last = n - win;
-    for (int i = 0; i < n; i++) {
-        int s = i - half;
-        cls[i] = wc[s < 0 ? 0 : s > last ? last : s];
-    }
-    int x = -2, lastStep = 0;
-    for (int i = 0; i < n; i++)
-        if (cls[i] != x) {
-            if (i - lastStep < 1000 && lastStep > 0 && cls[lastStep - 1] == cls[i])
-                for (int j = lastStep; j < i; j++) cls[j] = cls[i];
-            lastStep = i;
-            x = cls[i];
+    // runs of equal window class -> runs of positions (classes change every few kb at most: work per run, not per base)
+    std::vector<int> st, cl; // first position and class of each run
+    for (int s0 = 0; s0 <= last;) {
+        const uint8_t c = wc[s0];
+        int s1 = s0 + 1;
+        const uint64_t pat = 0x0101010101010101ull * c;
+        while (s1 + 8 <= last + 1) { // eight windows at a time while they agree
+            uint64_t w;
+            memcpy(&w, wc + s1, 8);
+            if (w != pat) break;
+            s1 += 8;
         }
+        while (s1 <= last && wc[s1] == c) s1++;
+        st.push_back(s0 == 0 ? 0 : s0 + half); // window s is centred on position s + half; the ends take the first / last window
+        cl.push_back(c);
+        s0 = s1;
+    }
+    // smoothing, in the order of the reference's loop over the positions: when run k begins, run k-1 is dissolved into its
+    // neighbours if it is shorter than 1000, does not start the piece, and the run before it has the class of run k
+    const int R = (int)st.size();
+    for (int k = 2; k < R; k++)
+        if (st[k] - st[k - 1] < 1000 && st[k - 1] > 0 && cl[k - 2] == cl[k]) cl[k - 1] = cl[k];
     int nPl = 0, map[256];
     for (int i = 0; i < 256; i++) map[i] = -1;
-    plane.assign((size_t)n, 0);
-    for (int i = 0; i < n; i++) {
-        int &m = map[cls[i]];
+    plane.resize((size_t)n);
+    for (int k = 0; k < R; k++) {
+        int &m = map[cl[k]];
         if (m < 0) {
             if (nPl >= MAXPL) return -1;
-            planeCls[nPl] = cls[i];
+            planeCls[nPl] = cl[k];
             m = nPl++;
         }
-        plane[i] = (uint8_t)m;
+        const int e = k + 1 < R ? st[k + 1] : n;
+        memset(plane.data() + st[k], m, (size_t)(e - st[k]));
     }
     return nPl;
 }
