@@ -82,3 +82,29 @@ def test_emulated_adversarial_sequences(species):
         assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
         assert path == [(b, e, s) for b, e, s, t in path2], name
     assert decoded == len(cases)
+
+
+def test_emulated_content_stairs_smoothing():
+    """GC-content stairs (reference ContentStairs::computeStairs, src/motif.cc:543-616), settled from the device's window
+    classes run by run (layout.h: stairsPlanes) vs the oracle's loop over the positions: all cells must be equal."""
+    import random
+
+    def gc_dna(n, gc, seed):
+        rng = random.Random(seed)
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(n))
+
+    m = ax.Model(config_path(), "human", softmasking="0")
+    S = m.n_states
+    seqs = [gc_dna(40000, 0.445, 11),                                                # GC content at the class boundary: the window
+                                                                                      # classes flicker, the stairs keep steps >= 1000 apart
+            gc_dna(9000, 0.30, 4) + gc_dna(6000, 0.65, 5) + gc_dna(9000, 0.30, 6),   # a real step up and down
+            gc_dna(2000, 0.65, 7) + gc_dna(9000, 0.30, 8)]                            # a step close to the start
+    res = emu_decode(m.tables_ptr, seqs, S, cells=True)
+    n_steps = []
+    for seq, (st, lnv, path, V, cls) in zip(seqs, res):
+        rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, S, cells=True)
+        n_steps.append(int((gc[1:] != gc[:-1]).sum()))
+        assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2)
+        assert path == [(b, e, s) for b, e, s, t in path2]
+    assert n_steps[0] >= 3 and n_steps[1] == 2 and n_steps[2] >= 1, n_steps
+
