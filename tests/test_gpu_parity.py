@@ -170,3 +170,43 @@ def test_gpu_adversarial_sequences(species):
         assert decoded == len(cases)
     finally:
         del os.environ["AUGX_DEBUG_CELLS"]
+
+
+@pytest.mark.parametrize("cfg", ["human", "fly", "arabidopsis", "saccharomyces"])
+def test_gpu_randomised_pieces(cfg):
+    """ragged batches of random composition -- real genes on both strands, N runs, soft-masked halves, stretches of
+    different GC content (several GC classes inside a piece), both init/term kinds: score and path bit-identical to the oracle"""
+    import random
+    recs = dict(golden_inputs())
+    ex = recs["HS04636"].upper()
+    rc_ex = ex[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+    def gc_dna(n, gc, rng):
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(n))
+
+    species, opts = GOLDEN_CFGS[cfg]
+    m = ax.Model(config_path(), species, **opts)
+    d = ax.Decoder(m, 0)
+    rng = random.Random(sum(map(ord, cfg)))
+    seqs = []
+    for i in range(24):
+        parts = []
+        for k in range(rng.randint(1, 5)):
+            r = rng.random()
+            if r < 0.25:
+                parts.append(ex if rng.random() < 0.5 else rc_ex)
+            elif r < 0.35:
+                parts.append("N" * rng.randint(1, 3000))
+            else:
+                parts.append(gc_dna(rng.randint(50, 30000), rng.choice([0.3, 0.4, 0.445, 0.5, 0.6, 0.7]), rng))
+        s = "".join(parts)
+        if rng.random() < 0.3:
+            s = s.lower() if rng.random() < 0.3 else s[:len(s) // 2] + s[len(s) // 2:].lower()
+        seqs.append(s)
+    multi = 0
+    for ik, tk in ((0, 0), (1, 1)):
+        for s, r in zip(seqs, d.decode(seqs, init_kind=ik, term_kind=tk)):
+            rc, lnv, path, _, gc = twin_decode(m.tables_ptr, s, m.n_states, init_kind=ik, term_kind=tk)
+            multi += len(set(gc.tolist())) > 1
+            assert (r.status == 0 and rc == 0 and r.ln_viterbi == lnv and r.states == path) or (r.status == ax.AUGX_E_NOPATH and rc != 0), len(s)
+    assert multi > 0 or cfg in ("fly", "arabidopsis")  # (one GC class)
