@@ -1134,10 +1134,12 @@ __device__ inline double ldCoherent(const double *p) {
 
 // cross-lane primitives of the trellis wavefront
 #ifdef AUGX_EMU
-// inclusive segmented arg-max scan: lanes with equal kp >> KEY_BITS form a segment (segments are contiguous)
+// inclusive segmented arg-max scan: lanes with equal kp >> KEY_BITS form a segment (segments are contiguous).  Inside a
+// segment (= the candidates of one (base, state) pair, newest first) the keys strictly decrease from lane to lane, so
+// "larger key wins a tie" is "the lane on the left wins a tie": the keys need not be compared.
 inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int w) {
     for (int l = w * WAVE + 1; l < w * WAVE + WAVE; l++)
-        if ((kp[l - 1] >> KEY_BITS) == (kp[l] >> KEY_BITS) && better(val[l - 1], (int)kp[l - 1], val[l], (int)kp[l])) {
+        if ((kp[l - 1] >> KEY_BITS) == (kp[l] >> KEY_BITS) && val[l - 1] >= val[l]) {
             val[l] = val[l - 1]; kp[l] = kp[l - 1]; src[l] = src[l - 1];
         }
 }
@@ -1156,7 +1158,7 @@ __device__ inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int
 #define AUGX_SEG_STEP(CTRL, ROWMASK) { \
         const double ov = dppMovD<CTRL, ROWMASK>(v, v); \
         const uint32_t ok = (uint32_t)dppMov<CTRL, ROWMASK>((int)k, (int)k), os = (uint32_t)dppMov<CTRL, ROWMASK>((int)s, (int)s); \
-        const bool tk = (ok >> KEY_BITS) == seg && better(ov, (int)ok, v, (int)k); \
+        const bool tk = (ok >> KEY_BITS) == seg && ov >= v; /* (the left lane holds the larger key) */ \
         v = tk ? ov : v; k = tk ? ok : k; s = tk ? os : s; }
     AUGX_SEG_STEP(0x111, 0xf)
     AUGX_SEG_STEP(0x112, 0xf)
