@@ -1117,6 +1117,7 @@ struct TrellisLds {
     double lcVal[4][LIST_WIN][3];   // Viterbi values (three frames) of the newest LIST_WIN entries of the four lists
     double col0[SP];                // column 0 (initial probabilities)
     uint8_t gcw[2][WAVE];           // plane (GC class) of the bases of the current / next tile (multi-class pieces only)
+    int flagSum;                     // sum of flagI[]: the workers are never more than one block apart, so flagSum >= NWORK * k <=> every flagI >= k
     int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     int abortFlag;
 };
@@ -1185,6 +1186,7 @@ inline void setFlag(int *f, int v) { *f = v; }
 inline void drainStores() {}
 inline int readFlag(const int *f) { return *f; }
 inline void addFlag(int *f) { *f += 1; }
+inline void bumpFlag(int *f) { *f += 1; }
 #else
 __device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
     int spins = 0;
@@ -1203,6 +1205,9 @@ __device__ inline void drainStores() { __builtin_amdgcn_s_waitcnt(0x0070); } // 
 __device__ inline void addFlag(int *f) { // one count per wavefront, after everything it loaded has landed in LDS
     __builtin_amdgcn_s_waitcnt(0x0070); // vmcnt(0) lgkmcnt(0)
     __asm__ volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ inline void bumpFlag(int *f) { // right after a setFlag of the same wavefront (its LDS writes have been performed)
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ inline void setFlag(int *f, int v) {
@@ -1476,6 +1481,13 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         else if (kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD) nNearStates += dL < 3 * BLK;
     }
     const int nearRounds = (nNearStates + SPR - 1) / SPR, farBase = nearRounds * SPR;
+    // the far step of block b reads cells back to base b*BLK + BLK-1 - farMinLag; among them RTERMINAL cells, which exist
+    // only once the igenic cells of their own block do: igenic must be complete up to that block (farNeedC)
+    int farMinLag = 1 << 20;
+    if (dssWhole >= 3 * BLK && dssWhole < farMinLag) farMinLag = dssWhole;
+    if (assLag >= 3 * BLK && assLag < farMinLag) farMinLag = assLag;
+    if (dL >= 3 * BLK && dL < farMinLag) farMinLag = dL;
+    auto farNeedC = [&](int gb) { const int q = gb * BLK + BLK - 1 - farMinLag; return q < 0 ? 0 : q / BLK + 1; };
     TV2(int, fS, FR); TV2(int, fLag, FR); TV2(int, fSig, FR); TV2(int, fLong, FR); TV2(int, fNanc, FR);
     TV2(int, fAnc0, FR); TV2(int, fAnc1, FR); TV2(double, fTr0, FR); TV2(double, fTr1, FR);
     TV2(int, fLrow, FR); TV2(int, fList, FR); TV2(int, fFrame, FR); TV2(int, fLate, FR);
@@ -1563,7 +1575,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
             L.col0[t] = v;
         }
-        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.flagR = 0; L.staged = 0; L.rtPub = 0; L.abortFlag = 0; }
+        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.flagR = 0; L.staged = 0; L.rtPub = 0; L.abortFlag = 0; L.flagSum = 0; }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
@@ -1826,9 +1838,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                       itA = it0 + (int)L.blkSplit[buf][blk][0], itB = it0 + (int)L.blkSplit[buf][blk][1], itS = it0 + (int)L.blkSplit[buf][blk][2];
             FOR_WAVES(w) {
                 if (w == W_X && gbk >= farPre) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk - 2);
+                    waitFlag(L, &L.flagSum, NWORK * (gbk - 2));
                     PROF_MARK(X, 1);
-                    rtCatchUp(w, buf, tile, readFlag(&L.flagC), jb); // RTERMINAL candidates of the blocks whose igenic cells are complete (at least b-5)
+                    waitFlag(L, &L.flagC, farNeedC(gbk)); // (lag 40 at block size 8: b-4, implied by the wait above; lag 39: b-3)
+                    rtCatchUp(w, buf, tile, readFlag(&L.flagC), jb); // RTERMINAL candidates of the blocks whose igenic cells are complete
                     PROF_MARK(X, 3);
                     farStep(w, buf, jb);
                     if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagN, gbk + 1);
@@ -1837,10 +1850,11 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
             FOR_WAVES(w) {
                 if (w == W_C) { // (1)
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gbk);
+                    waitFlag(L, &L.flagSum, NWORK * gbk); // (one poll instead of three: this hand-off is on the critical cycle)
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 6);
                     fixedStep(w, buf, jb, 3, 0, nearRounds); // near (class 0) and late (class 1) states
+                    waitFlag(L, &L.flagN, gbk + 1); // (the far step runs ahead: flagL then also tells the workers that it is done)
                     if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagL, gbk + 1);
                     PROF_STAMP(X, gbk, 7);
                     PROF_MARK(X, 2);
@@ -1859,15 +1873,14 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
             FOR_WAVES(w) {
                 if (w < NWORK) { // (4)
-                    waitFlag(L, &L.flagN, gbk + 1);
-                    waitFlag(L, &L.flagL, gbk + 1);
+                    waitFlag(L, &L.flagL, gbk + 1); // (implies flagN >= gbk + 1, see (1))
                     if (safeIg) waitFlag(L, &L.flagC, gbk);
                     PROF_MARK(X, 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 2 : 4);
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
                     const int lo2 = w == 0 ? it0 : w == 1 ? itA : itB, hi2 = w == 0 ? itA : w == 1 ? itB : itS;
                     if (hi2 > lo2) trellisItems(X, w, buf, blk, jb, lo2, hi2, vigLo);
-                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagI[w], gbk + 1);
+                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagI[w], gbk + 1); bumpFlag(&L.flagSum);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 3 : 5);
                     PROF_MARK(X, 2);
                 }
@@ -1878,7 +1891,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         FOR_WAVES(w) {
             if (w == W_C && nb > 0) {
                 const int gLast = tile * NB + nb - 1, jbLast = j0 + (nb - 1) * BLK;
-                for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gLast + 1);
+                waitFlag(L, &L.flagSum, NWORK * (gLast + 1));
                 PROF_MARK(X, 1);
                 PROF_TSTAMP(X, tile == 124, 11);
                 chainPass(w, buf, jbLast, -1);
@@ -1895,8 +1908,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const int gN = (tile + 1) * NB, jbN = j0 + WAVE;
                 if (tile + 1 < nTiles && jbN < n) {
                     waitFlag(L, &L.staged, (NWAVES - W_LOAD) * (tile + 1));
-                    for (int i = 0; i < NWORK; i++) waitFlag(L, &L.flagI[i], gN - 2);
-                    rtCatchUp(w, buf, tile, readFlag(&L.flagC), j0 + nb * BLK); // the far states read RTERMINAL cells 5 blocks back
+                    waitFlag(L, &L.flagSum, NWORK * (gN - 2));
+                    waitFlag(L, &L.flagC, farNeedC(gN));
+                    rtCatchUp(w, buf, tile, readFlag(&L.flagC), j0 + nb * BLK);
                     farStep(w, buf ^ 1, jbN);
                     if (wantCells) drainStores();
                     setFlag(&L.flagN, gN + 1);
