@@ -125,15 +125,15 @@ inline void checkModelSupported(const augx_tables &t, int BLK) {
              kind == AUGX_K_RSINGLE || kind == AUGX_K_RTERMINAL) && t.n_anc[s] != 1)
             throw std::runtime_error("augx: unexpected ancestor count (non-standard transition file)");
     }
-    // the trellis kernel finishes the RTERMINAL cells of a block while the next block is under way: their readers must
-    // be fixed-lag states more than two blocks away
+    // the trellis kernel finishes the RTERMINAL cells of a block when the igenic cells of that block exist, one or two
+    // blocks later: their readers must be fixed-lag states of the far class (lag >= 3 blocks), whose step waits for them
     for (int s = 0; s < t.S; s++)
         for (int a = 0; a < t.n_anc[s]; a++)
             if (t.reachable[s] && t.state_kind[t.anc[s][a]] == AUGX_K_RTERMINAL) {
                 int kind = t.state_kind[s];
                 int lag = (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? t.As + 2 + t.Ae + t.U
                           : (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? t.Ds + 2 + t.De : 0;
-                if (lag <= 2 * BLK) throw std::runtime_error("augx: unexpected successor of the reverse terminal exon state");
+                if (lag < 3 * BLK) throw std::runtime_error("augx: unexpected successor of the reverse terminal exon state");
             }
     // scheduling assumptions of the trellis kernel (device/kernels.h, trellisPiece)
     {
