@@ -1009,6 +1009,9 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         FOR_WLANES(t, w) { TX(ibase) = TX(tot); }
         waveInclScan(ibase, w);
         const int totalItems = waveRead(ibase, w, WAVE - 1);
+        // (the scan rows are free by now: row 0 takes the prefix, padded, for the candidates' search of their pair)
+        FOR_WLANES(t, w) { const int l = t & 63; L.scan[w][0][l] = l < nPr ? TX(ibase) : 0x7fffffff; }
+        WAVE_SYNC();
         FOR_WLANES(t, w) { // pair boundaries nearest to 1/3 and 2/3 of the block's candidates (RTERMINAL pairs come last and are not shared)
             const int l = t & 63;
             if (l < nPr && !((maskRT >> L.pairS[w][l]) & 1)) {
@@ -1022,11 +1025,14 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         for (int base = 0; base < totalItems; base += WAVE) {
             TV(int, myPair);
             TV(int, myFirst);
-            FOR_WLANES(t, w) { TX(myPair) = 0; TX(myFirst) = 0; }
-            for (int q = 0; q < nPr; q++) { // pair of candidate `base + lane`: last pair whose first candidate is <= it
-                const int first = q == 0 ? 0 : waveRead(ibase, w, q - 1); // all lanes active here (cross-lane read)
-                if (first >= base + WAVE) break;
-                FOR_WLANES(t, w) { if (first <= base + (t & 63)) { TX(myPair) = q; TX(myFirst) = first; } }
+            FOR_WLANES(t, w) { // pair of candidate `base + lane`: the number of pairs that end at or before it (binary search)
+                const int it = base + (t & 63);
+                int pos = 0;
+#pragma unroll
+                for (int step = WAVE / 2; step >= 1; step >>= 1)
+                    if (L.scan[w][0][pos + step - 1] <= it) pos += step;
+                TX(myPair) = pos;
+                TX(myFirst) = pos > 0 ? L.scan[w][0][pos - 1] : 0;
             }
             FOR_WLANES(t, w) { // one candidate per lane
                 const int l = t & 63;

@@ -160,6 +160,36 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         fprintf(stderr, "emu stats: N=%lld pairs=%lld items=%lld dead=%lld live list=%lld vig=%lld col0=%lld\n", (long long)B.N, (long long)ca.pairs,
                 (long long)B.itemCap, (long long)dead, (long long)byTag[0], (long long)byTag[1], (long long)byTag[2]);
         fprintf(stderr, "emu stats: general-path evaluations: igenic-pred %lld, list exon %lld\n", g_emuSlowA, g_emuSlowB);
+        {   // how often does a trellis worker need a second chunk of 64 candidates?  (pair-aligned split over k workers)
+            long long hist[3][6] = {{0}};
+            for (int64_t gb = 0; gb < B.nBlk; gb++) {
+                const uint64_t i0 = B.blkOff[gb * 2 + 1];
+                const uint32_t nonRT = B.blkSplit[gb * 3 + 2];
+                if (B.blkCnt[gb * 2] == 0) continue;
+                std::vector<uint32_t> bnd; // inclusive prefix at pair boundaries
+                uint32_t run = 0;
+                for (uint32_t i = 0; i < nonRT; i++) {
+                    run++;
+                    if (i + 1 == nonRT || (B.items[i0 + i].kp >> KEY_BITS) != (B.items[i0 + i + 1].kp >> KEY_BITS)) bnd.push_back(i + 1);
+                }
+                (void)run;
+                for (int kw = 3; kw <= 5; kw++) {
+                    uint32_t prev = 0; int worst = 0;
+                    for (int q = 1; q <= kw; q++) {
+                        uint32_t target = (uint32_t)((uint64_t)nonRT * q / kw), best = nonRT, bd = 0xffffffffu;
+                        if (q == kw) best = nonRT;
+                        else for (uint32_t x : bnd) { uint32_t d = x > target ? x - target : target - x; if (d < bd) { bd = d; best = x; } }
+                        if (best < prev) best = prev;
+                        int chunks = (int)((best - prev + 63) / 64);
+                        if (chunks > worst) worst = chunks;
+                        prev = best;
+                    }
+                    hist[kw - 3][worst < 5 ? worst : 5]++;
+                }
+            }
+            for (int kw = 3; kw <= 5; kw++)
+                fprintf(stderr, "emu stats: %d workers: blocks by chunks of the busiest worker: 0:%lld 1:%lld 2:%lld 3:%lld 4:%lld 5+:%lld\n", kw, hist[kw - 3][0], hist[kw - 3][1], hist[kw - 3][2], hist[kw - 3][3], hist[kw - 3][4], hist[kw - 3][5]);
+        }
     }
     // ---- K2b, K3
     TrellisLds *lds = new TrellisLds();
