@@ -229,6 +229,7 @@ AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
     int win = T.gc_win;
     if (win > n || win < 1) win = n;
     if (s < 0 || s > n - win) return -1;
+    if (T.C == 1) { B.gcRaw[g] = 0; return 0; } // (a single class: nothing to decide)
     double cnt[4];
     for (int i = 0; i < 4; i++) cnt[i] = (double)(B.cnt[fidx(o + s + win, i, NCNT)] - B.cnt[fidx(o + s, i, NCNT)]);
     const int c = nearestClass(T, cnt);
@@ -307,24 +308,31 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     if (cn[CNT_ATG] != cp[CNT_ATG]) B.atgPos[lo + cn[CNT_ATG] - 1] = q;
     // emission of the equalD states ending at q (reference IntronModel::seqProb, src/intronmodel.cc:1087-1107)
     if (q - T.dStateLen >= 0) sg[SIG_EQD] = P.seg(FX_INF, q - T.dStateLen + 1, q);
-    // end gates
+    // end gates.  They depend on the state's kind group and (forward splice end) frame only: each is evaluated once
     uint64_t gate = 0;
-    if (q >= 1)
+    if (q >= 1) {
+        const bool stopOpen = sg[SIG_STOPF] > AUGX_NINF && q - 3 >= 0;              // single, terminal: right = q - 3
+        const bool tisOpen = sg[SIG_TISR] > AUGX_NINF && q - T.W - 3 >= 0;           // rsingle, rinitial: right = q - W - 3
+        bool fwdOpen[3];                                                             // initial, internal per frame
+        for (int w2 = 0; w2 < 3; w2++) fwdOpen[w2] = exEndPart(P, AUGX_K_INTERNAL, w2, q, AUGX_NINF) > AUGX_NINF;
+        const bool revOpen = exEndPart(P, AUGX_K_RINTERNAL, 0, q, AUGX_NINF) > AUGX_NINF; // rinternal, rterminal (no frame in the gate)
+        const bool lessOpen = lessDGate(P, true, q), rlessOpen = lessDGate(P, false, q);
         for (int s = 0; s < T.S; s++) {
             if (!T.reachable[s]) continue;
-            int kind = T.kind[s];
+            const int kind = T.kind[s], w2 = T.win[s];
             bool open = false;
-            if (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) {
-                ExGeom gm = exGeom(T, kind);
-                double endP = exEndPart(P, kind, T.win[s], q, sg[SIG_TISR]);
-                int right = q + gm.baseOffset - gm.ipeo;
-                open = endP > AUGX_NINF && right >= 0;
-            } else if (kind == AUGX_K_LESSD)
-                open = lessDGate(P, true, q);
-            else if (kind == AUGX_K_RLESSD)
-                open = lessDGate(P, false, q);
+            switch (kind) {
+            case AUGX_K_SINGLE: case AUGX_K_TERMINAL: open = stopOpen; break;
+            case AUGX_K_RSINGLE: case AUGX_K_RINITIAL: open = tisOpen; break;
+            case AUGX_K_INITIAL: case AUGX_K_INTERNAL: open = w2 == 0 ? fwdOpen[0] : w2 == 1 ? fwdOpen[1] : fwdOpen[2]; break;
+            case AUGX_K_RINTERNAL: case AUGX_K_RTERMINAL: open = revOpen; break;
+            case AUGX_K_LESSD: open = lessOpen; break;
+            case AUGX_K_RLESSD: open = rlessOpen; break;
+            default: break;
+            }
             if (open) gate |= 1ull << s;
         }
+    }
     B.gate[g] = gate;
 }
 
