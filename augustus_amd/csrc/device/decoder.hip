@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(256) kSiteTerms(const DevTables *T, BatchView 
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1SiteTerms(*T, B, g);
 }
-__global__ void __launch_bounds__(256) kWindowClass(const DevTables *T, BatchView B) {
+// (min, max) of the window classes of every 256 slots (no atomics: tens of thousands of wavefronts of one piece hammering the
+// same two words cost more than the rest of the kernel); kClassFinal folds them per piece
+__global__ void __launch_bounds__(256) kWindowClass(const DevTables *T, BatchView B, int32_t *blkMinMax) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int c = g < B.N ? k1WindowClass(*T, B, g) : -1;
     // all slots of a block belong to one piece (pieces are CHUNK-aligned, 256 | CHUNK): reduce in the wave first
@@ -51,20 +53,27 @@ __global__ void __launch_bounds__(256) kWindowClass(const DevTables *T, BatchVie
         mn = min(mn, __shfl_xor(mn, o, 64));
         mx = max(mx, __shfl_xor(mx, o, 64));
     }
-    if ((threadIdx.x & 63) == 0 && mx >= 0) {
-        int p = B.chunkPiece[((int64_t)blockIdx.x * 256) / CHUNK];
-        atomicMin(&B.clsMinMax[2 * p], mn);
-        atomicMax(&B.clsMinMax[2 * p + 1], mx);
+    __shared__ int w[4][2];
+    if ((threadIdx.x & 63) == 0) { w[threadIdx.x >> 6][0] = mn; w[threadIdx.x >> 6][1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blkMinMax[2 * (int64_t)blockIdx.x] = min(min(w[0][0], w[1][0]), min(w[2][0], w[3][0]));
+        blkMinMax[2 * (int64_t)blockIdx.x + 1] = max(max(w[0][1], w[1][1]), max(w[2][1], w[3][1]));
     }
 }
-__global__ void kClassInit(BatchView B) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < B.nPieces) { B.clsMinMax[2 * p] = 1 << 30; B.clsMinMax[2 * p + 1] = -1; }
-}
-__global__ void kClassFinal(BatchView B) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < B.nPieces) {
-        B.cls[p] = B.clsMinMax[2 * p] == B.clsMinMax[2 * p + 1] ? B.clsMinMax[2 * p] : -1;
+__global__ void __launch_bounds__(64) kClassFinal(BatchView B, const int32_t *blkMinMax) { // one wavefront per piece
+    const int p = blockIdx.x;
+    int mn = 1 << 30, mx = -1;
+    for (int64_t b = B.off[p] / 256 + threadIdx.x; b < B.off[p + 1] / 256; b += 64) {
+        mn = min(mn, blkMinMax[2 * b]);
+        mx = max(mx, blkMinMax[2 * b + 1]);
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 64));
+        mx = max(mx, __shfl_xor(mx, o, 64));
+    }
+    if (threadIdx.x == 0) {
+        B.cls[p] = mn == mx ? mn : -1;
         B.nPlanes[p] = 1;
         B.planeCls[p * MAXPL] = B.cls[p];
     }
@@ -167,6 +176,7 @@ struct augx_batch {
     BatchView V;               // device pointers
     BatchView *dV = nullptr;   // device copy of V (kernels with high register pressure take it by pointer)
     std::vector<void *> bufs;
+    int32_t *blkMinMax = nullptr; // [N/256][2] window-class range of every 256 slots
     int nPlAlloc = 0;          // planes the class-dependent arrays are allocated for (0: not yet)
     void *planeBufs[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
@@ -328,6 +338,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(dRaw, char, Z.N);
     V.off = dOff; V.len = dLen; V.initKind = dIk; V.termKind = dTk; V.chunkPiece = dCp; V.raw = dRaw;
     DA(V.cls, int32_t, n); DA(V.clsMinMax, int32_t, 2 * n);
+    DA(b->blkMinMax, int32_t, (Z.N / 256 + 1) * 2);
     DA(V.nPlanes, int32_t, n); DA(V.planeCls, int32_t, (int64_t)n * MAXPL);
     DA(V.gcRaw, uint8_t, Z.N); DA(V.gcPlane, uint8_t, Z.N);
     V.nPl = 1; V.listCap = Z.listCap;
@@ -386,9 +397,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     int rc;
     if ((rc = runScan<false>(b, V.cnt, NCNT))) return rc;
     if ((rc = runScan<true>(b, V.nsm, 6))) return rc;
-    hipLaunchKernelGGL(kClassInit, dim3((n + 63) / 64), dim3(64), 0, st, V);
-    hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V);
-    hipLaunchKernelGGL(kClassFinal, dim3((n + 63) / 64), dim3(64), 0, st, V);
+    hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V, b->blkMinMax);
+    hipLaunchKernelGGL(kClassFinal, dim3(n), dim3(64), 0, st, V, b->blkMinMax);
     HIP_TRY(hipGetLastError());
     {   // pieces whose 1-bp-shifted GC windows do not all agree: the smoothed content stairs are settled on the host from
         // the window classes (1 byte per base; reference ContentStairs::computeStairs, src/motif.cc:543-616), and the
