@@ -72,11 +72,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "AUGX_BENCH_DEVICE" in os.environ:  # (testing the multi-rank path on a box with fewer GPUs than ranks)
+        local = int(os.environ["AUGX_BENCH_DEVICE"])
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        backend = os.environ.get("AUGX_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")  # ("nccl" is RCCL)
+        dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the decode path has no CPU fallback)")
     torch.cuda.set_device(local)
@@ -143,7 +146,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     # sanity: the decode produced feasible paths

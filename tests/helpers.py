@@ -30,9 +30,19 @@ def config_path():
         d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d" % (os.getuid(), os.path.getsize(tar)))
         marker = os.path.join(d, "config", "model", "states_shadow.cfg")
         if not os.path.exists(marker):
-            os.makedirs(d, exist_ok=True)
-            with tarfile.open(os.path.join(GOLDEN, "config_min.tar.gz")) as t:
-                t.extractall(d)
+            # several processes may get here at once (one rank per GPU, pytest-xdist): extract privately, publish with one
+            # atomic rename; whoever loses the race uses the winner's copy
+            import shutil
+            tmp = tempfile.mkdtemp(prefix="augx_config_tmp_")
+            with tarfile.open(tar) as t:
+                t.extractall(tmp)
+            try:
+                os.rename(tmp, d)
+            except OSError:
+                if os.path.exists(marker):
+                    shutil.rmtree(tmp, ignore_errors=True)
+                else:
+                    d = tmp  # (a stale, incomplete directory is in the way: use the private copy)
         _cfg_dir = os.path.join(d, "config") + "/"
     return _cfg_dir
 
