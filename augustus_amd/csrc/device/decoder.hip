@@ -4,7 +4,8 @@
 // Launch shapes (MI355X: 256 CUs, wave64):
 //   prep kernels : one thread per slot, 256-thread blocks, grid = N/256  (HBM-streaming, fully coalesced rows)
 //   scans        : grid (chunks x fields), 256 threads x 4 slots, rows of CHUNK=1024 contiguous uint64
-//   trellis      : one workgroup of 4 wavefronts per piece (one per SIMD of a CU), ~130 KB LDS, position-sequential
+//   candidates   : one wavefront per tile of 64 bases, 8 tiles per workgroup, 2 workgroups per CU (76 KB LDS, 128 VGPRs)
+//   trellis      : one workgroup of 8 wavefronts per piece = one CU per piece (155 KB LDS), position-sequential
 //   backtrace    : one wavefront per piece
 // There is no CPU fallback anywhere in this file: without a HIP device augx_decoder_create fails.
 #include <hip/hip_runtime.h>
@@ -142,7 +143,7 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
     row[t * 4 + 3] = comb<MAX>(pre, v3);
 }
 
-// ---- candidates of the variable-length states: one workgroup per tile of 64 bases (count, reserve, emit) ----
+// ---- candidates of the variable-length states: one wavefront per tile of 64 bases (describe + count, reserve, evaluate) ----
 // (MULTI: some piece of the batch has more than one GC class -- the plane of every class-dependent array is then chosen per
 //  end base; batches without such a piece run the variant with the plane folded away)
 template <int BLK, bool MULTI> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {

@@ -1,7 +1,7 @@
 // kernels.h -- bodies of the decode kernels, written once for gfx950 (hipcc) and for the lane-loop emulator
 // (-DAUGX_EMU, tests only).  See DESIGN.md for the kernel decomposition:
 //   K1  prep   : encode, site/stop/base-count prefix scans, GC class, fixed-point content prefix sums, signals
-//   K2a candidates: transition * emission of every candidate of the variable-length states, parallel over blocks
+//   K2a candidates: transition * emission of every candidate of the variable-length states, one wavefront per tile of 64 bases
 //   K2b trellis: one workgroup per piece, position-sequential, V columns in an LDS ring
 //   K3  back   : back-pointer chase, one wavefront per piece
 //
