@@ -79,6 +79,10 @@ __global__ void __launch_bounds__(64) kClassFinal(BatchView B, const int32_t *bl
         B.planeCls[p * MAXPL] = B.cls[p];
     }
 }
+__global__ void kListCount(BatchView B) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B.nPieces) k1ListCount(B, p);
+}
 __global__ void __launch_bounds__(256) kFxTerms(const DevTables *T, BatchView B) { // grid.y = plane
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1FxTerms(*T, B, g, blockIdx.y);
@@ -171,6 +175,7 @@ struct augx_decoder {
     int blk = 8;              // block size of the candidate / trellis kernels for this model (layout.h: chooseBlockSize)
 };
 
+constexpr int NARR = 20; // arrays managed by ensureArrays
 struct augx_batch {
     augx_decoder *dec = nullptr;
     BatchLayout L;
@@ -179,7 +184,10 @@ struct augx_batch {
     std::vector<void *> bufs;
     int32_t *blkMinMax = nullptr; // [N/256][2] window-class range of every 256 slots
     int nPlAlloc = 0;          // planes the class-dependent arrays are allocated for (0: not yet)
-    void *planeBufs[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t listCapAlloc = 0;  // entries per plane the candidate-list arrays are allocated for
+    bool listsReady = false;   // the list offsets of this batch's pieces have been computed (its first decode)
+    int64_t *dListOffs = nullptr;
+    void *planeBufs[20] = {};  // (ensureArrays)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
     uint64_t nItems = 0, nPairs = 0;
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
@@ -196,33 +204,46 @@ template <class T> int devAlloc(augx_batch *b, T **ptr, int64_t count) {
     return 0;
 }
 
-// the class-dependent arrays of a batch ([nPl][...], see BatchView): allocated for one plane when the batch is created, and
-// again, larger, by the first decode that meets a piece with more GC classes
-int ensurePlanes(augx_batch *b, int nPl) {
-    if (nPl <= b->nPlAlloc) return 0;
+// Arrays whose size is only known at decode time: the class-dependent arrays ([nPl][...], see BatchView: one plane when the
+// batch is created, more when a piece turns out to have several GC classes) and the candidate-list arrays (sized from the
+// counted sites).  Re-allocated, larger, when a decode needs more planes or entries than the batch has.
+int ensureArrays(augx_batch *b, int nPl, int64_t listCap) {
+    if (nPl <= b->nPlAlloc && listCap <= b->listCapAlloc) return 0;
+    if (nPl < b->nPlAlloc) nPl = b->nPlAlloc;
+    if (listCap < b->listCapAlloc) listCap = b->listCapAlloc;
     BatchView &V = b->V;
-    BatchSizes Z(b->L);
-    struct Slot { void **field; size_t elem; int64_t count; };
-    const Slot slots[11] = {
-        {(void **)&V.fx, sizeof(uint64_t), Z.N * NFX},         {(void **)&V.plsR, sizeof(double), Z.N * 3},
-        {(void **)&V.ldEnt, sizeof(IntronStart), Z.listCap},   {(void **)&V.rdEnt, sizeof(IntronStart), Z.listCap},
-        {(void **)&V.laPls, sizeof(double), Z.listCap * 3},    {(void **)&V.laFx, sizeof(uint64_t), Z.listCap * 3},
-        {(void **)&V.lrEt, sizeof(double), Z.listCap * 3},     {(void **)&V.lrFx, sizeof(uint64_t), Z.listCap * 3},
-        {(void **)&V.atgD, sizeof(double), Z.listCap * 3},     {(void **)&V.atgFx, sizeof(uint64_t), Z.listCap},
-        {(void **)&V.rsFx, sizeof(uint64_t), Z.listCap * 3}};
-    for (int i = 0; i < 11; i++) {
+    const int64_t N = b->L.N, LC = listCap > 0 ? listCap : 1;
+    struct Slot { void **field; size_t elem; int64_t count; int planes; };
+    const Slot slots[NARR] = {
+        {(void **)&V.fx, sizeof(uint64_t), N * NFX, nPl},          {(void **)&V.plsR, sizeof(double), N * 3, nPl},
+        {(void **)&V.ldEnt, sizeof(IntronStart), LC, nPl},         {(void **)&V.rdEnt, sizeof(IntronStart), LC, nPl},
+        {(void **)&V.laPls, sizeof(double), LC * 3, nPl},          {(void **)&V.laFx, sizeof(uint64_t), LC * 3, nPl},
+        {(void **)&V.lrEt, sizeof(double), LC * 3, nPl},           {(void **)&V.lrFx, sizeof(uint64_t), LC * 3, nPl},
+        {(void **)&V.atgD, sizeof(double), LC * 3, nPl},           {(void **)&V.atgFx, sizeof(uint64_t), LC, nPl},
+        {(void **)&V.rsFx, sizeof(uint64_t), LC * 3, nPl},
+        {(void **)&V.laPos, sizeof(int32_t), LC, 1},               {(void **)&V.laVal, sizeof(double), LC * 3, 1},
+        {(void **)&V.lrPos, sizeof(int32_t), LC, 1},               {(void **)&V.lrVal, sizeof(double), LC * 3, 1},
+        {(void **)&V.ldVal, sizeof(double), LC * 3, 1},            {(void **)&V.rdVal, sizeof(double), LC * 3, 1},
+        {(void **)&V.atgPos, sizeof(int32_t), LC, 1},              {(void **)&V.rsPos, sizeof(int32_t), LC, 1},
+        {(void **)&V.rsBegin, sizeof(double), LC, 1}};
+    for (int i = 0; i < NARR; i++) {
+        const bool isN = i < 2; // (fx, plsR: sized by the slots, they only grow with the planes)
+        if (isN && nPl == b->nPlAlloc && b->planeBufs[i]) continue;
         if (b->planeBufs[i]) { HIP_TRY(hipFree(b->planeBufs[i])); b->planeBufs[i] = nullptr; *slots[i].field = nullptr; }
         void *p = nullptr;
-        if (hipMalloc(&p, (size_t)nPl * (size_t)slots[i].count * slots[i].elem) != hipSuccess) {
+        if (hipMalloc(&p, (size_t)slots[i].planes * (size_t)slots[i].count * slots[i].elem) != hipSuccess) {
             (void)hipGetLastError();
-            b->nPlAlloc = 0;
-            setLastError("augx: out of device memory for the per-GC-class arrays (" + std::to_string(nPl) + " classes in one piece); decode fewer bases per batch");
+            b->nPlAlloc = 0; b->listCapAlloc = 0;
+            for (int k = 0; k < NARR; k++)
+                if (b->planeBufs[k]) { (void)hipFree(b->planeBufs[k]); b->planeBufs[k] = nullptr; }
+            setLastError("augx: out of device memory for the candidate-list / per-GC-class arrays (" + std::to_string(nPl) + " classes in one piece); decode fewer bases per batch");
             return AUGX_E_NOMEM;
         }
         b->planeBufs[i] = p;
         *slots[i].field = p;
     }
     b->nPlAlloc = nPl;
+    b->listCapAlloc = listCap;
     return 0;
 }
 
@@ -285,9 +306,10 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     if (!d) return 0;
     size_t freeB = 0, totalB = 0;
     if (hipSetDevice(d->device) != hipSuccess || hipMemGetInfo(&freeB, &totalB) != hipSuccess) return 16L * 1000 * 1000;
-    // ~1.1 KB of per-base arrays + ~0.3 KB of candidates, with head room; a model with several GC classes may need the
-    // class-dependent arrays (~0.28 KB per base) once more per extra class met inside one piece: room for two extra
-    int64_t cap = (int64_t)(freeB / (d->model->m.t.n_classes > 1 ? 2300 : 1700));
+    // ~0.6 KB of per-base arrays + ~0.3 KB of candidates + the candidate lists (sized from the counted sites: ~20 B per base,
+    // up to 150 B on site-dense sequence), with head room; a model with several GC classes may need the class-dependent
+    // arrays (~0.2 KB per base) once more per extra class met inside one piece: room for two extra
+    int64_t cap = (int64_t)(freeB / (d->model->m.t.n_classes > 1 ? 2000 : 1500));
     if (cap > 128L * 1000 * 1000) cap = 128L * 1000 * 1000;
     if (cap < 1000 * 1000) cap = 1000 * 1000;
     return cap;
@@ -342,7 +364,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(b->blkMinMax, int32_t, (Z.N / 256 + 1) * 2);
     DA(V.nPlanes, int32_t, n); DA(V.planeCls, int32_t, (int64_t)n * MAXPL);
     DA(V.gcRaw, uint8_t, Z.N); DA(V.gcPlane, uint8_t, Z.N);
-    V.nPl = 1; V.listCap = Z.listCap;
+    V.nPl = 1; V.listCap = 0; // (the list arrays are sized by the first decode, from the counted sites)
     DA(V.code, uint8_t, Z.N);
     DA(V.cnt, uint64_t, Z.N * NCNT);
     DA(V.nsm, uint64_t, Z.N * 6);
@@ -355,13 +377,9 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); HIP_TRY(hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8)); }
     DA(V.vig, double, Z.N);
     DA(V.longV, double, Z.N * 6);
-    DA(V.laPos, int32_t, Z.listCap); DA(V.laVal, double, Z.listCap * 3);
-    DA(V.lrPos, int32_t, Z.listCap); DA(V.lrVal, double, Z.listCap * 3);
-    DA(V.ldVal, double, Z.listCap * 3);
-    DA(V.rdVal, double, Z.listCap * 3);
-    DA(V.atgPos, int32_t, Z.listCap);
-    DA(V.rsPos, int32_t, Z.listCap); DA(V.rsBegin, double, Z.listCap);
-    if ((rc = ensurePlanes(b, 1))) { augx_batch_destroy(b); return rc; }
+    DA(V.listCnt, int32_t, n); DA(b->dListOffs, int64_t, n + 1);
+    V.listOffs = b->dListOffs;
+    if ((rc = ensureArrays(b, 1, 0))) { augx_batch_destroy(b); return rc; }
     V.blk = d->blk;
     V.nBlk = Z.N / V.blk;
     DA(V.blkCnt, uint32_t, V.nBlk * 2); DA(V.blkSplit, uint32_t, V.nBlk * 3); DA(V.blkOff, uint64_t, V.nBlk * 2);
@@ -398,6 +416,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     int rc;
     if ((rc = runScan<false>(b, V.cnt, NCNT))) return rc;
     if ((rc = runScan<true>(b, V.nsm, 6))) return rc;
+    if (!b->listsReady) hipLaunchKernelGGL(kListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
     hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V, b->blkMinMax);
     hipLaunchKernelGGL(kClassFinal, dim3(n), dim3(64), 0, st, V, b->blkMinMax);
     HIP_TRY(hipGetLastError());
@@ -431,8 +450,19 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             HIP_TRY(hipMemcpy(V.nPlanes, nPlanes.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(V.planeCls, planeCls.data(), sizeof(int32_t) * n * MAXPL, hipMemcpyHostToDevice));
         }
-        if ((rc = ensurePlanes(b, nPl))) return rc;
-        if (W.nPl != nPl) { // (the planes of a batch are a property of its sequences: this happens in its first decode only)
+        bool changed = W.nPl != nPl;
+        if (!b->listsReady) { // candidate lists: first entry of every piece from the counted sites
+            std::vector<int32_t> lc(n);
+            std::vector<int64_t> offs;
+            HIP_TRY(hipMemcpy(lc.data(), V.listCnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            W.listCap = listOffsets(lc.data(), n, offs);
+            HIP_TRY(hipMemcpy(b->dListOffs, offs.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
+            b->listsReady = true;
+            changed = true;
+        }
+        const void *fxBefore = W.fx;
+        if ((rc = ensureArrays(b, nPl, W.listCap))) return rc;
+        if (changed || fxBefore != W.fx) { // (planes and list sizes are properties of the batch's sequences: its first decode only)
             W.nPl = nPl;
             HIP_TRY(hipMemcpy(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice));
         }
@@ -441,15 +471,21 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     for (int pl = 0; pl < V.nPl; pl++)
         if ((rc = runScan<false>(b, V.fx + (int64_t)pl * V.N * NFX, NFX))) return rc;
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
-    hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.N / 2 + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
+    hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.listCap + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn
         // out too small (first decode of a batch, unusual sequence), it reports the size needed and is run again.
         BatchView &W = b->V;
         const unsigned nWg = (unsigned)(W.N / (WAVE * NWAVES)); // one wavefront per tile of 64 bases, NWAVES tiles per workgroup
+        if (b->itemBuf && b->nItems > 0 && (uint64_t)W.itemCap > b->nItems + b->nItems / 16 + 65536) {
+            // a batch decoded again: its candidate count is known, give back what the first estimate took too much
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipFree(b->itemBuf));
+            b->itemBuf = nullptr;
+        }
         if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
-            W.itemCap = W.N * 18 + 65536;
+            W.itemCap = b->nItems > 0 ? (int64_t)(b->nItems + b->nItems / 16 + 65536) : W.N * 18 + 65536;
             if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
                 (void)hipGetLastError();
                 b->itemBuf = nullptr;

@@ -91,6 +91,9 @@ struct BatchView {
     // once per plane ([nPl][...], plane-major), and the end base of a state selects the plane.
     int nPl;                   // planes allocated in this batch (1: no multi-class piece)
     int64_t listCap;           // entries per plane of the candidate-side list arrays
+    const int64_t *listOffs;   // [nPieces+1] first entry of each piece in the list arrays: the lists are sized from the counted
+                               // sites (the longest of the piece's six lists, padded), not from the worst case of one per two bases
+    int32_t *listCnt;          // [nPieces] entries of the longest list of the piece (K1 -> host)
     uint8_t *gcRaw;            // [N] class of the GC window STARTING at this base (unsmoothed; input of the stairs)
     uint8_t *gcPlane;          // [N] plane of the base
     int32_t *nPlanes;          // [nPieces]
@@ -142,7 +145,7 @@ AUGX_HD int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
 // scan-field arrays (cnt, nsm, fx) are stored chunk-major, field-major inside a chunk: [chunk][field][CHUNK],
 // so that the prefix scans stream contiguous rows.  g = global slot, f = field, nf = fields per slot.
 AUGX_HD int64_t fidx(int64_t g, int f, int nf) { return ((g / CHUNK) * nf + f) * CHUNK + (g % CHUNK); }
-AUGX_HD int64_t listOff(const BatchView &B, int p) { return B.off[p] / 2; }
+AUGX_HD int64_t listOff(const BatchView &B, int p) { return B.listOffs[p]; }
 AUGX_HD int64_t pathOff(const BatchView &B, int p) { return B.off[p] / 8 + 64 * (int64_t)p; }
 AUGX_HD int64_t pathCap(const BatchView &B, int p) { return (B.off[p + 1] - B.off[p]) / 8 + 64; }
 

@@ -193,6 +193,14 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
     for (int i = 0; i < 6; i++) B.nsm[fidx(g, i, 6)] = ns[i];
 }
 
+// entries of the longest candidate list of piece p (site counts at its last base): sizes the list arrays
+AUGX_HD void k1ListCount(const BatchView &B, int p) {
+    const int64_t g = B.off[p] + B.len[p];
+    uint64_t m = 0;
+    for (int f = CNT_ATG; f <= CNT_RS; f++) { const uint64_t c = B.cnt[fidx(g, f, NCNT)]; m = c > m ? c : m; }
+    B.listCnt[p] = (int32_t)m;
+}
+
 // GC class of the window starting at base s (one thread per slot; reference ContentStairs::computeStairs,
 // src/motif.cc:543-616; the set of window classes decides whether the piece is single-class)
 AUGX_HD int nearestClass(const DevTables &T, const double cnt[4]) {
@@ -340,8 +348,12 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
 // donor, 2 forward donor, 3 reverse acceptor); reference IntronModel::aSSProb / dSSProb via emiProbUnderModel,
 // src/intronmodel.cc:690-717,861-923.  Runs after k1Signals (which has reset the records and filled the positions).
 AUGX_HD void k1SiteSignals(const DevTables &T, const BatchView &B, int64_t t, int sel) {
-    if (t >= B.N / 2) return;
-    const int p = B.chunkPiece[(2 * t) / CHUNK];
+    if (t >= B.listCap) return;
+    int p = 0; // the piece that owns entry t: the last one whose first entry is <= t
+    for (int lo2 = 0, hi2 = B.nPieces - 1; lo2 <= hi2;) {
+        const int mid = (lo2 + hi2) / 2;
+        if (B.listOffs[mid] <= t) { p = mid; lo2 = mid + 1; } else hi2 = mid - 1;
+    }
     if (B.cls[p] < 0) return;
     const int64_t o = B.off[p], lo = listOff(B, p), li = t - lo;
     const int n = B.len[p];

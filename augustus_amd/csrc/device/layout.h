@@ -85,12 +85,18 @@ inline int stairsPlanes(const uint8_t *wc, int n, int win, std::vector<uint8_t> 
     return nPl;
 }
 
+// first list entry of every piece from the counted sites (k1ListCount); returns the total = entries per plane
+inline int64_t listOffsets(const int32_t *listCnt, int nPieces, std::vector<int64_t> &offs) {
+    offs.assign((size_t)nPieces + 1, 0);
+    for (int p = 0; p < nPieces; p++) offs[p + 1] = offs[p] + (((int64_t)listCnt[p] + 1 + 63) / 64) * 64; // (+1: index i1 may point one past)
+    return offs[nPieces] + 64;
+}
+
 // element counts of every device buffer of a batch (bytes = count * sizeof(element))
 struct BatchSizes {
-    int64_t N, nChunks, nPieces, listCap, pathCap;
+    int64_t N, nChunks, nPieces, pathCap;
     explicit BatchSizes(const BatchLayout &L) {
         N = L.N; nChunks = L.nChunks; nPieces = L.nPieces;
-        listCap = N / 2 + 64;
         pathCap = N / 8 + 64 * (int64_t)L.nPieces + 64;
     }
 };

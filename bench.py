@@ -99,7 +99,8 @@ def main():
         d = ax.Decoder(model, local)
         try:  # H2D upload: inputs are resident in HBM before the timed region
             b = ax.Batch(d, synth_contigs(a.contigs, a.contig_len, 12345 + 1000 * rank + 17 * i))
-            b.decode(sync=True)          # (first decode of a batch object sizes its candidate buffer: untimed)
+            b.decode(sync=True)          # (first decode of a batch object sizes its candidate lists and buffer: untimed;
+            b.decode(sync=True)          #  the second one gives back what the first estimate took too much)
         except ax.AugxError as e:
             if i == 0 or e.code not in (ax.AUGX_E_NOMEM, ax.AUGX_E_HIP):
                 raise

@@ -70,16 +70,13 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.cells = cells_out ? zalloc<double>(Z.N * t->S) : nullptr;
     B.vig = zalloc<double>(Z.N);
     B.longV = zalloc<double>(Z.N * 6);
-    B.laPos = zalloc<int32_t>(Z.listCap); B.laVal = zalloc<double>(Z.listCap * 3);
-    B.lrPos = zalloc<int32_t>(Z.listCap); B.lrVal = zalloc<double>(Z.listCap * 3);
-    B.ldVal = zalloc<double>(Z.listCap * 3);
-    B.rdVal = zalloc<double>(Z.listCap * 3);
-    B.atgPos = zalloc<int32_t>(Z.listCap);
-    B.rsPos = zalloc<int32_t>(Z.listCap); B.rsBegin = zalloc<double>(Z.listCap);
     B.gcRaw = zalloc<uint8_t>(Z.N); B.gcPlane = zalloc<uint8_t>(Z.N);
     std::vector<int32_t> nPlanes(n, 1), planeCls((size_t)n * MAXPL, 0);
     B.nPlanes = nPlanes.data(); B.planeCls = planeCls.data();
-    B.listCap = Z.listCap; B.nPl = 1;
+    B.nPl = 1;
+    std::vector<int32_t> listCnt(n);
+    std::vector<int64_t> listOffs;
+    B.listCnt = listCnt.data();
     std::vector<double> lnvv(n);
     std::vector<int32_t> st(n), fin(n), pc(n);
     B.lnv = lnvv.data(); B.status = st.data(); B.finalState = fin.data(); B.pathCount = pc.data();
@@ -112,22 +109,32 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             if (np > B.nPl) B.nPl = np;
         }
     }
+    // candidate lists: sized from the counted sites (as augx_batch_decode does)
+    for (int p = 0; p < n; p++) k1ListCount(B, p);
+    const int64_t listCap = listOffsets(listCnt.data(), n, listOffs);
+    B.listOffs = listOffs.data(); B.listCap = listCap;
+    B.laPos = zalloc<int32_t>(listCap); B.laVal = zalloc<double>(listCap * 3);
+    B.lrPos = zalloc<int32_t>(listCap); B.lrVal = zalloc<double>(listCap * 3);
+    B.ldVal = zalloc<double>(listCap * 3);
+    B.rdVal = zalloc<double>(listCap * 3);
+    B.atgPos = zalloc<int32_t>(listCap);
+    B.rsPos = zalloc<int32_t>(listCap); B.rsBegin = zalloc<double>(listCap);
     // class-dependent arrays: one plane per class of the most varied piece
     const int64_t nPl = B.nPl;
     B.fx = zalloc<uint64_t>(nPl * Z.N * NFX);
     B.plsR = zalloc<double>(nPl * Z.N * 3);
-    B.ldEnt = zalloc<IntronStart>(nPl * Z.listCap); B.rdEnt = zalloc<IntronStart>(nPl * Z.listCap);
-    B.laPls = zalloc<double>(nPl * Z.listCap * 3); B.laFx = zalloc<uint64_t>(nPl * Z.listCap * 3);
-    B.lrEt = zalloc<double>(nPl * Z.listCap * 3); B.lrFx = zalloc<uint64_t>(nPl * Z.listCap * 3);
-    B.atgD = zalloc<double>(nPl * Z.listCap * 3); B.atgFx = zalloc<uint64_t>(nPl * Z.listCap);
-    B.rsFx = zalloc<uint64_t>(nPl * Z.listCap * 3);
+    B.ldEnt = zalloc<IntronStart>(nPl * listCap); B.rdEnt = zalloc<IntronStart>(nPl * listCap);
+    B.laPls = zalloc<double>(nPl * listCap * 3); B.laFx = zalloc<uint64_t>(nPl * listCap * 3);
+    B.lrEt = zalloc<double>(nPl * listCap * 3); B.lrFx = zalloc<uint64_t>(nPl * listCap * 3);
+    B.atgD = zalloc<double>(nPl * listCap * 3); B.atgFx = zalloc<uint64_t>(nPl * listCap);
+    B.rsFx = zalloc<uint64_t>(nPl * listCap * 3);
     for (int pl = 0; pl < nPl; pl++) {
         for (int64_t g = 0; g < B.N; g++) k1FxTerms(T, B, g, pl);
         scanFields<false>(B.fx + (int64_t)pl * Z.N * NFX, NFX, L);
     }
     for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
     for (int sel = 0; sel < 4; sel++)
-        for (int64_t t2 = 0; t2 < B.N / 2; t2++) k1SiteSignals(T, B, t2, sel);
+        for (int64_t t2 = 0; t2 < B.listCap; t2++) k1SiteSignals(T, B, t2, sel);
     for (int pl = 0; pl < B.nPl; pl++)
         for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g, pl);
     // ---- K2a: candidates, tile by tile (first with buffers that are too small, to exercise the re-run path)
