@@ -25,10 +25,15 @@ oracle: oracle/libghmm_twin.so
 oracle/libghmm_twin.so: oracle/ghmm_twin.cc include/augx.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/ghmm_twin.cc
 
-emu: build/libaugx_emu.so
+emu: build/libaugx_emu.so build/libaugx_emu_pl1.so
 build/libaugx_emu.so: tests/emu/emu.cc $(DEVHDR) include/augx.h
 	@mkdir -p build
 	$(CXX) $(CXXFLAGS) -shared -o $@ tests/emu/emu.cc
+# the same emulator with one plane of transition terms in (emulated) LDS: pieces with two GC classes then take the path
+# that pieces with more than eight take in the product
+build/libaugx_emu_pl1.so: tests/emu/emu.cc $(DEVHDR) include/augx.h
+	@mkdir -p build
+	$(CXX) $(CXXFLAGS) -DAUGX_MAXPL_LDS=1 -shared -o $@ tests/emu/emu.cc
 
 ref:
 	$(MAKE) -C oracle -j8

@@ -439,7 +439,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             wc.resize((size_t)len);
             HIP_TRY(hipMemcpy(wc.data(), V.gcRaw + b->L.off[p] + 1, (size_t)len, hipMemcpyDeviceToHost));
             const int np = stairsPlanes(wc.data(), len, d->model->m.t.gc_win, plane, &planeCls[(size_t)p * MAXPL]);
-            if (np < 0) continue; // more than MAXPL classes: the piece reports AUGX_E_UNSUPPORTED
+            if (np < 0) continue; // (cannot happen: MAXPL is the largest class count a model may have)
             cls[p] = planeCls[(size_t)p * MAXPL];
             nPlanes[p] = np;
             if (np > nPl) nPl = np;

@@ -49,7 +49,11 @@ constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >
 constexpr uint32_t SRC_LIST = 0, SRC_VIG = 1, SRC_COL0 = 2; // tags; LIST payload: [27:26] list, [25:24] frame, [23:0] entry
 // bases per trellis block (template parameter BLK of the candidate and trellis kernels): smaller than every lag of the
 // model except the lag-1 chain states.  8 where the species' windows allow it, else 4 or 2 (layout.h: chooseBlockSize)
-constexpr int MAXPL = 8;                     // GC-content classes decoded inside one piece
+constexpr int MAXPL = AUGX_MAX_CLASSES;      // GC-content classes inside one piece: as many as a model may have
+#ifndef AUGX_MAXPL_LDS
+#define AUGX_MAXPL_LDS 8                      /* (tests build the emulator with 1 to exercise the other path) */
+#endif
+constexpr int MAXPL_LDS = AUGX_MAXPL_LDS;    // planes whose transition terms the candidate kernel keeps in LDS (the others: L2)
 constexpr int MAXNB = 32;                    // blocks per tile of 64 bases at the smallest block size (2)
 
 struct CandAlloc;
@@ -83,7 +87,7 @@ struct BatchView {
     const int32_t *len;        // [nPieces]
     const int32_t *initKind, *termKind;
     const int32_t *chunkPiece; // [nChunks]
-    int32_t *cls;              // [nPieces] GC class of plane 0 of the piece (-1: more than MAXPL classes, not decoded)
+    int32_t *cls;              // [nPieces] GC class of plane 0 of the piece (-1: only while the content stairs are being settled)
     int32_t *clsMinMax;        // [nPieces][2]
     // GC-content classes inside a piece (reference NAMGene::viterbiAndForward switches all class-dependent tables at every
     // step of the content stairs, src/namgene.cc:245-248: a state ENDING at base j is scored with the tables of class(j)).

@@ -499,7 +499,7 @@ AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 // per-state constants of the variable-length states
 struct VarConst {
     int kind, win, nanc, anc[4], ancWin[4];
-    double tr[MAXPL][4];   // ln transition probability from each ancestor, per plane of the piece
+    double tr[MAXPL_LDS][4]; // ln transition probability from each ancestor, per plane of the piece (the first MAXPL_LDS planes)
     ExGeom g;
 };
 
@@ -524,7 +524,7 @@ AUGX_HD void fillVarConst(const DevTables &T, const BatchView &B, int p, int l, 
         int a = ai < VC.nanc ? T.anc[l][ai] : 0;
         VC.anc[ai] = a; VC.ancWin[ai] = T.win[a];
         VC.tr[0][ai] = AUGX_NINF;
-        for (int pl = 0; pl < nPl; pl++) VC.tr[pl][ai] = ai < VC.nanc ? lnT(T, B.planeCls[p * MAXPL + pl], a, l) : AUGX_NINF; // (planes >= nPl are never read)
+        for (int pl = 0; pl < nPl && pl < MAXPL_LDS; pl++) VC.tr[pl][ai] = ai < VC.nanc ? lnT(T, B.planeCls[p * MAXPL + pl], a, l) : AUGX_NINF; // (planes >= nPl are never read)
     }
     VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
 }
@@ -699,7 +699,8 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     const int n = X.n, kind = VC.kind, win = VC.win, pl = MULTI ? D.pl : 0;
     const Piece P = X.pieceAt(pl); // (class-dependent reads of the general paths go through the plane of the end base)
     const ExGeom &Dg = VC.g;
-    const double *trPl = VC.tr[pl];
+    // (a piece rarely has more than MAXPL_LDS classes: those planes read the model's transition table)
+    auto trOf = [&](int ai) -> double { return pl < MAXPL_LDS ? VC.tr[pl][ai] : lnT(T, B.planeCls[X.p * MAXPL + pl], VC.anc[ai], s); };
     te = AUGX_NINF; key = 0; src = srcCol0(0, 0);
     if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
         // written without early exits so that the loads of one candidate are all in flight together: the list entry
@@ -747,7 +748,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         const double restSeq = listed ? (double)(int64_t)(D.eFx - cFx) * AUGX_FX_INV : P.seg(fwd ? FX_INF : FX_INR, begin, j);
         const double emi = lenI + restSeq;
         if (siteOk && !veto && lenOk && emi > AUGX_NINF) {
-            te = trPl[0] + emi;
+            te = trOf(0) + emi;
             key = eop + KEY_BIAS; src = sr;
         }
         return;
@@ -812,7 +813,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
 #endif
         if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, Dg, tisF);
         if (!(nep > AUGX_NINF)) return;
-        te = (trPl[0] + D.endP) + nep;
+        te = (trOf(0) + D.endP) + nep;
         key = eop + KEY_BIAS;
         src = eop <= 0 ? srcCol0(0, a) : srcVig(0, eop);
         return;
@@ -870,7 +871,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     // exactly one of the (up to three) ancestors has the reading frame that fits the exon length
     for (int ai = 0; ai < VC.nanc; ai++) {
         if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
-        te = (trPl[ai] + D.endP) + nep;
+        te = (trOf(ai) + D.endP) + nep;
         key = bs - Dg.bpl - 1 + KEY_BIAS;
         src = li >= 0 ? srcList(ai, D.listSel, VC.ancWin[ai], li) : srcCol0(ai, VC.anc[ai]);
         break;

@@ -368,7 +368,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             const Decoded &d = decoded[pi];
             if (d.status != 0) {
                 errmsg = d.status == AUGX_E_UNSUPPORTED
-                             ? "piece with more than 8 GC-content classes is not supported on the MI355X path"
+                             ? "piece outside what the MI355X path decodes"
                              : "No feasible path found in HMM";
                 continue;
             }

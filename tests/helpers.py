@@ -167,10 +167,12 @@ class _Piece(ctypes.Structure):
 _emu = None
 
 
-def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0):
+def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None):
     """Run the device kernel bodies on the CPU (tests/emu/emu.cc).  Returns [(status, lnv, path, V, cls)]."""
     global _emu
-    if _emu is None:
+    if lib is not None:
+        _emu_lib = ctypes.CDLL(lib)
+    elif _emu is None:
         _emu = ctypes.CDLL(EMU_LIB)
     n = len(seqs)
     P = (_Piece * n)()
@@ -185,7 +187,7 @@ def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0):
     cls = np.zeros(n, dtype=np.int32)
     tot = sum(len(s) for s in seqs)
     C = np.zeros(tot * S) if cells else None
-    rc = _emu.emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
+    rc = (_emu_lib if lib is not None else _emu).emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
                          po.ctypes.data_as(ctypes.c_void_p), cap, pn.ctypes.data_as(ctypes.c_void_p),
                          C.ctypes.data_as(ctypes.c_void_p) if cells else None, cls.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0

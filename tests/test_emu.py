@@ -108,3 +108,17 @@ def test_emulated_content_stairs_smoothing():
         assert path == [(b, e, s) for b, e, s, t in path2]
     assert n_steps[0] >= 3 and n_steps[1] == 2 and n_steps[2] >= 1, n_steps
 
+
+def test_emulated_planes_beyond_lds_table():
+    """a piece may have more GC classes than the candidate kernel keeps transition terms for in LDS (8): the others are read
+    from the model's table.  The emulator built with room for ONE plane takes that path on the two- and three-class records."""
+    for cfg in ("human_nosm", "saccharomyces"):
+        species, opts = GOLDEN_CFGS[cfg]
+        m = ax.Model(config_path(), species, **opts)
+        recs = [(n, s) for n, s in golden_inputs() if n.startswith("multigc")]
+        res = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, cells=True, lib=os.path.join(ROOT, "build", "libaugx_emu_pl1.so"))
+        for (name, seq), (st, lnv, path, V, cls) in zip(recs, res):
+            rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+            assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
+            assert path == [(b, e, s) for b, e, s, t in path2], name
+
