@@ -105,7 +105,12 @@ def test_cli_piece_cutting_matches_reference(tmp_path):
     if not os.path.exists(REF_AUGUSTUS):
         pytest.skip("oracle/_ref not present")
     fa = str(tmp_path / "long.fa")
-    write_fasta(fa, [("long1", random_dna(260000, 555)), ("tail", random_dna(30000, 556))])
+    ex = dict(golden_inputs())["HS04636"]
+    # two records with cut chains of different length (the exam windows of all unfinished records are decoded together),
+    # one of them with genes at and between its cut regions, and a record that needs no cut
+    write_fasta(fa, [("long1", random_dna(260000, 555)),
+                     ("long2", random_dna(50000, 557) + ex + random_dna(45000, 558) + ex + random_dna(30000, 559)),
+                     ("tail", random_dna(30000, 556))])
     env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
     args = ["--species=human", "--maxDNAPieceSize=60000", fa]
     ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
