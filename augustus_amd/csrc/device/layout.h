@@ -105,7 +105,9 @@ inline void checkModelSupported(const augx_tables &t, int BLK) {
     if (t.S > SP) throw std::runtime_error("augx: model has more than 48 states (UTR/nc models are not on the device path yet)");
     int dL = t.d - 2 - t.De - t.As - 2 - t.U;
     if (dL >= LONG_RING || dL <= BLK || (dL > WAVE - BLK && dL < WAVE)) throw std::runtime_error("augx: intron d out of the supported range");
-    if (t.Ds + 2 + t.De <= BLK || t.As + 2 + t.Ae + t.U <= BLK) throw std::runtime_error("augx: splice-site windows shorter than a trellis block");
+    // (a near fixed-lag state of block b is computed when the candidates of block b-1 are done: its lag must reach back past
+    //  the block, lag >= BLK)
+    if (t.Ds + 2 + t.De < BLK || t.As + 2 + t.Ae + t.U < BLK) throw std::runtime_error("augx: splice-site windows shorter than a trellis block");
     if (t.As + 2 + t.Ae + t.U > 63 || t.Ds + 2 + t.De > 63) throw std::runtime_error("augx: splice-site windows too long");
     if (t.max_exon_len + t.W + 64 > 0x3FFF) throw std::runtime_error("augx: maxexonlength too large for 14-bit back pointers");
     if (t.d > 0x3FFF) throw std::runtime_error("augx: intron d too large");

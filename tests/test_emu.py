@@ -122,3 +122,18 @@ def test_emulated_planes_beyond_lds_table():
             assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
             assert path == [(b, e, s) for b, e, s, t in path2], name
 
+
+@pytest.mark.parametrize("blk", ["4", "2"])
+def test_emulated_small_block_sizes(monkeypatch, blk):
+    """the candidate / trellis kernels are templates over the block size (8, 4 or 2 bases per step of the wavefront pipeline,
+    layout.h: chooseBlockSize); the smaller instantiations, forced here, must give the same cells"""
+    monkeypatch.setenv("AUGX_BLK", blk)
+    m = ax.Model(config_path(), "human")
+    S = m.n_states
+    recs = [(n, s) for n, s in golden_inputs() if n in ("HS04636", "withN", "short100", "softmask_gene", "multigc_gene", "trunc_both")]
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], S, cells=True)
+    for (name, seq), (st, lnv, path, V, cls) in zip(recs, res):
+        rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, S, cells=True)
+        assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
+        assert path == [(b, e, s) for b, e, s, t in path2], name
+

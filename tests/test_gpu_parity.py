@@ -215,3 +215,22 @@ def test_gpu_randomised_pieces(cfg):
             multi += len(set(gc.tolist())) > 1
             assert (r.status == 0 and rc == 0 and r.ln_viterbi == lnv and r.states == path) or (r.status == ax.AUGX_E_NOPATH and rc != 0), len(s)
     assert multi > 0 or cfg in ("fly", "arabidopsis")  # (one GC class)
+
+
+@pytest.mark.parametrize("blk", ["4", "2"])
+def test_gpu_small_block_sizes(monkeypatch, blk):
+    """block sizes 4 and 2 of the candidate / trellis kernels (species with short signal windows), forced on the human model:
+    cells, score and path bit-identical to the oracle"""
+    monkeypatch.setenv("AUGX_BLK", blk)
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    m = ax.Model(config_path(), "human")
+    d = ax.Decoder(m, 0)
+    recs = [(n, s) for n, s in golden_inputs() if n in ("HS04636", "withN", "rand60k", "softmask_gene", "multigc_gene", "multigc_two", "trunc_both")]
+    seqs = [s for _, s in recs] + [random_dna(50000, 77)]
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (s, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, i
+        assert np.array_equal(b.cells(i), V), i
+
