@@ -1126,10 +1126,11 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // list values) to HBM.  See trellisPiece for the schedule and DESIGN.md section 5 for the reasoning.
 // =================================================================================================
 constexpr int NWORK = 3, W_C = 3, W_X = 4, W_LOAD = 5; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4 far fixed-lag states, 5.. loaders
-constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM)
+constexpr int ITEM_CAP = 1664;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
 
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
+    uint32_t kmax[WAVE][SP];        // variable-length states: (tie-break key << 2 | ancestor index) of the best candidate so far
     uint16_t bp[2][WAVE][SP];       // back pointers of the current / previous tile
     double sig[2][WAVE][NSIG];      // signal records of the current / next tile
     int32_t site[2][WAVE][NSITE];
@@ -1160,50 +1161,10 @@ __device__ inline double ldCoherent(const double *p) {
 }
 #endif
 
-// cross-lane primitives of the trellis wavefront
 #ifdef AUGX_EMU
-// inclusive segmented arg-max scan: lanes with equal kp >> KEY_BITS form a segment (segments are contiguous).  Inside a
-// segment (= the candidates of one (base, state) pair, newest first) the keys strictly decrease from lane to lane, so
-// "larger key wins a tie" is "the lane on the left wins a tie": the keys need not be compared.
-inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int w) {
-    for (int l = w * WAVE + 1; l < w * WAVE + WAVE; l++)
-        if ((kp[l - 1] >> KEY_BITS) == (kp[l] >> KEY_BITS) && val[l - 1] >= val[l]) {
-            val[l] = val[l - 1]; kp[l] = kp[l - 1]; src[l] = src[l - 1];
-        }
-}
-inline void waveDown1(const uint32_t *in, uint32_t *out, int w, uint32_t fill) {
-    for (int l = w * WAVE; l < w * WAVE + WAVE; l++) out[l] = l + 1 < w * WAVE + WAVE ? in[l + 1] : fill;
-}
-inline double waveReadD(const double *v, int w, int lane) { return v[w * WAVE + lane]; }
-inline uint32_t waveReadU(const uint32_t *v, int w, int lane) { return v[w * WAVE + lane]; }
+inline bool waveAnyTrue(const int *flag, int w) { for (int l = w * WAVE; l < w * WAVE + WAVE; l++) if (flag[l]) return true; return false; }
 #else
-__device__ inline void waveSegScan(double *val, uint32_t *kp, uint32_t *src, int) {
-    double v = val[0];
-    uint32_t k = kp[0], s = src[0];
-    const uint32_t seg = k >> KEY_BITS;
-    // row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast 15 / 31 across the rows (lanes that receive nothing
-    // see their own value, which never beats itself)
-#define AUGX_SEG_STEP(CTRL, ROWMASK) { \
-        const double ov = dppMovD<CTRL, ROWMASK>(v, v); \
-        const uint32_t ok = (uint32_t)dppMov<CTRL, ROWMASK>((int)k, (int)k), os = (uint32_t)dppMov<CTRL, ROWMASK>((int)s, (int)s); \
-        const bool tk = (ok >> KEY_BITS) == seg && ov >= v; /* (the left lane holds the larger key) */ \
-        v = tk ? ov : v; k = tk ? ok : k; s = tk ? os : s; }
-    AUGX_SEG_STEP(0x111, 0xf)
-    AUGX_SEG_STEP(0x112, 0xf)
-    AUGX_SEG_STEP(0x114, 0xf)
-    AUGX_SEG_STEP(0x118, 0xf)
-    AUGX_SEG_STEP(0x142, 0xa)
-    AUGX_SEG_STEP(0x143, 0xc)
-#undef AUGX_SEG_STEP
-    val[0] = v; kp[0] = k; src[0] = s;
-}
-__device__ inline void waveDown1(const uint32_t *in, uint32_t *out, int, uint32_t fill) {
-    out[0] = (uint32_t)dppMov<0x130, 0xf>((int)fill, (int)in[0]); // wave_shl:1, lane 63 keeps the fill value
-}
-__device__ inline double waveReadD(const double *v, int, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v[0]), lane), __builtin_amdgcn_readlane(__double2loint(v[0]), lane));
-}
-__device__ inline uint32_t waveReadU(const uint32_t *v, int, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v[0], lane); }
+__device__ inline bool waveAnyTrue(const int *flag, int) { return __ballot(flag[0] != 0) != 0ull; }
 #endif
 
 // progress flags between the trellis wavefronts of one workgroup (all resident on one CU: spinning is safe)
@@ -1389,6 +1350,14 @@ AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int
         if (j0 + i / 6 >= 1 && j0 + i / 6 < X.n) gp(X.B.longV)[(X.o + 1 + j0) * 6 + i] = X.L.longW[buf][i / 6][i % 6];
 }
 
+#ifdef AUGX_EMU
+inline void ldsMaxD(double *p, double v) { if (v > *p) *p = v; }
+inline void ldsMaxU(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
+#else
+__device__ inline void ldsMaxD(double *p, double v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_max_f64
+__device__ inline void ldsMaxU(uint32_t *p, uint32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_max_u32
+#endif
+
 // ---- candidates [lo, hi) (indices relative to the first candidate of the tile) of block blk of the trellis
 //      wavefront: add the predecessor value, reduce per (base, state) pair, publish.  Candidates of one pair are
 //      contiguous; a pair may span several chunks of 64.  Written branch-light: one LDS read per candidate.
@@ -1403,14 +1372,16 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     const int top0 = L.listTop[buf][blk][0] - (LIST_WIN - LIST_AHEAD), top1 = L.listTop[buf][blk][1] - (LIST_WIN - LIST_AHEAD),
               top2 = L.listTop[buf][blk][2] - (LIST_WIN - LIST_AHEAD), top3 = L.listTop[buf][blk][3] - (LIST_WIN - LIST_AHEAD);
     const bool wantCells = B.cells != nullptr;
-    double cv = AUGX_NINF;       // best of the last pair of the previous chunk (it may continue in this one)
-    uint32_t ckp = 0xFFFFFFFFu, csrc = 0;
+    // The cell of a (base, state) pair is the maximum over the pair's candidates, which may sit in any lanes of any chunks of
+    // this wavefront (never of another one: the wavefronts split a block at pair boundaries).  No cross-lane scan: every live
+    // candidate does an LDS floating-point atomic max on the cell itself; the candidates that equal the result then settle
+    // the tie ("larger key wins") with an integer atomic max on the cell's key word, and the one whose key comes back writes
+    // the back pointer.  Cell and key word were reset by the far step of the block.
     PROF_MARK(X, 7);
     for (int base = lo; base < hi; base += WAVE) {
-        TV(double, val);
-        TV(uint32_t, kp);
-        TV(uint32_t, src);
-        TV(uint32_t, nkp);
+        TV(double, val); TV(double, f0);
+        TV(uint32_t, kp); TV(uint32_t, mine);
+        TV(int, live);
         const bool inLds = base + WAVE <= ITEM_CAP;
         FOR_WLANES(t, w) {
             const int l = t & 63, it = base + l;
@@ -1425,6 +1396,8 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
             const double *ptr = tag == SRC_LIST ? &L.lcVal[sel][pay & (LIST_WIN - 1)][fr]
                                 : tag == SRC_VIG ? &L.vigw[pay & (VIG_WIN - 1)] : &L.col0[sr & 0x3Fu];
             double pv = *ptr;
+            const int jc = (int)(I.kp >> (KEY_BITS + 6)) & 7, stc = (int)(I.kp >> KEY_BITS) & 63; // the pair id is (base offset, state)
+            TX(f0) = L.ring[(jb + jc) & 63][stc < SP ? stc : 0]; // the cell before this chunk
             const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= vigLo));
             if (slow) { // the value left the LDS windows long ago: read it back from HBM
                 if (tag == SRC_LIST) {
@@ -1433,27 +1406,41 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
                 } else
                     pv = ldCoherent(&B.vig[X.o + 1 + pay]);
             }
-            double v = valid ? pv + I.te : AUGX_NINF;
-            uint32_t k = valid ? I.kp : 0xFFFFFFFFu, s2 = sr;
-            const bool takeCarry = l == 0 && (ckp >> KEY_BITS) == (k >> KEY_BITS) && better(cv, (int)ckp, v, (int)k);
-            v = takeCarry ? cv : v; k = takeCarry ? ckp : k; s2 = takeCarry ? csrc : s2;
-            TX(val) = v; TX(kp) = k; TX(src) = s2;
+            const double v = valid ? pv + I.te : AUGX_NINF;
+            TX(val) = v; TX(kp) = I.kp; TX(live) = v > AUGX_NINF;
+            TX(mine) = ((I.kp & KEY_MASK) << 2) | ((sr >> 28) & 3);
         }
         PROF_MARK(X, 4);
-        waveSegScan(val, kp, src, w);
-        waveDown1(kp, nkp, w, 0xFFFFFFFFu);
+        FOR_WLANES(t, w) {
+            if (TX(live)) ldsMaxD(&L.ring[(jb + (int)(TX(kp) >> (KEY_BITS + 6))) & 63][(TX(kp) >> KEY_BITS) & 63], TX(val));
+        }
+        WAVE_SYNC();
+        TV(int, isTop);
+        TV(int, beaten);
+        FOR_WLANES(t, w) {
+            const int j = jb + (int)(TX(kp) >> (KEY_BITS + 6)), st = (int)(TX(kp) >> KEY_BITS) & 63;
+            const double f = TX(live) ? L.ring[j & 63][st] : AUGX_NINF;
+            TX(isTop) = TX(live) && TX(val) == f;
+            // an earlier chunk of this wavefront had a (lower) best for the cell: its key no longer counts
+            TX(beaten) = TX(isTop) && f > TX(f0) && TX(f0) > AUGX_NINF;
+            if (TX(beaten)) L.kmax[j & 63][st] = 0;
+        }
+        if (waveAnyTrue(beaten, w)) WAVE_SYNC();
+        FOR_WLANES(t, w) {
+            if (TX(isTop)) ldsMaxU(&L.kmax[(jb + (int)(TX(kp) >> (KEY_BITS + 6))) & 63][(TX(kp) >> KEY_BITS) & 63], TX(mine));
+        }
+        WAVE_SYNC();
         PROF_MARK(X, 5);
-        FOR_WLANES(t, w) { // the last lane of every segment publishes (a pair continuing in the next chunk is overwritten there)
-            const uint32_t k2 = TX(kp);
-            if (k2 != 0xFFFFFFFFu && (TX(nkp) >> KEY_BITS) != (k2 >> KEY_BITS) && TX(val) > AUGX_NINF) {
-                const int j = jb + (int)(k2 >> (KEY_BITS + 6)), st = (int)(k2 >> KEY_BITS) & 63; // the pair id is (base offset, state)
-                const int eop = (int)(k2 & KEY_MASK) - KEY_BIAS;
-                L.ring[j & 63][st] = TX(val);
-                L.bp[buf][j & 63][st] = bpVar((int)((TX(src) >> 28) & 3), j - eop);
-                if (wantCells) gp(B.cells)[(X.o + 1 + j) * S + st] = TX(val);
+        FOR_WLANES(t, w) {
+            if (TX(isTop)) {
+                const int j = jb + (int)(TX(kp) >> (KEY_BITS + 6)), st = (int)(TX(kp) >> KEY_BITS) & 63;
+                if (L.kmax[j & 63][st] == TX(mine)) {
+                    const int eop = (int)(TX(kp) & KEY_MASK) - KEY_BIAS;
+                    L.bp[buf][j & 63][st] = bpVar((int)(TX(mine) & 3), j - eop);
+                    if (wantCells) gp(B.cells)[(X.o + 1 + j) * S + st] = TX(val);
+                }
             }
         }
-        cv = waveReadD(val, w, WAVE - 1); ckp = waveReadU(kp, w, WAVE - 1); csrc = waveReadU(src, w, WAVE - 1);
         WAVE_SYNC();
         PROF_MARK(X, 6);
     }
@@ -1605,6 +1592,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.flagR = 0; L.staged = 0; L.rtPub = 0; L.abortFlag = 0; L.flagSum = 0; }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
+            L.kmax[i / SP][i % SP] = 0;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
         }
     }
@@ -1824,6 +1812,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const int s2 = vS[r][TI];
                 if (s2 < 0 || j < 1 || j >= n) continue;
                 L.ring[j & 63][s2] = AUGX_NINF;
+                L.kmax[j & 63][s2] = 0;
                 if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
             }
         }
