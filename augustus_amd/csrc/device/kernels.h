@@ -536,7 +536,6 @@ struct CandLds {
     uint8_t pairJ[NWAVES][WAVE], pairS[NWAVES][WAVE];    // the pairs of the current round: base offset in the tile, state
     int scan[NWAVES][3][WAVE];                           // inclusive lane scans of the pair counts of the three groups
     uint32_t cntItems[NWAVES][MAXNB], cntNonRT[NWAVES][MAXNB]; // per block: candidates (then: first candidate), candidates but RTERMINAL
-    unsigned long long bestMid[NWAVES][MAXNB][2];        // per block: (distance << 32 | position) of the pair boundaries nearest 1/3 and 2/3
     unsigned long long baseW[NWAVES][2];                 // first pair / first candidate of the tile in the batch's buffers
 };
 
@@ -925,7 +924,7 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         TX(gA) = gt & maskLess; TX(gB) = gt & maskVar & ~maskLess; TX(gC) = gt & maskRT;
         TX(nA) = popc64(TX(gA)); TX(nB) = popc64(TX(gB)); TX(nC) = popc64(TX(gC));
         TX(iA) = TX(nA); TX(iB) = TX(nB); TX(iC) = TX(nC);
-        if (l < NB) { L.cntItems[w][l] = 0; L.cntNonRT[w][l] = 0; L.bestMid[w][l][0] = ~0ull; L.bestMid[w][l][1] = ~0ull; }
+        if (l < NB) { L.cntItems[w][l] = 0; L.cntNonRT[w][l] = 0; }
     }
     waveInclScan(iA, w); waveInclScan(iB, w); waveInclScan(iC, w);
     FOR_WLANES(t, w) { const int l = t & 63; L.scan[w][0][l] = TX(iA); L.scan[w][1][l] = TX(iB); L.scan[w][2][l] = TX(iC); }
@@ -1004,7 +1003,10 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
             const int64_t gblk = gblk0 + l;
             B.blkOff[gblk * 2] = pairBase + (uint64_t)p0; B.blkOff[gblk * 2 + 1] = itemBase + (uint64_t)(TX(bInc) - TX(bItems));
             B.blkCnt[gblk * 2] = (uint32_t)(p1 - p0); B.blkCnt[gblk * 2 + 1] = (uint32_t)TX(bItems);
-            B.blkSplit[gblk * 3 + 2] = L.cntNonRT[w][l];
+            // the three trellis workers take a third each of the block's candidates but RTERMINAL (any split will do: a pair's
+            // candidates may be spread over wavefronts, the cell is an atomic max)
+            const uint32_t nr = L.cntNonRT[w][l];
+            B.blkSplit[gblk * 3] = nr / 3; B.blkSplit[gblk * 3 + 1] = 2 * nr / 3; B.blkSplit[gblk * 3 + 2] = nr;
             L.cntItems[w][l] = (uint32_t)(TX(bInc) - TX(bItems)); // from here on: first candidate of the block, relative to the tile
         }
     }
@@ -1033,16 +1035,6 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         // (the scan rows are free by now: row 0 takes the prefix, padded, for the candidates' search of their pair)
         FOR_WLANES(t, w) { const int l = t & 63; L.scan[w][0][l] = l < nPr ? TX(ibase) : 0x7fffffff; }
         WAVE_SYNC();
-        FOR_WLANES(t, w) { // pair boundaries nearest to 1/3 and 2/3 of the block's candidates (RTERMINAL pairs come last and are not shared)
-            const int l = t & 63;
-            if (l < nPr && !((maskRT >> L.pairS[w][l]) & 1)) {
-                const int blk = L.pairJ[w][l] / BLK;
-                const uint32_t loc = itemsDone + (uint32_t)TX(ibase) - L.cntItems[w][blk], nr = L.cntNonRT[w][blk];
-                const uint32_t t1 = nr / 3, t2 = 2 * nr / 3, d1 = loc > t1 ? loc - t1 : t1 - loc, d2 = loc > t2 ? loc - t2 : t2 - loc;
-                ldsMin64(&L.bestMid[w][blk][0], ((unsigned long long)d1 << 32) | loc);
-                ldsMin64(&L.bestMid[w][blk][1], ((unsigned long long)d2 << 32) | loc);
-            }
-        }
         for (int base = 0; base < totalItems; base += WAVE) {
             TV(int, myPair);
             TV(int, myFirst);
@@ -1072,15 +1064,6 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         }
         WAVE_SYNC();
         itemsDone += (uint32_t)totalItems;
-    }
-    FOR_WLANES(t, w) {
-        const int l = t & 63;
-        if (l < NB) {
-            const unsigned long long m1 = L.bestMid[w][l][0], m2 = L.bestMid[w][l][1];
-            uint32_t mid1 = m1 == ~0ull ? 0 : (uint32_t)m1, mid2 = m2 == ~0ull ? 0 : (uint32_t)m2;
-            if (mid2 < mid1) mid2 = mid1;
-            B.blkSplit[(gblk0 + l) * 3] = mid1; B.blkSplit[(gblk0 + l) * 3 + 1] = mid2;
-        }
     }
 }
 
@@ -1126,11 +1109,10 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // list values) to HBM.  See trellisPiece for the schedule and DESIGN.md section 5 for the reasoning.
 // =================================================================================================
 constexpr int NWORK = 3, W_C = 3, W_X = 4, W_LOAD = 5; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4 far fixed-lag states, 5.. loaders
-constexpr int ITEM_CAP = 1664;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
+constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
 
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
-    uint32_t kmax[WAVE][SP];        // variable-length states: (tie-break key << 2 | ancestor index) of the best candidate so far
     uint16_t bp[2][WAVE][SP];       // back pointers of the current / previous tile
     double sig[2][WAVE][NSIG];      // signal records of the current / next tile
     int32_t site[2][WAVE][NSITE];
@@ -1371,17 +1353,12 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     constexpr int LIST_AHEAD = 32;
     const int top0 = L.listTop[buf][blk][0] - (LIST_WIN - LIST_AHEAD), top1 = L.listTop[buf][blk][1] - (LIST_WIN - LIST_AHEAD),
               top2 = L.listTop[buf][blk][2] - (LIST_WIN - LIST_AHEAD), top3 = L.listTop[buf][blk][3] - (LIST_WIN - LIST_AHEAD);
-    const bool wantCells = B.cells != nullptr;
     // The cell of a (base, state) pair is the maximum over the pair's candidates, which may sit in any lanes of any chunks of
-    // this wavefront (never of another one: the wavefronts split a block at pair boundaries).  No cross-lane scan: every live
-    // candidate does an LDS floating-point atomic max on the cell itself; the candidates that equal the result then settle
-    // the tie ("larger key wins") with an integer atomic max on the cell's key word, and the one whose key comes back writes
-    // the back pointer.  Cell and key word were reset by the far step of the block.
+    // any of the wavefronts that share the block: every live candidate does one LDS floating-point atomic max on the cell
+    // itself (reset to -inf by the far step of the block).  Nothing else is kept: which candidate won is found again by the
+    // back-trace, for the few cells on the path (backtracePiece).
     PROF_MARK(X, 7);
     for (int base = lo; base < hi; base += WAVE) {
-        TV(double, val); TV(double, f0);
-        TV(uint32_t, kp); TV(uint32_t, mine);
-        TV(int, live);
         const bool inLds = base + WAVE <= ITEM_CAP;
         FOR_WLANES(t, w) {
             const int l = t & 63, it = base + l;
@@ -1396,8 +1373,6 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
             const double *ptr = tag == SRC_LIST ? &L.lcVal[sel][pay & (LIST_WIN - 1)][fr]
                                 : tag == SRC_VIG ? &L.vigw[pay & (VIG_WIN - 1)] : &L.col0[sr & 0x3Fu];
             double pv = *ptr;
-            const int jc = (int)(I.kp >> (KEY_BITS + 6)) & 7, stc = (int)(I.kp >> KEY_BITS) & 63; // the pair id is (base offset, state)
-            TX(f0) = L.ring[(jb + jc) & 63][stc < SP ? stc : 0]; // the cell before this chunk
             const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= vigLo));
             if (slow) { // the value left the LDS windows long ago: read it back from HBM
                 if (tag == SRC_LIST) {
@@ -1407,43 +1382,13 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
                     pv = ldCoherent(&B.vig[X.o + 1 + pay]);
             }
             const double v = valid ? pv + I.te : AUGX_NINF;
-            TX(val) = v; TX(kp) = I.kp; TX(live) = v > AUGX_NINF;
-            TX(mine) = ((I.kp & KEY_MASK) << 2) | ((sr >> 28) & 3);
+            // the pair id is (base offset in the block, state)
+            if (v > AUGX_NINF) ldsMaxD(&L.ring[(jb + (int)(I.kp >> (KEY_BITS + 6))) & 63][(I.kp >> KEY_BITS) & 63], v);
         }
         PROF_MARK(X, 4);
-        FOR_WLANES(t, w) {
-            if (TX(live)) ldsMaxD(&L.ring[(jb + (int)(TX(kp) >> (KEY_BITS + 6))) & 63][(TX(kp) >> KEY_BITS) & 63], TX(val));
-        }
-        WAVE_SYNC();
-        TV(int, isTop);
-        TV(int, beaten);
-        FOR_WLANES(t, w) {
-            const int j = jb + (int)(TX(kp) >> (KEY_BITS + 6)), st = (int)(TX(kp) >> KEY_BITS) & 63;
-            const double f = TX(live) ? L.ring[j & 63][st] : AUGX_NINF;
-            TX(isTop) = TX(live) && TX(val) == f;
-            // an earlier chunk of this wavefront had a (lower) best for the cell: its key no longer counts
-            TX(beaten) = TX(isTop) && f > TX(f0) && TX(f0) > AUGX_NINF;
-            if (TX(beaten)) L.kmax[j & 63][st] = 0;
-        }
-        if (waveAnyTrue(beaten, w)) WAVE_SYNC();
-        FOR_WLANES(t, w) {
-            if (TX(isTop)) ldsMaxU(&L.kmax[(jb + (int)(TX(kp) >> (KEY_BITS + 6))) & 63][(TX(kp) >> KEY_BITS) & 63], TX(mine));
-        }
-        WAVE_SYNC();
-        PROF_MARK(X, 5);
-        FOR_WLANES(t, w) {
-            if (TX(isTop)) {
-                const int j = jb + (int)(TX(kp) >> (KEY_BITS + 6)), st = (int)(TX(kp) >> KEY_BITS) & 63;
-                if (L.kmax[j & 63][st] == TX(mine)) {
-                    const int eop = (int)(TX(kp) & KEY_MASK) - KEY_BIAS;
-                    L.bp[buf][j & 63][st] = bpVar((int)(TX(mine) & 3), j - eop);
-                    if (wantCells) gp(B.cells)[(X.o + 1 + j) * S + st] = TX(val);
-                }
-            }
-        }
-        WAVE_SYNC();
-        PROF_MARK(X, 6);
     }
+    WAVE_SYNC();
+    PROF_MARK(X, 5);
 }
 
 template <int BLK>
@@ -1592,7 +1537,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.flagR = 0; L.staged = 0; L.rtPub = 0; L.abortFlag = 0; L.flagSum = 0; }
         for (int i = t; i < WAVE * SP; i += NT) {
             L.ring[i / SP][i % SP] = AUGX_NINF;
-            L.kmax[i / SP][i % SP] = 0;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
         }
     }
@@ -1791,11 +1735,26 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     // before lag > 2 blocks): done by the far wavefront for every block whose igenic cells are complete
     int rtNext = 0;  // (far wavefront) next block, global index, whose RTERMINAL candidates are due
     int farPre = 0;  // (far wavefront) blocks below this index already have their far step (pre-run across the tile boundary)
+    // (debug / test builds only: the dense ln V matrix.  Cells of the variable-length states are final when every candidate
+    //  of their block has been added: the chain wavefront, which waits for that anyway, writes them; RTERMINAL cells are
+    //  written by whoever did their candidates)
+    auto dumpVarCells = [&](int w, int jbD, bool rt) {
+        FOR_WLANES(t, w) {
+            const int j = jbD + (t & 63) % BLK;
+#pragma unroll
+            for (int r = 0; r < VR; r++) {
+                const int s2 = vS[r][TI];
+                if (s2 < 0 || j < 1 || j >= n || (T.kind[s2] == AUGX_K_RTERMINAL) != rt) continue;
+                gp(B.cells)[(o + 1 + j) * S + s2] = L.ring[j & 63][s2];
+            }
+        }
+    };
     auto doRT = [&](int w, int buf, int tile, int k, int jbNow) { // jbNow: no igenic cell at or beyond it exists yet
         const int bq = k - tile * NB;
         const int rt0 = L.blkItem[buf][bq] + (int)L.blkSplit[buf][bq][2], rt1 = L.blkItem[buf][bq + 1];
         const int vigLo = jbNow - 1 - VIG_WIN > -1 ? jbNow - 1 - VIG_WIN : -1;
         if (rt1 > rt0) trellisItems(X, w, buf, bq, k * BLK, rt0, rt1, vigLo);
+        if (wantCells) dumpVarCells(w, k * BLK, true);
     };
     auto rtCatchUp = [&](int w, int buf, int tile, int igDone, int jbNow) {
         if (rtNext < tile * NB) rtNext = tile * NB;
@@ -1812,7 +1771,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const int s2 = vS[r][TI];
                 if (s2 < 0 || j < 1 || j >= n) continue;
                 L.ring[j & 63][s2] = AUGX_NINF;
-                L.kmax[j & 63][s2] = 0;
                 if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
             }
         }
@@ -1867,6 +1825,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             FOR_WAVES(w) {
                 if (w == W_C) { // (1)
                     waitFlag(L, &L.flagSum, NWORK * gbk); // (one poll instead of three: this hand-off is on the critical cycle)
+                    if (wantCells && blk > 0) dumpVarCells(w, jb - BLK, false);
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 6);
                     fixedStep(w, buf, jb, 3, 0, nearRounds); // near (class 0) and late (class 1) states
@@ -1908,6 +1867,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (w == W_C && nb > 0) {
                 const int gLast = tile * NB + nb - 1, jbLast = j0 + (nb - 1) * BLK;
                 waitFlag(L, &L.flagSum, NWORK * (gLast + 1));
+                if (wantCells) dumpVarCells(w, jbLast, false);
                 PROF_MARK(X, 1);
                 PROF_TSTAMP(X, tile == 124, 11);
                 chainPass(w, buf, jbLast, -1);
@@ -1963,8 +1923,19 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)
         for (int i = 0; i < 8; i++) B.prof[((int64_t)p * 5 + (threadIdx.x >> 6)) * 8 + i] = X.pacc[i];
 #endif
-    // ---- back pointers of the last tile
-    FOR_THREADS(t) { flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT); }
+    // ---- back pointers of the last tile; list values of the sites of the last two tiles (the back-trace reads them)
+    FOR_THREADS(t) {
+        flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT);
+        for (int i = t; i < 2 * WAVE * NSITE; i += NT) {
+            const int bsel = i / (WAVE * NSITE), l = (i / NSITE) % WAVE, sel = i % NSITE;
+            if (bsel == 1 && nTiles < 2) continue; // (the other buffer was never loaded)
+            const int si = L.site[((nTiles - 1) & 1) ^ bsel][l][sel];
+            if (si >= 0) {
+                double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                for (int f = 0; f < 3; f++) a[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
+            }
+        }
+    }
     // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)
     FOR_THREADS(t) {
         if (t == 0) {
@@ -2048,10 +2019,52 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
             if (cur < 1) { eop = 0; ai = -1; }
             else { eop = cur - 1; ai = w; }
         } else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
-            uint16_t w = B.bp[(o + 1 + base) * SP + state];
-            ai = w >> 14;
-            eop = base - (int)(w & 0x3FFF);
-            if (w == BP_NONE) { overflow = true; break; }
+            // a variable-length state has no stored back pointer: the arg-max over the candidates of this one (base, state)
+            // pair is taken again, from the candidate records of its block and the predecessor values the trellis left in
+            // HBM -- the same additions, the same tie-break (larger key), a few hundred candidates per path element
+            const int blkSz = B.blk;
+            const int64_t gb = o / blkSz + base / blkSz;
+            const uint64_t i0 = B.blkOff[gb * 2 + 1];
+            const uint32_t cnt = B.blkCnt[gb * 2 + 1], pid = (uint32_t)(((base % blkSz) << 6) | state);
+            Best best{AUGX_NINF, -2147483647, -1};
+            for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
+                LV(double, cv);
+                LV(int, ck);
+                LV(int, ca);
+                FOR_LANES(l) {
+                    LX(cv) = AUGX_NINF; LX(ck) = -2147483647; LX(ca) = -1;
+                    const uint32_t it = c0 + (uint32_t)l;
+                    if (it < cnt) {
+                        const Item I = B.items[i0 + it];
+                        if ((I.kp >> KEY_BITS) == pid && I.te > AUGX_NINF) {
+                            const uint32_t sr = I.src, tag = sr >> 30;
+                            const int sel = (sr >> 26) & 3, fr = (sr >> 24) & 3, pay = (int)(sr & 0xFFFFFFu);
+                            double pv;
+                            if (tag == SRC_LIST) {
+                                const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                                pv = a[(listOff(B, p) + pay) * 3 + fr];
+                            } else if (tag == SRC_VIG)
+                                pv = B.vig[o + 1 + pay];
+                            else {
+                                const int a0 = (int)(sr & 0x3Fu);
+                                pv = B.initKind[p] == 0 ? T.ln_init[a0] : (a0 == T.synch ? 0.0 : AUGX_NINF);
+                            }
+                            LX(cv) = pv + I.te; LX(ck) = (int)(I.kp & KEY_MASK); LX(ca) = (int)((sr >> 28) & 3);
+                        }
+                    }
+                }
+                const Best b2 = waveArgMax(cv, ck, ca);
+                if (better(b2.v, b2.key, best.v, best.key)) best = b2;
+            }
+            if (!(best.v > AUGX_NINF)) { overflow = true; break; }
+            ai = best.aux;
+            eop = best.key - KEY_BIAS;
+#ifdef AUGX_EMU
+            {   // (while the trellis still stores these back pointers: they must agree)
+                const uint16_t w = B.bp[(o + 1 + base) * SP + state];
+                if (w != BP_NONE && (ai != (w >> 14) || eop != base - (int)(w & 0x3FFF))) { fprintf(stderr, "emu: recomputed back pointer differs at base %d state %d\n", base, state); abort(); }
+            }
+#endif
         } else {
             uint16_t w = B.bp[(o + 1 + base) * SP + state];
             if (w == BP_NONE) { overflow = true; break; }
