@@ -8,6 +8,7 @@
 // Lane discipline: a FOR_LANES block is executed by every lane (concurrently on the device, one after the other
 // in the emulator); lanes communicate only through LDS/global memory BETWEEN blocks, separated by WAVE_SYNC().
 #pragma once
+#include <type_traits>
 #include "dp.h"
 
 namespace augx {
@@ -1108,7 +1109,8 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // into the second half of the LDS buffers and retire the previous one (back pointers, igenic column, long-lag cells,
 // list values) to HBM.  See trellisPiece for the schedule and DESIGN.md section 5 for the reasoning.
 // =================================================================================================
-constexpr int NWORK = 3, W_C = 3, W_X = 4, W_LOAD = 5; // trellis workgroup: wavefronts 0..2 workers, 3 chain states, 4 far fixed-lag states, 5.. loaders
+constexpr int NWORK = 3, W_C = 3, W_X = 4, W_I = 5, W_LOAD = 6; // trellis workgroup: wavefronts 0..2 workers, 3 near/late + geometric states, 4 far fixed-lag states, 5 igenic, 6.. loaders
+constexpr int LOAD_T = (8 - W_LOAD) * WAVE;                     // threads of the loader wavefronts
 constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
 
 struct TrellisLds {
@@ -1223,7 +1225,7 @@ template <int BLK>
 AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth, bool flushOld) {
     constexpr int NB = WAVE / BLK; // blocks per tile
     // written in two phases -- every global load of the thread is issued before the first result is consumed -- so that a
-    // tile costs the loaders a few memory round trips, not one per element (nth >= 192: the unroll bounds below)
+    // tile costs the loaders a few memory round trips, not one per element (nth >= LOAD_T: the unroll bounds below)
     const BatchView &B = X.B;
     TrellisLds &L = X.L;
     const int n = X.n, j0 = tile * WAVE, dL = X.T.dStateLen;
@@ -1232,7 +1234,7 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     const int64_t gbL = gb0 + NB - 1 < B.nBlk ? gb0 + NB - 1 : B.nBlk - 1; // last block of the tile
     // (the candidate / pair ranges first: the loads that depend on them then overlap with everything else)
     const uint64_t firstI = gp(B.blkOff)[gb0 * 2 + 1], lastI = gp(B.blkOff)[gbL * 2 + 1] + gp(B.blkCnt)[gbL * 2 + 1];
-    constexpr int KSIG = (WAVE * NSIG + 191) / 192, KSITE = (WAVE * NSITE + 191) / 192, KEQ = (WAVE * 6 + 191) / 192;
+    constexpr int KSIG = (WAVE * NSIG + LOAD_T - 1) / LOAD_T, KSITE = (WAVE * NSITE + LOAD_T - 1) / LOAD_T, KEQ = (WAVE * 6 + LOAD_T - 1) / LOAD_T;
     double vSig[KSIG], vEq[KEQ];
     int vSite[KSITE];
 #pragma unroll
@@ -1268,14 +1270,13 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     }
     uint8_t vGc = 0;
     if (X.multi && tid < WAVE) vGc = gp(B.gcPlane)[g0 + (j0 + tid < n ? tid : n - 1 - j0)];
-    constexpr int KI = (ITEM_CAP + 191) / 192;
+    // (the candidate records go through registers in two halves: they are most of the tile's bytes)
+    constexpr int KI = (ITEM_CAP + LOAD_T - 1) / LOAD_T, KH = (KI + 1) / 2;
     const int cntI = lastI - firstI < (uint64_t)ITEM_CAP ? (int)(lastI - firstI) : ITEM_CAP;
-    Item vItem[KI];
-    {
-        const Item *gi = B.items + firstI;
+    Item vItem[KH];
+    const Item *gi = B.items + firstI;
 #pragma unroll
-        for (int k = 0; k < KI; k++) { const int i = tid + k * nth; vItem[k] = ldItem(gi + (i < cntI ? i : 0)); }
-    }
+    for (int k = 0; k < KH; k++) { const int i = tid + k * nth; vItem[k] = ldItem(gi + (i < cntI ? i : 0)); }
     // ---- second phase
 #pragma unroll
     for (int k = 0; k < KSIG; k++) {
@@ -1309,7 +1310,11 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
     if (tid < NB * 4) L.listTop[buf][tid / 4][tid % 4] = vTop;
     if (tid < WAVE) L.gcw[buf][tid] = vGc;
 #pragma unroll
-    for (int k = 0; k < KI; k++) { const int i = tid + k * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
+    for (int k = 0; k < KH; k++) { const int i = tid + k * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
+#pragma unroll
+    for (int k = 0; k < KH; k++) { const int i = tid + (KH + k) * nth; vItem[k] = ldItem(gi + (i < cntI ? i : 0)); }
+#pragma unroll
+    for (int k = 0; k < KH; k++) { const int i = tid + (KH + k) * nth; if (i < cntI) L.items[buf][i] = vItem[k]; }
 }
 // retire tile `tile` (LDS buffer buf) to HBM: back pointers (and reset of their buffer), igenic column, long-lag cells.
 // (The trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles.)
@@ -1440,6 +1445,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         else if (kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD) nNearStates += dL < 3 * BLK;
     }
     const int nearRounds = (nNearStates + SPR - 1) / SPR, farBase = nearRounds * SPR;
+    bool geoLight = true; // every geometric intron state has at most two ancestors (the usual graph: equalD and itself)
+    for (int s2 = 0; s2 < S; s2++)
+        if (T.reachable[s2] && (T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC) && T.n_anc[s2] > 2) geoLight = false;
     // the far step of block b reads cells back to base b*BLK + BLK-1 - farMinLag; among them RTERMINAL cells, which exist
     // only once the igenic cells of their own block do: igenic must be complete up to that block (farNeedC)
     int farMinLag = 1 << 20;
@@ -1626,7 +1634,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     // block starting at jbIg, the geometric intron states on the block starting at jbGeo (-1: not in this pass).
     // Lane (slot, dj): tree arg-max over the ancestors before / after the state itself (ascending order, strict '>'),
     // then the 8-step recurrence along the block, one lane per base.
-    auto chainPass = [&](int w, int buf, int jbIg, int jbGeo) {
+    // NAc: ancestors per lane that are looked at (5 in general; 2 when the pass serves geometric states with <= 2 ancestors only)
+    auto chainPass = [&](auto NAc, int w, int buf, int jbIg, int jbGeo) {
+        constexpr int NA = decltype(NAc)::value;
         TV(double, res);
         TV(double, prevRes);
         FOR_WLANES(t, w) { TX(res) = AUGX_NINF; TX(prevRes) = AUGX_NINF; }
@@ -1653,16 +1663,25 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const double emiL = L.sig[buf][j & 63][TX(cSig)];
                 double pv[5], v[5], te[5];
 #pragma unroll
-                for (int ai = 0; ai < 5; ai++) pv[ai] = L.ring[(j - 1) & 63][cAnc[ai][TI]];
+                for (int ai = 0; ai < 5; ai++) pv[ai] = ai < NA ? L.ring[(j - 1) & 63][cAnc[ai][TI]] : AUGX_NINF;
                 const double emi = valid ? emiL : AUGX_NINF;
                 const int self = TX(cSelf);
 #pragma unroll
-                for (int ai = 0; ai < 5; ai++) { te[ai] = cTr[ai][TI] + emi; v[ai] = pv[ai] + te[ai]; } // cTr = -inf beyond the last ancestor
-                TX(teS) = self == 0 ? te[0] : self == 1 ? te[1] : self == 2 ? te[2] : self == 3 ? te[3] : self == 4 ? te[4] : AUGX_NINF;
-                TX(psS) = self == 0 ? pv[0] : self == 1 ? pv[1] : self == 2 ? pv[2] : self == 3 ? pv[3] : self == 4 ? pv[4] : AUGX_NINF;
+                for (int ai = 0; ai < 5; ai++) { te[ai] = ai < NA ? cTr[ai][TI] + emi : AUGX_NINF; v[ai] = pv[ai] + te[ai]; } // cTr = -inf beyond the last ancestor
                 double vb[5], va[5];
 #pragma unroll
                 for (int ai = 0; ai < 5; ai++) { vb[ai] = ai < self ? v[ai] : AUGX_NINF; va[ai] = ai > self ? v[ai] : AUGX_NINF; }
+                if constexpr (NA == 2) {
+                    TX(teS) = self == 0 ? te[0] : self == 1 ? te[1] : AUGX_NINF;
+                    TX(psS) = self == 0 ? pv[0] : self == 1 ? pv[1] : AUGX_NINF;
+                    const bool t01 = vb[1] > vb[0];
+                    TX(bB) = t01 ? vb[1] : vb[0];
+                    TX(aB) = TX(bB) > AUGX_NINF ? (t01 ? 1 : 0) : -1;
+                    TX(bA) = va[1];
+                    TX(aA) = TX(bA) > AUGX_NINF ? 1 : -1;
+                } else {
+                TX(teS) = self == 0 ? te[0] : self == 1 ? te[1] : self == 2 ? te[2] : self == 3 ? te[3] : self == 4 ? te[4] : AUGX_NINF;
+                TX(psS) = self == 0 ? pv[0] : self == 1 ? pv[1] : self == 2 ? pv[2] : self == 3 ? pv[3] : self == 4 ? pv[4] : AUGX_NINF;
                 {
                     const bool t01 = vb[1] > vb[0], t23 = vb[3] > vb[2];
                     const double m01 = t01 ? vb[1] : vb[0], m23 = t23 ? vb[3] : vb[2];
@@ -1684,6 +1703,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     const bool t4 = va[4] > mq;
                     TX(bA) = t4 ? va[4] : mq;
                     TX(aA) = TX(bA) > AUGX_NINF ? (t4 ? 4 : iq) : -1;
+                }
                 }
             }
         }
@@ -1836,20 +1856,29 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
             }
             FOR_WAVES(w) {
-                if (w == W_C) { // (3)
+                if (w == W_C) { // (3) geometric intron states of block b (fed by fixed-lag states and themselves only)
                     waitFlag(L, &L.flagN, gbk + 1);
                     PROF_MARK(X, 1);
                     PROF_STAMP(X, gbk, 8);
-                    chainPass(w, buf, blk > 0 ? jb - BLK : -1, jb);
-                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagC, gbk); // igenic is complete up to block b-1
+                    if (geoLight) chainPass(std::integral_constant<int, 2>{}, w, buf, -1, jb);
+                    else chainPass(std::integral_constant<int, 5>{}, w, buf, -1, jb);
+                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */
                     PROF_STAMP(X, gbk, 9);
                     PROF_MARK(X, 3);
                 }
             }
             FOR_WAVES(w) {
+                if (w == W_I) { // (3') igenic of block b-1, fed by its exon cells: off the cycle, on a wavefront of its own
+                    waitFlag(L, &L.flagSum, NWORK * gbk);
+                    if (blk > 0) chainPass(std::integral_constant<int, 5>{}, w, buf, jb - BLK, -1);
+                    if (wantCells) drainStores();
+                    setFlag(&L.flagC, gbk); // igenic is complete up to block b-1
+                }
+            }
+            FOR_WAVES(w) {
                 if (w < NWORK) { // (4)
                     waitFlag(L, &L.flagL, gbk + 1); // (implies flagN >= gbk + 1, see (1))
-                    if (safeIg) waitFlag(L, &L.flagC, gbk);
+                    waitFlag(L, &L.flagC, safeIg ? gbk : gbk - 1); // igenic: no candidate reads a cell less than two blocks back (safe mode: one)
                     PROF_MARK(X, 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 2 : 4);
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;
@@ -1864,16 +1893,19 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 10); }
         // ---- end of the tile: igenic of the last block, then the RTERMINAL candidates of the last two blocks
         FOR_WAVES(w) {
-            if (w == W_C && nb > 0) {
+            if (w == W_C && nb > 0 && wantCells) {
                 const int gLast = tile * NB + nb - 1, jbLast = j0 + (nb - 1) * BLK;
                 waitFlag(L, &L.flagSum, NWORK * (gLast + 1));
-                if (wantCells) dumpVarCells(w, jbLast, false);
-                PROF_MARK(X, 1);
+                dumpVarCells(w, jbLast, false);
+                drainStores();
+            }
+            if (w == W_I && nb > 0) {
+                const int gLast = tile * NB + nb - 1, jbLast = j0 + (nb - 1) * BLK;
+                waitFlag(L, &L.flagSum, NWORK * (gLast + 1));
                 PROF_TSTAMP(X, tile == 124, 11);
-                chainPass(w, buf, jbLast, -1);
+                chainPass(std::integral_constant<int, 5>{}, w, buf, jbLast, -1);
                 if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagC, gLast + 1);
                 PROF_TSTAMP(X, tile == 124, 12);
-                PROF_MARK(X, 3);
             }
         }
         // the remaining RTERMINAL candidates of the tile (their back pointers live in this tile's buffer) are shared by
