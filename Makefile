@@ -4,7 +4,10 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
 # -ffp-contract=off: the decode path must round exactly like the CPU oracle (no FMA contraction)
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
+# -DAUGX_PROFILE: the trellis wavefronts' cycle counters (printed with AUGX_PROF=1) are compiled in.  They cost nothing when
+# off (uniform branches) -- and the kernel measured 3 % FASTER with them than without (260.7 vs 268.8 ms per launch,
+# reproducibly: code layout / register allocation), so they stay in the product build
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DAUGX_PROFILE
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
 SRC     = augustus_amd/csrc
 HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc

@@ -1077,7 +1077,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
     const int64_t gtile0 = wg * NWAVES;
     if (gtile0 * WAVE >= B.N) return;
     const int p = B.chunkPiece[gtile0 * WAVE / CHUNK];
-#ifndef AUGX_EMU
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     uint64_t cp0 = clock64(), cp1;
 #endif
     FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, B, p, t, L.vc[t]); }
@@ -1093,7 +1093,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
         const int64_t gtile = gtile0 + w;
         candTile<BLK, MULTI>(X, L, w, (int)(gtile * WAVE - X.o), gtile * NB, maskLess, maskVar, maskRT);
     }
-#ifndef AUGX_EMU
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     cp1 = clock64();
     if (B.prof && (threadIdx.x & 63) == 0) {
         unsigned long long *pp = (unsigned long long *)B.prof + (int64_t)B.nPieces * 56;
@@ -1189,7 +1189,7 @@ __device__ inline void setFlag(int *f, int v) {
 }
 #endif
 
-#ifdef AUGX_EMU
+#if defined(AUGX_EMU) || !defined(AUGX_PROFILE)
 #define PROF_MARK(X, sec) do {} while (0)
 #define PROF_STAMP(X, gbk, slot) do {} while (0)
 #define PROF_TSTAMP(X, cond, slot) do {} while (0)
@@ -1199,8 +1199,8 @@ __device__ inline void setFlag(int *f, int v) {
 #define PROF_MARK(X, sec) do { if ((X).B.prof) { uint64_t now_ = clock64(); (X).pacc[sec] += now_ - (X).plast; (X).plast = now_; } } while (0)
 #endif
 struct TrellisCtx {
-#ifndef AUGX_EMU
-    uint64_t pacc[8], plast;
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    uint64_t pacc[8], plast; // (developer build -DAUGX_PROFILE: cycle counters of the trellis wavefronts, printed with AUGX_PROF=1)
 #endif
     const DevTables &T;
     const BatchView &B;
@@ -1795,7 +1795,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
         }
     };
-#ifndef AUGX_EMU
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     for (int i = 0; i < 8; i++) X.pacc[i] = 0;
     X.plast = clock64();
 #endif
@@ -1951,7 +1951,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
         FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 15); }
     }
-#ifndef AUGX_EMU
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)
         for (int i = 0; i < 8; i++) B.prof[((int64_t)p * 5 + (threadIdx.x >> 6)) * 8 + i] = X.pacc[i];
 #endif
