@@ -150,9 +150,9 @@ template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *
 // ---- candidates of the variable-length states: one wavefront per tile of 64 bases (describe + count, reserve, evaluate) ----
 // (MULTI: some piece of the batch has more than one GC class -- the plane of every class-dependent array is then chosen per
 //  end base; batches without such a piece run the variant with the plane folded away)
-template <int BLK, bool MULTI> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
-    __shared__ CandLds lds;
-    candWorkgroup<BLK, MULTI>(*T, *B, lds, blockIdx.x);
+template <int BLK, bool MULTI> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView B) {
+    __shared__ CandLds lds; // (the batch view by value: its pointers are then known to be global, not generic)
+    candWorkgroup<BLK, MULTI>(*T, B, lds, blockIdx.x);
 }
 
 template <int BLK> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
@@ -498,8 +498,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
             const bool multi = W.nPl > 1;
-#define AUGX_LAUNCH_CAND(BLK_) do { if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, b->dV); \
-                                    else hipLaunchKernelGGL((kCand<BLK_, false>), dim3(nWg), dim3(NT), 0, st, d->dT, b->dV); } while (0)
+#define AUGX_LAUNCH_CAND(BLK_) do { if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
+                                    else hipLaunchKernelGGL((kCand<BLK_, false>), dim3(nWg), dim3(NT), 0, st, d->dT, W); } while (0)
             if (d->blk == 8) AUGX_LAUNCH_CAND(8);
             else if (d->blk == 4) AUGX_LAUNCH_CAND(4);
             else AUGX_LAUNCH_CAND(2);
