@@ -585,9 +585,9 @@ struct CandCtx {
         return Q;
     }
     AUGX_HD double lenAt(int sel, int len) const {
-        return (sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
+        return gp(sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
     }
-    AUGX_HD double lenIAt(int len) const { return T.len_intron[len]; }
+    AUGX_HD double lenIAt(int len) const { return gp(T.len_intron)[len]; } // (table pointers read from the model struct are generic to the compiler)
     AUGX_HD double plsRAt(int pl, int q, int fr) const { return B.plsR[((int64_t)pl * B.N + o + 1 + q) * 3 + fr]; }
     AUGX_HD double sigAt(int q, int i) const { return B.sig[(o + 1 + q) * NSIG + i]; }
 };
