@@ -65,10 +65,16 @@ constexpr int NWAVES = 8, NT = NWAVES * WAVE;
 // loads and stores do not count against the LDS wait counter (flat instructions do)
 #ifdef AUGX_EMU
 template <class T> inline T *gp(T *p) { return p; }
+inline double ldsLoadD(const double *p) { return *p; }
 inline Item ldItem(const Item *p) { return *p; }
 inline IntronStart ldIntronStart(const IntronStart *p) { return *p; }
 #else
 #define AUGX_GLOBAL __attribute__((address_space(1)))
+// a pointer INTO the workgroup's LDS that the compiler only knows as generic (selected among several LDS arrays, or accessed
+// as volatile): re-typed, so that the access is a ds_ instruction and not a flat one (slower, and counted against both
+// the LDS and the memory wait counters)
+#define AUGX_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ double ldsLoadD(const double *p) { return *(const AUGX_LDS double *)p; }
 template <class T> __device__ __forceinline__ AUGX_GLOBAL T *gp(T *p) { return (AUGX_GLOBAL T *)p; }
 __device__ __forceinline__ Item ldItem(const Item *p) { // one 16-byte global load
     typedef int v4i __attribute__((ext_vector_type(4)));
@@ -1162,14 +1168,14 @@ inline void bumpFlag(int *f) { *f += 1; }
 #else
 __device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
     int spins = 0;
-    while (*(const volatile int *)f < target && !*(const volatile int *)&L.abortFlag) {
-        if (++spins > (1 << 22)) *(volatile int *)&L.abortFlag = 1; // never expected: turns a logic error into an error status
+    while (*(const volatile AUGX_LDS int *)f < target && !*(const volatile AUGX_LDS int *)&L.abortFlag) {
+        if (++spins > (1 << 22)) *(volatile AUGX_LDS int *)&L.abortFlag = 1; // never expected: turns a logic error into an error status
         __builtin_amdgcn_s_sleep(1);
     }
     __asm__ volatile("" ::: "memory");
 }
 __device__ inline int readFlag(const int *f) {
-    const int v = *(const volatile int *)f;
+    const int v = *(const volatile AUGX_LDS int *)f;
     __asm__ volatile("" ::: "memory");
     return __builtin_amdgcn_readfirstlane(v);
 }
@@ -1185,7 +1191,7 @@ __device__ inline void bumpFlag(int *f) { // right after a setFlag of the same w
 __device__ inline void setFlag(int *f, int v) {
     __builtin_amdgcn_s_waitcnt(0xc07f); // the LDS writes of this wavefront have been performed
     __asm__ volatile("" ::: "memory");
-    if ((threadIdx.x & 63) == 0) *(volatile int *)f = v;
+    if ((threadIdx.x & 63) == 0) *(volatile AUGX_LDS int *)f = v;
 }
 #endif
 
@@ -1377,7 +1383,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
             const int top = sel == 0 ? top0 : sel == 1 ? top1 : sel == 2 ? top2 : top3;
             const double *ptr = tag == SRC_LIST ? &L.lcVal[sel][pay & (LIST_WIN - 1)][fr]
                                 : tag == SRC_VIG ? &L.vigw[pay & (VIG_WIN - 1)] : &L.col0[sr & 0x3Fu];
-            double pv = *ptr;
+            double pv = ldsLoadD(ptr);
             const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= vigLo));
             if (slow) { // the value left the LDS windows long ago: read it back from HBM
                 if (tag == SRC_LIST) {
@@ -1601,7 +1607,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const double *p0 = lg ? &L.eqPrev[buf][j & 63][fAnc0[r][TI]] : &L.ring[jp & 63][fAnc0[r][TI]];
                 const double *p1 = lg ? &L.eqPrev[buf][j & 63][fAnc1[r][TI]] : &L.ring[jp & 63][fAnc1[r][TI]];
                 emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
-                pv0[r] = *p0; pv1[r] = *p1;
+                pv0[r] = ldsLoadD(p0); pv1[r] = ldsLoadD(p1);
                 si[r] = L.site[buf][j & 63][fList[r][TI] & 3];
             }
 #pragma unroll
