@@ -899,10 +899,8 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
 // LDS accumulators shared by the lanes of one wavefront
 #ifdef AUGX_EMU
 inline void ldsAdd(uint32_t *p, uint32_t v) { *p += v; }
-inline void ldsMin64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 #else
 __device__ inline void ldsAdd(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ inline void ldsMin64(unsigned long long *p, unsigned long long v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 
 // global allocation state of the candidate buffer (one per batch)
