@@ -10,7 +10,7 @@ ARCH    ?= gfx950
 HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DAUGX_PROFILE
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
 SRC     = augustus_amd/csrc
-HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc
+HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc $(SRC)/sharded.cc
 DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/layout.h
 
 all: product oracle emu

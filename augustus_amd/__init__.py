@@ -60,6 +60,9 @@ def lib():
         L.augx_model_option.restype = ctypes.c_char_p
         L.augx_model_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         L.augx_model_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_device_count.restype = ctypes.c_int
+        L.augx_partition_lpt.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        L.augx_decode_sharded.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.augx_decoder_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.augx_decoder_destroy.argtypes = [ctypes.c_void_p]
         L.augx_decoder_batch_capacity.restype = ctypes.c_int64
@@ -141,6 +144,7 @@ class Batch:
             P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = s, len(s), iks[i], tks[i]
         self._h = ctypes.c_void_p()
         _check(L.augx_batch_create(decoder._h, P, self.n, ctypes.byref(self._h)))
+        decoder._batches.add(self)   # (a decoder closes its live batches before it goes: they hold a pointer to it)
 
     def decode(self, sync=True):
         _check(lib().augx_batch_decode(self.decoder._h, self._h))
@@ -183,11 +187,48 @@ class Batch:
             pass
 
 
+def device_count():
+    return lib().augx_device_count()
+
+
+def partition_lpt(lens, n_bins):
+    """Longest-first bin packing used by decode_sharded (host only)."""
+    import numpy as np
+    a = np.asarray(lens, dtype=np.int64)
+    out = np.zeros(len(a), dtype=np.int32)
+    _check(lib().augx_partition_lpt(a.ctypes.data_as(ctypes.c_void_p), len(a), n_bins, out.ctypes.data_as(ctypes.c_void_p)))
+    return out.tolist()
+
+
+def decode_sharded(decoders, seqs, init_kind=0, term_kind=0):
+    """``augx_decode_sharded``: pieces fanned over several decoders (one per GPU), results in input order."""
+    L = lib()
+    n = len(seqs)
+    keep = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+    P = (_Piece * n)()
+    iks = init_kind if isinstance(init_kind, (list, tuple)) else [init_kind] * n
+    tks = term_kind if isinstance(term_kind, (list, tuple)) else [term_kind] * n
+    for i, s in enumerate(keep):
+        P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = s, len(s), iks[i], tks[i]
+    D = (ctypes.c_void_p * len(decoders))(*[d._h for d in decoders])
+    out = (_Path * n)()
+    _check(L.augx_decode_sharded(D, len(decoders), P, n, out))
+    res = []
+    for i in range(n):
+        st = [(out[i].states[k].begin, out[i].states[k].end, out[i].states[k].state, out[i].states[k].type)
+              for k in range(out[i].n_states)]
+        res.append(DecodedPiece(out[i].status, out[i].ln_viterbi, st))
+        L.augx_path_free(ctypes.byref(out[i]))
+    return res
+
+
 class Decoder:
     """Device context (``augx_decoder_create``).  Raises AugxError(AUGX_E_NODEVICE) without a HIP device."""
 
     def __init__(self, model, device=0):
+        import weakref
         self.model = model
+        self._batches = weakref.WeakSet()
         self._h = ctypes.c_void_p()
         _check(lib().augx_decoder_create(model._h, device, ctypes.byref(self._h)))
 
@@ -201,6 +242,8 @@ class Decoder:
 
     def close(self):
         if self._h:
+            for b in list(self._batches):
+                b.close()
             lib().augx_decoder_destroy(self._h)
             self._h = ctypes.c_void_p()
 

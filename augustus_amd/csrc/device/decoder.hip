@@ -198,7 +198,13 @@ namespace {
 
 template <class T> int devAlloc(augx_batch *b, T **ptr, int64_t count) {
     void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+    const hipError_t e = hipMalloc(&p, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        setLastError("augx: out of device memory while allocating a batch; decode fewer bases per batch");
+        return AUGX_E_NOMEM;
+    }
+    HIP_TRY(e);
     b->bufs.push_back(p);
     *ptr = (T *)p;
     return 0;
@@ -261,6 +267,12 @@ template <bool MAX> int runScan(augx_batch *b, uint64_t *a, int nf) {
 
 extern "C" {
 
+int augx_device_count(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return ndev;
+}
+
 int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     if (!m || !out) { setLastError("augx_decoder_create: NULL argument"); return AUGX_E_ARG; }
     *out = nullptr;
@@ -286,18 +298,22 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->blk = blk;
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
-    HIP_TRY(hipStreamCreate(&d->stream));
-    fillDevTablesScalars(t, d->hostT);
-    for (auto &sp : tableSpans(t, d->hostT)) {
-        void *p = nullptr;
-        size_t bytes = (size_t)(sp.count > 0 ? sp.count : 1) * sizeof(double);
-        HIP_TRY(hipMalloc(&p, bytes));
-        d->tableBufs.push_back(p);
-        if (sp.count > 0) HIP_TRY(hipMemcpy(p, sp.src, (size_t)sp.count * sizeof(double), hipMemcpyHostToDevice));
-        *sp.dst = (const double *)p;
-    }
-    HIP_TRY(hipMalloc((void **)&d->dT, sizeof(DevTables)));
-    HIP_TRY(hipMemcpy(d->dT, &d->hostT, sizeof(DevTables), hipMemcpyHostToDevice));
+    const int rc = [&]() -> int { // (any failure below: the half-built decoder is destroyed, nothing leaks)
+        HIP_TRY(hipStreamCreate(&d->stream));
+        fillDevTablesScalars(t, d->hostT);
+        for (auto &sp : tableSpans(t, d->hostT)) {
+            void *p = nullptr;
+            size_t bytes = (size_t)(sp.count > 0 ? sp.count : 1) * sizeof(double);
+            HIP_TRY(hipMalloc(&p, bytes));
+            d->tableBufs.push_back(p);
+            if (sp.count > 0) HIP_TRY(hipMemcpy(p, sp.src, (size_t)sp.count * sizeof(double), hipMemcpyHostToDevice));
+            *sp.dst = (const double *)p;
+        }
+        HIP_TRY(hipMalloc((void **)&d->dT, sizeof(DevTables)));
+        HIP_TRY(hipMemcpy(d->dT, &d->hostT, sizeof(DevTables), hipMemcpyHostToDevice));
+        return AUGX_OK;
+    }();
+    if (rc) { augx_decoder_destroy(d); return rc; }
     *out = d;
     return AUGX_OK;
 }
@@ -374,7 +390,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
-    if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); HIP_TRY(hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8)); }
+    if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); if (hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8) != hipSuccess) { augx_batch_destroy(b); setLastError("augx_batch_create: hipMemset failed"); return AUGX_E_HIP; } }
     DA(V.vig, double, Z.N);
     DA(V.longV, double, Z.N * 6);
     DA(V.listCnt, int32_t, n); DA(b->dListOffs, int64_t, n + 1);
@@ -387,6 +403,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
 #undef DA
+    rc = [&]() -> int { // (any failure below: the batch is destroyed with everything it owns)
     HIP_TRY(hipMemcpy(dOff, L.off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dLen, L.len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dIk, L.initKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
@@ -399,6 +416,9 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     { void *pv = nullptr; HIP_TRY(hipMalloc(&pv, sizeof(BatchView))); b->bufs.push_back(pv); b->dV = (BatchView *)pv; }
     HIP_TRY(hipMemcpy(b->dV, &V, sizeof(BatchView), hipMemcpyHostToDevice));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    return AUGX_OK;
+    }();
+    if (rc) { augx_batch_destroy(b); return rc; }
     *out = b;
     return AUGX_OK;
 }
@@ -608,6 +628,11 @@ int augx_batch_paths(augx_decoder *d, augx_batch *b, augx_path *out) {
         int64_t po = b->L.off[p] / 8 + 64 * (int64_t)p;
         if (cnt > 0) HIP_TRY(hipMemcpy(rec.data(), V.pathRec + po * 3, sizeof(int32_t) * 3 * (size_t)cnt, hipMemcpyDeviceToHost));
         out[p].states = (augx_state *)malloc(sizeof(augx_state) * (size_t)(cnt > 0 ? cnt : 1));
+        if (!out[p].states) {
+            for (int q = 0; q < p; q++) augx_path_free(&out[q]);
+            setLastError("augx_batch_paths: out of host memory");
+            return AUGX_E_NOMEM;
+        }
         out[p].n_states = cnt;
         for (int i = 0; i < cnt; i++) {
             const int32_t *r = &rec[(size_t)(cnt - 1 - i) * 3];

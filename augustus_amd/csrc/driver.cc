@@ -3,7 +3,10 @@
 // NAMGene::doViterbiPiecewise / getNextCutEndPoint / tryFindCutEndPoint (src/namgene.cc:516-676, 973-1210)
 // for the ab-initio path.  Host C++; every Viterbi decode (pieces AND cut-finding exam windows) goes through
 // augx_decode_batch, i.e. runs on the GPU.
+#include <dirent.h>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,15 +55,22 @@ struct Decoded { std::vector<PathState> path; double lnv; int status; };
 
 struct Session {
     augx_model *model = nullptr;
-    augx_decoder *dec = nullptr;
+    std::vector<augx_decoder *> decs; // one per device in use (AUGX_DEVICES; default: every visible device)
     OutputOptions oo;
     int geneid = 1;
     std::string err;
 
-    // decode a set of pieces on the GPU
+    void destroy() {
+        for (augx_decoder *d : decs) augx_decoder_destroy(d);
+        decs.clear();
+        if (model) augx_model_destroy(model);
+        model = nullptr;
+    }
+    // decode a set of pieces on the GPUs: longest-first bin packing over the devices, one host thread per device, batches
+    // bounded by each device's free memory (sharded.cc)
     bool decode(const std::vector<augx_piece> &pieces, std::vector<Decoded> &out) {
         std::vector<augx_path> paths(pieces.size());
-        int rc = augx_decode_batch(dec, pieces.data(), (int)pieces.size(), paths.data());
+        int rc = augx_decode_sharded(decs.data(), (int)decs.size(), pieces.data(), (int)pieces.size(), paths.data());
         if (rc) { err = augx_last_error(); return false; }
         out.resize(pieces.size());
         for (size_t i = 0; i < pieces.size(); i++) {
@@ -97,6 +107,114 @@ long tryFindCutEndPoint(const std::vector<PathState> &path, long examStart, long
     return maxirend - maxirbegin > 0 ? (maxirend + maxirbegin) / 2 : -1;
 }
 
+
+// soft-masked runs [first, last] of a record (reference SequenceFeatureCollection::prepare, src/extrinsicinfo.cc:1696-1724:
+// one nonexonpart hint of source RM per lower-case run)
+std::vector<std::pair<long, long>> lowerRuns(const char *seq, long n) {
+    std::vector<std::pair<long, long>> runs;
+    for (long i = 0; i < n;) {
+        if (seq[i] >= 'a' && seq[i] <= 'z') {
+            long e = i;
+            while (e + 1 < n && seq[e + 1] >= 'a' && seq[e + 1] <= 'z') e++;
+            runs.push_back({i, e});
+            i = e + 1;
+        } else
+            i++;
+    }
+    return runs;
+}
+
+// The reference builds the soft-masking hints on the whole record and hands a piece [from, to] only the features that END
+// inside [from, to] (SequenceFeatureCollection(sfc, from, to), src/extrinsicinfo.cc:147-160; pieces: src/namgene.cc:607,
+// exam windows: to = examEnd + 10000, src/namgene.cc:1051).  A lower-case run that continues beyond `limit` therefore
+// gives no bonus inside the piece: the piece is decoded from a copy whose trailing run is upper-cased.
+// Returns the pointer to decode from (the record itself, or the copy appended to `copies`).
+const char *pieceSequence(const std::string &seq, long begin, long end, long limit, std::vector<std::string> &copies) {
+    const long n = (long)seq.size();
+    auto lower = [&](long i) { return seq[i] >= 'a' && seq[i] <= 'z'; };
+    if (end + 1 >= n || !lower(end) || !lower(end + 1)) return seq.data() + begin;
+    long e = end + 1;
+    while (e + 1 < n && e <= limit && lower(e + 1)) e++;
+    if (e <= limit) return seq.data() + begin; // the run ends within the limit: its feature is kept
+    copies.emplace_back(seq, (size_t)begin, (size_t)(end - begin + 1));
+    std::string &c = copies.back();
+    for (long i = (long)c.size() - 1; i >= 0 && c[i] >= 'a' && c[i] <= 'z'; i--) c[i] = (char)(c[i] - 'a' + 'A');
+    return c.data();
+}
+
+struct RecordView { const char *name; const char *seq; long len; };
+struct PieceOut { int rec; long begin, end; const std::vector<PathState> *path; int status; };
+
+// ---- gene structures + GFF for all records, in input order; gene ids are global and sequential over the run (reference
+//      NAMGene::doViterbiPiecewise, src/namgene.cc:526,626-650; block headers src/augustus.cc:395-398).  `pieces` may
+//      arrive in any order (they were decoded on several devices): they are gathered by (record, begin) first.
+//      Returns 0, or 1 when the very first record failed (the reference then aborts the run, src/augustus.cc:425-440).
+int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<RecordView> &recs, std::vector<PieceOut> pieces,
+                  int verbosity, int &geneid, std::string &out, std::string &err, std::string &fatal) {
+    std::stable_sort(pieces.begin(), pieces.end(), [](const PieceOut &a, const PieceOut &b) { return a.rec != b.rec ? a.rec < b.rec : a.begin < b.begin; });
+    size_t pi = 0;
+    int successful = 0;
+    char buf[256];
+    for (size_t r = 0; r < recs.size(); r++) {
+        const RecordView &rec = recs[r];
+        if (verbosity) {
+            out += "#\n# ----- prediction on sequence number " + std::to_string(r + 1) + " (length = " + std::to_string(rec.len) + ", name = " + rec.name + ") -----\n#\n";
+        }
+        {
+            const std::string st = M.opt.get("strand", "both");
+            const bool fw = st == "forward", bw = st == "backward"; // (other values fall back to both, see genes.cc)
+            out += "# Predicted genes for sequence number " + std::to_string(r + 1) + " on " + (fw ? "forward strand" : bw ? "reverse strand" : "both strands") + "\n";
+        }
+        bool any = false;
+        std::string errmsg;
+        std::vector<std::pair<long, long>> runs, pieceRuns;
+        bool haveRuns = false;
+        for (; pi < pieces.size() && pieces[pi].rec == (int)r; pi++) {
+            const PieceOut &pr = pieces[pi];
+            if (pr.status != 0) {
+                errmsg = pr.status == AUGX_E_UNSUPPORTED ? "piece outside what the MI355X path decodes"
+                         : pr.status == AUGX_E_NOPATH    ? "No feasible path found in HMM"
+                                                         : "device decode failed (HIP error or kernel abort; not a property of the input)";
+                continue;
+            }
+            std::vector<Transcript> txs;
+            try {
+                txs = filterTranscripts(M, projectOntoGeneSequence(M, *pr.path, pr.end - pr.begin + 1));
+            } catch (std::exception &e) { errmsg = e.what(); continue; }
+            std::vector<GeneOut> genes = groupToGenes(txs);
+            for (GeneOut &g : genes) {
+                g.seqname = rec.name;
+                if (oo.uniqueGeneId) { snprintf(buf, sizeof buf, "%.30s.g%d", rec.name, geneid); g.id = buf; }
+                else g.id = "g" + std::to_string(geneid);
+                int tid = 1;
+                for (Transcript &t : g.transcripts) {
+                    t.shift(pr.begin);
+                    t.seqname = rec.name;
+                    t.id = "t" + std::to_string(tid++);
+                    t.geneid = g.id;
+                }
+                geneid++;
+                any = true;
+            }
+            if (oo.evidence && oo.softmasking && !genes.empty()) {
+                // the hint groups of the evidence block: the soft-masked runs that END inside the piece (see pieceSequence)
+                if (!haveRuns) { runs = lowerRuns(rec.seq, rec.len); haveRuns = true; }
+                pieceRuns.clear();
+                for (auto &ru : runs)
+                    if (ru.second >= pr.begin && ru.second <= pr.end) pieceRuns.push_back(ru);
+            }
+            printGeneList(out, genes, rec.seq, rec.len, oo, &pieceRuns);
+        }
+        if (!errmsg.empty()) {
+            if (successful < 1) { fatal = errmsg; return 1; }
+            err += "\n augustus: ERROR\n\t" + errmsg + "\n\n";
+        } else
+            successful++;
+        if (!any) out += "# (none)\n";
+    }
+    return 0;
+}
+
 } // namespace
 
 extern "C" int augx_main(int argc, const char *const *argv) {
@@ -105,8 +223,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     for (int i = 0; i < argc; i++) { commandline += argv[i]; if (i < argc - 1) commandline += " "; }
     auto fail = [&](const std::string &msg) {
         std::cerr << "\n" << (argc > 0 ? argv[0] : "augustus") << ": ERROR\n\t" << msg << "\n\n";
-        if (S.dec) augx_decoder_destroy(S.dec);
-        if (S.model) augx_model_destroy(S.model);
+        S.destroy();
         return 1;
     };
     if (argc <= 1) {
@@ -134,16 +251,43 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         else
             return fail("Error: 2 query files given: " + queryfile + " and " + s + ".\nparameter names must start with '--'");
     }
-    if (species.empty()) return fail("No species specified. Type \"augustus --species=help\" to see available species.");
+    // config directory: command line > environment > relative to the executable, <dir of the binary>/../config
+    // (reference src/properties.cc:116-135, findLocationOfSelfBinary :648-684)
     if (configPath.empty()) {
         const char *e = getenv("AUGUSTUS_CONFIG_PATH");
         if (e) configPath = e;
-        else return fail("AUGUSTUS_CONFIG_PATH is not set and --AUGUSTUS_CONFIG_PATH was not given.");
+        else {
+            char self[4096];
+            ssize_t k = readlink("/proc/self/exe", self, sizeof self - 1);
+            if (k <= 0) return fail("/proc/self/exe not found.\nPlease specify environment variable or parameter AUGUSTUS_CONFIG_PATH.");
+            configPath.assign(self, (size_t)k);
+            size_t pos = configPath.find_last_of('/');
+            if (pos != std::string::npos && pos > 0) pos = configPath.find_last_of('/', pos - 1);
+            if (pos != std::string::npos) configPath.resize(pos);
+            configPath += "/config";
+        }
     }
     if (configPath.back() != '/') configPath += '/';
     struct stat sb;
     if (stat(configPath.c_str(), &sb) == -1 || !S_ISDIR(sb.st_mode))
         return fail(configPath + " is not a directory. Could not locate directory AUGUSTUS_CONFIG_PATH.");
+    if (species.empty()) return fail("No species specified. Type \"augustus --species=help\" to see available species.");
+    if (species == "help") { // reference: HelpException(SPECIES_LIST) -> message on stderr, exit code 0 (src/augustus.cc:240-242)
+        std::vector<std::string> names;
+        if (DIR *d = opendir((configPath + "species").c_str())) {
+            while (struct dirent *e = readdir(d)) {
+                std::string nm = e->d_name;
+                struct stat s2;
+                if (nm[0] != '.' && stat((configPath + "species/" + nm + "/" + nm + "_parameters.cfg").c_str(), &s2) == 0) names.push_back(nm);
+            }
+            closedir(d);
+        }
+        std::sort(names.begin(), names.end());
+        std::cerr << "usage:\naugustus [parameters] --species=SPECIES queryfilename\n\nwhere SPECIES is one of the following identifiers (parameter sets found in "
+                  << configPath << "species)\n\n";
+        for (auto &nm : names) std::cerr << nm << "\n";
+        return 0;
+    }
     {   // unknown parameters are an error (reference src/properties.cc:225-319, config/parameters/aug_cmdln_parameters.json)
         std::ifstream pj((configPath + "parameters/aug_cmdln_parameters.json").c_str());
         if (pj) {
@@ -160,7 +304,6 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     int rc = augx_model_load(configPath.c_str(), species.c_str(), (int)cmd.size(), names.data(), values.data(), &S.model);
     if (rc) return fail(augx_last_error());
     const Model &M = S.model->m;
-    const augx_tables &T = M.t;
     S.oo.fromModel(M);
     if (queryfile.empty()) return fail("No query file specified. Type \"augustus\" for help.");
     if (M.opt.getInt("sample", 0) > 0)
@@ -205,13 +348,29 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     }
     if (verbosity > 0) std::cout << "# We have hints for 0 sequences and for 0 of the sequences in the input set." << std::endl;
 
-    int device = 0;
-    if (const char *e = getenv("AUGX_DEVICE")) device = atoi(e);
-    rc = augx_decoder_create(S.model, device, &S.dec);
-    if (rc) { restore(); return fail(augx_last_error()); }
+    {   // ---- devices: every visible GPU, or the ones named by AUGX_DEVICES ("0,2,5"; a single number N = the first N);
+        //      AUGX_DEVICE (one index) is kept for single-device runs
+        std::vector<int> devs;
+        const int ndev = augx_device_count();
+        if (const char *e = getenv("AUGX_DEVICES")) {
+            std::string v(e);
+            if (v.find(',') == std::string::npos) { int k = atoi(e); for (int i = 0; i < k; i++) devs.push_back(i); }
+            else { std::stringstream ss(v); std::string tok; while (std::getline(ss, tok, ',')) if (!tok.empty()) devs.push_back(atoi(tok.c_str())); }
+        } else if (const char *e1 = getenv("AUGX_DEVICE"))
+            devs.push_back(atoi(e1));
+        else
+            for (int i = 0; i < ndev; i++) devs.push_back(i);
+        if (devs.empty()) devs.push_back(0); // (no device: augx_decoder_create reports it -- there is no CPU decode path)
+        for (int dv : devs) {
+            augx_decoder *d = nullptr;
+            rc = augx_decoder_create(S.model, dv, &d);
+            if (rc) { restore(); return fail(augx_last_error()); }
+            S.decs.push_back(d);
+        }
+    }
 
     const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
-    if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); return 1; }
+    if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); S.destroy(); return 1; }
     // --predictionStart / --predictionEnd: predict on a piece of the first sequence only and shift the printed coordinates
     // (reference cutRelevantPiece, src/augustus.cc:552-602)
     if ((M.opt.has("predictionStart") || M.opt.has("predictionEnd")) && !recs.empty()) {
@@ -239,10 +398,11 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         } else if (ps < 0 && pe < 0 && pe == ps)
             S.oo.offset = -ps - 1;
     }
+    const bool soft = S.oo.softmasking;
 
     // ---- phase 1: find the cut points of all records (reference src/namgene.cc:973-1133).  Inside a record the cuts are a
     //      serial chain (the next exam window starts where the last piece ended), but records are independent: every round
-    //      decodes the pending exam window of EVERY unfinished record in one batch.
+    //      decodes the pending exam window of EVERY unfinished record, fanned over the devices.
     struct PieceRef { int rec; long begin, end; int initKind, termKind; };
     struct CutState {
         long beginPos = 0;
@@ -250,10 +410,11 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         int attempt = 0;
         long examChunk = 0, es = 0, ee = 0;
         bool done = false;
+        int failStatus = 0;             // an exam window of this record could not be decoded: the record's error
     };
     std::vector<std::vector<PieceRef>> recPieces(recs.size());
+    std::vector<CutState> cs(recs.size());
     {
-        std::vector<CutState> cs(recs.size());
         auto pushPiece = [&](size_t r, long endPos) {
             const long seqlen = (long)recs[r].seq.size();
             CutState &c = cs[r];
@@ -270,6 +431,8 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (;;) {
             std::vector<augx_piece> ex;
             std::vector<size_t> who;
+            std::vector<std::string> copies;
+            copies.reserve(recs.size());
             for (size_t r = 0; r < recs.size(); r++) {
                 CutState &c = cs[r];
                 const long seqlen = (long)recs[r].seq.size();
@@ -290,7 +453,8 @@ extern "C" int augx_main(int argc, const char *const *argv) {
                     if (c.es < c.beginPos) { c.ee += c.beginPos - c.es; c.es = c.beginPos; }
                 }
                 augx_piece p;
-                p.seq = recs[r].seq.data() + c.es; p.len = c.ee - c.es + 1; p.init_kind = c.prevInit; p.term_kind = c.prevTerm;
+                p.seq = soft ? pieceSequence(recs[r].seq, c.es, c.ee, c.ee + 10000, copies) : recs[r].seq.data() + c.es;
+                p.len = c.ee - c.es + 1; p.init_kind = c.prevInit; p.term_kind = c.prevTerm;
                 ex.push_back(p);
                 who.push_back(r);
             }
@@ -302,7 +466,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
                 CutState &c = cs[r];
                 const long seqlen = (long)recs[r].seq.size();
                 const long gapStart = 1, gapEnd = seqlen;
-                if (dd[k].status != 0) { restore(); return fail("No feasible path found in HMM"); }
+                if (dd[k].status != 0) { c.failStatus = dd[k].status; c.done = true; continue; } // the record's error (reported in input order below)
                 long cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, true, gapStart, gapEnd, true);
                 if (cut == -1 && c.attempt == 0) { c.attempt = 1; continue; } // once more with a window twice as long
                 if (cut == -1) {
@@ -316,97 +480,48 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         }
     }
     std::vector<PieceRef> allPieces;
-    for (auto &v : recPieces) allPieces.insert(allPieces.end(), v.begin(), v.end());
+    for (size_t r = 0; r < recs.size(); r++)
+        if (!cs[r].failStatus) allPieces.insert(allPieces.end(), recPieces[r].begin(), recPieces[r].end());
+    if (M.opt.getBool("progress", false))
+        for (auto &pr : allPieces)
+            std::cerr << "examining piece " << pr.begin + S.oo.offset + 1 << ".." << pr.end + S.oo.offset + 1 << " (" << (pr.end - pr.begin + 1) << " bp)" << std::endl;
 
-    // ---- phase 2: decode all pieces in batches bounded by a slot budget.  (Taking the batches in turn on two decoders /
-    //      HIP streams, as bench.py does with its resident batches, was measured here and does not pay: genome pieces are
-    //      maxDNAPieceSize long, the trellis kernel's time is set by the piece length, and two half-size batches in flight
-    //      keep no more compute units busy than one full-size batch.)
+    // ---- phase 2: decode all pieces, sharded over the devices (longest first), each device in batches bounded by its memory
     std::vector<Decoded> decoded(allPieces.size());
     {
-        long budget = (long)augx_decoder_batch_capacity(S.dec); // bases per batch: what the free HBM holds, at most 128 Mbp
-        if (const char *e = getenv("AUGX_BATCH_BASES")) budget = atol(e);
-        size_t i = 0;
-        while (i < allPieces.size()) {
-            std::vector<augx_piece> batch;
-            long total = 0;
-            size_t j = i;
-            while (j < allPieces.size() && (batch.empty() || total + (allPieces[j].end - allPieces[j].begin + 1) <= budget)) {
-                augx_piece p;
-                p.seq = recs[allPieces[j].rec].seq.data() + allPieces[j].begin;
-                p.len = allPieces[j].end - allPieces[j].begin + 1;
-                p.init_kind = allPieces[j].initKind;
-                p.term_kind = allPieces[j].termKind;
-                batch.push_back(p);
-                total += p.len;
-                j++;
-            }
-            std::vector<Decoded> dd;
-            if (!S.decode(batch, dd)) { restore(); return fail(S.err); }
-            for (size_t k = 0; k < dd.size(); k++) decoded[i + k] = std::move(dd[k]);
-            i = j;
+        std::vector<augx_piece> ps(allPieces.size());
+        std::vector<std::string> copies;
+        copies.reserve(allPieces.size());
+        for (size_t i = 0; i < allPieces.size(); i++) {
+            const PieceRef &pr = allPieces[i];
+            ps[i].seq = soft ? pieceSequence(recs[pr.rec].seq, pr.begin, pr.end, pr.end, copies) : recs[pr.rec].seq.data() + pr.begin;
+            ps[i].len = pr.end - pr.begin + 1;
+            ps[i].init_kind = pr.initKind;
+            ps[i].term_kind = pr.termKind;
         }
+        if (!ps.empty() && !S.decode(ps, decoded)) { restore(); return fail(S.err); }
     }
 
-    // ---- phase 3: gene structures + GFF, in input order (gene ids are global and sequential, src/namgene.cc:526)
-    size_t pi = 0;
-    int successful = 0;
-    for (size_t r = 0; r < recs.size(); r++) {
-        const Record &rec = recs[r];
-        if (verbosity)
-            std::cout << "#\n# ----- prediction on sequence number " << (r + 1) << " (length = " << rec.seq.size()
-                      << ", name = " << rec.name << ") -----" << std::endl << "#" << std::endl;
-        {
-            const std::string st = M.opt.get("strand", "both");
-            const bool fw = st == "forward", bw = st == "backward"; // (other values fall back to both, see genes.cc)
-            std::cout << "# Predicted genes for sequence number " << (r + 1) << " on " << (fw ? "forward strand" : bw ? "reverse strand" : "both strands") << std::endl;
-        }
-        bool any = false;
-        std::string errmsg;
-        for (; pi < allPieces.size() && allPieces[pi].rec == (int)r; pi++) {
-            const PieceRef &pr = allPieces[pi];
-            const Decoded &d = decoded[pi];
-            if (d.status != 0) {
-                errmsg = d.status == AUGX_E_UNSUPPORTED
-                             ? "piece outside what the MI355X path decodes"
-                             : "No feasible path found in HMM";
-                continue;
-            }
-            std::vector<Transcript> txs;
-            try {
-                txs = filterTranscripts(M, projectOntoGeneSequence(M, d.path, pr.end - pr.begin + 1));
-            } catch (std::exception &e) { errmsg = e.what(); continue; }
-            std::vector<GeneOut> genes = groupToGenes(txs);
-            for (GeneOut &g : genes) {
-                g.seqname = rec.name;
-                if (S.oo.uniqueGeneId) { char buf[64]; snprintf(buf, sizeof buf, "%.30s.g%d", rec.name.c_str(), S.geneid); g.id = buf; }
-                else g.id = "g" + std::to_string(S.geneid);
-                int tid = 1;
-                for (Transcript &t : g.transcripts) {
-                    t.shift(pr.begin);
-                    t.seqname = rec.name;
-                    t.id = "t" + std::to_string(tid++);
-                    t.geneid = g.id;
-                }
-                S.geneid++;
-                any = true;
-            }
-            std::string text;
-            printGeneList(text, genes, rec.seq.data(), (long)rec.seq.size(), S.oo);
-            std::cout << text;
-        }
-        if (!errmsg.empty()) {
-            if (successful < 1) { restore(); return fail(errmsg); }
-            std::cerr << "\n augustus: ERROR\n\t" << errmsg << "\n\n";
-        } else
-            successful++;
-        if (!any) std::cout << "# (none)" << std::endl;
+    // ---- phase 3: gene structures + GFF, in input order
+    std::vector<RecordView> rv;
+    for (auto &r : recs) rv.push_back({r.name.c_str(), r.seq.data(), (long)r.seq.size()});
+    std::vector<PieceOut> po;
+    static const std::vector<PathState> noPath;
+    for (size_t i = 0; i < allPieces.size(); i++) po.push_back({allPieces[i].rec, allPieces[i].begin, allPieces[i].end, &decoded[i].path, decoded[i].status});
+    for (size_t r = 0; r < recs.size(); r++)
+        if (cs[r].failStatus) po.push_back({(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, cs[r].failStatus});
+    std::string text, errText, fatal;
+    if (formatRecords(M, S.oo, rv, po, verbosity, S.geneid, text, errText, fatal)) {
+        std::cout << text;
+        std::cerr << errText;
+        restore();
+        return fail(fatal);
     }
-    (void)T;
+    std::cout << text;
+    std::cerr << errText;
     std::cout << "# command line:" << std::endl << "# " << commandline << std::endl;
     restore();
-    augx_decoder_destroy(S.dec);
-    augx_model_destroy(S.model);
+    S.destroy();
     return 0;
 }
 
@@ -429,9 +544,42 @@ extern "C" int augx_format_gff(const augx_model *m, const char *name, const char
             for (Transcript &t : g.transcripts) { t.seqname = name; t.id = "t" + std::to_string(tid++); t.geneid = g.id; }
         }
         std::string text;
-        printGeneList(text, genes, seq, (long)len, oo);
+        printGeneList(text, genes, seq, (long)len, oo, nullptr);
         if (n_genes) *n_genes = (int)genes.size();
         if ((int64_t)text.size() + 1 > out_cap) { setLastError("augx_format_gff: output buffer too small"); return AUGX_E_ARG; }
+        memcpy(out, text.c_str(), text.size() + 1);
+        return AUGX_OK;
+    } catch (std::exception &e) {
+        setLastError(e.what());
+        return AUGX_E_CONFIG;
+    }
+}
+
+// ---- the ordered gather of a sharded run on its own: pieces of several records, decoded anywhere and handed over in any
+//      order, become the prediction part of the `augustus` output with global gene numbering in input order.
+extern "C" int augx_format_records(const augx_model *m, int n_records, const char *const *names, const char *const *seqs,
+                                   const int64_t *lens, int n_pieces, const augx_piece_result *pieces, char *out, int64_t out_cap) {
+    if (!m || n_records < 0 || n_pieces < 0 || !out || (n_records && (!names || !seqs || !lens)) || (n_pieces && !pieces)) {
+        setLastError("augx_format_records: bad argument");
+        return AUGX_E_ARG;
+    }
+    try {
+        OutputOptions oo;
+        oo.fromModel(m->m);
+        std::vector<RecordView> rv;
+        for (int r = 0; r < n_records; r++) rv.push_back({names[r], seqs[r], (long)lens[r]});
+        std::vector<std::vector<PathState>> paths(n_pieces);
+        std::vector<PieceOut> po;
+        for (int i = 0; i < n_pieces; i++) {
+            if (pieces[i].record < 0 || pieces[i].record >= n_records) { setLastError("augx_format_records: bad record index"); return AUGX_E_ARG; }
+            for (int k = 0; k < pieces[i].n_states; k++) paths[i].push_back({pieces[i].states[k].begin, pieces[i].states[k].end, pieces[i].states[k].type});
+            po.push_back({pieces[i].record, (long)pieces[i].begin, (long)pieces[i].end, &paths[i], pieces[i].status});
+        }
+        int geneid = 1;
+        std::string text, errText, fatal;
+        int rc = formatRecords(m->m, oo, rv, po, 1, geneid, text, errText, fatal);
+        if (rc) { setLastError(fatal); return AUGX_E_NOPATH; }
+        if ((int64_t)text.size() + 1 > out_cap) { setLastError("augx_format_records: output buffer too small"); return AUGX_E_ARG; }
         memcpy(out, text.c_str(), text.size() + 1);
         return AUGX_OK;
     } catch (std::exception &e) {

@@ -288,19 +288,21 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
     }
 }
 
-void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o) {
+void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o,
+                   const std::vector<std::pair<long, long>> *givenRuns) {
     // soft-masked runs of the input sequence = the hint groups of the evidence block
-    std::vector<std::pair<long, long>> rmRuns;
-    if (o.evidence && o.softmasking && seq && !genes.empty())
+    std::vector<std::pair<long, long>> ownRuns;
+    if (!givenRuns && o.evidence && o.softmasking && seq && !genes.empty())
         for (long i = 0; i < seqlen;) {
             if (seq[i] >= 'a' && seq[i] <= 'z') {
                 long e = i;
                 while (e + 1 < seqlen && seq[e + 1] >= 'a' && seq[e + 1] <= 'z') e++;
-                rmRuns.push_back({i, e});
+                ownRuns.push_back({i, e});
                 i = e + 1;
             } else
                 i++;
         }
+    const std::vector<std::pair<long, long>> &rmRuns = givenRuns ? *givenRuns : ownRuns;
     for (const GeneOut &g : genes) {
         long minB = 0x7fffffffffffffffL, maxE = 0;
         for (const Transcript &t : g.transcripts) { minB = std::min(minB, t.geneBegin()); maxE = std::max(maxE, t.geneEnd()); }

@@ -62,8 +62,11 @@ std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vecto
 std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs);
 // group into genes (one path => no overlaps => one transcript per gene), sorted by coding start
 std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs);
-// print the genes of one piece.  seq = the WHOLE input sequence (lower/upper case irrelevant), offset-free coordinates
-void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o);
+// print the genes of one piece.  seq = the WHOLE input sequence (lower/upper case irrelevant), offset-free coordinates.
+// rmRuns: the soft-masked runs [first, last] that are hint groups of this piece (evidence block); NULL = every lower-case
+// run of seq (a record decoded as one piece)
+void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o,
+                   const std::vector<std::pair<long, long>> *rmRuns = nullptr);
 
 std::string translateCDS(const char *codingSeq);
 

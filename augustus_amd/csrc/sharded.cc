@@ -1,0 +1,89 @@
+// sharded.cc -- multi-GPU decode of independent pieces: one decoder (= one device, one HIP stream) and one host thread per
+// GPU, pieces assigned by longest-processing-time-first bin packing (cost = length), results gathered in input order.
+// There is no exchange step in the DP (contigs and pieces are independent), hence no collective: the
+// "gather" is the host threads writing their slots of the caller's result array.
+// Replaces nothing of the reference one to one (it is single-threaded); it is the fan-out of NAMGene::doViterbiPiecewise's
+// piece loop (reference src/namgene.cc:575-676) and of the cut finder's exam windows over devices.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <numeric>
+#include <string>
+#include <thread>
+#include <vector>
+#include "capi_internal.h"
+
+using namespace augx;
+
+extern "C" {
+
+// bin_of[i] = bin of item i.  Items sorted by decreasing length (ties: input order), each to the least loaded bin
+// (ties: lowest index): deterministic.
+int augx_partition_lpt(const int64_t *lens, int n, int n_bins, int32_t *bin_of) {
+    if (!lens || !bin_of || n < 0 || n_bins < 1) { setLastError("augx_partition_lpt: bad argument"); return AUGX_E_ARG; }
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    std::vector<int64_t> load(n_bins, 0);
+    for (int i : order) {
+        int best = 0;
+        for (int b = 1; b < n_bins; b++)
+            if (load[b] < load[best]) best = b;
+        bin_of[i] = best;
+        load[best] += lens[i] > 0 ? lens[i] : 0;
+    }
+    return AUGX_OK;
+}
+
+int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, augx_path *out) {
+    if (!decs || n_dec < 1 || !pieces || n < 0 || !out) { setLastError("augx_decode_sharded: bad argument"); return AUGX_E_ARG; }
+    for (int i = 0; i < n; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = AUGX_E_ARG; out[i].ln_viterbi = 0; }
+    if (n == 0) return AUGX_OK;
+    std::vector<int64_t> lens(n);
+    for (int i = 0; i < n; i++) lens[i] = pieces[i].len;
+    std::vector<int32_t> bin(n);
+    int rc = augx_partition_lpt(lens.data(), n, n_dec, bin.data());
+    if (rc) return rc;
+    std::vector<int> rcs(n_dec, 0);
+    std::vector<std::string> errs(n_dec);
+    auto work = [&](int d) {
+        // pieces of this device in input order, decoded in batches bounded by what the device's free memory holds
+        std::vector<int> mine;
+        for (int i = 0; i < n; i++)
+            if (bin[i] == d) mine.push_back(i);
+        if (mine.empty()) return;
+        int64_t budget = augx_decoder_batch_capacity(decs[d]);
+        if (const char *e = getenv("AUGX_BATCH_BASES")) budget = atol(e);
+        size_t i = 0;
+        while (i < mine.size()) {
+            std::vector<augx_piece> batch;
+            int64_t total = 0;
+            size_t j = i;
+            while (j < mine.size() && (batch.empty() || total + pieces[mine[j]].len <= budget)) {
+                batch.push_back(pieces[mine[j]]);
+                total += pieces[mine[j]].len;
+                j++;
+            }
+            std::vector<augx_path> res(batch.size());
+            int r = augx_decode_batch(decs[d], batch.data(), (int)batch.size(), res.data());
+            if (r) { rcs[d] = r; errs[d] = augx_last_error(); return; }
+            for (size_t k = 0; k < batch.size(); k++) out[mine[i + k]] = res[k];
+            i = j;
+        }
+    };
+    if (n_dec == 1)
+        work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_dec; d++) th.emplace_back(work, d);
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < n_dec; d++)
+        if (rcs[d]) {
+            setLastError(errs[d]);
+            for (int i = 0; i < n; i++) augx_path_free(&out[i]);
+            return rcs[d];
+        }
+    return AUGX_OK;
+}
+}

@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- Mbp of DNA decoded per second (BASELINE.json metric), ab-initio human model, on N MI355X.
 
-One "step" = one pass of the hot path (prep -> trellis -> back-trace, all on the GPU) over one batch of synthetic
-input that is already resident in HBM: BASELINE.json configs[2], 100 contigs x 1 Mbp of upper-case uniform-random
-DNA per GPU (weak scaling: every rank decodes its own 100 contigs; contigs are independent, there is no data-path
-collective).  Launch:  python bench.py [--gpus N --steps K --warmup W]   (N>1 via torch.distributed.run).
+One "step" = one pass of the hot path (prep -> candidates -> trellis -> back-trace, all on the GPU) over one batch of
+synthetic input that is already resident in HBM: BASELINE.json configs[2], 100 contigs x 1 Mbp of upper-case uniform-random
+DNA.  `value` (the headline) is WEAK scaling: every rank decodes its own 100 contigs per step.  The same run also times the
+STRONG-scaling form of config 3 as it is written (100 contigs in total, split over the ranks longest-first) and reports it
+under "strong"; and, at N = 1, the end-to-end rates of the drop-in ("e2e": host buffers -> augx_decode_batch -> paths ->
+genes -> GFF text; "cli": the augustus executable, FASTA file in, GFF out) and the reference's CPU path ("cpu_baseline").
+Contigs are independent: there is no data-path collective, ranks only meet in the barriers around the timed regions.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+  N > 1: one process per GPU.  Under torch.distributed.run (RANK/WORLD_SIZE in the environment) this process is one rank;
+  started plainly with --gpus N > 1 it re-launches itself under torch.distributed.run with N ranks on 127.0.0.1.
 """
 import argparse
+import ctypes
 import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -18,6 +27,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SEED0 = 12345
 
 
 def synth_contigs(n_contigs, length, seed0):
@@ -29,29 +40,152 @@ def synth_contigs(n_contigs, length, seed0):
     return out
 
 
-def cpu_baseline(cfg, sample_bp):
-    """The reference's own CPU path (oracle/_ref/augustus_ref, 1 thread) on a bounded sample of the same workload."""
-    from helpers import REF_AUGUSTUS, write_fasta, twin_decode
-    import tempfile
-    seq = synth_contigs(1, sample_bp, 999)[0].decode()
-    if os.path.exists(REF_AUGUSTUS):
-        with tempfile.TemporaryDirectory() as d:
-            fa = os.path.join(d, "s.fa")
-            write_fasta(fa, [("sample", seq)])
-            env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg)
-            t0 = time.time()
-            r = subprocess.run([REF_AUGUSTUS, "--species=human", fa], capture_output=True, env=env)
-            dt = time.time() - t0
-            if r.returncode == 0:
-                return {"value": sample_bp / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "reference",
-                        "sample": "1 contig x %d bp uniform-random DNA, --species=human, reference binary wall-clock incl. parameter load" % sample_bp}
+def rank_contigs(mode, rank, world, n_contigs, length, batch=0):
+    """The contigs rank `rank` of `world` decodes.
+    weak:   its own n_contigs contigs (seeds disjoint from every other rank's and batch's)
+    strong: its share of the SAME n_contigs contigs (seeds SEED0..SEED0+n-1), split longest-first over the ranks by the
+            partition the product's multi-GPU path uses (augx_partition_lpt)"""
+    if mode == "weak":
+        return synth_contigs(n_contigs, length, SEED0 + 1000 * rank + 17 * batch)
     import augustus_amd as ax
-    m = ax.Model(cfg, "human")
-    t0 = time.time()
-    twin_decode(m.tables_ptr, seq, m.n_states)
-    dt = time.time() - t0
-    return {"value": sample_bp / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port",
-            "sample": "1 contig x %d bp uniform-random DNA, oracle/ghmm_twin.cc" % sample_bp}
+    bins = ax.partition_lpt([length] * n_contigs, world)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for i, b in enumerate(bins):
+        if b == rank:
+            rng = np.random.default_rng(SEED0 + i)
+            out.append(lut[rng.integers(0, 4, size=length, dtype=np.uint8)].tobytes())
+    return out
+
+
+def max_over_ranks(dt, dist):
+    if dist is None:
+        return dt
+    import torch
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, sample_bp, host_sample_bp):
+    """The reference's own CPU path (oracle/_ref/augustus_ref, built from /root/reference by oracle/Makefile) on a bounded
+    sample of the same workload: one process pinned to one core (the headline x-factor), and one pinned process per host core
+    on disjoint contigs (the whole-host figure; the reference has no threading).  The parameter-load time (the same binary on
+    a 2 kb record) is measured and subtracted."""
+    from helpers import REF_AUGUSTUS, write_fasta, twin_decode
+    cores = sorted(os.sched_getaffinity(0))
+    if not os.path.exists(REF_AUGUSTUS):
+        import augustus_amd as ax
+        m = ax.Model(cfg, "human")
+        seq = synth_contigs(1, min(sample_bp, 300000), 999)[0].decode()
+        t0 = time.time()
+        twin_decode(m.tables_ptr, seq, m.n_states)
+        dt = time.time() - t0
+        return {"value": len(seq) / 1e6 / dt, "unit": "Mbp/s", "cores": 1, "kind": "port", "cpu": cpu_model_string(),
+                "sample": "1 contig x %d bp uniform-random DNA, oracle/ghmm_twin.cc (oracle/_ref not present)" % len(seq)}
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg)
+    with tempfile.TemporaryDirectory() as d:
+        def run(files, pin):
+            t0 = time.time()
+            ps = [subprocess.Popen(["taskset", "-c", str(c), REF_AUGUSTUS, "--species=human", f], stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, env=env) for f, c in zip(files, pin)]
+            ok = all(p.wait() == 0 for p in ps)
+            return time.time() - t0, ok
+        tiny = os.path.join(d, "tiny.fa")
+        write_fasta(tiny, [("tiny", synth_contigs(1, 2000, 998)[0].decode())])
+        t_load, _ = run([tiny], cores[:1])
+        one = os.path.join(d, "one.fa")
+        write_fasta(one, [("sample", synth_contigs(1, sample_bp, 999)[0].decode())])
+        t1, ok1 = run([one], cores[:1])
+        out = {"value": sample_bp / 1e6 / max(t1 - t_load, 1e-9), "unit": "Mbp/s", "cores": 1, "kind": "reference", "cpu": cpu_model_string(),
+               "param_load_s": t_load, "ok": ok1,
+               "sample": "1 contig x %d bp uniform-random DNA, --species=human, reference binary pinned with taskset to one core, wall-clock minus "
+                         "parameter load" % sample_bp}
+        files = []
+        for i, c in enumerate(cores):
+            f = os.path.join(d, "h%d.fa" % i)
+            write_fasta(f, [("h%d" % i, synth_contigs(1, host_sample_bp, 2000 + i)[0].decode())])
+            files.append(f)
+        tn, okn = run(files, cores)
+        out["whole_host"] = {"value": len(cores) * host_sample_bp / 1e6 / max(tn - t_load, 1e-9), "unit": "Mbp/s", "cores": len(cores), "ok": okn,
+                             "sample": "%d processes, one per host core (taskset), each 1 contig x %d bp" % (len(cores), host_sample_bp)}
+        return out
+
+
+def e2e_legs(cfg, model, local, contigs):
+    """End-to-end rates of the drop-in on this rank's contigs (FASTA in -> GFF out, model load excluded)."""
+    import augustus_amd as ax
+    L = ax.lib()
+    n = len(contigs)
+    bases = sum(len(c) for c in contigs)
+    out = {}
+    # ---- e2e: host buffers -> augx_decode_batch (H2D, all kernels, path D2H + unpack) -> genes -> GFF text
+    dec = ax.Decoder(model, local)
+    names = ["rand%03d" % i for i in range(n)]
+
+    class PR(ctypes.Structure):
+        _fields_ = [("record", ctypes.c_int32), ("status", ctypes.c_int32), ("begin", ctypes.c_int64), ("end", ctypes.c_int64),
+                    ("states", ctypes.c_void_p), ("n_states", ctypes.c_int32)]
+    P = (ax._Piece * n)()
+    for i, s in enumerate(contigs):
+        P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = s, len(s), 0, 0
+    paths = (ax._Path * n)()
+    L.augx_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.augx_format_records.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
+    buf = ctypes.create_string_buffer(256 << 20)
+    c_names = (ctypes.c_char_p * n)(*[x.encode() for x in names])
+    c_seqs = (ctypes.c_char_p * n)(*contigs)
+    c_lens = (ctypes.c_int64 * n)(*[len(c) for c in contigs])
+    best = None
+    for rep in range(2):  # (the first pass pays the one-time allocations of a fresh decoder: report the second)
+        t0 = time.perf_counter()
+        ax._check(L.augx_decode_batch(dec._h, P, n, paths))
+        t1 = time.perf_counter()
+        R = (PR * n)()
+        for i in range(n):
+            R[i].record, R[i].status, R[i].begin, R[i].end = i, paths[i].status, 0, len(contigs[i]) - 1
+            R[i].states, R[i].n_states = ctypes.cast(paths[i].states, ctypes.c_void_p), paths[i].n_states
+        ax._check(L.augx_format_records(model._h, n, c_names, c_seqs, c_lens, n, R, buf, 256 << 20))
+        t2 = time.perf_counter()
+        for i in range(n):
+            L.augx_path_free(ctypes.byref(paths[i]))
+        best = (t1 - t0, t2 - t1)
+    out["e2e"] = {"value": bases / 1e6 / (best[0] + best[1]), "unit": "Mbp/s", "decode_s": best[0], "genes_gff_s": best[1],
+                  "gff_bytes": len(buf.value),
+                  "region": "host buffers -> augx_decode_batch (H2D + all kernels + path D2H) -> gene structures -> GFF text; model load excluded"}
+    dec.close()
+    # ---- cli: the augustus executable on the same contigs as a FASTA file (includes process start, parameter load, FASTA parse)
+    exe = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as d:
+            fa = os.path.join(d, "bench.fa")
+            with open(fa, "wb") as f:
+                for nm, s in zip(names, contigs):
+                    f.write(b">" + nm.encode() + b"\n")
+                    a = np.frombuffer(s, dtype=np.uint8)
+                    k = len(a) // 60 * 60
+                    rows = np.concatenate([a[:k].reshape(-1, 60), np.full((k // 60, 1), 10, dtype=np.uint8)], axis=1)
+                    f.write(rows.tobytes())
+                    if k < len(a):
+                        f.write(a[k:].tobytes() + b"\n")
+            env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg, AUGX_DEVICES=str(local) + ",")
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "--species=human", "--outfile=" + os.path.join(d, "out.gff"), fa], capture_output=True, env=env)
+            dt = time.perf_counter() - t0
+            out["cli"] = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode,
+                          "region": "augustus --species=human bench.fa (process start, parameter load, FASTA parse, decode on 1 GPU, GFF file written)"}
+    return out
 
 
 def main():
@@ -63,10 +197,20 @@ def main():
     ap.add_argument("--contig-len", type=int, default=1000000)
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches of --contigs contigs resident per GPU; consecutive steps alternate between them on separate "
-                         "HIP streams, so the prep kernels of one step overlap the (100-workgroup) trellis kernel of the other")
-    ap.add_argument("--cpu-sample-bp", type=int, default=300000)
+                         "HIP streams, so the prep kernels of one step overlap the trellis kernel of the other")
+    ap.add_argument("--cpu-sample-bp", type=int, default=1000000)
+    ap.add_argument("--cpu-host-sample-bp", type=int, default=400000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-strong", action="store_true")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: become N ranks, one per GPU (the driver normally launches torch.distributed.run itself)
+        port = 29500 + os.getpid() % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -89,99 +233,122 @@ def main():
     cfg = config_path()
     model = ax.Model(cfg, "human")
     S = model.n_states
-    bases = a.contigs * a.contig_len
-    # one step = one pass of the decode path over one batch of --contigs contigs.  --inflight batches (different contigs) are
-    # resident; step s runs on batch s % inflight, each batch on its own decoder (HIP stream) driven by its own host
-    # thread, so that consecutive steps overlap the way consecutive batches of a genome do in the CLI driver.
-    n_fl = max(1, min(a.inflight, a.steps))
-    decs, batches = [], []
-    for i in range(n_fl):
-        d = ax.Decoder(model, local)
-        try:  # H2D upload: inputs are resident in HBM before the timed region
-            b = ax.Batch(d, synth_contigs(a.contigs, a.contig_len, 12345 + 1000 * rank + 17 * i))
-            b.decode(sync=True)          # (first decode of a batch object sizes its candidate lists and buffer: untimed;
-            b.decode(sync=True)          #  the second one gives back what the first estimate took too much)
-        except ax.AugxError as e:
-            if i == 0 or e.code not in (ax.AUGX_E_NOMEM, ax.AUGX_E_HIP):
-                raise
-            break                        # not enough free HBM for another resident batch: run with the ones we have
-        decs.append(d); batches.append(b)
-    n_fl = len(batches)
+    import threading
 
-    def sync():
+    def sync_all(decs):
         for d in decs:
             ax._check(ax.lib().augx_batch_sync(d._h))
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    import threading
-    trellis_ms, prep_ms, back_ms = [], [], []
-    lock = threading.Lock()
-    todo = [0]
+    def timed_phase(mode, n_fl_want):
+        """Resident batches for `mode`, --warmup untimed steps, EXACTLY --steps timed steps bracketed by barrier + synchronize,
+        max over ranks.  One step = one decode of one batch; step s runs on batch s % inflight, each batch on its own decoder
+        (HIP stream) driven by its own host thread, so consecutive steps overlap like consecutive batches of a genome."""
+        decs, batches = [], []
+        for i in range(max(1, min(n_fl_want, a.steps))):
+            d = ax.Decoder(model, local)
+            try:  # H2D upload: inputs are resident in HBM before the timed region
+                seqs = rank_contigs(mode, rank, world, a.contigs, a.contig_len, batch=i)
+                if not seqs:
+                    break
+                b = ax.Batch(d, seqs)
+                b.decode(sync=True)      # (first decode of a batch object sizes its candidate lists and buffer: untimed;
+                b.decode(sync=True)      #  the second one gives back what the first estimate took too much)
+            except ax.AugxError as e:
+                if i == 0 or e.code not in (ax.AUGX_E_NOMEM, ax.AUGX_E_HIP):
+                    raise
+                break                    # not enough free HBM for another resident batch: run with the ones we have
+            decs.append(d); batches.append(b)
+        ms = {"trellis": [], "prep": [], "back": []}
+        lock = threading.Lock()
+        todo = [0]
 
-    def worker(batch, n_total, record):
-        while True:
-            with lock:
-                if todo[0] >= n_total:
-                    return
-                todo[0] += 1
-            batch.decode(sync=False)
-            k = batch.kernel_ms()        # HIP events on the decoder's stream (also waits for the step)
-            if record:
+        def worker(batch, n_total, record):
+            while True:
                 with lock:
-                    trellis_ms.append(k["trellis_ms"]); prep_ms.append(k["prep_ms"]); back_ms.append(k["backtrace_ms"])
+                    if todo[0] >= n_total:
+                        return
+                    todo[0] += 1
+                batch.decode(sync=False)
+                k = batch.kernel_ms()    # HIP events on the decoder's stream (also waits for the step)
+                if record:
+                    with lock:
+                        ms["trellis"].append(k["trellis_ms"]); ms["prep"].append(k["prep_ms"]); ms["back"].append(k["backtrace_ms"])
 
-    def run_steps(n_total, record):
-        todo[0] = 0
-        ts = [threading.Thread(target=worker, args=(b, n_total, record)) for b in batches]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        def run_steps(n_total, record):
+            todo[0] = 0
+            ts = [threading.Thread(target=worker, args=(b, n_total, record)) for b in batches]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
 
-    run_steps(a.warmup, False)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(a.steps, True)             # EXACTLY --steps steps
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    # sanity: the decode produced feasible paths
-    for b in batches:
-        assert all(r.status == 0 for r in b.paths()), "decode failed"
+        run_steps(a.warmup, False)
+        sync_all(decs)
+        t0 = time.perf_counter()
+        run_steps(a.steps, True)         # EXACTLY --steps steps
+        sync_all(decs)
+        dt = max_over_ranks(time.perf_counter() - t0, dist)
+        for b in batches:                # sanity: the decode produced feasible paths
+            assert all(r.status == 0 for r in b.paths()), "decode failed"
+        bases_rank = [sum(b.lens) for b in batches]
+        info = {"dt": dt, "n_fl": len(batches), "bases_per_step_rank": bases_rank[0] if bases_rank else 0,
+                "trellis_ms": float(np.mean(ms["trellis"])) if ms["trellis"] else 0.0,
+                "prep_ms": float(np.mean(ms["prep"])) if ms["prep"] else 0.0, "back_ms": float(np.mean(ms["back"])) if ms["back"] else 0.0}
+        for b in batches:
+            b.close()
+        for d in decs:
+            d.close()
+        return info
+
+    bases = a.contigs * a.contig_len
+    weak = timed_phase("weak", a.inflight)
+    strong = None
+    if world > 1 and not a.no_strong:
+        strong = timed_phase("strong", a.inflight)
     if rank == 0:
-        ms_per_step = dt / a.steps * 1e3
-        value = world * bases * a.steps / dt / 1e6
+        ms_per_step = weak["dt"] / a.steps * 1e3
+        value = world * bases * a.steps / weak["dt"] / 1e6
         # roofline of the dominant kernel (trellis): algorithmic bytes per bp = 0.25 + 20*S (SURVEY.md 8d / DESIGN.md)
         alg_bytes = (0.25 + 20.0 * S) * bases
-        tr_s = float(np.mean(trellis_ms)) / 1e3
+        tr_s = weak["trellis_ms"] / 1e3
         achieved = alg_bytes / tr_s / 1e9
         # HBM bytes per launch of the same kernel from the PMC passes committed under profiles/ (FETCH_SIZE and
-        # WRITE_SIZE in separate rocprofv3 runs, gfx950 correction applied; see profiles/r01_hbm_traffic.json)
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tj):
-            with open(tj) as fh:
-                traffic = json.load(fh)["kTrellis"]["traffic_bytes_per_bp"] * bases
+        # WRITE_SIZE in separate rocprofv3 runs, gfx950 correction applied)
+        traffic, tsrc = None, None
+        for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            tj = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tj):
+                with open(tj) as fh:
+                    traffic = json.load(fh)["kTrellis"]["traffic_bytes_per_bp"] * bases
+                tsrc = "profiles/" + name
+                break
         out = {
             "metric": "Mbp DNA decoded/sec (whole node), ab-initio human model",
             "value": value, "unit": "Mbp/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "timed_region": "device pipeline (prep, candidates, trellis, back-trace) on HBM-resident input; see e2e / cli for the drop-in end to end",
             "config": {"workload": "synthetic uniform-random DNA, %d contigs x %d bp per GPU, --species=human ab initio (47 states, sample=0)"
-                                   % (a.contigs, a.contig_len), "pieces_in_flight_per_gpu": a.contigs * n_fl, "batches_in_flight_per_gpu": n_fl,
-                       "sharding": "contigs sharded over ranks, no data-path collective"},
+                                   % (a.contigs, a.contig_len), "pieces_in_flight_per_gpu": a.contigs * weak["n_fl"], "batches_in_flight_per_gpu": weak["n_fl"],
+                       "sharding": "contigs sharded over ranks (one process per GPU), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/r01_hbm_traffic.json)", "kernel": "kTrellis", "kernel_ms": float(np.mean(trellis_ms)),
-                         "prep_ms": float(np.mean(prep_ms)), "backtrace_ms": float(np.mean(back_ms)),
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, %s)" % tsrc, "kernel": "kTrellis", "kernel_ms": weak["trellis_ms"],
+                         "prep_ms": weak["prep_ms"], "backtrace_ms": weak["back_ms"],
                          "positions_per_s_per_piece": a.contig_len / tr_s},
         }
-        if not a.no_cpu_baseline and world == 1:  # the reference's CPU path, timed beside it (rank 0, N = 1 only)
-            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample_bp)
+        if strong is not None:
+            out["strong"] = {"value": bases * a.steps / strong["dt"] / 1e6, "unit": "Mbp/s", "ms_per_step": strong["dt"] / a.steps * 1e3,
+                             "workload": "BASELINE config 3 as written: the same %d contigs x %d bp in total, split longest-first over %d ranks"
+                                         % (a.contigs, a.contig_len, world), "bases_per_step_rank0": strong["bases_per_step_rank"],
+                             "trellis_ms": strong["trellis_ms"], "prep_ms": strong["prep_ms"]}
+        if world == 1:
+            if not a.no_e2e:
+                out.update(e2e_legs(cfg, model, local, rank_contigs("weak", 0, 1, a.contigs, a.contig_len)))
+            if not a.no_cpu_baseline:  # the reference's CPU path, timed beside it (rank 0, N = 1 only)
+                out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample_bp, a.cpu_host_sample_bp)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

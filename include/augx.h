@@ -155,6 +155,7 @@ const char *augx_model_option(const augx_model *m, const char *name); /* NULL if
 void augx_model_destroy(augx_model *m);
 
 /* ---- decoder (device) ---- */
+int augx_device_count(void);              /* visible HIP devices (0 without a GPU: there is no CPU decode path)           */
 int augx_decoder_create(const augx_model *m, int device, augx_decoder **out);
 void augx_decoder_destroy(augx_decoder *d);
 /* bases one batch should hold at most: what fits the free device memory (about 1.5 KB per base), capped at 128 Mbp */
@@ -163,6 +164,14 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d);
 /* replaces viterbiAndForward + getViterbiPath for a batch of independent pieces */
 int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
 void augx_path_free(augx_path *p);
+
+/* ---- multi-GPU: pieces (and the cut finder's exam windows) are independent, so they shard over devices with no
+ *      exchange step.  One decoder per device; pieces are assigned longest-first to the least loaded
+ *      device (augx_partition_lpt, host only), each device is driven by its own host thread in batches bounded by its
+ *      free memory, and the results land in input order in out[0..n).  This is the fan-out of the piece loop of
+ *      NAMGene::doViterbiPiecewise (reference src/namgene.cc:575-676); the reference itself is single-threaded. ---- */
+int augx_partition_lpt(const int64_t *lens, int n, int n_bins, int32_t *bin_of /* [n] */);
+int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
 
 /* ---- device-resident batch interface (bench / multi-GPU driver): the batch is staged once, decode can be
  *      repeated and timed with the inputs resident in HBM ---- */
@@ -185,6 +194,19 @@ int augx_main(int argc, const char *const *argv);
  *      printGeneList, reference src/gene.cc:394-700,2465-2524,3071-3120) for one record decoded as one piece ---- */
 int augx_format_gff(const augx_model *m, const char *name, const char *seq, int64_t len, const augx_state *states,
                     int n_states, int first_gene_id, char *out, int64_t out_cap, int *n_genes);
+
+/* ---- the ordered gather of a sharded run (reference NAMGene::doViterbiPiecewise, src/namgene.cc:526,626-650: gene ids are
+ *      numbered over the whole run in input order): the pieces of n_records records, decoded on any device and handed over
+ *      in any order, become the prediction part of the `augustus` output (block headers of src/augustus.cc:395-398). ---- */
+typedef struct augx_piece_result {
+    int32_t record;            /* index of the FASTA record the piece belongs to                                 */
+    int32_t status;            /* 0 or an AUGX_E_* code (the record's error)                                     */
+    int64_t begin, end;        /* piece = bases [begin, end] of the record                                       */
+    const augx_state *states;  /* decoded path in piece coordinates                                              */
+    int32_t n_states;
+} augx_piece_result;
+int augx_format_records(const augx_model *m, int n_records, const char *const *names, const char *const *seqs,
+                        const int64_t *lens, int n_pieces, const augx_piece_result *pieces, char *out, int64_t out_cap);
 
 const char *augx_last_error(void);
 const char *augx_version(void);

@@ -13,7 +13,7 @@
  * prefix-sum array (the same formulation the HIP kernels use).  Extrinsic evidence is absent (ab initio;
  * every malus/bonus factor of the reference is exactly 1, reference config/extrinsic/extrinsic.cfg).
  *
- * Parity pin: tests/test_oracle_vs_reference.py checks this file against the REAL reference built by
+ * Parity pin: tests/test_oracle.py checks this file against the REAL reference built by
  * oracle/Makefile (oracle/_ref/ref_harness: ln Viterbi score to 1e-9 relative, state path exact, every
  * trellis cell to 1e-9) and against the committed golden vectors under tests/golden/.
  *

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Mb-scale golden vectors from the REAL reference (oracle/_ref, built by oracle/Makefile from /root/reference) for the
+BASELINE.json configurations.  Run in the build container:  python tests/golden/make_golden_big.py
+
+Inputs
+  big_inputs.tar.gz         examples/autoAug/genome.fa of the reference (chrI, 1.0 Mbp of real, soft-masked DNA: the
+                            in-container stand-in for examples/chr2L) -- DATA of the reference, not source
+  the first bench contig    bench.synth_contigs(1, 1000000, 12345) (BASELINE config 3), regenerated from its seed
+Outputs
+  golden_big_<cfg>.gff      the reference binary's GFF (prediction part) for
+      fly         genome.fa --species=fly --UTR=off --sample=0 --softmasking=0   (200 kb pieces: cut chain, config 2)
+      fly_sm      genome.fa --species=fly --UTR=off --sample=0                   (soft-masking bonus across the cuts)
+      human       genome.fa --species=human --softmasking=0                      (two GC classes inside one 1 Mbp piece)
+      human_sm    genome.fa --species=human                                      (default flags)
+      synth       the bench contig, --species=human                              (config 3)
+  golden_big_paths.json     ln Viterbi (%.17g) + raw state path of the single-piece cases (human, synth) from ref_harness
+"""
+import json
+import os
+import subprocess
+import sys
+import tarfile
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from helpers import *  # noqa
+
+BIG_CFGS = {
+    "fly": ("genome", "fly", ["--UTR=off", "--sample=0", "--softmasking=0"]),
+    "fly_sm": ("genome", "fly", ["--UTR=off", "--sample=0"]),
+    "human": ("genome", "human", ["--softmasking=0"]),
+    "human_sm": ("genome", "human", []),
+    "synth": ("synth", "human", []),
+}
+
+
+def main():
+    ref_genome = "/root/reference/examples/autoAug/genome.fa"
+    tar = os.path.join(HERE, "big_inputs.tar.gz")
+    with tarfile.open(tar, "w:gz") as t:
+        t.add(ref_genome, arcname="genome.fa")
+    import bench
+    d = tempfile.mkdtemp()
+    synth = os.path.join(d, "synth.fa")
+    write_fasta(synth, [("rand000", bench.synth_contigs(1, 1000000, 12345)[0].decode())])
+    files = {"genome": ref_genome, "synth": synth}
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
+    paths = {}
+    for cfg, (inp, species, extra) in BIG_CFGS.items():
+        txt = subprocess.run([REF_AUGUSTUS, "--species=" + species] + extra + [files[inp]], capture_output=True, text=True, env=env)
+        assert txt.returncode == 0 and txt.stderr == "", txt.stderr
+        body = gff_body(txt.stdout)
+        open(os.path.join(HERE, "golden_big_%s.gff" % cfg), "w").write("\n".join(body) + "\n")
+        print(cfg, len(body), "gff lines")
+        if cfg in ("human", "synth"):
+            res, err = ref_harness(files[inp], species, extra, cfg="/root/reference/config/")
+            assert len(res) == 1, err
+            paths[cfg] = {"lnv": repr(res[0]["lnv"]), "path": res[0]["path"], "n": res[0]["n"]}
+    json.dump(paths, open(os.path.join(HERE, "golden_big_paths.json"), "w"))
+
+
+if __name__ == "__main__":
+    main()

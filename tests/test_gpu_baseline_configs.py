@@ -1,0 +1,190 @@
+"""GPU parity on the BASELINE.json configurations at full size (run by the driver with -m gpu on a real MI355X), through the
+`augustus` executable and the C ABI of libaugx.so; checkers are golden files produced by the REAL reference
+(tests/golden/make_golden_big.py), the reference binary itself where it travels (oracle/_ref), and the CPU twin."""
+import json
+import os
+import shutil
+import subprocess
+import tarfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import augustus_amd as ax
+from helpers import *
+
+EXE = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
+
+
+@pytest.fixture(scope="module")
+def big_inputs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("big")
+    with tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz")) as t:
+        t.extractall(str(d))
+    import bench
+    synth = str(d / "synth.fa")
+    write_fasta(synth, [("rand000", bench.synth_contigs(1, 1000000, 12345)[0].decode())])
+    return {"genome": str(d / "genome.fa"), "synth": synth}
+
+
+BIG = {  # tests/golden/make_golden_big.py: BIG_CFGS
+    "fly": ("genome", "fly", ["--UTR=off", "--sample=0", "--softmasking=0"]),     # config 2 stand-in: 200 kb pieces, cut chain
+    "fly_sm": ("genome", "fly", ["--UTR=off", "--sample=0"]),                     # + soft-masking bonus across the cuts
+    "human": ("genome", "human", ["--softmasking=0"]),                           # two GC classes inside one 1 Mbp piece
+    "human_sm": ("genome", "human", []),                                         # default flags
+    "synth": ("synth", "human", []),                                             # config 3: one actual bench contig
+}
+
+
+@pytest.mark.parametrize("cfg", list(BIG))
+def test_cli_full_size_gff_identical_to_reference(big_inputs, cfg):
+    """Mb-scale inputs of BASELINE configs 2 and 3 through the executable: GFF byte-identical to the reference binary's"""
+    inp, species, extra = BIG[cfg]
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE, "--species=" + species] + extra + [big_inputs[inp]], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    gold = open(os.path.join(GOLDEN, "golden_big_%s.gff" % cfg)).read().splitlines()
+    assert gff_body(r.stdout) == gold
+    assert r.stderr == ""
+
+
+@pytest.mark.parametrize("cfg", ["human", "synth"])
+def test_full_size_piece_cells_and_reference_score(monkeypatch, big_inputs, cfg):
+    """one 1 Mbp piece (real DNA with two GC classes inside the piece / a bench contig) through the C ABI: every cell equal
+    to the twin, path equal to the REAL reference's, ln Viterbi within 1e-9 relative of the reference's"""
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    inp, species, extra = BIG[cfg]
+    opts = {e[2:].split("=")[0]: e.split("=")[1] for e in extra}
+    m = ax.Model(config_path(), species, **opts)
+    d = ax.Decoder(m, 0)
+    (name, seq), = read_fasta(big_inputs[inp])
+    b = ax.Batch(d, [seq])
+    b.decode()
+    r, = b.paths()
+    gold = json.load(open(os.path.join(GOLDEN, "golden_big_paths.json")))[cfg]
+    assert r.status == 0 and gold["n"] == len(seq)
+    assert [(bb, e, t) for bb, e, s, t in r.states] == [tuple(p) for p in gold["path"]]
+    assert abs(r.ln_viterbi - float(gold["lnv"])) <= 1e-9 * abs(float(gold["lnv"]))
+    rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+    assert rc == 0 and r.ln_viterbi == lnv and r.states == path
+    if cfg == "human":
+        assert len(set(gc.tolist())) > 1  # (more than one GC class inside the piece)
+    assert np.array_equal(b.cells(0), V)
+
+
+def _ladder_cases():
+    ex = dict(golden_inputs())["HS04636"]
+    core = ex[1100:8300]  # from inside the first intron to inside the last: tandem copies leave the cut finder no intergenic region
+    sm = list(random_dna(200000, 77))
+    for a, b in [(15000, 48000), (55000, 61000), (70000, 125000), (139000, 140500), (170000, 199000)]:
+        for i in range(a, b):
+            sm[i] = sm[i].lower()
+    return {
+        "tandem_core": random_dna(3000, 1) + core * 12 + random_dna(3000, 2),
+        "tandem_gene": ex[700:9000] * 10,
+        "rand": random_dna(150000, 5),
+        "softmasked": "".join(sm),
+    }
+
+
+@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not present")
+@pytest.mark.parametrize("species,extra", [("human", []), ("fly", ["--UTR=off", "--sample=0"])])
+@pytest.mark.parametrize("maxpiece", [20000, 60000])
+def test_cli_cut_finder_ladder_matches_reference(tmp_path, species, extra, maxpiece):
+    """every rung of the cut finder (reference src/namgene.cc:973-1133: first try, window doubled, non-internal intergenic
+    region, give up = maxstep, the 5 %% / 5 kb rule) on records built to defeat it, two species, soft-masked runs across the
+    cuts: the cut points (--progress lines on stderr) and the GFF equal the reference binary's"""
+    fa = str(tmp_path / "ladder.fa")
+    write_fasta(fa, list(_ladder_cases().items()))
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    args = ["--species=" + species] + extra + ["--progress=true", "--maxDNAPieceSize=%d" % maxpiece, fa]
+    ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
+    ours = subprocess.run([EXE] + args, capture_output=True, text=True, env=env)
+    assert ref.returncode == 0 and ours.returncode == 0, ours.stderr
+    pieces = lambda t: [l for l in t.splitlines() if l.startswith("examining piece")]
+    assert pieces(ours.stderr) == pieces(ref.stderr)
+    assert len(pieces(ref.stderr)) > 12
+    assert gff_body(ours.stdout) == gff_body(ref.stdout)
+
+
+def test_sharded_decode_two_decoders():
+    """the multi-GPU path of the C ABI (augx_decode_sharded) with two decoders -- on one device when the box has one -- gives
+    what one decoder gives, in input order; and so does the executable with AUGX_DEVICES naming two devices"""
+    m = ax.Model(config_path(), "human")
+    ndev = ax.device_count()
+    assert ndev >= 1
+    d0, d1 = ax.Decoder(m, 0), ax.Decoder(m, 1 if ndev > 1 else 0)
+    seqs = [random_dna(n, 900 + n) for n in (70000, 300, 120000, 9000, 45000, 64, 30000)]
+    one = d0.decode(seqs)
+    two = ax.decode_sharded([d0, d1], seqs)
+    bins = ax.partition_lpt([len(s) for s in seqs], 2)
+    assert set(bins) == {0, 1}
+    for a, b in zip(one, two):
+        assert a.status == b.status == 0 and a.ln_viterbi == b.ln_viterbi and a.states == b.states
+
+
+def test_cli_two_devices_same_output(tmp_path):
+    fa = str(tmp_path / "multi.fa")
+    ex = dict(golden_inputs())["HS04636"]
+    write_fasta(fa, [("a", random_dna(130000, 41)), ("b", ex), ("c", random_dna(90000, 42) + ex + random_dna(50000, 43)), ("d", random_dna(20000, 44))])
+    outs = []
+    second = "1" if ax.device_count() > 1 else "0"
+    for devs in ("0,", "0," + second):
+        env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path(), AUGX_DEVICES=devs)
+        r = subprocess.run([EXE, "--species=human", "--maxDNAPieceSize=60000", fa], capture_output=True, text=True, env=env)
+        assert r.returncode == 0 and r.stderr == "", r.stderr
+        outs.append(gff_body(r.stdout))
+    assert outs[0] == outs[1] and any("\tgene\t" in l for l in outs[0])
+
+
+@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not present")
+@pytest.mark.parametrize("extra", [["--uniqueGeneId=true"], ["--genemodel=complete"], ["--protein=off", "--start=off", "--stop=off"],
+                                   ["--cds=off", "--introns=on"], ["--stopCodonExcludedFromCDS=true"]])
+def test_cli_more_options_match_reference(tmp_path, extra):
+    recs = dict(golden_inputs())
+    fa = str(tmp_path / "opt.fa")
+    write_fasta(fa, [("HS04636", recs["HS04636"]), ("trunc_both", recs["trunc_both"]), ("revcomp", recs["revcomp"]), ("rand60k", recs["rand60k"])])
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    args = ["--species=human"] + extra + [fa]
+    ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
+    ours = subprocess.run([EXE] + args, capture_output=True, text=True, env=env)
+    assert ref.returncode == 0 and ours.returncode == 0, ours.stderr
+    assert gff_body(ours.stdout) == gff_body(ref.stdout)
+    assert ours.stderr == ref.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not present")
+def test_cli_outfile_errfile_stdin_and_config_next_to_binary(tmp_path):
+    """--outfile / --errfile, FASTA on standard input ('-'), and the config directory found relative to the executable
+    (<dir of the binary>/../config, reference src/properties.cc:116-135) when neither the option nor the variable is given"""
+    recs = dict(golden_inputs())
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, [("HS04636", recs["HS04636"]), ("HS08198", recs["HS08198"])])
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    ref = subprocess.run([REF_AUGUSTUS, "--species=human", fa], capture_output=True, text=True, env=env)
+    want = gff_body(ref.stdout)
+    # --outfile / --errfile
+    o, e = str(tmp_path / "o.gff"), str(tmp_path / "e.txt")
+    r = subprocess.run([EXE, "--species=human", "--outfile=" + o, "--errfile=" + e, fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout == "" and r.stderr == ""
+    assert gff_body(open(o).read()) == want and open(e).read() == ""
+    # stdin
+    r = subprocess.run([EXE, "--species=human", "-"], input=open(fa).read(), capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and gff_body(r.stdout) == want
+    # config relative to the binary
+    root = tmp_path / "inst"
+    (root / "bin").mkdir(parents=True)
+    shutil.copy(EXE, str(root / "bin" / "augustus"))
+    shutil.copy(os.path.join(ROOT, "augustus_amd", "libaugx.so"), str(root / "libaugx.so"))  # (rpath of the executable: $ORIGIN/..)
+    os.symlink(config_path().rstrip("/"), str(root / "config"))
+    env2 = {k: v for k, v in os.environ.items() if k != "AUGUSTUS_CONFIG_PATH"}
+    r = subprocess.run([str(root / "bin" / "augustus"), "--species=human", fa], capture_output=True, text=True, env=env2)
+    assert r.returncode == 0 and gff_body(r.stdout) == want, r.stderr
+    # a directory that does not exist: the reference's message
+    r = subprocess.run([EXE, "--species=human", "--AUGUSTUS_CONFIG_PATH=/nonexistent", fa], capture_output=True, text=True, env=env2)
+    assert r.returncode == 1 and "is not a directory. Could not locate directory AUGUSTUS_CONFIG_PATH." in r.stderr
+    # --species=help: usage on stderr, exit code 0
+    r = subprocess.run([EXE, "--species=help"], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "human" in r.stderr.split()

@@ -91,12 +91,7 @@ def test_cli_gff_identical_to_reference(tmp_path):
         args = [exe, "--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + ["--AUGUSTUS_CONFIG_PATH=" + config_path(), fa]
         r = subprocess.run(args, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
-        ours, gold = gff_body(r.stdout), golden_gff(cfg)
-        if ours != gold:
-            # the only tolerated difference: a record the GPU path refuses loudly (multi-GC-class piece)
-            assert "GC-content class" in r.stderr
-        else:
-            assert r.stderr == ""
+        assert gff_body(r.stdout) == golden_gff(cfg) and r.stderr == ""
 
 
 def test_cli_piece_cutting_matches_reference(tmp_path):
