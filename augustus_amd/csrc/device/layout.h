@@ -22,7 +22,8 @@ struct BatchLayout {
         off.assign(n + 1, 0);
         len.resize(n); initKind.resize(n); termKind.resize(n);
         for (int p = 0; p < n; p++) {
-            if (pieces[p].len < 1 || pieces[p].len >= (1 << KEY_BITS) - 64) throw std::runtime_error("augx: piece length out of range (device pieces are shorter than 4 Mbp; lower --maxDNAPieceSize)");
+            // (ln V falls by ~1.39 per base; it must stay above -2^(52-AUGX_Q_BITS) for the fp64 additions to be exact)
+            if (pieces[p].len < 1 || pieces[p].len >= 2900000) throw std::runtime_error("augx: piece length out of range (device pieces are shorter than 2.9 Mbp; lower --maxDNAPieceSize)");
             len[p] = (int32_t)pieces[p].len;
             initKind[p] = pieces[p].init_kind;
             termKind[p] = pieces[p].term_kind;

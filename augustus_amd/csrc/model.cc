@@ -837,7 +837,26 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
         r.comment();
         for (int i = 0; i < 16; i++) t.gc_weight_matrix[i] = r.readDouble();
     }
+    quantiseTables();
     bindPointers();
+}
+
+// Exact arithmetic (include/augx.h: AUGX_Q_BITS): every ln term of the model is rounded ONCE, here, to a multiple of
+// 2^-AUGX_Q_BITS.  All quantities of the decode are sums of such terms with magnitude below 2^(52 - AUGX_Q_BITS), so every
+// fp64 addition on the decode path is exact: the result does not depend on the association of the sums, and adding a
+// constant to all Viterbi values of a column commutes with everything that follows -- which is what lets a piece be decoded
+// in segments that start from an unknown offset (segment-parallel trellis).  The rounding error is <= 2^-32 per
+// factor, i.e. ~1e-13 relative on a Viterbi score (the reference's own LLDouble products round at 1.1e-16 per factor).
+void Model::quantiseTables() {
+    const double sc = std::ldexp(1.0, AUGX_Q_BITS), inv = std::ldexp(1.0, -AUGX_Q_BITS);
+    auto q = [&](double &x) { if (std::isfinite(x)) x = std::nearbyint(x * sc) * inv; };
+    for (std::vector<double> *v : {&ln_trans, &ig_emi, &ig_short, &in_emi, &ex_emi, &ex_init, &ex_et, &ex_pls, &tis_motif, &ass_motif,
+                                   &tis_bin_ln, &ass_pat, &dss_pat, &len_intron, &len_single, &len_initial, &len_internal, &len_terminal})
+        for (double &x : *v) q(x);
+    for (int i = 0; i < AUGX_MAX_STATES; i++) { q(t.ln_init[i]); q(t.ln_term[i]); }
+    for (int i = 0; i < 64; i++) q(t.ln_startcodon[i]);
+    q(t.ln_stop_ochre); q(t.ln_stop_amber); q(t.ln_stop_opal); q(t.ln_quarter); q(t.ln_n_coding); q(t.ln4);
+    q(t.ass_pat_invalid); q(t.ln_soft_bonus);
 }
 
 } // namespace augx

@@ -47,6 +47,7 @@ struct Model {
     void load(const std::string &configPath, const std::string &species,
               const std::vector<std::pair<std::string, std::string>> &cmdline);
     void bindPointers();
+    void quantiseTables();
 };
 
 int stateTypeFromName(const std::string &name);       // reference stateTypeIdentifiers, src/types.cc:157-171

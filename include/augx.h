@@ -24,6 +24,10 @@ extern "C" {
 #define AUGX_MAX_CLASSES 16
 /* Markov-chain content sums are accumulated in fixed point (ln p * 2^40 rounded to int64, wrap-around
  * uint64 adds): exactly associative, so device scans of any shape give bit-identical prefix differences. */
+/* Every ln term of the model tables is a multiple of 2^-AUGX_Q_BITS (rounded once when the model is loaded): all sums on the
+ * decode path stay below 2^(52-AUGX_Q_BITS) = 2^21 * 2 in magnitude (pieces shorter than 3 Mbp), hence every fp64 addition
+ * is EXACT -- associative and shift-invariant like integer arithmetic, with -inf for probability 0 kept for free. */
+#define AUGX_Q_BITS 31
 #define AUGX_FX_SHIFT 40
 #define AUGX_FX_SCALE 1099511627776.0          /* 2^40  */
 #define AUGX_FX_INV (1.0 / 1099511627776.0)    /* 2^-40 */
