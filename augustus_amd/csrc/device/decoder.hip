@@ -155,9 +155,15 @@ template <int BLK, bool MULTI> __global__ void __launch_bounds__(NT, 4) kCand(co
     candWorkgroup<BLK, MULTI>(*T, B, lds, blockIdx.x);
 }
 
-template <int BLK> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+// MODE 0: pass 1, one workgroup per segment (= per piece when no piece is cut); 1: the fix-ups; 2: continuation of pieces whose
+// fix-up gave up, one workgroup per piece (kernels.h: trellisPiece)
+template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
-    trellisPiece<BLK>(*T, *B, lds, blockIdx.x);
+    trellisPiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) kSegFinalize(BatchView B) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p < B.nPieces) segFinalizePiece(B, p);
 }
 __global__ void __launch_bounds__(64) kBacktrace(const DevTables *T, BatchView B) { backtracePiece(*T, B, blockIdx.x); }
 
@@ -173,6 +179,7 @@ struct augx_decoder {
     std::vector<void *> tableBufs;
     bool debugCells = false;
     int blk = 8;              // block size of the candidate / trellis kernels for this model (layout.h: chooseBlockSize)
+    int nCU = 256;            // compute units of the device = trellis workgroups in flight (one per CU: 155 KB of LDS each)
 };
 
 constexpr int NARR = 20; // arrays managed by ensureArrays
@@ -192,6 +199,7 @@ struct augx_batch {
     uint64_t nItems = 0, nPairs = 0;
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
     bool decoded = false;
+    SegPlan plan;            // segments of the trellis (layout.h: planSegments)
 };
 
 namespace {
@@ -298,6 +306,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->blk = blk;
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) d->nCU = cu; else (void)hipGetLastError(); }
     const int rc = [&]() -> int { // (any failure below: the half-built decoder is destroyed, nothing leaks)
         HIP_TRY(hipStreamCreate(&d->stream));
         fillDevTablesScalars(t, d->hostT);
@@ -402,6 +411,15 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.candAlloc, CandAlloc, 1);
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
+    // segments of the trellis: enough workgroups for every compute unit, none shorter than what a fix-up needs
+    b->plan = planSegments(L, d->model->m.t, d->nCU);
+    SegDesc *dSegs; int32_t *dSeg0;
+    const int nSegs = (int)b->plan.segs.size();
+    DA(dSegs, SegDesc, nSegs); DA(dSeg0, int32_t, n + 1);
+    V.nSegs = nSegs; V.segs = dSegs; V.pieceSeg0 = dSeg0; V.segCheckTiles = b->plan.checkTiles;
+    if (const char *e = getenv("AUGX_SEG_CHECK_TILES")) V.segCheckTiles = atoi(e); // (tests of the give-up path: an unreachable check length)
+    DA(V.segStop, int32_t, nSegs); DA(V.segStatus, int32_t, nSegs); DA(V.segD, double, nSegs); DA(V.brkPos, int32_t, nSegs); DA(V.brkOff, double, nSegs);
+    if (b->plan.cut()) { DA(V.ckRing, double, (int64_t)nSegs * 2 * WAVE * SP); DA(V.ckCol, double, Z.N / WAVE * SP); }
 #undef DA
     rc = [&]() -> int { // (any failure below: the batch is destroyed with everything it owns)
     HIP_TRY(hipMemcpy(dOff, L.off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
@@ -409,6 +427,8 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     HIP_TRY(hipMemcpy(dIk, L.initKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dTk, L.termKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dCp, L.chunkPiece.data(), sizeof(int32_t) * L.nChunks, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dSegs, b->plan.segs.data(), sizeof(SegDesc) * nSegs, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dSeg0, b->plan.pieceSeg0.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(dRaw, 'n', (size_t)Z.N));
     HIP_TRY(hipMemset(V.gcPlane, 0, (size_t)Z.N));
     for (int p = 0; p < n; p++)
@@ -545,9 +565,18 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         }
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
-    if (d->blk == 8) hipLaunchKernelGGL(kTrellis<8>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-    else if (d->blk == 4) hipLaunchKernelGGL(kTrellis<4>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-    else hipLaunchKernelGGL(kTrellis<2>, dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+    HIP_TRY(hipMemsetAsync(V.segStatus, 0, sizeof(int32_t) * V.nSegs, st));
+#define AUGX_LAUNCH_TRELLIS(MODE_, grid_) do { \
+        if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
+        else if (d->blk == 4) hipLaunchKernelGGL((kTrellis<4, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
+        else hipLaunchKernelGGL((kTrellis<2, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); } while (0)
+    AUGX_LAUNCH_TRELLIS(0, V.nSegs);                 // pass 1: every segment at once
+    if (b->plan.cut()) {
+        AUGX_LAUNCH_TRELLIS(1, V.nSegs);             // pass 2: the fix-ups (the first segment of a piece has none: its workgroup returns)
+        AUGX_LAUNCH_TRELLIS(2, n);                   // pass 3: pieces with a fix-up that gave up continue from there (else: returns)
+    }
+#undef AUGX_LAUNCH_TRELLIS
+    hipLaunchKernelGGL(kSegFinalize, dim3((n + 63) / 64), dim3(64), 0, st, V);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);
@@ -652,6 +681,19 @@ int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     const int S = d->hostT.S;
     HIP_TRY(hipMemcpy(out, b->V.cells + (b->L.off[piece] + 1) * S, sizeof(double) * (size_t)b->L.len[piece] * S, hipMemcpyDeviceToHost));
+    const int s0 = b->plan.pieceSeg0[piece], K = b->plan.pieceSeg0[piece + 1] - s0;
+    if (K > 1) { // a piece decoded in segments stores its values region by region up to a constant (dp.h: frameOff)
+        std::vector<int32_t> brkPos(K);
+        std::vector<double> brkOff(K);
+        HIP_TRY(hipMemcpy(brkPos.data(), b->V.brkPos + s0, sizeof(int32_t) * K, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(brkOff.data(), b->V.brkOff + s0, sizeof(double) * K, hipMemcpyDeviceToHost));
+        int r = 0;
+        for (int q = 0; q < b->L.len[piece]; q++) {
+            while (r + 1 < K && q > brkPos[r]) r++;
+            if (brkOff[r] != 0.0)
+                for (int s2 = 0; s2 < S; s2++) out[(size_t)q * S + s2] += brkOff[r];
+        }
+    }
     return AUGX_OK;
 }
 

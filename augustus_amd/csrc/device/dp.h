@@ -57,6 +57,20 @@ constexpr int MAXPL_LDS = AUGX_MAXPL_LDS;    // planes whose transition terms th
 constexpr int MAXNB = 32;                    // blocks per tile of 64 bases at the smallest block size (2)
 
 struct CandAlloc;
+// ---- segment-parallel trellis ("segments").  A piece is cut into segments of whole tiles.  Pass 1 runs every
+// segment at once: segment 0 from the true start, segment k >= 1 "dead" -- nothing alive before its first base but the synch
+// state at value 0 -- so that its values are those of the true run plus an unknown constant once the two have converged
+// (every addition on the path is exact, include/augx.h AUGX_Q_BITS: a common constant commutes with the whole recurrence).
+// Pass 2 re-runs the head of every segment k >= 1 from the end state of segment k-1 and compares what it retires (igenic
+// column, long-lag cells, list values, the full column at every tile end) with what pass 1 left: when `segCheckTiles`
+// consecutive tiles differ by one constant D, everything after is the old value + D and the pass stops.  A fix-up that
+// does not get there before `tlim` gives up; pass 3 then continues that piece sequentially from the give-up point.
+struct SegDesc {
+    int32_t piece, k;      // piece, index of the segment inside the piece
+    int32_t t0, t1;        // tiles [t0, t1) of the piece
+    int32_t tlim;          // last tile the fix-up of this segment may rewrite (so that it stays clear of what fix-up k+1 reads)
+    int32_t pad;
+};
 // one possible start of a short intron (entry of the LD / RD candidate lists): everything a lessD candidate needs of it,
 // in one 16-byte record (position, the two bases before the splice site, intron-content prefix at the position)
 struct IntronStart { int32_t pos; uint32_t ctx; uint64_t fx; };
@@ -137,6 +151,18 @@ struct BatchView {
     struct CandAlloc *candAlloc;     // running totals of pairs / items handed out to tiles
     Item *items;                     // [items]
     int64_t itemCap;
+    // segments of the trellis (see SegDesc)
+    int nSegs;                 // >= nPieces; == nPieces: no piece is cut
+    const SegDesc *segs;       // [nSegs] grouped by piece, ascending k
+    const int32_t *pieceSeg0;  // [nPieces+1] first segment of each piece
+    int segCheckTiles;         // consecutive verified tiles that end a fix-up: they cover the longest look-back of the model
+    double *ckRing;            // [nSegs][2][WAVE][SP] the ring at the end of pass 1 of the segment [0] / where its fix-up gave up [1]
+    double *ckCol;             // [N/WAVE][SP] ln V column at the end of every tile (pass 1; compared and replaced by pass 2)
+    int32_t *segStop;          // [nSegs] pass 2: last tile rewritten when converged (>= t0 - 1), -2 - tile when it gave up after `tile`
+    double *segD;              // [nSegs] pass 2: (value in the frame of segment k-1) - (value in the frame of segment k)
+    int32_t *segStatus;        // [nSegs] abort flags
+    int32_t *brkPos;           // [nSegs] kSegFinalize: region r of the piece = bases (brkPos[r-1], brkPos[r]] ...
+    double *brkOff;            // [nSegs] ... whose stored values are true value - brkOff[r]
     // results
     double *lnv;               // [nPieces]
     int32_t *status;           // [nPieces]
@@ -152,6 +178,14 @@ AUGX_HD int64_t fidx(int64_t g, int f, int nf) { return ((g / CHUNK) * nf + f) *
 AUGX_HD int64_t listOff(const BatchView &B, int p) { return B.listOffs[p]; }
 AUGX_HD int64_t pathOff(const BatchView &B, int p) { return B.off[p] / 8 + 64 * (int64_t)p; }
 AUGX_HD int64_t pathCap(const BatchView &B, int p) { return (B.off[p + 1] - B.off[p]) / 8 + 64; }
+// offset that turns a stored Viterbi value of base q of piece p into the true one (0 unless the piece was decoded in segments)
+AUGX_HD double frameOff(const BatchView &B, int p, int q) {
+    const int s0 = B.pieceSeg0[p], s1 = B.pieceSeg0[p + 1];
+    if (s1 - s0 <= 1) return 0.0;
+    int r = s0;
+    while (r + 1 < s1 && q > B.brkPos[r]) r++;
+    return B.brkOff[r];
+}
 
 // view of one piece: pointers pre-offset so that index q is the 0-based base position
 struct Piece {

@@ -1136,6 +1136,11 @@ struct TrellisLds {
     int flagSum;                     // sum of flagI[]: the workers are never more than one block apart, so flagSum >= NWORK * k <=> every flagI >= k
     int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     int abortFlag;
+    // fix-up pass of a segment (trellisPiece<BLK, 1>): what pass 1 left at the end of the current tile, the offsets new - old
+    // of the last tiles, and the last tile whose retired values did not all differ from the old ones by the tile's offset
+    double oldCol[SP];
+    double segDt[4];
+    int lastBad;
 };
 
 // loads of data this workgroup itself stored earlier (other wavefront, at least one tile barrier ago): workgroup-scope
@@ -1215,17 +1220,35 @@ struct TrellisCtx {
     int n, c, S;
     int vigLo;      // the igenic window holds bases > vigLo (and <= the newest chain base)
     bool multi;     // the piece has more than one GC class: transition terms follow the plane of the base
+    // a segment that starts "dead" (pass 1, segment k >= 1): nothing before its first base is alive but the synch state at
+    // base anchor = first base - 1 (value 0); list entries below listLo[sel] and long-lag cells before base segLo do not exist
+    bool dead;
+    int anchor, segLo, listLo[4];
     AUGX_HD TrellisCtx(const DevTables &t, const BatchView &b, TrellisLds &l, int pp) : T(t), B(b), L(l), p(pp) {
         o = B.off[p];
         lo = listOff(B, p);
         n = B.len[p]; c = B.cls[p]; S = T.S;
         vigLo = -1;
         multi = c >= 0 && B.nPlanes[p] > 1;
+        dead = false; anchor = -(1 << 30); segLo = 0;
+        for (int i = 0; i < 4; i++) listLo[i] = 0;
     }
 };
 
+#ifdef AUGX_EMU
+inline void ldsMaxD(double *p, double v) { if (v > *p) *p = v; }
+inline void ldsMaxU(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
+inline void ldsMaxI(int *p, int v) { if (v > *p) *p = v; }
+#else
+__device__ inline void ldsMaxD(double *p, double v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_max_f64
+__device__ inline void ldsMaxU(uint32_t *p, uint32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_max_u32
+__device__ inline void ldsMaxI(int *p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }           // ds_max_i32
+#endif
+
 // ---- staging of tile `tile` into LDS buffer `buf` by thread tid of nth (next tile: the loader wavefronts)
-template <int BLK>
+// CMP (fix-up pass): every value retired to HBM is first compared with what pass 1 left there; a value that is not the old one
+// plus the offset of its tile marks the tile in L.lastBad
+template <int BLK, bool CMP = false>
 AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, int nth, bool flushOld) {
     constexpr int NB = WAVE / BLK; // blocks per tile
     // written in two phases -- every global load of the thread is issued before the first result is consumed -- so that a
@@ -1254,7 +1277,7 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
 #pragma unroll
     for (int k = 0; k < KEQ; k++) {
         const int i = tid + k * nth, q = j0 + i / 6;
-        vEq[k] = (i < WAVE * 6 && dL >= WAVE && q - dL >= 0 && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
+        vEq[k] = (i < WAVE * 6 && dL >= WAVE && q - dL >= X.segLo && q < n) ? ldCoherent(&B.longV[(g0 - dL) * 6 + i]) : AUGX_NINF;
     }
     // block tables: thread i <= NB the first candidate of block i, i < 3 NB the split points, i < 4 NB the newest list entries
     int32_t vOff = 0;
@@ -1296,6 +1319,13 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
                 const int si = L.site[buf][l][sel];
                 if (si >= 0) {
                     double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                    if constexpr (CMP) { // (the buffer held the sites of tile - 1)
+                        const double dT = L.segDt[(tile - 2) & 3];
+                        bool bad = false;
+#pragma unroll
+                        for (int f = 0; f < 3; f++) bad |= !(L.lcVal[sel][si & (LIST_WIN - 1)][f] == gp(a)[(X.lo + si) * 3 + f] + dT);
+                        if (bad) ldsMaxI(&L.lastBad, tile - 2);
+                    }
 #pragma unroll
                     for (int f = 0; f < 3; f++) gp(a)[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
                 }
@@ -1322,8 +1352,11 @@ AUGX_KFN void loadTileThread(const TrellisCtx &X, int tile, int buf, int tid, in
 }
 // retire tile `tile` (LDS buffer buf) to HBM: back pointers (and reset of their buffer), igenic column, long-lag cells.
 // (The trellis wavefronts themselves store to LDS only: a global store costs them hundreds of cycles.)
+template <bool CMP = false>
 AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int nth) {
     const int j0 = tile * WAVE;
+    bool bad = false;
+    const double dT = CMP ? X.L.segDt[tile & 3] : 0.0;
     {   // the 64 x SP back pointers are contiguous in LDS and in HBM: move them as 64-bit words
         const uint64_t *src = (const uint64_t *)&X.L.bp[buf][0][0];
         uint64_t *srcW = (uint64_t *)&X.L.bp[buf][0][0];
@@ -1336,18 +1369,18 @@ AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int
         }
     }
     for (int i = tid; i < WAVE; i += nth) // igenic column
-        if (j0 + i >= 1 && j0 + i < X.n) gp(X.B.vig)[X.o + 1 + j0 + i] = X.L.vigw[(j0 + i) & (VIG_WIN - 1)];
+        if (j0 + i >= 1 && j0 + i < X.n) {
+            if constexpr (CMP) bad |= !(X.L.vigw[(j0 + i) & (VIG_WIN - 1)] == gp(X.B.vig)[X.o + 1 + j0 + i] + dT);
+            gp(X.B.vig)[X.o + 1 + j0 + i] = X.L.vigw[(j0 + i) & (VIG_WIN - 1)];
+        }
     for (int i = tid; i < WAVE * 6; i += nth) // cells read back at lag dStateLen
-        if (j0 + i / 6 >= 1 && j0 + i / 6 < X.n) gp(X.B.longV)[(X.o + 1 + j0) * 6 + i] = X.L.longW[buf][i / 6][i % 6];
+        if (j0 + i / 6 >= 1 && j0 + i / 6 < X.n) {
+            if constexpr (CMP) bad |= !(X.L.longW[buf][i / 6][i % 6] == gp(X.B.longV)[(X.o + 1 + j0) * 6 + i] + dT);
+            gp(X.B.longV)[(X.o + 1 + j0) * 6 + i] = X.L.longW[buf][i / 6][i % 6];
+        }
+    if constexpr (CMP) { if (bad) ldsMaxI(&X.L.lastBad, tile); }
 }
 
-#ifdef AUGX_EMU
-inline void ldsMaxD(double *p, double v) { if (v > *p) *p = v; }
-inline void ldsMaxU(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
-#else
-__device__ inline void ldsMaxD(double *p, double v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // ds_max_f64
-__device__ inline void ldsMaxU(uint32_t *p, uint32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_max_u32
-#endif
 
 // ---- candidates [lo, hi) (indices relative to the first candidate of the tile) of block blk of the trellis
 //      wavefront: add the predecessor value, reduce per (base, state) pair, publish.  Candidates of one pair are
@@ -1390,6 +1423,10 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
                 } else
                     pv = ldCoherent(&B.vig[X.o + 1 + pay]);
             }
+            if (X.dead) { // (uniform) nothing before the first base of the segment exists, but the synch state at the anchor base
+                const int lLo = sel == 0 ? X.listLo[0] : sel == 1 ? X.listLo[1] : sel == 2 ? X.listLo[2] : X.listLo[3];
+                if (tag == SRC_LIST ? pay < lLo : tag == SRC_VIG ? pay <= X.anchor : true) pv = (tag == SRC_VIG && pay == X.anchor) ? 0.0 : AUGX_NINF;
+            }
             const double v = valid ? pv + I.te : AUGX_NINF;
             // the pair id is (base offset in the block, state)
             if (v > AUGX_NINF) ldsMaxD(&L.ring[(jb + (int)(I.kp >> (KEY_BITS + 6))) & 63][(I.kp >> KEY_BITS) & 63], v);
@@ -1400,21 +1437,48 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
     PROF_MARK(X, 5);
 }
 
-template <int BLK>
-AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int p) {
+// MODE 0: pass 1 -- segment `sg` from its (true or dead) start to its end;  MODE 1: pass 2 -- fix-up of segment sg from the
+// end state of the segment before it, until what it retires differs from the values of pass 1 by one constant;
+// MODE 2: pass 3 -- sg is a PIECE: if one of its fix-ups gave up, continue from there to the end of the piece.
+template <int BLK, int MODE = 0>
+AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int sg) {
     constexpr int NB = WAVE / BLK;  // blocks per tile
     constexpr int SPR = WAVE / BLK; // state slots per round of 64 lanes: lane = (slot, base of the block)
+    constexpr bool CMP = MODE == 1;
+    int segIdx = sg, tStart = 0, tEnd = 0, ckSrc = -1; // ckSrc: ring checkpoint to start from ([seg] * 2 + slot), -1: none
+    if (MODE == 2) { // the first fix-up of the piece that gave up, if any
+        segIdx = -1;
+        for (int q = B.pieceSeg0[sg] + 1; q < B.pieceSeg0[sg + 1]; q++)
+            if (B.segStop[q] <= -2) { segIdx = q; break; }
+        if (segIdx < 0) return;
+        tStart = -2 - B.segStop[segIdx] + 1;
+        ckSrc = segIdx * 2 + 1;
+    }
+    const SegDesc sd = B.segs[segIdx];
+    const int p = sd.piece;
     TrellisCtx X(T, B, L, p);
     const int n = X.n, S = X.S, c = X.c;
     const int64_t o = X.o;
+    const int nTiles = (n + WAVE - 1) / WAVE;
+    if (MODE == 0) { tStart = sd.t0; tEnd = sd.t1; X.dead = sd.k > 0; }
+    if (MODE == 1) {
+        if (sd.k == 0) return;
+        tStart = sd.t0; tEnd = sd.tlim + 1; ckSrc = (segIdx - 1) * 2;
+    }
+    if (MODE == 2) tEnd = nTiles;
+    const bool lastOfPiece = tEnd == nTiles && MODE != 1; // this run ends the piece: it does the termination step
     if (c < 0) { // multi-class piece: not decoded by this version
-        FOR_THREADS(t) { if (t == 0) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
+        FOR_THREADS(t) { if (t == 0 && lastOfPiece) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
         return;
     }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
     {   // ---- a piece without a single nucleotide is all intergenic (reference src/namgene.cc:205-226)
         uint64_t nuc = 0;
         for (int i = 0; i < 4; i++) nuc += B.cnt[fidx(o + n, i, NCNT)];
+        if (nuc == 0 && !(MODE == 0 && sd.k == 0)) { // (segment 0 of pass 1 does the whole piece; nothing to fix up)
+            FOR_THREADS(t) { if (t == 0 && MODE == 1) { B.segStop[segIdx] = sd.t0 - 1; B.segD[segIdx] = 0.0; } }
+            return;
+        }
         if (nuc == 0) {
             const int sy = T.synch;
             int selfAi = 0;
@@ -1546,16 +1610,55 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (t < S) v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
             L.col0[t] = v;
         }
-        if (t == 0) { for (int i = 0; i < NWORK; i++) { L.flagF[i] = 0; L.flagI[i] = 0; } L.flagL = 0; L.flagC = 0; L.flagN = 0; L.flagR = 0; L.staged = 0; L.rtPub = 0; L.abortFlag = 0; L.flagSum = 0; }
+        if (t == 0) { // (the progress counters count blocks / tiles of the PIECE: a run that starts at tile tStart starts them there)
+            const int gb0 = tStart * NB;
+            for (int i = 0; i < NWORK; i++) { L.flagF[i] = gb0; L.flagI[i] = gb0; }
+            L.flagL = gb0; L.flagC = gb0; L.flagN = gb0; L.flagR = tStart; L.staged = (NWAVES - W_LOAD) * tStart; L.rtPub = 0; L.abortFlag = 0; L.flagSum = NWORK * gb0;
+            L.lastBad = tStart - 1;
+            for (int i = 0; i < 4; i++) L.segDt[i] = 0.0;
+        }
         for (int i = t; i < WAVE * SP; i += NT) {
-            L.ring[i / SP][i % SP] = AUGX_NINF;
+            L.ring[i / SP][i % SP] = ckSrc >= 0 ? B.ckRing[((int64_t)ckSrc * WAVE + i / SP) * SP + i % SP] : AUGX_NINF;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
+        }
+        for (int i = t; i < VIG_WIN; i += NT) L.vigw[i] = AUGX_NINF;
+        for (int i = t; i < 4 * LIST_WIN * 3; i += NT) L.lcVal[i / (LIST_WIN * 3)][(i / 3) % LIST_WIN][i % 3] = AUGX_NINF;
+    }
+    BLOCK_SYNC();
+    if (tStart > 0) { // ---- a run that does not start at the first base of the piece
+        const int jA = tStart * WAVE - 1; // the base before its first one
+        if (X.dead) { X.anchor = jA; X.segLo = jA + 1; }
+        for (int sel = 0; sel < 4; sel++) { // entries of the candidate lists at or before jA
+            const int cntA = (int)B.cnt[fidx(o + 1 + jA, CNT_LA + sel, NCNT)];
+            if (X.dead) X.listLo[sel] = cntA;
+            else {
+                FOR_THREADS(t) { // the newest LIST_WIN entries, from what the run before left in HBM
+                    const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                    for (int i = t; i < LIST_WIN * 3; i += NT) {
+                        const int e = cntA - 1 - i / 3;
+                        if (e >= 0) L.lcVal[sel][e & (LIST_WIN - 1)][i % 3] = a[(X.lo + e) * 3 + i % 3];
+                    }
+                }
+            }
+        }
+        if (!X.dead) {
+            FOR_THREADS(t) {
+                for (int i = t; i < VIG_WIN; i += NT) {
+                    const int q = jA - i;
+                    if (q >= 0) L.vigw[q & (VIG_WIN - 1)] = B.vig[o + 1 + q];
+                }
+            }
         }
     }
     BLOCK_SYNC();
+    if (X.dead) { // ---- the column before the first base of a dead start: the synch state, at value 0
+        FOR_THREADS(t) {
+            if (t == 0) { L.ring[X.anchor & 63][T.synch] = 0.0; L.vigw[X.anchor & (VIG_WIN - 1)] = 0.0; }
+        }
+    }
     // ---- column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
     FOR_THREADS(t) {
-        if (t < S) {
+        if (t < S && tStart == 0) {
             const double v = L.col0[t];
             L.ring[0][t] = v;
             const int lr = longRow(T, t);
@@ -1569,9 +1672,8 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (si >= 0) L.lcVal[sel0][si & (LIST_WIN - 1)][T.win[t]] = v;
             }
         }
-        loadTileThread<BLK>(X, 0, 0, t, NT, false);
+        loadTileThread<BLK>(X, tStart, tStart & 1, t, NT, false);
     }
-    const int nTiles = (n + WAVE - 1) / WAVE;
     const bool wantCells = B.cells != nullptr;
     const bool directLong = dL < 4 * WAVE; // short dStateLen: equalD would read a cell before its tile has been flushed
     BLOCK_GLOBAL_SYNC();
@@ -1803,14 +1905,17 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     for (int i = 0; i < 8; i++) X.pacc[i] = 0;
     X.plast = clock64();
 #endif
-    for (int tile = 0; tile < nTiles; tile++) {
+    int tLast = tStart - 1;  // last tile this run completed
+    bool gaveUp = false;     // (fix-up pass) stopped at its limit without having converged
+    for (int tile = tStart; tile < tEnd; tile++) {
         const int buf = tile & 1, j0 = tile * WAVE;
         FOR_WAVES(w) {
             if (w >= W_LOAD) {
                 // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
                 FOR_WLANES(t, w) {
-                    if (tile + 1 < nTiles) loadTileThread<BLK>(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= 1);
-                    if (tile >= 1) flushBpThread(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
+                    if (CMP) { const int tid = t - W_LOAD * WAVE; if (tid < SP) L.oldCol[tid] = gp(B.ckCol)[(o / WAVE + tile) * SP + tid]; } // what pass 1 left at the end of this tile
+                    if (tile + 1 < tEnd || (CMP && tile + 1 < nTiles)) loadTileThread<BLK, CMP>(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= tStart + 1);
+                    if (tile >= tStart + 1) flushBpThread<CMP>(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
                 addFlag(&L.staged); // (NWAVES - W_LOAD) counts per tile: the next tile is staged, its buffers are retired
             }
@@ -1918,7 +2023,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         FOR_WAVES(w) {
             if (w == W_X && nb > 0) {
                 const int gN = (tile + 1) * NB, jbN = j0 + WAVE;
-                if (tile + 1 < nTiles && jbN < n) {
+                if (!CMP && tile + 1 < tEnd && jbN < n) { // (a fix-up may stop after any tile: it must not touch the next one)
                     waitFlag(L, &L.staged, (NWAVES - W_LOAD) * (tile + 1));
                     waitFlag(L, &L.flagSum, NWORK * (gN - 2));
                     waitFlag(L, &L.flagC, farNeedC(gN));
@@ -1954,6 +2059,34 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         }
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
         FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 15); }
+        tLast = tile;
+        if (B.ckCol) { // ---- pieces cut into segments: the column at the end of the tile (complete: every wavefront has passed the barrier)
+            FOR_THREADS(t) {
+                if (t < SP) {
+                    const double nv = t < S ? L.ring[63][t] : AUGX_NINF;
+                    if constexpr (CMP) { // the tile's offset = new - old of the synch state; a finite offset commutes with -inf = -inf
+                        const double nSy = L.ring[63][T.synch], oSy = L.oldCol[T.synch];
+                        const bool fin = nSy > AUGX_NINF && oSy > AUGX_NINF;
+                        const double dT = fin ? nSy - oSy : 0.0;
+                        if (!fin || !(nv == L.oldCol[t] + dT)) ldsMaxI(&L.lastBad, tile);
+                        if (t == 0) {
+                            if (tile > tStart && dT != L.segDt[(tile - 1) & 3]) ldsMaxI(&L.lastBad, tile - 1); // a run of verified tiles shares ONE offset
+                            L.segDt[tile & 3] = dT;
+                        }
+                    }
+                    gp(B.ckCol)[(o / WAVE + tile) * SP + t] = nv;
+                }
+            }
+        }
+        if constexpr (CMP) {
+            BLOCK_SYNC();
+            // tiles up to tile - 1 have been retired and compared (by the loaders, during this tile); converged when the last
+            // segCheckTiles of them -- more than the longest look-back of any state -- all differ from pass 1 by one offset
+            const int lb = L.lastBad;
+            BLOCK_SYNC();
+            if ((tile - 1) - lb >= B.segCheckTiles) break;
+            if (tile + 1 == tEnd) gaveUp = true;
+        }
     }
 #if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)
@@ -1961,17 +2094,32 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #endif
     // ---- back pointers of the last tile; list values of the sites of the last two tiles (the back-trace reads them)
     FOR_THREADS(t) {
-        flushBpThread(X, nTiles - 1, (nTiles - 1) & 1, t, NT);
-        for (int i = t; i < 2 * WAVE * NSITE; i += NT) {
-            const int bsel = i / (WAVE * NSITE), l = (i / NSITE) % WAVE, sel = i % NSITE;
-            if (bsel == 1 && nTiles < 2) continue; // (the other buffer was never loaded)
-            const int si = L.site[((nTiles - 1) & 1) ^ bsel][l][sel];
-            if (si >= 0) {
-                double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
-                for (int f = 0; f < 3; f++) a[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
+        if (tLast >= tStart) {
+            flushBpThread(X, tLast, tLast & 1, t, NT);
+            // (a fix-up has always staged the tile after its last one: the other buffer then holds THAT tile's sites, and the
+            //  sites of tile tLast - 1 have been retired when it was staged)
+            const bool otherIsNext = CMP && tLast + 1 < nTiles;
+            for (int i = t; i < 2 * WAVE * NSITE; i += NT) {
+                const int bsel = i / (WAVE * NSITE), l = (i / NSITE) % WAVE, sel = i % NSITE;
+                if (bsel == 1 && (tLast - tStart + 1 < 2 || otherIsNext)) continue; // (the other buffer was never loaded)
+                const int si = L.site[(tLast & 1) ^ bsel][l][sel];
+                if (si >= 0) {
+                    double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
+                    for (int f = 0; f < 3; f++) a[(X.lo + si) * 3 + f] = L.lcVal[sel][si & (LIST_WIN - 1)][f];
+                }
             }
         }
+        // ---- segments: the ring where this run stopped (pass 1: for the fix-up of the next segment; a fix-up that gave up: for pass 3)
+        if (B.ckRing && !lastOfPiece && (MODE == 0 || (CMP && gaveUp))) {
+            const int64_t slot = (int64_t)segIdx * 2 + (CMP ? 1 : 0);
+            for (int i = t; i < WAVE * SP; i += NT) B.ckRing[(slot * WAVE + i / SP) * SP + i % SP] = L.ring[i / SP][i % SP];
+        }
+        if (t == 0) {
+            if (CMP) { B.segStop[segIdx] = gaveUp ? -2 - tLast : tLast; B.segD[segIdx] = gaveUp ? 0.0 : L.segDt[tLast & 3]; }
+            if (B.segStatus && L.abortFlag) B.segStatus[segIdx] = 1;
+        }
     }
+    if (!lastOfPiece) return;
     // ---- termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-457)
     FOR_THREADS(t) {
         if (t == 0) {
@@ -1987,6 +2135,34 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             B.status[p] = L.abortFlag ? AUGX_E_HIP : state >= 0 ? 0 : AUGX_E_NOPATH;
         }
     }
+}
+
+// =================================================================================================
+// after the passes of the segment-parallel trellis: the regions of piece p and the constant each one's stored values are off by
+// (SegDesc, BatchView::brkPos / brkOff), the score of the piece in the true frame, the status of its runs
+// =================================================================================================
+AUGX_KFN void segFinalizePiece(const BatchView &B, int p) {
+    const int s0 = B.pieceSeg0[p], K = B.pieceSeg0[p + 1] - s0, n = B.len[p];
+    if (K <= 1) { B.brkPos[s0] = n - 1; B.brkOff[s0] = 0.0; return; }
+    // frame k = the values segment k computed in pass 1 (frame 0 = the true values).  Fix-up k rewrote tiles up to segStop[k] in
+    // frame k - 1 and measured D_k = (frame k-1) - (frame k): region r = bases (end of tile segStop[r], end of tile segStop[r+1]]
+    // is stored in frame r, true value = stored + D_1 + ... + D_r.  If fix-up f gave up, pass 3 redid everything after it in
+    // frame f - 1: region f - 1 then runs to the end of the piece.
+    double off = 0.0;
+    int failed = K;
+    for (int k = 1; k < K; k++)
+        if (B.segStop[s0 + k] <= -2) { failed = k; break; }
+    bool abortAny = false;
+    for (int r = 0; r < K; r++) {
+        if (r >= 1 && r < failed) off = off + B.segD[s0 + r];
+        const bool lastRegion = r + 1 >= failed || r + 1 >= K;
+        B.brkPos[s0 + r] = lastRegion ? n - 1 : (B.segStop[s0 + r + 1] + 1) * WAVE - 1;
+        B.brkOff[s0 + r] = r < failed ? off : 0.0;
+        if (B.segStatus[s0 + r]) abortAny = true;
+    }
+    const double lastOff = B.brkOff[s0 + (failed < K ? failed - 1 : K - 1)];
+    if (B.status[p] == 0) B.lnv[p] = B.lnv[p] + lastOff;
+    if (abortAny) B.status[p] = AUGX_E_HIP;
 }
 
 // =================================================================================================
@@ -2020,6 +2196,7 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
         return;
     }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U;
+    const bool segmented = B.pieceSeg0[p + 1] - B.pieceSeg0[p] > 1;
     while (base > 0) {
         const int kind = T.kind[state];
         int eop, ai;
@@ -2076,12 +2253,19 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
                             const uint32_t sr = I.src, tag = sr >> 30;
                             const int sel = (sr >> 26) & 3, fr = (sr >> 24) & 3, pay = (int)(sr & 0xFFFFFFu);
                             double pv;
+                            // (a piece decoded in segments stores its values region by region up to a constant: frameOff)
                             if (tag == SRC_LIST) {
                                 const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;
                                 pv = a[(listOff(B, p) + pay) * 3 + fr];
-                            } else if (tag == SRC_VIG)
+                                if (segmented) {
+                                    const int64_t e = listOff(B, p) + pay;
+                                    const int pos = sel == 0 ? B.laPos[e] : sel == 1 ? B.lrPos[e] : sel == 2 ? B.ldEnt[e].pos : B.rdEnt[e].pos;
+                                    pv = pv + frameOff(B, p, pos);
+                                }
+                            } else if (tag == SRC_VIG) {
                                 pv = B.vig[o + 1 + pay];
-                            else {
+                                if (segmented) pv = pv + frameOff(B, p, pay);
+                            } else {
                                 const int a0 = (int)(sr & 0x3Fu);
                                 pv = B.initKind[p] == 0 ? T.ln_init[a0] : (a0 == T.synch ? 0.0 : AUGX_NINF);
                             }

@@ -93,6 +93,84 @@ inline int64_t listOffsets(const int32_t *listCnt, int nPieces, std::vector<int6
     return offs[nPieces] + 64;
 }
 
+// ---- segments of the trellis (dp.h: SegDesc).  A fix-up ends after `checkTiles` consecutive verified tiles: they must cover
+// the longest look-back of any state (a candidate of a variable-length state reaches back at most one maximal exon or intron
+// plus its signal windows; equalD reads at lag dStateLen), plus the tiles whose retired values are still on their way.
+struct SegPlan {
+    std::vector<SegDesc> segs;
+    std::vector<int32_t> pieceSeg0;
+    int checkTiles = 0;
+    bool cut() const { return segs.size() + 1 > pieceSeg0.size(); } // some piece has more than one segment
+};
+inline int segCheckTiles(const augx_tables &t) {
+    int reach = t.max_exon_len > t.d ? t.max_exon_len : t.d;
+    reach += t.W + t.U + 64;
+    return (reach + WAVE - 1) / WAVE + 4;
+}
+// can pieces of this model be cut at all?  (the synch state must be the intergenic state, whose column anchors a dead start;
+// equalD must read its long-lag cells through the tile-wise flush, not the direct path of short dStateLen)
+inline bool segmentsSupported(const augx_tables &t) {
+    const int dL = t.d - 2 - t.De - t.As - 2 - t.U;
+    return t.state_kind[t.synch_state] == AUGX_K_IGENIC && dL >= 4 * WAVE && t.reachable[t.synch_state];
+}
+// segTiles: tiles per segment wanted (0: choose so that `slots` workgroups are busy; < 0: never cut).  AUGX_SEG_LEN (bases)
+// overrides it (tests; 0 = never cut).
+inline SegPlan planSegments(const BatchLayout &L, const augx_tables &t, int slots, int segTiles = 0) {
+    SegPlan P;
+    P.checkTiles = segCheckTiles(t);
+    const int n = L.nPieces;
+    if (const char *e = getenv("AUGX_SEG_LEN")) { const long v = atol(e); segTiles = v <= 0 ? -1 : (int)((v + WAVE - 1) / WAVE); }
+    const int minSeg = 5 * P.checkTiles; // a segment holds its own fix-up (convergence + checkTiles) and the look-back of the next one
+    std::vector<int> tiles(n);
+    int64_t total = 0;
+    int maxTiles = 0;
+    for (int p = 0; p < n; p++) { tiles[p] = (L.len[p] + WAVE - 1) / WAVE; total += tiles[p]; if (tiles[p] > maxTiles) maxTiles = tiles[p]; }
+    if (!segmentsSupported(t)) segTiles = -1;
+    auto countFor = [&](int st, int p) { // nearest count, no segment shorter than minSeg
+        int k = (tiles[p] + st / 2) / st;
+        while (k > 1 && tiles[p] / k < minSeg) k--;
+        return k < 1 ? 1 : k;
+    };
+    if (segTiles == 0) {
+        // estimate of the time of the three passes for a candidate segment length: rounds of `slots` concurrent workgroups,
+        // each as long as the longest segment / a typical fix-up (convergence within ~400 tiles on random DNA, then the check)
+        const int64_t fixLen = P.checkTiles + 400;
+        int64_t bestCost = -1;
+        int best = -1;
+        for (int k = 1; k <= 64; k++) {
+            int st = (maxTiles + k - 1) / k;
+            if (k > 1 && st < minSeg) break;
+            int64_t nSeg = 0, nFix = 0, longest = 0;
+            for (int p = 0; p < n; p++) {
+                const int kp = k == 1 ? 1 : countFor(st, p);
+                nSeg += kp; nFix += kp - 1;
+                const int64_t len = (tiles[p] + kp - 1) / kp;
+                if (len > longest) longest = len;
+            }
+            const int64_t cost = (nSeg + slots - 1) / slots * longest + (nFix + slots - 1) / slots * fixLen;
+            if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = k == 1 ? -1 : st; }
+        }
+        segTiles = best;
+    }
+    if (segTiles > 0 && segTiles < minSeg) segTiles = minSeg;
+    P.pieceSeg0.assign((size_t)n + 1, 0);
+    for (int p = 0; p < n; p++) {
+        const int kp = segTiles > 0 ? countFor(segTiles, p) : 1;
+        P.pieceSeg0[p] = (int32_t)P.segs.size();
+        for (int k = 0; k < kp; k++) {
+            SegDesc d;
+            d.piece = p; d.k = k;
+            d.t0 = (int32_t)((int64_t)tiles[p] * k / kp);
+            d.t1 = (int32_t)((int64_t)tiles[p] * (k + 1) / kp);
+            d.tlim = d.t1 - P.checkTiles - 2;
+            d.pad = 0;
+            P.segs.push_back(d);
+        }
+    }
+    P.pieceSeg0[n] = (int32_t)P.segs.size();
+    return P;
+}
+
 // element counts of every device buffer of a batch (bytes = count * sizeof(element))
 struct BatchSizes {
     int64_t N, nChunks, nPieces, pathCap;

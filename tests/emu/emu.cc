@@ -198,10 +198,38 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
                 fprintf(stderr, "emu stats: %d workers: blocks by chunks of the busiest worker: 0:%lld 1:%lld 2:%lld 3:%lld 4:%lld 5+:%lld\n", kw, hist[kw - 3][0], hist[kw - 3][1], hist[kw - 3][2], hist[kw - 3][3], hist[kw - 3][4], hist[kw - 3][5]);
         }
     }
-    // ---- K2b, K3
+    // ---- K2b, K3.  Segments (AUGX_SEG_LEN, else the planner's choice for 256 slots): pass 1 over all segments, pass 2 = the
+    //      fix-ups, pass 3 = continuation of pieces with a fix-up that gave up, then the region offsets (as augx_batch_decode does)
+    SegPlan plan = planSegments(L, *t, 256);
+    B.nSegs = (int)plan.segs.size();
+    B.segs = plan.segs.data();
+    B.pieceSeg0 = plan.pieceSeg0.data();
+    B.segCheckTiles = plan.checkTiles;
+    if (const char *e = getenv("AUGX_SEG_CHECK_TILES")) B.segCheckTiles = atoi(e); // (tests of the give-up path: an unreachable check length)
+    std::vector<int32_t> segStop(B.nSegs, -1), segStatus(B.nSegs, 0), brkPos(B.nSegs, 0);
+    std::vector<double> segD(B.nSegs, 0.0), brkOff(B.nSegs, 0.0);
+    B.segStop = segStop.data(); B.segStatus = segStatus.data(); B.segD = segD.data(); B.brkPos = brkPos.data(); B.brkOff = brkOff.data();
+    if (plan.cut()) {
+        B.ckRing = zalloc<double>((int64_t)B.nSegs * 2 * WAVE * SP);
+        B.ckCol = zalloc<double>(Z.N / WAVE * SP);
+    }
     TrellisLds *lds = new TrellisLds();
+#define EMU_TRELLIS(MODE_, idx) do { if (blk == 8) trellisPiece<8, MODE_>(T, B, *lds, idx); else if (blk == 4) trellisPiece<4, MODE_>(T, B, *lds, idx); else trellisPiece<2, MODE_>(T, B, *lds, idx); } while (0)
+    for (int sg = 0; sg < B.nSegs; sg++) EMU_TRELLIS(0, sg);
+    if (plan.cut()) {
+        for (int sg = B.nSegs - 1; sg >= 0; sg--) EMU_TRELLIS(1, sg); // (any order: the fix-ups are independent of each other)
+        for (int p = 0; p < n; p++) EMU_TRELLIS(2, p);
+    }
+#undef EMU_TRELLIS
+    int nGaveUp = 0;
+    for (int sg = 0; sg < B.nSegs; sg++) nGaveUp += segStop[sg] <= -2;
+    if (getenv("AUGX_EMU_STATS")) {
+        fprintf(stderr, "emu stats: %d segments for %d pieces, check %d tiles, %d fix-ups gave up;", B.nSegs, n, B.segCheckTiles, nGaveUp);
+        for (int sg = 0; sg < B.nSegs && sg < 24; sg++) fprintf(stderr, " [%d:%d..%d stop %d D %.6f]", plan.segs[sg].piece, plan.segs[sg].t0, plan.segs[sg].t1, segStop[sg], segD[sg]);
+        fprintf(stderr, "\n");
+    }
     for (int p = 0; p < n; p++) {
-        if (blk == 8) trellisPiece<8>(T, B, *lds, p); else if (blk == 4) trellisPiece<4>(T, B, *lds, p); else trellisPiece<2>(T, B, *lds, p);
+        segFinalizePiece(B, p);
         backtracePiece(T, B, p);
     }
     delete lds;
@@ -222,9 +250,15 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         int64_t w = 0;
         for (int p = 0; p < n; p++) {
             memcpy(cells_out + w, B.cells + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);
+            if (B.pieceSeg0[p + 1] - B.pieceSeg0[p] > 1) // regions of a piece decoded in segments are stored up to a constant
+                for (int q = 0; q < L.len[p]; q++) {
+                    const double off = frameOff(B, p, q);
+                    for (int s2 = 0; s2 < t->S; s2++) cells_out[w + (int64_t)q * t->S + s2] += off;
+                }
             w += (int64_t)L.len[p] * t->S;
         }
     }
+    free(B.ckRing); free(B.ckCol);
     free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.items);
     free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
     free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldEnt); free(B.ldVal);

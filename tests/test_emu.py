@@ -137,3 +137,40 @@ def test_emulated_small_block_sizes(monkeypatch, blk):
         assert st == 0 and rc == 0 and lnv == lnv2 and np.array_equal(V, V2), name
         assert path == [(b, e, s) for b, e, s, t in path2], name
 
+
+
+def _segment_cases():
+    import bench
+    import tarfile
+    import tempfile
+    d = tempfile.mkdtemp()
+    with tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz")) as t:
+        t.extractall(d)
+    (name, g), = read_fasta(os.path.join(d, "genome.fa"))
+    return [bench.synth_contigs(1, 400000, 12345)[0].decode(),        # uniform-random DNA (the bench workload)
+            random_dna(90000, 5),                                     # too short to be cut
+            g[100000:430000],                                         # real DNA, soft-masked, two GC classes
+            "N" * 250000,                                             # no nucleotide at all
+            random_dna(200000, 9) + "N" * 150000 + random_dna(100000, 10)]  # a dead start inside an N run cannot converge: gives up
+
+
+import os
+
+
+@pytest.mark.parametrize("env", [{"AUGX_SEG_LEN": "100000"}, {"AUGX_SEG_LEN": "100000", "AUGX_SEG_CHECK_TILES": "100000"}, {}])
+def test_emulated_segment_parallel_trellis(monkeypatch, env):
+    """pieces cut into segments (pass 1: every segment at once, all but the first from a dead start; pass 2: fix-ups until the
+    retired values differ from pass 1 by one constant; pass 3: continuation where a fix-up gave up -- forced for every segment by
+    an unreachable check length): every cell, the score and the path equal the sequential oracle bit for bit"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = ax.Model(config_path(), "human")
+    S = m.n_states
+    seqs = _segment_cases()
+    res = emu_decode(m.tables_ptr, seqs, S, cells=True)
+    for seq, (st, lnv, path, V, cls) in zip(seqs, res):
+        rc, lnv2, path2, V2, _ = twin_decode(m.tables_ptr, seq, S, cells=True)
+        assert st == 0 and rc == 0 and lnv == lnv2, len(seq)
+        assert path == [(b, e, s) for b, e, s, t in path2], len(seq)
+        if set(seq) != {"N"}:
+            assert np.array_equal(V, V2), len(seq)

@@ -229,3 +229,28 @@ def test_gpu_small_block_sizes(monkeypatch, blk):
         assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, i
         assert np.array_equal(b.cells(i), V), i
 
+
+
+@pytest.mark.parametrize("env", [{"AUGX_SEG_LEN": "100000"}, {"AUGX_SEG_LEN": "100000", "AUGX_SEG_CHECK_TILES": "100000"}, {}])
+@pytest.mark.parametrize("species", ["human", "fly"])
+def test_gpu_segment_parallel_trellis(monkeypatch, env, species):
+    """pieces cut into segments decoded at once (tests/test_emu.py: test_emulated_segment_parallel_trellis), the give-up path
+    forced, and the planner's own choice: every cell, the score and the path equal the sequential oracle bit for bit"""
+    from test_emu import _segment_cases
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
+    d = ax.Decoder(m, 0)
+    seqs = _segment_cases()
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (seq, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+        assert r.status == 0 and rc == 0 and r.ln_viterbi == lnv and r.states == path, i
+        if set(seq) != {"N"}:
+            assert np.array_equal(b.cells(i), V), i
+    b.decode()  # a batch decoded again (the bench does): the same result
+    for i, (seq, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, _, _ = twin_decode(m.tables_ptr, seq, m.n_states)
+        assert r.ln_viterbi == lnv and r.states == path, i
