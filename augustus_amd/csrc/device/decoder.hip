@@ -419,6 +419,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     V.nSegs = nSegs; V.segs = dSegs; V.pieceSeg0 = dSeg0; V.segCheckTiles = b->plan.checkTiles;
     if (const char *e = getenv("AUGX_SEG_CHECK_TILES")) V.segCheckTiles = atoi(e); // (tests of the give-up path: an unreachable check length)
     DA(V.segStop, int32_t, nSegs); DA(V.segStatus, int32_t, nSegs); DA(V.segD, double, nSegs); DA(V.brkPos, int32_t, nSegs); DA(V.brkOff, double, nSegs);
+    DA(V.segStop2, int32_t, nSegs); DA(V.segD2, double, nSegs); DA(V.pieceCovered, int32_t, n);
     if (b->plan.cut()) { DA(V.ckRing, double, (int64_t)nSegs * 2 * WAVE * SP); DA(V.ckCol, double, Z.N / WAVE * SP); }
 #undef DA
     rc = [&]() -> int { // (any failure below: the batch is destroyed with everything it owns)
@@ -572,8 +573,13 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         else hipLaunchKernelGGL((kTrellis<2, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); } while (0)
     AUGX_LAUNCH_TRELLIS(0, V.nSegs);                 // pass 1: every segment at once
     if (b->plan.cut()) {
+        HIP_TRY(hipMemsetAsync(V.segStop2, 0xFF, sizeof(int32_t) * V.nSegs, st));
+        HIP_TRY(hipMemsetAsync(V.pieceCovered, 0xFF, sizeof(int32_t) * n, st));
         AUGX_LAUNCH_TRELLIS(1, V.nSegs);             // pass 2: the fix-ups (the first segment of a piece has none: its workgroup returns)
-        AUGX_LAUNCH_TRELLIS(2, n);                   // pass 3: pieces with a fix-up that gave up continue from there (else: returns)
+        // pass 3: a fix-up that gave up continues, still comparing, one per piece and launch (workgroups with nothing to do
+        // return at once); whatever is left after that goes sequentially to the end of its piece
+        for (int round = 0; round < SEG_CONT_ROUNDS; round++) AUGX_LAUNCH_TRELLIS(2, n);
+        AUGX_LAUNCH_TRELLIS(3, n);
     }
 #undef AUGX_LAUNCH_TRELLIS
     hipLaunchKernelGGL(kSegFinalize, dim3((n + 63) / 64), dim3(64), 0, st, V);

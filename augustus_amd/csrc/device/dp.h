@@ -160,6 +160,9 @@ struct BatchView {
     double *ckCol;             // [N/WAVE][SP] ln V column at the end of every tile (pass 1; compared and replaced by pass 2)
     int32_t *segStop;          // [nSegs] pass 2: last tile rewritten when converged (>= t0 - 1), -2 - tile when it gave up after `tile`
     double *segD;              // [nSegs] pass 2: (value in the frame of segment k-1) - (value in the frame of segment k)
+    int32_t *segStop2;         // [nSegs] pass 3: the continuation of a fix-up that gave up converged after this tile (-1: none; last tile of the piece: ran to the end)
+    double *segD2;             // [nSegs] its offset
+    int32_t *pieceCovered;     // [nPieces] last tile of the piece a continuation has redone (-1: none)
     int32_t *segStatus;        // [nSegs] abort flags
     int32_t *brkPos;           // [nSegs] kSegFinalize: region r of the piece = bases (brkPos[r-1], brkPos[r]] ...
     double *brkOff;            // [nSegs] ... whose stored values are true value - brkOff[r]

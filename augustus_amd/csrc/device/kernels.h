@@ -1439,17 +1439,20 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
 
 // MODE 0: pass 1 -- segment `sg` from its (true or dead) start to its end;  MODE 1: pass 2 -- fix-up of segment sg from the
 // end state of the segment before it, until what it retires differs from the values of pass 1 by one constant;
-// MODE 2: pass 3 -- sg is a PIECE: if one of its fix-ups gave up, continue from there to the end of the piece.
+// MODE 2: pass 3 -- sg is a PIECE: its first fix-up that gave up and has not been redone continues from where it stopped, still
+// comparing, with no limit (one per launch; the piece's runs of this pass must not overlap);  MODE 3: such a fix-up continues
+// to the end of the piece without comparing (what is left after the launches of pass 3).
 template <int BLK, int MODE = 0>
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int sg) {
     constexpr int NB = WAVE / BLK;  // blocks per tile
     constexpr int SPR = WAVE / BLK; // state slots per round of 64 lanes: lane = (slot, base of the block)
-    constexpr bool CMP = MODE == 1;
+    constexpr bool CMP = MODE == 1 || MODE == 2;
     int segIdx = sg, tStart = 0, tEnd = 0, ckSrc = -1; // ckSrc: ring checkpoint to start from ([seg] * 2 + slot), -1: none
-    if (MODE == 2) { // the first fix-up of the piece that gave up, if any
+    if (MODE >= 2) { // the first fix-up of the piece that gave up beyond everything a continuation has redone so far
         segIdx = -1;
+        const int cov = B.pieceCovered[sg];
         for (int q = B.pieceSeg0[sg] + 1; q < B.pieceSeg0[sg + 1]; q++)
-            if (B.segStop[q] <= -2) { segIdx = q; break; }
+            if (B.segStop[q] <= -2 && -2 - B.segStop[q] > cov && B.segStop2[q] < 0) { segIdx = q; break; }
         if (segIdx < 0) return;
         tStart = -2 - B.segStop[segIdx] + 1;
         ckSrc = segIdx * 2 + 1;
@@ -1465,10 +1468,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         if (sd.k == 0) return;
         tStart = sd.t0; tEnd = sd.tlim + 1; ckSrc = (segIdx - 1) * 2;
     }
-    if (MODE == 2) tEnd = nTiles;
-    const bool lastOfPiece = tEnd == nTiles && MODE != 1; // this run ends the piece: it does the termination step
+    if (MODE >= 2) tEnd = nTiles;
+    const bool mayEndPiece = tEnd == nTiles; // a run that completes the last tile of the piece does the termination step
     if (c < 0) { // multi-class piece: not decoded by this version
-        FOR_THREADS(t) { if (t == 0 && lastOfPiece) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
+        FOR_THREADS(t) { if (t == 0 && mayEndPiece) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
         return;
     }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
@@ -2085,13 +2088,14 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             const int lb = L.lastBad;
             BLOCK_SYNC();
             if ((tile - 1) - lb >= B.segCheckTiles) break;
-            if (tile + 1 == tEnd) gaveUp = true;
+            if (MODE == 1 && tile + 1 == tEnd) gaveUp = true;
         }
     }
 #if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)
         for (int i = 0; i < 8; i++) B.prof[((int64_t)p * 5 + (threadIdx.x >> 6)) * 8 + i] = X.pacc[i];
 #endif
+    const bool lastOfPiece = mayEndPiece && tLast == nTiles - 1;
     // ---- back pointers of the last tile; list values of the sites of the last two tiles (the back-trace reads them)
     FOR_THREADS(t) {
         if (tLast >= tStart) {
@@ -2110,12 +2114,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
         }
         // ---- segments: the ring where this run stopped (pass 1: for the fix-up of the next segment; a fix-up that gave up: for pass 3)
-        if (B.ckRing && !lastOfPiece && (MODE == 0 || (CMP && gaveUp))) {
-            const int64_t slot = (int64_t)segIdx * 2 + (CMP ? 1 : 0);
+        if (B.ckRing && !lastOfPiece && (MODE == 0 || (MODE == 1 && gaveUp))) {
+            const int64_t slot = (int64_t)segIdx * 2 + (MODE == 1 ? 1 : 0);
             for (int i = t; i < WAVE * SP; i += NT) B.ckRing[(slot * WAVE + i / SP) * SP + i % SP] = L.ring[i / SP][i % SP];
         }
         if (t == 0) {
-            if (CMP) { B.segStop[segIdx] = gaveUp ? -2 - tLast : tLast; B.segD[segIdx] = gaveUp ? 0.0 : L.segDt[tLast & 3]; }
+            if (MODE == 1) { B.segStop[segIdx] = gaveUp ? -2 - tLast : tLast; B.segD[segIdx] = gaveUp ? 0.0 : L.segDt[tLast & 3]; }
+            if (MODE >= 2) { // converged after tile tLast (or ran to the end of the piece: then it is in the frame it started in)
+                B.segStop2[segIdx] = tLast; B.segD2[segIdx] = (CMP && !lastOfPiece) ? L.segDt[tLast & 3] : 0.0;
+                B.pieceCovered[sg] = tLast;
+            }
             if (B.segStatus && L.abortFlag) B.segStatus[segIdx] = 1;
         }
     }
@@ -2144,24 +2152,35 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 AUGX_KFN void segFinalizePiece(const BatchView &B, int p) {
     const int s0 = B.pieceSeg0[p], K = B.pieceSeg0[p + 1] - s0, n = B.len[p];
     if (K <= 1) { B.brkPos[s0] = n - 1; B.brkOff[s0] = 0.0; return; }
-    // frame k = the values segment k computed in pass 1 (frame 0 = the true values).  Fix-up k rewrote tiles up to segStop[k] in
-    // frame k - 1 and measured D_k = (frame k-1) - (frame k): region r = bases (end of tile segStop[r], end of tile segStop[r+1]]
-    // is stored in frame r, true value = stored + D_1 + ... + D_r.  If fix-up f gave up, pass 3 redid everything after it in
-    // frame f - 1: region f - 1 then runs to the end of the piece.
+    // frame k = the values segment k computed in pass 1 (frame 0 = the true values).  Fix-up k rewrote the tiles up to segStop[k]
+    // in the frame of what lies before it and measured D = (that frame) - (frame behind): every converged run ends a region,
+    // and the region after it is off by D more.  A fix-up that gave up was continued by pass 3 (segStop2 / segD2) -- possibly
+    // across later segments, whose own records inside the span it redid no longer exist.  A run that reached the end of the
+    // piece leaves one last region in the frame it started in.
     double off = 0.0;
-    int failed = K;
-    for (int k = 1; k < K; k++)
-        if (B.segStop[s0 + k] <= -2) { failed = k; break; }
-    bool abortAny = false;
-    for (int r = 0; r < K; r++) {
-        if (r >= 1 && r < failed) off = off + B.segD[s0 + r];
-        const bool lastRegion = r + 1 >= failed || r + 1 >= K;
-        B.brkPos[s0 + r] = lastRegion ? n - 1 : (B.segStop[s0 + r + 1] + 1) * WAVE - 1;
-        B.brkOff[s0 + r] = r < failed ? off : 0.0;
-        if (B.segStatus[s0 + r]) abortAny = true;
+    int covered = -1, r = 0;
+    bool done = false, abortAny = false;
+    const int lastTile = (n + WAVE - 1) / WAVE - 1;
+    for (int k = 0; k < K; k++)
+        if (B.segStatus[s0 + k]) abortAny = true;
+    for (int k = 1; k < K && !done; k++) {
+        const int st = B.segStop[s0 + k];
+        int endTile;
+        double D;
+        if (st >= -1) { endTile = st; D = B.segD[s0 + k]; }
+        else {
+            if (-2 - st <= covered) continue;
+            endTile = B.segStop2[s0 + k]; D = B.segD2[s0 + k];
+            if (endTile < 0) { abortAny = true; endTile = lastTile; } // (never expected: pass 3 leaves no fix-up behind)
+            covered = endTile;
+        }
+        if (st >= -1 && endTile <= covered) continue;
+        if (endTile >= lastTile) { done = true; break; }
+        B.brkPos[s0 + r] = (endTile + 1) * WAVE - 1; B.brkOff[s0 + r] = off; r++;
+        off = off + D;
     }
-    const double lastOff = B.brkOff[s0 + (failed < K ? failed - 1 : K - 1)];
-    if (B.status[p] == 0) B.lnv[p] = B.lnv[p] + lastOff;
+    for (; r < K; r++) { B.brkPos[s0 + r] = n - 1; B.brkOff[s0 + r] = off; }
+    if (B.status[p] == 0) B.lnv[p] = B.lnv[p] + off;
     if (abortAny) B.status[p] = AUGX_E_HIP;
 }
 

@@ -96,6 +96,7 @@ inline int64_t listOffsets(const int32_t *listCnt, int nPieces, std::vector<int6
 // ---- segments of the trellis (dp.h: SegDesc).  A fix-up ends after `checkTiles` consecutive verified tiles: they must cover
 // the longest look-back of any state (a candidate of a variable-length state reaches back at most one maximal exon or intron
 // plus its signal windows; equalD reads at lag dStateLen), plus the tiles whose retired values are still on their way.
+constexpr int SEG_CONT_ROUNDS = 3; // launches of pass 3 (one continuation per piece each); what is left goes sequentially to the end
 struct SegPlan {
     std::vector<SegDesc> segs;
     std::vector<int32_t> pieceSeg0;

@@ -206,9 +206,10 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.pieceSeg0 = plan.pieceSeg0.data();
     B.segCheckTiles = plan.checkTiles;
     if (const char *e = getenv("AUGX_SEG_CHECK_TILES")) B.segCheckTiles = atoi(e); // (tests of the give-up path: an unreachable check length)
-    std::vector<int32_t> segStop(B.nSegs, -1), segStatus(B.nSegs, 0), brkPos(B.nSegs, 0);
-    std::vector<double> segD(B.nSegs, 0.0), brkOff(B.nSegs, 0.0);
+    std::vector<int32_t> segStop(B.nSegs, -1), segStop2(B.nSegs, -1), segStatus(B.nSegs, 0), brkPos(B.nSegs, 0), pieceCovered(n, -1);
+    std::vector<double> segD(B.nSegs, 0.0), segD2(B.nSegs, 0.0), brkOff(B.nSegs, 0.0);
     B.segStop = segStop.data(); B.segStatus = segStatus.data(); B.segD = segD.data(); B.brkPos = brkPos.data(); B.brkOff = brkOff.data();
+    B.segStop2 = segStop2.data(); B.segD2 = segD2.data(); B.pieceCovered = pieceCovered.data();
     if (plan.cut()) {
         B.ckRing = zalloc<double>((int64_t)B.nSegs * 2 * WAVE * SP);
         B.ckCol = zalloc<double>(Z.N / WAVE * SP);
@@ -218,14 +219,16 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     for (int sg = 0; sg < B.nSegs; sg++) EMU_TRELLIS(0, sg);
     if (plan.cut()) {
         for (int sg = B.nSegs - 1; sg >= 0; sg--) EMU_TRELLIS(1, sg); // (any order: the fix-ups are independent of each other)
-        for (int p = 0; p < n; p++) EMU_TRELLIS(2, p);
+        for (int round = 0; round < SEG_CONT_ROUNDS; round++)
+            for (int p = 0; p < n; p++) EMU_TRELLIS(2, p);
+        for (int p = 0; p < n; p++) EMU_TRELLIS(3, p);
     }
 #undef EMU_TRELLIS
     int nGaveUp = 0;
     for (int sg = 0; sg < B.nSegs; sg++) nGaveUp += segStop[sg] <= -2;
     if (getenv("AUGX_EMU_STATS")) {
         fprintf(stderr, "emu stats: %d segments for %d pieces, check %d tiles, %d fix-ups gave up;", B.nSegs, n, B.segCheckTiles, nGaveUp);
-        for (int sg = 0; sg < B.nSegs && sg < 24; sg++) fprintf(stderr, " [%d:%d..%d stop %d D %.6f]", plan.segs[sg].piece, plan.segs[sg].t0, plan.segs[sg].t1, segStop[sg], segD[sg]);
+        for (int sg = 0; sg < B.nSegs && sg < 24; sg++) fprintf(stderr, " [%d:%d..%d stop %d D %.3f cont %d]", plan.segs[sg].piece, plan.segs[sg].t0, plan.segs[sg].t1, segStop[sg], segD[sg], segStop2[sg]);
         fprintf(stderr, "\n");
     }
     for (int p = 0; p < n; p++) {
