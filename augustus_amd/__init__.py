@@ -65,6 +65,7 @@ def lib():
         L.augx_decode_sharded.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.augx_decoder_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.augx_decoder_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_decoder_set_share.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.augx_decoder_batch_capacity.restype = ctypes.c_int64
         L.augx_decoder_batch_capacity.argtypes = [ctypes.c_void_p]
         L.augx_batch_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -231,6 +232,10 @@ class Decoder:
         self._batches = weakref.WeakSet()
         self._h = ctypes.c_void_p()
         _check(lib().augx_decoder_create(model._h, device, ctypes.byref(self._h)))
+
+    def set_share(self, n):
+        """n decoders (streams) work on this device at the same time: plan the trellis segments for 1/n of its compute units"""
+        _check(lib().augx_decoder_set_share(self._h, n))
 
     def decode(self, seqs, init_kind=0, term_kind=0):
         b = Batch(self, seqs, init_kind, term_kind)

@@ -39,10 +39,6 @@ __global__ void __launch_bounds__(256) kEncode(BatchView B) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1Encode(B, g);
 }
-__global__ void __launch_bounds__(256) kSiteTerms(const DevTables *T, BatchView B) {
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < B.N) k1SiteTerms(*T, B, g);
-}
 // (min, max) of the window classes of every 256 slots (no atomics: tens of thousands of wavefronts of one piece hammering the
 // same two words cost more than the rest of the kernel); kClassFinal folds them per piece
 __global__ void __launch_bounds__(256) kWindowClass(const DevTables *T, BatchView B, int32_t *blkMinMax) {
@@ -83,10 +79,6 @@ __global__ void kListCount(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < B.nPieces) k1ListCount(B, p);
 }
-__global__ void __launch_bounds__(256) kFxTerms(const DevTables *T, BatchView B) { // grid.y = plane
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < B.N) k1FxTerms(*T, B, g, blockIdx.y);
-}
 __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1Signals(*T, B, g);
@@ -99,52 +91,109 @@ __global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView
     if (g < B.N) k1SiteConsts(*T, B, g, blockIdx.y);
 }
 
-// ---- chunked piece-local inclusive scans over rows [chunk][field][CHUNK] of uint64 (sum or max) ----
-template <bool MAX> __device__ inline uint64_t comb(uint64_t a, uint64_t b) { return MAX ? (a > b ? a : b) : a + b; }
-
-template <bool MAX> __global__ void __launch_bounds__(256) kScanTotals(const uint64_t *a, uint64_t *tot, int nf) {
-    const int chunk = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
-    const uint64_t *row = a + ((int64_t)chunk * nf + f) * CHUNK;
-    uint64_t v = comb<MAX>(comb<MAX>(row[t * 4], row[t * 4 + 1]), comb<MAX>(row[t * 4 + 2], row[t * 4 + 3]));
-    for (int o = 32; o >= 1; o >>= 1) v = comb<MAX>(v, (uint64_t)__shfl_xor((unsigned long long)v, o, 64));
-    __shared__ uint64_t w[4];
-    if ((t & 63) == 0) w[t >> 6] = v;
+// ---- fused term + scan kernels: one workgroup of 1024 threads per chunk of CHUNK slots, one thread per slot.  The terms of a
+// slot (11 site counts + 6 stop positions, or 20 fixed-point content terms) are computed in registers in BOTH passes -- totals
+// of the chunk, then the scan proper -- so that the prefix arrays are written to HBM once and never read by the scans (the
+// separate term kernels wrote them, kScanTotals read them, kScanApply read and rewrote them: four passes over 296 B per base).
+// Integer sums and maxima are exact: any scan shape gives the same bits as the sequential loop of the emulator.
+static_assert(CHUNK == 1024, "one thread per slot of a chunk");
+template <int NF, int NMAX> struct ScanLds { uint64_t w[NF][16]; };
+// field f < NMAXFIRST ... : the first `nSum` fields are summed, the rest take the maximum
+template <int NF> __device__ inline void chunkTotals(const uint64_t (&v)[NF], int nSum, ScanLds<NF, 0> &L, uint64_t *tot /* [NF] of this chunk */) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        uint64_t x = v[f];
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)x, o, 64);
+            x = f < nSum ? x + y : (x > y ? x : y);
+        }
+        if (lane == 0) L.w[f][wave] = x;
+    }
     __syncthreads();
-    if (t == 0) tot[(int64_t)chunk * nf + f] = comb<MAX>(comb<MAX>(w[0], w[1]), comb<MAX>(w[2], w[3]));
+    if (t < NF) {
+        uint64_t x = L.w[t][0];
+        for (int i = 1; i < 16; i++) x = t < nSum ? x + L.w[t][i] : (x > L.w[t][i] ? x : L.w[t][i]);
+        tot[t] = x;
+    }
 }
-// exclusive scan of the chunk totals inside each piece: one block per piece, one thread per field
-template <bool MAX> __global__ void kScanPieceOffsets(uint64_t *tot, BatchView B, int nf) {
+// inclusive scan of every field across the 1024 slots of the chunk, on top of the chunk's exclusive offset pre[f]
+template <int NF> __device__ inline void chunkScan(uint64_t (&v)[NF], int nSum, ScanLds<NF, 0> &L, const uint64_t *pre) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        uint64_t x = v[f];
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = (uint64_t)__shfl_up((unsigned long long)x, o, 64);
+            if (lane >= o) x = f < nSum ? x + y : (x > y ? x : y);
+        }
+        v[f] = x;
+        if (lane == 63) L.w[f][wave] = x;
+    }
+    __syncthreads();
+    if (t < NF) { // exclusive scan of the 16 wave totals of field t, seeded with the chunk's offset
+        uint64_t acc = pre[t];
+        for (int i = 0; i < 16; i++) {
+            const uint64_t x = L.w[t][i];
+            L.w[t][i] = acc;
+            acc = t < nSum ? acc + x : (acc > x ? acc : x);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < NF; f++) {
+        const uint64_t a = L.w[f][wave];
+        v[f] = f < nSum ? v[f] + a : (v[f] > a ? v[f] : a);
+    }
+}
+constexpr int NSF = NCNT + 6; // site scans: 11 counts (sums) then 6 stop positions (maxima)
+__global__ void __launch_bounds__(1024) kSiteScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nChunks][NSF] */) {
+    __shared__ ScanLds<NSF, 0> L;
+    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    uint64_t v[NSF];
+    k1SiteTermsCalc(*T, B, g, v, v + NCNT);
+    chunkTotals<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
+}
+__global__ void __launch_bounds__(1024) kSiteScanApply(const DevTables *T, BatchView B, const uint64_t *tot) {
+    __shared__ ScanLds<NSF, 0> L;
+    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    uint64_t v[NSF];
+    k1SiteTermsCalc(*T, B, g, v, v + NCNT);
+    chunkScan<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
+#pragma unroll
+    for (int f = 0; f < NCNT; f++) B.cnt[fidx(g, f, NCNT)] = v[f];
+#pragma unroll
+    for (int f = 0; f < 6; f++) B.nsm[fidx(g, f, 6)] = v[NCNT + f];
+}
+__global__ void __launch_bounds__(1024) kFxScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nPl][nChunks][NFX] */) { // grid.y = plane
+    __shared__ ScanLds<NFX, 0> L;
+    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    uint64_t v[NFX];
+    if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v)) return; // (uniform over the chunk: a chunk belongs to one piece)
+    chunkTotals<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * B.nChunks + blockIdx.x) * NFX);
+}
+__global__ void __launch_bounds__(1024) kFxScanApply(const DevTables *T, BatchView B, const uint64_t *tot) { // grid.y = plane
+    __shared__ ScanLds<NFX, 0> L;
+    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    uint64_t v[NFX];
+    if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v)) return;
+    chunkScan<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * B.nChunks + blockIdx.x) * NFX);
+    uint64_t *fx = B.fx + (int64_t)blockIdx.y * B.N * NFX;
+#pragma unroll
+    for (int f = 0; f < NFX; f++) fx[fidx(g, f, NFX)] = v[f];
+}
+// exclusive scan of the chunk totals inside each piece (one workgroup per piece and plane, one thread per field; the first nSum
+// fields are sums, the rest maxima)
+__global__ void kChunkOffsets(uint64_t *tot, BatchView B, int nf, int nSum) {
     const int p = blockIdx.x, f = threadIdx.x;
     if (f >= nf) return;
+    tot += (int64_t)blockIdx.y * B.nChunks * nf;
     uint64_t acc = 0;
     for (int64_t ch = B.off[p] / CHUNK; ch < B.off[p + 1] / CHUNK; ch++) {
-        uint64_t v = tot[ch * nf + f];
+        const uint64_t v = tot[ch * nf + f];
         tot[ch * nf + f] = acc;
-        acc = comb<MAX>(acc, v);
+        acc = f < nSum ? acc + v : (acc > v ? acc : v);
     }
-}
-template <bool MAX> __global__ void __launch_bounds__(256) kScanApply(uint64_t *a, const uint64_t *tot, int nf) {
-    const int chunk = blockIdx.x, f = blockIdx.y, t = threadIdx.x;
-    uint64_t *row = a + ((int64_t)chunk * nf + f) * CHUNK;
-    uint64_t v0 = row[t * 4], v1 = comb<MAX>(v0, row[t * 4 + 1]), v2 = comb<MAX>(v1, row[t * 4 + 2]), v3 = comb<MAX>(v2, row[t * 4 + 3]);
-    // inclusive scan of the thread totals across the block
-    uint64_t inc = v3;
-    const int lane = t & 63;
-    for (int o = 1; o < 64; o <<= 1) {
-        uint64_t up = (uint64_t)__shfl_up((unsigned long long)inc, o, 64);
-        if (lane >= o) inc = comb<MAX>(inc, up);
-    }
-    __shared__ uint64_t w[4];
-    if (lane == 63) w[t >> 6] = inc;
-    __syncthreads();
-    uint64_t pre = tot[(int64_t)chunk * nf + f];
-    for (int i = 0; i < (t >> 6); i++) pre = comb<MAX>(pre, w[i]);
-    uint64_t excl = (uint64_t)__shfl_up((unsigned long long)inc, 1, 64);
-    if (lane > 0) pre = comb<MAX>(pre, excl);
-    row[t * 4] = comb<MAX>(pre, v0);
-    row[t * 4 + 1] = comb<MAX>(pre, v1);
-    row[t * 4 + 2] = comb<MAX>(pre, v2);
-    row[t * 4 + 3] = comb<MAX>(pre, v3);
 }
 
 // ---- candidates of the variable-length states: one wavefront per tile of 64 bases (describe + count, reserve, evaluate) ----
@@ -180,6 +229,7 @@ struct augx_decoder {
     bool debugCells = false;
     int blk = 8;              // block size of the candidate / trellis kernels for this model (layout.h: chooseBlockSize)
     int nCU = 256;            // compute units of the device = trellis workgroups in flight (one per CU: 155 KB of LDS each)
+    int share = 1;            // decoders working on this device at the same time (augx_decoder_set_share)
 };
 
 constexpr int NARR = 20; // arrays managed by ensureArrays
@@ -200,6 +250,7 @@ struct augx_batch {
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
     bool decoded = false;
     SegPlan plan;            // segments of the trellis (layout.h: planSegments)
+    int chunkTotPlanes = 1;  // planes the scan totals are allocated for
 };
 
 namespace {
@@ -261,16 +312,6 @@ int ensureArrays(augx_batch *b, int nPl, int64_t listCap) {
     return 0;
 }
 
-template <bool MAX> int runScan(augx_batch *b, uint64_t *a, int nf) {
-    augx_decoder *d = b->dec;
-    dim3 grid(b->L.nChunks, nf);
-    hipLaunchKernelGGL((kScanTotals<MAX>), grid, dim3(256), 0, d->stream, a, b->V.chunkTot, nf);
-    hipLaunchKernelGGL((kScanPieceOffsets<MAX>), dim3(b->L.nPieces), dim3(32), 0, d->stream, b->V.chunkTot, b->V, nf);
-    hipLaunchKernelGGL((kScanApply<MAX>), grid, dim3(256), 0, d->stream, a, b->V.chunkTot, nf);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 } // namespace
 
 extern "C" {
@@ -324,6 +365,12 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     }();
     if (rc) { augx_decoder_destroy(d); return rc; }
     *out = d;
+    return AUGX_OK;
+}
+
+int augx_decoder_set_share(augx_decoder *d, int n) {
+    if (!d || n < 1) { setLastError("augx_decoder_set_share: bad argument"); return AUGX_E_ARG; }
+    d->share = n;
     return AUGX_OK;
 }
 
@@ -412,7 +459,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
     // segments of the trellis: enough workgroups for every compute unit, none shorter than what a fix-up needs
-    b->plan = planSegments(L, d->model->m.t, d->nCU);
+    b->plan = planSegments(L, d->model->m.t, d->nCU / d->share > 0 ? d->nCU / d->share : 1);
     SegDesc *dSegs; int32_t *dSeg0;
     const int nSegs = (int)b->plan.segs.size();
     DA(dSegs, SegDesc, nSegs); DA(dSeg0, int32_t, n + 1);
@@ -453,10 +500,11 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipStream_t st = d->stream;
     HIP_TRY(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(kEncode, dim3(gridN), dim3(256), 0, st, V);
-    hipLaunchKernelGGL(kSiteTerms, dim3(gridN), dim3(256), 0, st, d->dT, V);
     int rc;
-    if ((rc = runScan<false>(b, V.cnt, NCNT))) return rc;
-    if ((rc = runScan<true>(b, V.nsm, 6))) return rc;
+    // site counts and stop positions: terms and prefix scans fused (the prefix arrays are written once, never read back here)
+    hipLaunchKernelGGL(kSiteScanTotals, dim3(V.nChunks), dim3(1024), 0, st, d->dT, V, V.chunkTot);
+    hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1), dim3(32), 0, st, V.chunkTot, V, NSF, NCNT);
+    hipLaunchKernelGGL(kSiteScanApply, dim3(V.nChunks), dim3(1024), 0, st, d->dT, V, V.chunkTot);
     if (!b->listsReady) hipLaunchKernelGGL(kListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
     hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V, b->blkMinMax);
     hipLaunchKernelGGL(kClassFinal, dim3(n), dim3(64), 0, st, V, b->blkMinMax);
@@ -508,9 +556,20 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             HIP_TRY(hipMemcpy(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice));
         }
     }
-    hipLaunchKernelGGL(kFxTerms, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);
-    for (int pl = 0; pl < V.nPl; pl++)
-        if ((rc = runScan<false>(b, V.fx + (int64_t)pl * V.N * NFX, NFX))) return rc;
+    if (V.nPl > b->chunkTotPlanes) { // (one set of chunk totals per plane of the class-dependent arrays)
+        uint64_t *nt = nullptr;
+        if (hipMalloc((void **)&nt, sizeof(uint64_t) * (size_t)V.nPl * V.nChunks * NFX) != hipSuccess) {
+            (void)hipGetLastError();
+            setLastError("augx_batch_decode: out of device memory for the scan totals");
+            return AUGX_E_NOMEM;
+        }
+        b->bufs.push_back(nt);
+        b->V.chunkTot = nt;
+        b->chunkTotPlanes = V.nPl;
+    }
+    hipLaunchKernelGGL(kFxScanTotals, dim3(V.nChunks, V.nPl), dim3(1024), 0, st, d->dT, V, V.chunkTot);
+    hipLaunchKernelGGL(kChunkOffsets, dim3(n, V.nPl), dim3(32), 0, st, V.chunkTot, V, NFX, NFX);
+    hipLaunchKernelGGL(kFxScanApply, dim3(V.nChunks, V.nPl), dim3(1024), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.listCap + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);

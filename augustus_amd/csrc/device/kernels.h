@@ -168,14 +168,14 @@ AUGX_HD void k1Encode(const BatchView &B, int64_t g) {
     B.code[g] = c;
 }
 
-// site flags and stop codons -> terms of the count / max scans
-AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
+// site flags and stop codons -> terms of the count / max scans (in registers: the device scans recompute them in both of
+// their passes instead of reading them back from HBM, decoder.hip kSiteScan*)
+AUGX_HD void k1SiteTermsCalc(const DevTables &T, const BatchView &B, int64_t g, uint64_t cnt[NCNT], uint64_t ns[6]) {
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
     Piece P;
     P.t = &T; P.n = B.len[p]; P.c = 0; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
-    uint64_t cnt[NCNT], ns[6];
     for (int i = 0; i < NCNT; i++) cnt[i] = 0;
     for (int i = 0; i < 6; i++) ns[i] = 0;
     if (q >= 0 && q < P.n) {
@@ -196,6 +196,10 @@ AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
         if (P.isRCStop(q)) { ns[3 + q % 3] = (uint64_t)q + 1; cnt[CNT_RS] = 1; }
     }
     }
+}
+AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
+    uint64_t cnt[NCNT], ns[6];
+    k1SiteTermsCalc(T, B, g, cnt, ns);
     for (int i = 0; i < NCNT; i++) B.cnt[fidx(g, i, NCNT)] = cnt[i];
     for (int i = 0; i < 6; i++) B.nsm[fidx(g, i, 6)] = ns[i];
 }
@@ -252,13 +256,12 @@ AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
     return c;
 }
 
-// fixed-point terms of the 20 content prefix fields
-AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g, int pl) {
+// fixed-point terms of the 20 content prefix fields (false: the piece has no plane pl)
+AUGX_HD bool k1FxTermsCalc(const DevTables &T, const BatchView &B, int64_t g, int pl, uint64_t out[NFX]) {
     int p = B.chunkPiece[g / CHUNK];
-    if (pl > 0 && pl >= B.nPlanes[p]) return; // (this piece has no such plane)
+    if (pl > 0 && pl >= B.nPlanes[p]) return false; // (this piece has no such plane)
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
-    uint64_t out[NFX];
     for (int i = 0; i < NFX; i++) out[i] = 0;
     Piece P;
     P.t = &T; P.n = B.len[p]; P.c = B.cls[p] < 0 ? -1 : B.planeCls[p * MAXPL + pl]; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
@@ -281,6 +284,11 @@ AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g, int pl
     int rn2 = (q + k < P.n) ? rn : -1;
     out[FX_INR] = toFx((rn2 >= 0 ? inE[rn2] : T.ln_quarter) + softB);
     }
+    return true;
+}
+AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g, int pl) {
+    uint64_t out[NFX];
+    if (!k1FxTermsCalc(T, B, g, pl, out)) return;
     uint64_t *fx = B.fx + (int64_t)pl * B.N * NFX;
     for (int i = 0; i < NFX; i++) fx[fidx(g, i, NFX)] = out[i];
 }

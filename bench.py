@@ -249,8 +249,10 @@ def main():
         max over ranks.  One step = one decode of one batch; step s runs on batch s % inflight, each batch on its own decoder
         (HIP stream) driven by its own host thread, so consecutive steps overlap like consecutive batches of a genome."""
         decs, batches = [], []
-        for i in range(max(1, min(n_fl_want, a.steps))):
+        n_dec = max(1, min(n_fl_want, a.steps))
+        for i in range(n_dec):
             d = ax.Decoder(model, local)
+            d.set_share(n_dec)           # (the decoders of the resident batches share the device: each plans its trellis segments for its share)
             try:  # H2D upload: inputs are resident in HBM before the timed region
                 seqs = rank_contigs(mode, rank, world, a.contigs, a.contig_len, batch=i)
                 if not seqs:

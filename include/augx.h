@@ -162,6 +162,9 @@ void augx_model_destroy(augx_model *m);
 int augx_device_count(void);              /* visible HIP devices (0 without a GPU: there is no CPU decode path)           */
 int augx_decoder_create(const augx_model *m, int device, augx_decoder **out);
 void augx_decoder_destroy(augx_decoder *d);
+/* how many decoders (streams) decode on this device at the same time (default 1).  The trellis kernel cuts pieces into
+ * segments so that every compute unit has a workgroup; a decoder that shares the device plans for its share of them. */
+int augx_decoder_set_share(augx_decoder *d, int n_decoders_on_device);
 /* bases one batch should hold at most: what fits the free device memory (about 1.5 KB per base), capped at 128 Mbp */
 int64_t augx_decoder_batch_capacity(augx_decoder *d);
 

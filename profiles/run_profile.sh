@@ -1,0 +1,18 @@
+#!/bin/bash
+# On the GPU box (through gpurun): per-kernel time of one bench configuration -> gpurun_out/<tag>_kernel_stats.txt
+#   usage: profiles/run_profile.sh <tag> [bench.py arguments...]
+# (counters are collected in their own runs, see profiles/run_pmc.sh: --pmc is never combined with other trace domains)
+set -e
+TAG=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p "$ROOT/gpurun_out"
+export TMPDIR=/tmp
+OUT=/tmp/prof_$TAG
+rm -rf "$OUT"
+cd /tmp
+rocprofv3 --kernel-trace --stats -d "$OUT" -o t1 -- python "$ROOT/bench.py" --no-cpu-baseline --no-e2e "$@" > "$ROOT/gpurun_out/${TAG}_bench.json" 2> "$ROOT/gpurun_out/${TAG}_bench.err" || true
+DB=$(find "$OUT" -name '*results.db' | head -1)
+python "$ROOT/profiles/summarize_rocpd.py" "$DB" > "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-e2e $*" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+cat "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+tail -1 "$ROOT/gpurun_out/${TAG}_bench.json" | cut -c1-600
