@@ -10,6 +10,8 @@
 // There is no CPU fallback anywhere in this file: without a HIP device augx_decoder_create fails.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <map>
+#include <unordered_map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -230,7 +232,44 @@ struct augx_decoder {
     int blk = 8;              // block size of the candidate / trellis kernels for this model (layout.h: chooseBlockSize)
     int nCU = 256;            // compute units of the device = trellis workgroups in flight (one per CU: 155 KB of LDS each)
     int share = 1;            // decoders working on this device at the same time (augx_decoder_set_share)
+    // device buffers of destroyed batches, kept for the next batch (the cut finder decodes a small batch per round, a genome
+    // many large ones: dozens of hipMalloc / hipFree per batch otherwise); given back to the runtime when an allocation fails
+    std::multimap<size_t, void *> pool;
+    std::unordered_map<void *, size_t> live;
+    size_t pooledBytes = 0;
 };
+
+namespace {
+void poolRelease(augx_decoder *d) {
+    for (auto &kv : d->pool) (void)hipFree(kv.second);
+    d->pool.clear();
+    d->pooledBytes = 0;
+}
+hipError_t devMalloc(augx_decoder *d, void **out, size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    auto it = d->pool.lower_bound(bytes);
+    if (it != d->pool.end() && it->first <= bytes + bytes / 4 + 4096) { // a pooled buffer that is not wastefully large
+        *out = it->second;
+        d->live[*out] = it->first;
+        d->pooledBytes -= it->first;
+        d->pool.erase(it);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !d->pool.empty()) { (void)hipGetLastError(); poolRelease(d); e = hipMalloc(out, bytes); }
+    if (e == hipSuccess) d->live[*out] = bytes;
+    return e;
+}
+void devFree(augx_decoder *d, void *p) {
+    if (!p) return;
+    auto it = d->live.find(p);
+    if (it == d->live.end()) { (void)hipFree(p); return; }
+    d->pool.emplace(it->second, p);
+    d->pooledBytes += it->second;
+    d->live.erase(it);
+}
+} // namespace
+
 
 constexpr int NARR = 20; // arrays managed by ensureArrays
 struct augx_batch {
@@ -257,7 +296,7 @@ namespace {
 
 template <class T> int devAlloc(augx_batch *b, T **ptr, int64_t count) {
     void *p = nullptr;
-    const hipError_t e = hipMalloc(&p, (size_t)(count > 0 ? count : 1) * sizeof(T));
+    const hipError_t e = devMalloc(b->dec, &p, (size_t)(count > 0 ? count : 1) * sizeof(T));
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         setLastError("augx: out of device memory while allocating a batch; decode fewer bases per batch");
@@ -294,13 +333,13 @@ int ensureArrays(augx_batch *b, int nPl, int64_t listCap) {
     for (int i = 0; i < NARR; i++) {
         const bool isN = i < 2; // (fx, plsR: sized by the slots, they only grow with the planes)
         if (isN && nPl == b->nPlAlloc && b->planeBufs[i]) continue;
-        if (b->planeBufs[i]) { HIP_TRY(hipFree(b->planeBufs[i])); b->planeBufs[i] = nullptr; *slots[i].field = nullptr; }
+        if (b->planeBufs[i]) { devFree(b->dec, b->planeBufs[i]); b->planeBufs[i] = nullptr; *slots[i].field = nullptr; }
         void *p = nullptr;
-        if (hipMalloc(&p, (size_t)slots[i].planes * (size_t)slots[i].count * slots[i].elem) != hipSuccess) {
+        if (devMalloc(b->dec, &p, (size_t)slots[i].planes * (size_t)slots[i].count * slots[i].elem) != hipSuccess) {
             (void)hipGetLastError();
             b->nPlAlloc = 0; b->listCapAlloc = 0;
             for (int k = 0; k < NARR; k++)
-                if (b->planeBufs[k]) { (void)hipFree(b->planeBufs[k]); b->planeBufs[k] = nullptr; }
+                if (b->planeBufs[k]) { devFree(b->dec, b->planeBufs[k]); b->planeBufs[k] = nullptr; }
             setLastError("augx: out of device memory for the candidate-list / per-GC-class arrays (" + std::to_string(nPl) + " classes in one piece); decode fewer bases per batch");
             return AUGX_E_NOMEM;
         }
@@ -381,6 +420,7 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     // ~0.6 KB of per-base arrays + ~0.3 KB of candidates + the candidate lists (sized from the counted sites: ~20 B per base,
     // up to 150 B on site-dense sequence), with head room; a model with several GC classes may need the class-dependent
     // arrays (~0.2 KB per base) once more per extra class met inside one piece: room for two extra
+    freeB += d->pooledBytes; // (buffers of earlier batches kept by this decoder are free for the next one)
     int64_t cap = (int64_t)(freeB / (d->model->m.t.n_classes > 1 ? 2000 : 1500));
     if (cap > 128L * 1000 * 1000) cap = 128L * 1000 * 1000;
     if (cap < 1000 * 1000) cap = 1000 * 1000;
@@ -390,6 +430,7 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
 void augx_decoder_destroy(augx_decoder *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
+    poolRelease(d);
     for (void *p : d->tableBufs) (void)hipFree(p);
     if (d->dT) (void)hipFree(d->dT);
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -399,10 +440,10 @@ void augx_decoder_destroy(augx_decoder *d) {
 void augx_batch_destroy(augx_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->dec->device);
-    for (void *p : b->bufs) (void)hipFree(p);
+    for (void *p : b->bufs) devFree(b->dec, p);
     for (void *p : b->planeBufs)
-        if (p) (void)hipFree(p);
-    if (b->itemBuf) (void)hipFree(b->itemBuf);
+        if (p) devFree(b->dec, p);
+    if (b->itemBuf) devFree(b->dec, b->itemBuf);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
     delete b;
@@ -481,7 +522,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     HIP_TRY(hipMemset(V.gcPlane, 0, (size_t)Z.N));
     for (int p = 0; p < n; p++)
         HIP_TRY(hipMemcpy(dRaw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p], hipMemcpyHostToDevice));
-    { void *pv = nullptr; HIP_TRY(hipMalloc(&pv, sizeof(BatchView))); b->bufs.push_back(pv); b->dV = (BatchView *)pv; }
+    { void *pv = nullptr; HIP_TRY(devMalloc(d, &pv, sizeof(BatchView))); b->bufs.push_back(pv); b->dV = (BatchView *)pv; }
     HIP_TRY(hipMemcpy(b->dV, &V, sizeof(BatchView), hipMemcpyHostToDevice));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
     return AUGX_OK;
@@ -558,7 +599,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     }
     if (V.nPl > b->chunkTotPlanes) { // (one set of chunk totals per plane of the class-dependent arrays)
         uint64_t *nt = nullptr;
-        if (hipMalloc((void **)&nt, sizeof(uint64_t) * (size_t)V.nPl * V.nChunks * NFX) != hipSuccess) {
+        if (devMalloc(d, (void **)&nt, sizeof(uint64_t) * (size_t)V.nPl * V.nChunks * NFX) != hipSuccess) {
             (void)hipGetLastError();
             setLastError("augx_batch_decode: out of device memory for the scan totals");
             return AUGX_E_NOMEM;
@@ -581,12 +622,12 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         if (b->itemBuf && b->nItems > 0 && (uint64_t)W.itemCap > b->nItems + b->nItems / 16 + 65536) {
             // a batch decoded again: its candidate count is known, give back what the first estimate took too much
             HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipFree(b->itemBuf));
+            devFree(d, b->itemBuf);
             b->itemBuf = nullptr;
         }
         if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
             W.itemCap = b->nItems > 0 ? (int64_t)(b->nItems + b->nItems / 16 + 65536) : W.N * 18 + 65536;
-            if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
+            if (devMalloc(d, &b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
                 (void)hipGetLastError();
                 b->itemBuf = nullptr;
                 setLastError("augx_batch_decode: out of device memory for the candidate buffer; decode fewer bases per batch");
@@ -611,10 +652,10 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             b->nPairs = tot.pairs; b->nItems = tot.items;
             if ((int64_t)tot.items <= W.itemCap) break;
             if (attempt > 0) { setLastError("augx_batch_decode: candidate buffers overflowed twice"); return AUGX_E_HIP; }
-            HIP_TRY(hipFree(b->itemBuf));
+            devFree(d, b->itemBuf);
             b->itemBuf = nullptr;
             W.itemCap = (int64_t)tot.items + 64;
-            if (hipMalloc(&b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
+            if (devMalloc(d, &b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
                 (void)hipGetLastError();
                 b->itemBuf = nullptr;
                 setLastError("augx_batch_decode: out of device memory for the candidate buffer (" + std::to_string(tot.items) + " candidates); decode fewer bases per batch");

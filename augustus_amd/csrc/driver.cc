@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,28 +25,54 @@ namespace {
 
 struct Record { std::string name, seq; };
 
-// reference readOneFastaSeq / readFastaHeader, src/fasta.cc:132-182
+// reference readOneFastaSeq / readFastaHeader, src/fasta.cc:132-182: a record starts at '>' (name = first word of the header;
+// a sequence before any header is "unnamed-N"), its sequence is every alphabetic character of the lines that follow.
+// The whole input is read at once and scanned line by line with memchr (a genome is hundreds of megabytes).
 bool readFasta(std::istream &in, std::vector<Record> &recs) {
-    std::string line;
+    std::string data;
+    {
+        std::ostringstream ss;
+        ss << in.rdbuf();
+        data = ss.str();
+    }
+    size_t i = 0;
+    const size_t n = data.size();
+    while (i < n && isspace((unsigned char)data[i])) i++;
+    if (i >= n || data[i] != '>') return false;
     int unnamed = 1;
-    in >> std::ws;
-    if (!in || in.peek() != '>') return false;
-    while (in) {
-        in >> std::ws;
-        if (!in) break;
+    while (i < n) {
+        while (i < n && isspace((unsigned char)data[i])) i++;
+        if (i >= n) break;
         Record r;
-        if (in.peek() == '>') {
-            std::getline(in, line);
-            size_t e = 1;
-            while (e < line.size() && !isspace((unsigned char)line[e])) e++;
-            r.name = line.substr(1, e - 1);
+        if (data[i] == '>') {
+            const char *nl = (const char *)memchr(data.data() + i, '\n', n - i);
+            const size_t e = nl ? (size_t)(nl - data.data()) : n;
+            size_t w = i + 1;
+            while (w < e && !isspace((unsigned char)data[w])) w++;
+            r.name.assign(data, i + 1, w - i - 1);
+            i = e < n ? e + 1 : n;
         } else
             r.name = "unnamed-" + std::to_string(unnamed++);
-        while (in && in.peek() != '>') {
-            if (std::getline(in, line))
-                for (char c : line)
-                    if (isalpha((unsigned char)c)) r.seq.push_back(c);
+        // the record's lines: up to the next line that begins with '>'
+        size_t j = i;
+        while (j < n && data[j] != '>') {
+            const char *nl = (const char *)memchr(data.data() + j, '\n', n - j);
+            j = nl ? (size_t)(nl - data.data()) + 1 : n;
         }
+        r.seq.reserve(j - i);
+        for (size_t a = i; a < j;) {
+            const char *nl = (const char *)memchr(data.data() + a, '\n', j - a);
+            const size_t e = nl ? (size_t)(nl - data.data()) : j;
+            bool clean = true; // (the usual line: letters only -- appended in one piece)
+            for (size_t k = a; k < e; k++)
+                if (!isalpha((unsigned char)data[k])) { clean = false; break; }
+            if (clean) r.seq.append(data, a, e - a);
+            else
+                for (size_t k = a; k < e; k++)
+                    if (isalpha((unsigned char)data[k])) r.seq.push_back(data[k]);
+            a = e + 1;
+        }
+        i = j;
         if (!r.seq.empty()) recs.push_back(std::move(r));
     }
     return true;
@@ -219,6 +246,11 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
 
 extern "C" int augx_main(int argc, const char *const *argv) {
     Session S;
+    // AUGX_TIMING=1: wall-clock of the phases on stderr (developer aid; stderr is otherwise empty on success)
+    const bool timing = getenv("AUGX_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tPrev = now();
+    auto lap = [&](const char *what) { if (timing) { const double t = now(); fprintf(stderr, "augx timing: %-28s %8.3f s\n", what, t - tPrev); tPrev = t; } };
     std::string commandline;
     for (int i = 0; i < argc; i++) { commandline += argv[i]; if (i < argc - 1) commandline += " "; }
     auto fail = [&](const std::string &msg) {
@@ -303,6 +335,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     for (auto &kv : cmd) { names.push_back(kv.first.c_str()); values.push_back(kv.second.c_str()); }
     int rc = augx_model_load(configPath.c_str(), species.c_str(), (int)cmd.size(), names.data(), values.data(), &S.model);
     if (rc) return fail(augx_last_error());
+    lap("model load");
     const Model &M = S.model->m;
     S.oo.fromModel(M);
     if (queryfile.empty()) return fail("No query file specified. Type \"augustus\" for help.");
@@ -342,6 +375,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         }
         if (!ok) { restore(); return fail("File format of " + queryfile + " not recognized (only FASTA input is supported on the MI355X path)."); }
     }
+    lap("FASTA read");
     if (verbosity > 2) {
         if (queryfile == "-") std::cout << "# Reading sequences from standard input. Assuming fasta format." << std::endl;
         else std::cout << "# Looks like " << queryfile << " is in fasta format." << std::endl;
@@ -369,6 +403,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         }
     }
 
+    lap("device / decoder create");
     const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
     if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); S.destroy(); return 1; }
     // --predictionStart / --predictionEnd: predict on a piece of the first sequence only and shift the printed coordinates
@@ -479,6 +514,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             }
         }
     }
+    lap("cut finder");
     std::vector<PieceRef> allPieces;
     for (size_t r = 0; r < recs.size(); r++)
         if (!cs[r].failStatus) allPieces.insert(allPieces.end(), recPieces[r].begin(), recPieces[r].end());
@@ -502,6 +538,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         if (!ps.empty() && !S.decode(ps, decoded)) { restore(); return fail(S.err); }
     }
 
+    lap("decode of the pieces");
     // ---- phase 3: gene structures + GFF, in input order
     std::vector<RecordView> rv;
     for (auto &r : recs) rv.push_back({r.name.c_str(), r.seq.data(), (long)r.seq.size()});
@@ -521,7 +558,9 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     std::cerr << errText;
     std::cout << "# command line:" << std::endl << "# " << commandline << std::endl;
     restore();
+    lap("genes + GFF");
     S.destroy();
+    lap("teardown");
     return 0;
 }
 
