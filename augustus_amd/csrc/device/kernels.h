@@ -170,12 +170,14 @@ AUGX_HD void k1Encode(const BatchView &B, int64_t g) {
 
 // site flags and stop codons -> terms of the count / max scans (in registers: the device scans recompute them in both of
 // their passes instead of reading them back from HBM, decoder.hip kSiteScan*)
-AUGX_HD void k1SiteTermsCalc(const DevTables &T, const BatchView &B, int64_t g, uint64_t cnt[NCNT], uint64_t ns[6]) {
+AUGX_HD void k1SiteTermsCalc(const DevTables &T, const BatchView &B, int64_t g, uint64_t cnt[NCNT], uint64_t ns[6],
+                             const uint8_t *lcode = nullptr, int lLo = 0, int lHi = 0) {
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
     Piece P;
     P.t = &T; P.n = B.len[p]; P.c = 0; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
     for (int i = 0; i < NCNT; i++) cnt[i] = 0;
     for (int i = 0; i < 6; i++) ns[i] = 0;
     if (q >= 0 && q < P.n) {
@@ -257,7 +259,8 @@ AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
 }
 
 // fixed-point terms of the 20 content prefix fields (false: the piece has no plane pl)
-AUGX_HD bool k1FxTermsCalc(const DevTables &T, const BatchView &B, int64_t g, int pl, uint64_t out[NFX]) {
+AUGX_HD bool k1FxTermsCalc(const DevTables &T, const BatchView &B, int64_t g, int pl, uint64_t out[NFX],
+                           const uint8_t *lcode = nullptr, int lLo = 0, int lHi = 0) {
     int p = B.chunkPiece[g / CHUNK];
     if (pl > 0 && pl >= B.nPlanes[p]) return false; // (this piece has no such plane)
     int64_t o = B.off[p];
@@ -265,6 +268,7 @@ AUGX_HD bool k1FxTermsCalc(const DevTables &T, const BatchView &B, int64_t g, in
     for (int i = 0; i < NFX; i++) out[i] = 0;
     Piece P;
     P.t = &T; P.n = B.len[p]; P.c = B.cls[p] < 0 ? -1 : B.planeCls[p * MAXPL + pl]; P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
     if (q >= 0 && q < B.len[p] && P.c >= 0) {
     const int k = T.k, NP = T.NP, c = P.c;
     int pn = q >= k ? P.pat(q - k, k + 1) : -1;
