@@ -237,42 +237,6 @@ template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kTrellis(cons
     __shared__ TrellisLds lds;
     trellisPiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
 }
-// passes 1 and 2 of a batch with cut pieces in ONE launch: persistent workgroups (one per compute unit) take items from a queue
-// -- every segment's pass 1 first, then the fix-ups.  A fix-up needs pass 1 of its own segment (the values it compares with)
-// and of the segment before it (the state it starts from): it spins until both are flagged.  Items are handed out in queue
-// order, so when a fix-up is taken every pass-1 item has been taken by a workgroup that is running or done: nothing waits
-// for work that has not started.  With separate launches the slowest fix-up (their length has a heavy tail) and the last
-// round of pass 1 each leave most of the chip idle; here a workgroup that is done takes the next item at once.
-template <int BLK> __global__ void __launch_bounds__(NT) kTrellisQueue(const DevTables *__restrict__ T, const BatchView *__restrict__ Bp) {
-    __shared__ TrellisLds lds;
-    __shared__ int item;
-    const BatchView &B = *Bp;
-    const int nItems = B.nSegs + B.nFix;
-    for (;;) {
-        if (threadIdx.x == 0) item = atomicAdd(B.queueHead, 1);
-        __syncthreads();
-        const int it = item;
-        __syncthreads();
-        if (it >= nItems) break;
-        if (it < B.nSegs) {
-            trellisPiece<BLK, 0>(*T, B, lds, it);
-            __threadfence(); // everything this thread stored is visible device-wide before the segment is flagged
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(&B.segDone[it], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            const int sg = B.fixList[it - B.nSegs];
-            if (threadIdx.x == 0) {
-                while (__hip_atomic_load(&B.segDone[sg - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
-                       __hip_atomic_load(&B.segDone[sg], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
-                    __builtin_amdgcn_s_sleep(32);
-            }
-            __syncthreads();
-            __threadfence(); // (acquire for every wavefront: nothing stale of the other workgroups' regions in this CU's caches)
-            trellisPiece<BLK, 1>(*T, B, lds, sg);
-        }
-        __syncthreads();
-    }
-}
 __global__ void __launch_bounds__(64) kSegFinalize(BatchView B) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p < B.nPieces) segFinalizePiece(B, p);
@@ -569,14 +533,6 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     if (const char *e = getenv("AUGX_SEG_CHECK_TILES")) V.segCheckTiles = atoi(e); // (tests of the give-up path: an unreachable check length)
     DA(V.segStop, int32_t, nSegs); DA(V.segStatus, int32_t, nSegs); DA(V.segD, double, nSegs); DA(V.brkPos, int32_t, nSegs); DA(V.brkOff, double, nSegs);
     DA(V.segStop2, int32_t, nSegs); DA(V.segD2, double, nSegs); DA(V.pieceCovered, int32_t, n);
-    DA(V.segDone, int32_t, nSegs + 1);
-    V.queueHead = V.segDone + nSegs;
-    std::vector<int32_t> fixList;
-    for (int i = 0; i < nSegs; i++)
-        if (b->plan.segs[i].k > 0) fixList.push_back(i);
-    int32_t *dFix;
-    DA(dFix, int32_t, (int64_t)fixList.size());
-    V.fixList = dFix; V.nFix = (int)fixList.size();
     if (b->plan.cut()) { DA(V.ckRing, double, (int64_t)nSegs * 2 * WAVE * SP); DA(V.ckCol, double, Z.N / WAVE * SP); }
 #undef DA
     rc = [&]() -> int { // (any failure below: the batch is destroyed with everything it owns)
@@ -587,7 +543,6 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     HIP_TRY(hipMemcpy(dCp, L.chunkPiece.data(), sizeof(int32_t) * L.nChunks, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dSegs, b->plan.segs.data(), sizeof(SegDesc) * nSegs, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dSeg0, b->plan.pieceSeg0.data(), sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
-    if (!fixList.empty()) HIP_TRY(hipMemcpy(dFix, fixList.data(), sizeof(int32_t) * fixList.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(dRaw, 'n', (size_t)Z.N));
     HIP_TRY(hipMemset(V.gcPlane, 0, (size_t)Z.N));
     for (int p = 0; p < n; p++)
@@ -741,16 +696,14 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
         else if (d->blk == 4) hipLaunchKernelGGL((kTrellis<4, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
         else hipLaunchKernelGGL((kTrellis<2, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); } while (0)
-    if (!b->plan.cut()) AUGX_LAUNCH_TRELLIS(0, V.nSegs); // one workgroup per piece
-    else {
+    AUGX_LAUNCH_TRELLIS(0, V.nSegs);                 // pass 1: every segment at once (one workgroup per piece when no piece is cut)
+    if (b->plan.cut()) {
         HIP_TRY(hipMemsetAsync(V.segStop2, 0xFF, sizeof(int32_t) * V.nSegs, st));
         HIP_TRY(hipMemsetAsync(V.pieceCovered, 0xFF, sizeof(int32_t) * n, st));
-        HIP_TRY(hipMemsetAsync(V.segDone, 0, sizeof(int32_t) * (V.nSegs + 1), st)); // (+ the queue head behind it)
-        // passes 1 and 2: persistent workgroups over the queue of segments and fix-ups
-        const int nItems = V.nSegs + V.nFix, nWg = nItems < d->nCU ? nItems : d->nCU;
-        if (d->blk == 8) hipLaunchKernelGGL(kTrellisQueue<8>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-        else if (d->blk == 4) hipLaunchKernelGGL(kTrellisQueue<4>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
-        else hipLaunchKernelGGL(kTrellisQueue<2>, dim3(nWg), dim3(NT), 0, st, d->dT, b->dV);
+        // pass 2: the fix-ups (the first segment of a piece has none: its workgroup returns).  (Both passes in one launch of
+        // persistent workgroups over a queue was measured: no faster in queue order -- a fix-up cannot start before pass 1 of
+        // its neighbours -- and the kernel holding both bodies spills more, 88 instead of 54 VGPRs.)
+        AUGX_LAUNCH_TRELLIS(1, V.nSegs);
         // pass 3: a fix-up that gave up continues, still comparing, one per piece and launch (workgroups with nothing to do
         // return at once); whatever is left after that goes sequentially to the end of its piece
         for (int round = 0; round < SEG_CONT_ROUNDS; round++) AUGX_LAUNCH_TRELLIS(2, n);

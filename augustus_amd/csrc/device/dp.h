@@ -163,12 +163,6 @@ struct BatchView {
     int32_t *segStop2;         // [nSegs] pass 3: the continuation of a fix-up that gave up converged after this tile (-1: none; last tile of the piece: ran to the end)
     double *segD2;             // [nSegs] its offset
     int32_t *pieceCovered;     // [nPieces] last tile of the piece a continuation has redone (-1: none)
-    // passes 1 and 2 in one launch: persistent workgroups take items from a queue -- first every segment's pass 1, then every
-    // fix-up, which waits (spinning on segDone) until pass 1 of its own segment and of the one before it are complete
-    const int32_t *fixList;    // [nFix] segments with k >= 1
-    int nFix;
-    int32_t *segDone;          // [nSegs] set when pass 1 of the segment is complete and visible
-    int32_t *queueHead;        // next item
     int32_t *segStatus;        // [nSegs] abort flags
     int32_t *brkPos;           // [nSegs] kSegFinalize: region r of the piece = bases (brkPos[r-1], brkPos[r]] ...
     double *brkOff;            // [nSegs] ... whose stored values are true value - brkOff[r]

@@ -182,7 +182,7 @@ AUGX_HD void k1SiteTermsCalc(const DevTables &T, const BatchView &B, int64_t g, 
     for (int i = 0; i < 6; i++) ns[i] = 0;
     if (q >= 0 && q < P.n) {
     int c = P.b(q);
-    if (c < 4) cnt[c] = 1;
+    cnt[0] = c == 0; cnt[1] = c == 1; cnt[2] = c == 2; cnt[3] = c == 3; // (no dynamic index: the arrays stay in registers)
     if (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') cnt[CNT_SOFT] = 1; // lower-case base = nonexonpart hint (src/extrinsicinfo.cc:1703-1720)
     // start codon with positive probability at q (a of atg)
     if (q < P.n - 2) { int pn = P.pat(q, 3); if (pn >= 0 && T.ln_startcodon[pn] > AUGX_NINF) cnt[CNT_ATG] = 1; }
@@ -194,8 +194,11 @@ AUGX_HD void k1SiteTermsCalc(const DevTables &T, const BatchView &B, int64_t g, 
     if (P.possDSS(q - T.De - 2 + 1)) cnt[CNT_LD] = 1;               // longdss may end at q   (:693)
     if (P.possRASS(q - T.U - T.As - 2 + 1)) cnt[CNT_RD] = 1;        // rlongass may end at q  (:713)
     if (q <= P.n - 3) {
-        if (P.isStop(q)) ns[q % 3] = (uint64_t)q + 1;
-        if (P.isRCStop(q)) { ns[3 + q % 3] = (uint64_t)q + 1; cnt[CNT_RS] = 1; }
+        const int r = q % 3;
+        const uint64_t fs = P.isStop(q) ? (uint64_t)q + 1 : 0, rs = P.isRCStop(q) ? (uint64_t)q + 1 : 0;
+        ns[0] = r == 0 ? fs : 0; ns[1] = r == 1 ? fs : 0; ns[2] = r == 2 ? fs : 0;
+        ns[3] = r == 0 ? rs : 0; ns[4] = r == 1 ? rs : 0; ns[5] = r == 2 ? rs : 0;
+        if (rs) cnt[CNT_RS] = 1;
     }
     }
 }
