@@ -184,9 +184,9 @@ __global__ void __launch_bounds__(1024) kSiteScanApply(const DevTables *T, Batch
     k1SiteTermsCalc(*T, B, g, v, v + NCNT, C.c, C.lo, C.lo + CHUNK + 2 * SCAN_HALO);
     chunkScan<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
 #pragma unroll
-    for (int f = 0; f < NCNT; f++) B.cnt[fidx(g, f, NCNT)] = v[f];
+    for (int f = 0; f < NCNT; f++) B.cnt[fidx(g, f, NCNT)] = (uint32_t)v[f];
 #pragma unroll
-    for (int f = 0; f < 6; f++) B.nsm[fidx(g, f, 6)] = v[NCNT + f];
+    for (int f = 0; f < 6; f++) B.nsm[fidx(g, f, 6)] = (uint32_t)v[NCNT + f];
 }
 __global__ void __launch_bounds__(1024) kFxScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nPl][nChunks][NFX] */) { // grid.y = plane
     __shared__ ScanLds<NFX, 0> L;
@@ -504,8 +504,8 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.gcRaw, uint8_t, Z.N); DA(V.gcPlane, uint8_t, Z.N);
     V.nPl = 1; V.listCap = 0; // (the list arrays are sized by the first decode, from the counted sites)
     DA(V.code, uint8_t, Z.N);
-    DA(V.cnt, uint64_t, Z.N * NCNT);
-    DA(V.nsm, uint64_t, Z.N * 6);
+    DA(V.cnt, uint32_t, Z.N * NCNT);
+    DA(V.nsm, uint32_t, Z.N * 6);
     DA(V.sig, double, Z.N * NSIG);
     DA(V.gate, uint64_t, Z.N);
     DA(V.site, int32_t, Z.N * NSITE);

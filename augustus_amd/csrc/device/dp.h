@@ -118,8 +118,8 @@ struct BatchView {
     int32_t *planeCls;         // [nPieces][MAXPL] class of each plane
     const char *raw;           // [N] ASCII (slot layout)
     uint8_t *code;             // [N] 0..3 acgt, 4 invalid / padding
-    uint64_t *cnt;             // [N][4] prefix base counts
-    uint64_t *nsm;             // [N][6] prefix max of (stop position+1) per residue class, fwd 0..2, rev 3..5
+    uint32_t *cnt;             // [N][NCNT] prefix counts (32 bits: a piece is shorter than 2^22 bases)
+    uint32_t *nsm;             // [N][6] prefix max of (stop position+1) per residue class, fwd 0..2, rev 3..5
     uint64_t *fx;              // [N][NFX] fixed-point prefix sums
     double *sig;               // [N][NSIG]
     uint64_t *gate;            // [N] bit s: variable-length state s passes its end gate at this base
@@ -197,7 +197,7 @@ struct Piece {
     int64_t o;                 // slot offset of the piece: base q lives in slot o+1+q
     const uint8_t *code;       // code[q]
     const uint64_t *fx;        // fx[fidx(o+1+q, f, NFX)] = prefix sum up to and including q
-    const uint64_t *nsm;       // nsm[fidx(o+1+q, r, 6)]
+    const uint32_t *nsm;       // nsm[fidx(o+1+q, r, 6)]
     const double *sig;         // sig[q*NSIG + i]
     // optional LDS windows (trellis kernel only): recent bases / stop tables are served from LDS, the rest from HBM
     const uint8_t *wcode = nullptr;  // wcode[q & (CODE_WIN-1)] for q in [wcLo, wcHi)

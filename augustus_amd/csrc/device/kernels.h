@@ -205,8 +205,8 @@ AUGX_HD void k1SiteTermsCalc(const DevTables &T, const BatchView &B, int64_t g, 
 AUGX_HD void k1SiteTerms(const DevTables &T, const BatchView &B, int64_t g) {
     uint64_t cnt[NCNT], ns[6];
     k1SiteTermsCalc(T, B, g, cnt, ns);
-    for (int i = 0; i < NCNT; i++) B.cnt[fidx(g, i, NCNT)] = cnt[i];
-    for (int i = 0; i < 6; i++) B.nsm[fidx(g, i, 6)] = ns[i];
+    for (int i = 0; i < NCNT; i++) B.cnt[fidx(g, i, NCNT)] = (uint32_t)cnt[i];
+    for (int i = 0; i < 6; i++) B.nsm[fidx(g, i, 6)] = (uint32_t)ns[i];
 }
 
 // entries of the longest candidate list of piece p (site counts at its last base): sizes the list arrays

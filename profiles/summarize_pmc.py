@@ -31,9 +31,13 @@ for k in sorted(set(fetch) | set(write)):
     res["kernels"][k] = {"FETCH_SIZE_bytes_raw": f, "FETCH_SIZE_bytes_corrected_x2": 2 * f, "WRITE_SIZE_bytes": w,
                          "traffic_bytes_per_launch": 2 * f + w, "traffic_bytes_per_bp": (2 * f + w) / bases,
                          "dispatches_in_run": len(fetch.get(k, []))}
+# the trellis runs in passes (kTrellis<BLK, 0>: every segment, <BLK, 1>: fix-ups, <BLK, 2/3>: continuations): their sum
+tr = [v for k, v in res["kernels"].items() if k.startswith("kTrellis")]
+if tr:
+    res["kTrellis"] = {"traffic_bytes_per_launch": sum(v["traffic_bytes_per_launch"] for v in tr),
+                       "traffic_bytes_per_bp": sum(v["traffic_bytes_per_bp"] for v in tr),
+                       "passes": {k: v["traffic_bytes_per_launch"] for k, v in res["kernels"].items() if k.startswith("kTrellis")}}
 for k, v in res["kernels"].items():
-    if k.startswith("kTrellis"):
-        res["kTrellis"] = v
     if k.startswith("kCand"):
         res["kCand"] = v
 json.dump(res, sys.stdout, indent=1)

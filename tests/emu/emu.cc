@@ -18,12 +18,12 @@ namespace {
 template <class T> T *zalloc(int64_t n) { return (T *)calloc((size_t)(n > 0 ? n : 1), sizeof(T)); }
 
 // piece-local inclusive scans over the AoS field arrays (the device does the same with chunked kernels)
-template <bool MAX> void scanFields(uint64_t *a, int nf, const BatchLayout &L) {
+template <bool MAX, class E> void scanFields(E *a, int nf, const BatchLayout &L) {
     for (int p = 0; p < L.nPieces; p++) {
-        std::vector<uint64_t> acc(nf, 0);
+        std::vector<E> acc(nf, 0);
         for (int64_t g = L.off[p]; g < L.off[p + 1]; g++)
             for (int f = 0; f < nf; f++) {
-                uint64_t v = a[fidx(g, f, nf)];
+                E v = a[fidx(g, f, nf)];
                 acc[f] = MAX ? (v > acc[f] ? v : acc[f]) : acc[f] + v;
                 a[fidx(g, f, nf)] = acc[f];
             }
@@ -61,8 +61,8 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     for (int p = 0; p < n; p++) memcpy(raw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p]);
     B.raw = raw;
     B.code = zalloc<uint8_t>(Z.N);
-    B.cnt = zalloc<uint64_t>(Z.N * NCNT);
-    B.nsm = zalloc<uint64_t>(Z.N * 6);
+    B.cnt = zalloc<uint32_t>(Z.N * NCNT);
+    B.nsm = zalloc<uint32_t>(Z.N * 6);
     B.sig = zalloc<double>(Z.N * NSIG);
     B.gate = zalloc<uint64_t>(Z.N);
     B.site = zalloc<int32_t>(Z.N * NSITE);
