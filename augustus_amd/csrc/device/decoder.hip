@@ -511,6 +511,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.site, int32_t, Z.N * NSITE);
     DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
+    DA(V.bpChain, uint8_t, Z.N * 8);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
     if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); if (hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8) != hipSuccess) { augx_batch_destroy(b); setLastError("augx_batch_create: hipMemset failed"); return AUGX_E_HIP; } }
     DA(V.vig, double, Z.N);

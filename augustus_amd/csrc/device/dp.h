@@ -127,6 +127,8 @@ struct BatchView {
     uint64_t *chunkTot;        // scratch [nChunks][NFX]
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
+    uint8_t *bpChain;          // [N][8] the back pointers of the (at most 8) single-base chain states once more, one byte each, in
+                               // the order of their state index: the back-trace walks their long runs 256 bases per step through it
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
     uint64_t *prof;            // [nPieces][4][8] cycle counters of the trellis wavefronts (AUGX_PROF=1) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)

@@ -1135,6 +1135,7 @@ constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the re
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]
     uint16_t bp[2][WAVE][SP];       // back pointers of the current / previous tile
+    uint8_t bpc[2][WAVE][8];        // ... those of the chain states once more, compact (BatchView::bpChain)
     double sig[2][WAVE][NSIG];      // signal records of the current / next tile
     int32_t site[2][WAVE][NSITE];
     double eqPrev[2][WAVE][6];      // predecessor cells of the equalD states (lag dStateLen)
@@ -1383,6 +1384,8 @@ AUGX_KFN void flushBpThread(const TrellisCtx &X, int tile, int buf, int tid, int
             srcW[i] = none;
         }
     }
+    for (int i = tid; i < WAVE; i += nth) // compact back pointers of the chain states
+        if (j0 + i < X.n) gp((uint64_t *)X.B.bpChain)[X.o + 1 + j0 + i] = *(const uint64_t *)&X.L.bpc[buf][i][0];
     for (int i = tid; i < WAVE; i += nth) // igenic column
         if (j0 + i >= 1 && j0 + i < X.n) {
             if constexpr (CMP) bad |= !(X.L.vigw[(j0 + i) & (VIG_WIN - 1)] == gp(X.B.vig)[X.o + 1 + j0 + i] + dT);
@@ -1503,8 +1506,13 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             for (int ai = 0; ai < T.n_anc[sy]; ai++)
                 if (T.anc[sy][ai] == sy) selfAi = ai;
             FOR_THREADS(t) {
-                for (int q = t; q < n; q += NT)
+                int sySlot = 0; // chain slot of the synch state: chain states before it in state order
+                for (int s2 = 0; s2 < sy; s2++)
+                    if (T.reachable[s2] && (T.kind[s2] == AUGX_K_IGENIC || T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC)) sySlot++;
+                for (int q = t; q < n; q += NT) {
                     for (int s2 = 0; s2 < SP; s2++) B.bp[(o + 1 + q) * SP + s2] = (s2 == sy && q >= 1) ? bpFixed(selfAi) : BP_NONE;
+                    for (int c2 = 0; c2 < 8; c2++) B.bpChain[(o + 1 + q) * 8 + c2] = (c2 == sySlot && q >= 1) ? (uint8_t)selfAi : (uint8_t)0xFF;
+                }
                 if (t == 0) {
                     double v = B.initKind[p] == 0 ? T.ln_init[sy] : 0.0;
                     for (int q = 1; q < n; q++) v = v - T.ln4;
@@ -1639,6 +1647,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             L.ring[i / SP][i % SP] = ckSrc >= 0 ? B.ckRing[((int64_t)ckSrc * WAVE + i / SP) * SP + i % SP] : AUGX_NINF;
             L.bp[0][i / SP][i % SP] = BP_NONE; L.bp[1][i / SP][i % SP] = BP_NONE;
         }
+        for (int i = t; i < 2 * WAVE * 8; i += NT) L.bpc[i / (WAVE * 8)][(i / 8) % WAVE][i % 8] = 0xFF;
         for (int i = t; i < VIG_WIN; i += NT) L.vigw[i] = AUGX_NINF;
         for (int i = t; i < 4 * LIST_WIN * 3; i += NT) L.lcVal[i / (LIST_WIN * 3)][(i / 3) % LIST_WIN][i % 3] = AUGX_NINF;
     }
@@ -1866,6 +1875,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 const int s2 = TX(cS);
                 L.ring[j & 63][s2] = TX(res);
                 L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
+                L.bpc[buf][j & 63][(t & 63) / BLK] = TX(res) > AUGX_NINF ? (uint8_t)TX(rai) : (uint8_t)0xFF; // (chain slot = lane / BLK, see the set-up above)
                 if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = TX(res);
                 if (TX(cIsIg)) L.vigw[j & (VIG_WIN - 1)] = TX(res); // (HBM copy: flushed with the tile)
             }
@@ -2241,26 +2251,34 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
                 if (T.anc[state][i] == state) selfAi = i;
             int cur = base;
             uint16_t w = BP_NONE;
-            for (;;) { // find the first base <= cur whose predecessor is not the state itself
+            int cslot = 0; // chain slot of the state (BatchView::bpChain)
+            for (int s2 = 0; s2 < state; s2++)
+                if (T.reachable[s2] && (T.kind[s2] == AUGX_K_IGENIC || T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC)) cslot++;
+            for (;;) { // find the first base <= cur whose predecessor is not the state itself: 4 bases per lane, 256 per step
                 LV(int, flag);
                 LV(int, wv);
+                LV(int, hit);
                 FOR_LANES(l) {
-                    int q = cur - l;
-                    int ww = q >= 1 ? (int)B.bp[(o + 1 + q) * SP + state] : -1;
-                    LX(wv) = ww;
-                    LX(flag) = (q < 1) || ww != selfAi;
+                    LX(flag) = 0; LX(wv) = -1; LX(hit) = 4;
+#pragma unroll
+                    for (int k = 3; k >= 0; k--) { // (descending k: the hit nearest to cur is kept)
+                        const int q = cur - 4 * l - k;
+                        const int ww = q >= 1 ? (int)B.bpChain[(o + 1 + q) * 8 + cslot] : -1;
+                        if (q < 1 || ww != selfAi) { LX(flag) = 1; LX(wv) = ww; LX(hit) = k; }
+                    }
                 }
                 int first = waveFirstTrue(flag);
                 if (first < WAVE) {
-                    cur -= first;
 #ifdef AUGX_EMU
-                    w = cur >= 1 ? (uint16_t)wv[first] : BP_NONE;
+                    const int hk = hit[first], hw = wv[first];
 #else
-                    w = cur >= 1 ? (uint16_t)__shfl(wv[0], first, 64) : BP_NONE;
+                    const int hk = __shfl(hit[0], first, 64), hw = __shfl(wv[0], first, 64);
 #endif
+                    cur -= 4 * first + hk;
+                    w = cur >= 1 ? (uint16_t)hw : BP_NONE;
                     break;
                 }
-                cur -= WAVE;
+                cur -= 4 * WAVE;
             }
             // bases cur..base are in `state`; base `cur` was entered from another state (or cur < 1: sequence start)
             if (cur < 1) { eop = 0; ai = -1; }

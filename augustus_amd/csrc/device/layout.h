@@ -148,7 +148,9 @@ inline SegPlan planSegments(const BatchLayout &L, const augx_tables &t, int slot
                 const int64_t len = (tiles[p] + kp - 1) / kp;
                 if (len > longest) longest = len;
             }
-            const int64_t cost = (nSeg + slots - 1) / slots * longest + (nFix + slots - 1) / slots * fixLen;
+            int64_t cost = (nSeg + slots - 1) / slots * longest + (nFix + slots - 1) / slots * fixLen;
+            // (the fix-ups are extra work and their length has a heavy tail: cutting must promise a clear gain to be chosen)
+            if (k > 1) cost += cost / 6;
             if (bestCost < 0 || cost < bestCost) { bestCost = cost; best = k == 1 ? -1 : st; }
         }
         segTiles = best;

@@ -67,6 +67,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.gate = zalloc<uint64_t>(Z.N);
     B.site = zalloc<int32_t>(Z.N * NSITE);
     B.bp = zalloc<uint16_t>(Z.N * SP);
+    B.bpChain = zalloc<uint8_t>(Z.N * 8);
     B.cells = cells_out ? zalloc<double>(Z.N * t->S) : nullptr;
     B.vig = zalloc<double>(Z.N);
     B.longV = zalloc<double>(Z.N * 6);
@@ -263,7 +264,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     }
     free(B.ckRing); free(B.ckCol);
     free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.items);
-    free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp);
+    free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp); free(B.bpChain);
     free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldEnt); free(B.ldVal);
     free(B.rdEnt); free(B.rdVal); free(B.atgPos); free(B.pathRec);
     free(B.laPls); free(B.laFx); free(B.lrEt); free(B.lrFx); free(B.atgD); free(B.atgFx); free(B.rsPos); free(B.rsBegin); free(B.rsFx); free(B.plsR); free(B.gcRaw); free(B.gcPlane);
