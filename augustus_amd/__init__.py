@@ -12,7 +12,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaugx.so")
+LIB_PATH = os.environ.get("AUGX_LIB") or os.path.join(_HERE, "libaugx.so")  # (AUGX_LIB: a developer build of the same library)
 
 AUGX_E_NODEVICE = -3
 AUGX_E_HIP = -4
