@@ -755,7 +755,7 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
         {
             const uint64_t *cp = &h[(size_t)b->L.nPieces * 56];
             const double nw = (double)(cp[4] ? cp[4] : 1);
-            fprintf(stderr, "kCand cycles per wavefront (= tile; avg over %.0f): %.0f\n", nw, cp[0] / nw);
+            fprintf(stderr, "kCand cycles per wavefront (= tile; avg over %.0f): %.0f  (describe + count %.0f, reserve %.0f)\n", nw, cp[0] / nw, cp[1] / nw, cp[2] / nw);
         }
         {   // time stamps of block 1000 of piece 0, relative to the start of its fixed-lag step
             const uint64_t *ts = &h[(size_t)b->L.nPieces * 40];

@@ -559,6 +559,8 @@ struct CandLds {
     int scan[NWAVES][3][WAVE];                           // inclusive lane scans of the pair counts of the three groups
     uint32_t cntItems[NWAVES][MAXNB], cntNonRT[NWAVES][MAXNB]; // per block: candidates (then: first candidate), candidates but RTERMINAL
     unsigned long long baseW[NWAVES][2];                 // first pair / first candidate of the tile in the batch's buffers
+    uint32_t slowIt[NWAVES][2 * WAVE];                   // candidates of the current round that need the general formula (index in the round)
+    int slowN[NWAVES];
 };
 
 // read-only view of one piece for the candidate kernel (everything comes from HBM / L2)
@@ -712,8 +714,12 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
 
 // candidate number idx (0 = newest) of the state described by D: te = ln(transition * emission) (-inf: infeasible),
 // tie-break key, and the address of the predecessor's Viterbi value
-template <bool MULTI>
-AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int idx, double &te, int &key, uint32_t &src) {
+// FASTONLY: a candidate that needs the general emission formula (exNotEndPart: motif sums, short-exon cases -- 2 % of the
+// candidates, thousands of cycles each) is not evaluated but reported in needSlow: the caller evaluates such candidates
+// together, a wavefront full at a time, instead of stalling 63 lanes of every chunk for the one lane that needs it
+template <bool MULTI, bool FASTONLY = false>
+AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int idx, double &te, int &key, uint32_t &src, bool &needSlow) {
+    needSlow = false;
     const DevTables &T = X.T;
     const BatchView &B = X.B;
     const VarConst &VC = X.vc[s];
@@ -829,6 +835,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                 nep = (B.rsBegin[X.lo + ri] + (D.plsEnd + inner)) + lenPart;
             }
         }
+        if (FASTONLY && !fast) { needSlow = true; return; }
 #ifdef AUGX_EMU
         if (!fast) g_emuSlowA++;
 #endif
@@ -883,6 +890,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                 }
             }
         }
+        if (FASTONLY && !fast) { needSlow = true; return; }
 #ifdef AUGX_EMU
         if (!fast) g_emuSlowB++;
 #endif
@@ -978,6 +986,9 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         }
         WAVE_SYNC();
     };
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    const uint64_t cpA = B.prof ? clock64() : 0;
+#endif
     // ---- pass 1: describe and count
     for (int r0 = 0; r0 < totalPairs; r0 += WAVE) {
         expand(r0);
@@ -995,6 +1006,9 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         }
         WAVE_SYNC();
     }
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    const uint64_t cpB = B.prof ? clock64() : 0;
+#endif
     // ---- reserve the tile's range; per-block tables
     TV(int, bItems); TV(int, bInc);
     FOR_WLANES(t, w) { const int l = t & 63; TX(bItems) = l < NB ? (int)L.cntItems[w][l] : 0; TX(bInc) = TX(bItems); }
@@ -1031,6 +1045,13 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         }
     }
     WAVE_SYNC();
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    const uint64_t cpC = B.prof ? clock64() : 0;
+    if (B.prof && (threadIdx.x & 63) == 0) {
+        unsigned long long *pp = (unsigned long long *)B.prof + (int64_t)B.nPieces * 56;
+        atomicAdd(pp + 1, cpB - cpA); atomicAdd(pp + 2, cpC - cpB);
+    }
+#endif
     // ---- pass 2: evaluate and store
     uint32_t itemsDone = 0;
     for (int r0 = 0; r0 < totalPairs; r0 += WAVE) {
@@ -1055,6 +1076,35 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         // (the scan rows are free by now: row 0 takes the prefix, padded, for the candidates' search of their pair)
         FOR_WLANES(t, w) { const int l = t & 63; L.scan[w][0][l] = l < nPr ? TX(ibase) : 0x7fffffff; }
         WAVE_SYNC();
+        int nSlow = 0; // (uniform) queued candidates of this round
+        auto evalSlow = [&](int cnt) { // the first cnt queued candidates, one per lane; the rest moves to the front
+            FOR_WLANES(t, w) {
+                const int l = t & 63;
+                if (l < cnt) {
+                    const int it = (int)L.slowIt[w][l];
+                    int pos = 0;
+#pragma unroll
+                    for (int step = WAVE / 2; step >= 1; step >>= 1)
+                        if (L.scan[w][0][pos + step - 1] <= it) pos += step;
+                    const int first = pos > 0 ? L.scan[w][0][pos - 1] : 0;
+                    const int dj = L.pairJ[w][pos], s2 = L.pairS[w][pos];
+                    double te; int key; uint32_t src;
+                    bool dummy;
+                    varEvalItem<MULTI, false>(X, s2, j0 + dj, L.desc[w][r0 + pos < DCAP ? r0 + pos : pos], it - first, te, key, src, dummy);
+                    if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                    Item I;
+                    I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+                    B.items[itemBase + itemsDone + it] = I;
+                }
+            }
+            WAVE_SYNC();
+            TV(int, mv);
+            FOR_WLANES(t, w) { const int l = t & 63; TX(mv) = cnt + l < nSlow ? (int)L.slowIt[w][cnt + l] : -1; }
+            WAVE_SYNC();
+            FOR_WLANES(t, w) { const int l = t & 63; if (TX(mv) >= 0) L.slowIt[w][l] = (uint32_t)TX(mv); }
+            WAVE_SYNC();
+            nSlow -= cnt;
+        };
         for (int base = 0; base < totalItems; base += WAVE) {
             TV(int, myPair);
             TV(int, myFirst);
@@ -1067,21 +1117,39 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
                 TX(myPair) = pos;
                 TX(myFirst) = pos > 0 ? L.scan[w][0][pos - 1] : 0;
             }
+            TV(int, slow);
             FOR_WLANES(t, w) { // one candidate per lane
                 const int l = t & 63;
                 const int it = base + l;
+                TX(slow) = 0;
                 if (it < totalItems) {
                     const int q = TX(myPair);
                     const int dj = L.pairJ[w][q], s2 = L.pairS[w][q];
                     double te; int key; uint32_t src;
-                    varEvalItem<MULTI>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - TX(myFirst), te, key, src);
-                    if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
-                    Item I;
-                    I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
-                    B.items[itemBase + itemsDone + it] = I;
+                    bool needSlow;
+                    varEvalItem<MULTI, true>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - TX(myFirst), te, key, src, needSlow);
+                    TX(slow) = needSlow;
+                    if (!needSlow) {
+                        if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                        Item I;
+                        I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+                        B.items[itemBase + itemsDone + it] = I;
+                    }
                 }
             }
+            // the candidates that need the general formula queue up; a wavefront full of them is evaluated at once
+            TV(int, sInc);
+            FOR_WLANES(t, w) { TX(sInc) = TX(slow); }
+            waveInclScan(sInc, w);
+            const int nNew = waveRead(sInc, w, WAVE - 1);
+            if (nNew > 0) {
+                FOR_WLANES(t, w) { if (TX(slow)) L.slowIt[w][nSlow + TX(sInc) - 1] = (uint32_t)(base + (t & 63)); }
+                nSlow += nNew;
+                WAVE_SYNC();
+                if (nSlow >= WAVE) { evalSlow(WAVE); }
+            }
         }
+        if (nSlow > 0) evalSlow(nSlow);
         WAVE_SYNC();
         itemsDone += (uint32_t)totalItems;
     }
