@@ -237,6 +237,10 @@ template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kTrellis(cons
     __shared__ TrellisLds lds;
     trellisPiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
 }
+__global__ void __launch_bounds__(256) kTileCross(BatchView B) {
+    const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gt < B.N / WAVE) tileCrossOne(B, gt);
+}
 __global__ void __launch_bounds__(64) kSegFinalize(BatchView B) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p < B.nPieces) segFinalizePiece(B, p);
@@ -534,7 +538,10 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     if (const char *e = getenv("AUGX_SEG_CHECK_TILES")) V.segCheckTiles = atoi(e); // (tests of the give-up path: an unreachable check length)
     DA(V.segStop, int32_t, nSegs); DA(V.segStatus, int32_t, nSegs); DA(V.segD, double, nSegs); DA(V.brkPos, int32_t, nSegs); DA(V.brkOff, double, nSegs);
     DA(V.segStop2, int32_t, nSegs); DA(V.segD2, double, nSegs); DA(V.pieceCovered, int32_t, n);
-    if (b->plan.cut()) { DA(V.ckRing, double, (int64_t)nSegs * 2 * WAVE * SP); DA(V.ckCol, double, Z.N / WAVE * SP); }
+    if (b->plan.cut()) {
+        DA(V.ckRing, double, (int64_t)nSegs * 2 * WAVE * SP); DA(V.ckCol, double, Z.N / WAVE * SP);
+        DA(V.tileMinEop, int32_t, Z.N / WAVE); DA(V.tileCross, int32_t, Z.N / WAVE);
+    }
 #undef DA
     rc = [&]() -> int { // (any failure below: the batch is destroyed with everything it owns)
     HIP_TRY(hipMemcpy(dOff, L.off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
@@ -691,6 +698,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
     }
+    if (b->plan.cut()) hipLaunchKernelGGL(kTileCross, dim3((unsigned)((V.N / WAVE + 255) / 256)), dim3(256), 0, st, V); // how far back the future reads (fix-ups)
     HIP_TRY(hipEventRecord(b->ev[1], st));
     HIP_TRY(hipMemsetAsync(V.segStatus, 0, sizeof(int32_t) * V.nSegs, st));
 #define AUGX_LAUNCH_TRELLIS(MODE_, grid_) do { \

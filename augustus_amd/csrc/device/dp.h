@@ -158,6 +158,8 @@ struct BatchView {
     const SegDesc *segs;       // [nSegs] grouped by piece, ascending k
     const int32_t *pieceSeg0;  // [nPieces+1] first segment of each piece
     int segCheckTiles;         // consecutive verified tiles that end a fix-up: they cover the longest look-back of the model
+    int32_t *tileMinEop;       // [N/WAVE] smallest predecessor position (eop) of any live candidate that ends in the tile (K2a; INT_MAX: none)
+    int32_t *tileCross;        // [N/WAVE] ... of any candidate that ends in one of the next segCheckTiles tiles: what the future can still read
     double *ckRing;            // [nSegs][2][WAVE][SP] the ring at the end of pass 1 of the segment [0] / where its fix-up gave up [1]
     double *ckCol;             // [N/WAVE][SP] ln V column at the end of every tile (pass 1; compared and replaced by pass 2)
     int32_t *segStop;          // [nSegs] pass 2: last tile rewritten when converged (>= t0 - 1), -2 - tile when it gave up after `tile`

@@ -516,6 +516,15 @@ __device__ inline void waveInclScan(int *v, int) {
 }
 __device__ inline int waveRead(const int *v, int, int lane) { return __shfl(v[0], lane, 64); }
 #endif
+#ifdef AUGX_EMU
+inline int waveMin(const int *v, int w) { int m = v[w * WAVE]; for (int l = 1; l < WAVE; l++) m = v[w * WAVE + l] < m ? v[w * WAVE + l] : m; return m; }
+#else
+__device__ inline int waveMin(const int *v, int) {
+    int x = v[0];
+    for (int o = 32; o >= 1; o >>= 1) { const int y = __shfl_xor(x, o, 64); x = y < x ? y : x; }
+    return x;
+}
+#endif
 AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
 // per-state constants of the variable-length states
@@ -1054,6 +1063,8 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
 #endif
     // ---- pass 2: evaluate and store
     uint32_t itemsDone = 0;
+    TV(int, mnEop); // smallest predecessor position of a live candidate of the tile (BatchView::tileMinEop)
+    FOR_WLANES(t, w) { TX(mnEop) = 0x7fffffff; }
     for (int r0 = 0; r0 < totalPairs; r0 += WAVE) {
         if (totalPairs > WAVE) expand(r0); // (a single round: pairJ / pairS still hold it)
         const int nPr = totalPairs - r0 < WAVE ? totalPairs - r0 : WAVE;
@@ -1092,6 +1103,7 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
                     bool dummy;
                     varEvalItem<MULTI, false>(X, s2, j0 + dj, L.desc[w][r0 + pos < DCAP ? r0 + pos : pos], it - first, te, key, src, dummy);
                     if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                    else if (key - KEY_BIAS < TX(mnEop)) TX(mnEop) = key - KEY_BIAS;
                     Item I;
                     I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
                     B.items[itemBase + itemsDone + it] = I;
@@ -1131,6 +1143,7 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
                     TX(slow) = needSlow;
                     if (!needSlow) {
                         if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+                        else if (key - KEY_BIAS < TX(mnEop)) TX(mnEop) = key - KEY_BIAS;
                         Item I;
                         I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
                         B.items[itemBase + itemsDone + it] = I;
@@ -1152,6 +1165,10 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         if (nSlow > 0) evalSlow(nSlow);
         WAVE_SYNC();
         itemsDone += (uint32_t)totalItems;
+    }
+    if (B.tileMinEop) { // (batches with cut pieces: the fix-ups of the trellis size their check window by it)
+        const int m = waveMin(mnEop, w);
+        FOR_WLANES(t, w) { if ((t & 63) == 0) B.tileMinEop[gblk0 / NB] = m; }
     }
 }
 
@@ -1225,6 +1242,7 @@ struct TrellisLds {
     double oldCol[SP];
     double segDt[4];
     int lastBad;
+    int needPos;                     // first base whose retired values the state at the end of the current tile still depends on
 };
 
 // loads of data this workgroup itself stored earlier (other wavefront, at least one tile barrier ago): workgroup-scope
@@ -2009,7 +2027,18 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (w >= W_LOAD) {
                 // ---- loader wavefronts: stage the next tile, retire the back pointers of the previous one
                 FOR_WLANES(t, w) {
-                    if (CMP) { const int tid = t - W_LOAD * WAVE; if (tid < SP) L.oldCol[tid] = gp(B.ckCol)[(o / WAVE + tile) * SP + tid]; } // what pass 1 left at the end of this tile
+                    if (CMP) { // what pass 1 left at the end of this tile; how far back the state at its end reaches (candidates of
+                               // this tile and the one before, of every later tile, the long-lag cells of equalD)
+                        const int tid = t - W_LOAD * WAVE;
+                        if (tid < SP) L.oldCol[tid] = gp(B.ckCol)[(o / WAVE + tile) * SP + tid];
+                        if (tid == SP) {
+                            const int64_t gt = o / WAVE + tile;
+                            int m = gp(B.tileCross)[gt];
+                            const int a = gp(B.tileMinEop)[gt], b2 = tile > 0 ? gp(B.tileMinEop)[gt - 1] : 0x7fffffff, c2 = tile * WAVE - dL - WAVE;
+                            m = a < m ? a : m; m = b2 < m ? b2 : m; m = c2 < m ? c2 : m;
+                            L.needPos = m;
+                        }
+                    }
                     if (tile + 1 < tEnd || (CMP && tile + 1 < nTiles)) loadTileThread<BLK, CMP>(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= tStart + 1);
                     if (tile >= tStart + 1) flushBpThread<CMP>(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
@@ -2179,8 +2208,13 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             // tiles up to tile - 1 have been retired and compared (by the loaders, during this tile); converged when the last
             // segCheckTiles of them -- more than the longest look-back of any state -- all differ from pass 1 by one offset
             const int lb = L.lastBad;
+            const int needTile = L.needPos < 0 ? -1 : L.needPos / WAVE; // the tile of that base: verified from its first base on
             BLOCK_SYNC();
-            if ((tile - 1) - lb >= B.segCheckTiles) break;
+            // converged: every tile from needTile to tile - 1 -- at least the last three -- has been verified with one offset.
+            // (Then the ring at the end of this tile and every retired value a later cell can read are old + D, by induction
+            // over the columns from the fully verified column at the end of tile - 2)
+            const int win = B.segCheckTiles > 0x10000 ? B.segCheckTiles : 3; // (tests force the give-up path with a huge check length)
+            if (lb < needTile && (tile - 1) - lb >= win) break;
             if (MODE == 1 && tile + 1 == tEnd) gaveUp = true;
         }
     }
@@ -2236,6 +2270,15 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             B.status[p] = L.abortFlag ? AUGX_E_HIP : state >= 0 ? 0 : AUGX_E_NOPATH;
         }
     }
+}
+
+// tileCross[t] = the smallest predecessor position any candidate ending in the tiles t+1 .. t+W of the same piece reads
+AUGX_HD void tileCrossOne(const BatchView &B, int64_t gt) {
+    const int p = B.chunkPiece[gt * WAVE / CHUNK];
+    const int64_t last = B.off[p] / WAVE + (B.len[p] + WAVE - 1) / WAVE - 1; // last tile of the piece
+    int m = 0x7fffffff;
+    for (int64_t u = gt + 1; u <= gt + B.segCheckTiles && u <= last; u++) { const int v = B.tileMinEop[u]; m = v < m ? v : m; }
+    B.tileCross[gt] = m;
 }
 
 // =================================================================================================

@@ -144,6 +144,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.blkCnt = zalloc<uint32_t>(B.nBlk * 2);
     B.blkSplit = zalloc<uint32_t>(B.nBlk * 3);
     B.blkOff = zalloc<uint64_t>(B.nBlk * 2);
+    B.tileMinEop = zalloc<int32_t>(Z.N / WAVE + 1); B.tileCross = zalloc<int32_t>(Z.N / WAVE + 1);
     CandAlloc ca;
     B.candAlloc = &ca;
     CandLds *cl = new CandLds();
@@ -212,6 +213,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     B.segStop = segStop.data(); B.segStatus = segStatus.data(); B.segD = segD.data(); B.brkPos = brkPos.data(); B.brkOff = brkOff.data();
     B.segStop2 = segStop2.data(); B.segD2 = segD2.data(); B.pieceCovered = pieceCovered.data();
     if (plan.cut()) {
+        for (int64_t gt = 0; gt < B.N / WAVE; gt++) tileCrossOne(B, gt);
         B.ckRing = zalloc<double>((int64_t)B.nSegs * 2 * WAVE * SP);
         B.ckCol = zalloc<double>(Z.N / WAVE * SP);
     }
@@ -262,7 +264,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             w += (int64_t)L.len[p] * t->S;
         }
     }
-    free(B.ckRing); free(B.ckCol);
+    free(B.ckRing); free(B.ckCol); free(B.tileMinEop); free(B.tileCross);
     free(B.blkCnt); free(B.blkSplit); free(B.blkOff); free(B.items);
     free(raw); free(B.code); free(B.cnt); free(B.nsm); free(B.fx); free(B.sig); free(B.gate); free(B.site); free(B.bp); free(B.bpChain);
     free(B.cells); free(B.vig); free(B.longV); free(B.laPos); free(B.laVal); free(B.lrPos); free(B.lrVal); free(B.ldEnt); free(B.ldVal);

@@ -36,6 +36,13 @@ BIG_CFGS = {
 }
 
 
+def genome_like_records(g):
+    import bench
+    rc = g[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+    big = g + rc[100000:900000] + bench.synth_contigs(1, 1300000, 777)[0].decode() + g[300000:1000000] + rc[:400000]
+    return [("chrBig", big), ("chrI_tail", g[650000:])]
+
+
 def main():
     ref_genome = "/root/reference/examples/autoAug/genome.fa"
     tar = os.path.join(HERE, "big_inputs.tar.gz")
@@ -59,6 +66,16 @@ def main():
             assert len(res) == 1, err
             paths[cfg] = {"lnv": repr(res[0]["lnv"]), "path": res[0]["path"], "n": res[0]["n"]}
     json.dump(paths, open(os.path.join(HERE, "golden_big_paths.json"), "w"))
+    # a genome-like input for the human model at its own maxDNAPieceSize (2 Mbp): one 4.2 Mbp record (three pieces, two cut
+    # points found in 150 kb exam windows) + one short record; soft-masked real DNA in both orientations and random DNA
+    import gzip
+    fa = os.path.join(d, "genome_like.fa")
+    write_fasta(fa, genome_like_records(read_fasta(ref_genome)[0][1]))
+    txt = subprocess.run([REF_AUGUSTUS, "--species=human", "--progress=true", fa], capture_output=True, text=True, env=env)
+    assert txt.returncode == 0, txt.stderr
+    with gzip.open(os.path.join(HERE, "golden_big_genome_like.gff.gz"), "wt") as f:
+        f.write("\n".join([l for l in txt.stderr.splitlines() if l.startswith("examining piece")] + gff_body(txt.stdout)) + "\n")
+    print("genome_like", len(gff_body(txt.stdout)), "gff lines")
 
 
 if __name__ == "__main__":

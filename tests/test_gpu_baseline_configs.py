@@ -4,6 +4,7 @@
 import json
 import os
 import shutil
+import sys
 import subprocess
 import tarfile
 
@@ -188,3 +189,21 @@ def test_cli_outfile_errfile_stdin_and_config_next_to_binary(tmp_path):
     # --species=help: usage on stderr, exit code 0
     r = subprocess.run([EXE, "--species=help"], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "human" in r.stderr.split()
+
+
+def test_cli_genome_like_default_pieces(big_inputs, tmp_path):
+    """a genome-like run with default flags (BASELINE config 5 in small): a 4.2 Mbp record at the human model's own
+    maxDNAPieceSize (2 Mbp) -- two cut points found by decoding 150 kb exam windows, which the trellis itself cuts into
+    segments --, soft-masked real DNA in both orientations, a second record: cut points and GFF equal the reference binary's
+    (tests/golden/make_golden_big.py: genome_like)"""
+    import gzip
+    sys.path.insert(0, GOLDEN)
+    from make_golden_big import genome_like_records
+    fa = str(tmp_path / "genome_like.fa")
+    write_fasta(fa, genome_like_records(read_fasta(big_inputs["genome"])[0][1]))
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE, "--species=human", "--progress=true", fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    ours = [l for l in r.stderr.splitlines() if l.startswith("examining piece")] + gff_body(r.stdout)
+    gold = gzip.open(os.path.join(GOLDEN, "golden_big_genome_like.gff.gz"), "rt").read().splitlines()
+    assert ours == gold
