@@ -81,16 +81,39 @@ __global__ void kListCount(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < B.nPieces) k1ListCount(B, p);
 }
+// the bases of the 256 slots of a workgroup and of their surroundings, staged in LDS once: the per-slot code reads dozens of
+// single bases around its own (motif windows, splice-site and codon tests) -- from LDS instead of one byte load each
+constexpr int SLOT_HALO = 64;
+struct SlotCodes {
+    uint8_t c[256 + 2 * SLOT_HALO];
+    int lo;
+    __device__ void load(const BatchView &B) {
+        const int64_t g0 = (int64_t)blockIdx.x * 256;
+        const int p = B.chunkPiece[g0 / CHUNK]; // (256 | CHUNK: the slots of a workgroup belong to one piece)
+        const int64_t o = B.off[p];
+        const int n = B.len[p], q0 = (int)(g0 - o - 1) - SLOT_HALO;
+        for (int i = threadIdx.x; i < 256 + 2 * SLOT_HALO; i += 256) {
+            const int q = q0 + i;
+            c[i] = (q >= 0 && q < n) ? B.code[o + 1 + q] : 4;
+        }
+        if (threadIdx.x == 0) lo = q0;
+        __syncthreads();
+    }
+};
 __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B) {
+    __shared__ SlotCodes C;
+    C.load(B);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < B.N) k1Signals(*T, B, g);
+    if (g < B.N) k1Signals(*T, B, g, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
 __global__ void __launch_bounds__(256) kSiteSignals(const DevTables *T, BatchView B) {
     k1SiteSignals(*T, B, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
 __global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView B) { // grid.y = plane
+    __shared__ SlotCodes C;
+    C.load(B);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g < B.N) k1SiteConsts(*T, B, g, blockIdx.y);
+    if (g < B.N) k1SiteConsts(*T, B, g, blockIdx.y, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
 
 // ---- fused term + scan kernels: one workgroup of 1024 threads per chunk of CHUNK slots, one thread per slot.  The terms of a
@@ -317,6 +340,7 @@ struct augx_batch {
     uint64_t nItems = 0, nPairs = 0;
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
     bool decoded = false;
+    bool itemsVerified = false; // the candidate buffer in use has held all candidates of this batch once
     SegPlan plan;            // segments of the trellis (layout.h: planSegments)
     int chunkTotPlanes = 1;  // planes the scan totals are allocated for
 };
@@ -580,6 +604,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1), dim3(32), 0, st, V.chunkTot, V, NSF, NCNT);
     hipLaunchKernelGGL(kSiteScanApply, dim3(V.nChunks), dim3(1024), 0, st, d->dT, V, V.chunkTot);
     if (!b->listsReady) hipLaunchKernelGGL(kListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
+    // GC classes, planes and list sizes are properties of the batch's sequences: settled by its first decode (with one host
+    // round trip); a batch decoded again re-uses them and never waits for the host
+    if (!b->decoded) {
     hipLaunchKernelGGL(kWindowClass, dim3(gridN), dim3(256), 0, st, d->dT, V, b->blkMinMax);
     hipLaunchKernelGGL(kClassFinal, dim3(n), dim3(64), 0, st, V, b->blkMinMax);
     HIP_TRY(hipGetLastError());
@@ -625,10 +652,11 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         }
         const void *fxBefore = W.fx;
         if ((rc = ensureArrays(b, nPl, W.listCap))) return rc;
-        if (changed || fxBefore != W.fx) { // (planes and list sizes are properties of the batch's sequences: its first decode only)
+        if (changed || fxBefore != W.fx) {
             W.nPl = nPl;
             HIP_TRY(hipMemcpy(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice));
         }
+    }
     }
     if (V.nPl > b->chunkTotPlanes) { // (one set of chunk totals per plane of the class-dependent arrays)
         uint64_t *nt = nullptr;
@@ -657,6 +685,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             HIP_TRY(hipStreamSynchronize(st));
             devFree(d, b->itemBuf);
             b->itemBuf = nullptr;
+            b->itemsVerified = false;
         }
         if (!b->itemBuf) { // first estimate: uniform-random DNA has 1.2 pairs and 15 candidates per base
             W.itemCap = b->nItems > 0 ? (int64_t)(b->nItems + b->nItems / 16 + 65536) : W.N * 18 + 65536;
@@ -669,6 +698,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             W.items = (Item *)b->itemBuf;
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
+        // (steady: the batch has been decoded with this very buffer before -- the same sequences give the same candidates, no
+        //  need to read the count back)
+        const bool steady = b->decoded && b->itemBuf && b->nItems > 0 && (uint64_t)W.itemCap >= b->nItems && b->itemsVerified;
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
             const bool multi = W.nPl > 1;
@@ -679,11 +711,12 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             else AUGX_LAUNCH_CAND(2);
 #undef AUGX_LAUNCH_CAND
             HIP_TRY(hipGetLastError());
+            if (steady) break;
             CandAlloc tot;
             HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             b->nPairs = tot.pairs; b->nItems = tot.items;
-            if ((int64_t)tot.items <= W.itemCap) break;
+            if ((int64_t)tot.items <= W.itemCap) { b->itemsVerified = true; break; }
             if (attempt > 0) { setLastError("augx_batch_decode: candidate buffers overflowed twice"); return AUGX_E_HIP; }
             devFree(d, b->itemBuf);
             b->itemBuf = nullptr;

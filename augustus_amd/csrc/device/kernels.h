@@ -302,7 +302,7 @@ AUGX_HD void k1FxTerms(const DevTables &T, const BatchView &B, int64_t g, int pl
 
 // per-base signal record + end-gate mask of the variable-length states
 constexpr int NSITE = 4;
-AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
+AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g, const uint8_t *lcode = nullptr, int lLo = 0, int lHi = 0) {
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
@@ -313,6 +313,7 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g) {
     for (int i = 0; i < NSITE; i++) st[i] = -1;
     if (q < 0 || q >= B.len[p] || B.cls[p] < 0) return;
     Piece P = makePieceAt(T, B, p, B.gcPlane[g]); // everything ending at q is scored with the class of q
+    P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;    // (device: the bases around the workgroup's slots, staged in LDS)
     const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
     const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0; // (src/igenicmodel.cc:306-326)
     sg[SIG_EIG] = q >= 1 ? eIg(P, q) + softB : AUGX_NINF;
@@ -402,7 +403,7 @@ AUGX_HD void k1SiteSignals(const DevTables &T, const BatchView &B, int64_t t, in
 // values).  Fast-path evaluation in the trellis combines them with end-side constants; the arithmetic is exactly that
 // of exNotEndPart (same prefix differences, same order of additions).
 // One set of constants per plane (GC class) of the piece -- the END of the candidate's state selects the plane: pl = plane.
-AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int pl) {
+AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int pl, const uint8_t *lcode = nullptr, int lLo = 0, int lHi = 0) {
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
@@ -413,6 +414,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
     pr[0] = pr[1] = pr[2] = AUGX_NINF;
     if (B.cls[p] < 0) return;
     Piece P = makePieceAt(T, B, p, pl);
+    P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
     const int k = T.k, c = P.c, n = P.n;
     const int64_t lo = listOff(B, p);
     auto fxv = [&](int pos, int f) -> uint64_t { return pos < 0 ? 0 : P.fx[fidx(o + 1 + (pos < n ? pos : n - 1), f, NFX)]; };
