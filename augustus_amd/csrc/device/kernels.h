@@ -570,6 +570,7 @@ struct CandLds {
     int scan[NWAVES][3][WAVE];                           // inclusive lane scans of the pair counts of the three groups
     uint32_t cntItems[NWAVES][MAXNB], cntNonRT[NWAVES][MAXNB]; // per block: candidates (then: first candidate), candidates but RTERMINAL
     unsigned long long baseW[NWAVES][2];                 // first pair / first candidate of the tile in the batch's buffers
+    uint8_t codes[NWAVES * WAVE + 2 * WAVE];             // the bases of the workgroup's tiles and 64 to either side (Piece::lcode)
     uint32_t slowIt[NWAVES][2 * WAVE];                   // candidates of the current round that need the general formula (index in the round)
     int slowN[NWAVES];
 };
@@ -1187,8 +1188,16 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
     uint64_t cp0 = clock64(), cp1;
 #endif
     FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, B, p, t, L.vc[t]); }
+    const int cLo = (int)(gtile0 * WAVE - B.off[p] - 1) - WAVE; // first staged base
+    FOR_THREADS(t) {
+        for (int i = t; i < NWAVES * WAVE + 2 * WAVE; i += NT) {
+            const int q = cLo + i;
+            L.codes[i] = (q >= 0 && q < B.len[p]) ? B.code[B.off[p] + 1 + q] : 4;
+        }
+    }
     BLOCK_SYNC();
     CandCtx X(T, B, L.vc, p);
+    X.P.lcode = L.codes; X.P.lLo = cLo; X.P.lHi = cLo + NWAVES * WAVE + 2 * WAVE;
     uint64_t maskVar, maskRT;
     varMasks(T, maskVar, maskRT);
     uint64_t maskLess = 0;
