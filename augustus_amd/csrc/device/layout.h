@@ -135,7 +135,7 @@ inline SegPlan planSegments(const BatchLayout &L, const augx_tables &t, int slot
     if (segTiles == 0) {
         // estimate of the time of the three passes for a candidate segment length: rounds of `slots` concurrent workgroups,
         // each as long as the longest segment / a typical fix-up (convergence within ~400 tiles on random DNA, then the check)
-        const int64_t fixLen = P.checkTiles + 400;
+        const int64_t fixLen = 450; // (convergence ~400 tiles on random DNA + the check window, which follows the candidates that really cross the stop point)
         int64_t bestCost = -1;
         int best = -1;
         for (int k = 1; k <= 64; k++) {

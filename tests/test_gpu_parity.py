@@ -232,7 +232,7 @@ def test_gpu_small_block_sizes(monkeypatch, blk):
 
 
 @pytest.mark.parametrize("env", [{"AUGX_SEG_LEN": "100000"}, {"AUGX_SEG_LEN": "100000", "AUGX_SEG_CHECK_TILES": "100000"}, {}])
-@pytest.mark.parametrize("species", ["human", "fly"])
+@pytest.mark.parametrize("species", ["human", "fly", "arabidopsis"])
 def test_gpu_segment_parallel_trellis(monkeypatch, env, species):
     """pieces cut into segments decoded at once (tests/test_emu.py: test_emulated_segment_parallel_trellis), the give-up path
     forced, and the planner's own choice: every cell, the score and the path equal the sequential oracle bit for bit"""
