@@ -265,19 +265,29 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     }
     // ---- command line (reference Properties::init, src/properties.cc:66-135)
     std::vector<std::pair<std::string, std::string>> cmd;
+    std::vector<std::pair<std::string, bool>> plain; // every non-special --name in the reference's order of checking (right to left), with "has '='"
     std::string queryfile, species, configPath;
     for (int a = argc - 1; a >= 1; a--) {
         std::string s(argv[a]);
-        if (s.size() > 2 && s.compare(0, 2, "--") == 0) {
+        if (s == "--version") { std::cerr << augx_version() << "\n"; return 0; }  // (reference: HelpException -> message on stderr, exit 0)
+        if (s == "--help") { std::cerr << "usage:\naugustus [parameters] --species=SPECIES queryfilename\n"; return 0; }
+        if (s.size() >= 2 && s.compare(0, 2, "--") == 0) {
             s.erase(0, 2);
             size_t pos = s.find('=');
             std::string name = s.substr(0, pos);
-            if (pos == std::string::npos || pos >= s.size() - 1)
+            // the parameters the reference takes from the command line in its first pass (src/properties.cc:93-108)
+            const bool special = name == "genemodel" || name == "nc" || name == "singlestrand" || name == "species" || name == "extrinsicCfgFile" ||
+                                 name == "AUGUSTUS_CONFIG_PATH" || name == "alnfile" || name == "treefile" || name == "dbaccess" ||
+                                 name == "speciesfilenames" || name == "codonAlignmentFile" || name == "referenceFile";
+            if (special && (pos == std::string::npos || pos >= s.size() - 1))
                 return fail("Wrong argument format for " + name + ". Use: --argument=value");
-            std::string value = s.substr(pos + 1);
+            std::string value = pos == std::string::npos ? "" : s.substr(pos + 1);
             if (name == "species") species = value;
             else if (name == "AUGUSTUS_CONFIG_PATH") configPath = value;
-            else cmd.insert(cmd.begin(), {name, value});
+            else {
+                if (!special) plain.push_back({name, pos != std::string::npos});
+                if (pos != std::string::npos) cmd.insert(cmd.begin(), {name, value});
+            }
         } else if (queryfile.empty())
             queryfile = s;
         else
@@ -320,15 +330,31 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (auto &nm : names) std::cerr << nm << "\n";
         return 0;
     }
-    {   // unknown parameters are an error (reference src/properties.cc:225-319, config/parameters/aug_cmdln_parameters.json)
+    {   // the species' parameter file must exist (reference Properties::readFile, src/properties.cc:35-60, prints its search on stderr)
+        const std::string rel = "species/" + species + "/" + species + "_parameters.cfg";
+        struct stat s2;
+        if (stat((configPath + rel).c_str(), &s2) != 0) {
+            std::cerr << "Could not find the config file " << configPath << rel << "." << std::endl;
+            std::cerr << " Looking for " << species << "_parameters.cfg in the configuration directory instead ...";
+            if (stat((configPath + species + "_parameters.cfg").c_str(), &s2) != 0) std::cerr << " not";
+            std::cerr << " found." << std::endl;
+        }
+    }
+    {   // a parameter without '=' and unknown parameters are errors, checked right to left (reference src/properties.cc:275-319,
+        // names from config/parameters/aug_cmdln_parameters.json) -- after the species' files have been found
+        struct stat s2;
+        const bool haveSpecies = stat((configPath + "species/" + species + "/" + species + "_parameters.cfg").c_str(), &s2) == 0 ||
+                                 stat((configPath + species + "_parameters.cfg").c_str(), &s2) == 0;
         std::ifstream pj((configPath + "parameters/aug_cmdln_parameters.json").c_str());
-        if (pj) {
+        if (pj && haveSpecies) {
             std::stringstream ss;
             ss << pj.rdbuf();
             const std::string js = ss.str();
-            for (auto &kv : cmd)
+            for (auto &kv : plain) {
+                if (!kv.second) return fail("'=' missing for parameter: " + kv.first);
                 if (js.find("\"name\": \"" + kv.first + "\"") == std::string::npos && js.find("\"name\":\"" + kv.first + "\"") == std::string::npos)
                     return fail("Unknown parameter: \"" + kv.first + "\". Type \"augustus\" for help.");
+            }
         }
     }
     std::vector<const char *> names, values;
@@ -339,6 +365,10 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     const Model &M = S.model->m;
     S.oo.fromModel(M);
     if (queryfile.empty()) return fail("No query file specified. Type \"augustus\" for help.");
+    if (queryfile != "-") { // (reference: the input file is opened before the header is printed)
+        std::ifstream probe(queryfile.c_str());
+        if (!probe) return fail("Could not open input file \"" + queryfile + "\"!");
+    }
     if (M.opt.getInt("sample", 0) > 0)
         return fail("sampling (--sample>0: forward algorithm + posterior probabilities) is not implemented on the MI355X path yet; "
                     "run with --sample=0 (the human default).");
@@ -370,7 +400,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         if (queryfile == "-") ok = readFasta(std::cin, recs);
         else {
             std::ifstream in(queryfile.c_str());
-            if (!in) { restore(); return fail("Could not open input file " + queryfile); }
+            if (!in) { restore(); return fail("Could not open input file \"" + queryfile + "\"!"); }
             ok = readFasta(in, recs);
         }
         if (!ok) { restore(); return fail("File format of " + queryfile + " not recognized (only FASTA input is supported on the MI355X path)."); }
@@ -382,6 +412,8 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     }
     if (verbosity > 0) std::cout << "# We have hints for 0 sequences and for 0 of the sequences in the input set." << std::endl;
 
+    const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
+    if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); S.destroy(); return 1; }
     {   // ---- devices: every visible GPU, or the ones named by AUGX_DEVICES ("0,2,5"; a single number N = the first N);
         //      AUGX_DEVICE (one index) is kept for single-device runs
         std::vector<int> devs;
@@ -404,8 +436,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     }
 
     lap("device / decoder create");
-    const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
-    if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); S.destroy(); return 1; }
+
     // --predictionStart / --predictionEnd: predict on a piece of the first sequence only and shift the printed coordinates
     // (reference cutRelevantPiece, src/augustus.cc:552-602)
     if ((M.opt.has("predictionStart") || M.opt.has("predictionEnd")) && !recs.empty()) {
