@@ -77,6 +77,69 @@ __global__ void __launch_bounds__(64) kClassFinal(BatchView B, const int32_t *bl
         B.planeCls[p * MAXPL] = B.cls[p];
     }
 }
+// smoothed GC-content stairs of the pieces whose windows disagree, on the device (the same algorithm as layout.h: stairsPlanes,
+// reference ContentStairs::computeStairs, src/motif.cc:543-616): runs of equal window class, a run shorter than 1000 bases
+// between two runs of one class is dissolved, classes are numbered by first appearance (planes), every base gets its plane.
+// One workgroup per piece; a piece with more runs than STAIR_RUNS is left to the host (info[1] is set).
+constexpr int STAIR_RUNS = 4096;
+__global__ void __launch_bounds__(256) kStairs(const DevTables *T, BatchView B, int32_t *info /* [0] max planes, [1] pieces left to the host */) {
+    const int p = blockIdx.x, t = threadIdx.x;
+    if (B.cls[p] >= 0) return; // all windows agree: one class, plane 0 (gcPlane is zero)
+    __shared__ int st[STAIR_RUNS];
+    __shared__ uint8_t cl[STAIR_RUNS], pl[STAIR_RUNS];
+    __shared__ int cnt[256];
+    __shared__ int R, nPlS;
+    const int n = B.len[p];
+    int win = T->gc_win;
+    if (win > n || win < 1) win = n;
+    const int half = win / 2, last = n - win;
+    const uint8_t *wc = B.gcRaw + B.off[p] + 1;
+    // window starts 1..last where the class changes, counted per thread (contiguous chunks), then written in order
+    const int per = (last + 256) / 256, a = 1 + t * per, b = a + per < last + 1 ? a + per : last + 1;
+    int c = 0;
+    for (int s0 = a; s0 < b; s0++) c += wc[s0] != wc[s0 - 1];
+    cnt[t] = c;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 1; // (run 0 starts at window 0)
+        for (int i = 0; i < 256; i++) { const int v = cnt[i]; cnt[i] = acc; acc += v; }
+        R = acc;
+    }
+    __syncthreads();
+    if (R > STAIR_RUNS) { if (t == 0) atomicAdd(&info[1], 1); return; }
+    if (t == 0) { st[0] = 0; cl[0] = wc[0]; }
+    int k = cnt[t];
+    for (int s0 = a; s0 < b; s0++)
+        if (wc[s0] != wc[s0 - 1]) { st[k] = s0 + half; cl[k] = wc[s0]; k++; } // window s is centred on base s + half
+    __syncthreads();
+    if (t == 0) {
+        for (int q = 2; q < R; q++)
+            if (st[q] - st[q - 1] < 1000 && st[q - 1] > 0 && cl[q - 2] == cl[q]) cl[q - 1] = cl[q];
+        int map[AUGX_MAX_CLASSES], nPl = 0;
+        for (int i = 0; i < AUGX_MAX_CLASSES; i++) map[i] = -1;
+        for (int q = 0; q < R; q++) {
+            const int cc = cl[q] < AUGX_MAX_CLASSES ? cl[q] : 0;
+            if (map[cc] < 0) { B.planeCls[p * MAXPL + nPl] = cc; map[cc] = nPl++; } // (MAXPL = the largest class count a model may have)
+            pl[q] = (uint8_t)map[cc];
+        }
+        B.cls[p] = B.planeCls[p * MAXPL];
+        B.nPlanes[p] = nPl;
+        nPlS = nPl;
+        atomicMax(&info[0], nPl);
+    }
+    __syncthreads();
+    if (nPlS <= 1) return;
+    // every base: the plane of its run (thread = contiguous chunk of bases; the run is found by bisection, then walked)
+    const int perB = (n + 255) / 256, b0 = t * perB, b1 = b0 + perB < n ? b0 + perB : n;
+    if (b0 >= n) return;
+    int lo = 0, hi = R - 1;
+    while (lo < hi) { const int m = (lo + hi + 1) / 2; if (st[m] <= b0) lo = m; else hi = m - 1; }
+    uint8_t *gp2 = B.gcPlane + B.off[p] + 1;
+    for (int q = b0; q < b1; q++) {
+        while (lo + 1 < R && st[lo + 1] <= q) lo++;
+        gp2[q] = pl[lo];
+    }
+}
 __global__ void kListCount(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < B.nPieces) k1ListCount(B, p);
@@ -331,6 +394,7 @@ struct augx_batch {
     BatchView *dV = nullptr;   // device copy of V (kernels with high register pressure take it by pointer)
     std::vector<void *> bufs;
     int32_t *blkMinMax = nullptr; // [N/256][2] window-class range of every 256 slots
+    int32_t *stairInfo = nullptr; // [2] kStairs: most planes of a piece, pieces left to the host
     int nPlAlloc = 0;          // planes the class-dependent arrays are allocated for (0: not yet)
     int64_t listCapAlloc = 0;  // entries per plane the candidate-list arrays are allocated for
     bool listsReady = false;   // the list offsets of this batch's pieces have been computed (its first decode)
@@ -528,6 +592,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     V.off = dOff; V.len = dLen; V.initKind = dIk; V.termKind = dTk; V.chunkPiece = dCp; V.raw = dRaw;
     DA(V.cls, int32_t, n); DA(V.clsMinMax, int32_t, 2 * n);
     DA(b->blkMinMax, int32_t, (Z.N / 256 + 1) * 2);
+    DA(b->stairInfo, int32_t, 2);
     DA(V.nPlanes, int32_t, n); DA(V.planeCls, int32_t, (int64_t)n * MAXPL);
     DA(V.gcRaw, uint8_t, Z.N); DA(V.gcPlane, uint8_t, Z.N);
     V.nPl = 1; V.listCap = 0; // (the list arrays are sized by the first decode, from the counted sites)
@@ -614,28 +679,30 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         // the window classes (1 byte per base; reference ContentStairs::computeStairs, src/motif.cc:543-616), and the
         // classes of the piece become planes of the class-dependent arrays
         BatchView &W = b->V;
-        std::vector<int32_t> cls(n);
-        HIP_TRY(hipMemcpyAsync(cls.data(), V.cls, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(b->stairInfo, 0, 2 * sizeof(int32_t), st));
+        hipLaunchKernelGGL(kStairs, dim3(n), dim3(256), 0, st, d->dT, V, b->stairInfo);
+        int32_t info[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(info, b->stairInfo, sizeof info, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        int nPl = 1;
-        bool any = false;
-        std::vector<int32_t> nPlanes(n, 1), planeCls((size_t)n * MAXPL, 0);
-        std::vector<uint8_t> wc, plane;
-        for (int p = 0; p < n; p++) {
-            planeCls[(size_t)p * MAXPL] = cls[p];
-            if (cls[p] >= 0) continue; // (gcPlane is all zero for such a piece: set when the batch was created)
-            const int len = b->L.len[p];
-            any = true;
-            wc.resize((size_t)len);
-            HIP_TRY(hipMemcpy(wc.data(), V.gcRaw + b->L.off[p] + 1, (size_t)len, hipMemcpyDeviceToHost));
-            const int np = stairsPlanes(wc.data(), len, d->model->m.t.gc_win, plane, &planeCls[(size_t)p * MAXPL]);
-            if (np < 0) continue; // (cannot happen: MAXPL is the largest class count a model may have)
-            cls[p] = planeCls[(size_t)p * MAXPL];
-            nPlanes[p] = np;
-            if (np > nPl) nPl = np;
-            if (np > 1) HIP_TRY(hipMemcpy(V.gcPlane + b->L.off[p] + 1, plane.data(), (size_t)len, hipMemcpyHostToDevice));
-        }
-        if (any) {
+        int nPl = info[0] > 1 ? info[0] : 1;
+        if (info[1] > 0) { // a piece with more class changes than the kernel holds (thousands): its stairs on the host
+            std::vector<int32_t> cls(n), nPlanes(n), planeCls((size_t)n * MAXPL);
+            HIP_TRY(hipMemcpy(cls.data(), V.cls, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(nPlanes.data(), V.nPlanes, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(planeCls.data(), V.planeCls, sizeof(int32_t) * n * MAXPL, hipMemcpyDeviceToHost));
+            std::vector<uint8_t> wc, plane;
+            for (int p = 0; p < n; p++) {
+                if (cls[p] >= 0) continue;
+                const int len = b->L.len[p];
+                wc.resize((size_t)len);
+                HIP_TRY(hipMemcpy(wc.data(), V.gcRaw + b->L.off[p] + 1, (size_t)len, hipMemcpyDeviceToHost));
+                const int np = stairsPlanes(wc.data(), len, d->model->m.t.gc_win, plane, &planeCls[(size_t)p * MAXPL]);
+                if (np < 0) continue; // (cannot happen: MAXPL is the largest class count a model may have)
+                cls[p] = planeCls[(size_t)p * MAXPL];
+                nPlanes[p] = np;
+                if (np > nPl) nPl = np;
+                if (np > 1) HIP_TRY(hipMemcpy(V.gcPlane + b->L.off[p] + 1, plane.data(), (size_t)len, hipMemcpyHostToDevice));
+            }
             HIP_TRY(hipMemcpy(V.cls, cls.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(V.nPlanes, nPlanes.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(V.planeCls, planeCls.data(), sizeof(int32_t) * n * MAXPL, hipMemcpyHostToDevice));
