@@ -78,5 +78,29 @@ def main():
     print("genome_like", len(gff_body(txt.stdout)), "gff lines")
 
 
+def more_species():
+    """two more species (config_more.tar.gz): nasonia (5 GC classes) and rice (4), 200 kb pieces"""
+    g = read_fasta("/root/reference/examples/autoAug/genome.fa")[0][1]
+    byname = dict(golden_inputs())
+    recs = [("chrI_300k", g[100000:400000]), ("multigc_levels", byname["multigc_levels"]), ("HS04636", byname["HS04636"])]
+    fa = os.path.join(HERE, "inputs_more.fa")
+    write_fasta(fa, recs)
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
+    for cfg, (species, opts) in MORE_CFGS.items():
+        extra = ["--%s=%s" % kv for kv in opts.items()]
+        res, err = ref_harness(fa, species, extra, cfg="/root/reference/config/")
+        assert len(res) == len(recs), err
+        json.dump({"species": species, "records": [{"name": r["name"], "n": r["n"], "lnv": repr(r["lnv"]), "path": r["path"]} for r in res]},
+                  open(os.path.join(HERE, "golden_more_paths_%s.json" % cfg), "w"))
+        txt = subprocess.run([REF_AUGUSTUS, "--species=" + species, "--progress=true"] + extra + [fa], capture_output=True, text=True, env=env)
+        assert txt.returncode == 0, txt.stderr
+        open(os.path.join(HERE, "golden_more_%s.gff" % cfg), "w").write(
+            "\n".join([l for l in txt.stderr.splitlines() if l.startswith("examining piece")] + gff_body(txt.stdout)) + "\n")
+        print(cfg, len(res), "records")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "more":
+        more_species()
+        sys.exit(0)
     main()

@@ -27,15 +27,17 @@ def config_path():
     global _cfg_dir
     if _cfg_dir is None:
         tar = os.path.join(GOLDEN, "config_min.tar.gz")
-        d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d" % (os.getuid(), os.path.getsize(tar)))
+        more = os.path.join(GOLDEN, "config_more.tar.gz")  # two more species (nasonia: 5 GC classes, rice: 4)
+        d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d_%d" % (os.getuid(), os.path.getsize(tar), os.path.getsize(more)))
         marker = os.path.join(d, "config", "model", "states_shadow.cfg")
         if not os.path.exists(marker):
             # several processes may get here at once (one rank per GPU, pytest-xdist): extract privately, publish with one
             # atomic rename; whoever loses the race uses the winner's copy
             import shutil
             tmp = tempfile.mkdtemp(prefix="augx_config_tmp_")
-            with tarfile.open(tar) as t:
-                t.extractall(tmp)
+            for tf in (tar, more):
+                with tarfile.open(tf) as t:
+                    t.extractall(tmp)
             try:
                 os.rename(tmp, d)
             except OSError:
@@ -142,6 +144,18 @@ GOLDEN_CFGS = {
     "arabidopsis": ("arabidopsis", {"UTR": "off", "sample": "0", "softmasking": "0"}),
     "saccharomyces": ("saccharomyces", {"UTR": "off", "sample": "0", "softmasking": "0"}),
 }
+
+
+# species pinned at a larger scale (tests/golden/make_golden_big.py: more_species): 300 kb of real DNA and records whose GC
+# content runs through many classes, at the species' own maxDNAPieceSize (200 kb: one cut)
+MORE_CFGS = {
+    "nasonia": ("nasonia", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+    "rice": ("rice", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+}
+
+
+def more_inputs():
+    return read_fasta(os.path.join(GOLDEN, "inputs_more.fa"))
 
 
 def golden_inputs():

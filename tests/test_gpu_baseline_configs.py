@@ -207,3 +207,30 @@ def test_cli_genome_like_default_pieces(big_inputs, tmp_path):
     ours = [l for l in r.stderr.splitlines() if l.startswith("examining piece")] + gff_body(r.stdout)
     gold = gzip.open(os.path.join(GOLDEN, "golden_big_genome_like.gff.gz"), "rt").read().splitlines()
     assert ours == gold
+
+
+@pytest.mark.parametrize("cfg", list(MORE_CFGS))
+def test_more_species_match_reference(monkeypatch, cfg):
+    """nasonia (5 GC classes) and rice (4) at a larger scale (tests/golden/make_golden_big.py: more_species): through the C ABI
+    every cell equal to the twin and the path equal to the reference's; through the executable at the species' own 200 kb
+    pieces the cut points and the GFF equal the reference binary's"""
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    species, opts = MORE_CFGS[cfg]
+    m = ax.Model(config_path(), species, **opts)
+    d = ax.Decoder(m, 0)
+    recs = more_inputs()
+    gold = json.load(open(os.path.join(GOLDEN, "golden_more_paths_%s.json" % cfg)))["records"]
+    b = ax.Batch(d, [s for _, s in recs])
+    b.decode()
+    for i, ((name, seq), r, g) in enumerate(zip(recs, b.paths(), gold)):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+        assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, name
+        assert np.array_equal(b.cells(i), V), name
+        assert [(bb, e, t) for bb, e, s, t in r.states] == [tuple(p) for p in g["path"]], name
+        assert abs(r.ln_viterbi - float(g["lnv"])) <= 1e-9 * abs(float(g["lnv"])), name
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    args = [EXE, "--species=" + species, "--progress=true"] + ["--%s=%s" % kv for kv in opts.items()] + [os.path.join(GOLDEN, "inputs_more.fa")]
+    r = subprocess.run(args, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    ours = [l for l in r.stderr.splitlines() if l.startswith("examining piece")] + gff_body(r.stdout)
+    assert ours == open(os.path.join(GOLDEN, "golden_more_%s.gff" % cfg)).read().splitlines()
