@@ -37,6 +37,25 @@ using namespace augx::dev;
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
+// the bases of the 256 slots of a workgroup and of their surroundings, staged in LDS once: the per-slot code reads dozens of
+// single bases around its own (motif windows, splice-site and codon tests) -- from LDS instead of one byte load each
+constexpr int SLOT_HALO = 64;
+struct SlotCodes {
+    uint8_t c[256 + 2 * SLOT_HALO];
+    int lo;
+    __device__ void load(const BatchView &B) {
+        const int64_t g0 = (int64_t)blockIdx.x * 256;
+        const int p = B.chunkPiece[g0 / CHUNK]; // (256 | CHUNK: the slots of a workgroup belong to one piece)
+        const int64_t o = B.off[p];
+        const int n = B.len[p], q0 = (int)(g0 - o - 1) - SLOT_HALO;
+        for (int i = threadIdx.x; i < 256 + 2 * SLOT_HALO; i += 256) {
+            const int q = q0 + i;
+            c[i] = (q >= 0 && q < n) ? B.code[o + 1 + q] : 4;
+        }
+        if (threadIdx.x == 0) lo = q0;
+        __syncthreads();
+    }
+};
 __global__ void __launch_bounds__(256) kEncode(BatchView B) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1Encode(B, g);
@@ -144,25 +163,6 @@ __global__ void kListCount(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < B.nPieces) k1ListCount(B, p);
 }
-// the bases of the 256 slots of a workgroup and of their surroundings, staged in LDS once: the per-slot code reads dozens of
-// single bases around its own (motif windows, splice-site and codon tests) -- from LDS instead of one byte load each
-constexpr int SLOT_HALO = 64;
-struct SlotCodes {
-    uint8_t c[256 + 2 * SLOT_HALO];
-    int lo;
-    __device__ void load(const BatchView &B) {
-        const int64_t g0 = (int64_t)blockIdx.x * 256;
-        const int p = B.chunkPiece[g0 / CHUNK]; // (256 | CHUNK: the slots of a workgroup belong to one piece)
-        const int64_t o = B.off[p];
-        const int n = B.len[p], q0 = (int)(g0 - o - 1) - SLOT_HALO;
-        for (int i = threadIdx.x; i < 256 + 2 * SLOT_HALO; i += 256) {
-            const int q = q0 + i;
-            c[i] = (q >= 0 && q < n) ? B.code[o + 1 + q] : 4;
-        }
-        if (threadIdx.x == 0) lo = q0;
-        __syncthreads();
-    }
-};
 __global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B) {
     __shared__ SlotCodes C;
     C.load(B);
@@ -179,15 +179,18 @@ __global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView
     if (g < B.N) k1SiteConsts(*T, B, g, blockIdx.y, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
 
-// ---- fused term + scan kernels: one workgroup of 1024 threads per chunk of CHUNK slots, one thread per slot.  The terms of a
-// slot (11 site counts + 6 stop positions, or 20 fixed-point content terms) are computed in registers in BOTH passes -- totals
-// of the chunk, then the scan proper -- so that the prefix arrays are written to HBM once and never read by the scans (the
-// separate term kernels wrote them, kScanTotals read them, kScanApply read and rewrote them: four passes over 296 B per base).
-// Integer sums and maxima are exact: any scan shape gives the same bits as the sequential loop of the emulator.
-static_assert(CHUNK == 1024, "one thread per slot of a chunk");
-template <int NF, int NMAX> struct ScanLds { uint64_t w[NF][16]; };
-// field f < NMAXFIRST ... : the first `nSum` fields are summed, the rest take the maximum
-template <int NF> __device__ inline void chunkTotals(const uint64_t (&v)[NF], int nSum, ScanLds<NF, 0> &L, uint64_t *tot /* [NF] of this chunk */) {
+// ---- fused term + scan kernels: one workgroup of SCAN_T threads per scan block of SCAN_T slots, one thread per slot.  The terms
+// of a slot (11 site counts + 6 stop positions, or 20 fixed-point content terms) are computed in registers in BOTH passes --
+// totals of the block, then the scan proper -- so that the prefix arrays are written to HBM once and never read by the scans
+// (round 1: separate term kernels wrote them, kScanTotals read them, kScanApply read and rewrote them: four passes over
+// 296 B per base).  The bases the terms look at are staged in LDS (SlotCodes).  Integer sums and maxima are exact: any scan
+// shape gives the same bits as the sequential loop of the emulator.  (SCAN_T = 256: several workgroups per compute unit hide
+// each other's barriers; with one workgroup of 1024 threads per chunk the scans ran 40 % longer.)
+constexpr int SCAN_T = 256, SCAN_W = SCAN_T / 64;
+static_assert(CHUNK % SCAN_T == 0, "scan blocks do not straddle pieces");
+template <int NF> struct ScanLds { uint64_t w[NF][SCAN_W]; };
+// the first nSum fields are summed, the rest take the maximum
+template <int NF> __device__ inline void blockTotals(const uint64_t (&v)[NF], int nSum, ScanLds<NF> &L, uint64_t *tot /* [NF] of this block */) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
@@ -201,12 +204,12 @@ template <int NF> __device__ inline void chunkTotals(const uint64_t (&v)[NF], in
     __syncthreads();
     if (t < NF) {
         uint64_t x = L.w[t][0];
-        for (int i = 1; i < 16; i++) x = t < nSum ? x + L.w[t][i] : (x > L.w[t][i] ? x : L.w[t][i]);
+        for (int i = 1; i < SCAN_W; i++) x = t < nSum ? x + L.w[t][i] : (x > L.w[t][i] ? x : L.w[t][i]);
         tot[t] = x;
     }
 }
-// inclusive scan of every field across the 1024 slots of the chunk, on top of the chunk's exclusive offset pre[f]
-template <int NF> __device__ inline void chunkScan(uint64_t (&v)[NF], int nSum, ScanLds<NF, 0> &L, const uint64_t *pre) {
+// inclusive scan of every field across the slots of the block, on top of the block's exclusive offset pre[f]
+template <int NF> __device__ inline void blockScan(uint64_t (&v)[NF], int nSum, ScanLds<NF> &L, const uint64_t *pre) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
@@ -219,9 +222,9 @@ template <int NF> __device__ inline void chunkScan(uint64_t (&v)[NF], int nSum, 
         if (lane == 63) L.w[f][wave] = x;
     }
     __syncthreads();
-    if (t < NF) { // exclusive scan of the 16 wave totals of field t, seeded with the chunk's offset
+    if (t < NF) { // exclusive scan of the wave totals of field t, seeded with the block's offset
         uint64_t acc = pre[t];
-        for (int i = 0; i < 16; i++) {
+        for (int i = 0; i < SCAN_W; i++) {
             const uint64_t x = L.w[t][i];
             L.w[t][i] = acc;
             acc = t < nSum ? acc + x : (acc > x ? acc : x);
@@ -234,75 +237,58 @@ template <int NF> __device__ inline void chunkScan(uint64_t (&v)[NF], int nSum, 
         v[f] = f < nSum ? v[f] + a : (v[f] > a ? v[f] : a);
     }
 }
-// the bases of the chunk and of its surroundings (the terms look up to SCAN_HALO bases to either side), staged in LDS once
-constexpr int SCAN_HALO = 64;
-struct ChunkCodes {
-    uint8_t c[CHUNK + 2 * SCAN_HALO];
-    int lo;
-    __device__ void load(const BatchView &B) {
-        const int p = B.chunkPiece[blockIdx.x];
-        const int64_t o = B.off[p];
-        const int n = B.len[p], q0 = (int)((int64_t)blockIdx.x * CHUNK - o - 1) - SCAN_HALO;
-        for (int i = threadIdx.x; i < CHUNK + 2 * SCAN_HALO; i += blockDim.x) {
-            const int q = q0 + i;
-            c[i] = (q >= 0 && q < n) ? B.code[o + 1 + q] : 4;
-        }
-        if (threadIdx.x == 0) lo = q0;
-        __syncthreads();
-    }
-};
 constexpr int NSF = NCNT + 6; // site scans: 11 counts (sums) then 6 stop positions (maxima)
-__global__ void __launch_bounds__(1024) kSiteScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nChunks][NSF] */) {
-    __shared__ ScanLds<NSF, 0> L;
-    __shared__ ChunkCodes C;
+__global__ void __launch_bounds__(SCAN_T) kSiteScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [N / SCAN_T][NSF] */) {
+    __shared__ ScanLds<NSF> L;
+    __shared__ SlotCodes C;
     C.load(B);
-    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
     uint64_t v[NSF];
-    k1SiteTermsCalc(*T, B, g, v, v + NCNT, C.c, C.lo, C.lo + CHUNK + 2 * SCAN_HALO);
-    chunkTotals<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
+    k1SiteTermsCalc(*T, B, g, v, v + NCNT, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
+    blockTotals<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
 }
-__global__ void __launch_bounds__(1024) kSiteScanApply(const DevTables *T, BatchView B, const uint64_t *tot) {
-    __shared__ ScanLds<NSF, 0> L;
-    __shared__ ChunkCodes C;
+__global__ void __launch_bounds__(SCAN_T) kSiteScanApply(const DevTables *T, BatchView B, const uint64_t *tot) {
+    __shared__ ScanLds<NSF> L;
+    __shared__ SlotCodes C;
     C.load(B);
-    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
     uint64_t v[NSF];
-    k1SiteTermsCalc(*T, B, g, v, v + NCNT, C.c, C.lo, C.lo + CHUNK + 2 * SCAN_HALO);
-    chunkScan<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
+    k1SiteTermsCalc(*T, B, g, v, v + NCNT, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
+    blockScan<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
 #pragma unroll
     for (int f = 0; f < NCNT; f++) B.cnt[fidx(g, f, NCNT)] = (uint32_t)v[f];
 #pragma unroll
     for (int f = 0; f < 6; f++) B.nsm[fidx(g, f, 6)] = (uint32_t)v[NCNT + f];
 }
-__global__ void __launch_bounds__(1024) kFxScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nPl][nChunks][NFX] */) { // grid.y = plane
-    __shared__ ScanLds<NFX, 0> L;
-    __shared__ ChunkCodes C;
+__global__ void __launch_bounds__(SCAN_T) kFxScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nPl][N / SCAN_T][NFX] */) { // grid.y = plane
+    __shared__ ScanLds<NFX> L;
+    __shared__ SlotCodes C;
     C.load(B);
-    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
     uint64_t v[NFX];
-    if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v, C.c, C.lo, C.lo + CHUNK + 2 * SCAN_HALO)) return; // (uniform over the chunk: a chunk belongs to one piece)
-    chunkTotals<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * B.nChunks + blockIdx.x) * NFX);
+    if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO)) return; // (uniform over the block: it belongs to one piece)
+    blockTotals<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * (B.N / SCAN_T) + blockIdx.x) * NFX);
 }
-__global__ void __launch_bounds__(1024) kFxScanApply(const DevTables *T, BatchView B, const uint64_t *tot) { // grid.y = plane
-    __shared__ ScanLds<NFX, 0> L;
-    __shared__ ChunkCodes C;
+__global__ void __launch_bounds__(SCAN_T) kFxScanApply(const DevTables *T, BatchView B, const uint64_t *tot) { // grid.y = plane
+    __shared__ ScanLds<NFX> L;
+    __shared__ SlotCodes C;
     C.load(B);
-    const int64_t g = (int64_t)blockIdx.x * CHUNK + threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
     uint64_t v[NFX];
-    if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v, C.c, C.lo, C.lo + CHUNK + 2 * SCAN_HALO)) return;
-    chunkScan<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * B.nChunks + blockIdx.x) * NFX);
+    if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO)) return;
+    blockScan<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * (B.N / SCAN_T) + blockIdx.x) * NFX);
     uint64_t *fx = B.fx + (int64_t)blockIdx.y * B.N * NFX;
 #pragma unroll
     for (int f = 0; f < NFX; f++) fx[fidx(g, f, NFX)] = v[f];
 }
-// exclusive scan of the chunk totals inside each piece (one workgroup per piece and plane, one thread per field; the first nSum
+// exclusive scan of the block totals inside each piece (one workgroup per piece and plane, one thread per field; the first nSum
 // fields are sums, the rest maxima)
 __global__ void kChunkOffsets(uint64_t *tot, BatchView B, int nf, int nSum) {
     const int p = blockIdx.x, f = threadIdx.x;
     if (f >= nf) return;
-    tot += (int64_t)blockIdx.y * B.nChunks * nf;
+    tot += (int64_t)blockIdx.y * (B.N / SCAN_T) * nf;
     uint64_t acc = 0;
-    for (int64_t ch = B.off[p] / CHUNK; ch < B.off[p + 1] / CHUNK; ch++) {
+    for (int64_t ch = B.off[p] / SCAN_T; ch < B.off[p + 1] / SCAN_T; ch++) {
         const uint64_t v = tot[ch * nf + f];
         tot[ch * nf + f] = acc;
         acc = f < nSum ? acc + v : (acc > v ? acc : v);
@@ -602,7 +588,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.sig, double, Z.N * NSIG);
     DA(V.gate, uint64_t, Z.N);
     DA(V.site, int32_t, Z.N * NSITE);
-    DA(V.chunkTot, uint64_t, (int64_t)L.nChunks * NFX);
+    DA(V.chunkTot, uint64_t, Z.N / SCAN_T * NFX);
     DA(V.bp, uint16_t, Z.N * SP);
     DA(V.bpChain, uint8_t, Z.N * 8);
     if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
@@ -665,9 +651,10 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kEncode, dim3(gridN), dim3(256), 0, st, V);
     int rc;
     // site counts and stop positions: terms and prefix scans fused (the prefix arrays are written once, never read back here)
-    hipLaunchKernelGGL(kSiteScanTotals, dim3(V.nChunks), dim3(1024), 0, st, d->dT, V, V.chunkTot);
+    const unsigned nScan = (unsigned)(V.N / SCAN_T);
+    hipLaunchKernelGGL(kSiteScanTotals, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1), dim3(32), 0, st, V.chunkTot, V, NSF, NCNT);
-    hipLaunchKernelGGL(kSiteScanApply, dim3(V.nChunks), dim3(1024), 0, st, d->dT, V, V.chunkTot);
+    hipLaunchKernelGGL(kSiteScanApply, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     if (!b->listsReady) hipLaunchKernelGGL(kListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
     // GC classes, planes and list sizes are properties of the batch's sequences: settled by its first decode (with one host
     // round trip); a batch decoded again re-uses them and never waits for the host
@@ -727,7 +714,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     }
     if (V.nPl > b->chunkTotPlanes) { // (one set of chunk totals per plane of the class-dependent arrays)
         uint64_t *nt = nullptr;
-        if (devMalloc(d, (void **)&nt, sizeof(uint64_t) * (size_t)V.nPl * V.nChunks * NFX) != hipSuccess) {
+        if (devMalloc(d, (void **)&nt, sizeof(uint64_t) * (size_t)V.nPl * (V.N / SCAN_T) * NFX) != hipSuccess) {
             (void)hipGetLastError();
             setLastError("augx_batch_decode: out of device memory for the scan totals");
             return AUGX_E_NOMEM;
@@ -736,9 +723,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         b->V.chunkTot = nt;
         b->chunkTotPlanes = V.nPl;
     }
-    hipLaunchKernelGGL(kFxScanTotals, dim3(V.nChunks, V.nPl), dim3(1024), 0, st, d->dT, V, V.chunkTot);
+    hipLaunchKernelGGL(kFxScanTotals, dim3(nScan, V.nPl), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kChunkOffsets, dim3(n, V.nPl), dim3(32), 0, st, V.chunkTot, V, NFX, NFX);
-    hipLaunchKernelGGL(kFxScanApply, dim3(V.nChunks, V.nPl), dim3(1024), 0, st, d->dT, V, V.chunkTot);
+    hipLaunchKernelGGL(kFxScanApply, dim3(nScan, V.nPl), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.listCap + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);

@@ -156,9 +156,20 @@ inline SegPlan planSegments(const BatchLayout &L, const augx_tables &t, int slot
         segTiles = best;
     }
     if (segTiles > 0 && segTiles < minSeg) segTiles = minSeg;
+    std::vector<int> kOf(n, 1);
+    if (segTiles > 0) {
+        int64_t nSeg = 0;
+        for (int p = 0; p < n; p++) { kOf[p] = countFor(segTiles, p); nSeg += kOf[p]; }
+        // whole rounds: when the segments nearly fill a last round of `slots` workgroups, a few pieces get one segment more
+        // (100 pieces x 5 = 500 segments on 256 compute units -> 12 pieces with 6: two full rounds of shorter segments)
+        int extra = nSeg > slots ? (int)((slots - nSeg % slots) % slots) : 0;
+        if (extra > 0 && extra <= n / 4 + 1)
+            for (int p = 0; p < n && extra > 0; p++)
+                if (kOf[p] > 1 && tiles[p] / (kOf[p] + 1) >= minSeg) { kOf[p]++; extra--; }
+    }
     P.pieceSeg0.assign((size_t)n + 1, 0);
     for (int p = 0; p < n; p++) {
-        const int kp = segTiles > 0 ? countFor(segTiles, p) : 1;
+        const int kp = kOf[p];
         P.pieceSeg0[p] = (int32_t)P.segs.size();
         for (int k = 0; k < kp; k++) {
             SegDesc d;
