@@ -281,17 +281,28 @@ __global__ void __launch_bounds__(SCAN_T) kFxScanApply(const DevTables *T, Batch
 #pragma unroll
     for (int f = 0; f < NFX; f++) fx[fidx(g, f, NFX)] = v[f];
 }
-// exclusive scan of the block totals inside each piece (one workgroup per piece and plane, one thread per field; the first nSum
-// fields are sums, the rest maxima)
-__global__ void kChunkOffsets(uint64_t *tot, BatchView B, int nf, int nSum) {
-    const int p = blockIdx.x, f = threadIdx.x;
-    if (f >= nf) return;
+// exclusive scan of the block totals inside each piece: one wavefront per (piece, plane, field), 64 blocks per step (the first
+// nSum fields are sums, the rest maxima)
+__global__ void __launch_bounds__(64) kChunkOffsets(uint64_t *tot, BatchView B, int nf, int nSum) {
+    const int p = blockIdx.x, f = blockIdx.z, lane = threadIdx.x;
     tot += (int64_t)blockIdx.y * (B.N / SCAN_T) * nf;
+    const bool sum = f < nSum;
     uint64_t acc = 0;
-    for (int64_t ch = B.off[p] / SCAN_T; ch < B.off[p + 1] / SCAN_T; ch++) {
-        const uint64_t v = tot[ch * nf + f];
-        tot[ch * nf + f] = acc;
-        acc = f < nSum ? acc + v : (acc > v ? acc : v);
+    const int64_t c1 = B.off[p + 1] / SCAN_T;
+    for (int64_t c0 = B.off[p] / SCAN_T; c0 < c1; c0 += 64) {
+        const int64_t ch = c0 + lane;
+        const uint64_t v = ch < c1 ? tot[ch * nf + f] : 0;
+        uint64_t x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = (uint64_t)__shfl_up((unsigned long long)x, o, 64);
+            if (lane >= o) x = sum ? x + y : (x > y ? x : y);
+        }
+        // exclusive value of the lane = what came before the 64 blocks combined with the inclusive value of the lane before
+        const uint64_t prev = (uint64_t)__shfl_up((unsigned long long)x, 1, 64);
+        const uint64_t ex = lane == 0 ? acc : (sum ? acc + prev : (acc > prev ? acc : prev));
+        if (ch < c1) tot[ch * nf + f] = ex;
+        const uint64_t last = (uint64_t)__shfl((unsigned long long)x, 63, 64);
+        acc = sum ? acc + last : (acc > last ? acc : last);
     }
 }
 
@@ -653,7 +664,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     // site counts and stop positions: terms and prefix scans fused (the prefix arrays are written once, never read back here)
     const unsigned nScan = (unsigned)(V.N / SCAN_T);
     hipLaunchKernelGGL(kSiteScanTotals, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
-    hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1), dim3(32), 0, st, V.chunkTot, V, NSF, NCNT);
+    hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1, NSF), dim3(64), 0, st, V.chunkTot, V, NSF, NCNT);
     hipLaunchKernelGGL(kSiteScanApply, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     if (!b->listsReady) hipLaunchKernelGGL(kListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
     // GC classes, planes and list sizes are properties of the batch's sequences: settled by its first decode (with one host
@@ -724,7 +735,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         b->chunkTotPlanes = V.nPl;
     }
     hipLaunchKernelGGL(kFxScanTotals, dim3(nScan, V.nPl), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
-    hipLaunchKernelGGL(kChunkOffsets, dim3(n, V.nPl), dim3(32), 0, st, V.chunkTot, V, NFX, NFX);
+    hipLaunchKernelGGL(kChunkOffsets, dim3(n, V.nPl, NFX), dim3(64), 0, st, V.chunkTot, V, NFX, NFX);
     hipLaunchKernelGGL(kFxScanApply, dim3(nScan, V.nPl), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.listCap + 255) / 256), 4), dim3(256), 0, st, d->dT, V);

@@ -571,8 +571,8 @@ struct CandLds {
     uint32_t cntItems[NWAVES][MAXNB], cntNonRT[NWAVES][MAXNB]; // per block: candidates (then: first candidate), candidates but RTERMINAL
     unsigned long long baseW[NWAVES][2];                 // first pair / first candidate of the tile in the batch's buffers
     uint8_t codes[NWAVES * WAVE + 2 * WAVE];             // the bases of the workgroup's tiles and 64 to either side (Piece::lcode)
-    uint32_t slowIt[NWAVES][2 * WAVE];                   // candidates of the current round that need the general formula (index in the round)
-    int slowN[NWAVES];
+    uint16_t queue[NWAVES][2][2 * WAVE];                 // candidates of the current round waiting to be evaluated with their kind: [0] exon
+                                                         // states, [1] those that need the general formula (index in the round)
 };
 
 // read-only view of one piece for the candidate kernel (everything comes from HBM / L2)
@@ -729,7 +729,9 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
 // FASTONLY: a candidate that needs the general emission formula (exNotEndPart: motif sums, short-exon cases -- 2 % of the
 // candidates, thousands of cycles each) is not evaluated but reported in needSlow: the caller evaluates such candidates
 // together, a wavefront full at a time, instead of stalling 63 lanes of every chunk for the one lane that needs it
-template <bool MULTI, bool FASTONLY = false>
+// ONLY: 0 every kind, 1 short introns (lessD) only, 2 exon states only -- the caller has sorted the candidates by kind, the other
+// kind's code is not even compiled into that call
+template <bool MULTI, bool FASTONLY = false, int ONLY = 0>
 AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int idx, double &te, int &key, uint32_t &src, bool &needSlow) {
     needSlow = false;
     const DevTables &T = X.T;
@@ -741,7 +743,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     // (a piece rarely has more than MAXPL_LDS classes: those planes read the model's transition table)
     auto trOf = [&](int ai) -> double { return pl < MAXPL_LDS ? VC.tr[pl][ai] : lnT(T, B.planeCls[X.p * MAXPL + pl], VC.anc[ai], s); };
     te = AUGX_NINF; key = 0; src = srcCol0(0, 0);
-    if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {
+    if (ONLY != 2 && (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD)) {
         // written without early exits so that the loads of one candidate are all in flight together: the list entry
         // first, then the four sequence bytes, the content prefix and the length term
         const bool fwd = kind == AUGX_K_LESSD;
@@ -792,6 +794,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         }
         return;
     }
+    if (ONLY == 1) return;
     if (D.listSel >= 4) { // predecessor is the igenic state
         const int a = VC.anc[0];
         int bs;
@@ -1090,82 +1093,106 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
         // (the scan rows are free by now: row 0 takes the prefix, padded, for the candidates' search of their pair)
         FOR_WLANES(t, w) { const int l = t & 63; L.scan[w][0][l] = l < nPr ? TX(ibase) : 0x7fffffff; }
         WAVE_SYNC();
-        int nSlow = 0; // (uniform) queued candidates of this round
-        auto evalSlow = [&](int cnt) { // the first cnt queued candidates, one per lane; the rest moves to the front
+        // A chunk of 64 consecutive candidates mixes kinds: short-intron candidates (87 %, a short code path with one 16-byte
+        // load) and, in small clusters at the end of every block, exon candidates (long paths with a dozen dependent loads), 2 %
+        // of which need the general emission formula (thousands of cycles).  Evaluating a mixed chunk in place runs every path
+        // with a few live lanes each.  So: short introns are evaluated in place, exon candidates queue up and are evaluated a
+        // wavefront at a time, and from there the few that need the general formula queue up once more.
+        int nQ[2] = {0, 0};               // (uniform) queued candidates of this round
+        const bool canQueue = totalItems < 65536;
+        // candidate `it` of the round by the lane of thread t; mode: 0 everything, 1 short introns only, 2 exon states (fast
+        // formulas) only.  Returns true if the candidate needs the general formula (mode 2) and was not stored
+        auto evalStore = [&](auto modeC, int t, int it, int q, int first) -> bool {
+            constexpr int MODE = decltype(modeC)::value;
+            const int dj = L.pairJ[w][q], s2 = L.pairS[w][q];
+            double te; int key; uint32_t src;
+            bool needSlow;
+            varEvalItem<MULTI, MODE == 2, MODE>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - first, te, key, src, needSlow);
+            if (needSlow) return true;
+            if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
+            else if (key - KEY_BIAS < TX(mnEop)) TX(mnEop) = key - KEY_BIAS;
+            Item I;
+            I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+            B.items[itemBase + itemsDone + it] = I;
+            return false;
+        };
+        auto pairOf = [&](int it, int &first) -> int { // the pair of candidate `it`: the number of pairs that end at or before it
+            int pos = 0;
+#pragma unroll
+            for (int step = WAVE / 2; step >= 1; step >>= 1)
+                if (L.scan[w][0][pos + step - 1] <= it) pos += step;
+            first = pos > 0 ? L.scan[w][0][pos - 1] : 0;
+            return pos;
+        };
+        auto push = [&](int qi, int *flag, int *itv) { // lanes with flag: their candidate joins queue qi, in lane order
+            TV(int, inc);
+            FOR_WLANES(t, w) { TX(inc) = flag[TI]; }
+            waveInclScan(inc, w);
+            const int nNew = waveRead(inc, w, WAVE - 1);
+            if (nNew > 0) {
+                FOR_WLANES(t, w) { if (flag[TI]) L.queue[w][qi][nQ[qi] + TX(inc) - 1] = (uint16_t)itv[TI]; }
+                nQ[qi] += nNew;
+                WAVE_SYNC();
+            }
+        };
+        auto drop = [&](int qi, int cnt) { // the first cnt entries of queue qi are done: the rest moves to the front
+            TV(int, mv);
+            FOR_WLANES(t, w) { const int l = t & 63; TX(mv) = cnt + l < nQ[qi] ? (int)L.queue[w][qi][cnt + l] : -1; }
+            WAVE_SYNC();
+            FOR_WLANES(t, w) { const int l = t & 63; if (TX(mv) >= 0) L.queue[w][qi][l] = (uint16_t)TX(mv); }
+            WAVE_SYNC();
+            nQ[qi] -= cnt;
+        };
+        auto flushSlow = [&](int cnt) {
             FOR_WLANES(t, w) {
                 const int l = t & 63;
                 if (l < cnt) {
-                    const int it = (int)L.slowIt[w][l];
-                    int pos = 0;
-#pragma unroll
-                    for (int step = WAVE / 2; step >= 1; step >>= 1)
-                        if (L.scan[w][0][pos + step - 1] <= it) pos += step;
-                    const int first = pos > 0 ? L.scan[w][0][pos - 1] : 0;
-                    const int dj = L.pairJ[w][pos], s2 = L.pairS[w][pos];
-                    double te; int key; uint32_t src;
-                    bool dummy;
-                    varEvalItem<MULTI, false>(X, s2, j0 + dj, L.desc[w][r0 + pos < DCAP ? r0 + pos : pos], it - first, te, key, src, dummy);
-                    if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
-                    else if (key - KEY_BIAS < TX(mnEop)) TX(mnEop) = key - KEY_BIAS;
-                    Item I;
-                    I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
-                    B.items[itemBase + itemsDone + it] = I;
+                    const int it = (int)L.queue[w][1][l];
+                    int first;
+                    const int q = pairOf(it, first);
+                    evalStore(std::integral_constant<int, 0>{}, t, it, q, first);
                 }
             }
             WAVE_SYNC();
-            TV(int, mv);
-            FOR_WLANES(t, w) { const int l = t & 63; TX(mv) = cnt + l < nSlow ? (int)L.slowIt[w][cnt + l] : -1; }
+            drop(1, cnt);
+        };
+        auto flushExon = [&](int cnt) {
+            TV(int, slow); TV(int, itv);
+            FOR_WLANES(t, w) {
+                const int l = t & 63;
+                TX(slow) = 0; TX(itv) = 0;
+                if (l < cnt) {
+                    const int it = (int)L.queue[w][0][l];
+                    int first;
+                    const int q = pairOf(it, first);
+                    TX(itv) = it;
+                    TX(slow) = evalStore(std::integral_constant<int, 2>{}, t, it, q, first);
+                }
+            }
             WAVE_SYNC();
-            FOR_WLANES(t, w) { const int l = t & 63; if (TX(mv) >= 0) L.slowIt[w][l] = (uint32_t)TX(mv); }
-            WAVE_SYNC();
-            nSlow -= cnt;
+            drop(0, cnt);
+            push(1, slow, itv);
+            if (nQ[1] >= WAVE) flushSlow(WAVE);
         };
         for (int base = 0; base < totalItems; base += WAVE) {
-            TV(int, myPair);
-            TV(int, myFirst);
-            FOR_WLANES(t, w) { // pair of candidate `base + lane`: the number of pairs that end at or before it (binary search)
-                const int it = base + (t & 63);
-                int pos = 0;
-#pragma unroll
-                for (int step = WAVE / 2; step >= 1; step >>= 1)
-                    if (L.scan[w][0][pos + step - 1] <= it) pos += step;
-                TX(myPair) = pos;
-                TX(myFirst) = pos > 0 ? L.scan[w][0][pos - 1] : 0;
-            }
-            TV(int, slow);
+            TV(int, exon); TV(int, itv);
             FOR_WLANES(t, w) { // one candidate per lane
-                const int l = t & 63;
-                const int it = base + l;
-                TX(slow) = 0;
+                const int it = base + (t & 63);
+                TX(exon) = 0; TX(itv) = it;
                 if (it < totalItems) {
-                    const int q = TX(myPair);
-                    const int dj = L.pairJ[w][q], s2 = L.pairS[w][q];
-                    double te; int key; uint32_t src;
-                    bool needSlow;
-                    varEvalItem<MULTI, true>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - TX(myFirst), te, key, src, needSlow);
-                    TX(slow) = needSlow;
-                    if (!needSlow) {
-                        if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
-                        else if (key - KEY_BIAS < TX(mnEop)) TX(mnEop) = key - KEY_BIAS;
-                        Item I;
-                        I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
-                        B.items[itemBase + itemsDone + it] = I;
-                    }
+                    int first;
+                    const int q = pairOf(it, first);
+                    const int kind = X.vc[L.pairS[w][q]].kind;
+                    if (!canQueue) evalStore(std::integral_constant<int, 0>{}, t, it, q, first);
+                    else if (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) evalStore(std::integral_constant<int, 1>{}, t, it, q, first);
+                    else TX(exon) = 1;
                 }
             }
-            // the candidates that need the general formula queue up; a wavefront full of them is evaluated at once
-            TV(int, sInc);
-            FOR_WLANES(t, w) { TX(sInc) = TX(slow); }
-            waveInclScan(sInc, w);
-            const int nNew = waveRead(sInc, w, WAVE - 1);
-            if (nNew > 0) {
-                FOR_WLANES(t, w) { if (TX(slow)) L.slowIt[w][nSlow + TX(sInc) - 1] = (uint32_t)(base + (t & 63)); }
-                nSlow += nNew;
-                WAVE_SYNC();
-                if (nSlow >= WAVE) { evalSlow(WAVE); }
-            }
+            push(0, exon, itv);
+            if (nQ[0] >= WAVE) flushExon(WAVE);
         }
-        if (nSlow > 0) evalSlow(nSlow);
+        if (nQ[0] > 0) flushExon(nQ[0]);
+        if (nQ[1] > 0) flushSlow(nQ[1]);
         WAVE_SYNC();
         itemsDone += (uint32_t)totalItems;
     }
