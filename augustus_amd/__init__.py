@@ -75,6 +75,8 @@ def lib():
         L.augx_batch_cells.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.augx_batch_kernel_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
                                            ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.augx_batch_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.augx_batch_forward_cells.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         L.augx_batch_destroy.argtypes = [ctypes.c_void_p]
         L.augx_path_free.argtypes = [ctypes.c_void_p]
         _lib = L
@@ -175,6 +177,19 @@ class Batch:
         V = np.empty((self.lens[piece], S), dtype=np.float64)
         _check(lib().augx_batch_cells(self.decoder._h, self._h, piece, V.ctypes.data_as(ctypes.c_void_p)))
         return V
+
+    def forward(self):
+        """run the forward algorithm on the decoded batch (``augx_batch_forward``)"""
+        _check(lib().augx_batch_forward(self.decoder._h, self._h))
+
+    def forward_cells(self, piece):
+        """(ln F matrix [len, S], ln P(sequence)) of one piece"""
+        import numpy as np
+        S = self.decoder.model.n_states
+        F = np.empty((self.lens[piece], S), dtype=np.float64)
+        lnp = ctypes.c_double()
+        _check(lib().augx_batch_forward_cells(self.decoder._h, self._h, piece, F.ctypes.data_as(ctypes.c_void_p), ctypes.byref(lnp)))
+        return F, lnp.value
 
     def close(self):
         if self._h:

@@ -329,6 +329,11 @@ __global__ void __launch_bounds__(64) kSegFinalize(BatchView B) {
     if (p < B.nPieces) segFinalizePiece(B, p);
 }
 __global__ void __launch_bounds__(64) kBacktrace(const DevTables *T, BatchView B) { backtracePiece(*T, B, blockIdx.x); }
+// forward algorithm (posterior sampling only): one workgroup per piece, after the Viterbi decode (kernels.h: forwardPiece)
+template <int BLK> __global__ void __launch_bounds__(NT) kForward(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+    __shared__ FwdLds lds;
+    forwardPiece<BLK>(*T, *B, lds, blockIdx.x);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // host objects
@@ -935,6 +940,39 @@ int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out) {
                 for (int s2 = 0; s2 < S; s2++) out[(size_t)q * S + s2] += brkOff[r];
         }
     }
+    return AUGX_OK;
+}
+
+int augx_batch_forward(augx_decoder *d, augx_batch *b) {
+    if (!d || !b || !b->decoded) { setLastError("augx_batch_forward: the batch has not been decoded"); return AUGX_E_ARG; }
+    HIP_TRY(hipSetDevice(d->device));
+    BatchView &W = b->V;
+    if (!W.fwd) {
+        void *p = nullptr, *q = nullptr;
+        if (devMalloc(d, &p, sizeof(double) * (size_t)W.N * d->hostT.S) != hipSuccess || devMalloc(d, &q, sizeof(double) * (size_t)W.nPieces) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p) devFree(d, p);
+            setLastError("augx_batch_forward: out of device memory for the forward matrix; decode fewer bases per batch");
+            return AUGX_E_NOMEM;
+        }
+        b->bufs.push_back(p); b->bufs.push_back(q);
+        W.fwd = (double *)p; W.lnFwd = (double *)q;
+        HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, d->stream));
+    }
+    if (d->blk == 8) hipLaunchKernelGGL(kForward<8>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+    else if (d->blk == 4) hipLaunchKernelGGL(kForward<4>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+    else hipLaunchKernelGGL(kForward<2>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+    HIP_TRY(hipGetLastError());
+    return AUGX_OK;
+}
+
+int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *out, double *ln_p) {
+    if (!d || !b || piece < 0 || piece >= b->V.nPieces || !b->V.fwd) { setLastError("augx_batch_forward_cells: run augx_batch_forward first"); return AUGX_E_ARG; }
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    const int S = d->hostT.S;
+    if (out) HIP_TRY(hipMemcpy(out, b->V.fwd + (b->L.off[piece] + 1) * S, sizeof(double) * (size_t)b->L.len[piece] * S, hipMemcpyDeviceToHost));
+    if (ln_p) HIP_TRY(hipMemcpy(ln_p, b->V.lnFwd + piece, sizeof(double), hipMemcpyDeviceToHost));
     return AUGX_OK;
 }
 

@@ -130,6 +130,8 @@ struct BatchView {
     uint8_t *bpChain;          // [N][8] the back pointers of the (at most 8) single-base chain states once more, one byte each, in
                                // the order of their state index: the back-trace walks their long runs 256 bases per step through it
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
+    double *fwd;               // [N][S] dense ln of the forward variables (only when posterior sampling is asked for) or NULL
+    double *lnFwd;             // [nPieces] ln P(sequence) = the sum over all paths
     uint64_t *prof;            // [nPieces][4][8] cycle counters of the trellis wavefronts (AUGX_PROF=1) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD

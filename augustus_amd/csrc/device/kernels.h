@@ -2320,6 +2320,206 @@ AUGX_HD void tileCrossOne(const BatchView &B, int64_t gt) {
 }
 
 // =================================================================================================
+// Forward algorithm (reference NAMGene::viterbiAndForward with needForwardTable, src/namgene.cc:168-365; the per-state sums
+// `fwdsum` of src/igenicmodel.cc:247-287, src/intronmodel.cc:585-629,757-858, src/exonmodel.cc:1059-1145): the same recurrences
+// as the trellis with every maximum replaced by a sum -- in ln space, ln(sum_i exp(x_i)) around the largest term.  It runs only
+// when posterior sampling is asked for, after the Viterbi decode, and reuses the candidates of K2a (their te is V-independent).
+// Kept simple: one workgroup per piece, one block of BLK bases after the other with workgroup barriers between the stages
+//   A fixed-lag states   B geometric chain   C candidates of the variable-length states but RTERMINAL   D igenic chain
+//   E RTERMINAL candidates (they may start at an igenic cell of their own block)
+// The dense ln F matrix goes to HBM (the host's sampler walks it); the last 64 columns also live in an LDS ring.
+// Sums are not exact (exp / log round): the result agrees with the reference's LLDouble sums to ~1e-12 relative.
+// =================================================================================================
+AUGX_HD double lse2(double a, double b) { // ln(e^a + e^b)
+    if (!(a > AUGX_NINF)) return b;
+    if (!(b > AUGX_NINF)) return a;
+    return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
+}
+#ifdef AUGX_EMU
+inline void ldsAddD(double *p, double v) { *p += v; }
+#else
+__device__ inline void ldsAddD(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_add_f64
+#endif
+struct FwdLds {
+    double ring[WAVE][SP];   // ln F of the last 64 columns, [j & 63][state]
+    double cmax[8][SP];      // variable-length cells of the current block: largest candidate ...
+    double csum[8][SP];      // ... and the sum of exp(candidate - largest)
+};
+template <int BLK>
+AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, int p) {
+    const int n = B.len[p], S = T.S, c0 = B.cls[p];
+    const int64_t o = B.off[p];
+    double *F = B.fwd + (o + 1) * S; // F[q * S + s]
+    if (c0 < 0) { FOR_THREADS(t) { if (t == 0) B.lnFwd[p] = AUGX_NINF; } return; }
+    const bool multi = B.nPlanes[p] > 1;
+    const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
+    auto clsAt = [&](int j) { return multi ? B.planeCls[p * MAXPL + B.gcPlane[o + 1 + j]] : c0; };
+    // value of state a at base q: from the ring while no base of the block being computed (first base jb) has taken its column,
+    // from HBM before
+    auto at = [&](int q, int a, int jb) -> double {
+        if (q < 0) return AUGX_NINF;
+        return jb + BLK - 1 - q < WAVE ? L.ring[q & 63][a] : ldCoherent(&F[(int64_t)q * S + a]);
+    };
+    FOR_THREADS(t) {
+        for (int i = t; i < WAVE * SP; i += NT) L.ring[i / SP][i % SP] = AUGX_NINF;
+        for (int i = t; i < n * S; i += NT) F[i] = AUGX_NINF; // (absent cells stay -inf)
+    }
+    BLOCK_GLOBAL_SYNC();
+    FOR_THREADS(t) { // column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
+        if (t < S) {
+            const double v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
+            L.ring[0][t] = v;
+            F[t] = v;
+        }
+    }
+    BLOCK_GLOBAL_SYNC();
+    // the states by group (uniform)
+    int fixS[24], nFix = 0, geoS[8], nGeo = 0, igS = -1;
+    for (int s2 = 0; s2 < S; s2++) {
+        if (!T.reachable[s2]) continue;
+        const int k = T.kind[s2];
+        if (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS || k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS || k == AUGX_K_EQUALD || k == AUGX_K_REQUALD) { if (nFix < 24) fixS[nFix++] = s2; }
+        else if (k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC) { if (nGeo < 8) geoS[nGeo++] = s2; }
+        else if (k == AUGX_K_IGENIC) igS = s2;
+    }
+    const int nBlocks = (n + BLK - 1) / BLK;
+    for (int b = 0; b < nBlocks; b++) {
+        const int jb = b * BLK;
+        const int64_t gb = o / BLK + b;
+        // ---- A: fixed-lag states; accumulators of the variable-length cells
+        FOR_THREADS(t) {
+            if (t < BLK * SP) { L.cmax[t / SP][t % SP] = AUGX_NINF; L.csum[t / SP][t % SP] = 0.0; }
+            if (t < nFix * BLK) {
+                const int s2 = fixS[t / BLK], j = jb + t % BLK, k = T.kind[s2];
+                if (j >= 1 && j < n) {
+                    const int lag = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
+                    const int sg = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
+                    const double emi = B.sig[(o + 1 + j) * NSIG + sg];
+                    double f = AUGX_NINF;
+                    if (j - lag >= 0 && emi > AUGX_NINF) {
+                        const int cc = clsAt(j);
+                        for (int ai = 0; ai < T.n_anc[s2]; ai++) {
+                            const int a = T.anc[s2][ai];
+                            const double pv = at(j - lag, a, jb);
+                            if (pv > AUGX_NINF) f = lse2(f, pv + (lnT(T, cc, a, s2) + emi));
+                        }
+                    }
+                    L.ring[j & 63][s2] = f;
+                    if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
+                }
+            }
+        }
+        BLOCK_SYNC();
+        // ---- B: geometric intron states, base after base (fed by equalD of the base before and by themselves)
+        FOR_THREADS(t) {
+            if (t < nGeo) {
+                const int s2 = geoS[t];
+                for (int dj = 0; dj < BLK; dj++) {
+                    const int j = jb + dj;
+                    if (j < 1 || j >= n) continue;
+                    const double emi = B.sig[(o + 1 + j) * NSIG + SIG_EIN];
+                    const int cc = clsAt(j);
+                    double f = AUGX_NINF;
+                    for (int ai = 0; ai < T.n_anc[s2]; ai++) {
+                        const int a = T.anc[s2][ai];
+                        const double pv = L.ring[(j - 1) & 63][a];
+                        if (pv > AUGX_NINF) f = lse2(f, pv + (lnT(T, cc, a, s2) + emi));
+                    }
+                    L.ring[j & 63][s2] = f;
+                    if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
+                }
+            }
+        }
+        BLOCK_SYNC();
+        // ---- C / E: candidates of the variable-length states (C: all but RTERMINAL, E: RTERMINAL), three steps each: the largest
+        //      candidate of every cell, the sum around it, the cell
+        const uint64_t i0 = B.blkOff[gb * 2 + 1];
+        const uint32_t cntAll = B.blkCnt[gb * 2 + 1], cntNonRT = B.blkSplit[gb * 3 + 2];
+        auto candValue = [&](const Item &I, int &dj, int &s2) -> double {
+            dj = (int)(I.kp >> (KEY_BITS + 6)); s2 = (int)((I.kp >> KEY_BITS) & 63);
+            if (!(I.te > AUGX_NINF)) return AUGX_NINF;
+            const uint32_t tag = I.src >> 30;
+            const int ai = (int)((I.src >> 28) & 3), eop = (int)(I.kp & KEY_MASK) - KEY_BIAS, j = jb + dj;
+            double pv;
+            if (tag == SRC_COL0) { const int a = (int)(I.src & 0x3Fu); pv = B.initKind[p] == 0 ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF); }
+            else pv = at(eop, tag == SRC_VIG ? igS : T.anc[s2][ai], jb);
+            return pv + I.te;
+        };
+        auto candidates = [&](uint32_t lo, uint32_t hi) {
+            FOR_THREADS(t) {
+                for (uint32_t it = lo + (uint32_t)t; it < hi; it += NT) {
+                    int dj, s2;
+                    const double v = candValue(ldItem(B.items + i0 + it), dj, s2);
+                    if (v > AUGX_NINF) ldsMaxD(&L.cmax[dj][s2], v);
+                }
+            }
+            BLOCK_SYNC();
+            FOR_THREADS(t) {
+                for (uint32_t it = lo + (uint32_t)t; it < hi; it += NT) {
+                    int dj, s2;
+                    const double v = candValue(ldItem(B.items + i0 + it), dj, s2);
+                    if (v > AUGX_NINF) ldsAddD(&L.csum[dj][s2], exp(v - L.cmax[dj][s2]));
+                }
+            }
+            BLOCK_SYNC();
+        };
+        auto cells = [&](bool rt) {
+            FOR_THREADS(t) {
+                if (t < BLK * SP) {
+                    const int dj = t / SP, s2 = t % SP, j = jb + dj;
+                    if (s2 < S && j >= 1 && j < n && T.reachable[s2]) {
+                        const int k = T.kind[s2];
+                        const bool var = (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD;
+                        if (var && (k == AUGX_K_RTERMINAL) == rt) {
+                            const double f = L.csum[dj][s2] > 0.0 ? L.cmax[dj][s2] + log(L.csum[dj][s2]) : AUGX_NINF;
+                            L.ring[j & 63][s2] = f;
+                            if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
+                        }
+                    }
+                }
+            }
+            BLOCK_SYNC();
+        };
+        candidates(0, cntNonRT);
+        cells(false);
+        // ---- D: the intergenic state, base after base (fed by itself and by the exon cells of the base before)
+        FOR_THREADS(t) {
+            if (t == 0 && igS >= 0) {
+                for (int dj = 0; dj < BLK; dj++) {
+                    const int j = jb + dj;
+                    if (j < 1 || j >= n) continue;
+                    const double emi = B.sig[(o + 1 + j) * NSIG + SIG_EIG];
+                    const int cc = clsAt(j);
+                    double f = AUGX_NINF;
+                    for (int ai = 0; ai < T.n_anc[igS]; ai++) {
+                        const int a = T.anc[igS][ai];
+                        const double pv = L.ring[(j - 1) & 63][a];
+                        if (pv > AUGX_NINF) f = lse2(f, pv + (lnT(T, cc, a, igS) + emi));
+                    }
+                    L.ring[j & 63][igS] = f;
+                    if (f > AUGX_NINF) F[(int64_t)j * S + igS] = f;
+                }
+            }
+        }
+        BLOCK_SYNC();
+        candidates(cntNonRT, cntAll);
+        cells(true);
+        BLOCK_GLOBAL_SYNC(); // the columns of this block are in HBM for the candidates of later blocks
+    }
+    FOR_THREADS(t) { // ln P(sequence) (reference NAMGene::getSampledPath's option list over the last column, src/namgene.cc:385-392)
+        if (t == 0) {
+            double tot = AUGX_NINF;
+            for (int i = 0; i < S; i++) {
+                const double tl = B.termKind[p] == 0 ? T.ln_term[i] : (i == T.synch ? 0.0 : AUGX_NINF);
+                const double v = L.ring[(n - 1) & 63][i] + tl;
+                if (v > AUGX_NINF) tot = lse2(tot, v);
+            }
+            B.lnFwd[p] = tot;
+        }
+    }
+}
+
+// =================================================================================================
 // after the passes of the segment-parallel trellis: the regions of piece p and the constant each one's stored values are off by
 // (SegDesc, BatchView::brkPos / brkOff), the score of the piece in the true frame, the status of its runs
 // =================================================================================================

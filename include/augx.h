@@ -191,6 +191,12 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
 /* test hook: copy the dense ln V[j][s] matrix (len*S doubles, -inf = absent) of piece i to host; only
  * valid on a decoder created with AUGX_DEBUG_CELLS=1 in the environment */
 int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out);
+/* forward algorithm of a decoded batch (reference NAMGene::viterbiAndForward with needForwardTable, src/namgene.cc:168-365,
+ * the per-state `fwdsum`s): the dense ln F matrix stays on the device for the posterior sampling; the second call copies the
+ * len*S matrix of one piece (-inf = absent) and ln P(sequence) to the host (tests; groundwork of --sample > 0, which the
+ * executable still rejects) */
+int augx_batch_forward(augx_decoder *d, augx_batch *b);
+int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *out, double *ln_p);
 void augx_batch_destroy(augx_batch *b);
 
 /* ---- whole-program driver (replaces main(), reference src/augustus.cc:94-248): same argv as `augustus`,

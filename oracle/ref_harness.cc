@@ -15,7 +15,7 @@
  * Interior-cut pieces (init/term = synch state only, src/namgene.cc:594-603) are reproduced by
  * patching NAMGene::initProbs/termProbs, which is why the private members are opened below.
  *
- * usage: ref_harness [--name=value ...] --species=SP [--dumpcells=FILE] [--initkind=0|1] [--termkind=0|1] in.fa
+ * usage: ref_harness [--name=value ...] --species=SP [--dumpcells=FILE] [--dumpforward=FILE] [--initkind=0|1] [--termkind=0|1] in.fa
  * stdout (one block per FASTA record):
  *   SEQ <name> <len>
  *   LNV <%.17g>
@@ -87,17 +87,19 @@ int verbosity = 0;          // augustus.cc:27-28 defines these in the real binar
 bool mea_prediction = false;
 
 int main(int argc, char *argv[]) {
-    std::string dumpfile;
+    std::string dumpfile, fwdfile;
     int initkind = 0, termkind = 0;
     std::vector<char *> args;
     for (int i = 0; i < argc; i++) {
         if (strncmp(argv[i], "--dumpcells=", 12) == 0) dumpfile = argv[i] + 12;
+        else if (strncmp(argv[i], "--dumpforward=", 14) == 0) fwdfile = argv[i] + 14; // (needs --sample > 0: the forward table is only filled then)
         else if (strncmp(argv[i], "--initkind=", 11) == 0) initkind = atoi(argv[i] + 11);
         else if (strncmp(argv[i], "--termkind=", 11) == 0) termkind = atoi(argv[i] + 11);
         else args.push_back(argv[i]);
     }
     int nargs = (int)args.size();
     FILE *dump = dumpfile.empty() ? NULL : fopen(dumpfile.c_str(), "wb");
+    FILE *fdump = fwdfile.empty() ? NULL : fopen(fwdfile.c_str(), "wb");
     try {
         LLDouble::setOutputPrecision(3);
         Properties::init(nargs, args.data());
@@ -177,6 +179,19 @@ int main(int argc, char *argv[]) {
                 for (int j = 0; j < n; j++) gc[j] = namgene.cs.idx[j];
                 fwrite(gc.data(), 4, n, dump);
             }
+            if (fdump) { // ln of the forward variables (reference NAMGene::getForwardVariables, include/namgene.hh:56), same layout
+                const ViterbiMatrixType &v = namgene.getForwardVariables();
+                int32_t hdr[2] = {n, S};
+                fwrite(hdr, 4, 2, fdump);
+                std::vector<double> col(S);
+                for (int j = 0; j < n; j++) {
+                    for (int i = 0; i < S; i++) {
+                        Double val = v[j].get(i);
+                        col[i] = (val > 0) ? val.log() : -std::numeric_limits<double>::infinity();
+                    }
+                    fwrite(col.data(), 8, S, fdump);
+                }
+            }
             delete p;
         }
     } catch (ProjectError &err) {
@@ -184,5 +199,6 @@ int main(int argc, char *argv[]) {
         return 1;
     }
     if (dump) fclose(dump);
+    if (fdump) fclose(fdump);
     return 0;
 }

@@ -7,6 +7,7 @@
 // fallback: libaugx never links it and the product path fails without a HIP device.
 #define AUGX_EMU 1
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 #include "../../augustus_amd/csrc/device/kernels.h"
@@ -35,8 +36,9 @@ extern "C" {
 // decode a batch on the emulator.  Outputs: lnv[n], status[n]; paths as (begin,end,state) triples in 5'->3'
 // order into path_out (capacity path_cap triples per piece, counts in path_n); cells_out (optional) receives
 // the dense ln V matrices piece after piece (len*S doubles each).
+// fwd_out (optional): the dense ln F matrices of the forward algorithm, piece after piece; lnfwd_out[n]: ln P(sequence)
 int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *lnv, int32_t *status, int32_t *path_out,
-               int32_t path_cap, int32_t *path_n, double *cells_out, int32_t *cls_out) {
+               int32_t path_cap, int32_t *path_n, double *cells_out, int32_t *cls_out, double *fwd_out, double *lnfwd_out) {
     int blk = 8;
     try {
         blk = chooseBlockSize(*t);
@@ -239,6 +241,21 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         backtracePiece(T, B, p);
     }
     delete lds;
+    if (fwd_out) { // ---- forward algorithm (posterior sampling), after the Viterbi decode
+        B.fwd = zalloc<double>(Z.N * t->S);
+        std::vector<double> lnF(n);
+        B.lnFwd = lnF.data();
+        FwdLds *fl = new FwdLds();
+        for (int p = 0; p < n; p++) { if (blk == 8) forwardPiece<8>(T, B, *fl, p); else if (blk == 4) forwardPiece<4>(T, B, *fl, p); else forwardPiece<2>(T, B, *fl, p); }
+        delete fl;
+        int64_t w = 0;
+        for (int p = 0; p < n; p++) {
+            memcpy(fwd_out + w, B.fwd + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);
+            w += (int64_t)L.len[p] * t->S;
+            if (lnfwd_out) lnfwd_out[p] = lnF[p];
+        }
+        free(B.fwd);
+    }
     for (int p = 0; p < n; p++) {
         lnv[p] = lnvv[p];
         status[p] = st[p];

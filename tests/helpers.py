@@ -132,6 +132,27 @@ def ref_harness(fasta, species, extra=(), cells_file=None, cfg=None):
     return res, out.stderr
 
 
+def ref_forward(fasta, species, extra=(), cfg=None):
+    """ln of the REAL reference's forward variables (oracle/_ref/ref_harness --sample=100 --dumpforward): one [len, S] array
+    per record, -inf where the cell is absent"""
+    import struct
+    dump = fasta + ".fwd.bin"
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg or config_path())
+    out = subprocess.run([REF_HARNESS, "--species=" + species, "--sample=100"] + list(extra) + ["--dumpforward=" + dump, fasta],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    mats = []
+    with open(dump, "rb") as f:
+        while True:
+            h = f.read(8)
+            if len(h) < 8:
+                break
+            n, S = struct.unpack("ii", h)
+            mats.append(np.frombuffer(f.read(n * S * 8), dtype=np.float64).reshape(n, S))
+    os.remove(dump)
+    return mats
+
+
 # ---------------------------------------------------------------------------------------------------
 # golden vectors (tests/golden/make_golden.py) and the lane-loop emulator of the device kernels
 # ---------------------------------------------------------------------------------------------------
@@ -181,8 +202,9 @@ class _Piece(ctypes.Structure):
 _emu = None
 
 
-def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None):
-    """Run the device kernel bodies on the CPU (tests/emu/emu.cc).  Returns [(status, lnv, path, V, cls)]."""
+def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None, forward=False):
+    """Run the device kernel bodies on the CPU (tests/emu/emu.cc).  Returns [(status, lnv, path, V, cls)]
+    (forward=True: [(status, lnv, path, V, cls, F, lnP)] with the ln forward matrix F and ln P(sequence))."""
     global _emu
     if lib is not None:
         _emu_lib = ctypes.CDLL(lib)
@@ -201,15 +223,20 @@ def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=N
     cls = np.zeros(n, dtype=np.int32)
     tot = sum(len(s) for s in seqs)
     C = np.zeros(tot * S) if cells else None
+    FW = np.zeros(tot * S) if forward else None
+    lnF = np.zeros(n)
     rc = (_emu_lib if lib is not None else _emu).emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
                          po.ctypes.data_as(ctypes.c_void_p), cap, pn.ctypes.data_as(ctypes.c_void_p),
-                         C.ctypes.data_as(ctypes.c_void_p) if cells else None, cls.ctypes.data_as(ctypes.c_void_p))
+                         C.ctypes.data_as(ctypes.c_void_p) if cells else None, cls.ctypes.data_as(ctypes.c_void_p),
+                         FW.ctypes.data_as(ctypes.c_void_p) if forward else None, lnF.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0
     out, w = [], 0
     for i, s in enumerate(seqs):
         V = C[w:w + len(s) * S].reshape(len(s), S) if cells else None
+        Fm = FW[w:w + len(s) * S].reshape(len(s), S) if forward else None
         w += len(s) * S
-        out.append((int(st[i]), float(lnv[i]), [tuple(int(x) for x in po[i, k]) for k in range(pn[i])], V, int(cls[i])))
+        rec = (int(st[i]), float(lnv[i]), [tuple(int(x) for x in po[i, k]) for k in range(pn[i])], V, int(cls[i]))
+        out.append(rec + (Fm, float(lnF[i])) if forward else rec)
     return out
 
 

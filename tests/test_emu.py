@@ -174,3 +174,32 @@ def test_emulated_segment_parallel_trellis(monkeypatch, env):
         assert path == [(b, e, s) for b, e, s, t in path2], len(seq)
         if set(seq) != {"N"}:
             assert np.array_equal(V, V2), len(seq)
+
+
+def _forward_records():
+    byname = dict(golden_inputs())
+    return [(k, byname[k]) for k in ("HS04636", "HS08198", "rand20k_b", "withN", "short7", "short100", "short600", "iupac", "trunc_left",
+                                     "trunc_right", "trunc_both", "revcomp", "softmask_rand")]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("cfg", ["human_nosm", "human", "fly", "arabidopsis"])
+def test_emulated_forward_matches_reference(tmp_path, cfg):
+    """the forward algorithm (groundwork of posterior sampling; device/kernels.h: forwardPiece) against every forward variable
+    of the REAL reference (NAMGene::getForwardVariables): the same cells are alive, ln F within 1e-9 relative (+ the absolute
+    slack of the first bases, see test_oracle.py), on single-class records of three species incl. soft-masked ones"""
+    species, opts = GOLDEN_CFGS[cfg]
+    recs = _forward_records()
+    fa = str(tmp_path / "f.fa")
+    write_fasta(fa, recs)
+    extra = ["--%s=%s" % kv for kv in opts.items() if kv[0] != "sample"]
+    Fref = ref_forward(fa, species, extra)
+    m = ax.Model(config_path(), species, **opts)
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, forward=True)
+    for (name, seq), fr, r in zip(recs, Fref, res):
+        F = r[5]
+        assert np.array_equal(np.isfinite(F), np.isfinite(fr)), name
+        both = np.isfinite(F)
+        assert np.all(np.abs(F[both] - fr[both]) <= 1e-9 * np.abs(fr[both]) + 5e-9), name
+        # ln P(sequence) = the terminal-weighted sum of the last column
+        assert r[6] >= r[1] and r[6] - r[1] < 0.01 * len(seq) + 5

@@ -254,3 +254,27 @@ def test_gpu_segment_parallel_trellis(monkeypatch, env, species):
     for i, (seq, r) in enumerate(zip(seqs, b.paths())):
         rc, lnv, path, _, _ = twin_decode(m.tables_ptr, seq, m.n_states)
         assert r.ln_viterbi == lnv and r.states == path, i
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not present")
+@pytest.mark.parametrize("cfg", ["human_nosm", "fly"])
+def test_gpu_forward_matches_reference(tmp_path, cfg):
+    """the forward algorithm on the device (augx_batch_forward; groundwork of posterior sampling) against every forward variable
+    of the REAL reference, run live: the same cells alive, ln F within 1e-9 relative"""
+    from test_emu import _forward_records
+    species, opts = GOLDEN_CFGS[cfg]
+    recs = _forward_records() + [("rand60k", dict(golden_inputs())["rand60k"])]
+    fa = str(tmp_path / "f.fa")
+    write_fasta(fa, recs)
+    Fref = ref_forward(fa, species, ["--%s=%s" % kv for kv in opts.items() if kv[0] != "sample"])
+    m = ax.Model(config_path(), species, **opts)
+    d = ax.Decoder(m, 0)
+    b = ax.Batch(d, [s for _, s in recs])
+    b.decode()
+    b.forward()
+    for i, ((name, seq), fr, r) in enumerate(zip(recs, Fref, b.paths())):
+        F, lnp = b.forward_cells(i)
+        assert np.array_equal(np.isfinite(F), np.isfinite(fr)), name
+        both = np.isfinite(F)
+        assert np.all(np.abs(F[both] - fr[both]) <= 1e-9 * np.abs(fr[both]) + 5e-9), name
+        assert lnp >= r.ln_viterbi
