@@ -1590,11 +1590,11 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     constexpr int SPR = WAVE / BLK; // state slots per round of 64 lanes: lane = (slot, base of the block)
     constexpr bool CMP = MODE == 1 || MODE == 2;
     int segIdx = sg, tStart = 0, tEnd = 0, ckSrc = -1; // ckSrc: ring checkpoint to start from ([seg] * 2 + slot), -1: none
-    if (MODE >= 2) { // the first fix-up of the piece that gave up beyond everything a continuation has redone so far
+    if (MODE >= 2) { // a fix-up of the piece that gave up and has not been continued: pass 3 takes the LAST one (a continuation
+                     // reads only what lies behind it, so the ones further on must be settled first), the final pass the first
         segIdx = -1;
-        const int cov = B.pieceCovered[sg];
         for (int q = B.pieceSeg0[sg] + 1; q < B.pieceSeg0[sg + 1]; q++)
-            if (B.segStop[q] <= -2 && -2 - B.segStop[q] > cov && B.segStop2[q] < 0) { segIdx = q; break; }
+            if (B.segStop[q] <= -2 && B.segStop2[q] < 0) { segIdx = q; if (MODE == 3) break; }
         if (segIdx < 0) return;
         tStart = -2 - B.segStop[segIdx] + 1;
         ckSrc = segIdx * 2 + 1;
@@ -2252,7 +2252,15 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             // (Then the ring at the end of this tile and every retired value a later cell can read are old + D, by induction
             // over the columns from the fully verified column at the end of tile - 2)
             const int win = B.segCheckTiles > 0x10000 ? B.segCheckTiles : 3; // (tests force the give-up path with a huge check length)
-            if (lb < needTile && (tile - 1) - lb >= win) break;
+            bool atSeam = false;
+            if (MODE == 2) { // a continuation crosses regions other runs have rewritten: the stored values change frame where such a
+                             // run stopped.  It must not stop on top of such a seam -- its offset would belong to one side only
+                for (int q = B.pieceSeg0[p] + 1; q < B.pieceSeg0[p + 1]; q++) {
+                    const int e = q == segIdx ? -100 : B.segStop[q] >= -1 ? B.segStop[q] : B.segStop2[q];
+                    if (e == tile || e == tile - 1) atSeam = true;
+                }
+            }
+            if (lb < needTile && (tile - 1) - lb >= win && !atSeam) break;
             if (MODE == 1 && tile + 1 == tEnd) gaveUp = true;
         }
     }
@@ -2532,24 +2540,21 @@ AUGX_KFN void segFinalizePiece(const BatchView &B, int p) {
     // across later segments, whose own records inside the span it redid no longer exist.  A run that reached the end of the
     // piece leaves one last region in the frame it started in.
     double off = 0.0;
-    int covered = -1, r = 0;
-    bool done = false, abortAny = false;
+    int covered = -1, r = 0; // covered: last tile a continuation has redone so far
+    bool abortAny = false;
     const int lastTile = (n + WAVE - 1) / WAVE - 1;
     for (int k = 0; k < K; k++)
         if (B.segStatus[s0 + k]) abortAny = true;
-    for (int k = 1; k < K && !done; k++) {
+    for (int k = 1; k < K; k++) {
         const int st = B.segStop[s0 + k];
-        int endTile;
-        double D;
-        if (st >= -1) { endTile = st; D = B.segD[s0 + k]; }
-        else {
-            if (-2 - st <= covered) continue;
-            endTile = B.segStop2[s0 + k]; D = B.segD2[s0 + k];
-            if (endTile < 0) { abortAny = true; endTile = lastTile; } // (never expected: pass 3 leaves no fix-up behind)
-            covered = endTile;
-        }
-        if (st >= -1 && endTile <= covered) continue;
-        if (endTile >= lastTile) { done = true; break; }
+        // the seam this segment's run left: where it stopped, and the offset of what lies behind it.  A fix-up that gave up and
+        // its continuation are one run in one frame: its seam is where the continuation stopped
+        int endTile = st >= -1 ? st : B.segStop2[s0 + k];
+        const double D = st >= -1 ? B.segD[s0 + k] : B.segD2[s0 + k];
+        if (st < -1 && endTile < 0) { abortAny = true; endTile = lastTile; } // (never expected: the last pass leaves no fix-up behind)
+        if (endTile < covered - 1) continue; // a later continuation ran over this seam: its own offset is relative to what lies behind
+        if (st < -1 && endTile > covered) covered = endTile;
+        if (endTile >= lastTile) break;     // the run reached the end of the piece: one last region in the frame it started in
         B.brkPos[s0 + r] = (endTile + 1) * WAVE - 1; B.brkOff[s0 + r] = off; r++;
         off = off + D;
     }
