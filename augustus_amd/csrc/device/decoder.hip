@@ -976,6 +976,77 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
     return AUGX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// posterior sampling of state paths (host; reference NAMGene::getSampledPath, src/namgene.cc:367-426)
+// ---------------------------------------------------------------------------------------------------
+} // extern "C"
+
+#include "sampler.h"
+
+extern "C" {
+
+augx_rand *augx_rand_create(unsigned seed) { return new augx_rand(seed); }
+int augx_rand_next(augx_rand *r) { return r ? r->next() : -1; }
+void augx_rand_destroy(augx_rand *r) { delete r; }
+
+int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, augx_rand *R, augx_path *out) {
+    if (!d || !b || !R || !out || piece < 0 || piece >= b->V.nPieces || n_samples < 0 || !b->V.fwd) {
+        setLastError("augx_batch_sample: bad argument (run augx_batch_forward first)");
+        return AUGX_E_ARG;
+    }
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    const BatchView &V = b->V;
+    const augx_tables &t = d->model->m.t;
+    SamplePiece P;
+    P.t = &t; P.S = t.S; P.n = b->L.len[piece]; P.blk = V.blk;
+    const int n = P.n, S = P.S;
+    const int64_t o = b->L.off[piece];
+    for (int i = 0; i < n_samples; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = 0; out[i].ln_viterbi = 0; }
+    int32_t cls = 0, nPl = 1;
+    HIP_TRY(hipMemcpy(&cls, V.cls + piece, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&nPl, V.nPlanes + piece, 4, hipMemcpyDeviceToHost));
+    P.cls0 = cls; P.nPlanes = nPl;
+    P.F.resize((size_t)n * S);
+    HIP_TRY(hipMemcpy(P.F.data(), V.fwd + (o + 1) * S, sizeof(double) * P.F.size(), hipMemcpyDeviceToHost));
+    P.sig.resize((size_t)n * NSIG);
+    HIP_TRY(hipMemcpy(P.sig.data(), V.sig + (o + 1) * NSIG, sizeof(double) * P.sig.size(), hipMemcpyDeviceToHost));
+    if (nPl > 1) {
+        P.plane.resize((size_t)n);
+        HIP_TRY(hipMemcpy(P.plane.data(), V.gcPlane + o + 1, (size_t)n, hipMemcpyDeviceToHost));
+        P.planeCls.resize(MAXPL);
+        HIP_TRY(hipMemcpy(P.planeCls.data(), V.planeCls + (int64_t)piece * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+    }
+    const int nBlocks = (n + V.blk - 1) / V.blk;
+    const int64_t gb0 = o / V.blk;
+    P.blkOff.resize((size_t)nBlocks * 2); P.blkCnt.resize((size_t)nBlocks * 2);
+    HIP_TRY(hipMemcpy(P.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * P.blkOff.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(P.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * P.blkCnt.size(), hipMemcpyDeviceToHost));
+    P.item0 = P.blkOff[1];
+    const uint64_t itemEnd = P.blkOff[(size_t)(nBlocks - 1) * 2 + 1] + P.blkCnt[(size_t)(nBlocks - 1) * 2 + 1];
+    P.items.resize((size_t)(itemEnd - P.item0) + 1);
+    if (itemEnd > P.item0) HIP_TRY(hipMemcpy(P.items.data(), V.items + P.item0, sizeof(Item) * (size_t)(itemEnd - P.item0), hipMemcpyDeviceToHost));
+    P.termKind = b->L.termKind[piece];
+    {
+        std::vector<uint8_t> code((size_t)n);
+        HIP_TRY(hipMemcpy(code.data(), V.code + o + 1, (size_t)n, hipMemcpyDeviceToHost));
+        for (int q = 0; q < n && !P.anyNuc; q++) P.anyNuc = code[q] < 4;
+    }
+    std::vector<std::vector<augx_state>> paths;
+    std::vector<int> status;
+    samplePaths(P, n_samples, *R, paths, status);
+    for (int it = 0; it < n_samples; it++) {
+        out[it].status = status[it];
+        if (status[it] != AUGX_OK) continue;
+        const std::vector<augx_state> &m2 = paths[it];
+        out[it].states = (augx_state *)malloc(sizeof(augx_state) * (m2.size() ? m2.size() : 1));
+        if (!out[it].states) { setLastError("augx_batch_sample: out of host memory"); return AUGX_E_NOMEM; }
+        memcpy(out[it].states, m2.data(), sizeof(augx_state) * m2.size());
+        out[it].n_states = (int32_t)m2.size();
+    }
+    return AUGX_OK;
+}
+
 int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out) {
     augx_batch *b = nullptr;
     int rc = augx_batch_create(d, pieces, n, &b);

@@ -1,0 +1,184 @@
+// Posterior sampling of state paths from the forward matrix -- host code shared by the device library (decoder.hip fills
+// SamplePiece from HBM) and the lane-loop emulator (tests/emu/emu.cc fills it from its host arrays).
+// Reference: NAMGene::getSampledPath (src/namgene.cc:367-426), the doSampling branches of the state models
+// (src/exonmodel.cc, src/intronmodel.cc:700-800, src/igenicmodel.cc) and OptionsList (src/vitmatrix.cc:270-320).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+#include "dp.h"
+
+// glibc's rand(): the TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31] of random_r.c, seeded by the Lehmer
+// generator 16807 * x mod 2^31-1, the first 310 outputs discarded, the result shifted right by one
+struct augx_rand {
+    uint32_t r[34];
+    int k = 0;
+    explicit augx_rand(unsigned seed) {
+        int32_t st[34];
+        st[0] = seed == 0 ? 1 : (int32_t)seed;
+        for (int i = 1; i < 31; i++) {
+            const int64_t hi = st[i - 1] / 127773, lo = st[i - 1] % 127773;
+            int64_t w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            st[i] = (int32_t)w;
+        }
+        for (int i = 31; i < 34; i++) st[i] = st[i - 31];
+        for (int i = 0; i < 34; i++) r[i] = (uint32_t)st[i];
+        for (int i = 34; i < 344; i++) (void)step();
+    }
+    uint32_t step() { // r[k] = r[k-31] + r[k-3] on a ring of 34
+        const uint32_t v = r[(k + 34 - 31) % 34] + r[(k + 34 - 3) % 34];
+        r[k % 34] = v;
+        k = (k + 1) % 34;
+        return v;
+    }
+    int next() { return (int)(step() >> 1); }
+};
+
+namespace augx {
+namespace dev {
+// everything of one piece the sampler reads, on the host
+struct SamplePiece {
+    int n = 0, S = 0, blk = 8, nPlanes = 1;
+    const augx_tables *t = nullptr;
+    std::vector<double> F;        // [n][S] ln forward
+    std::vector<double> sig;      // [n][NSIG]
+    std::vector<uint8_t> plane;   // [n] (empty: one class)
+    std::vector<int32_t> planeCls;
+    int cls0 = 0;
+    std::vector<Item> items;      // candidates of the piece
+    std::vector<uint64_t> blkOff; // [nBlocks][2] (relative item offsets are blkOff[.][1] - item0)
+    std::vector<uint32_t> blkCnt; // [nBlocks][2]
+    uint64_t item0 = 0;
+    int igS = -1, termKind = 0;
+    bool anyNuc = true;
+    double lnT(int j, int a, int s) const {
+        const int c = plane.empty() ? cls0 : planeCls[plane[j]];
+        return t->ln_trans[((int64_t)c * S + a) * S + s];
+    }
+};
+struct Opt { int state, base; double lp; };
+struct OptList { std::vector<Opt> o; std::vector<double> p; double cum = 0; };
+
+inline void sortOptions(OptList &L);
+
+// the options of reaching (state s, base j), in the reference's order of listing, then sorted by probability (stable)
+inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
+    const augx_tables &t = *P.t;
+    const int S = P.S, kind = t.state_kind[s];
+    const int dssWhole = t.Ds + 2 + t.De, assLag = t.As + 2 + t.Ae + t.U, dL = t.d - 2 - t.De - t.As - 2 - t.U;
+    auto Fat = [&](int q, int a) { return q < 0 ? -INFINITY : P.F[(size_t)q * S + a]; };
+    L.o.clear();
+    const bool chain = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC;
+    const bool fixed = kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS || kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS ||
+                       kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD;
+    if (chain || fixed) {
+        const int lag = chain ? 1 : (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? dssWhole : (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? assLag : dL;
+        const int sg = kind == AUGX_K_IGENIC ? SIG_EIG : chain ? SIG_EIN : kind == AUGX_K_LONGDSS ? SIG_DSSF : kind == AUGX_K_RLONGDSS ? SIG_DSSR
+                       : kind == AUGX_K_LONGASS ? SIG_ASSF : kind == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
+        const double emi = P.sig[(size_t)j * NSIG + sg];
+        const int eop = j - lag;
+        if (eop >= 0 && emi > -INFINITY)
+            for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                const int a = t.anc[s][ai];
+                const double lp = Fat(eop, a) + (P.lnT(j, a, s) + emi);
+                if (lp > -INFINITY) L.o.push_back({a, eop, lp});
+            }
+    } else { // variable-length state: the candidates of its (base, state) pair, newest first (K2a's order = the reference's loops)
+        const int b = j / P.blk;
+        const uint64_t i0 = P.blkOff[(size_t)b * 2 + 1] - P.item0;
+        const uint32_t cnt = P.blkCnt[(size_t)b * 2 + 1], pid = (uint32_t)(((j % P.blk) << 6) | s);
+        for (uint32_t it = 0; it < cnt; it++) {
+            const Item &I = P.items[i0 + it];
+            if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
+            const uint32_t tag = I.src >> 30;
+            const int ai = (int)((I.src >> 28) & 3), eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
+            int a;
+            double pv;
+            if (tag == SRC_COL0) { a = (int)(I.src & 0x3Fu); pv = P.F[a]; } // column 0 holds the initial probabilities
+            else { a = tag == SRC_VIG ? P.igS : t.anc[s][ai]; pv = Fat(eop, a); }
+            const double lp = pv + I.te;
+            if (lp > -INFINITY) L.o.push_back({a, eop, lp});
+        }
+    }
+    sortOptions(L);
+}
+// reference OptionsList::sample, src/vitmatrix.cc:295-320
+inline const Opt *drawOption(const OptList &L, augx_rand &R) {
+    if (L.o.empty() || !(L.cum > 0)) return nullptr;
+    const double z = (double)R.next() / 2147483647.0 * L.cum * 0.99999;
+    double cumsum = 0;
+    for (size_t i = 0; i < L.o.size(); i++) {
+        cumsum += L.p[i];
+        if (z < cumsum) return &L.o[i];
+    }
+    return &L.o[0];
+}
+
+inline void sortOptions(OptList &L) {
+    // OptionsList::add accumulates the sum in listing order; prepareSampling sorts with the largest first (std::list::sort: stable)
+    double mx = -INFINITY;
+    for (const Opt &x : L.o) mx = x.lp > mx ? x.lp : mx;
+    L.p.resize(L.o.size());
+    L.cum = 0;
+    for (size_t i = 0; i < L.o.size(); i++) { L.p[i] = exp(L.o[i].lp - mx); L.cum += L.p[i]; }
+    std::vector<size_t> ord(L.o.size());
+    for (size_t i = 0; i < ord.size(); i++) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b2) { return L.p[a] > L.p[b2]; });
+    std::vector<Opt> o2(L.o.size());
+    std::vector<double> p2(L.o.size());
+    for (size_t i = 0; i < ord.size(); i++) { o2[i] = L.o[ord[i]]; p2[i] = L.p[ord[i]]; }
+    L.o.swap(o2); L.p.swap(p2);
+}
+
+// n_samples paths of one piece, 5'->3', runs of the single-base chain states merged (as the Viterbi path is delivered)
+inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector<std::vector<augx_state>> &paths, std::vector<int> &status) {
+    const augx_tables &t = *P.t;
+    const int n = P.n, S = P.S;
+    for (int s2 = 0; s2 < S; s2++)
+        if (t.state_kind[s2] == AUGX_K_IGENIC && P.igS < 0) P.igS = s2;
+    paths.assign((size_t)n_samples, {});
+    status.assign((size_t)n_samples, AUGX_OK);
+    std::unordered_map<uint64_t, OptList> memo; // the options of a (base, state) pair are the same for every sample
+    std::vector<augx_state> st;
+    for (int it = 0; it < n_samples; it++) {
+        st.clear();
+        // a piece without a nucleotide: one intergenic state, no draw (reference src/namgene.cc:380-384)
+        if (!P.anyNuc) st.push_back({0, n - 1, (int16_t)t.synch_state, (int16_t)t.state_type[t.synch_state]});
+        else {
+            OptList last;
+            for (int i = 0; i < S; i++) {
+                const double tl = P.termKind == 0 ? t.ln_term[i] : (i == t.synch_state ? 0.0 : -INFINITY);
+                const double lp = P.F[(size_t)(n - 1) * S + i] + tl;
+                if (lp > -INFINITY) last.o.push_back({i, n - 1, lp});
+            }
+            sortOptions(last);
+            const Opt *c = drawOption(last, R);
+            if (!c) { status[it] = AUGX_E_NOPATH; continue; }
+            int base = c->base, state = c->state;
+            bool bad = false;
+            while (base > 0) {
+                const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;
+                auto f = memo.find(key);
+                if (f == memo.end()) { f = memo.emplace(key, OptList()).first; buildOptions(P, state, base, f->second); }
+                const Opt *x = drawOption(f->second, R);
+                if (!x) { bad = true; break; }
+                st.push_back({x->base + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
+                base = x->base; state = x->state;
+            }
+            if (bad) { status[it] = AUGX_E_NOPATH; continue; }
+        }
+        std::vector<augx_state> &m2 = paths[it];
+        for (size_t i = st.size(); i-- > 0;) {
+            const augx_state &x = st[i];
+            const int k = t.state_kind[x.state];
+            const bool chain = k == AUGX_K_IGENIC || k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC;
+            if (chain && !m2.empty() && m2.back().state == x.state && m2.back().end + 1 == x.begin) m2.back().end = x.end;
+            else m2.push_back(x);
+        }
+    }
+}
+} // namespace dev
+} // namespace augx

@@ -197,6 +197,17 @@ int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out);
  * executable still rejects) */
 int augx_batch_forward(augx_decoder *d, augx_batch *b);
 int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *out, double *ln_p);
+/* posterior sampling (reference NAMGene::getSampledPath, src/namgene.cc:367-426, OptionsList::sample, src/vitmatrix.cc:295-320):
+ * n_samples state paths of one piece of a batch whose forward matrix has been computed, drawn backwards from the last column;
+ * every step lists its options in the reference's order, sorts them by probability and draws with
+ * rand() / RAND_MAX * sum * 0.99999.  The reference draws from glibc's rand() (never seeded: seed 1), one call per step, over
+ * the whole run: augx_rand is that generator (the TYPE_3 additive-feedback generator of glibc, restated), kept by the caller
+ * across pieces in input order.  (Groundwork of --sample > 0, which the executable still rejects.) */
+typedef struct augx_rand augx_rand;
+augx_rand *augx_rand_create(unsigned seed);
+int augx_rand_next(augx_rand *r);               /* == rand() of glibc after srand(seed) */
+void augx_rand_destroy(augx_rand *r);
+int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, augx_rand *r, augx_path *out /* array[n_samples] */);
 void augx_batch_destroy(augx_batch *b);
 
 /* ---- whole-program driver (replaces main(), reference src/augustus.cc:94-248): same argv as `augustus`,

@@ -87,18 +87,22 @@ int verbosity = 0;          // augustus.cc:27-28 defines these in the real binar
 bool mea_prediction = false;
 
 int main(int argc, char *argv[]) {
-    std::string dumpfile, fwdfile;
+    std::string dumpfile, fwdfile, smpfile;
+    int nsamples = 0;
     int initkind = 0, termkind = 0;
     std::vector<char *> args;
     for (int i = 0; i < argc; i++) {
         if (strncmp(argv[i], "--dumpcells=", 12) == 0) dumpfile = argv[i] + 12;
         else if (strncmp(argv[i], "--dumpforward=", 14) == 0) fwdfile = argv[i] + 14; // (needs --sample > 0: the forward table is only filled then)
+        else if (strncmp(argv[i], "--dumpsamples=", 14) == 0) smpfile = argv[i] + 14; // text: per record "SEQ name", then per sample "SAMPLE i n" + "ST b e type" lines
+        else if (strncmp(argv[i], "--nsamples=", 11) == 0) nsamples = atoi(argv[i] + 11);
         else if (strncmp(argv[i], "--initkind=", 11) == 0) initkind = atoi(argv[i] + 11);
         else if (strncmp(argv[i], "--termkind=", 11) == 0) termkind = atoi(argv[i] + 11);
         else args.push_back(argv[i]);
     }
     int nargs = (int)args.size();
     FILE *dump = dumpfile.empty() ? NULL : fopen(dumpfile.c_str(), "wb");
+    FILE *sdump = smpfile.empty() ? NULL : fopen(smpfile.c_str(), "w");
     FILE *fdump = fwdfile.empty() ? NULL : fopen(fwdfile.c_str(), "wb");
     try {
         LLDouble::setOutputPrecision(3);
@@ -192,6 +196,23 @@ int main(int argc, char *argv[]) {
                     fwrite(col.data(), 8, S, fdump);
                 }
             }
+            if (sdump) { // reference NAMGene::getSampledPath (src/namgene.cc:367): draws from rand(), one stream over the run
+                fprintf(sdump, "SEQ %s\n", cur->seqname);
+                for (int it = 0; it < nsamples; it++) {
+                    StatePath *sp = namgene.getSampledPath(cur->sequence, cur->seqname);
+                    std::vector<State> sr;
+                    for (State *st = sp->first; st; st = st->next) {
+                        bool mergeable = st->type == igenic || isGeometricIntron(st->type) || isRGeometricIntron(st->type);
+                        if (mergeable && !sr.empty() && sr.back().type == st->type && sr.back().end + 1 == st->begin)
+                            sr.back().end = st->end;
+                        else
+                            sr.push_back(State(st->begin, st->end, st->type));
+                    }
+                    fprintf(sdump, "SAMPLE %d %d\n", it, (int)sr.size());
+                    for (size_t r = 0; r < sr.size(); r++) fprintf(sdump, "ST %d %d %d\n", sr[r].begin, sr[r].end, (int)sr[r].type);
+                    delete sp;
+                }
+            }
             delete p;
         }
     } catch (ProjectError &err) {
@@ -200,5 +221,6 @@ int main(int argc, char *argv[]) {
     }
     if (dump) fclose(dump);
     if (fdump) fclose(fdump);
+    if (sdump) fclose(sdump);
     return 0;
 }
