@@ -78,6 +78,16 @@ def lib():
         L.augx_batch_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.augx_batch_forward_cells.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         L.augx_batch_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_rand_create.restype = ctypes.c_void_p
+        L.augx_rand_create.argtypes = [ctypes.c_uint]
+        L.augx_rand_next.argtypes = [ctypes.c_void_p]
+        L.augx_rand_destroy.argtypes = [ctypes.c_void_p]
+        L.augx_batch_sample.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.augx_decode_sampled.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+        L.augx_format_gff_sampled.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64,
+                                              ctypes.POINTER(ctypes.c_int)]
         L.augx_path_free.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
@@ -191,6 +201,21 @@ class Batch:
         _check(lib().augx_batch_forward_cells(self.decoder._h, self._h, piece, F.ctypes.data_as(ctypes.c_void_p), ctypes.byref(lnp)))
         return F, lnp.value
 
+    def sample(self, piece, n, rand):
+        """n state paths of one piece sampled from the forward matrix (``augx_batch_sample``; run forward() first); the draws
+        come from ``rand`` (a Rand: glibc's rand() restated, one stream over a run).  Returns [[(begin, end, state, type)]]"""
+        L = lib()
+        out = (_Path * max(1, n))()
+        _check(L.augx_batch_sample(self.decoder._h, self._h, piece, n, rand._h, out))
+        res = []
+        for i in range(n):
+            if out[i].status != 0:
+                raise AugxError(out[i].status, "sampling failed")
+            res.append([(out[i].states[k].begin, out[i].states[k].end, out[i].states[k].state, out[i].states[k].type)
+                        for k in range(out[i].n_states)])
+            L.augx_path_free(ctypes.byref(out[i]))
+        return res
+
     def close(self):
         if self._h:
             lib().augx_batch_destroy(self._h)
@@ -201,6 +226,52 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class Rand:
+    """glibc's rand() after srand(seed), restated (``augx_rand``): the generator the reference samples with (never seeded: 1)."""
+
+    def __init__(self, seed=1):
+        self._h = ctypes.c_void_p(lib().augx_rand_create(seed))
+
+    def next(self):
+        return lib().augx_rand_next(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().augx_rand_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def decode_sampled(decoders, seqs, n_samples, rand, init_kind=0, term_kind=0):
+    """``augx_decode_sampled``: Viterbi path + n_samples sampled paths per piece, batches in input order over the decoders.
+    Returns [(DecodedPiece, [sampled paths])]."""
+    L = lib()
+    n = len(seqs)
+    keep = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+    P = (_Piece * n)()
+    iks = init_kind if isinstance(init_kind, (list, tuple)) else [init_kind] * n
+    tks = term_kind if isinstance(term_kind, (list, tuple)) else [term_kind] * n
+    for i, s in enumerate(keep):
+        P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = s, len(s), iks[i], tks[i]
+    D = (ctypes.c_void_p * len(decoders))(*[d._h for d in decoders])
+    out = (_Path * n)()
+    smp = (_Path * max(1, n * n_samples))()
+    _check(L.augx_decode_sampled(D, len(decoders), P, n, n_samples, rand._h, out, smp))
+    res = []
+    for i in range(n):
+        st = [(out[i].states[k].begin, out[i].states[k].end, out[i].states[k].state, out[i].states[k].type) for k in range(out[i].n_states)]
+        sm = []
+        for q in range(n_samples):
+            sp = smp[i * n_samples + q]
+            sm.append([(sp.states[k].begin, sp.states[k].end, sp.states[k].state, sp.states[k].type) for k in range(sp.n_states)])
+            L.augx_path_free(ctypes.byref(sp))
+        res.append((DecodedPiece(out[i].status, out[i].ln_viterbi, st), sm))
+        L.augx_path_free(ctypes.byref(out[i]))
+    return res
 
 
 def device_count():

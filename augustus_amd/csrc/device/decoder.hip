@@ -1022,14 +1022,25 @@ int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, 
     P.blkOff.resize((size_t)nBlocks * 2); P.blkCnt.resize((size_t)nBlocks * 2);
     HIP_TRY(hipMemcpy(P.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * P.blkOff.size(), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(P.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * P.blkCnt.size(), hipMemcpyDeviceToHost));
-    P.item0 = P.blkOff[1];
-    const uint64_t itemEnd = P.blkOff[(size_t)(nBlocks - 1) * 2 + 1] + P.blkCnt[(size_t)(nBlocks - 1) * 2 + 1];
-    P.items.resize((size_t)(itemEnd - P.item0) + 1);
-    if (itemEnd > P.item0) HIP_TRY(hipMemcpy(P.items.data(), V.items + P.item0, sizeof(Item) * (size_t)(itemEnd - P.item0), hipMemcpyDeviceToHost));
+    // (K2a hands out the candidate ranges of the blocks through an atomic counter: a piece's candidates lie wherever its work
+    //  groups were served, so the span between its lowest and highest range is fetched)
+    uint64_t lo = ~0ull, hi = 0;
+    for (int q = 0; q < nBlocks; q++) {
+        const uint64_t a = P.blkOff[(size_t)q * 2 + 1], c = P.blkCnt[(size_t)q * 2 + 1];
+        if (c == 0) continue;
+        lo = a < lo ? a : lo;
+        hi = a + c > hi ? a + c : hi;
+    }
+    if (hi <= lo) lo = hi = 0;
+    if (hi > b->nItems && b->nItems) { setLastError("augx_batch_sample: candidate ranges outside the candidate buffer"); return AUGX_E_HIP; }
+    P.item0 = lo;
+    P.items.resize((size_t)(hi - lo) + 1);
+    if (hi > lo) HIP_TRY(hipMemcpy(P.items.data(), V.items + lo, sizeof(Item) * (size_t)(hi - lo), hipMemcpyDeviceToHost));
     P.termKind = b->L.termKind[piece];
     {
         std::vector<uint8_t> code((size_t)n);
         HIP_TRY(hipMemcpy(code.data(), V.code + o + 1, (size_t)n, hipMemcpyDeviceToHost));
+        P.anyNuc = false;
         for (int q = 0; q < n && !P.anyNuc; q++) P.anyNuc = code[q] < 4;
     }
     std::vector<std::vector<augx_state>> paths;

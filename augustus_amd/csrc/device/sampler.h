@@ -102,6 +102,13 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
             const double lp = pv + I.te;
             if (lp > -INFINITY) L.o.push_back({a, eop, lp});
         }
+        // the reference lists them exon start after exon start, the latest first, and for each the ancestors in their order
+        // (src/exonmodel.cc:1058-1100); K2a's order within a pair depends on how its queues were served.  The order decides
+        // between options of exactly equal probability (e.g. the three intron phases at the start of a piece).
+        int pos[AUGX_MAX_STATES];
+        for (int q = 0; q < AUGX_MAX_STATES; q++) pos[q] = AUGX_MAX_STATES;
+        for (int ai = t.n_anc[s] - 1; ai >= 0; ai--) pos[t.anc[s][ai]] = ai;
+        std::stable_sort(L.o.begin(), L.o.end(), [&](const Opt &x, const Opt &y) { return x.base != y.base ? x.base > y.base : pos[x.state] < pos[y.state]; });
     }
     sortOptions(L);
 }

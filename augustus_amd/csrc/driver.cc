@@ -78,7 +78,7 @@ bool readFasta(std::istream &in, std::vector<Record> &recs) {
     return true;
 }
 
-struct Decoded { std::vector<PathState> path; double lnv; int status; };
+struct Decoded { std::vector<PathState> path; double lnv; int status; std::vector<std::vector<PathState>> samples; };
 
 struct Session {
     augx_model *model = nullptr;
@@ -86,8 +86,14 @@ struct Session {
     OutputOptions oo;
     int geneid = 1;
     std::string err;
+    // posterior sampling (--sample=n >= 10): n - 1 paths are sampled per piece next to the Viterbi path, the draws of the whole
+    // run come from one generator (reference src/namgene.cc:824-871, src/vitmatrix.cc:312)
+    int sampleiterations = 0;
+    augx_rand *rng = nullptr;
 
     void destroy() {
+        if (rng) augx_rand_destroy(rng);
+        rng = nullptr;
         for (augx_decoder *d : decs) augx_decoder_destroy(d);
         decs.clear();
         if (model) augx_model_destroy(model);
@@ -104,9 +110,35 @@ struct Session {
             out[i].lnv = paths[i].ln_viterbi;
             out[i].status = paths[i].status;
             out[i].path.clear();
+            out[i].samples.clear();
             for (int k = 0; k < paths[i].n_states; k++)
                 out[i].path.push_back({paths[i].states[k].begin, paths[i].states[k].end, paths[i].states[k].type});
             augx_path_free(&paths[i]);
+        }
+        return true;
+    }
+    // the same with sampleiterations - 1 sampled paths per piece (pieces in input order: the order of the draws)
+    bool decodeSampled(const std::vector<augx_piece> &pieces, std::vector<Decoded> &out) {
+        const int ns = sampleiterations - 1;
+        if (!rng) rng = augx_rand_create(1);
+        std::vector<augx_path> paths(pieces.size()), smp(pieces.size() * (size_t)ns);
+        int rc = augx_decode_sampled(decs.data(), (int)decs.size(), pieces.data(), (int)pieces.size(), ns, rng, paths.data(), smp.data());
+        if (rc) { err = augx_last_error(); return false; }
+        out.resize(pieces.size());
+        for (size_t i = 0; i < pieces.size(); i++) {
+            out[i].lnv = paths[i].ln_viterbi;
+            out[i].status = paths[i].status;
+            out[i].path.clear();
+            for (int k = 0; k < paths[i].n_states; k++)
+                out[i].path.push_back({paths[i].states[k].begin, paths[i].states[k].end, paths[i].states[k].type});
+            augx_path_free(&paths[i]);
+            out[i].samples.assign((size_t)ns, {});
+            for (int q = 0; q < ns; q++) {
+                augx_path &sp = smp[i * (size_t)ns + q];
+                if (out[i].status == 0 && sp.status != 0) out[i].status = sp.status;
+                for (int k = 0; k < sp.n_states; k++) out[i].samples[q].push_back({sp.states[k].begin, sp.states[k].end, sp.states[k].type});
+                augx_path_free(&sp);
+            }
         }
         return true;
     }
@@ -170,14 +202,14 @@ const char *pieceSequence(const std::string &seq, long begin, long end, long lim
 }
 
 struct RecordView { const char *name; const char *seq; long len; };
-struct PieceOut { int rec; long begin, end; const std::vector<PathState> *path; int status; };
+struct PieceOut { int rec; long begin, end; const std::vector<PathState> *path; int status; const std::vector<std::vector<PathState>> *samples = nullptr; };
 
 // ---- gene structures + GFF for all records, in input order; gene ids are global and sequential over the run (reference
 //      NAMGene::doViterbiPiecewise, src/namgene.cc:526,626-650; block headers src/augustus.cc:395-398).  `pieces` may
 //      arrive in any order (they were decoded on several devices): they are gathered by (record, begin) first.
 //      Returns 0, or 1 when the very first record failed (the reference then aborts the run, src/augustus.cc:425-440).
 int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<RecordView> &recs, std::vector<PieceOut> pieces,
-                  int verbosity, int &geneid, std::string &out, std::string &err, std::string &fatal) {
+                  int verbosity, int &geneid, std::string &out, std::string &err, std::string &fatal, int sampleiterations = 0) {
     std::stable_sort(pieces.begin(), pieces.end(), [](const PieceOut &a, const PieceOut &b) { return a.rec != b.rec ? a.rec < b.rec : a.begin < b.begin; });
     size_t pi = 0;
     int successful = 0;
@@ -206,7 +238,10 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
             }
             std::vector<Transcript> txs;
             try {
-                txs = filterTranscripts(M, projectOntoGeneSequence(M, *pr.path, pr.end - pr.begin + 1));
+                if (sampleiterations > 0 && pr.samples)
+                    txs = filterTranscripts(M, posteriorTranscripts(M, *pr.path, *pr.samples, pr.end - pr.begin + 1, sampleiterations));
+                else
+                    txs = filterTranscripts(M, projectOntoGeneSequence(M, *pr.path, pr.end - pr.begin + 1));
             } catch (std::exception &e) { errmsg = e.what(); continue; }
             std::vector<GeneOut> genes = groupToGenes(txs);
             for (GeneOut &g : genes) {
@@ -369,9 +404,17 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         std::ifstream probe(queryfile.c_str());
         if (!probe) return fail("Could not open input file \"" + queryfile + "\"!");
     }
-    if (M.opt.getInt("sample", 0) > 0)
-        return fail("sampling (--sample>0: forward algorithm + posterior probabilities) is not implemented on the MI355X path yet; "
-                    "run with --sample=0 (the human default).");
+    { // reference NAMGene::NAMGene, src/namgene.cc:53-67
+        int si = M.opt.getInt("sample", 0);
+        if (si > 0 && si < 10) {
+            std::cerr << "Error: Number of sample iterations is too low. (sample=" << si << ")" << std::endl
+                      << "I will not sample (sample=0) and will not estimate posterior probabilities." << std::endl;
+            si = 0;
+        } else if (si >= 10 && si < 20)
+            std::cerr << "Warning: Number of sample iterations 'sample'=" << si << " is low." << std::endl
+                      << "Posterior probabilities will be only rough estimates." << std::endl;
+        S.sampleiterations = si > 0 ? si : 0;
+    }
     // redirect output if requested (reference src/augustus.cc:503-520)
     std::ofstream outfile, errfile;
     std::streambuf *coutbuf = std::cout.rdbuf(), *cerrbuf = std::cerr.rdbuf();
@@ -566,7 +609,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             ps[i].init_kind = pr.initKind;
             ps[i].term_kind = pr.termKind;
         }
-        if (!ps.empty() && !S.decode(ps, decoded)) { restore(); return fail(S.err); }
+        if (!ps.empty() && !(S.sampleiterations > 0 ? S.decodeSampled(ps, decoded) : S.decode(ps, decoded))) { restore(); return fail(S.err); }
     }
 
     lap("decode of the pieces");
@@ -575,11 +618,12 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     for (auto &r : recs) rv.push_back({r.name.c_str(), r.seq.data(), (long)r.seq.size()});
     std::vector<PieceOut> po;
     static const std::vector<PathState> noPath;
-    for (size_t i = 0; i < allPieces.size(); i++) po.push_back({allPieces[i].rec, allPieces[i].begin, allPieces[i].end, &decoded[i].path, decoded[i].status});
+    for (size_t i = 0; i < allPieces.size(); i++)
+        po.push_back({allPieces[i].rec, allPieces[i].begin, allPieces[i].end, &decoded[i].path, decoded[i].status, S.sampleiterations > 0 ? &decoded[i].samples : nullptr});
     for (size_t r = 0; r < recs.size(); r++)
         if (cs[r].failStatus) po.push_back({(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, cs[r].failStatus});
     std::string text, errText, fatal;
-    if (formatRecords(M, S.oo, rv, po, verbosity, S.geneid, text, errText, fatal)) {
+    if (formatRecords(M, S.oo, rv, po, verbosity, S.geneid, text, errText, fatal, S.sampleiterations)) {
         std::cout << text;
         std::cerr << errText;
         restore();
@@ -617,6 +661,40 @@ extern "C" int augx_format_gff(const augx_model *m, const char *name, const char
         printGeneList(text, genes, seq, (long)len, oo, nullptr);
         if (n_genes) *n_genes = (int)genes.size();
         if ((int64_t)text.size() + 1 > out_cap) { setLastError("augx_format_gff: output buffer too small"); return AUGX_E_ARG; }
+        memcpy(out, text.c_str(), text.size() + 1);
+        return AUGX_OK;
+    } catch (std::exception &e) {
+        setLastError(e.what());
+        return AUGX_E_CONFIG;
+    }
+}
+
+// ---- the same with sampled paths (n_samples of them, e.g. from augx_batch_sample): posterior probabilities in the score columns;
+//      sampleiterations = n_samples + 1 as in the reference's --sample
+extern "C" int augx_format_gff_sampled(const augx_model *m, const char *name, const char *seq, int64_t len, const augx_state *states,
+                                       int n_states, int n_samples, const augx_state *const *sample_states, const int *sample_n,
+                                       int first_gene_id, char *out, int64_t out_cap, int *n_genes) {
+    if (!m || !name || !seq || !out || n_samples < 0 || (n_samples && (!sample_states || !sample_n))) return AUGX_E_ARG;
+    try {
+        OutputOptions oo;
+        oo.fromModel(m->m);
+        std::vector<PathState> path;
+        for (int i = 0; i < n_states; i++) path.push_back({states[i].begin, states[i].end, states[i].type});
+        std::vector<std::vector<PathState>> smp((size_t)n_samples);
+        for (int q = 0; q < n_samples; q++)
+            for (int i = 0; i < sample_n[q]; i++) smp[q].push_back({sample_states[q][i].begin, sample_states[q][i].end, sample_states[q][i].type});
+        std::vector<GeneOut> genes = groupToGenes(filterTranscripts(m->m, posteriorTranscripts(m->m, path, smp, (long)len, n_samples + 1)));
+        int gid = first_gene_id;
+        for (GeneOut &g : genes) {
+            g.seqname = name;
+            g.id = "g" + std::to_string(gid++);
+            int tid = 1;
+            for (Transcript &t : g.transcripts) { t.seqname = name; t.id = "t" + std::to_string(tid++); t.geneid = g.id; }
+        }
+        std::string text;
+        printGeneList(text, genes, seq, (long)len, oo, nullptr);
+        if (n_genes) *n_genes = (int)genes.size();
+        if ((int64_t)text.size() + 1 > out_cap) { setLastError("augx_format_gff_sampled: output buffer too small"); return AUGX_E_ARG; }
         memcpy(out, text.c_str(), text.size() + 1);
         return AUGX_OK;
     } catch (std::exception &e) {

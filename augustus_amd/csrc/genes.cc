@@ -170,19 +170,117 @@ std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vecto
     return out;
 }
 
+// reference Transcript::meanStateProb, src/gene.cc:1241-1254: the geometric mean of the exon and intron probabilities
+double Transcript::meanStateProb() const {
+    if (!hasProbs) return 0.0;
+    double p = 1.0;
+    int k = 0;
+    for (const BioState &e : exons) { p *= e.apostprob; k++; }
+    for (const BioState &e : introns) { p *= e.apostprob; k++; }
+    return pow(p, 1.0 / k);
+}
+
 std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs) {
     std::vector<Transcript> out;
     // --strand (reference src/augustus.cc:177-191, filterGenePrediction src/gene.cc:2474-2475).  Only the values listed as
     // possible_values in aug_cmdln_parameters.json reach the reference's parser: anything but forward / backward means both
     const std::string st = m.opt.get("strand", "both");
     const int want = st == "forward" ? 1 : st == "backward" ? -1 : 0;
+    const double minmean = m.opt.getDouble("minmeanexonintronprob", 0.0), minprob = m.opt.getDouble("minexonintronprob", 0.0);
+    const bool keepViterbi = m.opt.getBool("keep_viterbi", false);
     for (const Transcript &g : txs) {
         bool keep = !(want == 1 && !g.plus) && !(want == -1 && g.plus);
+        if (g.throwaway) keep = false;
         bool cc = g.completeCDS();
         if ((g.clength < m.t.min_coding_len && cc) || (g.clength < 4 && g.clength < m.t.min_coding_len && !cc)) keep = false;
+        if (keep && g.hasProbs) { // src/gene.cc:2489-2514
+            const bool kv = keepViterbi && g.viterbi;
+            if (g.meanStateProb() < minmean && !kv) keep = false;
+            for (const BioState &e : g.exons)
+                if (e.apostprob < minprob && !kv) keep = false;
+            for (const BioState &e : g.introns)
+                if (e.apostprob < minprob && !kv) keep = false;
+        }
         if (keep) out.push_back(g);
     }
     return out;
+}
+
+// reference Transcript::operator==, src/gene.cc:1149-1175: the same exon and intron intervals (types and strand are not compared)
+static bool sameIntervals(const Transcript &a, const Transcript &b) {
+    if (a.exons.size() != b.exons.size() || a.introns.size() != b.introns.size()) return false;
+    for (size_t i = 0; i < a.exons.size(); i++)
+        if (a.exons[i].begin != b.exons[i].begin || a.exons[i].end != b.exons[i].end) return false;
+    for (size_t i = 0; i < a.introns.size(); i++)
+        if (a.introns[i].begin != b.introns[i].begin || a.introns[i].end != b.introns[i].end) return false;
+    return true;
+}
+// reference Transcript::updatePostProb, src/gene.cc:1204-1235
+static void mergeCount(std::vector<BioState> &x, std::vector<BioState> &y) {
+    size_t i = 0, j = 0;
+    while (i < x.size() && j < y.size()) {
+        if (x[i].begin == y[j].begin && x[i].end == y[j].end && x[i].type == y[j].type) {
+            x[i].apostprob += y[j].sampleCount;
+            y[j].apostprob += x[i].sampleCount;
+            i++; j++;
+        } else if (x[i].begin < y[j].begin) i++;
+        else j++;
+    }
+}
+
+std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<PathState> &viterbi,
+                                             const std::vector<std::vector<PathState>> &samples, long dnalen, int sampleiterations) {
+    std::vector<Transcript> all;
+    auto add = [&](const std::vector<PathState> &path, bool vit) {
+        for (Transcript &g : projectOntoGeneSequence(m, path, dnalen)) {
+            g.apostprob = 1.0f;
+            for (BioState &e : g.exons) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
+            for (BioState &e : g.introns) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
+            g.hasProbs = true;
+            g.viterbi = vit;
+            g.throwaway = !vit; // (alternatives-from-sampling=false: a sampled transcript only adds to the counts)
+            all.push_back(std::move(g));
+        }
+    };
+    add(viterbi, true);
+    for (const auto &sp : samples) add(sp, false);
+    if (sampleiterations > 1) {
+        std::stable_sort(all.begin(), all.end(), [](const Transcript &a, const Transcript &b) { return a.geneBegin() < b.geneBegin(); });
+        // copies of one transcript are united, the count goes up instead (src/namgene.cc:876-893)
+        std::vector<char> dead(all.size(), 0);
+        for (size_t i = 0; i < all.size(); i++) {
+            if (dead[i]) continue;
+            for (size_t j = i + 1; j < all.size() && all[j].geneBegin() == all[i].geneBegin(); j++) {
+                if (dead[j] || !sameIntervals(all[i], all[j])) continue;
+                all[i].throwaway = all[i].throwaway && all[j].throwaway;
+                all[i].viterbi = all[i].viterbi || all[j].viterbi;
+                all[i].apostprob += 1.0f;
+                for (BioState &e : all[i].exons) { e.sampleCount += 1; e.apostprob += 1.0f; }
+                for (BioState &e : all[i].introns) { e.sampleCount += 1; e.apostprob += 1.0f; }
+                dead[j] = 1;
+            }
+        }
+        {
+            std::vector<Transcript> live;
+            for (size_t i = 0; i < all.size(); i++)
+                if (!dead[i]) live.push_back(std::move(all[i]));
+            all.swap(live);
+        }
+        // exons and introns shared with overlapping transcripts (src/namgene.cc:898-903)
+        for (size_t i = 0; i < all.size(); i++)
+            for (size_t j = i + 1; j < all.size() && all[j].geneBegin() <= all[i].geneEnd(); j++) {
+                if (all[j].geneBegin() > all[i].geneEnd() || all[i].geneBegin() > all[j].geneEnd()) continue;
+                mergeCount(all[i].exons, all[j].exons);
+                mergeCount(all[i].introns, all[j].introns);
+            }
+        const float n = (float)sampleiterations;
+        for (Transcript &g : all) {
+            g.apostprob /= n;
+            for (BioState &e : g.exons) e.apostprob /= n;
+            for (BioState &e : g.introns) e.apostprob /= n;
+        }
+    }
+    return all;
 }
 
 std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs) {
@@ -193,7 +291,9 @@ std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs) {
         ag.plus = t.plus;
         ag.mincodstart = t.codingstart;
         ag.maxcodend = t.codingend;
-        ag.apostprob = 1.0; // Viterbi transcripts enter with apostprob 1 (src/namgene.cc:813-821, src/gene.cc:2706)
+        // AltGene::addGene: the sum of its transcripts' apostprob (src/gene.cc:2706); a Viterbi transcript enters with 1 when
+        // nothing was sampled (src/namgene.cc:813-821)
+        ag.apostprob = t.apostprob;
         genes.push_back(ag);
     }
     std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
@@ -252,18 +352,25 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
         if (o.print_stop && !t.plus && (f.type == T_TERMINAL || f.type == T_SINGLE || isRTerminalExon(f.type) || f.type == T_RSINGLE))
             appendf(out, "%s\t%s\tstop_codon\t%ld\t%ld\t.\t-\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
     }
+    // score column: the posterior probability with setprecision(3), "." without sampling
+    auto score = [&](const BioState &e) {
+        if (!e.hasScore) return std::string(".");
+        char b[32];
+        snprintf(b, sizeof b, "%.3g", (double)e.apostprob);
+        return std::string(b);
+    };
     auto frameCol = [&](const BioState &e) { return t.plus ? mod3(3 - (e.frame() - e.length())) : mod3(2 - e.frame()); };
     if (o.print_exonnames && !o.gff3)
         for (const BioState &e : t.exons) {
             const char *nm = (e.type == T_SINGLE || e.type == T_RSINGLE) ? "single"
                              : (isInitialExon(e.type) || e.type == T_RINITIAL) ? "initial"
                              : (e.type == T_TERMINAL || isRTerminalExon(e.type)) ? "terminal" : "internal";
-            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t.\t%c\t%d\ttranscript_id \"%s.%s\"; gene_id \"%s\";\n", seqname, source, nm,
-                    e.begin + 1, e.end + 1, strand, frameCol(e), t.geneid.c_str(), t.id.c_str(), t.geneid.c_str());
+            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t%s\t%c\t%d\ttranscript_id \"%s.%s\"; gene_id \"%s\";\n", seqname, source, nm,
+                    e.begin + 1, e.end + 1, score(e).c_str(), strand, frameCol(e), t.geneid.c_str(), t.id.c_str(), t.geneid.c_str());
         }
     if (o.print_introns)
         for (const BioState &e : t.introns)
-            appendf(out, "%s\t%s\tintron\t%ld\t%ld\t.\t%c\t.\t%s\n", seqname, source, e.begin + 1, e.end + 1, strand, parentstr.c_str());
+            appendf(out, "%s\t%s\tintron\t%ld\t%ld\t%s\t%c\t.\t%s\n", seqname, source, e.begin + 1, e.end + 1, score(e).c_str(), strand, parentstr.c_str());
     for (const BioState &e : t.exons) {
         if (o.print_cds) {
             int beginmod = 0, endmod = 0;
@@ -272,7 +379,7 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
                 if (isRTerminalExon(e.type) || e.type == T_RSINGLE) beginmod = 3;
             }
             if (e.begin + 1 + beginmod <= e.end + 1 + endmod) {
-                appendf(out, "%s\t%s\tCDS\t%ld\t%ld\t.\t%c\t%d\t", seqname, source, e.begin + 1 + beginmod, e.end + 1 + endmod, strand, frameCol(e));
+                appendf(out, "%s\t%s\tCDS\t%ld\t%ld\t%s\t%c\t%d\t", seqname, source, e.begin + 1 + beginmod, e.end + 1 + endmod, score(e).c_str(), strand, frameCol(e));
                 if (o.gff3) appendf(out, "ID=%s.%s.cds;", t.geneid.c_str(), t.id.c_str());
                 out += parentstr;
                 out += "\n";
@@ -314,7 +421,9 @@ void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const ch
         appendf(out, "%s\tAUGUSTUS\tgene\t%ld\t%ld\t%s\t%c\t.\t%s%s\n", g.seqname.c_str(), minB + 1 + o.offset, maxE + 1 + o.offset, score, g.plus ? '+' : '-',
                 o.gff3 ? "ID=" : "", g.id.c_str());
         for (const Transcript &t : g.transcripts) {
-            appendf(out, "%s\tAUGUSTUS\ttranscript\t%ld\t%ld\t.\t%c\t.\t", g.seqname.c_str(), t.geneBegin() + 1 + o.offset, t.geneEnd() + 1 + o.offset, t.plus ? '+' : '-');
+            char tscore[32] = ".";
+            if (t.hasProbs) snprintf(tscore, sizeof tscore, "%.3g", (double)t.apostprob);
+            appendf(out, "%s\tAUGUSTUS\ttranscript\t%ld\t%ld\t%s\t%c\t.\t", g.seqname.c_str(), t.geneBegin() + 1 + o.offset, t.geneEnd() + 1 + o.offset, tscore, t.plus ? '+' : '-');
             if (o.gff3) out += "ID=" + g.id + "." + t.id + ";Parent=" + g.id + "\n";
             else out += g.id + "." + t.id + "\n";
             { // printed coordinates are shifted by the offset of --predictionStart (reference AnnoSequence::offset)

@@ -19,6 +19,10 @@ struct BioState {
     int type = -1;
     int truncated = 0;
     int framemod = 0;
+    // posterior probability of the exon / intron after sampling (reference State::apostprob, a float; include/gene.hh:117-119)
+    float apostprob = 0;
+    int sampleCount = 1;
+    bool hasScore = false;
     int frame() const;
     int length() const { return (int)(end - begin + 1); }
 };
@@ -31,6 +35,10 @@ struct Transcript {
     long transstart = -1, transend = -1, codingstart = -1, codingend = -1;
     int clength = 0;
     std::string id, geneid, seqname;
+    // sampling (reference Transcript::apostprob / hasProbs / viterbi / throwaway, include/gene.hh)
+    float apostprob = 1.0f;
+    bool hasProbs = false, viterbi = true, throwaway = false;
+    double meanStateProb() const;
     long geneBegin() const { return transstart >= 0 ? transstart : codingstart; }
     long geneEnd() const { return transend >= 0 ? transend : codingend; }
     bool completeCDS() const;
@@ -42,7 +50,7 @@ struct GeneOut {
     std::string id, seqname;
     bool plus = true;
     long mincodstart = 0, maxcodend = 0;
-    double apostprob = 0;
+    float apostprob = 0;
 };
 
 struct OutputOptions {
@@ -60,6 +68,11 @@ struct PathState { long begin, end; int type; };
 std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vector<PathState> &path, long dnalen);
 // drop transcripts the reference's filterGenePrediction would drop (ab initio: CDS length rules only)
 std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs);
+// the transcripts of the Viterbi path and of the sampled paths of one piece, identical ones united, with the posterior
+// probabilities of transcripts, exons and introns estimated from the sample (reference NAMGene::findGenes, src/namgene.cc:795-905;
+// sampleiterations = the Viterbi path + the sampled ones)
+std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<PathState> &viterbi,
+                                             const std::vector<std::vector<PathState>> &samples, long dnalen, int sampleiterations);
 // group into genes (one path => no overlaps => one transcript per gene), sorted by coding start
 std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs);
 // print the genes of one piece.  seq = the WHOLE input sequence (lower/upper case irrelevant), offset-free coordinates.

@@ -6,6 +6,8 @@
 // piece loop (reference src/namgene.cc:575-676) and of the cut finder's exam windows over devices.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cstdlib>
 #include <numeric>
 #include <string>
@@ -82,6 +84,79 @@ int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *
         if (rcs[d]) {
             setLastError(errs[d]);
             for (int i = 0; i < n; i++) augx_path_free(&out[i]);
+            return rcs[d];
+        }
+    return AUGX_OK;
+}
+
+// Decode + sample.  The draws come from ONE stream over the run, piece after piece in input order (the reference never seeds
+// rand(), src/vitmatrix.cc:312), so the pieces are batched in input order, batch k on device k mod n_dec: the devices decode
+// and run the forward algorithm of their batches concurrently, the host sampling of batch k waits for batch k-1's.
+int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, int n_samples, augx_rand *r,
+                        augx_path *out, augx_path *samples) {
+    if (!decs || n_dec < 1 || !pieces || n < 0 || n_samples < 0 || !r || !out || (n_samples && !samples)) {
+        setLastError("augx_decode_sampled: bad argument");
+        return AUGX_E_ARG;
+    }
+    for (int i = 0; i < n; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = AUGX_E_ARG; out[i].ln_viterbi = 0; }
+    for (int64_t i = 0; i < (int64_t)n * n_samples; i++) { samples[i].states = nullptr; samples[i].n_states = 0; samples[i].status = AUGX_E_ARG; samples[i].ln_viterbi = 0; }
+    if (n == 0) return AUGX_OK;
+    // the forward matrix (S doubles per base) comes on top of what a decode needs: half the bases per batch
+    int64_t budget = augx_decoder_batch_capacity(decs[0]) / 2;
+    for (int d = 1; d < n_dec; d++) budget = std::min<int64_t>(budget, augx_decoder_batch_capacity(decs[d]) / 2);
+    if (const char *e = getenv("AUGX_BATCH_BASES")) budget = atol(e);
+    std::vector<std::pair<int, int>> batches; // [first, last)
+    for (int i = 0; i < n;) {
+        int j = i;
+        int64_t total = 0;
+        while (j < n && (j == i || total + pieces[j].len <= budget)) total += pieces[j++].len;
+        batches.push_back({i, j});
+        i = j;
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    int turn = 0;
+    bool failed = false;
+    std::vector<int> rcs(n_dec, 0);
+    std::vector<std::string> errs(n_dec);
+    auto work = [&](int d) {
+        for (size_t k = (size_t)d; k < batches.size(); k += (size_t)n_dec) {
+            const int first = batches[k].first, cnt = batches[k].second - batches[k].first;
+            augx_batch *b = nullptr;
+            int rc = augx_batch_create(decs[d], pieces + first, cnt, &b);
+            if (!rc) rc = augx_batch_decode(decs[d], b);
+            if (!rc) rc = augx_batch_paths(decs[d], b, out + first);
+            if (!rc && n_samples) rc = augx_batch_forward(decs[d], b);
+            if (rc) errs[d] = augx_last_error();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return turn == (int)k || failed; });
+                if (!rc && !failed)
+                    for (int p = 0; p < cnt && !rc; p++) {
+                        if (out[first + p].status != AUGX_OK) continue; // (no path: nothing is drawn)
+                        rc = augx_batch_sample(decs[d], b, p, n_samples, r, samples + (int64_t)(first + p) * n_samples);
+                        if (rc) errs[d] = augx_last_error();
+                    }
+                if (rc) { rcs[d] = rc; failed = true; }
+                turn = (int)k + 1;
+            }
+            cv.notify_all();
+            if (b) augx_batch_destroy(b);
+            if (rc || failed) return;
+        }
+    };
+    if (n_dec == 1)
+        work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int d = 0; d < n_dec; d++) th.emplace_back(work, d);
+        for (auto &t : th) t.join();
+    }
+    for (int d = 0; d < n_dec; d++)
+        if (rcs[d]) {
+            setLastError(errs[d]);
+            for (int i = 0; i < n; i++) augx_path_free(&out[i]);
+            for (int64_t i = 0; i < (int64_t)n * n_samples; i++) augx_path_free(&samples[i]);
             return rcs[d];
         }
     return AUGX_OK;

@@ -208,6 +208,10 @@ augx_rand *augx_rand_create(unsigned seed);
 int augx_rand_next(augx_rand *r);               /* == rand() of glibc after srand(seed) */
 void augx_rand_destroy(augx_rand *r);
 int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, augx_rand *r, augx_path *out /* array[n_samples] */);
+/* decode + sample n pieces on n_dec devices: out[i] = the Viterbi path of piece i, samples[i * n_samples + k] = its k-th sampled
+ * path; the draws are taken from r in input order (piece 0's first), whatever device a piece ran on */
+int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, int n_samples, augx_rand *r,
+                        augx_path *out /* array[n] */, augx_path *samples /* array[n * n_samples] */);
 void augx_batch_destroy(augx_batch *b);
 
 /* ---- whole-program driver (replaces main(), reference src/augustus.cc:94-248): same argv as `augustus`,
@@ -218,6 +222,12 @@ int augx_main(int argc, const char *const *argv);
  *      printGeneList, reference src/gene.cc:394-700,2465-2524,3071-3120) for one record decoded as one piece ---- */
 int augx_format_gff(const augx_model *m, const char *name, const char *seq, int64_t len, const augx_state *states,
                     int n_states, int first_gene_id, char *out, int64_t out_cap, int *n_genes);
+/* the same with n_samples sampled paths next to the Viterbi path (--sample = n_samples + 1): transcripts of the sample are
+ * united with the Viterbi transcripts, the score columns carry the posterior probabilities (reference NAMGene::findGenes,
+ * src/namgene.cc:795-905) */
+int augx_format_gff_sampled(const augx_model *m, const char *name, const char *seq, int64_t len, const augx_state *states,
+                            int n_states, int n_samples, const augx_state *const *sample_states, const int *sample_n,
+                            int first_gene_id, char *out, int64_t out_cap, int *n_genes);
 
 /* ---- the ordered gather of a sharded run (reference NAMGene::doViterbiPiecewise, src/namgene.cc:526,626-650: gene ids are
  *      numbered over the whole run in input order): the pieces of n_records records, decoded on any device and handed over

@@ -45,6 +45,7 @@ void emu_set_sampling(int n, unsigned seed) {
     delete g_rand;
     g_rand = n > 0 ? new augx_rand(seed) : nullptr;
 }
+int emu_state_type(const augx_tables *t, int s) { return s >= 0 && s < t->S ? t->state_type[s] : -1; }
 int emu_sample_get(int p, int it, int32_t *out, int cap) {
     if (p < 0 || p >= (int)g_samples.size() || it < 0 || it >= (int)g_samples[p].size()) return -1;
     const std::vector<augx_state> &v = g_samples[p][it];

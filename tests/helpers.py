@@ -153,6 +153,28 @@ def ref_forward(fasta, species, extra=(), cfg=None):
     return mats
 
 
+def ref_samples(fasta, species, extra=(), n=5, cfg=None):
+    """n sampled state paths per record from the REAL reference (oracle/_ref/ref_harness --dumpsamples: NAMGene::getSampledPath,
+    rand() never seeded): [[(begin, end, type), ...] per sample] per record"""
+    dump = fasta + ".smp.txt"
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg or config_path())
+    ex = [e for e in extra if not e.startswith("--sample=")]
+    out = subprocess.run([REF_HARNESS, "--species=" + species, "--sample=100"] + ex + ["--dumpsamples=" + dump, "--nsamples=%d" % n, fasta],
+                         capture_output=True, text=True, env=env)
+    assert out.returncode == 0, out.stderr
+    recs = []
+    for l in open(dump):
+        w = l.split()
+        if w[0] == "SEQ":
+            recs.append([])
+        elif w[0] == "SAMPLE":
+            recs[-1].append([])
+        else:
+            recs[-1][-1].append([int(x) for x in w[1:4]])
+    os.remove(dump)
+    return recs
+
+
 # ---------------------------------------------------------------------------------------------------
 # golden vectors (tests/golden/make_golden.py) and the lane-loop emulator of the device kernels
 # ---------------------------------------------------------------------------------------------------
@@ -179,6 +201,38 @@ def more_inputs():
     return read_fasta(os.path.join(GOLDEN, "inputs_more.fa"))
 
 
+# posterior sampling (tests/golden/make_golden_sampled.py): cfg -> (species, options, record names of inputs.fa or None = all).
+# The reference's sampling inside a piece with several GC classes depends on the order its snippet cache was filled in
+# (DESIGN.md); the human cases are the records with one class.
+_ONE_CLASS = ("HS04636", "HS08198", "rand20k_b", "withN", "allN", "short7", "short100", "short600", "iupac", "trunc_left", "trunc_right",
+              "trunc_both", "revcomp", "softmask_rand")
+SAMPLED_CFGS = {
+    "fly": ("fly", {"UTR": "off", "softmasking": "0"}, None),                 # sample = 100 is the species' default
+    "fly_sm": ("fly", {"UTR": "off"}, None),
+    "arabidopsis": ("arabidopsis", {"UTR": "off", "softmasking": "0", "sample": "100"}, None),
+    "human1": ("human", {"sample": "100", "softmasking": "0"}, _ONE_CLASS),
+    "human1_sm": ("human", {"sample": "50"}, _ONE_CLASS),
+}
+
+
+def sampled_records(cfg):
+    names = SAMPLED_CFGS[cfg][2]
+    recs = golden_inputs()
+    if names is None:
+        return recs
+    byname = dict(recs)
+    return [(k, byname[k]) for k in names]
+
+
+def golden_sampled_gff(cfg):
+    return open(os.path.join(GOLDEN, "golden_sampled_%s.gff" % cfg)).read().splitlines()
+
+
+def golden_sampled_paths(cfg):
+    g = json.load(open(os.path.join(GOLDEN, "golden_sampled_paths_%s.json" % cfg)))
+    return [[[tuple(st) for st in smp] for smp in r["samples"]] for r in g["records"]]
+
+
 def golden_inputs():
     return read_fasta(os.path.join(GOLDEN, "inputs.fa"))
 
@@ -202,9 +256,11 @@ class _Piece(ctypes.Structure):
 _emu = None
 
 
-def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None, forward=False):
+def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None, forward=False, samples=0, seed=1):
     """Run the device kernel bodies on the CPU (tests/emu/emu.cc).  Returns [(status, lnv, path, V, cls)]
-    (forward=True: [(status, lnv, path, V, cls, F, lnP)] with the ln forward matrix F and ln P(sequence))."""
+    (forward=True: [(status, lnv, path, V, cls, F, lnP)] with the ln forward matrix F and ln P(sequence);
+    samples=n: [(status, lnv, path, V, cls, F, lnP, [n sampled paths of (begin, end, type)])], drawn from one rand() stream over seqs)."""
+    forward = forward or samples > 0
     global _emu
     if lib is not None:
         _emu_lib = ctypes.CDLL(lib)
@@ -225,7 +281,9 @@ def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=N
     C = np.zeros(tot * S) if cells else None
     FW = np.zeros(tot * S) if forward else None
     lnF = np.zeros(n)
-    rc = (_emu_lib if lib is not None else _emu).emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
+    E = _emu_lib if lib is not None else _emu
+    E.emu_set_sampling(samples, seed)
+    rc = E.emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
                          po.ctypes.data_as(ctypes.c_void_p), cap, pn.ctypes.data_as(ctypes.c_void_p),
                          C.ctypes.data_as(ctypes.c_void_p) if cells else None, cls.ctypes.data_as(ctypes.c_void_p),
                          FW.ctypes.data_as(ctypes.c_void_p) if forward else None, lnF.ctypes.data_as(ctypes.c_void_p))
@@ -236,8 +294,56 @@ def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=N
         Fm = FW[w:w + len(s) * S].reshape(len(s), S) if forward else None
         w += len(s) * S
         rec = (int(st[i]), float(lnv[i]), [tuple(int(x) for x in po[i, k]) for k in range(pn[i])], V, int(cls[i]))
-        out.append(rec + (Fm, float(lnF[i])) if forward else rec)
+        if samples:
+            buf = np.zeros((max(1024, len(s) // 2 + 16), 3), dtype=np.int32)
+            sm = []
+            for it in range(samples):
+                k = E.emu_sample_get(i, it, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+                assert 0 <= k <= len(buf)
+                sm.append([tuple(int(x) for x in buf[q]) for q in range(k)])
+            out.append(rec + (Fm, float(lnF[i]), sm))
+        else:
+            out.append(rec + (Fm, float(lnF[i])) if forward else rec)
+    E.emu_set_sampling(0, 1)
     return out
+
+
+def emu_state_type(tables_ptr, s):
+    return _emu.emu_state_type(tables_ptr, s)
+
+
+def format_gff_sampled(model, recs, paths, samples):
+    """GFF text of the product's gene-structure stage with posterior probabilities (augx_format_gff_sampled): paths[k] the Viterbi
+    path [(begin, end, state, type)], samples[k] the sampled paths [(begin, end, type)] of record k"""
+    import augustus_amd as ax
+    L = ax.lib()
+    out, gid = [], 1
+    for k, ((name, seq), path, smp) in enumerate(zip(recs, paths, samples)):
+        sts = (_St * max(1, len(path)))()
+        for i, (b, e, st, t) in enumerate(path):
+            sts[i].begin, sts[i].end, sts[i].state, sts[i].type = b, e, st, t
+        arrs, ns, ptrs = [], (ctypes.c_int * max(1, len(smp)))(), (ctypes.POINTER(_St) * max(1, len(smp)))()
+        for q, sp in enumerate(smp):
+            a = (_St * max(1, len(sp)))()
+            for i, (b, e, t) in enumerate(sp):
+                a[i].begin, a[i].end, a[i].state, a[i].type = b, e, 0, t
+            arrs.append(a)
+            ns[q] = len(sp)
+            ptrs[q] = ctypes.cast(a, ctypes.POINTER(_St))
+        buf = ctypes.create_string_buffer(16 << 20)
+        ng = ctypes.c_int()
+        rc = L.augx_format_gff_sampled(model._h, name.encode(), seq.encode(), ctypes.c_int64(len(seq)), sts, len(path), len(smp), ptrs, ns,
+                                       gid, buf, ctypes.c_int64(16 << 20), ctypes.byref(ng))
+        assert rc == 0, ax.last_error() if hasattr(ax, "last_error") else rc
+        out.append("# ----- prediction on sequence number %d (length = %d, name = %s) -----" % (k + 1, len(seq), name))
+        out.append("#")
+        out.append("# Predicted genes for sequence number %d on both strands" % (k + 1))
+        out += buf.value.decode().splitlines()
+        if ng.value == 0:
+            out.append("# (none)")
+        gid += ng.value
+        out.append("#")
+    return out[:-1]
 
 
 def format_gff(model, recs, paths):

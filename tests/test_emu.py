@@ -205,6 +205,36 @@ def test_emulated_forward_matches_reference(tmp_path, cfg):
         assert r[6] >= r[1] and r[6] - r[1] < 0.01 * len(seq) + 5
 
 
+@pytest.mark.parametrize("cfg", ["fly", "arabidopsis", "human1", "human1_sm"])
+def test_emulated_sampling_matches_reference_paths(cfg):
+    """posterior sampling of state paths (device/sampler.h on the emulator's forward matrix) against the REAL reference's
+    NAMGene::getSampledPath (tests/golden/make_golden_sampled.py: 5 paths per record, one rand() stream over the records):
+    every sampled path is the reference's, state by state -- the generator, the order of the options and the draw rule agree"""
+    species, opts, _ = SAMPLED_CFGS[cfg]
+    recs = sampled_records(cfg)
+    gold = golden_sampled_paths(cfg)
+    m = ax.Model(config_path(), species, **opts)
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, samples=5)
+    for (name, seq), r, g in zip(recs, res, gold):
+        assert len(g) == 5
+        for it in range(5):
+            assert r[7][it] == g[it], (name, it)
+
+
+@pytest.mark.parametrize("cfg", ["fly", "fly_sm", "human1"])
+def test_emulated_sampling_gff_is_the_reference_binarys(cfg):
+    """--sample=100 end to end on the CPU: emulator decode + forward + 99 sampled paths per record, the host gene stage
+    (genes.cc: posteriorTranscripts) -> the GFF with posterior probabilities of genes, transcripts and CDS is byte-identical
+    to the reference binary's (fly: sample = 100 is the species default; fly_sm: with the soft-masking bonus)"""
+    species, opts, _ = SAMPLED_CFGS[cfg]
+    n = int(opts.get("sample", 100))
+    recs = sampled_records(cfg)
+    m = ax.Model(config_path(), species, **opts)
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, samples=n - 1)
+    paths = [[(b, e, st, emu_state_type(m.tables_ptr, st)) for b, e, st in r[2]] for r in res]
+    assert format_gff_sampled(m, recs, paths, [r[7] for r in res]) == golden_sampled_gff(cfg)
+
+
 @pytest.mark.parametrize("seed", [74, 3, 58, 1007])
 def test_emulated_segments_randomised(monkeypatch, seed):
     """random pieces (real and random DNA, N runs, GC-shifted stretches), random segment lengths, species and init / term kinds:
