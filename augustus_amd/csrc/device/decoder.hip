@@ -1007,8 +1007,9 @@ int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, 
     HIP_TRY(hipMemcpy(&cls, V.cls + piece, 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&nPl, V.nPlanes + piece, 4, hipMemcpyDeviceToHost));
     P.cls0 = cls; P.nPlanes = nPl;
-    P.F.resize((size_t)n * S);
-    HIP_TRY(hipMemcpy(P.F.data(), V.fwd + (o + 1) * S, sizeof(double) * P.F.size(), hipMemcpyDeviceToHost));
+    P.Fown.reset(new double[(size_t)n * S]);
+    P.F = P.Fown.get();
+    HIP_TRY(hipMemcpy(P.Fown.get(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)n * S, hipMemcpyDeviceToHost));
     P.sig.resize((size_t)n * NSIG);
     HIP_TRY(hipMemcpy(P.sig.data(), V.sig + (o + 1) * NSIG, sizeof(double) * P.sig.size(), hipMemcpyDeviceToHost));
     if (nPl > 1) {

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <memory>
 #include <unordered_map>
 #include <vector>
 #include "dp.h"
@@ -13,8 +14,8 @@
 // glibc's rand(): the TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31] of random_r.c, seeded by the Lehmer
 // generator 16807 * x mod 2^31-1, the first 310 outputs discarded, the result shifted right by one
 struct augx_rand {
-    uint32_t r[34];
-    int k = 0;
+    uint32_t r[64]; // ring of the last 64 values (34 are needed)
+    unsigned k = 0;
     explicit augx_rand(unsigned seed) {
         int32_t st[34];
         st[0] = seed == 0 ? 1 : (int32_t)seed;
@@ -25,13 +26,16 @@ struct augx_rand {
             st[i] = (int32_t)w;
         }
         for (int i = 31; i < 34; i++) st[i] = st[i - 31];
+        for (int i = 0; i < 64; i++) r[i] = 0;
         for (int i = 0; i < 34; i++) r[i] = (uint32_t)st[i];
+        k = 34;
         for (int i = 34; i < 344; i++) (void)step();
     }
-    uint32_t step() { // r[k] = r[k-31] + r[k-3] on a ring of 34
-        const uint32_t v = r[(k + 34 - 31) % 34] + r[(k + 34 - 3) % 34];
-        r[k % 34] = v;
-        k = (k + 1) % 34;
+    void skip(int64_t n) { for (int64_t i = 0; i < n; i++) (void)step(); }
+    uint32_t step() { // r[k] = r[k-31] + r[k-3]
+        const uint32_t v = r[(k - 31) & 63] + r[(k - 3) & 63];
+        r[k & 63] = v;
+        k++;
         return v;
     }
     int next() { return (int)(step() >> 1); }
@@ -43,7 +47,8 @@ namespace dev {
 struct SamplePiece {
     int n = 0, S = 0, blk = 8, nPlanes = 1;
     const augx_tables *t = nullptr;
-    std::vector<double> F;        // [n][S] ln forward
+    const double *F = nullptr;    // [n][S] ln forward
+    std::unique_ptr<double[]> Fown; // (the device library keeps its host copy here)
     std::vector<double> sig;      // [n][NSIG]
     std::vector<uint8_t> plane;   // [n] (empty: one class)
     std::vector<int32_t> planeCls;
@@ -150,6 +155,26 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
     status.assign((size_t)n_samples, AUGX_OK);
     std::unordered_map<uint64_t, OptList> memo; // the options of a (base, state) pair are the same for every sample
     std::vector<augx_state> st;
+    // Most steps of a path are a single-base state (intergenic region, long intron) following itself with no alternative: the
+    // draw is spent (the reference draws for a list of one, too) but decides nothing.  stops[s] = the bases, in increasing
+    // order, where state s has anything but that one option; between two of them a path runs through without looking.
+    std::vector<std::vector<int32_t>> stops((size_t)S);
+    std::vector<char> haveStops((size_t)S, 0);
+    auto buildStops = [&](int s) {
+        std::vector<int32_t> &v = stops[s];
+        const int sg = t.state_kind[s] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
+        for (int j = 1; j < n; j++) {
+            int cnt = 0;
+            bool self = false;
+            if (P.sig[(size_t)j * NSIG + sg] > -INFINITY)
+                for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                    const int a = t.anc[s][ai];
+                    if (P.F[(size_t)(j - 1) * S + a] > -INFINITY && P.lnT(j, a, s) > -INFINITY) { cnt++; self = self || a == s; }
+                }
+            if (!(cnt == 1 && self)) v.push_back(j);
+        }
+        haveStops[s] = 1;
+    };
     for (int it = 0; it < n_samples; it++) {
         st.clear();
         // a piece without a nucleotide: one intergenic state, no draw (reference src/namgene.cc:380-384)
@@ -167,6 +192,19 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
             int base = c->base, state = c->state;
             bool bad = false;
             while (base > 0) {
+                const int kd = t.state_kind[state];
+                if (kd == AUGX_K_IGENIC || kd == AUGX_K_GEOMETRIC || kd == AUGX_K_RGEOMETRIC) {
+                    if (!haveStops[state]) buildStops(state);
+                    const std::vector<int32_t> &v = stops[state];
+                    auto ub = std::upper_bound(v.begin(), v.end(), base); // first stop > base
+                    const int stop = ub == v.begin() ? 0 : *(ub - 1);     // the last stop <= base (0: none, run to the first base)
+                    if (stop < base) {
+                        R.skip(base - stop);
+                        st.push_back({stop + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
+                        base = stop;
+                        continue;
+                    }
+                }
                 const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;
                 auto f = memo.find(key);
                 if (f == memo.end()) { f = memo.emplace(key, OptList()).first; buildOptions(P, state, base, f->second); }

@@ -111,6 +111,17 @@ def cpu_baseline(cfg, sample_bp, host_sample_bp):
                "param_load_s": t_load, "ok": ok1,
                "sample": "1 contig x %d bp uniform-random DNA, --species=human, reference binary pinned with taskset to one core, wall-clock minus "
                          "parameter load" % sample_bp}
+        # the same with posterior sampling (--sample=100) on a shorter sample: the forward pass and 99 sampled paths
+        smp_bp = min(sample_bp, 200000)
+        smp = os.path.join(d, "smp.fa")
+        write_fasta(smp, [("sample", synth_contigs(1, smp_bp, 999)[0].decode())])
+        t0 = time.time()
+        p = subprocess.Popen(["taskset", "-c", str(cores[0]), REF_AUGUSTUS, "--species=human", "--sample=100", smp], stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL, env=env)
+        oks = p.wait() == 0
+        ts = time.time() - t0
+        out["sampled"] = {"value": smp_bp / 1e6 / max(ts - t_load, 1e-9), "unit": "Mbp/s", "cores": 1, "ok": oks,
+                          "sample": "1 contig x %d bp, --species=human --sample=100, pinned to one core, wall-clock minus parameter load" % smp_bp}
         cores = cores[:16]  # (a bounded sample: boxes whose affinity mask shows hundreds of cores may grant far fewer)
         files = []
         for i, c in enumerate(cores):
@@ -187,6 +198,20 @@ def e2e_legs(cfg, model, local, contigs):
             dt = time.perf_counter() - t0
             out["cli"] = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode,
                           "region": "augustus --species=human bench.fa (process start, parameter load, FASTA parse, decode on 1 GPU, GFF file written)"}
+            # ---- the same executable with posterior sampling (the default of 162 of the reference's species): forward algorithm on the
+            #      device, 99 sampled paths per contig on the host, posterior probabilities in the GFF
+            ns = min(n, 8)
+            fa2 = os.path.join(d, "bench_s.fa")
+            with open(fa2, "wb") as f:
+                for nm, s in list(zip(names, contigs))[:ns]:
+                    f.write(b">" + nm.encode() + b"\n" + s + b"\n")
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "--species=human", "--sample=100", "--outfile=" + os.path.join(d, "out_s.gff"), fa2], capture_output=True, env=env)
+            dt = time.perf_counter() - t0
+            b2 = sum(len(c) for c in contigs[:ns])
+            out["cli_sampled"] = {"value": b2 / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "contigs": ns,
+                                  "region": "augustus --species=human --sample=100 (Viterbi + forward on 1 GPU, 99 sampled paths per contig on the host, "
+                                            "posterior probabilities in the GFF)"}
     return out
 
 

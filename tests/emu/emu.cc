@@ -279,7 +279,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             const int len = L.len[p], S = t->S;
             const int64_t o = L.off[p];
             P.t = t; P.S = S; P.n = len; P.blk = blk; P.cls0 = cls[p]; P.nPlanes = B.nPlanes[p]; P.termKind = L.termKind[p];
-            P.F.assign(B.fwd + (o + 1) * S, B.fwd + (o + 1 + len) * S);
+            P.F = B.fwd + (o + 1) * S;
             P.sig.assign(B.sig + (o + 1) * NSIG, B.sig + (o + 1 + len) * NSIG);
             if (P.nPlanes > 1) {
                 P.plane.assign(B.gcPlane + o + 1, B.gcPlane + o + 1 + len);
