@@ -10,3 +10,11 @@ struct augx_model {
 namespace augx {
 void setLastError(const std::string &m);
 }
+
+// sampling in two halves (device/decoder.hip): what the sampler reads of a piece is fetched and indexed ahead of the sampling
+struct augx_sample_prep;
+extern "C" {
+int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sample_prep **out);
+int augx_sample_prep_run(augx_sample_prep *h, int n_samples, augx_rand *R, augx_path *out);
+void augx_sample_prep_destroy(augx_sample_prep *h);
+}

@@ -403,6 +403,7 @@ struct augx_batch {
     int64_t *dListOffs = nullptr;
     void *planeBufs[20] = {};  // (ensureArrays)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
+    hipEvent_t evFwd = nullptr; // forward matrix complete (the sampler waits for this, not for what the stream got after it)
     uint64_t nItems = 0, nPairs = 0;
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
     bool decoded = false;
@@ -565,6 +566,7 @@ void augx_batch_destroy(augx_batch *b) {
     if (b->itemBuf) devFree(b->dec, b->itemBuf);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
+    if (b->evFwd) (void)hipEventDestroy(b->evFwd);
     delete b;
 }
 
@@ -963,6 +965,8 @@ int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     else if (d->blk == 4) hipLaunchKernelGGL(kForward<4>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     else hipLaunchKernelGGL(kForward<2>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
+    if (!b->evFwd) HIP_TRY(hipEventCreateWithFlags(&b->evFwd, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->evFwd, d->stream));
     return AUGX_OK;
 }
 
@@ -983,26 +987,31 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
 
 #include "sampler.h"
 
+struct augx_sample_prep { SamplePiece P; };
+
 extern "C" {
 
 augx_rand *augx_rand_create(unsigned seed) { return new augx_rand(seed); }
 int augx_rand_next(augx_rand *r) { return r ? r->next() : -1; }
 void augx_rand_destroy(augx_rand *r) { delete r; }
 
-int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, augx_rand *R, augx_path *out) {
-    if (!d || !b || !R || !out || piece < 0 || piece >= b->V.nPieces || n_samples < 0 || !b->V.fwd) {
+// everything the host sampler reads of one piece, fetched from HBM, and the sampler's look-up tables: independent of the draws,
+// so a run prepares the pieces ahead of the sampling, on other threads (sharded.cc)
+int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sample_prep **out) {
+    if (!d || !b || !out || piece < 0 || piece >= b->V.nPieces || !b->V.fwd) {
         setLastError("augx_batch_sample: bad argument (run augx_batch_forward first)");
         return AUGX_E_ARG;
     }
+    *out = nullptr;
     HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (b->evFwd) HIP_TRY(hipEventSynchronize(b->evFwd)); else HIP_TRY(hipStreamSynchronize(d->stream));
     const BatchView &V = b->V;
     const augx_tables &t = d->model->m.t;
-    SamplePiece P;
+    std::unique_ptr<augx_sample_prep> H(new augx_sample_prep());
+    SamplePiece &P = H->P;
     P.t = &t; P.S = t.S; P.n = b->L.len[piece]; P.blk = V.blk;
     const int n = P.n, S = P.S;
     const int64_t o = b->L.off[piece];
-    for (int i = 0; i < n_samples; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = 0; out[i].ln_viterbi = 0; }
     int32_t cls = 0, nPl = 1;
     HIP_TRY(hipMemcpy(&cls, V.cls + piece, 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&nPl, V.nPlanes + piece, 4, hipMemcpyDeviceToHost));
@@ -1044,9 +1053,19 @@ int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, 
         P.anyNuc = false;
         for (int q = 0; q < n && !P.anyNuc; q++) P.anyNuc = code[q] < 4;
     }
+    prepareStops(P);
+    *out = H.release();
+    return AUGX_OK;
+}
+
+void augx_sample_prep_destroy(augx_sample_prep *h) { delete h; }
+
+int augx_sample_prep_run(augx_sample_prep *h, int n_samples, augx_rand *R, augx_path *out) {
+    if (!h || !R || !out || n_samples < 0) { setLastError("augx_sample_prep_run: bad argument"); return AUGX_E_ARG; }
+    for (int i = 0; i < n_samples; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = 0; out[i].ln_viterbi = 0; }
     std::vector<std::vector<augx_state>> paths;
     std::vector<int> status;
-    samplePaths(P, n_samples, *R, paths, status);
+    samplePaths(h->P, n_samples, *R, paths, status);
     for (int it = 0; it < n_samples; it++) {
         out[it].status = status[it];
         if (status[it] != AUGX_OK) continue;
@@ -1057,6 +1076,15 @@ int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, 
         out[it].n_states = (int32_t)m2.size();
     }
     return AUGX_OK;
+}
+
+int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, augx_rand *R, augx_path *out) {
+    if (!R || !out || n_samples < 0) { setLastError("augx_batch_sample: bad argument"); return AUGX_E_ARG; }
+    augx_sample_prep *h = nullptr;
+    int rc = augx_batch_sample_prepare(d, b, piece, &h);
+    if (!rc) rc = augx_sample_prep_run(h, n_samples, R, out);
+    augx_sample_prep_destroy(h);
+    return rc;
 }
 
 int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out) {

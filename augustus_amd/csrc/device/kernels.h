@@ -2344,14 +2344,18 @@ AUGX_HD double lse2(double a, double b) { // ln(e^a + e^b)
     return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
 }
 #ifdef AUGX_EMU
-inline void ldsAddD(double *p, double v) { *p += v; }
+inline void ldsAddU(unsigned long long *p, unsigned long long v) { *p += v; }
 #else
-__device__ inline void ldsAddD(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_add_f64
+__device__ inline void ldsAddU(unsigned long long *p, unsigned long long v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } // ds_add_u64
 #endif
+// the sum over the candidates of a cell is taken in fixed point (terms in (0, 1], 2^-52 apart; < 2048 of them): integer adds
+// commute, so the result does not depend on the order the wavefronts' atomics arrive in -- the same forward matrix, hence the
+// same sampled paths, run after run
+constexpr double FWD_FIX = 4503599627370496.0; // 2^52
 struct FwdLds {
     double ring[WAVE][SP];   // ln F of the last 64 columns, [j & 63][state]
     double cmax[8][SP];      // variable-length cells of the current block: largest candidate ...
-    double csum[8][SP];      // ... and the sum of exp(candidate - largest)
+    unsigned long long csum[8][SP]; // ... and the sum of exp(candidate - largest), fixed point (FWD_FIX)
 };
 template <int BLK>
 AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, int p) {
@@ -2396,7 +2400,7 @@ AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, in
         const int64_t gb = o / BLK + b;
         // ---- A: fixed-lag states; accumulators of the variable-length cells
         FOR_THREADS(t) {
-            if (t < BLK * SP) { L.cmax[t / SP][t % SP] = AUGX_NINF; L.csum[t / SP][t % SP] = 0.0; }
+            if (t < BLK * SP) { L.cmax[t / SP][t % SP] = AUGX_NINF; L.csum[t / SP][t % SP] = 0ull; }
             if (t < nFix * BLK) {
                 const int s2 = fixS[t / BLK], j = jb + t % BLK, k = T.kind[s2];
                 if (j >= 1 && j < n) {
@@ -2466,7 +2470,7 @@ AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, in
                 for (uint32_t it = lo + (uint32_t)t; it < hi; it += NT) {
                     int dj, s2;
                     const double v = candValue(ldItem(B.items + i0 + it), dj, s2);
-                    if (v > AUGX_NINF) ldsAddD(&L.csum[dj][s2], exp(v - L.cmax[dj][s2]));
+                    if (v > AUGX_NINF) ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - L.cmax[dj][s2]) * FWD_FIX));
                 }
             }
             BLOCK_SYNC();
@@ -2479,7 +2483,7 @@ AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, in
                         const int k = T.kind[s2];
                         const bool var = (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD;
                         if (var && (k == AUGX_K_RTERMINAL) == rt) {
-                            const double f = L.csum[dj][s2] > 0.0 ? L.cmax[dj][s2] + log(L.csum[dj][s2]) : AUGX_NINF;
+                            const double f = L.csum[dj][s2] > 0ull ? L.cmax[dj][s2] + log((double)L.csum[dj][s2] / FWD_FIX) : AUGX_NINF;
                             L.ring[j & 63][s2] = f;
                             if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
                         }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <unordered_map>
 #include <vector>
@@ -59,6 +60,9 @@ struct SamplePiece {
     uint64_t item0 = 0;
     int igS = -1, termKind = 0;
     bool anyNuc = true;
+    // filled by prepareStops (may run on another thread, ahead of the sampling): see samplePaths
+    std::vector<std::vector<int32_t>> stops, stopOpt;
+    bool prepared = false;
     double lnT(int j, int a, int s) const {
         const int c = plane.empty() ? cls0 : planeCls[plane[j]];
         return t->ln_trans[((int64_t)c * S + a) * S + s];
@@ -145,24 +149,19 @@ inline void sortOptions(OptList &L) {
     L.o.swap(o2); L.p.swap(p2);
 }
 
-// n_samples paths of one piece, 5'->3', runs of the single-base chain states merged (as the Viterbi path is delivered)
-inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector<std::vector<augx_state>> &paths, std::vector<int> &status) {
+// Most steps of a path are a single-base state (intergenic region, long intron) following itself with no alternative: the
+// draw is spent (the reference draws for a list of one, too) but decides nothing.  stops[s] = the bases, in increasing order,
+// where chain state s has anything but that one option; between two of them a path runs through without looking.
+inline void prepareStops(SamplePiece &P) {
     const augx_tables &t = *P.t;
     const int n = P.n, S = P.S;
-    for (int s2 = 0; s2 < S; s2++)
-        if (t.state_kind[s2] == AUGX_K_IGENIC && P.igS < 0) P.igS = s2;
-    paths.assign((size_t)n_samples, {});
-    status.assign((size_t)n_samples, AUGX_OK);
-    std::unordered_map<uint64_t, OptList> memo; // the options of a (base, state) pair are the same for every sample
-    std::vector<augx_state> st;
-    // Most steps of a path are a single-base state (intergenic region, long intron) following itself with no alternative: the
-    // draw is spent (the reference draws for a list of one, too) but decides nothing.  stops[s] = the bases, in increasing
-    // order, where state s has anything but that one option; between two of them a path runs through without looking.
-    std::vector<std::vector<int32_t>> stops((size_t)S);
-    std::vector<char> haveStops((size_t)S, 0);
-    auto buildStops = [&](int s) {
-        std::vector<int32_t> &v = stops[s];
-        const int sg = t.state_kind[s] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
+    P.stops.assign((size_t)S, {});
+    P.stopOpt.assign((size_t)S, {});
+    for (int s = 0; s < S && P.anyNuc; s++) {
+        const int kd = t.state_kind[s];
+        if (kd != AUGX_K_IGENIC && kd != AUGX_K_GEOMETRIC && kd != AUGX_K_RGEOMETRIC) continue;
+        std::vector<int32_t> &v = P.stops[s];
+        const int sg = kd == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
         for (int j = 1; j < n; j++) {
             int cnt = 0;
             bool self = false;
@@ -173,8 +172,25 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                 }
             if (!(cnt == 1 && self)) v.push_back(j);
         }
-        haveStops[s] = 1;
-    };
+        P.stopOpt[s].assign(v.size(), -1);
+    }
+    P.prepared = true;
+}
+
+// n_samples paths of one piece, 5'->3', runs of the single-base chain states merged (as the Viterbi path is delivered)
+inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector<std::vector<augx_state>> &paths, std::vector<int> &status) {
+    const augx_tables &t = *P.t;
+    const int n = P.n, S = P.S;
+    for (int s2 = 0; s2 < S; s2++)
+        if (t.state_kind[s2] == AUGX_K_IGENIC && P.igS < 0) P.igS = s2;
+    paths.assign((size_t)n_samples, {});
+    status.assign((size_t)n_samples, AUGX_OK);
+    std::unordered_map<uint64_t, OptList> memo; // the options of a (base, state) pair are the same for every sample
+    std::vector<augx_state> st;
+    if (!P.prepared) prepareStops(P);
+    std::vector<std::vector<int32_t>> &stops = P.stops, &stopOpt = P.stopOpt;
+    std::deque<OptList> pool;
+    std::vector<int64_t> cur((size_t)S, 0); // per sample: index of the last stop <= the base the path was last at in this state
     for (int it = 0; it < n_samples; it++) {
         st.clear();
         // a piece without a nucleotide: one intergenic state, no draw (reference src/namgene.cc:380-384)
@@ -191,19 +207,34 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
             if (!c) { status[it] = AUGX_E_NOPATH; continue; }
             int base = c->base, state = c->state;
             bool bad = false;
+            for (int s2 = 0; s2 < S; s2++) cur[s2] = (int64_t)stops[s2].size() - 1;
             while (base > 0) {
                 const int kd = t.state_kind[state];
                 if (kd == AUGX_K_IGENIC || kd == AUGX_K_GEOMETRIC || kd == AUGX_K_RGEOMETRIC) {
-                    if (!haveStops[state]) buildStops(state);
                     const std::vector<int32_t> &v = stops[state];
-                    auto ub = std::upper_bound(v.begin(), v.end(), base); // first stop > base
-                    const int stop = ub == v.begin() ? 0 : *(ub - 1);     // the last stop <= base (0: none, run to the first base)
+                    // the last stop <= base: bases only fall along a path, so the cursor of the state only moves down -- a step
+                    // at a time while the path stays in the state, by bisection when it comes back to it further down
+                    int64_t c = cur[state];
+                    if (c >= (int64_t)v.size()) c = (int64_t)v.size() - 1;
+                    if (c >= 0 && v[c] > base) {
+                        if (c >= 1 && v[c - 1] <= base) c--;
+                        else c = (int64_t)(std::upper_bound(v.begin(), v.begin() + c, base) - v.begin()) - 1;
+                    }
+                    cur[state] = c;
+                    const int stop = c < 0 ? 0 : v[c];
                     if (stop < base) {
                         R.skip(base - stop);
                         st.push_back({stop + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
                         base = stop;
                         continue;
                     }
+                    int32_t &oi = stopOpt[state][c];
+                    if (oi < 0) { pool.emplace_back(); oi = (int32_t)pool.size() - 1; buildOptions(P, state, base, pool[oi]); }
+                    const Opt *x = drawOption(pool[oi], R);
+                    if (!x) { bad = true; break; }
+                    st.push_back({x->base + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
+                    base = x->base; state = x->state;
+                    continue;
                 }
                 const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;
                 auto f = memo.find(key);

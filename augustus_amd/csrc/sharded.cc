@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <future>
 #include <mutex>
 #include <cstdlib>
 #include <numeric>
@@ -128,16 +129,37 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             if (!rc) rc = augx_batch_paths(decs[d], b, out + first);
             if (!rc && n_samples) rc = augx_batch_forward(decs[d], b);
             if (rc) errs[d] = augx_last_error();
+            // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
+            // (it does not depend on the draws), also while earlier batches are still being sampled
+            const int AHEAD = 4;
+            std::vector<std::future<std::pair<int, augx_sample_prep *>>> prep((size_t)cnt);
+            auto launch = [&](int p) {
+                if (p >= cnt || rc || !n_samples || out[first + p].status != AUGX_OK) return;
+                prep[p] = std::async(std::launch::async, [&, p]() {
+                    augx_sample_prep *h = nullptr;
+                    const int r = augx_batch_sample_prepare(decs[d], b, p, &h);
+                    return std::make_pair(r, h);
+                });
+            };
+            for (int p = 0; p < AHEAD; p++) launch(p);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return turn == (int)k || failed; });
-                if (!rc && !failed)
-                    for (int p = 0; p < cnt && !rc; p++) {
-                        if (out[first + p].status != AUGX_OK) continue; // (no path: nothing is drawn)
-                        rc = augx_batch_sample(decs[d], b, p, n_samples, r, samples + (int64_t)(first + p) * n_samples);
-                        if (rc) errs[d] = augx_last_error();
+                for (int p = 0; p < cnt; p++) {
+                    if (!prep[p].valid()) { launch(p + AHEAD); continue; } // (no path: nothing is drawn)
+                    std::pair<int, augx_sample_prep *> pr = prep[p].get();
+                    launch(p + AHEAD);
+                    if (!rc && !failed) {
+                        rc = pr.first;
+                        if (rc) errs[d] = augx_last_error(); // (thread-local: set again below if it was another thread's)
+                        if (!rc) {
+                            rc = augx_sample_prep_run(pr.second, n_samples, r, samples + (int64_t)(first + p) * n_samples);
+                            if (rc) errs[d] = augx_last_error();
+                        }
                     }
-                if (rc) { rcs[d] = rc; failed = true; }
+                    augx_sample_prep_destroy(pr.second);
+                }
+                if (rc) { rcs[d] = rc; failed = true; if (errs[d].empty()) errs[d] = "augx_decode_sampled: fetching a piece for the sampler failed"; }
                 turn = (int)k + 1;
             }
             cv.notify_all();
