@@ -977,6 +977,13 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
     const int S = d->hostT.S;
     if (out) HIP_TRY(hipMemcpy(out, b->V.fwd + (b->L.off[piece] + 1) * S, sizeof(double) * (size_t)b->L.len[piece] * S, hipMemcpyDeviceToHost));
     if (ln_p) HIP_TRY(hipMemcpy(ln_p, b->V.lnFwd + piece, sizeof(double), hipMemcpyDeviceToHost));
+    if (b->V.prof) { // developer aid (AUGX_PROF=1): where thread 0 of the forward kernel spent its time
+        uint64_t h[12];
+        HIP_TRY(hipMemcpy(h, b->V.prof + (int64_t)piece * 56, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "forward piece %d, ticks of thread 0:", piece);
+        for (int k = 0; k < 11; k++) fprintf(stderr, " [%d]=%.2fM", k, h[k] / 1e6);
+        fprintf(stderr, "  (0 loop, 1 A, 2 B others, 3 B run, 4 C max+sum, 5 C cells, 6 D others, 7 D run, 8 E max+sum, 9 E cells, 10 fence)\n");
+    }
     return AUGX_OK;
 }
 

@@ -65,6 +65,7 @@ constexpr int NWAVES = 8, NT = NWAVES * WAVE;
 // loads and stores do not count against the LDS wait counter (flat instructions do)
 #ifdef AUGX_EMU
 template <class T> inline T *gp(T *p) { return p; }
+template <class T> inline T *lp(T *p) { return p; }
 inline double ldsLoadD(const double *p) { return *p; }
 inline Item ldItem(const Item *p) { return *p; }
 inline IntronStart ldIntronStart(const IntronStart *p) { return *p; }
@@ -76,6 +77,7 @@ inline IntronStart ldIntronStart(const IntronStart *p) { return *p; }
 #define AUGX_LDS __attribute__((address_space(3)))
 __device__ __forceinline__ double ldsLoadD(const double *p) { return *(const AUGX_LDS double *)p; }
 template <class T> __device__ __forceinline__ AUGX_GLOBAL T *gp(T *p) { return (AUGX_GLOBAL T *)p; }
+template <class T> __device__ __forceinline__ AUGX_LDS T *lp(T *p) { return (AUGX_LDS T *)p; } // (a pointer into the LDS, re-typed)
 __device__ __forceinline__ Item ldItem(const Item *p) { // one 16-byte global load
     typedef int v4i __attribute__((ext_vector_type(4)));
     const v4i r = *(const AUGX_GLOBAL v4i *)p;
@@ -2338,7 +2340,9 @@ AUGX_HD void tileCrossOne(const BatchView &B, int64_t gt) {
 // The dense ln F matrix goes to HBM (the host's sampler walks it); the last 64 columns also live in an LDS ring.
 // Sums are not exact (exp / log round): the result agrees with the reference's LLDouble sums to ~1e-12 relative.
 // =================================================================================================
-AUGX_HD double lse2(double a, double b) { // ln(e^a + e^b)
+// (not inlined: exp and log1p are a few hundred instructions, and the forward kernel has dozens of call sites -- inlined, a block
+//  of 8 bases walked through more code than the instruction cache holds)
+__attribute__((noinline)) AUGX_HD double lse2(double a, double b) { // ln(e^a + e^b)
     if (!(a > AUGX_NINF)) return b;
     if (!(b > AUGX_NINF)) return a;
     return a > b ? a + log1p(exp(b - a)) : b + log1p(exp(a - b));
@@ -2356,32 +2360,69 @@ struct FwdLds {
     double ring[WAVE][SP];   // ln F of the last 64 columns, [j & 63][state]
     double cmax[8][SP];      // variable-length cells of the current block: largest candidate ...
     unsigned long long csum[8][SP]; // ... and the sum of exp(candidate - largest), fixed point (FWD_FIX)
+    double lt[SP][SP];       // ln transition a -> s of the piece's first class (a piece with one class never leaves it)
+    double sg[2][8][NSIG];   // signal records of the block ([parity of the block]; the next block's are staged meanwhile)
+    uint64_t bOff[2];        // candidates of the block: first record ...
+    uint32_t bCnt[2][2];     // ... their number, and how many of them are not RTERMINAL  ([parity of the block])
+    uint8_t anc[SP][4];      // ancestor ai of a variable-length state (the candidate records name it by index)
+    uint8_t cellKind[SP];    // 1: variable-length state (all but RTERMINAL), 2: RTERMINAL, 0: no cell of the candidate steps
+    // the single-base ("chain") states: slot 0..6 the geometric intron states, slot 7 the intergenic state
+    int chS[8], chNa[8], chAnc[8][5];
+    uint8_t chLive[8][5];    // the ancestor is a chain state itself (its cell of the base before is made in the same step)
+    uint8_t chSelf[8], chOther[8]; // ... the state itself is among them / another chain state is
+    int chNd[8], chDead[8][5];     // the ancestors that are not chain states, packed
+    double oth[8][8];        // [slot][base of the block]: ln sum over the other ancestors' contributions
 };
+// One workgroup walks a piece block by block (BLK bases).  What a block needs from HBM is independent of the forward values and is
+// in flight a block ahead: the candidate records in registers (the first NT of a block; more are rare and loaded when needed),
+// the block's offsets and signal records in LDS.  A candidate's value is computed once and kept in a register between the
+// max, the sum and the cell step.  The columns of a block are written to HBM as they are made; only columns older than the ring
+// (64 bases) are read back from there, so the stores are fenced every fourth block, not every block.
 template <int BLK>
 AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, int p) {
     const int n = B.len[p], S = T.S, c0 = B.cls[p];
     const int64_t o = B.off[p];
     double *F = B.fwd + (o + 1) * S; // F[q * S + s]
+    // (the BatchView's pointers and the piece's scalars once, in registers: the stores to F could alias them for all the compiler
+    //  knows, and every one of them would be fetched again after every store)
+    const double *gSig = B.sig + (o + 1) * NSIG;
+    const Item *gItems = B.items;
+    const uint64_t *gBlkOff = B.blkOff;
+    const uint32_t *gBlkCnt = B.blkCnt, *gBlkSplit = B.blkSplit;
+    const uint8_t *gPlane = B.gcPlane + o + 1;
+    const int32_t *gPlaneCls = B.planeCls + p * MAXPL;
+    const int initKind = B.initKind[p], termKind = B.termKind[p], synch = T.synch;
     if (c0 < 0) { FOR_THREADS(t) { if (t == 0) B.lnFwd[p] = AUGX_NINF; } return; }
     const bool multi = B.nPlanes[p] > 1;
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
-    auto clsAt = [&](int j) { return multi ? B.planeCls[p * MAXPL + B.gcPlane[o + 1 + j]] : c0; };
+    auto clsAt = [&](int j) __attribute__((always_inline)) { return multi ? (int)gp(gPlaneCls)[gp(gPlane)[j]] : c0; };
+    // (two loads behind a branch, not one load through a selected pointer: that would be a flat load, slower than either)
+    const double *gTrans = T.ln_trans;
+    auto trn = [&](int cc, int a, int s2) __attribute__((always_inline)) -> double { if (multi) return gp(gTrans)[((int64_t)cc * S + a) * S + s2]; return ldsLoadD(&L.lt[a][s2]); };
     // value of state a at base q: from the ring while no base of the block being computed (first base jb) has taken its column,
     // from HBM before
-    auto at = [&](int q, int a, int jb) -> double {
+    auto at = [&](int q, int a, int jb) __attribute__((always_inline)) -> double {
         if (q < 0) return AUGX_NINF;
-        return jb + BLK - 1 - q < WAVE ? L.ring[q & 63][a] : ldCoherent(&F[(int64_t)q * S + a]);
+        if (jb + BLK - 1 - q < WAVE) return ldsLoadD(&L.ring[q & 63][a]);
+        return ldCoherent(&F[(int64_t)q * S + a]);
     };
     FOR_THREADS(t) {
-        for (int i = t; i < WAVE * SP; i += NT) L.ring[i / SP][i % SP] = AUGX_NINF;
-        for (int i = t; i < n * S; i += NT) F[i] = AUGX_NINF; // (absent cells stay -inf)
+        for (int i = t; i < WAVE * SP; i += NT) (*lp(&L.ring[i / SP][i % SP])) = AUGX_NINF;
+        for (int i = t; i < SP * SP; i += NT) (*lp(&L.lt[i / SP][i % SP])) = (i / SP < S && i % SP < S) ? lnT(T, c0, i / SP, i % SP) : AUGX_NINF;
+        if (t < SP) {
+            const int k = t < S && T.reachable[t] ? T.kind[t] : -1;
+            const bool var = (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD;
+            (*lp(&L.cellKind[t])) = !var ? 0 : k == AUGX_K_RTERMINAL ? 2 : 1;
+            for (int ai = 0; ai < 4; ai++) (*lp(&L.anc[t][ai])) = (uint8_t)((t < S && ai < T.n_anc[t]) ? T.anc[t][ai] : 0);
+        }
+        for (int i = t; i < n * S; i += NT) gp(F)[i] = AUGX_NINF; // (absent cells stay -inf)
     }
     BLOCK_GLOBAL_SYNC();
     FOR_THREADS(t) { // column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
         if (t < S) {
-            const double v = B.initKind[p] == 0 ? T.ln_init[t] : (t == T.synch ? 0.0 : AUGX_NINF);
-            L.ring[0][t] = v;
-            F[t] = v;
+            const double v = initKind == 0 ? T.ln_init[t] : (t == synch ? 0.0 : AUGX_NINF);
+            (*lp(&L.ring[0][t])) = v;
+            gp(F)[t] = v;
         }
     }
     BLOCK_GLOBAL_SYNC();
@@ -2395,135 +2436,290 @@ AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, in
         else if (k == AUGX_K_IGENIC) igS = s2;
     }
     const int nBlocks = (n + BLK - 1) / BLK;
+    const int64_t gb0 = o / BLK;
+    // per-thread constants of the fixed-lag step (thread = (state, base of the block)): state, lag, signal, ancestors -- read from the
+    // tables once, not in every block
+    TV(int, fS2); TV(int, fLag); TV(int, fSg); TV(int, fNa); TV2(int, fAn, 4);
+    FOR_THREADS(t) {
+        TX(fS2) = -1; TX(fLag) = 1; TX(fSg) = 0; TX(fNa) = 0;
+        for (int ai = 0; ai < 4; ai++) fAn[ai][TI] = 0;
+        if (t >= WAVE && t - WAVE < nFix * BLK) {
+            const int s2 = fixS[(t - WAVE) / BLK], k = T.kind[s2];
+            TX(fS2) = s2;
+            TX(fLag) = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
+            TX(fSg) = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
+            TX(fNa) = T.n_anc[s2] < 4 ? T.n_anc[s2] : 4;
+            for (int ai = 0; ai < 4; ai++) if (ai < TX(fNa)) fAn[ai][TI] = T.anc[s2][ai];
+        }
+        if (t < 8) {
+            const int s2 = t < nGeo ? geoS[t] : (t == 7 ? igS : -1);
+            (*lp(&L.chS[t])) = s2;
+            (*lp(&L.chNa[t])) = s2 >= 0 ? (T.n_anc[s2] < 5 ? T.n_anc[s2] : 5) : 0;
+            for (int ai = 0; ai < 5; ai++) {
+                const int a = (s2 >= 0 && ai < (*lp(&L.chNa[t]))) ? T.anc[s2][ai] : 0;
+                const int ak = T.kind[a];
+                (*lp(&L.chAnc[t][ai])) = a;
+                (*lp(&L.chLive[t][ai])) = ak == AUGX_K_IGENIC || ak == AUGX_K_GEOMETRIC || ak == AUGX_K_RGEOMETRIC;
+            }
+            int nd = 0;
+            bool self = false, other = false;
+            for (int ai = 0; ai < 5; ai++) {
+                if (!(s2 >= 0 && ai < (*lp(&L.chNa[t])))) continue;
+                if ((*lp(&L.chLive[t][ai]))) { if ((*lp(&L.chAnc[t][ai])) == s2) self = true; else other = true; }
+                else (*lp(&L.chDead[t][nd++])) = (*lp(&L.chAnc[t][ai]));
+            }
+            for (int k = nd; k < 5; k++) (*lp(&L.chDead[t][k])) = 0;
+            (*lp(&L.chNd[t])) = nd; (*lp(&L.chSelf[t])) = self; (*lp(&L.chOther[t])) = other;
+        }
+    }
+    // the candidate of this thread in the current block (cur*) and in the next one (nxt*): record, and whether there is one
+    // Wavefront 0 does nothing but the runs of the chain states (register to register, LDS in and out): it never has a load or a
+    // store to HBM in flight, so nothing in its runs waits for memory.  The other NTW threads (u = t - WAVE) share the rest.
+    constexpr int NTW = NT - WAVE;
+    TV(Item, curI); TV(Item, nxtI); TV(double, cv); TV(int, cdj); TV(int, cs2);
+    FOR_THREADS(t) { // block 0: offsets now, its records below
+        if (t == NT - 1) { (*lp(&L.bOff[0])) = gp(gBlkOff)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][0])) = gp(gBlkCnt)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][1])) = gp(gBlkSplit)[gb0 * 3 + 2]; }
+        TX(cv) = AUGX_NINF; TX(cdj) = 0; TX(cs2) = 0;
+    }
+    BLOCK_SYNC();
+    FOR_THREADS(t) {
+        TX(nxtI) = (t >= WAVE && (uint32_t)(t - WAVE) < (*lp(&L.bCnt[0][0]))) ? ldItem(gItems + (*lp(&L.bOff[0])) + (t - WAVE)) : Item{AUGX_NINF, 0u, 0u};
+        if (t >= NT - BLK * NSIG) { const int i = t - (NT - BLK * NSIG); (*lp(&L.sg[0][i / NSIG][i % NSIG])) = i / NSIG < n ? gp(gSig)[(int64_t)(i / NSIG) * NSIG + i % NSIG] : AUGX_NINF; }
+    }
+    BLOCK_SYNC();
+    // a chain state at base j: first what reaches it from the states made in earlier steps of the block (all bases of the block
+    // side by side: chainOthers), then, base after base, itself and the other chain states (chainRun)
+    auto chainOthers = [&](int slot, int dj, int jb, int par) __attribute__((always_inline)) {
+        const int s2 = (*lp(&L.chS[slot])), j = jb + dj;
+        double f = AUGX_NINF;
+        if (s2 >= 0 && j >= 1 && j < n) {
+            const double emi = (*lp(&L.sg[par][dj][slot == 7 ? SIG_EIG : SIG_EIN]));
+            const int cc = clsAt(j);
+            const int nd = (*lp(&L.chNd[slot]));
+            // all contributions first (-inf where there is none), then their ln-sum around the largest: no branch per ancestor
+            double x[5], m = AUGX_NINF;
+            int fin = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int a = (*lp(&L.chDead[slot][k]));
+                const double pv = k < nd ? ldsLoadD(&L.ring[(j - 1) & 63][a]) : AUGX_NINF;
+                x[k] = pv + (trn(cc, a, s2) + emi);
+                if (!(pv > AUGX_NINF)) x[k] = AUGX_NINF; // (a transition of -inf next to a value of +... cannot happen; this guards 0 * inf forms)
+                m = x[k] > m ? x[k] : m;
+                fin += x[k] > AUGX_NINF;
+            }
+            f = m;
+            if (fin > 1) {
+                double sum = 0.0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) sum += x[k] > AUGX_NINF ? exp(x[k] - m) : 0.0;
+                f = m + log(sum);
+            }
+        }
+        (*lp(&L.oth[slot][dj])) = f;
+    };
+    auto chainRun = [&](int slot, int jb, int par) __attribute__((always_inline)) {
+        const int s2 = (*lp(&L.chS[slot]));
+        if (s2 < 0) return;
+        // what does not change along the block, once: which ancestors are chain states (as a rule only the state itself), the
+        // block's signal records and the sums over the other ancestors -- the run itself then goes from register to register
+        const int na = (*lp(&L.chNa[slot])), sgi = slot == 7 ? SIG_EIG : SIG_EIN;
+        const bool self = (*lp(&L.chSelf[slot])) != 0, otherLive = (*lp(&L.chOther[slot])) != 0;
+        double emiR[BLK], othR[BLK];
+#pragma unroll
+        for (int dj = 0; dj < BLK; dj++) { emiR[dj] = (*lp(&L.sg[par][dj][sgi])); othR[dj] = (*lp(&L.oth[slot][dj])); }
+        const double trSelf = multi ? 0.0 : ldsLoadD(&L.lt[s2][s2]);
+        double fprev = jb >= 1 ? ldsLoadD(&L.ring[(jb - 1) & 63][s2]) : AUGX_NINF;
+        if (!multi && !otherLive && self && jb >= 1 && jb + BLK <= n) {
+            // the usual block (one class, the state follows only itself, no piece end inside): straight-line code -- a taken
+            // branch costs more than the arithmetic of a base; -inf takes care of itself in the sums and the max
+#pragma unroll
+            for (int dj = 0; dj < BLK; dj++) {
+                const double x = fprev + (trSelf + emiR[dj]), o = othR[dj];
+                double f = x > o ? x : o;
+                if (o > AUGX_NINF && x > AUGX_NINF) f = lse2(o, x);
+                (*lp(&L.ring[(jb + dj) & 63][s2])) = f;
+                fprev = f;
+            }
+            return;
+        }
+#pragma unroll
+        for (int dj = 0; dj < BLK; dj++) {
+            const int j = jb + dj;
+            if (j >= n) continue;
+            if (j < 1) { fprev = ldsLoadD(&L.ring[0][s2]); continue; }
+            const int cc = clsAt(j);
+            double f = othR[dj];
+            if (otherLive) {
+#pragma unroll
+                for (int ai = 0; ai < 5; ai++) {
+                    if (ai < na && (*lp(&L.chLive[slot][ai])) && (*lp(&L.chAnc[slot][ai])) != s2) {
+                        const int a = (*lp(&L.chAnc[slot][ai]));
+                        const double pv = ldsLoadD(&L.ring[(j - 1) & 63][a]);
+                        if (pv > AUGX_NINF) f = lse2(f, pv + (trn(cc, a, s2) + emiR[dj]));
+                    }
+                }
+            }
+            if (self && fprev > AUGX_NINF) { // (the call only when there are two terms: it waits for every store in flight)
+                const double x = fprev + ((multi ? trn(cc, s2, s2) : trSelf) + emiR[dj]);
+                f = f > AUGX_NINF ? lse2(f, x) : x;
+            }
+            (*lp(&L.ring[j & 63][s2])) = f;
+            fprev = f;
+        }
+    };
+    // the cells a run left in the ring go to HBM from another wavefront (u: thread of the rest, slot0: first slot of the run)
+    auto chainFlush = [&](int u, int slot0, int nSlots, int jb) __attribute__((always_inline)) {
+        if (u < nSlots * BLK) {
+            const int slot = slot0 + u / BLK, j = jb + u % BLK, s2 = (*lp(&L.chS[slot]));
+            if (s2 >= 0 && j >= 1 && j < n) {
+                const double f = ldsLoadD(&L.ring[j & 63][s2]);
+                if (f > AUGX_NINF) gp(F)[(int64_t)j * S + s2] = f;
+            }
+        }
+    };
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    uint64_t fpa[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, fpl = clock64();
+    const bool doProf = B.prof != nullptr && threadIdx.x == 0;
+#define FMARK(k) do { if (doProf) { const uint64_t now_ = clock64(); fpa[k] += now_ - fpl; fpl = now_; } } while (0)
+#else
+#define FMARK(k) do {} while (0)
+#endif
     for (int b = 0; b < nBlocks; b++) {
-        const int jb = b * BLK;
-        const int64_t gb = o / BLK + b;
-        // ---- A: fixed-lag states; accumulators of the variable-length cells
+        const int jb = b * BLK, par = b & 1;
+        FMARK(0);
+        const int64_t gb = gb0 + b;
+        // ---- A: fixed-lag states; accumulators of the variable-length cells; the block's signal records; the next block's offsets
         FOR_THREADS(t) {
-            if (t < BLK * SP) { L.cmax[t / SP][t % SP] = AUGX_NINF; L.csum[t / SP][t % SP] = 0ull; }
-            if (t < nFix * BLK) {
-                const int s2 = fixS[t / BLK], j = jb + t % BLK, k = T.kind[s2];
+            TX(curI) = TX(nxtI);
+            if (t < BLK * SP) { (*lp(&L.cmax[t / SP][t % SP])) = AUGX_NINF; (*lp(&L.csum[t / SP][t % SP])) = 0ull; }
+            if (t == NT - 1 && b + 1 < nBlocks) {
+                (*lp(&L.bOff[par ^ 1])) = gp(gBlkOff)[(gb + 1) * 2 + 1]; (*lp(&L.bCnt[par ^ 1][0])) = gp(gBlkCnt)[(gb + 1) * 2 + 1]; (*lp(&L.bCnt[par ^ 1][1])) = gp(gBlkSplit)[(gb + 1) * 3 + 2];
+            }
+            if (TX(fS2) >= 0) {
+                const int s2 = TX(fS2), j = jb + (t - WAVE) % BLK;
                 if (j >= 1 && j < n) {
-                    const int lag = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
-                    const int sg = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
-                    const double emi = B.sig[(o + 1 + j) * NSIG + sg];
+                    const int lag = TX(fLag);
+                    const double emi = (*lp(&L.sg[par][(t - WAVE) % BLK][TX(fSg)]));
                     double f = AUGX_NINF;
                     if (j - lag >= 0 && emi > AUGX_NINF) {
                         const int cc = clsAt(j);
-                        for (int ai = 0; ai < T.n_anc[s2]; ai++) {
-                            const int a = T.anc[s2][ai];
-                            const double pv = at(j - lag, a, jb);
-                            if (pv > AUGX_NINF) f = lse2(f, pv + (lnT(T, cc, a, s2) + emi));
+#pragma unroll
+                        for (int ai = 0; ai < 4; ai++) {
+                            if (ai < TX(fNa)) {
+                                const int a = fAn[ai][TI];
+                                const double pv = at(j - lag, a, jb);
+                                if (pv > AUGX_NINF) f = lse2(f, pv + (trn(cc, a, s2) + emi));
+                            }
                         }
                     }
-                    L.ring[j & 63][s2] = f;
-                    if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
+                    (*lp(&L.ring[j & 63][s2])) = f;
+                    if (f > AUGX_NINF) gp(F)[(int64_t)j * S + s2] = f;
                 }
             }
         }
         BLOCK_SYNC();
-        // ---- B: geometric intron states, base after base (fed by equalD of the base before and by themselves)
+        FMARK(1);
+        // ---- B: geometric intron states, base after base (fed by equalD of the base before and by themselves); the records of
+        //      the next block set off
         FOR_THREADS(t) {
-            if (t < nGeo) {
-                const int s2 = geoS[t];
-                for (int dj = 0; dj < BLK; dj++) {
-                    const int j = jb + dj;
-                    if (j < 1 || j >= n) continue;
-                    const double emi = B.sig[(o + 1 + j) * NSIG + SIG_EIN];
-                    const int cc = clsAt(j);
-                    double f = AUGX_NINF;
-                    for (int ai = 0; ai < T.n_anc[s2]; ai++) {
-                        const int a = T.anc[s2][ai];
-                        const double pv = L.ring[(j - 1) & 63][a];
-                        if (pv > AUGX_NINF) f = lse2(f, pv + (lnT(T, cc, a, s2) + emi));
-                    }
-                    L.ring[j & 63][s2] = f;
-                    if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
-                }
+            if (b + 1 < nBlocks) TX(nxtI) = (t >= WAVE && (uint32_t)(t - WAVE) < (*lp(&L.bCnt[par ^ 1][0]))) ? ldItem(gItems + (*lp(&L.bOff[par ^ 1])) + (t - WAVE)) : Item{AUGX_NINF, 0u, 0u};
+            if (b + 1 < nBlocks && t >= NT - BLK * NSIG) { // (the last wavefronts: the first one has the geometric states)
+                const int i = t - (NT - BLK * NSIG), dj = i / NSIG, j = jb + BLK + dj;
+                (*lp(&L.sg[par ^ 1][dj][i % NSIG])) = j < n ? gp(gSig)[(int64_t)j * NSIG + i % NSIG] : AUGX_NINF;
             }
+            if (t >= WAVE && t - WAVE < 7 * BLK) chainOthers((t - WAVE) / BLK, (t - WAVE) % BLK, jb, par);
         }
+        BLOCK_SYNC();
+        FMARK(2);
+        FOR_THREADS(t) { if (t < 7) chainRun(t, jb, par); }
         BLOCK_SYNC();
         // ---- C / E: candidates of the variable-length states (C: all but RTERMINAL, E: RTERMINAL), three steps each: the largest
         //      candidate of every cell, the sum around it, the cell
-        const uint64_t i0 = B.blkOff[gb * 2 + 1];
-        const uint32_t cntAll = B.blkCnt[gb * 2 + 1], cntNonRT = B.blkSplit[gb * 3 + 2];
-        auto candValue = [&](const Item &I, int &dj, int &s2) -> double {
+        const uint64_t i0 = (*lp(&L.bOff[par]));
+        const uint32_t cntAll = (*lp(&L.bCnt[par][0])), cntNonRT = (*lp(&L.bCnt[par][1]));
+        auto candValue = [&](const Item &I, int &dj, int &s2) __attribute__((always_inline)) -> double {
             dj = (int)(I.kp >> (KEY_BITS + 6)); s2 = (int)((I.kp >> KEY_BITS) & 63);
             if (!(I.te > AUGX_NINF)) return AUGX_NINF;
             const uint32_t tag = I.src >> 30;
-            const int ai = (int)((I.src >> 28) & 3), eop = (int)(I.kp & KEY_MASK) - KEY_BIAS, j = jb + dj;
+            const int ai = (int)((I.src >> 28) & 3), eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
             double pv;
-            if (tag == SRC_COL0) { const int a = (int)(I.src & 0x3Fu); pv = B.initKind[p] == 0 ? T.ln_init[a] : (a == T.synch ? 0.0 : AUGX_NINF); }
-            else pv = at(eop, tag == SRC_VIG ? igS : T.anc[s2][ai], jb);
+            if (tag == SRC_COL0) { const int a = (int)(I.src & 0x3Fu); pv = initKind == 0 ? T.ln_init[a] : (a == synch ? 0.0 : AUGX_NINF); }
+            else pv = at(eop, tag == SRC_VIG ? igS : (int)(*lp(&L.anc[s2][ai])), jb);
             return pv + I.te;
         };
-        auto candidates = [&](uint32_t lo, uint32_t hi) {
+        auto candidates = [&](uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
             FOR_THREADS(t) {
-                for (uint32_t it = lo + (uint32_t)t; it < hi; it += NT) {
+                TX(cv) = AUGX_NINF;
+                if (t >= WAVE && (uint32_t)(t - WAVE) >= lo && (uint32_t)(t - WAVE) < hi) { // this thread's own record: value kept for the next two steps
+                    TX(cv) = candValue(TX(curI), TX(cdj), TX(cs2));
+                    if (TX(cv) > AUGX_NINF) ldsMaxD(&L.cmax[TX(cdj)][TX(cs2)], TX(cv));
+                }
+                for (uint32_t it = (lo > (uint32_t)NTW ? lo : (uint32_t)NTW) + (uint32_t)(t - WAVE); t >= WAVE && it < hi; it += NTW) { // (a block with more than NT candidates)
                     int dj, s2;
-                    const double v = candValue(ldItem(B.items + i0 + it), dj, s2);
+                    const double v = candValue(ldItem(gItems + i0 + it), dj, s2);
                     if (v > AUGX_NINF) ldsMaxD(&L.cmax[dj][s2], v);
                 }
             }
             BLOCK_SYNC();
             FOR_THREADS(t) {
-                for (uint32_t it = lo + (uint32_t)t; it < hi; it += NT) {
+                if (TX(cv) > AUGX_NINF) ldsAddU(&L.csum[TX(cdj)][TX(cs2)], (unsigned long long)(exp(TX(cv) - (*lp(&L.cmax[TX(cdj)][TX(cs2)]))) * FWD_FIX));
+                for (uint32_t it = (lo > (uint32_t)NTW ? lo : (uint32_t)NTW) + (uint32_t)(t - WAVE); t >= WAVE && it < hi; it += NTW) {
                     int dj, s2;
-                    const double v = candValue(ldItem(B.items + i0 + it), dj, s2);
-                    if (v > AUGX_NINF) ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - L.cmax[dj][s2]) * FWD_FIX));
+                    const double v = candValue(ldItem(gItems + i0 + it), dj, s2);
+                    if (v > AUGX_NINF) ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - (*lp(&L.cmax[dj][s2]))) * FWD_FIX));
                 }
             }
             BLOCK_SYNC();
         };
-        auto cells = [&](bool rt) {
+        auto cells = [&](bool rt) __attribute__((always_inline)) {
             FOR_THREADS(t) {
-                if (t < BLK * SP) {
-                    const int dj = t / SP, s2 = t % SP, j = jb + dj;
-                    if (s2 < S && j >= 1 && j < n && T.reachable[s2]) {
-                        const int k = T.kind[s2];
-                        const bool var = (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD;
-                        if (var && (k == AUGX_K_RTERMINAL) == rt) {
-                            const double f = L.csum[dj][s2] > 0ull ? L.cmax[dj][s2] + log((double)L.csum[dj][s2] / FWD_FIX) : AUGX_NINF;
-                            L.ring[j & 63][s2] = f;
-                            if (f > AUGX_NINF) F[(int64_t)j * S + s2] = f;
+                for (int i = t - WAVE; t >= WAVE && i < BLK * SP; i += NTW) {
+                    const int dj = i / SP, s2 = i % SP, j = jb + dj;
+                    if (j >= 1 && j < n) {
+                        if ((*lp(&L.cellKind[s2])) == (rt ? 2 : 1)) {
+                            const double f = (*lp(&L.csum[dj][s2])) > 0ull ? (*lp(&L.cmax[dj][s2])) + log((double)(*lp(&L.csum[dj][s2])) / FWD_FIX) : AUGX_NINF;
+                            (*lp(&L.ring[j & 63][s2])) = f;
+                            if (f > AUGX_NINF) gp(F)[(int64_t)j * S + s2] = f;
                         }
                     }
                 }
             }
             BLOCK_SYNC();
         };
+        FMARK(3);
+        FOR_THREADS(t) { if (t >= WAVE) chainFlush(t - WAVE, 0, 7, jb); }
         candidates(0, cntNonRT);
+        FMARK(4);
         cells(false);
+        FMARK(5);
         // ---- D: the intergenic state, base after base (fed by itself and by the exon cells of the base before)
-        FOR_THREADS(t) {
-            if (t == 0 && igS >= 0) {
-                for (int dj = 0; dj < BLK; dj++) {
-                    const int j = jb + dj;
-                    if (j < 1 || j >= n) continue;
-                    const double emi = B.sig[(o + 1 + j) * NSIG + SIG_EIG];
-                    const int cc = clsAt(j);
-                    double f = AUGX_NINF;
-                    for (int ai = 0; ai < T.n_anc[igS]; ai++) {
-                        const int a = T.anc[igS][ai];
-                        const double pv = L.ring[(j - 1) & 63][a];
-                        if (pv > AUGX_NINF) f = lse2(f, pv + (lnT(T, cc, a, igS) + emi));
-                    }
-                    L.ring[j & 63][igS] = f;
-                    if (f > AUGX_NINF) F[(int64_t)j * S + igS] = f;
-                }
-            }
-        }
+        FOR_THREADS(t) { if (t >= WAVE && t - WAVE < BLK) chainOthers(7, t - WAVE, jb, par); }
         BLOCK_SYNC();
+        FMARK(6);
+        FOR_THREADS(t) { if (t == 0) chainRun(7, jb, par); }
+        BLOCK_SYNC();
+        FMARK(7);
+        FOR_THREADS(t) { if (t >= WAVE) chainFlush(t - WAVE, 7, 1, jb); }
         candidates(cntNonRT, cntAll);
+        FMARK(8);
         cells(true);
-        BLOCK_GLOBAL_SYNC(); // the columns of this block are in HBM for the candidates of later blocks
+        FMARK(9);
+        // the columns of this block reach HBM before any later block reads them from there: that is 7 blocks away at the earliest
+        if ((b & 3) == 3) BLOCK_GLOBAL_SYNC();
+        FMARK(10);
     }
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    if (B.prof && threadIdx.x == 0) for (int k = 0; k < 12; k++) B.prof[(int64_t)p * 56 + k] = fpa[k];
+#endif
+#undef FMARK
+    BLOCK_SYNC();
     FOR_THREADS(t) { // ln P(sequence) (reference NAMGene::getSampledPath's option list over the last column, src/namgene.cc:385-392)
         if (t == 0) {
             double tot = AUGX_NINF;
             for (int i = 0; i < S; i++) {
-                const double tl = B.termKind[p] == 0 ? T.ln_term[i] : (i == T.synch ? 0.0 : AUGX_NINF);
-                const double v = L.ring[(n - 1) & 63][i] + tl;
+                const double tl = termKind == 0 ? T.ln_term[i] : (i == synch ? 0.0 : AUGX_NINF);
+                const double v = (*lp(&L.ring[(n - 1) & 63][i])) + tl;
                 if (v > AUGX_NINF) tot = lse2(tot, v);
             }
             B.lnFwd[p] = tot;
