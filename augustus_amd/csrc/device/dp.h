@@ -213,9 +213,15 @@ struct Piece {
     const uint8_t *lcode = nullptr;  // (prep kernels) the bases lLo..lHi-1 staged by the workgroup: lcode[q - lLo], 4 outside the piece
     int lLo = 0, lHi = 0;
     AUGX_HD int b(int p) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (two typed loads behind a branch; one load through a pointer selected between LDS and HBM would be a flat load, which
+        //  holds up the LDS and the memory wait counters alike)
+        if (p >= lLo && p < lHi) return *(const __attribute__((address_space(3))) uint8_t *)(lcode + (p - lLo));
+        return (p >= 0 && p < n) ? *(const __attribute__((address_space(1))) uint8_t *)(code + p) : 4;
+#else
         if (p >= lLo && p < lHi) return lcode[p - lLo];
-        if (p >= wcLo && p < wcHi) return wcode[p & (CODE_WIN - 1)];
         return (p >= 0 && p < n) ? code[p] : 4;
+#endif
     }
     AUGX_HD bool is2(int p, int x, int y) const { return b(p) == x && b(p + 1) == y; }
     AUGX_HD int pat(int p, int len) const {
