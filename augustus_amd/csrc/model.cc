@@ -317,8 +317,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     if (singleStrand) throw UnsupportedError("--singlestrand=true is outside the MI355X hot path (shadow-state model only)");
     if (utr) throw UnsupportedError("--UTR=on (71-state UTR trellis) is not implemented yet on the MI355X path; run with --UTR=off");
     if (nc) throw UnsupportedError("--nc=on is outside the MI355X hot path");
-    if (genemodel != "partial" && genemodel != "complete")
-        throw UnsupportedError("--genemodel=" + genemodel + " is outside the MI355X hot path (partial|complete only)");
+    if (genemodel != "partial" && genemodel != "complete" && genemodel != "intronless")
+        throw UnsupportedError("--genemodel=" + genemodel + " is outside the MI355X hot path (partial|complete|intronless only)");
     if (opt.has("hintsfile")) throw UnsupportedError("--hintsfile (extrinsic evidence) is outside the MI355X ab-initio hot path");
     if (opt.has("proteinprofile")) throw UnsupportedError("--proteinprofile (PPX) is outside the MI355X ab-initio hot path");
     if (opt.getBool("mea", false)) throw UnsupportedError("--mea=1 is outside the MI355X ab-initio hot path");
@@ -337,7 +337,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     std::string strandName = "shadow";
     std::string transFile = "trans_" + strandName + "_" + genemodel + ".pbl";
     opt.set("/NAMGene/TransFile", transFile);
-    opt.readFile(configPath + "model/states_" + strandName + ".cfg", configPath);
+    opt.readFile(configPath + "model/states_" + strandName + (genemodel == "intronless" ? "_intronless" : "") + ".cfg", configPath);
 
     // ---- constants (reference Constant::init, src/types.cc:208-450; defaults src/types.cc:20-116)
     t.W = opt.getInt("/Constant/trans_init_window", 12);
@@ -394,7 +394,9 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     double opal = opt.getDouble("/Constant/opalprob", 0.333), amber = opt.getDouble("/Constant/amberprob", 0.333),
            ochre = opt.getDouble("/Constant/ochreprob", 0.333);
     double gcMin = opt.getDouble("/Constant/gc_range_min", 0.32), gcMax = opt.getDouble("/Constant/gc_range_max", 0.73);
-    bool tie = opt.getBool("tieIgenicIntron", true);
+    // (without an intron model -- genemodel=intronless -- the intergenic model keeps its own content model: reference
+    //  IGenicModel::updateToLocalGC, src/igenicmodel.cc:71-79, IntronModel::GCemiprobs == NULL)
+    bool tie = opt.getBool("tieIgenicIntron", true) && genemodel != "intronless";
     if (opt.getBool("/IntronModel/allow_dss_consensus_gc", false))
         throw UnsupportedError("allow_dss_consensus_gc is not supported on the MI355X path");
     t.ln_quarter = std::log(0.25);

@@ -26,6 +26,10 @@ CFGS = {
     # 3 GC classes (the multigc_* records have up to three of them in one piece) and ass_end = 0 (an exon may follow base 0
     # without an acceptor site)
     "saccharomyces": ("saccharomyces", ["--UTR=off", "--sample=0", "--softmasking=0"]),
+    # --genemodel=intronless: three states (intergenic, single-exon gene on either strand); the intergenic model keeps its own
+    # content model (no intron model to tie it to); human: several GC classes inside a piece
+    "human_intronless": ("human", ["--genemodel=intronless", "--softmasking=0"]),
+    "fly_intronless": ("fly", ["--genemodel=intronless", "--UTR=off", "--sample=0"]),
 }
 
 
@@ -80,7 +84,10 @@ def main():
     recs = build_inputs()
     fa = os.path.join(HERE, "inputs.fa")
     write_fasta(fa, recs)
+    only = sys.argv[1:]
     for cfg, (species, extra) in CFGS.items():
+        if only and cfg not in only:
+            continue
         res, err = ref_harness(fa, species, extra, cfg="/root/reference/config/")
         assert len(res) == len(recs), (cfg, err)
         out = {"species": species, "extra": extra,

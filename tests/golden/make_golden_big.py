@@ -33,6 +33,8 @@ BIG_CFGS = {
     "human": ("genome", "human", ["--softmasking=0"]),
     "human_sm": ("genome", "human", []),
     "synth": ("synth", "human", []),
+    "human_intronless": ("genome", "human", ["--genemodel=intronless"]),          # 3-state model, default flags, one 1 Mbp piece
+    "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
 }
 
 
@@ -55,7 +57,10 @@ def main():
     files = {"genome": ref_genome, "synth": synth}
     env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
     paths = {}
+    only = [a for a in sys.argv[1:] if a in BIG_CFGS]
     for cfg, (inp, species, extra) in BIG_CFGS.items():
+        if only and cfg not in only:
+            continue
         txt = subprocess.run([REF_AUGUSTUS, "--species=" + species] + extra + [files[inp]], capture_output=True, text=True, env=env)
         assert txt.returncode == 0 and txt.stderr == "", txt.stderr
         body = gff_body(txt.stdout)
@@ -65,6 +70,8 @@ def main():
             res, err = ref_harness(files[inp], species, extra, cfg="/root/reference/config/")
             assert len(res) == 1, err
             paths[cfg] = {"lnv": repr(res[0]["lnv"]), "path": res[0]["path"], "n": res[0]["n"]}
+    if only:
+        return
     json.dump(paths, open(os.path.join(HERE, "golden_big_paths.json"), "w"))
     # a genome-like input for the human model at its own maxDNAPieceSize (2 Mbp): one 4.2 Mbp record (three pieces, two cut
     # points found in 150 kb exam windows) + one short record; soft-masked real DNA in both orientations and random DNA

@@ -186,6 +186,8 @@ GOLDEN_CFGS = {
     "fly": ("fly", {"UTR": "off", "sample": "0", "softmasking": "0"}),
     "arabidopsis": ("arabidopsis", {"UTR": "off", "sample": "0", "softmasking": "0"}),
     "saccharomyces": ("saccharomyces", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+    "human_intronless": ("human", {"genemodel": "intronless", "softmasking": "0"}),          # 3 states; several GC classes in a piece
+    "fly_intronless": ("fly", {"genemodel": "intronless", "UTR": "off", "sample": "0"}),     # with the soft-masking bonus
 }
 
 

@@ -36,6 +36,8 @@ BIG = {  # tests/golden/make_golden_big.py: BIG_CFGS
     "human": ("genome", "human", ["--softmasking=0"]),                           # two GC classes inside one 1 Mbp piece
     "human_sm": ("genome", "human", []),                                         # default flags
     "synth": ("synth", "human", []),                                             # config 3: one actual bench contig
+    "human_intronless": ("genome", "human", ["--genemodel=intronless"]),         # 3-state model: one 1 Mbp piece in segments
+    "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
 }
 
 
