@@ -202,7 +202,13 @@ const char *pieceSequence(const std::string &seq, long begin, long end, long lim
 }
 
 struct RecordView { const char *name; const char *seq; long len; };
-struct PieceOut { int rec; long begin, end; const std::vector<PathState> *path; int status; const std::vector<std::vector<PathState>> *samples = nullptr; };
+struct PieceOut {
+    int rec; long begin, end; const std::vector<PathState> *path; int status; const std::vector<std::vector<PathState>> *samples = nullptr;
+    // --singlestrand=true: the run on the piece as it is (path: nullptr when --strand=backward leaves it out) and the run on its
+    // reverse complement (pathR; nullptr with --strand=forward)
+    const std::vector<PathState> *pathR = nullptr; const std::vector<std::vector<PathState>> *samplesR = nullptr;
+    bool single = false;
+};
 
 // ---- gene structures + GFF for all records, in input order; gene ids are global and sequential over the run (reference
 //      NAMGene::doViterbiPiecewise, src/namgene.cc:526,626-650; block headers src/augustus.cc:395-398).  `pieces` may
@@ -223,6 +229,7 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
             const std::string st = M.opt.get("strand", "both");
             const bool fw = st == "forward", bw = st == "backward"; // (other values fall back to both, see genes.cc)
             out += "# Predicted genes for sequence number " + std::to_string(r + 1) + " on " + (fw ? "forward strand" : bw ? "reverse strand" : "both strands") + "\n";
+            if (M.opt.getBool("singlestrand", false)) out += "# Overlapping genes on opposite strand are allowed.\n";
         }
         bool any = false;
         std::string errmsg;
@@ -237,11 +244,21 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
                 continue;
             }
             std::vector<Transcript> txs;
+            const long plen = pr.end - pr.begin + 1;
+            auto run = [&](const std::vector<PathState> &path, const std::vector<std::vector<PathState>> *smp, bool anyStrand) {
+                return sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand)
+                                                    : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand);
+            };
             try {
-                if (sampleiterations > 0 && pr.samples)
-                    txs = filterTranscripts(M, posteriorTranscripts(M, *pr.path, *pr.samples, pr.end - pr.begin + 1, sampleiterations));
-                else
-                    txs = filterTranscripts(M, projectOntoGeneSequence(M, *pr.path, pr.end - pr.begin + 1));
+                if (!pr.single) txs = run(*pr.path, pr.samples, false);
+                else { // reference NAMGene::doViterbiPiecewise, src/namgene.cc:611-626: the genes of the forward run, then those of the
+                       // run on the reverse complement mapped back (reverseGeneList: in reversed order); sorted by start below
+                    if (pr.path) txs = run(*pr.path, pr.samples, true);
+                    if (pr.pathR) {
+                        std::vector<Transcript> rv = run(*pr.pathR, pr.samplesR, true);
+                        for (size_t k = rv.size(); k-- > 0;) { reverseTranscript(rv[k], plen - 1); txs.push_back(rv[k]); }
+                    }
+                }
             } catch (std::exception &e) { errmsg = e.what(); continue; }
             std::vector<GeneOut> genes = groupToGenes(txs);
             for (GeneOut &g : genes) {
@@ -597,19 +614,50 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             std::cerr << "examining piece " << pr.begin + S.oo.offset + 1 << ".." << pr.end + S.oo.offset + 1 << " (" << (pr.end - pr.begin + 1) << " bp)" << std::endl;
 
     // ---- phase 2: decode all pieces, sharded over the devices (longest first), each device in batches bounded by its memory
-    std::vector<Decoded> decoded(allPieces.size());
+    // (--singlestrand=true: the model has no shadow states; every piece is decoded as it is and as its reverse complement --
+    //  --strand picks the runs -- in this order, which is also the order of the draws when sampling)
+    const bool single = M.opt.getBool("singlestrand", false);
+    const std::string strandOpt = M.opt.get("strand", "both");
+    const bool runF = !single || strandOpt != "backward", runR = single && strandOpt != "forward";
+    const size_t per = single ? 2 : 1;
+    std::vector<Decoded> decoded(allPieces.size() * per);
     {
-        std::vector<augx_piece> ps(allPieces.size());
-        std::vector<std::string> copies;
+        std::vector<augx_piece> ps;
+        std::vector<size_t> slot; // ps[k] is decoded[slot[k]]
+        std::vector<std::string> copies, rcs;
         copies.reserve(allPieces.size());
+        rcs.reserve(allPieces.size());
         for (size_t i = 0; i < allPieces.size(); i++) {
             const PieceRef &pr = allPieces[i];
-            ps[i].seq = soft ? pieceSequence(recs[pr.rec].seq, pr.begin, pr.end, pr.end, copies) : recs[pr.rec].seq.data() + pr.begin;
-            ps[i].len = pr.end - pr.begin + 1;
-            ps[i].init_kind = pr.initKind;
-            ps[i].term_kind = pr.termKind;
+            augx_piece p;
+            p.seq = soft ? pieceSequence(recs[pr.rec].seq, pr.begin, pr.end, pr.end, copies) : recs[pr.rec].seq.data() + pr.begin;
+            p.len = pr.end - pr.begin + 1;
+            p.init_kind = pr.initKind;
+            p.term_kind = pr.termKind;
+            if (runF) { ps.push_back(p); slot.push_back(i * per); }
+            if (runR) { // reverse complement, case kept (the soft-masked runs are the hints of this run, too); the initial and
+                        // terminal probabilities are the piece's, not swapped (src/namgene.cc:594-603 precede both runs)
+                rcs.emplace_back((size_t)p.len, 'n');
+                std::string &rc = rcs.back();
+                for (int64_t q = 0; q < p.len; q++) {
+                    const char c = p.seq[p.len - 1 - q];
+                    char d;
+                    switch (c) {
+                    case 'a': d = 't'; break; case 'c': d = 'g'; break; case 'g': d = 'c'; break; case 't': d = 'a'; break;
+                    case 'A': d = 'T'; break; case 'C': d = 'G'; break; case 'G': d = 'C'; break; case 'T': d = 'A'; break;
+                    default: d = c;
+                    }
+                    rc[(size_t)q] = d;
+                }
+                augx_piece q2 = p;
+                q2.seq = rc.data();
+                ps.push_back(q2);
+                slot.push_back(i * per + 1);
+            }
         }
-        if (!ps.empty() && !(S.sampleiterations > 0 ? S.decodeSampled(ps, decoded) : S.decode(ps, decoded))) { restore(); return fail(S.err); }
+        std::vector<Decoded> dd;
+        if (!ps.empty() && !(S.sampleiterations > 0 ? S.decodeSampled(ps, dd) : S.decode(ps, dd))) { restore(); return fail(S.err); }
+        for (size_t k = 0; k < dd.size(); k++) decoded[slot[k]] = std::move(dd[k]);
     }
 
     lap("decode of the pieces");
@@ -618,10 +666,22 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     for (auto &r : recs) rv.push_back({r.name.c_str(), r.seq.data(), (long)r.seq.size()});
     std::vector<PieceOut> po;
     static const std::vector<PathState> noPath;
-    for (size_t i = 0; i < allPieces.size(); i++)
-        po.push_back({allPieces[i].rec, allPieces[i].begin, allPieces[i].end, &decoded[i].path, decoded[i].status, S.sampleiterations > 0 ? &decoded[i].samples : nullptr});
+    for (size_t i = 0; i < allPieces.size(); i++) {
+        PieceOut o{allPieces[i].rec, allPieces[i].begin, allPieces[i].end, &decoded[i * per].path, decoded[i * per].status,
+                   S.sampleiterations > 0 ? &decoded[i * per].samples : nullptr};
+        if (single) {
+            o.single = true;
+            if (!runF) { o.path = nullptr; o.samples = nullptr; o.status = 0; }
+            if (runR) {
+                o.pathR = &decoded[i * per + 1].path;
+                o.samplesR = S.sampleiterations > 0 ? &decoded[i * per + 1].samples : nullptr;
+                if (o.status == 0) o.status = decoded[i * per + 1].status;
+            }
+        }
+        po.push_back(o);
+    }
     for (size_t r = 0; r < recs.size(); r++)
-        if (cs[r].failStatus) po.push_back({(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, cs[r].failStatus});
+        if (cs[r].failStatus) { PieceOut o{(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, cs[r].failStatus}; po.push_back(o); }
     std::string text, errText, fatal;
     if (formatRecords(M, S.oo, rv, po, verbosity, S.geneid, text, errText, fatal, S.sampleiterations)) {
         std::cout << text;

@@ -180,12 +180,12 @@ double Transcript::meanStateProb() const {
     return pow(p, 1.0 / k);
 }
 
-std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs) {
+std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs, bool anyStrand) {
     std::vector<Transcript> out;
     // --strand (reference src/augustus.cc:177-191, filterGenePrediction src/gene.cc:2474-2475).  Only the values listed as
     // possible_values in aug_cmdln_parameters.json reach the reference's parser: anything but forward / backward means both
     const std::string st = m.opt.get("strand", "both");
-    const int want = st == "forward" ? 1 : st == "backward" ? -1 : 0;
+    const int want = anyStrand ? 0 : st == "forward" ? 1 : st == "backward" ? -1 : 0;
     const double minmean = m.opt.getDouble("minmeanexonintronprob", 0.0), minprob = m.opt.getDouble("minexonintronprob", 0.0);
     const bool keepViterbi = m.opt.getBool("keep_viterbi", false);
     for (const Transcript &g : txs) {
@@ -204,6 +204,37 @@ std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Tran
         if (keep) out.push_back(g);
     }
     return out;
+}
+
+void reverseTranscript(Transcript &t, long endpos) {
+    auto mirror = [&](std::vector<BioState> &v, bool exons) {
+        for (BioState &e : v) {
+            const long b = e.begin;
+            e.begin = endpos - e.end;
+            e.end = endpos - b;
+            if (!exons) continue;
+            const int ty = e.type; // (frame() and length() below are those of the type before the change, as in the reference)
+            if (isInitialExon(ty)) e.type = T_RINITIAL;
+            else if (ty == T_TERMINAL) e.type = 41 + mod3(2 - e.length());
+            else if (isInternalExon(ty)) e.type = 38 + mod3(2 + e.frame() - e.length());
+            else if (ty == T_SINGLE) e.type = T_RSINGLE;
+            else if (isRTerminalExon(ty)) e.type = T_TERMINAL;
+            else if (ty == T_RINITIAL) e.type = 2 + mod3(e.length());
+            else if (isRInternalExon(ty)) e.type = 5 + mod3(1 + e.frame() + e.length());
+            else if (ty == T_RSINGLE) e.type = T_SINGLE;
+        }
+        std::reverse(v.begin(), v.end());
+    };
+    mirror(t.exons, true);
+    mirror(t.introns, false);
+    const long ce = t.codingend;
+    t.codingend = t.codingstart >= 0 ? endpos - t.codingstart : -1;
+    t.codingstart = ce >= 0 ? endpos - ce : -1;
+    const long te = t.transend;
+    t.transend = t.transstart >= 0 ? endpos - t.transstart : -1;
+    t.transstart = te >= 0 ? endpos - te : -1;
+    t.plus = !t.plus;
+    t.revRun = true;
 }
 
 // reference Transcript::operator==, src/gene.cc:1149-1175: the same exon and intron intervals (types and strand are not compared)
@@ -294,6 +325,7 @@ std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs) {
         // AltGene::addGene: the sum of its transcripts' apostprob (src/gene.cc:2706); a Viterbi transcript enters with 1 when
         // nothing was sampled (src/namgene.cc:813-821)
         ag.apostprob = t.apostprob;
+        ag.hasProbs = !t.revRun;
         genes.push_back(ag);
     }
     std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
@@ -416,8 +448,8 @@ void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const ch
         out += "# start gene " + g.id + "\n";
         // gene line: AltGene::hasProbs is true after joinGenesFromPredRuns, apostprob = sum of transcript apostprobs
         // (= 1 for the single Viterbi transcript), printed with setprecision(3)
-        char score[32];
-        snprintf(score, sizeof score, "%.3g", g.apostprob);
+        char score[32] = ".";
+        if (g.hasProbs) snprintf(score, sizeof score, "%.3g", (double)g.apostprob);
         appendf(out, "%s\tAUGUSTUS\tgene\t%ld\t%ld\t%s\t%c\t.\t%s%s\n", g.seqname.c_str(), minB + 1 + o.offset, maxE + 1 + o.offset, score, g.plus ? '+' : '-',
                 o.gff3 ? "ID=" : "", g.id.c_str());
         for (const Transcript &t : g.transcripts) {

@@ -38,6 +38,7 @@ struct Transcript {
     // sampling (reference Transcript::apostprob / hasProbs / viterbi / throwaway, include/gene.hh)
     float apostprob = 1.0f;
     bool hasProbs = false, viterbi = true, throwaway = false;
+    bool revRun = false; // mapped back from the run on the reverse complement (--singlestrand=true)
     double meanStateProb() const;
     long geneBegin() const { return transstart >= 0 ? transstart : codingstart; }
     long geneEnd() const { return transend >= 0 ? transend : codingend; }
@@ -51,6 +52,7 @@ struct GeneOut {
     bool plus = true;
     long mincodstart = 0, maxcodend = 0;
     float apostprob = 0;
+    bool hasProbs = true; // (the gene line's score; reverseGeneList builds its AltGenes afresh, with hasProbs = false: '.')
 };
 
 struct OutputOptions {
@@ -67,7 +69,12 @@ struct PathState { long begin, end; int type; };
 // path -> list of (possibly partial) transcripts in piece coordinates
 std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vector<PathState> &path, long dnalen);
 // drop transcripts the reference's filterGenePrediction would drop (ab initio: CDS length rules only)
-std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs);
+// (anyStrand: the --strand option is not applied -- runs of the single-strand model, where the caller picks the runs)
+std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs, bool anyStrand = false);
+// a transcript predicted on the reverse complement of a piece (--singlestrand=true) mapped back onto the piece: coordinates
+// mirrored at endpos = piece length - 1, exon types turned into those of the other strand (reference reverseGeneSequence,
+// src/gene.cc:3246-3365)
+void reverseTranscript(Transcript &t, long endpos);
 // the transcripts of the Viterbi path and of the sampled paths of one piece, identical ones united, with the posterior
 // probabilities of transcripts, exons and introns estimated from the sample (reference NAMGene::findGenes, src/namgene.cc:795-905;
 // sampleiterations = the Viterbi path + the sampled ones)

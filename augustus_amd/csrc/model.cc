@@ -314,7 +314,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
         }
     }
     bool nc = opt.getBool("nc", false);
-    if (singleStrand) throw UnsupportedError("--singlestrand=true is outside the MI355X hot path (shadow-state model only)");
+    if (singleStrand && genemodel != "partial" && genemodel != "complete")
+        throw UnsupportedError("--singlestrand=true with --genemodel=" + genemodel + " is outside the MI355X hot path (partial|complete only)");
     if (utr) throw UnsupportedError("--UTR=on (71-state UTR trellis) is not implemented yet on the MI355X path; run with --UTR=off");
     if (nc) throw UnsupportedError("--nc=on is outside the MI355X hot path");
     if (genemodel != "partial" && genemodel != "complete" && genemodel != "intronless")
@@ -334,7 +335,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     for (const char *o2 : {"speciesfilenames", "alnfile", "treefile", "dbaccess", "dbhints", "referenceFile", "refSpecies", "optCfgFile",
                            "codonAlignmentFile", "trainFeatureFile"})
         if (opt.has(o2)) throw UnsupportedError(std::string("--") + o2 + " (comparative / training mode) is outside the MI355X ab-initio hot path");
-    std::string strandName = "shadow";
+    std::string strandName = singleStrand ? "singlestrand" : "shadow";
     std::string transFile = "trans_" + strandName + "_" + genemodel + ".pbl";
     opt.set("/NAMGene/TransFile", transFile);
     opt.readFile(configPath + "model/states_" + strandName + (genemodel == "intronless" ? "_intronless" : "") + ".cfg", configPath);

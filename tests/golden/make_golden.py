@@ -103,5 +103,20 @@ def main():
         print(cfg, len(res), "records", len(body), "gff lines")
 
 
+def single():
+    """golden_single_<cfg>.gff: the reference binary with --singlestrand=true (helpers.SINGLE_CFGS) on inputs.fa"""
+    fa = os.path.join(HERE, "inputs.fa")
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
+    for cfg, (species, opts) in SINGLE_CFGS.items():
+        txt = subprocess.run([REF_AUGUSTUS, "--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa], capture_output=True, text=True, env=env)
+        assert txt.returncode == 0 and txt.stderr == "", txt.stderr
+        body = gff_body(txt.stdout)
+        open(os.path.join(HERE, "golden_single_%s.gff" % cfg), "w").write("\n".join(body) + "\n")
+        print(cfg, len(body), "gff lines")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "single":
+        single()
+        sys.exit(0)
     main()

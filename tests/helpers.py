@@ -222,6 +222,21 @@ SAMPLED_CFGS = {
 }
 
 
+# --singlestrand=true (tests/golden/make_golden.py single): the 24-state model without shadow states, every piece decoded as it is and
+# as its reverse complement, genes on opposite strands may overlap
+SINGLE_CFGS = {
+    "human": ("human", {"singlestrand": "true"}),                                              # default flags: soft-masking bonus
+    "human_complete": ("human", {"singlestrand": "true", "genemodel": "complete", "softmasking": "0"}),
+    "fly_sampled": ("fly", {"singlestrand": "true", "UTR": "off", "softmasking": "0"}),       # sample = 100: draws run forward, then reverse
+    "fly_backward": ("fly", {"singlestrand": "true", "UTR": "off", "sample": "0", "strand": "backward"}),
+    "fly_pieces": ("fly", {"singlestrand": "true", "UTR": "off", "sample": "0", "maxDNAPieceSize": "20000"}),  # cut finder + both runs per piece
+}
+
+
+def golden_single_gff(cfg):
+    return open(os.path.join(GOLDEN, "golden_single_%s.gff" % cfg)).read().splitlines()
+
+
 def sampled_records(cfg):
     names = SAMPLED_CFGS[cfg][2]
     recs = golden_inputs()

@@ -27,12 +27,16 @@ def test_model_tables_human():
 
 
 def test_unsupported_features_fail_loudly():
-    for opts in ({"UTR": "on"}, {"singlestrand": "true"}, {"hintsfile": "x.gff"}, {"genemodel": "bacterium"}):
+    for opts in ({"UTR": "on"}, {"singlestrand": "true", "genemodel": "atleastone"}, {"hintsfile": "x.gff"}, {"genemodel": "bacterium"},
+                 {"genemodel": "exactlyone"}, {"alternatives-from-sampling": "true"}):
         with pytest.raises(ax.AugxError) as e:
             ax.Model(config_path(), "human", **opts)
         assert e.value.code == ax.AUGX_E_UNSUPPORTED
     with pytest.raises(ax.AugxError):
         ax.Model(config_path(), "no_such_species")
+    # the single-strand and the intron-less model load (24 and 3 states)
+    assert ax.Model(config_path(), "human", singlestrand="true").n_states == 24
+    assert ax.Model(config_path(), "human", genemodel="intronless").n_states == 3
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")

@@ -38,6 +38,7 @@ BIG = {  # tests/golden/make_golden_big.py: BIG_CFGS
     "synth": ("synth", "human", []),                                             # config 3: one actual bench contig
     "human_intronless": ("genome", "human", ["--genemodel=intronless"]),         # 3-state model: one 1 Mbp piece in segments
     "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
+    "fly_single": ("genome", "fly", ["--singlestrand=true", "--UTR=off", "--sample=0"]),    # 24-state model, both runs of five 200 kb pieces
 }
 
 
@@ -236,3 +237,18 @@ def test_more_species_match_reference(monkeypatch, cfg):
     assert r.returncode == 0, r.stderr
     ours = [l for l in r.stderr.splitlines() if l.startswith("examining piece")] + gff_body(r.stdout)
     assert ours == open(os.path.join(GOLDEN, "golden_more_%s.gff" % cfg)).read().splitlines()
+
+
+@pytest.mark.parametrize("cfg", list(SINGLE_CFGS))
+def test_cli_singlestrand_matches_reference(tmp_path, cfg):
+    """--singlestrand=true: the model without shadow states on every piece and on its reverse complement, the genes of the second run
+    mapped back (exon types of the other strand), both lists merged by start -- incl. soft-masking, sampling (the draws run through the
+    forward run, then the reverse one), --strand=backward and the cut finder at 20 kb pieces: the reference binary's GFF"""
+    species, opts = SINGLE_CFGS[cfg]
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, golden_inputs())
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE, "--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert gff_body(r.stdout) == golden_single_gff(cfg)
+    assert r.stderr == ""
