@@ -488,7 +488,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
 // src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
 // =================================================================================================
 #ifdef AUGX_EMU
-static long long g_emuSlowA = 0, g_emuSlowB = 0; // emulator statistics: candidates taking the general evaluation path
+static long long g_emuSlowA = 0, g_emuSlowB = 0, g_emuSlowVig = 0, g_emuSlowList = 0, g_emuSlowWaves = 0, g_emuItemWaves = 0; // emulator statistics: candidates taking the general evaluation path
 #endif
 struct VarDesc { // 64 bytes (kind, frame and geometry of the state are per-state constants: VarConst)
     int8_t pl;              // plane (GC class) of the end base j: selects every class-dependent array
@@ -1560,6 +1560,10 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
                                 : tag == SRC_VIG ? &L.vigw[pay & (VIG_WIN - 1)] : &L.col0[sr & 0x3Fu];
             double pv = ldsLoadD(ptr);
             const bool slow = valid && ((tag == SRC_LIST && pay <= top) || (tag == SRC_VIG && pay <= vigLo));
+#ifdef AUGX_EMU
+            if (l == 0) g_emuItemWaves++;
+            if (slow) { if (tag == SRC_LIST) g_emuSlowList++; else g_emuSlowVig++; }
+#endif
             if (slow) { // the value left the LDS windows long ago: read it back from HBM
                 if (tag == SRC_LIST) {
                     const double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;

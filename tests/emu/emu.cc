@@ -251,6 +251,8 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     int nGaveUp = 0;
     for (int sg = 0; sg < B.nSegs; sg++) nGaveUp += segStop[sg] <= -2;
     if (getenv("AUGX_EMU_STATS")) {
+        fprintf(stderr, "emu stats: trellis candidates read back from HBM: igenic %lld, list %lld, in %lld chunks of 64\n", g_emuSlowVig, g_emuSlowList, g_emuItemWaves);
+
         fprintf(stderr, "emu stats: %d segments for %d pieces, check %d tiles, %d fix-ups gave up;", B.nSegs, n, B.segCheckTiles, nGaveUp);
         for (int sg = 0; sg < B.nSegs && sg < 24; sg++) fprintf(stderr, " [%d:%d..%d stop %d D %.3f cont %d]", plan.segs[sg].piece, plan.segs[sg].t0, plan.segs[sg].t1, segStop[sg], segD[sg], segStop2[sg]);
         fprintf(stderr, "\n");
