@@ -19,6 +19,14 @@
 #define AUGX_HD __host__ __device__ __forceinline__
 #endif
 
+// a table pointer read from a struct is generic to the compiler, and a load through it a flat load (slower, and it holds up the
+// LDS wait counter as well): the tables live in HBM, say so
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AUGX_GTAB(p) ((const __attribute__((address_space(1))) double *)(p))
+#else
+#define AUGX_GTAB(p) (p)
+#endif
+
 namespace augx {
 namespace dev {
 
@@ -483,7 +491,7 @@ AUGX_HD double exNotEndPart(const Piece &P, int kind, int win, int bs, int right
         int pn = g.fwd ? P.pat(bs, l + 1) : P.rcpat(bs, l + 1);
         if (pn >= 0) {
             int f = g.fwd ? fOR : mod3(fOR + right - bs);
-            rest = t.ex_pls[(((int64_t)c * (k + 1) + l) * 3 + f) * t.NP + pn];
+            rest = AUGX_GTAB(t.ex_pls)[(((int64_t)c * (k + 1) + l) * 3 + f) * t.NP + pn];
         } else
             rest = (l + 1) * t.ln_n_coding;
     } else {
@@ -491,10 +499,10 @@ AUGX_HD double exNotEndPart(const Piece &P, int kind, int win, int bs, int right
         if (k == 0) rest = 0;
         else if (g.fwd) {
             int pn = P.pat(bs, k);
-            rest = pn >= 0 ? t.ex_pls[(((int64_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR - right + endOfStart)) * t.NP + pn] : k * t.ln_n_coding;
+            rest = pn >= 0 ? AUGX_GTAB(t.ex_pls)[(((int64_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR - right + endOfStart)) * t.NP + pn] : k * t.ln_n_coding;
         } else {
             int pn = P.rcpat(beginOfInitP, k);
-            rest = pn >= 0 ? t.ex_pls[(((int64_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR + right - beginOfInitP)) * t.NP + pn] : k * t.ln_n_coding;
+            rest = pn >= 0 ? AUGX_GTAB(t.ex_pls)[(((int64_t)c * (k + 1) + (k - 1)) * 3 + mod3(fOR + right - beginOfInitP)) * t.NP + pn] : k * t.ln_n_coding;
         }
         const int a = g.fwd ? mod3(fOR - right) : mod3(fOR + right);
         const int fb = ((g.fwd ? 0 : 1) * 3 + a) * 3; // field base: +0 exon, +1 init, +2 et
@@ -547,12 +555,12 @@ AUGX_HD double exNotEndPart(const Piece &P, int kind, int win, int bs, int right
     double lenPart;
     if (len < 1 || len > t.max_exon_len) return AUGX_NINF;
     switch (kind) {
-    case AUGX_K_SINGLE: case AUGX_K_RSINGLE: lenPart = len % 3 == 0 ? t.len_single[len] : AUGX_NINF; break;
-    case AUGX_K_INITIAL: lenPart = (len % 3 == win && len > 2) ? t.len_initial[len] : AUGX_NINF; break;
-    case AUGX_K_RINITIAL: lenPart = len > 2 ? t.len_initial[len] : AUGX_NINF; break;
-    case AUGX_K_INTERNAL: case AUGX_K_RINTERNAL: lenPart = t.len_internal[len]; break;
-    case AUGX_K_TERMINAL: lenPart = t.len_terminal[len]; break;
-    default: lenPart = mod3(2 - len) == win ? t.len_terminal[len] : AUGX_NINF;
+    case AUGX_K_SINGLE: case AUGX_K_RSINGLE: lenPart = len % 3 == 0 ? AUGX_GTAB(t.len_single)[len] : AUGX_NINF; break;
+    case AUGX_K_INITIAL: lenPart = (len % 3 == win && len > 2) ? AUGX_GTAB(t.len_initial)[len] : AUGX_NINF; break;
+    case AUGX_K_RINITIAL: lenPart = len > 2 ? AUGX_GTAB(t.len_initial)[len] : AUGX_NINF; break;
+    case AUGX_K_INTERNAL: case AUGX_K_RINTERNAL: lenPart = AUGX_GTAB(t.len_internal)[len]; break;
+    case AUGX_K_TERMINAL: lenPart = AUGX_GTAB(t.len_terminal)[len]; break;
+    default: lenPart = mod3(2 - len) == win ? AUGX_GTAB(t.len_terminal)[len] : AUGX_NINF;
     }
     if (lenPart == AUGX_NINF) return AUGX_NINF;
     return (begin + rest) + lenPart;

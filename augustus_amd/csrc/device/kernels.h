@@ -544,7 +544,7 @@ AUGX_HD int longRow(const DevTables &T, int s) {
     if (kind == AUGX_K_RLONGASS) return 3 + T.win[s];
     return -1;
 }
-AUGX_HD double lnT(const DevTables &T, int c, int a, int s) { return T.ln_trans[((int64_t)c * T.S + a) * T.S + s]; }
+AUGX_HD double lnT(const DevTables &T, int c, int a, int s) { return AUGX_GTAB(T.ln_trans)[((int64_t)c * T.S + a) * T.S + s]; }
 AUGX_HD uint16_t bpFixed(int ai) { return (uint16_t)ai; }
 AUGX_HD uint16_t bpVar(int ai, int dist) { return (uint16_t)((ai << 14) | (dist & 0x3FFF)); }
 AUGX_HD uint32_t srcList(int ai, int sel, int frame, int64_t li) { return (SRC_LIST << 30) | ((uint32_t)ai << 28) | ((uint32_t)sel << 26) | ((uint32_t)frame << 24) | ((uint32_t)li & 0xFFFFFFu); }
