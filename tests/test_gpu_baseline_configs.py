@@ -212,6 +212,23 @@ def test_cli_genome_like_default_pieces(big_inputs, tmp_path):
     assert ours == gold
 
 
+def test_cli_genome_like_fly_defaults_with_sampling(big_inputs, tmp_path):
+    """the same two records with the fly model at its defaults but --UTR=off: 200 kb pieces (26 of them, cut points from 50 kb exam
+    windows), soft-masking bonus, --sample=100 -- 99 sampled paths per piece, one stream of draws over all pieces of both records --:
+    cut points, genes and every posterior probability equal the reference binary's (6 min on one core there)"""
+    import gzip
+    sys.path.insert(0, GOLDEN)
+    from make_golden_big import genome_like_records
+    fa = str(tmp_path / "genome_like.fa")
+    write_fasta(fa, genome_like_records(read_fasta(big_inputs["genome"])[0][1]))
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE, "--species=fly", "--UTR=off", "--progress=true", fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    ours = [l for l in r.stderr.splitlines() if l.startswith("examining piece")] + gff_body(r.stdout)
+    gold = gzip.open(os.path.join(GOLDEN, "golden_big_genome_like_fly_sampled.gff.gz"), "rt").read().splitlines()
+    assert ours == gold
+
+
 @pytest.mark.parametrize("cfg", list(MORE_CFGS))
 def test_more_species_match_reference(monkeypatch, cfg):
     """nasonia (5 GC classes) and rice (4) at a larger scale (tests/golden/make_golden_big.py: more_species): through the C ABI
