@@ -330,6 +330,11 @@ __global__ void __launch_bounds__(64) kSegFinalize(BatchView B) {
 }
 __global__ void __launch_bounds__(64) kBacktrace(const DevTables *T, BatchView B) { backtracePiece(*T, B, blockIdx.x); }
 // forward algorithm (posterior sampling only): one workgroup per piece, after the Viterbi decode (kernels.h: forwardPiece)
+// (snipmemo.h) candidate terms rebuilt on the host from the reference's snippet cache go back into the candidate records
+__global__ void __launch_bounds__(256) kPatchItems(BatchView B, const uint64_t *idx, const double *te, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) B.items[idx[i]].te = te[i];
+}
 template <int BLK> __global__ void __launch_bounds__(NT) kForward(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ FwdLds lds;
     forwardPiece<BLK>(*T, *B, lds, blockIdx.x);
@@ -945,7 +950,7 @@ int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out) {
     return AUGX_OK;
 }
 
-int augx_batch_forward(augx_decoder *d, augx_batch *b) {
+static int augx_batch_forward_launch(augx_decoder *d, augx_batch *b) {
     if (!d || !b || !b->decoded) { setLastError("augx_batch_forward: the batch has not been decoded"); return AUGX_E_ARG; }
     HIP_TRY(hipSetDevice(d->device));
     BatchView &W = b->V;
@@ -965,6 +970,100 @@ int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     else if (d->blk == 4) hipLaunchKernelGGL(kForward<4>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     else hipLaunchKernelGGL(kForward<2>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
+    return AUGX_OK;
+}
+
+} // extern "C"
+
+#include "snipmemo.h"
+
+namespace {
+// Pieces with several GC classes: within 2 d bases after a class step the reference's short-intron interiors are products of
+// cached chunks scored under different classes (snipmemo.h).  Which chunks depends on which predecessor cells are alive, and
+// that the first forward run has just told: the terms of the candidates concerned are rebuilt on the host and written back into
+// the candidate records.  Returns the number of rebuilt terms (> 0: the forward kernel has to run once more).
+int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched) {
+    nPatched = 0;
+    const BatchView &V = b->V;
+    const int n = V.nPieces, S = d->hostT.S;
+    std::vector<int32_t> nPl((size_t)n);
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(hipMemcpy(nPl.data(), V.nPlanes, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> pIdx;
+    std::vector<double> pTe;
+    for (int p = 0; p < n; p++) {
+        if (nPl[p] <= 1) continue;
+        SnippetReplay R;
+        const int len = b->L.len[p];
+        const int64_t o = b->L.off[p];
+        R.t = &d->model->m.t; R.n = len; R.S = S; R.blk = V.blk; R.d = d->model->m.t.d; R.nPlanes = nPl[p];
+        std::vector<double> F((size_t)len * S);
+        HIP_TRY(hipMemcpy(F.data(), V.fwd + (o + 1) * S, sizeof(double) * F.size(), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> plane((size_t)len);
+        HIP_TRY(hipMemcpy(plane.data(), V.gcPlane + o + 1, (size_t)len, hipMemcpyDeviceToHost));
+        std::vector<int32_t> planeCls(MAXPL);
+        HIP_TRY(hipMemcpy(planeCls.data(), V.planeCls + (int64_t)p * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+        const int nBlocks = (len + V.blk - 1) / V.blk;
+        const int64_t gb0 = o / V.blk;
+        std::vector<uint64_t> blkOff((size_t)nBlocks * 2);
+        std::vector<uint32_t> blkCnt((size_t)nBlocks * 2);
+        HIP_TRY(hipMemcpy(blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * blkOff.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * blkCnt.size(), hipMemcpyDeviceToHost));
+        uint64_t lo = ~0ull, hi = 0;
+        for (int q = 0; q < nBlocks; q++) {
+            const uint64_t a = blkOff[(size_t)q * 2 + 1], c = blkCnt[(size_t)q * 2 + 1];
+            if (c == 0) continue;
+            lo = a < lo ? a : lo;
+            hi = a + c > hi ? a + c : hi;
+        }
+        if (hi <= lo) continue;
+        std::vector<Item> items((size_t)(hi - lo));
+        HIP_TRY(hipMemcpy(items.data(), V.items + lo, sizeof(Item) * items.size(), hipMemcpyDeviceToHost));
+        R.F = F.data(); R.plane = plane.data(); R.planeCls = planeCls.data(); R.blkOff = blkOff.data(); R.blkCnt = blkCnt.data();
+        R.items = items.data(); R.item0 = lo;
+        // the intron content prefix of every plane: rows of CHUNK slots, NFX rows per chunk (dp.h: fidx)
+        const int64_t nCh = (b->L.off[p + 1] - o) / CHUNK;
+        R.fxF.assign((size_t)nPl[p], {}); R.fxR.assign((size_t)nPl[p], {});
+        for (int pl = 0; pl < nPl[p]; pl++)
+            for (int rev = 0; rev < 2; rev++) {
+                std::vector<uint64_t> &dst = rev ? R.fxR[pl] : R.fxF[pl];
+                dst.resize((size_t)nCh * CHUNK);
+                const uint64_t *src = V.fx + (int64_t)pl * V.N * NFX + ((o / CHUNK) * NFX + (rev ? FX_INR : FX_INF)) * CHUNK;
+                HIP_TRY(hipMemcpy2D(dst.data(), sizeof(uint64_t) * CHUNK, src, sizeof(uint64_t) * CHUNK * NFX, sizeof(uint64_t) * CHUNK, (size_t)nCh, hipMemcpyDeviceToHost));
+            }
+        R.run();
+        for (const MemoPatch &mp : R.patches) { pIdx.push_back(lo + mp.item); pTe.push_back(mp.te); }
+    }
+    nPatched = (int64_t)pIdx.size();
+    if (pIdx.empty()) return AUGX_OK;
+    void *dIdx = nullptr, *dTe = nullptr;
+    if (devMalloc(d, &dIdx, sizeof(uint64_t) * pIdx.size()) != hipSuccess || devMalloc(d, &dTe, sizeof(double) * pTe.size()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (dIdx) devFree(d, dIdx);
+        setLastError("augx_batch_forward: out of device memory");
+        return AUGX_E_NOMEM;
+    }
+    HIP_TRY(hipMemcpyAsync(dIdx, pIdx.data(), sizeof(uint64_t) * pIdx.size(), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemcpyAsync(dTe, pTe.data(), sizeof(double) * pTe.size(), hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(kPatchItems, dim3((unsigned)((pIdx.size() + 255) / 256)), dim3(256), 0, d->stream, V, (const uint64_t *)dIdx, (const double *)dTe, (int)pIdx.size());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->stream)); // (the host vectors and the two buffers go away)
+    devFree(d, dIdx); devFree(d, dTe);
+    return AUGX_OK;
+}
+} // namespace
+
+extern "C" {
+
+int augx_batch_forward(augx_decoder *d, augx_batch *b) {
+    int rc = augx_batch_forward_launch(d, b);
+    if (rc) return rc;
+    if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO")) { // (a batch with a multi-class piece)
+        int64_t nPatched = 0;
+        rc = snippetCacheReplay(d, b, nPatched);
+        if (rc) return rc;
+        if (nPatched > 0 && (rc = augx_batch_forward_launch(d, b))) return rc;
+    }
     if (!b->evFwd) HIP_TRY(hipEventCreateWithFlags(&b->evFwd, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->evFwd, d->stream));
     return AUGX_OK;

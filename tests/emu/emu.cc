@@ -13,6 +13,7 @@
 #include "../../augustus_amd/csrc/device/kernels.h"
 #include "../../augustus_amd/csrc/device/layout.h"
 #include "../../augustus_amd/csrc/device/sampler.h"
+#include "../../augustus_amd/csrc/device/snipmemo.h"
 
 using namespace augx::dev;
 
@@ -267,7 +268,36 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         std::vector<double> lnF(n);
         B.lnFwd = lnF.data();
         FwdLds *fl = new FwdLds();
-        for (int p = 0; p < n; p++) { if (blk == 8) forwardPiece<8>(T, B, *fl, p); else if (blk == 4) forwardPiece<4>(T, B, *fl, p); else forwardPiece<2>(T, B, *fl, p); }
+        auto fwdPiece = [&](int p) { if (blk == 8) forwardPiece<8>(T, B, *fl, p); else if (blk == 4) forwardPiece<4>(T, B, *fl, p); else forwardPiece<2>(T, B, *fl, p); };
+        for (int p = 0; p < n; p++) {
+            fwdPiece(p);
+            if (B.nPlanes[p] > 1 && !getenv("AUGX_NO_MEMO")) { // the reference's snippet cache around the class steps (snipmemo.h), then once more
+                SnippetReplay R;
+                const int len = L.len[p], S = t->S;
+                const int64_t o = L.off[p];
+                R.t = t; R.n = len; R.S = S; R.blk = blk; R.d = t->d;
+                R.F = B.fwd + (o + 1) * S;
+                R.plane = B.gcPlane + o + 1;
+                R.planeCls = B.planeCls + (int64_t)p * MAXPL;
+                R.nPlanes = B.nPlanes[p];
+                const int nBlocks = (len + blk - 1) / blk;
+                const int64_t gb0 = o / blk;
+                R.blkOff = B.blkOff + gb0 * 2; R.blkCnt = B.blkCnt + gb0 * 2;
+                uint64_t lo = ~0ull;
+                for (int q = 0; q < nBlocks; q++) if (R.blkCnt[(size_t)q * 2 + 1] && R.blkOff[(size_t)q * 2 + 1] < lo) lo = R.blkOff[(size_t)q * 2 + 1];
+                if (lo == ~0ull) lo = 0;
+                R.item0 = lo; R.items = B.items + lo;
+                R.fxF.assign((size_t)R.nPlanes, {}); R.fxR.assign((size_t)R.nPlanes, {});
+                for (int pl = 0; pl < R.nPlanes; pl++) {
+                    R.fxF[pl].resize((size_t)len + 1); R.fxR[pl].resize((size_t)len + 1);
+                    const uint64_t *fx = B.fx + (int64_t)pl * B.N * NFX;
+                    for (int g = 0; g <= len; g++) { R.fxF[pl][g] = fx[fidx(o + g, FX_INF, NFX)]; R.fxR[pl][g] = fx[fidx(o + g, FX_INR, NFX)]; }
+                }
+                R.run();
+                if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu stats: piece %d: %zu candidate terms rebuilt from the reference's snippet cache\n", p, R.patches.size());
+                if (!R.patches.empty()) fwdPiece(p);
+            }
+        }
         delete fl;
         int64_t w = 0;
         for (int p = 0; p < n; p++) {

@@ -204,8 +204,7 @@ def more_inputs():
 
 
 # posterior sampling (tests/golden/make_golden_sampled.py): cfg -> (species, options, record names of inputs.fa or None = all).
-# The reference's sampling inside a piece with several GC classes depends on the order its snippet cache was filled in
-# (DESIGN.md); the human cases are the records with one class.
+# (human1: the records with one GC class; human_all: every record)
 _ONE_CLASS = ("HS04636", "HS08198", "rand20k_b", "withN", "allN", "short7", "short100", "short600", "iupac", "trunc_left", "trunc_right",
               "trunc_both", "revcomp", "softmask_rand")
 SAMPLED_CFGS = {
@@ -215,8 +214,7 @@ SAMPLED_CFGS = {
     "human1": ("human", {"sample": "100", "softmasking": "0"}, _ONE_CLASS),
     "human1_sm": ("human", {"sample": "50"}, _ONE_CLASS),
     # the probability filter (src/gene.cc:2489-2512) with the Viterbi transcripts not exempt: genes drop out, the numbering follows
-    # all records incl. the ones with several GC classes in a piece: the reference's own draws there depend on the order its snippet
-    # cache was filled in; compared as "same genes, probabilities of another, equally valid sample" (test_gpu_sampling.py)
+    # all records incl. the ones with several GC classes in a piece (the reference's snippet cache around the class steps is replayed)
     "human_all": ("human", {"sample": "100", "softmasking": "0"}, None),
     "fly_filter": ("fly", {"UTR": "off", "softmasking": "0", "keep_viterbi": "false", "minexonintronprob": "0.3", "minmeanexonintronprob": "0.6"}, None),
 }

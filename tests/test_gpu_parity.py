@@ -263,7 +263,10 @@ def test_gpu_forward_matches_reference(tmp_path, cfg):
     of the REAL reference, run live: the same cells alive, ln F within 1e-9 relative"""
     from test_emu import _forward_records
     species, opts = GOLDEN_CFGS[cfg]
-    recs = _forward_records() + [("rand60k", dict(golden_inputs())["rand60k"])]
+    byname = dict(golden_inputs())
+    recs = _forward_records() + [("rand60k", byname["rand60k"])]
+    if cfg == "human_nosm": # pieces with several GC classes: the reference's snippet cache around the class steps is replayed (snipmemo.h)
+        recs += [(k, byname[k]) for k in ("multigc_gene", "multigc_two", "multigc_rand", "multigc_levels")]
     fa = str(tmp_path / "f.fa")
     write_fasta(fa, recs)
     Fref = ref_forward(fa, species, ["--%s=%s" % kv for kv in opts.items() if kv[0] != "sample"])
