@@ -35,6 +35,7 @@ BIG_CFGS = {
     "synth": ("synth", "human", []),
     "human_intronless": ("genome", "human", ["--genemodel=intronless"]),          # 3-state model, default flags, one 1 Mbp piece
     "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
+    "human_sampled": ("genome", "human", ["--sample=100"]),   # one 1 Mbp piece, two GC classes with ten steps, soft-masking, sampling
     "fly_single": ("genome", "fly", ["--singlestrand=true", "--UTR=off", "--sample=0"]),    # 24-state model, both runs of five 200 kb pieces
 }
 

@@ -39,6 +39,7 @@ BIG = {  # tests/golden/make_golden_big.py: BIG_CFGS
     "human_intronless": ("genome", "human", ["--genemodel=intronless"]),         # 3-state model: one 1 Mbp piece in segments
     "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
     "fly_single": ("genome", "fly", ["--singlestrand=true", "--UTR=off", "--sample=0"]),    # 24-state model, both runs of five 200 kb pieces
+    "human_sampled": ("genome", "human", ["--sample=100"]),   # one 1 Mbp piece, two GC classes with ten steps, soft-masking, sampling
 }
 
 
