@@ -66,6 +66,7 @@ def lib():
         L.augx_decoder_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.augx_decoder_destroy.argtypes = [ctypes.c_void_p]
         L.augx_decoder_set_share.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.augx_decoder_set_exact.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.augx_decoder_batch_capacity.restype = ctypes.c_int64
         L.augx_decoder_batch_capacity.argtypes = [ctypes.c_void_p]
         L.augx_batch_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -318,6 +319,10 @@ class Decoder:
         self._batches = weakref.WeakSet()
         self._h = ctypes.c_void_p()
         _check(lib().augx_decoder_create(model._h, device, ctypes.byref(self._h)))
+
+    def set_exact(self, on=True):
+        """``augx_decoder_set_exact``: replay the reference's snippet cache on pieces with several GC classes for the Viterbi run, too"""
+        _check(lib().augx_decoder_set_exact(self._h, 1 if on else 0))
 
     def set_share(self, n):
         """n decoders (streams) work on this device at the same time: plan the trellis segments for 1/n of its compute units"""

@@ -359,9 +359,11 @@ struct augx_decoder {
     std::multimap<size_t, void *> pool;
     std::unordered_map<void *, size_t> live;
     size_t pooledBytes = 0;
+    bool exactMulti = false;   // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
 namespace {
+int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists); // (below, with the forward algorithm)
 void poolRelease(augx_decoder *d) {
     for (auto &kv : d->pool) (void)hipFree(kv.second);
     d->pool.clear();
@@ -511,6 +513,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->blk = blk;
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
+    if (const char *ex = getenv("AUGX_EXACT_MULTICLASS")) d->exactMulti = atoi(ex) != 0;
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) d->nCU = cu; else (void)hipGetLastError(); }
     const int rc = [&]() -> int { // (any failure below: the half-built decoder is destroyed, nothing leaks)
         HIP_TRY(hipStreamCreate(&d->stream));
@@ -535,6 +538,12 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
 int augx_decoder_set_share(augx_decoder *d, int n) {
     if (!d || n < 1) { setLastError("augx_decoder_set_share: bad argument"); return AUGX_E_ARG; }
     d->share = n;
+    return AUGX_OK;
+}
+
+int augx_decoder_set_exact(augx_decoder *d, int on) {
+    if (!d) return AUGX_E_ARG;
+    d->exactMulti = on != 0;
     return AUGX_OK;
 }
 
@@ -810,6 +819,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     }
     if (b->plan.cut()) hipLaunchKernelGGL(kTileCross, dim3((unsigned)((V.N / WAVE + 255) / 256)), dim3(256), 0, st, V); // how far back the future reads (fix-ups)
     HIP_TRY(hipEventRecord(b->ev[1], st));
+    auto runTrellis = [&]() -> int { // the trellis passes and the back-trace (run again when candidate terms were rebuilt, see below)
     HIP_TRY(hipMemsetAsync(V.segStatus, 0, sizeof(int32_t) * V.nSegs, st));
 #define AUGX_LAUNCH_TRELLIS(MODE_, grid_) do { \
         if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
@@ -834,8 +844,22 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     HIP_TRY(hipEventRecord(b->ev[2], st));
     hipLaunchKernelGGL(kBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->ev[3], st));
+    return AUGX_OK;
+    };
+    int rcT = runTrellis();
+    if (rcT) return rcT;
     b->decoded = true;
+    // Pieces with several GC classes, exact mode (augx_decoder_set_exact; always on when sampling): the reference's snippet cache
+    // around the class steps is replayed from which donor-site values are alive (snipmemo.h), the candidate terms concerned are
+    // rebuilt and the trellis runs once more -- every Viterbi variable is then the reference's to 1e-9 there, too.  Off by default:
+    // it costs a second trellis run, and no path has been seen to depend on it.
+    if (d->exactMulti && b->nPlAlloc > 1) {
+        int64_t nPatched = 0;
+        int rc2 = snippetCacheReplay(d, b, nPatched, true);
+        if (rc2) return rc2;
+        if (nPatched > 0 && (rc2 = runTrellis())) return rc2;
+    }
+    HIP_TRY(hipEventRecord(b->ev[3], st));
     return AUGX_OK;
 }
 
@@ -982,7 +1006,7 @@ namespace {
 // cached chunks scored under different classes (snipmemo.h).  Which chunks depends on which predecessor cells are alive, and
 // that the first forward run has just told: the terms of the candidates concerned are rebuilt on the host and written back into
 // the candidate records.  Returns the number of rebuilt terms (> 0: the forward kernel has to run once more).
-int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched) {
+int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists) {
     nPatched = 0;
     const BatchView &V = b->V;
     const int n = V.nPieces, S = d->hostT.S;
@@ -997,8 +1021,22 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched) {
         const int len = b->L.len[p];
         const int64_t o = b->L.off[p];
         R.t = &d->model->m.t; R.n = len; R.S = S; R.blk = V.blk; R.d = d->model->m.t.d; R.nPlanes = nPl[p];
-        std::vector<double> F((size_t)len * S);
-        HIP_TRY(hipMemcpy(F.data(), V.fwd + (o + 1) * S, sizeof(double) * F.size(), hipMemcpyDeviceToHost));
+        std::vector<double> F, ldV, rdV, col0;
+        if (!fromLists) {
+            F.resize((size_t)len * S);
+            HIP_TRY(hipMemcpy(F.data(), V.fwd + (o + 1) * S, sizeof(double) * F.size(), hipMemcpyDeviceToHost));
+        } else { // (after a Viterbi run: what the trellis left at the donor sites of the short introns, and the initial column)
+            int64_t lo2[2] = {0, 0};
+            HIP_TRY(hipMemcpy(lo2, V.listOffs + p, sizeof(int64_t) * 2, hipMemcpyDeviceToHost));
+            const size_t cnt = (size_t)(lo2[1] - lo2[0]) * 3;
+            ldV.resize(cnt + 1); rdV.resize(cnt + 1);
+            if (cnt) {
+                HIP_TRY(hipMemcpy(ldV.data(), V.ldVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(rdV.data(), V.rdVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+            }
+            col0.resize((size_t)S);
+            for (int s2 = 0; s2 < S; s2++) col0[s2] = b->L.initKind[p] == 0 ? d->hostT.ln_init[s2] : (s2 == d->hostT.synch ? 0.0 : -INFINITY);
+        }
         std::vector<uint8_t> plane((size_t)len);
         HIP_TRY(hipMemcpy(plane.data(), V.gcPlane + o + 1, (size_t)len, hipMemcpyDeviceToHost));
         std::vector<int32_t> planeCls(MAXPL);
@@ -1019,7 +1057,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched) {
         if (hi <= lo) continue;
         std::vector<Item> items((size_t)(hi - lo));
         HIP_TRY(hipMemcpy(items.data(), V.items + lo, sizeof(Item) * items.size(), hipMemcpyDeviceToHost));
-        R.F = F.data(); R.plane = plane.data(); R.planeCls = planeCls.data(); R.blkOff = blkOff.data(); R.blkCnt = blkCnt.data();
+        R.F = fromLists ? nullptr : F.data(); R.ldVal = ldV.data(); R.rdVal = rdV.data(); R.col0 = col0.data(); R.plane = plane.data(); R.planeCls = planeCls.data(); R.blkOff = blkOff.data(); R.blkCnt = blkCnt.data();
         R.items = items.data(); R.item0 = lo;
         // the intron content prefix of every plane: rows of CHUNK slots, NFX rows per chunk (dp.h: fidx)
         const int64_t nCh = (b->L.off[p + 1] - o) / CHUNK;
@@ -1060,7 +1098,7 @@ int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     if (rc) return rc;
     if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO")) { // (a batch with a multi-class piece)
         int64_t nPatched = 0;
-        rc = snippetCacheReplay(d, b, nPatched);
+        rc = snippetCacheReplay(d, b, nPatched, false);
         if (rc) return rc;
         if (nPatched > 0 && (rc = augx_batch_forward_launch(d, b))) return rc;
     }

@@ -31,7 +31,10 @@ struct MemoPatch { uint64_t item; double te; }; // item index relative to Snippe
 struct SnippetReplay {
     const augx_tables *t = nullptr;
     int n = 0, S = 0, blk = 8, d = 0;
-    const double *F = nullptr;            // [n][S] ln forward of a first run (only which cells are alive is used)
+    // which predecessor cells are alive, from a first run: the ln forward matrix F [n][S], or -- after a Viterbi run, which keeps no
+    // matrix -- the values the trellis left at the donor sites (ldVal / rdVal: [entry][3 frames]) and the initial column col0 [S]
+    const double *F = nullptr;
+    const double *ldVal = nullptr, *rdVal = nullptr, *col0 = nullptr;
     const uint8_t *plane = nullptr;       // [n] plane of every base
     const int32_t *planeCls = nullptr;    // [MAXPL] class of a plane
     int nPlanes = 1;
@@ -127,7 +130,10 @@ struct SnippetReplay {
                         const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
                         const uint32_t tag = I.src >> 30;
                         // (a request is made only where a predecessor cell is alive; column 0 holds the initial probabilities)
-                        const double pv = tag == SRC_COL0 ? F[(size_t)(I.src & 0x3Fu)] : (eop >= 0 ? F[(size_t)eop * S2 + a] : -INFINITY);
+                        double pv;
+                        if (F) pv = tag == SRC_COL0 ? F[(size_t)(I.src & 0x3Fu)] : (eop >= 0 ? F[(size_t)eop * S2 + a] : -INFINITY);
+                        else if (tag == SRC_COL0) pv = col0[I.src & 0x3Fu];
+                        else pv = (((I.src >> 26) & 3) == 2 ? ldVal : rdVal)[(size_t)(I.src & 0xFFFFFFu) * 3 + ((I.src >> 24) & 3)];
                         if (!(pv > -INFINITY)) continue;
                         reqs.push_back({tag == SRC_COL0 ? 0 : eop, i0 + it});
                     }

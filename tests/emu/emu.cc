@@ -241,12 +241,49 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     }
     TrellisLds *lds = new TrellisLds();
 #define EMU_TRELLIS(MODE_, idx) do { if (blk == 8) trellisPiece<8, MODE_>(T, B, *lds, idx); else if (blk == 4) trellisPiece<4, MODE_>(T, B, *lds, idx); else trellisPiece<2, MODE_>(T, B, *lds, idx); } while (0)
-    for (int sg = 0; sg < B.nSegs; sg++) EMU_TRELLIS(0, sg);
-    if (plan.cut()) {
-        for (int sg = B.nSegs - 1; sg >= 0; sg--) EMU_TRELLIS(1, sg); // (any order: the fix-ups are independent of each other)
-        for (int round = 0; round < SEG_CONT_ROUNDS; round++)
-            for (int p = 0; p < n; p++) EMU_TRELLIS(2, p);
-        for (int p = 0; p < n; p++) EMU_TRELLIS(3, p);
+    auto runTrellis = [&]() {
+        std::fill(segStop.begin(), segStop.end(), -1); std::fill(segStop2.begin(), segStop2.end(), -1); std::fill(segStatus.begin(), segStatus.end(), 0);
+        std::fill(pieceCovered.begin(), pieceCovered.end(), -1);
+        for (int sg = 0; sg < B.nSegs; sg++) EMU_TRELLIS(0, sg);
+        if (plan.cut()) {
+            for (int sg = B.nSegs - 1; sg >= 0; sg--) EMU_TRELLIS(1, sg); // (any order: the fix-ups are independent of each other)
+            for (int round = 0; round < SEG_CONT_ROUNDS; round++)
+                for (int p = 0; p < n; p++) EMU_TRELLIS(2, p);
+            for (int p = 0; p < n; p++) EMU_TRELLIS(3, p);
+        }
+    };
+    runTrellis();
+    if (getenv("AUGX_EXACT_MULTICLASS")) { // (augx_decoder_set_exact) the reference's snippet cache on pieces with several GC classes, then again
+        size_t nPatched = 0;
+        for (int p = 0; p < n; p++) {
+            if (B.nPlanes[p] <= 1) continue;
+            SnippetReplay R;
+            const int len = L.len[p], S = t->S;
+            const int64_t o = L.off[p], lo2 = B.listOffs[p];
+            std::vector<double> col0((size_t)S);
+            for (int s2 = 0; s2 < S; s2++) col0[s2] = L.initKind[p] == 0 ? t->ln_init[s2] : (s2 == t->synch_state ? 0.0 : -INFINITY);
+            R.t = t; R.n = len; R.S = S; R.blk = blk; R.d = t->d;
+            R.ldVal = B.ldVal + lo2 * 3; R.rdVal = B.rdVal + lo2 * 3; R.col0 = col0.data();
+            R.plane = B.gcPlane + o + 1;
+            R.planeCls = B.planeCls + (int64_t)p * MAXPL;
+            R.nPlanes = B.nPlanes[p];
+            const int nBlocks = (len + blk - 1) / blk;
+            const int64_t gb0 = o / blk;
+            R.blkOff = B.blkOff + gb0 * 2; R.blkCnt = B.blkCnt + gb0 * 2;
+            uint64_t lo = ~0ull;
+            for (int q = 0; q < nBlocks; q++) if (R.blkCnt[(size_t)q * 2 + 1] && R.blkOff[(size_t)q * 2 + 1] < lo) lo = R.blkOff[(size_t)q * 2 + 1];
+            if (lo == ~0ull) lo = 0;
+            R.item0 = lo; R.items = B.items + lo;
+            R.fxF.assign((size_t)R.nPlanes, {}); R.fxR.assign((size_t)R.nPlanes, {});
+            for (int pl = 0; pl < R.nPlanes; pl++) {
+                R.fxF[pl].resize((size_t)len + 1); R.fxR[pl].resize((size_t)len + 1);
+                const uint64_t *fx = B.fx + (int64_t)pl * B.N * NFX;
+                for (int g = 0; g <= len; g++) { R.fxF[pl][g] = fx[fidx(o + g, FX_INF, NFX)]; R.fxR[pl][g] = fx[fidx(o + g, FX_INR, NFX)]; }
+            }
+            R.run();
+            nPatched += R.patches.size();
+        }
+        if (nPatched) runTrellis();
     }
 #undef EMU_TRELLIS
     int nGaveUp = 0;
