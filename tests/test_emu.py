@@ -233,6 +233,59 @@ def test_emulated_exact_mode_viterbi_cells_with_several_gc_classes(tmp_path, mon
             assert [(b, e2, emu_state_type(m.tables_ptr, st)) for b, e2, st in e[2]] == r["path"], name
 
 
+@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [901, 909, 916])
+def test_emulated_exact_mode_randomised(tmp_path, monkeypatch, seed):
+    """random records of GC-shifted stretches, real DNA and N runs (two to four GC classes per record) for the human and the
+    saccharomyces model, exact mode: every Viterbi and every forward variable and the path of the live reference (a soak of 30 such
+    cases incl. rice and nasonia, 4 classes, was clean)"""
+    import random
+    import struct
+    import tarfile
+    rng = random.Random(seed)
+    with tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz")) as t:
+        t.extractall(str(tmp_path))
+    g = read_fasta(str(tmp_path / "genome.fa"))[0][1]
+
+    def gc_dna(n, gc):
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(n))
+
+    def mk():
+        parts = []
+        for k in range(rng.randint(3, 6)):
+            L = rng.choice([1500, 3000, 4000, 6000])
+            r = rng.random()
+            if r < 0.6:
+                parts.append(gc_dna(L, rng.choice([0.25, 0.33, 0.38, 0.42, 0.47, 0.52, 0.58, 0.65, 0.72])))
+            elif r < 0.85:
+                st = rng.randrange(0, len(g) - L)
+                parts.append(g[st:st + L].upper())
+            else:
+                parts.append(gc_dna(L // 2, 0.4) + "N" * rng.choice([1, 30, 400]) + gc_dna(L // 2, 0.6))
+        return "".join(parts)
+    species = rng.choice(["human", "saccharomyces"])
+    recs = [("r%d" % k, mk()) for k in range(2)]
+    fa = str(tmp_path / "f.fa")
+    write_fasta(fa, recs)
+    extra = ["--softmasking=0", "--UTR=off"]
+    cells = str(tmp_path / "cells.bin")
+    res, err = ref_harness(fa, species, extra, cells_file=cells)
+    Fref = ref_forward(fa, species, extra)
+    m = ax.Model(config_path(), species, softmasking="0", UTR="off", sample="0")
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "1")
+    em = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, cells=True, forward=True)
+    with open(cells, "rb") as f:
+        for (name, seq), r, e, fr in zip(recs, res, em, Fref):
+            n, S = struct.unpack("ii", f.read(8))
+            vref = np.frombuffer(f.read(n * S * 8), dtype=np.float64).reshape(n, S)
+            f.read(n * 4)
+            for X, ref in ((e[3], vref), (e[5], fr)):
+                assert np.array_equal(np.isfinite(X), np.isfinite(ref)), name
+                both = np.isfinite(X)
+                assert np.all(np.abs(X[both] - ref[both]) <= 1e-9 * np.abs(ref[both]) + 5e-9), name
+            assert [(b, e2, emu_state_type(m.tables_ptr, st)) for b, e2, st in e[2]] == r["path"], name
+
+
 @pytest.mark.parametrize("cfg", ["fly", "arabidopsis", "human1", "human1_sm"])
 def test_emulated_sampling_matches_reference_paths(cfg):
     """posterior sampling of state paths (device/sampler.h on the emulator's forward matrix) against the REAL reference's
