@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <string>
 #include <vector>
 #include "kernels.h"
@@ -1015,62 +1017,123 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     HIP_TRY(hipMemcpy(nPl.data(), V.nPlanes, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     std::vector<uint64_t> pIdx;
     std::vector<double> pTe;
-    for (int p = 0; p < n; p++) {
-        if (nPl[p] <= 1) continue;
+    // what the replay of one piece reads, fetched from HBM; the replays themselves run side by side on host threads, eight pieces
+    // at a time (each holds its piece's candidate records: 0.23 GB per Mbp)
+    struct PieceData {
         SnippetReplay R;
+        std::vector<double> F, F0, ldV, rdV, col0;
+        std::vector<uint8_t> plane;
+        std::vector<int32_t> planeCls;
+        std::vector<uint64_t> blkOff;
+        std::vector<uint32_t> blkCnt;
+    };
+    auto fetch = [&](int p, PieceData &D) -> int {
+        SnippetReplay &R = D.R;
         const int len = b->L.len[p];
         const int64_t o = b->L.off[p];
         R.t = &d->model->m.t; R.n = len; R.S = S; R.blk = V.blk; R.d = d->model->m.t.d; R.nPlanes = nPl[p];
-        std::vector<double> F, ldV, rdV, col0;
-        if (!fromLists) {
-            F.resize((size_t)len * S);
-            HIP_TRY(hipMemcpy(F.data(), V.fwd + (o + 1) * S, sizeof(double) * F.size(), hipMemcpyDeviceToHost));
+        if (!fromLists) { // (the rows of F a window reads are fetched with the window; the initial column now)
+            D.F0.resize((size_t)S);
+            HIP_TRY(hipMemcpy(D.F0.data(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)S, hipMemcpyDeviceToHost));
         } else { // (after a Viterbi run: what the trellis left at the donor sites of the short introns, and the initial column)
             int64_t lo2[2] = {0, 0};
             HIP_TRY(hipMemcpy(lo2, V.listOffs + p, sizeof(int64_t) * 2, hipMemcpyDeviceToHost));
             const size_t cnt = (size_t)(lo2[1] - lo2[0]) * 3;
-            ldV.resize(cnt + 1); rdV.resize(cnt + 1);
+            D.ldV.resize(cnt + 1); D.rdV.resize(cnt + 1);
             if (cnt) {
-                HIP_TRY(hipMemcpy(ldV.data(), V.ldVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(rdV.data(), V.rdVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(D.ldV.data(), V.ldVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(D.rdV.data(), V.rdVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
             }
-            col0.resize((size_t)S);
-            for (int s2 = 0; s2 < S; s2++) col0[s2] = b->L.initKind[p] == 0 ? d->hostT.ln_init[s2] : (s2 == d->hostT.synch ? 0.0 : -INFINITY);
+            D.col0.resize((size_t)S);
+            for (int s2 = 0; s2 < S; s2++) D.col0[s2] = b->L.initKind[p] == 0 ? d->hostT.ln_init[s2] : (s2 == d->hostT.synch ? 0.0 : -INFINITY);
         }
-        std::vector<uint8_t> plane((size_t)len);
-        HIP_TRY(hipMemcpy(plane.data(), V.gcPlane + o + 1, (size_t)len, hipMemcpyDeviceToHost));
-        std::vector<int32_t> planeCls(MAXPL);
-        HIP_TRY(hipMemcpy(planeCls.data(), V.planeCls + (int64_t)p * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+        D.plane.resize((size_t)len);
+        HIP_TRY(hipMemcpy(D.plane.data(), V.gcPlane + o + 1, (size_t)len, hipMemcpyDeviceToHost));
+        D.planeCls.resize(MAXPL);
+        HIP_TRY(hipMemcpy(D.planeCls.data(), V.planeCls + (int64_t)p * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
         const int nBlocks = (len + V.blk - 1) / V.blk;
         const int64_t gb0 = o / V.blk;
-        std::vector<uint64_t> blkOff((size_t)nBlocks * 2);
-        std::vector<uint32_t> blkCnt((size_t)nBlocks * 2);
-        HIP_TRY(hipMemcpy(blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * blkOff.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * blkCnt.size(), hipMemcpyDeviceToHost));
-        uint64_t lo = ~0ull, hi = 0;
-        for (int q = 0; q < nBlocks; q++) {
-            const uint64_t a = blkOff[(size_t)q * 2 + 1], c = blkCnt[(size_t)q * 2 + 1];
-            if (c == 0) continue;
-            lo = a < lo ? a : lo;
-            hi = a + c > hi ? a + c : hi;
-        }
-        if (hi <= lo) continue;
-        std::vector<Item> items((size_t)(hi - lo));
-        HIP_TRY(hipMemcpy(items.data(), V.items + lo, sizeof(Item) * items.size(), hipMemcpyDeviceToHost));
-        R.F = fromLists ? nullptr : F.data(); R.ldVal = ldV.data(); R.rdVal = rdV.data(); R.col0 = col0.data(); R.plane = plane.data(); R.planeCls = planeCls.data(); R.blkOff = blkOff.data(); R.blkCnt = blkCnt.data();
-        R.items = items.data(); R.item0 = lo;
-        // the intron content prefix of every plane: rows of CHUNK slots, NFX rows per chunk (dp.h: fidx)
-        const int64_t nCh = (b->L.off[p + 1] - o) / CHUNK;
+        D.blkOff.resize((size_t)nBlocks * 2);
+        D.blkCnt.resize((size_t)nBlocks * 2);
+        HIP_TRY(hipMemcpy(D.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * D.blkOff.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(D.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * D.blkCnt.size(), hipMemcpyDeviceToHost));
+        R.F = nullptr; R.F0 = fromLists ? nullptr : D.F0.data(); R.ldVal = D.ldV.data(); R.rdVal = D.rdV.data(); R.col0 = D.col0.data();
+        R.plane = D.plane.data(); R.planeCls = D.planeCls.data(); R.blkOff = D.blkOff.data(); R.blkCnt = D.blkCnt.data();
+        R.items = nullptr; R.item0 = 0;
+        R.blkPool.assign((size_t)nBlocks, -1);
         R.fxF.assign((size_t)nPl[p], {}); R.fxR.assign((size_t)nPl[p], {});
-        for (int pl = 0; pl < nPl[p]; pl++)
-            for (int rev = 0; rev < 2; rev++) {
-                std::vector<uint64_t> &dst = rev ? R.fxR[pl] : R.fxF[pl];
-                dst.resize((size_t)nCh * CHUNK);
-                const uint64_t *src = V.fx + (int64_t)pl * V.N * NFX + ((o / CHUNK) * NFX + (rev ? FX_INR : FX_INF)) * CHUNK;
-                HIP_TRY(hipMemcpy2D(dst.data(), sizeof(uint64_t) * CHUNK, src, sizeof(uint64_t) * CHUNK * NFX, sizeof(uint64_t) * CHUNK, (size_t)nCh, hipMemcpyDeviceToHost));
+        const int nplP = nPl[p], blkSz = V.blk;
+        PieceData *DP = &D;
+        // what the window [t0, t1] reads: the candidate records of its blocks (a tile's records are contiguous), the rows of F and
+        // the slots of the intron content prefix from d bases before it on
+        R.fetch = [=](int t0, int t1) -> int {
+            SnippetReplay &R2 = DP->R;
+            if (t0 < 0) t0 = 0;
+            if (t1 > len - 1) t1 = len - 1;
+            const int r0 = t0 - R2.d - 2 > 0 ? t0 - R2.d - 2 : 0;
+            const int b0 = t0 / blkSz, b1 = t1 / blkSz;
+            R2.pool.clear();
+            std::fill(R2.blkPool.begin(), R2.blkPool.end(), (int64_t)-1);
+            size_t total = 0;
+            for (int q = b0; q <= b1; q++) total += DP->blkCnt[(size_t)q * 2 + 1];
+            R2.pool.resize(total + 1);
+            size_t w = 0;
+            for (int q = b0; q <= b1;) { // runs of blocks whose records follow each other in HBM: one copy each
+                const uint64_t a0 = DP->blkOff[(size_t)q * 2 + 1];
+                uint64_t a1 = a0;
+                int q1 = q;
+                while (q1 <= b1 && (DP->blkCnt[(size_t)q1 * 2 + 1] == 0 || DP->blkOff[(size_t)q1 * 2 + 1] == a1)) {
+                    if (DP->blkCnt[(size_t)q1 * 2 + 1]) { R2.blkPool[(size_t)q1] = (int64_t)(w + (a1 - a0)); a1 += DP->blkCnt[(size_t)q1 * 2 + 1]; }
+                    q1++;
+                }
+                if (a1 > a0) HIP_TRY(hipMemcpy(R2.pool.data() + w, V.items + a0, sizeof(Item) * (size_t)(a1 - a0), hipMemcpyDeviceToHost));
+                w += (size_t)(a1 - a0);
+                if (q1 == q) q1 = q + 1; // (cannot happen: the first block of a run always joins it)
+                q = q1;
             }
-        R.run();
-        for (const MemoPatch &mp : R.patches) { pIdx.push_back(lo + mp.item); pTe.push_back(mp.te); }
+            if (!fromLists) {
+                DP->F.resize((size_t)(t1 - r0 + 1) * S);
+                HIP_TRY(hipMemcpy(DP->F.data(), V.fwd + (o + 1 + r0) * S, sizeof(double) * DP->F.size(), hipMemcpyDeviceToHost));
+                R2.F = DP->F.data(); R2.fRow0 = r0;
+            }
+            // prefix slots r0 .. t1 + 1 (slot g = prefix up to base g - 1) of both strands and every plane: field rows of CHUNK slots
+            R2.fx0 = r0;
+            const int g0 = r0, g1 = t1 + 1;
+            for (int pl = 0; pl < nplP; pl++)
+                for (int rev = 0; rev < 2; rev++) {
+                    std::vector<uint64_t> &dst = rev ? R2.fxR[pl] : R2.fxF[pl];
+                    dst.resize((size_t)(g1 - g0 + 1));
+                    for (int g = g0; g <= g1;) {
+                        const int64_t slot = o + g, ch = slot / CHUNK;
+                        int cnt = (int)((ch + 1) * CHUNK - slot);
+                        if (cnt > g1 - g + 1) cnt = g1 - g + 1;
+                        const uint64_t *src = V.fx + (int64_t)pl * V.N * NFX + (ch * NFX + (rev ? FX_INR : FX_INF)) * CHUNK + slot % CHUNK;
+                        HIP_TRY(hipMemcpy(dst.data() + (g - g0), src, sizeof(uint64_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+                        g += cnt;
+                    }
+                }
+            return AUGX_OK;
+        };
+        return AUGX_OK;
+    };
+    std::vector<int> todo;
+    for (int p = 0; p < n; p++)
+        if (nPl[p] > 1) todo.push_back(p);
+    for (size_t g0 = 0; g0 < todo.size(); g0 += 8) {
+        const size_t g1 = g0 + 8 < todo.size() ? g0 + 8 : todo.size();
+        std::vector<std::unique_ptr<PieceData>> grp;
+        for (size_t k = g0; k < g1; k++) {
+            grp.emplace_back(new PieceData());
+            const int rc = fetch(todo[k], *grp.back());
+            if (rc) return rc;
+        }
+        std::vector<std::future<int>> runs;
+        for (auto &D : grp) runs.push_back(std::async(std::launch::async, [&D, d]() { (void)hipSetDevice(d->device); return D->R.run(); }));
+        int rcRun = 0;
+        for (auto &f : runs) { const int r1 = f.get(); if (r1 && !rcRun) rcRun = r1; }
+        if (rcRun) { setLastError("augx: fetching the data of a snippet-cache window failed"); return rcRun; }
+        for (auto &D : grp)
+            for (const MemoPatch &mp : D->R.patches) { pIdx.push_back(mp.item); pTe.push_back(mp.te); }
     }
     nPatched = (int64_t)pIdx.size();
     if (pIdx.empty()) return AUGX_OK;

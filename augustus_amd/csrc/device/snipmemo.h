@@ -14,6 +14,7 @@
 // What comes out are the forward values of the reference to 1e-9, hence its sampled paths.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <vector>
 #include <algorithm>
@@ -25,7 +26,7 @@ namespace dev {
 struct MemoChunk { int32_t end, len; int32_t plane; };
 struct MemoEntry { int32_t len; std::vector<MemoChunk> dec; };
 
-struct MemoPatch { uint64_t item; double te; }; // item index relative to SnippetReplay::items
+struct MemoPatch { uint64_t item; double te; }; // global index of the candidate record (as in blkOff)
 
 // everything of one piece the replay reads (host memory)
 struct SnippetReplay {
@@ -40,6 +41,15 @@ struct SnippetReplay {
     int nPlanes = 1;
     Item *items = nullptr;                // candidates of the piece, starting at global index item0 (te is rewritten in place)
     uint64_t item0 = 0;
+    // Windowed mode (the device library): only what a window reads is fetched from HBM, by `fetch`, before the window is replayed --
+    // the candidate records of its blocks (pool / blkPool), the rows fRow0.. of F, the prefix slots fx0.. .  Whole mode (the
+    // emulator, whose arrays are host memory anyway): fetch is empty, everything above points at the whole piece.
+    std::function<int(int, int)> fetch;   // (t0, t1) -> 0, or an error code that run() hands on
+    std::vector<Item> pool;
+    std::vector<int64_t> blkPool;         // [nBlocks] first record of the block in pool, -1: not fetched
+    const double *F0 = nullptr;           // row 0 of F (the initial column), windowed mode
+    int fRow0 = 0, fx0 = 0;
+    Item *blockItems(int b) { return fetch ? (blkPool[(size_t)b] >= 0 ? pool.data() + blkPool[(size_t)b] : nullptr) : items + (blkOff[(size_t)b * 2 + 1] - item0); }
     const uint64_t *blkOff = nullptr;     // [nBlocks][2]
     const uint32_t *blkCnt = nullptr;     // [nBlocks][2]
     // fixed-point content prefix of the intron model: fx(plane, rev, g) with g = slot relative to the piece (0 = before the first base)
@@ -49,7 +59,7 @@ struct SnippetReplay {
     int64_t segFx(int pl, bool rev, int l, int r) const { // fixed-point content of bases l..r under plane pl
         if (l > r) return 0;
         const std::vector<uint64_t> &a = rev ? fxR[pl] : fxF[pl];
-        return (int64_t)(a[(size_t)r + 1] - a[(size_t)l]);
+        return (int64_t)(a[(size_t)(r + 1 - fx0)] - a[(size_t)(l - fx0)]);
     }
 
     // ---- the cache of one strand: lists[base] sorted by length (SnippetList)
@@ -111,13 +121,13 @@ struct SnippetReplay {
             if (t->state_kind[s] == AUGX_K_LESSD) lessF.push_back(s);
             else if (t->state_kind[s] == AUGX_K_RLESSD) lessR.push_back(s);
         }
-        struct Req { int eop; uint64_t item; };
+        struct Req { int eop; Item *item; uint64_t gidx; };
         std::vector<Req> reqs;
         for (int j = (t0 < 1 ? 1 : t0); j <= t1 && j < n; j++) {
             const int pl = plane[j];
             const int b = j / blk;
-            const uint64_t i0 = blkOff[(size_t)b * 2 + 1] - item0;
-            const uint32_t cnt = blkCnt[(size_t)b * 2 + 1];
+            Item *bi = blockItems(b);
+            const uint32_t cnt = bi ? blkCnt[(size_t)b * 2 + 1] : 0;
             for (int st = 0; st < 2; st++) {
                 const std::vector<int> &states = st == 0 ? lessF : lessR;
                 for (int s : states) {
@@ -125,17 +135,17 @@ struct SnippetReplay {
                     const int a = t->anc[s][0];
                     reqs.clear();
                     for (uint32_t it = 0; it < cnt; it++) {
-                        const Item &I = items[i0 + it];
+                        const Item &I = bi[it];
                         if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
                         const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
                         const uint32_t tag = I.src >> 30;
                         // (a request is made only where a predecessor cell is alive; column 0 holds the initial probabilities)
                         double pv;
-                        if (F) pv = tag == SRC_COL0 ? F[(size_t)(I.src & 0x3Fu)] : (eop >= 0 ? F[(size_t)eop * S2 + a] : -INFINITY);
+                        if (F) pv = tag == SRC_COL0 ? (F0 ? F0 : F)[(size_t)(I.src & 0x3Fu)] : (eop >= fRow0 ? F[(size_t)(eop - fRow0) * S2 + a] : -INFINITY);
                         else if (tag == SRC_COL0) pv = col0[I.src & 0x3Fu];
                         else pv = (((I.src >> 26) & 3) == 2 ? ldVal : rdVal)[(size_t)(I.src & 0xFFFFFFu) * 3 + ((I.src >> 24) & 3)];
                         if (!(pv > -INFINITY)) continue;
-                        reqs.push_back({tag == SRC_COL0 ? 0 : eop, i0 + it});
+                        reqs.push_back({tag == SRC_COL0 ? 0 : eop, bi + it, blkOff[(size_t)b * 2 + 1] + it});
                     }
                     std::sort(reqs.begin(), reqs.end(), [](const Req &x, const Req &y) { return x.eop > y.eop; }); // from near to far
                     for (const Req &rq : reqs) {
@@ -157,7 +167,7 @@ struct SnippetReplay {
                         const int cls = planeCls[pl];
                         const double tr = t->ln_trans[((int64_t)cls * S2 + a) * S2 + s];
                         const double te = tr + (t->len_intron[intronLength] + (double)fx * AUGX_FX_INV);
-                        if (te != items[rq.item].te) { items[rq.item].te = te; patches.push_back({rq.item, te}); }
+                        if (te != rq.item->te) { rq.item->te = te; patches.push_back({rq.gidx, te}); }
                     }
                 }
             }
@@ -166,9 +176,9 @@ struct SnippetReplay {
 
     // all windows of the piece: a class step at base b can leave its mark on candidates ending in [b, b + 2 d]; the caches that
     // matter then were started no earlier than b - d
-    void run() {
+    int run() {
         patches.clear();
-        if (nPlanes <= 1) return;
+        if (nPlanes <= 1) return 0;
         std::vector<int> steps;
         for (int j = 1; j < n; j++)
             if (plane[j] != plane[j - 1]) steps.push_back(j);
@@ -178,9 +188,11 @@ struct SnippetReplay {
             int t1 = first + 2 * d + 64;
             size_t k = i + 1;
             while (k < steps.size() && steps[k] - d - 64 <= t1) { t1 = steps[k] + 2 * d + 64; k++; }
+            if (fetch) { const int rc = fetch(first - d - 64, t1); if (rc) return rc; }
             window(first - d - 64, t1, first);
             i = k;
         }
+        return 0;
     }
 };
 
