@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end soak on a GPU box: random inputs and option combinations through the `augustus` executable and through the
+REAL reference binary (oracle/_ref/augustus_ref, which travels with the repository), GFF compared byte for byte.
+    python tests/soak_cli.py SEED0 N          (prints one line per case; exit code = number of failures)"""
+import os
+import random
+import subprocess
+import sys
+import tarfile
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import *  # noqa
+
+EXE = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
+
+
+def main():
+    seed0, n = int(sys.argv[1]), int(sys.argv[2])
+    d = tempfile.mkdtemp()
+    with tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz")) as t:
+        t.extractall(d)
+    g = read_fasta(os.path.join(d, "genome.fa"))[0][1]
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    fails = 0
+    for seed in range(seed0, seed0 + n):
+        rng = random.Random(seed)
+
+        def gc_dna(k, gc):
+            return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(k))
+        recs = []
+        for k in range(rng.randint(1, 4)):
+            parts = []
+            for _ in range(rng.randint(1, 5)):
+                L = rng.choice([800, 3000, 7000, 15000, 40000])
+                r = rng.random()
+                if r < 0.45:
+                    st = rng.randrange(0, len(g) - L)
+                    s = g[st:st + L]
+                    if rng.random() < 0.5:
+                        s = s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+                    parts.append(s)
+                elif r < 0.8:
+                    parts.append(gc_dna(L, rng.choice([0.3, 0.4, 0.45, 0.5, 0.6, 0.7])))
+                else:
+                    parts.append(gc_dna(L // 2, 0.45) + "N" * rng.choice([1, 50, 900]) + gc_dna(L // 2, 0.55).lower())
+            recs.append(("r%d" % k, "".join(parts)))
+        species = rng.choice(["human", "fly", "arabidopsis", "saccharomyces", "human", "fly"])
+        opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
+        if rng.random() < 0.4:
+            opts["softmasking"] = "0"
+        if rng.random() < 0.3:
+            opts["singlestrand"] = "true"
+        elif rng.random() < 0.2:
+            opts["genemodel"] = rng.choice(["intronless", "complete"])
+        if rng.random() < 0.3:
+            opts["strand"] = rng.choice(["forward", "backward"])
+        if rng.random() < 0.4:
+            opts["maxDNAPieceSize"] = rng.choice(["20000", "50000"])
+        if rng.random() < 0.2:
+            opts["gff3"] = "on"
+        if rng.random() < 0.2:
+            opts["introns"] = "on"
+        fa = os.path.join(d, "c%d.fa" % seed)
+        write_fasta(fa, recs)
+        args = ["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa]
+        ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
+        ours = subprocess.run([EXE] + args, capture_output=True, text=True, env=env)
+        ok = ref.returncode == ours.returncode and (ref.returncode != 0 or gff_body(ref.stdout) == gff_body(ours.stdout))
+        print("seed", seed, species, opts, [len(s) for _, s in recs], "OK" if ok else "FAIL rc %d/%d" % (ref.returncode, ours.returncode), flush=True)
+        if not ok:
+            fails += 1
+            if ref.returncode == 0 and ours.returncode == 0:
+                import difflib
+                print("\n".join(list(difflib.unified_diff(gff_body(ref.stdout), gff_body(ours.stdout), lineterm="", n=0))[:12]))
+            else:
+                print(ours.stderr[-300:], ref.stderr[-300:])
+        else:
+            os.remove(fa)
+    return fails
+
+
+if __name__ == "__main__":
+    sys.exit(main())
