@@ -9,6 +9,7 @@ Mirrors the reference's call sequence for this path
 ``NAMGene::doViterbiPiecewise``; reference ``src/augustus.cc:111-176,420``).
 """
 import ctypes
+import sys
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -129,6 +130,10 @@ class Model:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
+        # (objects that live until the interpreter shuts down -- e.g. held by the traceback of a failed test -- are left to the
+        #  operating system: by then the HIP runtime may have run its own exit handlers, and calling into it crashes)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -223,6 +228,10 @@ class Batch:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
+        # (objects that live until the interpreter shuts down -- e.g. held by the traceback of a failed test -- are left to the
+        #  operating system: by then the HIP runtime may have run its own exit handlers, and calling into it crashes)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -239,6 +248,8 @@ class Rand:
         return lib().augx_rand_next(self._h)
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             if self._h:
                 lib().augx_rand_destroy(self._h)
@@ -344,6 +355,10 @@ class Decoder:
             self._h = ctypes.c_void_p()
 
     def __del__(self):
+        # (objects that live until the interpreter shuts down -- e.g. held by the traceback of a failed test -- are left to the
+        #  operating system: by then the HIP runtime may have run its own exit handlers, and calling into it crashes)
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

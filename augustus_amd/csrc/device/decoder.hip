@@ -361,7 +361,7 @@ struct augx_decoder {
     std::multimap<size_t, void *> pool;
     std::unordered_map<void *, size_t> live;
     size_t pooledBytes = 0;
-    bool exactMulti = false;   // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
+    bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
 namespace {
@@ -853,8 +853,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     b->decoded = true;
     // Pieces with several GC classes, exact mode (augx_decoder_set_exact; always on when sampling): the reference's snippet cache
     // around the class steps is replayed from which donor-site values are alive (snipmemo.h), the candidate terms concerned are
-    // rebuilt and the trellis runs once more -- every Viterbi variable is then the reference's to 1e-9 there, too.  Off by default:
-    // it costs a second trellis run, and no path has been seen to depend on it.
+    // rebuilt and the trellis runs once more -- every Viterbi variable is then the reference's to 1e-9 there, too.  On by default:
+    // a randomised soak found a record whose optimal path depends on it; AUGX_EXACT_MULTICLASS=0 trades that for
+    // the second trellis run.
     if (d->exactMulti && b->nPlAlloc > 1) {
         int64_t nPatched = 0;
         int rc2 = snippetCacheReplay(d, b, nPatched, true);

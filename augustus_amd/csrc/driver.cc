@@ -510,8 +510,6 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             augx_decoder *d = nullptr;
             rc = augx_decoder_create(S.model, dv, &d);
             if (rc) { restore(); return fail(augx_last_error()); }
-            // (with sampling the Viterbi run and the forward run see the same candidate terms on pieces with several GC classes)
-            if (S.sampleiterations > 0) augx_decoder_set_exact(d, 1);
             S.decs.push_back(d);
         }
     }

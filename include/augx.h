@@ -168,9 +168,10 @@ int augx_decoder_set_share(augx_decoder *d, int n_decoders_on_device);
 /* bases one batch should hold at most: what fits the free device memory (about 1.5 KB per base), capped at 128 Mbp */
 /* Pieces with several GC classes: the reference's short-intron content cache (SnippetProbs, src/statemodel.cc:312-342) is not
  * emptied at a class step, so within 2 d bases after one an interior may be scored in chunks of different classes.  With
- * exact = 1 the cache is replayed after a first trellis run and the run repeated with the rebuilt terms: every Viterbi variable
- * is then the reference's to 1e-9 there as well (default 0: one trellis run; no path has been seen to differ).  The forward
- * algorithm (augx_batch_forward) always replays it. */
+ * exact = 1 (the default; environment AUGX_EXACT_MULTICLASS=0 turns it off) the cache is replayed after a first trellis run and
+ * the run repeated with the rebuilt terms: every Viterbi variable is then the reference's to 1e-9 there as well -- and the path:
+ * a randomised soak found a record where the optimal path depends on it.  exact = 0 saves the second trellis run on batches
+ * with such pieces.  The forward algorithm (augx_batch_forward) always replays it. */
 int augx_decoder_set_exact(augx_decoder *d, int exact);
 int64_t augx_decoder_batch_capacity(augx_decoder *d);
 

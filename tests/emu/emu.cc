@@ -253,7 +253,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         }
     };
     runTrellis();
-    if (getenv("AUGX_EXACT_MULTICLASS")) { // (augx_decoder_set_exact) the reference's snippet cache on pieces with several GC classes, then again
+    if (!getenv("AUGX_EXACT_MULTICLASS") || atoi(getenv("AUGX_EXACT_MULTICLASS")) != 0) { // (augx_decoder_set_exact, on by default) the reference's snippet cache on pieces with several GC classes, then again
         size_t nPatched = 0;
         for (int p = 0; p < n; p++) {
             if (B.nPlanes[p] <= 1) continue;

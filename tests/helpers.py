@@ -231,6 +231,15 @@ SINGLE_CFGS = {
 }
 
 
+def multiclass_path_case():
+    """a 25 kb record (found by tests/soak_cli.py, seed 4025) whose OPTIMAL PATH under the human single-strand model depends on the
+    reference's snippet cache across a GC-class step: (sequence, options, reference ln Viterbi, reference path)"""
+    import gzip
+    g = json.load(open(os.path.join(GOLDEN, "multiclass_path_case.json")))
+    seq = gzip.open(os.path.join(GOLDEN, "multiclass_path_case.fa.gz"), "rt").read().split("\n")[1]
+    return seq, g["options"], float(g["lnv"]), [tuple(p) for p in g["path"]]
+
+
 def golden_single_gff(cfg):
     return open(os.path.join(GOLDEN, "golden_single_%s.gff" % cfg)).read().splitlines()
 

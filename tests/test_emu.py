@@ -8,6 +8,14 @@ import augustus_amd as ax
 from helpers import *
 
 
+@pytest.fixture(autouse=True)
+def _one_class_per_end_base(monkeypatch):
+    """The CPU twin scores a short-intron interior with the class of its end base, as the kernels do; the replay of the reference's
+    snippet cache on pieces with several GC classes (exact mode, the product's default) sits on top of that and is tested against the
+    real reference by the tests that switch it on.  Everything else here compares kernels and twin: exact mode off."""
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
+
+
 @pytest.mark.parametrize("cfg", list(GOLDEN_CFGS))
 def test_emulated_kernels_bit_identical_to_oracle(cfg):
     species, opts = GOLDEN_CFGS[cfg]
@@ -286,6 +294,19 @@ def test_emulated_exact_mode_randomised(tmp_path, monkeypatch, seed):
             assert [(b, e2, emu_state_type(m.tables_ptr, st)) for b, e2, st in e[2]] == r["path"], name
 
 
+def test_emulated_exact_mode_decides_a_path(monkeypatch):
+    """the record a randomised end-to-end soak found: with one class per end base the optimal path takes another acceptor site
+    (ln V off by 0.03) than the reference; with the reference's snippet cache replayed (exact mode, the product's default) path and
+    score are the reference's"""
+    seq, opts, lnv, path = multiclass_path_case()
+    m = ax.Model(config_path(), "human", sample="0", **opts)
+    r0, = emu_decode(m.tables_ptr, [seq.upper()], m.n_states)
+    assert [(b, e, emu_state_type(m.tables_ptr, st)) for b, e, st in r0[2]] != path and abs(r0[1] - lnv) > 0.01
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "1")
+    r1, = emu_decode(m.tables_ptr, [seq.upper()], m.n_states)
+    assert [(b, e, emu_state_type(m.tables_ptr, st)) for b, e, st in r1[2]] == path and abs(r1[1] - lnv) <= 1e-9 * abs(lnv)
+
+
 @pytest.mark.parametrize("cfg", ["fly", "arabidopsis", "human1", "human1_sm"])
 def test_emulated_sampling_matches_reference_paths(cfg):
     """posterior sampling of state paths (device/sampler.h on the emulator's forward matrix) against the REAL reference's
@@ -335,6 +356,7 @@ def test_emulated_forward_with_several_gc_classes_matches_reference(tmp_path, mo
         both = np.isfinite(F)
         assert np.all(np.abs(F[both] - fr[both]) <= 1e-9 * np.abs(fr[both]) + 5e-9), name
     monkeypatch.setenv("AUGX_NO_MEMO", "1") # (and the replay is what does it)
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
     res = emu_decode(m.tables_ptr, [recs[2][1].upper()], m.n_states, forward=True)
     both = np.isfinite(res[0][5])
     assert np.sum(np.abs(res[0][5][both] - Fref[2][both]) > 1e-9 * np.abs(Fref[2][both]) + 5e-9) > 1000

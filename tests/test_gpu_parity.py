@@ -12,6 +12,14 @@ import augustus_amd as ax
 from helpers import *
 
 
+@pytest.fixture(autouse=True)
+def _one_class_per_end_base(monkeypatch):
+    """the CPU twin scores a short-intron interior with the class of its end base, as the kernels do; the replay of the reference's
+    snippet cache on pieces with several GC classes (exact mode, the decoder's default) sits on top of that and is checked against the
+    real reference by the tests that switch it on.  The tests here compare device and twin: decoders are created with exact mode off."""
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
+
+
 @pytest.fixture(scope="module")
 def human():
     m = ax.Model(config_path(), "human")
@@ -281,3 +289,22 @@ def test_gpu_forward_matches_reference(tmp_path, cfg):
         both = np.isfinite(F)
         assert np.all(np.abs(F[both] - fr[both]) <= 1e-9 * np.abs(fr[both]) + 5e-9), name
         assert lnp >= r.ln_viterbi
+
+
+def test_gpu_exact_mode_decides_a_path():
+    """the record whose optimal path depends on the reference's snippet cache across a GC-class step (tests/soak_cli.py, seed 4025):
+    the decoder's default (exact mode) gives the reference's path and score, augx_decoder_set_exact(0) the one-class-per-end-base
+    answer of the CPU twin"""
+    seq, opts, lnv, path = multiclass_path_case()
+    m = ax.Model(config_path(), "human", sample="0", **opts)
+    d = ax.Decoder(m, 0)
+    d.set_exact(True) # (the default of a decoder; the fixture of this file turned it off)
+    b = ax.Batch(d, [seq.upper()])
+    b.decode()
+    r, = b.paths()
+    assert [(bb, e, t) for bb, e, s, t in r.states] == path and abs(r.ln_viterbi - lnv) <= 1e-9 * abs(lnv)
+    d.set_exact(False)
+    b.decode()
+    r0, = b.paths()
+    rc, lnv0, path0, _, _ = twin_decode(m.tables_ptr, seq.upper(), m.n_states)
+    assert r0.states == path0 and r0.ln_viterbi == lnv0 and [(bb, e, t) for bb, e, s, t in r0.states] != path
