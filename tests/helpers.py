@@ -313,7 +313,9 @@ def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=N
     P = (_Piece * n)()
     keep = [s.encode() if isinstance(s, str) else s for s in seqs]
     for i, b in enumerate(keep):
-        P[i].seq, P[i].len, P[i].init_kind, P[i].term_kind = b, len(b), init_kind, term_kind
+        P[i].seq, P[i].len = b, len(b)
+        P[i].init_kind = init_kind[i] if isinstance(init_kind, (list, tuple)) else init_kind
+        P[i].term_kind = term_kind[i] if isinstance(term_kind, (list, tuple)) else term_kind
     lnv = np.zeros(n)
     st = np.zeros(n, dtype=np.int32)
     cap = max(1024, max(len(s) for s in seqs) // 4 + 16)
