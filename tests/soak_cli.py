@@ -34,7 +34,7 @@ def main():
             for _ in range(rng.randint(1, 5)):
                 L = rng.choice([800, 3000, 7000, 15000, 40000])
                 r = rng.random()
-                if r < 0.45:
+                if r < (0.9 if os.environ.get("SOAK_REAL") else 0.45): # (SOAK_REAL=1: nine parts in ten are slices of real DNA)
                     st = rng.randrange(0, len(g) - L)
                     s = g[st:st + L]
                     if rng.random() < 0.5:
