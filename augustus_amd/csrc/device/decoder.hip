@@ -18,6 +18,7 @@
 #include <future>
 #include <memory>
 #include <string>
+#include <system_error>
 #include <vector>
 #include "kernels.h"
 #include "layout.h"
@@ -858,7 +859,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     // the second trellis run.
     if (d->exactMulti && b->nPlAlloc > 1) {
         int64_t nPatched = 0;
-        int rc2 = snippetCacheReplay(d, b, nPatched, true);
+        int rc2;
+        try { rc2 = snippetCacheReplay(d, b, nPatched, true); }
+        catch (const std::exception &e) { setLastError(std::string("augx_batch_decode: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc2) return rc2;
         if (nPatched > 0 && (rc2 = runTrellis())) return rc2;
     }
@@ -1129,8 +1132,15 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
             if (rc) return rc;
         }
         std::vector<std::future<int>> runs;
-        for (auto &D : grp) runs.push_back(std::async(std::launch::async, [&D, d]() { (void)hipSetDevice(d->device); return D->R.run(); }));
         int rcRun = 0;
+        for (auto &D : grp) {
+            try {
+                runs.push_back(std::async(std::launch::async, [&D, d]() { (void)hipSetDevice(d->device); return D->R.run(); }));
+            } catch (const std::system_error &) { // (no more threads to be had: this piece on the calling thread)
+                const int r1 = D->R.run();
+                if (r1 && !rcRun) rcRun = r1;
+            }
+        }
         for (auto &f : runs) { const int r1 = f.get(); if (r1 && !rcRun) rcRun = r1; }
         if (rcRun) { setLastError("augx: fetching the data of a snippet-cache window failed"); return rcRun; }
         for (auto &D : grp)
@@ -1162,7 +1172,8 @@ int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     if (rc) return rc;
     if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO")) { // (a batch with a multi-class piece)
         int64_t nPatched = 0;
-        rc = snippetCacheReplay(d, b, nPatched, false);
+        try { rc = snippetCacheReplay(d, b, nPatched, false); }
+        catch (const std::exception &e) { setLastError(std::string("augx_batch_forward: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc) return rc;
         if (nPatched > 0 && (rc = augx_batch_forward_launch(d, b))) return rc;
     }
@@ -1215,6 +1226,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     if (b->evFwd) HIP_TRY(hipEventSynchronize(b->evFwd)); else HIP_TRY(hipStreamSynchronize(d->stream));
     const BatchView &V = b->V;
     const augx_tables &t = d->model->m.t;
+    try {
     std::unique_ptr<augx_sample_prep> H(new augx_sample_prep());
     SamplePiece &P = H->P;
     P.t = &t; P.S = t.S; P.n = b->L.len[piece]; P.blk = V.blk;
@@ -1264,6 +1276,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     prepareStops(P);
     *out = H.release();
     return AUGX_OK;
+    } catch (const std::exception &e) { setLastError(std::string("augx_batch_sample: ") + e.what() + " (out of host memory?)"); return AUGX_E_NOMEM; }
 }
 
 void augx_sample_prep_destroy(augx_sample_prep *h) { delete h; }
@@ -1273,7 +1286,8 @@ int augx_sample_prep_run(augx_sample_prep *h, int n_samples, augx_rand *R, augx_
     for (int i = 0; i < n_samples; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = 0; out[i].ln_viterbi = 0; }
     std::vector<std::vector<augx_state>> paths;
     std::vector<int> status;
-    samplePaths(h->P, n_samples, *R, paths, status);
+    try { samplePaths(h->P, n_samples, *R, paths, status); }
+    catch (const std::exception &e) { setLastError(std::string("augx_batch_sample: ") + e.what() + " (out of host memory?)"); return AUGX_E_NOMEM; }
     for (int it = 0; it < n_samples; it++) {
         out[it].status = status[it];
         if (status[it] != AUGX_OK) continue;

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include "capi_internal.h"
@@ -135,11 +136,16 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             std::vector<std::future<std::pair<int, augx_sample_prep *>>> prep((size_t)cnt);
             auto launch = [&](int p) {
                 if (p >= cnt || rc || !n_samples || out[first + p].status != AUGX_OK) return;
-                prep[p] = std::async(std::launch::async, [&, p]() {
+                auto job = [&, p]() {
                     augx_sample_prep *h = nullptr;
                     const int r = augx_batch_sample_prepare(decs[d], b, p, &h);
                     return std::make_pair(r, h);
-                });
+                };
+                try {
+                    prep[p] = std::async(std::launch::async, job);
+                } catch (const std::system_error &) { // (no more threads to be had: fetched when its turn comes)
+                    prep[p] = std::async(std::launch::deferred, job);
+                }
             };
             for (int p = 0; p < AHEAD; p++) launch(p);
             {
