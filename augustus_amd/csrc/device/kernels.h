@@ -1861,8 +1861,14 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (r < rlo || r >= rhi) continue;
                 const int jp = j - fLag[r][TI];
                 const bool lg = fLong[r][TI] != 0;
-                const double *p0 = lg ? &L.eqPrev[buf][j & 63][fAnc0[r][TI]] : &L.ring[jp & 63][fAnc0[r][TI]];
-                const double *p1 = lg ? &L.eqPrev[buf][j & 63][fAnc1[r][TI]] : &L.ring[jp & 63][fAnc1[r][TI]];
+                // a long-lag cell (equalD: its predecessors dStateLen bases back) comes from eqPrev, which the loaders staged from HBM
+                // while the tile before this one was being computed.  With dStateLen in [64, 128) the predecessor may lie IN that
+                // tile -- not computed yet when eqPrev was staged: it is read from that tile's own long-lag rows, which stay in
+                // LDS (the other half of the double buffer) until the next tile starts.  (The first tile of a run has no tile
+                // before it in LDS; its eqPrev was staged before anything ran, from values an earlier run completed.)
+                const bool inPrevTile = lg && dL < 2 * WAVE && jp >= (jb / WAVE) * WAVE - WAVE && jb / WAVE > tStart;
+                const double *p0 = lg ? (inPrevTile ? &L.longW[buf ^ 1][jp & 63][fAnc0[r][TI]] : &L.eqPrev[buf][j & 63][fAnc0[r][TI]]) : &L.ring[jp & 63][fAnc0[r][TI]];
+                const double *p1 = lg ? (inPrevTile ? &L.longW[buf ^ 1][jp & 63][fAnc1[r][TI]] : &L.eqPrev[buf][j & 63][fAnc1[r][TI]]) : &L.ring[jp & 63][fAnc1[r][TI]];
                 emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
                 pv0[r] = ldsLoadD(p0); pv1[r] = ldsLoadD(p1);
                 si[r] = L.site[buf][j & 63][fList[r][TI] & 3];

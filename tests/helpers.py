@@ -196,6 +196,10 @@ GOLDEN_CFGS = {
 MORE_CFGS = {
     "nasonia": ("nasonia", {"UTR": "off", "sample": "0", "softmasking": "0"}),
     "rice": ("rice", {"UTR": "off", "sample": "0", "softmasking": "0"}),
+    # two fungi whose equalD states look back 64 and 112 bases (dStateLen = d - splice windows): one to two tiles -- their predecessors
+    # may lie in the tile before the current one, which is not in HBM yet when the current tile's long-lag values are staged
+    "fusarium_graminearum": ("fusarium_graminearum", {"UTR": "off", "softmasking": "0"}),          # dStateLen 64; sample = 100 (default)
+    "phanerochaete_chrysosporium": ("phanerochaete_chrysosporium", {"UTR": "off", "sample": "0", "softmasking": "0"}),  # 112
 }
 
 
