@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Sweep over every species directory of the reference (build container only: needs /root/reference and oracle/_ref): the device
+kernels on the lane-loop emulator + the host gene stage against the REAL reference, species after species.
+    python tests/sweep_species.py sampled [K N]     each species at its defaults (--UTR=off; sample 100 where that is the default):
+                                                    GFF incl. posterior probabilities against the reference binary, four records
+    python tests/sweep_species.py variants [K N]    --singlestrand=true / --genemodel=intronless / complete / soft-masking on:
+                                                    state paths and ln Viterbi against the reference harness, three records
+    python tests/sweep_species.py edge [K N]        twelve edge-case records (7 bases, all N, IUPAC, cut genes, ...): paths and scores
+(K N: this process takes every N-th species starting at K -- run N of them side by side.)  One line per species and mode; a species
+whose model is outside the path says why (SKIP / EMU FAILED), anything else but OK is a bug."""
+import os
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from helpers import *  # noqa
+import augustus_amd as ax
+
+CFG = "/root/reference/config/"
+
+
+def species_list(k, nw):
+    for i, sp in enumerate(sorted(os.listdir(CFG + "species"))):
+        if i % nw == k and os.path.exists(CFG + "species/%s/%s_parameters.cfg" % (sp, sp)):
+            yield sp
+
+
+def sampled(k, nw):
+    byname = dict(golden_inputs())
+    recs = [(n, byname[n]) for n in ("HS04636", "multigc_levels", "rand20k_b", "trunc_both")]
+    fa = "/tmp/sweep_sampled_%d.fa" % k
+    write_fasta(fa, recs)
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=CFG)
+    for sp in species_list(k, nw):
+        opts = {"UTR": "off", "softmasking": "0"}
+        try:
+            m = ax.Model(CFG, sp, **opts)
+        except Exception as e:
+            print(sp, "SKIP", str(e)[:70], flush=True)
+            continue
+        ns = int(m.option("sample") or 0)
+        ns = 0 if 0 < ns < 10 else ns
+        out = subprocess.run([REF_AUGUSTUS, "--species=" + sp] + ["--%s=%s" % kv for kv in opts.items()] + [fa], capture_output=True, text=True, env=env)
+        if out.returncode != 0:
+            print(sp, "REF FAILED", flush=True)
+            continue
+        try:
+            res = emu_decode(m.tables_ptr, [s.upper() for _, s in recs], m.n_states, samples=max(ns - 1, 0))
+        except Exception:
+            print(sp, "EMU FAILED (model outside the kernels' scheduling assumptions, layout.h: checkModelSupported)", flush=True)
+            continue
+        if any(r[0] != 0 for r in res):
+            print(sp, "STATUS", [r[0] for r in res], flush=True)
+            continue
+        paths = [[(b, e, st, emu_state_type(m.tables_ptr, st)) for b, e, st in r[2]] for r in res]
+        mine = format_gff_sampled(m, recs, paths, [r[7] for r in res]) if ns else format_gff(m, recs, paths)
+        print(sp, "sample", ns, "OK" if mine == gff_body(out.stdout) else "FAIL", flush=True)
+
+
+def paths_against_harness(k, nw, names, modes):
+    byname = dict(golden_inputs())
+    recs = [(n, byname[n]) for n in names]
+    fa = "/tmp/sweep_paths_%d.fa" % k
+    write_fasta(fa, recs)
+    for sp in species_list(k, nw):
+        for mode, mopts, soft in modes:
+            opts = {"UTR": "off", "sample": "0"}
+            opts.update(mopts)
+            if not soft:
+                opts["softmasking"] = "0"
+            try:
+                m = ax.Model(CFG, sp, **opts)
+            except Exception as e:
+                print(sp, mode, "SKIP", str(e)[:60], flush=True)
+                break
+            res, err = ref_harness(fa, sp, ["--%s=%s" % kv for kv in opts.items()], cfg=CFG)
+            if len(res) != len(recs):
+                print(sp, mode, "REF FAILED", flush=True)
+                continue
+            try:
+                em = emu_decode(m.tables_ptr, [s if soft else s.upper() for _, s in recs], m.n_states)
+            except Exception:
+                print(sp, mode, "EMU FAILED", flush=True)
+                continue
+            ok = True
+            for (name, s), r, e in zip(recs, res, em):
+                if "err" in r or r["lnv"] is None:
+                    ok = ok and e[0] != 0
+                    continue
+                p2 = [(b, e2, emu_state_type(m.tables_ptr, st)) for b, e2, st in e[2]]
+                if e[0] != 0 or p2 != r["path"] or abs(e[1] - r["lnv"]) > 1e-9 * abs(r["lnv"]) + 1e-9:
+                    ok = False
+                    print("   ", sp, mode, name, "status", e[0], "lnv", e[1], r["lnv"], "path same", p2 == r["path"], flush=True)
+            print(sp, mode, "OK" if ok else "FAIL", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1]
+    k, nw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 1)
+    os.environ.setdefault("AUGX_EXACT_MULTICLASS", "1")
+    if what == "sampled":
+        sampled(k, nw)
+    elif what == "variants":
+        paths_against_harness(k, nw, ("HS04636", "multigc_levels", "softmask_gene"),
+                              [("single", {"singlestrand": "true"}, False), ("intronless", {"genemodel": "intronless"}, False),
+                               ("complete", {"genemodel": "complete"}, False), ("softmask", {}, True)])
+    else:
+        paths_against_harness(k, nw, ("short7", "short100", "short600", "allN", "iupac", "withN", "trunc_left", "trunc_right", "revcomp",
+                                      "softmask_all", "softmask_rand", "multigc_two"), [("edge", {}, True)])
