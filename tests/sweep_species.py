@@ -6,6 +6,8 @@ kernels on the lane-loop emulator + the host gene stage against the REAL referen
     python tests/sweep_species.py variants [K N]    --singlestrand=true / --genemodel=intronless / complete / soft-masking on:
                                                     state paths and ln Viterbi against the reference harness, three records
     python tests/sweep_species.py edge [K N]        twelve edge-case records (7 bases, all N, IUPAC, cut genes, ...): paths and scores
+    python tests/sweep_species.py segments [K N]    90 + 60 kb of soft-masked real DNA, the trellis forced into 20 kb segments: score and
+                                                    path bit-identical to the sequential CPU twin
 (K N: this process takes every N-th species starting at K -- run N of them side by side.)  One line per species and mode; a species
 whose model is outside the path says why (SKIP / EMU FAILED), anything else but OK is a bug."""
 import os
@@ -95,12 +97,41 @@ def paths_against_harness(k, nw, names, modes):
             print(sp, mode, "OK" if ok else "FAIL", flush=True)
 
 
+def segments(k, nw):
+    import tarfile
+    import tempfile
+    d = tempfile.mkdtemp()
+    with tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz")) as t:
+        t.extractall(d)
+    g = read_fasta(os.path.join(d, "genome.fa"))[0][1]
+    seqs = [g[200000:290000], g[500000:560000][::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))]
+    os.environ["AUGX_EXACT_MULTICLASS"] = "0" # (the twin scores with one class per end base)
+    os.environ["AUGX_SEG_LEN"] = "20000"
+    for sp in species_list(k, nw):
+        try:
+            m = ax.Model(CFG, sp, UTR="off", sample="0")
+        except Exception:
+            continue
+        try:
+            em = emu_decode(m.tables_ptr, seqs, m.n_states)
+        except Exception:
+            print(sp, "EMU FAILED", flush=True)
+            continue
+        ok = True
+        for s, e in zip(seqs, em):
+            rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states)
+            ok = ok and e[0] == rc and e[1] == lnv and e[2] == [(b, e2, st) for b, e2, st, t in path]
+        print(sp, "segments", "OK" if ok else "FAIL", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     k, nw = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 1)
     os.environ.setdefault("AUGX_EXACT_MULTICLASS", "1")
     if what == "sampled":
         sampled(k, nw)
+    elif what == "segments":
+        segments(k, nw)
     elif what == "variants":
         paths_against_harness(k, nw, ("HS04636", "multigc_levels", "softmask_gene"),
                               [("single", {"singlestrand": "true"}, False), ("intronless", {"genemodel": "intronless"}, False),
