@@ -17,9 +17,14 @@
  * oracle/Makefile (oracle/_ref/ref_harness: ln Viterbi score to 1e-9 relative, state path exact, every
  * trellis cell to 1e-9) and against the committed golden vectors under tests/golden/.
  *
- * Known, documented deviations (none observed on any test input):
- *  - multi-GC-class pieces: a short (lessD) intron is scored with the class of its END position; the
- *    reference's SnippetProbs cache mixes classes in call-history order (src/statemodel.cc:312-342).
+ * Multi-GC-class pieces: the reference answers the content of a short (lessD) intron from its SnippetProbs
+ * cache (src/statemodel.cc:312-393), which is not emptied when the class changes, so that near a class
+ * step an interior can be the product of pieces scored under different classes, in call-history order.
+ * The cache is restated here (snipGet below) and is on by default; twin_set_snippet_cache(0) scores every
+ * interior with the class of its END base instead -- what the first pass of the device computes, kept so
+ * that this pass can be checked on its own.
+ *
+ * Known, documented deviation (not observed on any test input):
  *  - IntronModel::codon is a shared scratch buffer in the reference; for short introns that begin before
  *    sequence position 2 the spliced-codon stop test reads stale bytes (src/intronmodel.cc:935-958).
  *    Here the test is skipped for those (left-truncated) introns.
@@ -35,6 +40,8 @@
 #include "../include/augx.h"
 
 namespace {
+
+int g_snippetCache = 1; // twin_set_snippet_cache
 
 const double NINF = -std::numeric_limits<double>::infinity();
 inline int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
@@ -242,6 +249,53 @@ struct Twin {
     static inline uint64_t fx(double lnp) { return (uint64_t)(int64_t)llrint(lnp * AUGX_FX_SCALE); }
     inline double seg(const std::vector<uint64_t> &P, int l, int r) const {
         return l > r ? 0.0 : (double)(int64_t)(P[r + 1] - P[l]) * AUGX_FX_INV;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // content of a short intron's interior: reference IntronModel::seqProb -> SnippetProbs::getSeqProb(right, len),
+    // src/intronmodel.cc:1063-1067, src/statemodel.cc:312-393.  One cache per strand, a list per end base, sorted by
+    // length; values here are the fixed-point ln sums (exact, so that a value put together from cached pieces equals the
+    // directly computed one whenever all pieces are of one class).  What is not cached is computed with the tables of
+    // the class current at the time of the request (c) -- IntronModel::updateToLocalGC, src/intronmodel.cc:495-503.
+    // ------------------------------------------------------------------------------------------
+    struct Snip { int len; int64_t fx; };
+    std::vector<std::vector<Snip>> snips[2];
+    bool useSnips = false;
+    int64_t snipElem(int st, int base, int len, int c) { // SnippetProbs::getElemSeqProb :283-310
+        const std::vector<uint64_t> &P = st ? ca[c].inR : ca[c].inF;
+        return (int64_t)(P[base + 1] - P[base - len + 1]);
+    }
+    void snipAdd(int st, int base, int len, int64_t v) { // SnippetProbs::addProb :344-370 (an entry of the same length stays)
+        std::vector<Snip> &L = snips[st][base];
+        size_t pos = 0;
+        while (pos < L.size() && L[pos].len < len) pos++;
+        if (pos < L.size() && L[pos].len == len) return;
+        L.insert(L.begin() + (long)pos, Snip{len, v});
+    }
+    int64_t snipGet(int st, int base, int len, int c) { // SnippetProbs::getSeqProb :312-342
+        if (len == 0) return 0;
+        std::vector<Snip> &L = snips[st][base];
+        if (L.empty()) {
+            const int64_t v = snipElem(st, base, len, c);
+            snipAdd(st, base, len, v);
+            return v;
+        }
+        if (L.back().len < len) { // longer than everything cached: the longest piece + the rest, and the sum is cached
+            const Snip last = L.back();
+            const int64_t v = snipGet(st, base - last.len, len - last.len, c) + last.fx;
+            snipAdd(st, base, len, v);
+            return v;
+        }
+        int best = -1; // SnippetList::getProb :378-393: the longest cached length <= len
+        for (size_t i = 0; i < L.size() && L[i].len <= len; i++) best = (int)i;
+        if (best < 0) {
+            const int64_t v = snipElem(st, base, len, c);
+            snipAdd(st, base, len, v);
+            return v;
+        }
+        const Snip part = L[(size_t)best];
+        if (part.len == len) return part.fx;
+        return snipGet(st, base - part.len, len - part.len, c) + part.fx; // (not cached, as in the reference)
     }
 
     // ------------------------------------------------------------------------------------------
@@ -619,7 +673,8 @@ struct Twin {
                 }
                 int intronLength = eobi - bobi + 1;
                 if (intronLength > t.d) continue; // cannot happen without hints (j - eop <= dStateLen)
-                double restSeq = fwd ? seg(A.inF, begin, j) : seg(A.inR, begin, j);
+                double restSeq = useSnips ? (double)snipGet(fwd ? 0 : 1, j, j - begin + 1, c) * AUGX_FX_INV
+                                          : (fwd ? seg(A.inF, begin, j) : seg(A.inR, begin, j));
                 double emi = t.len_intron[intronLength] + restSeq;
                 if (emi == NINF) continue;
                 for (int ai = 0; ai < t.n_anc[s]; ai++) {
@@ -707,6 +762,10 @@ struct Twin {
             }
         } else {
             for (int j = 0; j < n; j++) buildClass(cls[j]);
+            // (with one class in the piece the cache cannot change a value: left out for speed)
+            useSnips = false;
+            for (int j = 1; j < n && g_snippetCache; j++) useSnips = useSnips || cls[j] != cls[0];
+            if (useSnips) { snips[0].assign((size_t)n, {}); snips[1].assign((size_t)n, {}); }
             for (int j = 1; j < n; j++)
                 for (int s = 0; s < S; s++) {
                     if (!t.reachable[s]) continue;
@@ -756,6 +815,8 @@ struct Twin {
 } // namespace
 
 extern "C" {
+/* 1 (default): short-intron interiors through the restated SnippetProbs cache, as the reference; 0: class of the end base */
+void twin_set_snippet_cache(int on) { g_snippetCache = on; }
 /* decode one piece on the CPU.  V_out (len*S doubles) and gc_out (len int32) may be NULL.
  * states_out receives at most cap records; *n_states is the number available. */
 int twin_decode(const augx_tables *t, const char *seq, int64_t len, int init_kind, int term_kind, double *V_out,

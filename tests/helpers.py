@@ -91,9 +91,14 @@ def twin():
     return _twin
 
 
-def twin_decode(tables_ptr, seq, S, cells=False, init_kind=0, term_kind=0):
-    """CPU oracle (oracle/ghmm_twin.cc).  Returns (status, lnv, [(begin,end,state,type)], V or None, gc)."""
+def twin_decode(tables_ptr, seq, S, cells=False, init_kind=0, term_kind=0, cache=None):
+    """CPU oracle (oracle/ghmm_twin.cc).  Returns (status, lnv, [(begin,end,state,type)], V or None, gc).
+    cache: the restated SnippetProbs cache of the reference (multi-class pieces) on or off; by default it follows
+    AUGX_EXACT_MULTICLASS like the emulator, so that a test that switches the device's exact mode off compares like with like."""
     n = len(seq)
+    if cache is None:
+        cache = os.environ.get("AUGX_EXACT_MULTICLASS", "1") != "0"
+    twin().twin_set_snippet_cache(1 if cache else 0)
     V = np.empty((n, S)) if cells else None
     gc = np.empty(n, dtype=np.int32)
     cap = max(1024, n // 4 + 16)

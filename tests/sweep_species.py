@@ -105,7 +105,8 @@ def segments(k, nw):
         t.extractall(d)
     g = read_fasta(os.path.join(d, "genome.fa"))[0][1]
     seqs = [g[200000:290000], g[500000:560000][::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))]
-    os.environ["AUGX_EXACT_MULTICLASS"] = "0" # (the twin scores with one class per end base)
+    # (the decoder's default: the snippet cache replayed on pieces with several classes -- the twin restates it; run with
+    #  AUGX_EXACT_MULTICLASS=0 in the environment to compare the first pass on its own)
     os.environ["AUGX_SEG_LEN"] = "20000"
     for sp in species_list(k, nw):
         try:

@@ -294,6 +294,56 @@ def test_emulated_exact_mode_randomised(tmp_path, monkeypatch, seed):
             assert [(b, e2, emu_state_type(m.tables_ptr, st)) for b, e2, st in e[2]] == r["path"], name
 
 
+def _multiclass_records(seed, n=5):
+    """GC-shifted stretches, a gene, N runs: two to five GC classes per record"""
+    import random
+    rng = random.Random(seed)
+    gene = dict(golden_inputs())["HS04636"].upper()
+
+    def gc_dna(L, gc):
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(L))
+    recs = []
+    for k in range(n):
+        parts = []
+        for _ in range(rng.randint(3, 6)):
+            r = rng.random()
+            L = rng.choice([1500, 2500, 4000, 6000])
+            if r < 0.65:
+                parts.append(gc_dna(L, rng.choice([0.25, 0.33, 0.38, 0.42, 0.47, 0.52, 0.58, 0.65, 0.72])))
+            elif r < 0.85:
+                st = rng.randrange(0, len(gene) - L)
+                parts.append(gene[st:st + L])
+            else:
+                parts.append(gc_dna(L // 2, 0.4) + "N" * rng.choice([1, 30, 400]) + gc_dna(L // 2, 0.6))
+        recs.append(("mc%d_%d" % (seed, k), "".join(parts)))
+    return recs
+
+
+@pytest.mark.parametrize("species", ["human", "nasonia", "rice"])
+def test_emulated_exact_mode_is_the_oracle_bit_for_bit(monkeypatch, species):
+    """The oracle restates the reference's SnippetProbs cache (oracle/ghmm_twin.cc: snipGet; pinned against every cell of the real
+    reference in test_oracle.py); the device replays it from what the first trellis run left (device/snipmemo.h).  Two independent
+    routes to the same numbers: every cell, score and path bit-identical, on records with two to five GC classes."""
+    m = ax.Model(config_path(), species, softmasking="0", UTR="off")
+    recs = _multiclass_records({"human": 11, "nasonia": 12, "rice": 13}[species])
+    if species == "human":
+        byname = dict(golden_inputs())
+        recs += [(k, byname[k].upper()) for k in ("multigc_gene", "multigc_two", "multigc_rand", "multigc_levels")]
+        recs.append(("path_case", multiclass_path_case()[0].upper()))
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "1")
+    em = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, cells=True)
+    differs = multi = 0
+    for (name, seq), e in zip(recs, em):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+        assert rc == 0 and e[0] == 0, name
+        multi += int(len(set(gc.tolist())) > 1)
+        assert np.array_equal(e[3], V), name
+        assert e[1] == lnv and [tuple(x) for x in e[2]] == [(b, en, st) for b, en, st, t in path], name
+        rc, lnv0, path0, V0, _ = twin_decode(m.tables_ptr, seq, m.n_states, cells=True, cache=False)
+        differs += int(not np.array_equal(V0, V))
+    assert multi >= 2 and differs > 0, (multi, differs) # (and the cache is what the comparison is about: without it the cells of some record are different)
+
+
 def test_emulated_exact_mode_decides_a_path(monkeypatch):
     """the record a randomised end-to-end soak found: with one class per end base the optimal path takes another acceptor site
     (ln V off by 0.03) than the reference; with the reference's snippet cache replayed (exact mode, the product's default) path and

@@ -72,11 +72,11 @@ def test_full_size_piece_cells_and_reference_score(monkeypatch, big_inputs, cfg)
     assert r.status == 0 and gold["n"] == len(seq)
     assert [(bb, e, t) for bb, e, s, t in r.states] == [tuple(p) for p in gold["path"]]
     assert abs(r.ln_viterbi - float(gold["lnv"])) <= 1e-9 * abs(float(gold["lnv"]))
-    # (the twin scores with one class per end base: the decoder's replay of the reference's snippet cache off)
+    # (the first pass on its own: the decoder's replay of the reference's snippet cache off, and the twin's restatement of it)
     d.set_exact(False)
     b.decode()
     r, = b.paths()
-    rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+    rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True, cache=False)
     assert rc == 0 and r.ln_viterbi == lnv and r.states == path
     if cfg == "human":
         assert len(set(gc.tolist())) > 1  # (more than one GC class inside the piece)
@@ -279,10 +279,10 @@ def test_more_species_match_reference(monkeypatch, cfg):
         assert r.status == 0, name
         assert [(bb, e, t) for bb, e, s, t in r.states] == [tuple(p) for p in g["path"]], name
         assert abs(r.ln_viterbi - float(g["lnv"])) <= 1e-9 * abs(float(g["lnv"])), name
-    d.set_exact(False) # (and without it: the kernels against the twin, which scores with one class per end base)
+    d.set_exact(False) # (and without it: the kernels against the twin with its restatement of the cache off -- one class per end base)
     b.decode()
     for i, ((name, seq), r, g) in enumerate(zip(recs, b.paths(), gold)):
-        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True)
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True, cache=False)
         assert r.status == 0 and r.ln_viterbi == lnv and r.states == path, name
         assert np.array_equal(b.cells(i), V), name
     env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
