@@ -261,24 +261,25 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
                                                          : "device decode failed (HIP error or kernel abort; not a property of the input)";
                 continue;
             }
-            std::vector<Transcript> txs;
+            std::vector<GeneOut> genes;
             const long plen = pr.end - pr.begin + 1;
             auto run = [&](const std::vector<PathState> &path, const std::vector<std::vector<PathState>> *smp, bool anyStrand) {
-                return sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand)
-                                                    : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand);
+                return groupToGenes(M, sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand)
+                                                                   : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand));
             };
             try {
-                if (!pr.single) txs = run(*pr.path, pr.samples, false);
+                if (!pr.single) genes = run(*pr.path, pr.samples, false);
                 else { // reference NAMGene::doViterbiPiecewise, src/namgene.cc:611-626: the genes of the forward run, then those of the
-                       // run on the reverse complement mapped back (reverseGeneList: in reversed order); sorted by start below
-                    if (pr.path) txs = run(*pr.path, pr.samples, true);
+                       // run on the reverse complement mapped back (reverseGeneList); sorted by coding start
+                    if (pr.path) genes = run(*pr.path, pr.samples, true);
                     if (pr.pathR) {
-                        std::vector<Transcript> rv = run(*pr.pathR, pr.samplesR, true);
-                        for (size_t k = rv.size(); k-- > 0;) { reverseTranscript(rv[k], plen - 1); txs.push_back(rv[k]); }
+                        std::vector<GeneOut> rv = run(*pr.pathR, pr.samplesR, true);
+                        reverseGenes(rv, plen - 1);
+                        for (GeneOut &g : rv) genes.push_back(std::move(g));
                     }
+                    std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
                 }
             } catch (std::exception &e) { errmsg = e.what(); continue; }
-            std::vector<GeneOut> genes = groupToGenes(txs);
             for (GeneOut &g : genes) {
                 g.seqname = rec.name;
                 if (oo.uniqueGeneId) { snprintf(buf, sizeof buf, "%.30s.g%d", rec.name, geneid); g.id = buf; }
@@ -728,7 +729,7 @@ extern "C" int augx_format_gff(const augx_model *m, const char *name, const char
         oo.fromModel(m->m);
         std::vector<PathState> path;
         for (int i = 0; i < n_states; i++) path.push_back({states[i].begin, states[i].end, states[i].type});
-        std::vector<GeneOut> genes = groupToGenes(filterTranscripts(m->m, projectOntoGeneSequence(m->m, path, (long)len)));
+        std::vector<GeneOut> genes = groupToGenes(m->m, filterTranscripts(m->m, projectOntoGeneSequence(m->m, path, (long)len)));
         int gid = first_gene_id;
         for (GeneOut &g : genes) {
             g.seqname = name;
@@ -762,7 +763,7 @@ extern "C" int augx_format_gff_sampled(const augx_model *m, const char *name, co
         std::vector<std::vector<PathState>> smp((size_t)n_samples);
         for (int q = 0; q < n_samples; q++)
             for (int i = 0; i < sample_n[q]; i++) smp[q].push_back({sample_states[q][i].begin, sample_states[q][i].end, sample_states[q][i].type});
-        std::vector<GeneOut> genes = groupToGenes(filterTranscripts(m->m, posteriorTranscripts(m->m, path, smp, (long)len, n_samples + 1)));
+        std::vector<GeneOut> genes = groupToGenes(m->m, filterTranscripts(m->m, posteriorTranscripts(m->m, path, smp, (long)len, n_samples + 1)));
         int gid = first_gene_id;
         for (GeneOut &g : genes) {
             g.seqname = name;

@@ -262,14 +262,17 @@ static void mergeCount(std::vector<BioState> &x, std::vector<BioState> &y) {
 std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<PathState> &viterbi,
                                              const std::vector<std::vector<PathState>> &samples, long dnalen, int sampleiterations) {
     std::vector<Transcript> all;
+    const bool alternatives = m.opt.getBool("alternatives-from-sampling", false);
+    int serial = 0;
     auto add = [&](const std::vector<PathState> &path, bool vit) {
         for (Transcript &g : projectOntoGeneSequence(m, path, dnalen)) {
+            g.serial = serial++;
             g.apostprob = 1.0f;
             for (BioState &e : g.exons) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
             for (BioState &e : g.introns) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
             g.hasProbs = true;
             g.viterbi = vit;
-            g.throwaway = !vit; // (alternatives-from-sampling=false: a sampled transcript only adds to the counts)
+            g.throwaway = !vit && !alternatives; // (alternatives-from-sampling=false: a sampled transcript only adds to the counts)
             all.push_back(std::move(g));
         }
     };
@@ -314,22 +317,140 @@ std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<P
     return all;
 }
 
-std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs) {
+// reference frame_compatible(State*, State*), src/gene.cc:163-166
+static bool frameCompatible(const BioState &a, const BioState &b) {
+    const bool fa = isOnFStrand(a.type), fb = isOnFStrand(b.type);
+    return (fa && fb && mod3((int)(b.end - a.end) - b.frame() + a.frame()) == 0) ||
+           (!fa && !fb && mod3((int)(b.end - a.end) + b.frame() - a.frame()) == 0);
+}
+
+namespace {
+struct AltGeneBuild { // reference AltGene, src/gene.cc:2676-2731
+    std::vector<const Transcript *> tx;
+    bool plus = true;
+    long mincodstart = 0, maxcodend = 0;
+    float apostprob = 0;
+    void add(const Transcript *t) { // AltGene::addGene (identical transcripts were united before)
+        if (tx.empty()) { plus = t->plus; mincodstart = t->codingstart; maxcodend = t->codingend; }
+        else { mincodstart = std::min(mincodstart, t->codingstart); maxcodend = std::max(maxcodend, t->codingend); }
+        tx.push_back(t);
+        apostprob += t->apostprob;
+    }
+    bool overlaps(const Transcript *t) const { // AltGene::overlaps: a coding exon in common, in the same reading frame
+        if (t->exons.empty() || plus != t->plus || t->geneBegin() > maxcodend || t->geneEnd() < mincodstart) return false;
+        for (const Transcript *a : tx)
+            for (const BioState &ae : a->exons)
+                for (const BioState &e : t->exons)
+                    if (!(e.end < ae.begin || e.begin > ae.end) && frameCompatible(e, ae)) return true;
+        return false;
+    }
+};
+} // namespace
+
+// What happens to the transcripts of one run between filterGenePrediction and the printing (reference
+// SequenceFeatureCollection::joinGenesFromPredRuns with its one run of an ab initio prediction, src/extrinsicinfo.cc:1616-1657;
+// NAMGene::doViterbiPiecewise, src/namgene.cc:627-650): --maxtracks, overlapping transcripts of one strand and reading frame
+// become the alternatives of one gene, the genes are sorted by coding start, the transcripts of a gene by their mean state
+// probability.  (AltGene::deleteSuboptimalTranscripts drops nothing here: without hints every "% supported" is 0, and two
+// transcripts with the same CDS and no UTR are the same transcript.)
+// Where the reference's order rests on the addresses of its Transcript objects (list<Transcript*>::sort() without a comparison in
+// groupTranscriptsToGenes, src/gene.cc:3196) the order of creation -- Viterbi path first, then the sampled paths -- is used: it
+// decides between transcripts of one gene with EQUAL mean state probability only.
+std::vector<GeneOut> groupToGenes(const Model &m, const std::vector<Transcript> &txs) {
+    std::vector<const Transcript *> list;
+    for (const Transcript &t : txs) list.push_back(&t);
+    std::stable_sort(list.begin(), list.end(), [](const Transcript *a, const Transcript *b) { return a->geneBegin() < b->geneBegin(); });
+    // Transcript::filterTranscriptsByMaxTracks, src/gene.cc:2533-2634
+    int maxTracks = m.opt.getInt("maxtracks", -1);
+    if (maxTracks >= 0) {
+        const bool keepViterbi = m.opt.getBool("keep_viterbi", false);
+        std::vector<const Transcript *> sorted, rest = list;
+        while (!rest.empty()) { // by mean state probability, the first of equals; a Viterbi transcript first with keep_viterbi (the last)
+            double best = -1.0;
+            size_t at = 0;
+            for (size_t i = 0; i < rest.size(); i++) {
+                const double p = rest[i]->meanStateProb();
+                if (p > best) { best = p; at = i; }
+                if (rest[i]->viterbi && keepViterbi) { at = i; best = 1.0; }
+            }
+            sorted.push_back(rest[at]);
+            rest.erase(rest.begin() + (long)at);
+        }
+        list.clear();
+        for (const Transcript *t : sorted) { // kept while fewer than maxTracks kept ones cover any base of its range
+            std::vector<std::pair<long, int>> ev; // sweep over the kept transcripts that meet the range
+            for (const Transcript *k : list)
+                if (!(k->geneEnd() < t->geneBegin() || k->geneBegin() > t->geneEnd())) {
+                    ev.push_back({std::max(k->geneBegin(), t->geneBegin()), 1});
+                    ev.push_back({std::min(k->geneEnd(), t->geneEnd()) + 1, -1});
+                }
+            std::sort(ev.begin(), ev.end());
+            int cover = 0, most = 0;
+            for (const auto &e : ev) { cover += e.second; most = std::max(most, cover); }
+            if (most < maxTracks) list.push_back(t);
+        }
+    }
+    // groupTranscriptsToGenes, src/gene.cc:3191-3240
+    std::stable_sort(list.begin(), list.end(), [](const Transcript *a, const Transcript *b) { return a->serial < b->serial; });
+    std::vector<AltGeneBuild> agl;
+    for (const Transcript *t : list) {
+        long first = -1;
+        for (size_t i = 0; i < agl.size();) {
+            if (!agl[i].overlaps(t)) { i++; continue; }
+            if (first < 0) { agl[i].add(t); first = (long)i; i++; }
+            else { // the transcript ties another gene to the first one
+                for (const Transcript *o : agl[i].tx) agl[(size_t)first].add(o);
+                agl.erase(agl.begin() + (long)i);
+            }
+        }
+        if (first < 0) { agl.emplace_back(); agl.back().add(t); }
+    }
+    std::stable_sort(agl.begin(), agl.end(), [](const AltGeneBuild &a, const AltGeneBuild &b) { return a.mincodstart < b.mincodstart; });
     std::vector<GeneOut> genes;
-    for (const Transcript &t : txs) {
-        GeneOut ag;
-        ag.transcripts.push_back(t);
-        ag.plus = t.plus;
-        ag.mincodstart = t.codingstart;
-        ag.maxcodend = t.codingend;
+    for (AltGeneBuild &ag : agl) {
+        GeneOut g;
+        g.plus = ag.plus;
+        g.mincodstart = ag.mincodstart;
+        g.maxcodend = ag.maxcodend;
         // AltGene::addGene: the sum of its transcripts' apostprob (src/gene.cc:2706); a Viterbi transcript enters with 1 when
         // nothing was sampled (src/namgene.cc:813-821)
-        ag.apostprob = t.apostprob;
-        ag.hasProbs = !t.revRun;
-        genes.push_back(ag);
+        g.apostprob = ag.apostprob;
+        g.hasProbs = true;
+        // AltGene::sortTranscripts, src/gene.cc:2745-2778: by mean state probability (the running maximum is kept as a float)
+        std::vector<const Transcript *> rest = ag.tx;
+        while (!rest.empty()) {
+            float best = -1.0f;
+            size_t at = 0;
+            if (ag.tx.size() > 1)
+                for (size_t i = 0; i < rest.size(); i++) {
+                    const double p = rest[i]->meanStateProb();
+                    if (p > best) { best = (float)p; at = i; }
+                }
+            g.transcripts.push_back(*rest[at]);
+            rest.erase(rest.begin() + (long)at);
+        }
+        genes.push_back(std::move(g));
     }
-    std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
     return genes;
+}
+
+// the genes of a run on the reverse complement of a piece mapped back (reference reverseGeneList, src/gene.cc:3169-3185: every
+// AltGene is built afresh from its mirrored transcripts -- hasProbs stays false, the gene line's score is '.')
+void reverseGenes(std::vector<GeneOut> &genes, long endpos) {
+    for (GeneOut &g : genes) {
+        float sum = 0;
+        bool first = true;
+        for (Transcript &t : g.transcripts) {
+            reverseTranscript(t, endpos);
+            g.mincodstart = first ? t.codingstart : std::min(g.mincodstart, t.codingstart);
+            g.maxcodend = first ? t.codingend : std::max(g.maxcodend, t.codingend);
+            g.plus = t.plus;
+            sum += t.apostprob;
+            first = false;
+        }
+        g.apostprob = sum;
+        g.hasProbs = false;
+    }
 }
 
 static const char kTransTable1[] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";

@@ -38,6 +38,7 @@ struct Transcript {
     // sampling (reference Transcript::apostprob / hasProbs / viterbi / throwaway, include/gene.hh)
     float apostprob = 1.0f;
     bool hasProbs = false, viterbi = true, throwaway = false;
+    int serial = 0;      // order of creation within a run: the transcripts of the Viterbi path, then those of the sampled paths
     bool revRun = false; // mapped back from the run on the reverse complement (--singlestrand=true)
     double meanStateProb() const;
     long geneBegin() const { return transstart >= 0 ? transstart : codingstart; }
@@ -80,8 +81,11 @@ void reverseTranscript(Transcript &t, long endpos);
 // sampleiterations = the Viterbi path + the sampled ones)
 std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<PathState> &viterbi,
                                              const std::vector<std::vector<PathState>> &samples, long dnalen, int sampleiterations);
-// group into genes (one path => no overlaps => one transcript per gene), sorted by coding start
-std::vector<GeneOut> groupToGenes(const std::vector<Transcript> &txs);
+// the kept transcripts of one run grouped into genes: --maxtracks, overlapping transcripts of one strand and reading frame as the
+// alternatives of one gene (--alternatives-from-sampling=true; one path alone has no overlaps), genes sorted by coding start
+std::vector<GeneOut> groupToGenes(const Model &m, const std::vector<Transcript> &txs);
+// the genes of a run on the reverse complement mapped back onto the piece (endpos = piece length - 1)
+void reverseGenes(std::vector<GeneOut> &genes, long endpos);
 // print the genes of one piece.  seq = the WHOLE input sequence (lower/upper case irrelevant), offset-free coordinates.
 // rmRuns: the soft-masked runs [first, last] that are hint groups of this piece (evidence block); NULL = every lower-case
 // run of seq (a record decoded as one piece)

@@ -326,8 +326,6 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     // options that would change the prediction or the output and are not implemented here: fail loudly instead of
     // silently printing something else than the reference
     if (!opt.getBool("contentmodels", true)) throw UnsupportedError("--contentmodels=false is outside the MI355X hot path");
-    if (opt.getBool("alternatives-from-sampling", false))
-        throw UnsupportedError("--alternatives-from-sampling=true (alternative transcripts from the sample) is not implemented on the MI355X path yet");
     if (opt.getBool("noInFrameStop", false)) throw UnsupportedError("--noInFrameStop=true is not implemented on the MI355X path yet");
     for (const char *o2 : {"emiprobs", "exoncands", "printHints", "printSampled", "printOEs", "printGeneRangesBED", "printGeneRangesGFF",
                            "print_blocks", "printMEA"})

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Golden vectors of posterior sampling (--sample=100) from the REAL reference (oracle/_ref).  Run in the build container:
-    python tests/golden/make_golden_sampled.py [big]
+    python tests/golden/make_golden_sampled.py [big | cfg ...]      (no argument: every configuration)
 
   golden_sampled_<cfg>.gff          the reference binary's GFF (prediction part) with posterior probabilities in the score
                                     columns, for helpers.SAMPLED_CFGS (inputs.fa, or its single-GC-class records for human)
@@ -30,6 +30,8 @@ def main():
     import tempfile
     d = tempfile.mkdtemp()
     for cfg, (species, opts, names) in SAMPLED_CFGS.items():
+        if len(sys.argv) > 1 and cfg not in sys.argv[1:]:
+            continue
         recs = sampled_records(cfg)
         fa = os.path.join(d, cfg + ".fa")
         write_fasta(fa, recs)

@@ -226,6 +226,10 @@ SAMPLED_CFGS = {
     # all records incl. the ones with several GC classes in a piece (the reference's snippet cache around the class steps is replayed)
     "human_all": ("human", {"sample": "100", "softmasking": "0"}, None),
     "fly_filter": ("fly", {"UTR": "off", "softmasking": "0", "keep_viterbi": "false", "minexonintronprob": "0.3", "minmeanexonintronprob": "0.6"}, None),
+    # --alternatives-from-sampling=true: the sampled transcripts that pass the filter stay, overlapping ones of one strand and reading
+    # frame become the alternatives t1, t2, ... of a gene (sorted by mean state probability); --maxtracks bounds how many may overlap
+    "fly_alt": ("fly", {"UTR": "off", "softmasking": "0", "alternatives-from-sampling": "true"}, None),
+    "human_alt": ("human", {"sample": "100", "alternatives-from-sampling": "true", "maxtracks": "2"}, None),
 }
 
 
@@ -237,6 +241,8 @@ SINGLE_CFGS = {
     "fly_sampled": ("fly", {"singlestrand": "true", "UTR": "off", "softmasking": "0"}),       # sample = 100: draws run forward, then reverse
     "fly_backward": ("fly", {"singlestrand": "true", "UTR": "off", "sample": "0", "strand": "backward"}),
     "fly_pieces": ("fly", {"singlestrand": "true", "UTR": "off", "sample": "0", "maxDNAPieceSize": "20000"}),  # cut finder + both runs per piece
+    # alternatives from the sample in both runs: the genes of the reverse run are mirrored transcript by transcript
+    "fly_alt": ("fly", {"singlestrand": "true", "UTR": "off", "softmasking": "0", "alternatives-from-sampling": "true", "maxtracks": "3"}),
 }
 
 
