@@ -237,6 +237,7 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
     std::stable_sort(pieces.begin(), pieces.end(), [](const PieceOut &a, const PieceOut &b) { return a.rec != b.rec ? a.rec < b.rec : a.begin < b.begin; });
     size_t pi = 0;
     int successful = 0;
+    const bool noInFrameStop = M.opt.getBool("noInFrameStop", false);
     char buf[256];
     for (size_t r = 0; r < recs.size(); r++) {
         const RecordView &rec = recs[r];
@@ -263,17 +264,26 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
             }
             std::vector<GeneOut> genes;
             const long plen = pr.end - pr.begin + 1;
-            auto run = [&](const std::vector<PathState> &path, const std::vector<std::vector<PathState>> *smp, bool anyStrand) {
-                return groupToGenes(M, sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand)
-                                                                   : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand));
+            auto run = [&](const std::vector<PathState> &path, const std::vector<std::vector<PathState>> *smp, bool anyStrand, const char *runSeq) {
+                return groupToGenes(M, sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand, runSeq)
+                                                                   : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand, runSeq));
             };
             try {
-                if (!pr.single) genes = run(*pr.path, pr.samples, false);
+                if (!pr.single) genes = run(*pr.path, pr.samples, false, rec.seq + pr.begin);
                 else { // reference NAMGene::doViterbiPiecewise, src/namgene.cc:611-626: the genes of the forward run, then those of the
                        // run on the reverse complement mapped back (reverseGeneList); sorted by coding start
-                    if (pr.path) genes = run(*pr.path, pr.samples, true);
+                    if (pr.path) genes = run(*pr.path, pr.samples, true, rec.seq + pr.begin);
                     if (pr.pathR) {
-                        std::vector<GeneOut> rv = run(*pr.pathR, pr.samplesR, true);
+                        std::string rc; // (the sequence of the second run is read by --noInFrameStop=true only)
+                        if (noInFrameStop) {
+                            rc.assign(rec.seq + pr.begin, (size_t)plen);
+                            std::reverse(rc.begin(), rc.end());
+                            for (char &c : rc) {
+                                const char l = (char)tolower((unsigned char)c);
+                                c = l == 'a' ? 't' : l == 'c' ? 'g' : l == 'g' ? 'c' : l == 't' ? 'a' : 'n';
+                            }
+                        }
+                        std::vector<GeneOut> rv = run(*pr.pathR, pr.samplesR, true, noInFrameStop ? rc.c_str() : nullptr);
                         reverseGenes(rv, plen - 1);
                         for (GeneOut &g : rv) genes.push_back(std::move(g));
                     }
@@ -729,7 +739,7 @@ extern "C" int augx_format_gff(const augx_model *m, const char *name, const char
         oo.fromModel(m->m);
         std::vector<PathState> path;
         for (int i = 0; i < n_states; i++) path.push_back({states[i].begin, states[i].end, states[i].type});
-        std::vector<GeneOut> genes = groupToGenes(m->m, filterTranscripts(m->m, projectOntoGeneSequence(m->m, path, (long)len)));
+        std::vector<GeneOut> genes = groupToGenes(m->m, filterTranscripts(m->m, projectOntoGeneSequence(m->m, path, (long)len), false, seq));
         int gid = first_gene_id;
         for (GeneOut &g : genes) {
             g.seqname = name;
@@ -763,7 +773,7 @@ extern "C" int augx_format_gff_sampled(const augx_model *m, const char *name, co
         std::vector<std::vector<PathState>> smp((size_t)n_samples);
         for (int q = 0; q < n_samples; q++)
             for (int i = 0; i < sample_n[q]; i++) smp[q].push_back({sample_states[q][i].begin, sample_states[q][i].end, sample_states[q][i].type});
-        std::vector<GeneOut> genes = groupToGenes(m->m, filterTranscripts(m->m, posteriorTranscripts(m->m, path, smp, (long)len, n_samples + 1)));
+        std::vector<GeneOut> genes = groupToGenes(m->m, filterTranscripts(m->m, posteriorTranscripts(m->m, path, smp, (long)len, n_samples + 1), false, seq));
         int gid = first_gene_id;
         for (GeneOut &g : genes) {
             g.seqname = name;

@@ -180,8 +180,30 @@ double Transcript::meanStateProb() const {
     return pow(p, 1.0 / k);
 }
 
-std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs, bool anyStrand) {
+// reference Gene::hasInFrameStop, src/gene.cc:1422-1438: a stop codon in the reading frame of the CDS before its last codon (the
+// stop codon of a gene can be put together by a long intron; short introns are kept from it in the trellis).  A codon with
+// anything but acgt in it does not count.
+static bool hasInFrameStop(const Transcript &t, const char *seq) {
+    std::string cds;
+    for (const BioState &e : t.exons) cds.append(seq + e.begin, (size_t)e.length());
+    if (!t.plus) {
+        std::string r(cds.rbegin(), cds.rend());
+        for (char &c : r) {
+            const char l = (char)tolower((unsigned char)c);
+            c = l == 'a' ? 't' : l == 'c' ? 'g' : l == 'g' ? 'c' : l == 't' ? 'a' : 'n';
+        }
+        cds.swap(r);
+    }
+    for (size_t i = (size_t)mod3(-t.frame); i + 3 < cds.size(); i += 3) {
+        const char a = (char)tolower((unsigned char)cds[i]), b = (char)tolower((unsigned char)cds[i + 1]), c = (char)tolower((unsigned char)cds[i + 2]);
+        if (a == 't' && ((b == 'a' && (c == 'a' || c == 'g')) || (b == 'g' && c == 'a'))) return true;
+    }
+    return false;
+}
+
+std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs, bool anyStrand, const char *seq) {
     std::vector<Transcript> out;
+    const bool noInFrameStop = seq && m.opt.getBool("noInFrameStop", false);
     // --strand (reference src/augustus.cc:177-191, filterGenePrediction src/gene.cc:2474-2475).  Only the values listed as
     // possible_values in aug_cmdln_parameters.json reach the reference's parser: anything but forward / backward means both
     const std::string st = m.opt.get("strand", "both");
@@ -193,6 +215,7 @@ std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Tran
         if (g.throwaway) keep = false;
         bool cc = g.completeCDS();
         if ((g.clength < m.t.min_coding_len && cc) || (g.clength < 4 && g.clength < m.t.min_coding_len && !cc)) keep = false;
+        if (noInFrameStop && hasInFrameStop(g, seq)) keep = false;
         if (keep && g.hasProbs) { // src/gene.cc:2489-2514
             const bool kv = keepViterbi && g.viterbi;
             if (g.meanStateProb() < minmean && !kv) keep = false;

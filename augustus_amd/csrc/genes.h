@@ -71,7 +71,9 @@ struct PathState { long begin, end; int type; };
 std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vector<PathState> &path, long dnalen);
 // drop transcripts the reference's filterGenePrediction would drop (ab initio: CDS length rules only)
 // (anyStrand: the --strand option is not applied -- runs of the single-strand model, where the caller picks the runs)
-std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs, bool anyStrand = false);
+// seq: the sequence the run was made on (piece coordinates; the reverse complement of the piece for the second run of the
+// single-strand model) -- read with --noInFrameStop=true only, which drops transcripts with a stop codon inside their CDS
+std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Transcript> &txs, bool anyStrand = false, const char *seq = nullptr);
 // a transcript predicted on the reverse complement of a piece (--singlestrand=true) mapped back onto the piece: coordinates
 // mirrored at endpos = piece length - 1, exon types turned into those of the other strand (reference reverseGeneSequence,
 // src/gene.cc:3246-3365)

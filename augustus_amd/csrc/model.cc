@@ -326,7 +326,6 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     // options that would change the prediction or the output and are not implemented here: fail loudly instead of
     // silently printing something else than the reference
     if (!opt.getBool("contentmodels", true)) throw UnsupportedError("--contentmodels=false is outside the MI355X hot path");
-    if (opt.getBool("noInFrameStop", false)) throw UnsupportedError("--noInFrameStop=true is not implemented on the MI355X path yet");
     for (const char *o2 : {"emiprobs", "exoncands", "printHints", "printSampled", "printOEs", "printGeneRangesBED", "printGeneRangesGFF",
                            "print_blocks", "printMEA"})
         if (opt.getBool(o2, false)) throw UnsupportedError(std::string("--") + o2 + " (extra output) is not implemented on the MI355X path");

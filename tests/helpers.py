@@ -246,6 +246,21 @@ SINGLE_CFGS = {
 }
 
 
+# --noInFrameStop (tests/golden/make_golden_noinframestop.py): a gene whose CDS holds a stop codon put together by a long intron
+NOINFRAMESTOP_CFGS = {
+    "off": {"UTR": "off", "sample": "0", "softmasking": "0", "noInFrameStop": "false"},
+    "on": {"UTR": "off", "sample": "0", "softmasking": "0", "noInFrameStop": "true"},
+    "on_single": {"UTR": "off", "sample": "0", "softmasking": "0", "noInFrameStop": "true", "singlestrand": "true"},
+    "on_sampled": {"UTR": "off", "softmasking": "0", "noInFrameStop": "true", "sample": "30"},
+}
+
+
+def inframe_stop_records():
+    import gzip
+    txt = gzip.open(os.path.join(GOLDEN, "inframe_stop.fa.gz"), "rt").read().split("\n")
+    return [(txt[0][1:], txt[1]), (txt[2][1:], txt[3])]
+
+
 def multiclass_path_case():
     """a 25 kb record (found by tests/soak_cli.py, seed 4025) whose OPTIMAL PATH under the human single-strand model depends on the
     reference's snippet cache across a GC-class step: (sequence, options, reference ln Viterbi, reference path)"""

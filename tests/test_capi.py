@@ -28,7 +28,7 @@ def test_model_tables_human():
 
 def test_unsupported_features_fail_loudly():
     for opts in ({"UTR": "on"}, {"singlestrand": "true", "genemodel": "atleastone"}, {"hintsfile": "x.gff"}, {"genemodel": "bacterium"},
-                 {"genemodel": "exactlyone"}, {"noInFrameStop": "true"}):
+                 {"genemodel": "exactlyone"}, {"mea": "1"}, {"contentmodels": "false"}):
         with pytest.raises(ax.AugxError) as e:
             ax.Model(config_path(), "human", **opts)
         assert e.value.code == ax.AUGX_E_UNSUPPORTED

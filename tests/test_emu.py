@@ -389,6 +389,18 @@ def test_emulated_sampling_gff_is_the_reference_binarys(cfg):
     assert format_gff_sampled(m, recs, paths, [r[7] for r in res]) == golden_sampled_gff(cfg)
 
 
+def test_emulated_sampling_with_noinframestop_is_the_reference_binarys():
+    """--noInFrameStop=true with sampling on (--sample=30): the transcripts with a stop codon inside their CDS are dropped after the
+    posterior probabilities were estimated -- the reference binary's GFF"""
+    opts = NOINFRAMESTOP_CFGS["on_sampled"]
+    recs = inframe_stop_records()
+    m = ax.Model(config_path(), "fly", **opts)
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], m.n_states, samples=29)
+    paths = [[(b, e, st, emu_state_type(m.tables_ptr, st)) for b, e, st in r[2]] for r in res]
+    gold = open(os.path.join(GOLDEN, "golden_noinframestop_on_sampled.gff")).read().splitlines()
+    assert format_gff_sampled(m, recs, paths, [r[7] for r in res]) == gold
+
+
 @pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
 def test_emulated_forward_with_several_gc_classes_matches_reference(tmp_path, monkeypatch):
     """pieces with several GC classes: near a class step the reference's short-intron interiors are products of cached chunks scored

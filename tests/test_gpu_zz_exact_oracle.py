@@ -57,3 +57,17 @@ def test_gpu_default_mode_full_size_multiclass_piece_is_the_oracle(monkeypatch, 
     assert rc == 0 and r.status == 0 and len(set(gc.tolist())) > 1
     assert r.ln_viterbi == lnv and r.states == path
     assert np.array_equal(b.cells(0), V)
+
+
+@pytest.mark.parametrize("cfg", list(NOINFRAMESTOP_CFGS))
+def test_cli_noinframestop_matches_reference(tmp_path, cfg):
+    """--noInFrameStop through the executable: off, on, on with the single-strand model (the second run is filtered on the reverse
+    complement it was made on) and on with sampling -- the reference binary's GFF"""
+    import subprocess
+    exe = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, inframe_stop_records())
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([exe, "--species=fly"] + ["--%s=%s" % kv for kv in NOINFRAMESTOP_CFGS[cfg].items()] + [fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    assert gff_body(r.stdout) == open(os.path.join(GOLDEN, "golden_noinframestop_%s.gff" % cfg)).read().splitlines()
