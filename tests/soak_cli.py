@@ -61,6 +61,12 @@ def main():
             opts["gff3"] = "on"
         if rng.random() < 0.2:
             opts["introns"] = "on"
+        if rng.random() < 0.15:
+            opts["noInFrameStop"] = "true"
+        if opts["sample"] != "0" and rng.random() < 0.2: # (the order of alternatives with EQUAL mean state probability follows heap
+            opts["alternatives-from-sampling"] = "true"  #  addresses in the reference, DESIGN.md section 6: a FAIL that only swaps
+            if rng.random() < 0.5:                       #  two t-numbers of a gene is that)
+                opts["maxtracks"] = rng.choice(["1", "2", "3"])
         fa = os.path.join(d, "c%d.fa" % seed)
         write_fasta(fa, recs)
         args = ["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa]
