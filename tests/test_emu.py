@@ -10,9 +10,10 @@ from helpers import *
 
 @pytest.fixture(autouse=True)
 def _one_class_per_end_base(monkeypatch):
-    """The CPU twin scores a short-intron interior with the class of its end base, as the kernels do; the replay of the reference's
-    snippet cache on pieces with several GC classes (exact mode, the product's default) sits on top of that and is tested against the
-    real reference by the tests that switch it on.  Everything else here compares kernels and twin: exact mode off."""
+    """The kernels score a short-intron interior with the class of its end base; the replay of the reference's snippet cache on
+    pieces with several GC classes (exact mode, the product's default) sits on top of that.  The tests here check the first pass
+    on its own: exact mode off, and with it the twin's restatement of the cache (helpers.twin_decode follows the same switch).
+    The tests that switch it on compare the whole with the real reference and with the twin's cache."""
     monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
 
 

@@ -14,9 +14,10 @@ from helpers import *
 
 @pytest.fixture(autouse=True)
 def _one_class_per_end_base(monkeypatch):
-    """the CPU twin scores a short-intron interior with the class of its end base, as the kernels do; the replay of the reference's
-    snippet cache on pieces with several GC classes (exact mode, the decoder's default) sits on top of that and is checked against the
-    real reference by the tests that switch it on.  The tests here compare device and twin: decoders are created with exact mode off."""
+    """the kernels score a short-intron interior with the class of its end base; the replay of the reference's snippet cache on pieces
+    with several GC classes (exact mode, the decoder's default) sits on top of that.  The tests here check the first pass on its own:
+    decoders are created with exact mode off, and the twin's restatement of the cache is off with it (helpers.twin_decode follows the
+    same switch).  The default mode against the twin's cache: tests/test_gpu_zz_exact_oracle.py."""
     monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
 
 
