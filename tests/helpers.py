@@ -412,7 +412,8 @@ def format_gff_sampled(model, recs, paths, samples):
         assert rc == 0, ax.last_error() if hasattr(ax, "last_error") else rc
         out.append("# ----- prediction on sequence number %d (length = %d, name = %s) -----" % (k + 1, len(seq), name))
         out.append("#")
-        out.append("# Predicted genes for sequence number %d on both strands" % (k + 1))
+        st = model.option("strand")
+        out.append("# Predicted genes for sequence number %d on %s" % (k + 1, "forward strand" if st == "forward" else "reverse strand" if st == "backward" else "both strands"))
         out += buf.value.decode().splitlines()
         if ng.value == 0:
             out.append("# (none)")
@@ -438,7 +439,8 @@ def format_gff(model, recs, paths):
         assert rc == 0, L.augx_last_error()
         out.append("# ----- prediction on sequence number %d (length = %d, name = %s) -----" % (k + 1, len(seq), name))
         out.append("#")
-        out.append("# Predicted genes for sequence number %d on both strands" % (k + 1))
+        st = model.option("strand")
+        out.append("# Predicted genes for sequence number %d on %s" % (k + 1, "forward strand" if st == "forward" else "reverse strand" if st == "backward" else "both strands"))
         out += buf.value.decode().splitlines()
         if ng.value == 0:
             out.append("# (none)")
