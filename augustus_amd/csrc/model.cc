@@ -61,6 +61,8 @@ int kindOfType(int t) {
         static const int m[5] = {AUGX_K_RLESSD, AUGX_K_RLONGDSS, AUGX_K_REQUALD, AUGX_K_RGEOMETRIC, AUGX_K_RLONGASS};
         return m[(t - 44) % 5];
     }
+    if (t >= 24 && t <= 35) return AUGX_K_UTR5SINGLE + (t - 24);   // utr5single .. utr3term
+    if (t >= 59 && t <= 70) return AUGX_K_RUTR5SINGLE + (t - 59);  // rutr5single .. rutr3term
     return -1;
 }
 
@@ -282,6 +284,14 @@ void Model::bindPointers() {
     t.len_initial = len_initial.data();
     t.len_internal = len_internal.data();
     t.len_terminal = len_terminal.data();
+    auto ptr = [](const std::vector<double> &v) { return v.empty() ? nullptr : v.data(); };
+    t.utr5init_emi = ptr(utr5init_emi); t.utr5_emi = ptr(utr5_emi); t.utr3_emi = ptr(utr3_emi); t.tssup_emi = ptr(tssup_emi);
+    t.tss_motif = ptr(tss_motif); t.tsstata_motif = ptr(tsstata_motif); t.tata_motif = ptr(tata_motif); t.tts_motif = ptr(tts_motif);
+    t.aataaa = ptr(aataaa);
+    t.len5_single = ptr(len5_single); t.len5_initial = ptr(len5_initial); t.len5_internal = ptr(len5_internal);
+    t.len5_terminal = ptr(len5_terminal); t.len3_single = ptr(len3_single); t.len3_initial = ptr(len3_initial);
+    t.len3_internal = ptr(len3_internal); t.len3_terminal = ptr(len3_terminal);
+    t.tail5_single = ptr(tail5_single); t.tail3_single = ptr(tail3_single);
 }
 
 void Model::load(const std::string &cfgPathIn, const std::string &sp,
@@ -316,7 +326,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     bool nc = opt.getBool("nc", false);
     if (singleStrand && genemodel != "partial" && genemodel != "complete")
         throw UnsupportedError("--singlestrand=true with --genemodel=" + genemodel + " is outside the MI355X hot path (partial|complete only)");
-    if (utr) throw UnsupportedError("--UTR=on (71-state UTR trellis) is not implemented yet on the MI355X path; run with --UTR=off");
+    if (utr && (singleStrand || !(genemodel == "partial" || genemodel == "complete")))
+        throw ConfigError("UTR only implemented with shadow and partial or complete."); // (reference src/properties.cc:363-365)
     if (nc) throw UnsupportedError("--nc=on is outside the MI355X hot path");
     if (genemodel != "partial" && genemodel != "complete" && genemodel != "intronless")
         throw UnsupportedError("--genemodel=" + genemodel + " is outside the MI355X hot path (partial|complete|intronless only)");
@@ -333,9 +344,10 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
                            "codonAlignmentFile", "trainFeatureFile"})
         if (opt.has(o2)) throw UnsupportedError(std::string("--") + o2 + " (comparative / training mode) is outside the MI355X ab-initio hot path");
     std::string strandName = singleStrand ? "singlestrand" : "shadow";
-    std::string transFile = "trans_" + strandName + "_" + genemodel + ".pbl";
+    std::string transFile = "trans_" + strandName + "_" + genemodel + (utr ? "_utr" : "") + ".pbl";
     opt.set("/NAMGene/TransFile", transFile);
-    opt.readFile(configPath + "model/states_" + strandName + (genemodel == "intronless" ? "_intronless" : "") + ".cfg", configPath);
+    opt.readFile(configPath + "model/states_" + strandName + (genemodel == "intronless" ? "_intronless" : utr ? "_utr" : "") + ".cfg", configPath);
+    t.utr = utr ? 1 : 0;
 
     // ---- constants (reference Constant::init, src/types.cc:208-450; defaults src/types.cc:20-116)
     t.W = opt.getInt("/Constant/trans_init_window", 12);
@@ -416,7 +428,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     if (t.S > AUGX_MAX_STATES) throw ConfigError("too many states");
     t.synch_state = opt.getInt("/NAMGene/SynchState", 0);
     {
-        int ne = 0, ni = 0, ng = 0;
+        int ne = 0, ni = 0, ng = 0, nu = 0;
         char key[64];
         for (int i = 0; i < t.S; i++) {
             snprintf(key, sizeof key, "/NAMGene/state%02d", i);
@@ -425,6 +437,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
             if (mdl == "exonmodel") { snprintf(key, sizeof key, "/ExonModel/type%02d", ne++); typeName = opt.get(key); }
             else if (mdl == "intronmodel") { snprintf(key, sizeof key, "/IntronModel/type%02d", ni++); typeName = opt.get(key); }
             else if (mdl == "igenicmodel") { snprintf(key, sizeof key, "/IGenicModel/type%02d", ng++); typeName = opt.get(key, "igenic"); }
+            else if (mdl == "utrmodel" && utr) { snprintf(key, sizeof key, "/UtrModel/type%02d", nu++); typeName = opt.get(key); }
             else throw UnsupportedError("state model \"" + mdl + "\" is outside the MI355X hot path");
             int ty = stateTypeFromName(typeName);
             int kind = kindOfType(ty);
@@ -645,7 +658,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     }
 
     // ---- intron parameters (reference IntronModel::readAllParameters, src/intronmodel.cc:295-415)
-    std::vector<double> probShort(C), mal(C);
+    std::vector<double> probShort(C), mal(C), inEmiLinear;
     {
         PblReader r(full + opt.get("/IntronModel/infile"));
         const int assSize = ipow4(t.As + t.Ae), dssSize = ipow4(t.Ds + t.De);
@@ -695,6 +708,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
         len_intron.resize(dd + 1);
         for (int i = 0; i <= dd; i++) { r.comment(); len_intron[i] = lnp(r.readDouble() / 1000); }
         in_emi.assign((size_t)C * NP, NEG_INF);
+        inEmiLinear.assign((size_t)C * NP, 0.0);
         for (int c = 0; c < C; c++) {
             char tag[16];
             snprintf(tag, sizeof tag, "[%d]", c + 1);
@@ -711,7 +725,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
             for (int i = 0; i < sz; i++) {
                 r.comment();
                 int pn = r.readPattern(k + 1);
-                in_emi[(size_t)c * NP + pn] = lnp(r.readDouble());
+                inEmiLinear[(size_t)c * NP + pn] = r.readDouble();
+                in_emi[(size_t)c * NP + pn] = lnp(inEmiLinear[(size_t)c * NP + pn]);
             }
             r.need("[ASSMOTIF]");
             Motif m = readMotif(r);
@@ -782,6 +797,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
         }
     }
 
+    if (utr) loadUtr(full, inEmiLinear);
+
     // ---- per-class transition matrices (reference IntronModel::updateToLocalGCEach, src/intronmodel.cc:439-488)
     ln_trans.assign((size_t)C * t.S * t.S, NEG_INF);
     for (int c = 0; c < C; c++) {
@@ -841,6 +858,146 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     bindPointers();
 }
 
+// ---- UTR parameters (reference UtrModel::init src/utrmodel.cc:149-264, readAllParameters :540-696,
+//      fillTailsOfLengthDistributions :293-361).  inEmi: the intron emission probabilities (linear), [C][NP]
+void Model::loadUtr(const std::string &full, const std::vector<double> &inEmi) {
+    const int k = t.k, NP = ipow4(k + 1), C = t.n_classes;
+    if (opt.getInt("/UtrModel/k", 4) != k) throw UnsupportedError("UTR Markov order differs from the exon/intron order; not supported");
+    t.tss_upwin = opt.getInt("/Constant/tss_upwindow_size", 0);
+    t.tss_start = opt.getInt("/UtrModel/tss_start", 4);
+    t.tss_end = opt.getInt("/UtrModel/tss_end", 4);
+    t.tata_start = opt.getInt("/UtrModel/tata_start", 1);
+    t.tata_end = opt.getInt("/UtrModel/tata_end", 10);
+    t.d_tss_tata_min = opt.getInt("/UtrModel/d_tss_tata_min", 17);
+    t.d_tss_tata_max = opt.getInt("/UtrModel/d_tss_tata_max", 40);
+    t.d_polyasig_cleavage = opt.getInt("/UtrModel/d_polyasig_cleavage", 20); // Constant::d_polyasig_cleavage, src/types.cc:40,407
+    t.tts_spacing = 10;                                                        // UtrModel::ttsSpacing, src/utrmodel.cc:122
+    t.utr_max_exon_len = opt.getInt("/UtrModel/maxexonlength");
+    t.utr_max3single = opt.getInt("/UtrModel/max3singlelength");
+    t.utr_max3term = opt.getInt("/UtrModel/max3termlength");
+    const std::string cons = opt.get("/UtrModel/polyasig_consensus", "aataaa");
+    t.aataaa_boxlen = (int)cons.size();
+    const double probPolya = opt.getDouble("/UtrModel/prob_polya", 0.9);
+    const double w5 = opt.getDouble("/UtrModel/utr5patternweight", 0.0), w3 = opt.getDouble("/UtrModel/utr3patternweight", 0.0);
+    if (t.d_tss_tata_max + t.tata_start > t.tss_upwin)
+        throw ConfigError("Inconsistent UTR training parameters. Must have d_tss_tata_max <= tss_upwindow_size - tata_start");
+    if (t.d_tss_tata_min < t.tata_end + t.tss_start)
+        throw ConfigError("Inconsistent UTR training parameters. Must have d_tss_tata_min >= tata_end + tss_start");
+    t.ln2 = std::log(2.0);
+    std::string fname = full + opt.get("/UtrModel/infile");
+    {
+        std::ifstream probe(fname.c_str());
+        if (!probe) throw ConfigError("UtrModel::readProbabilities: Couldn't open file " + fname);
+    }
+    PblReader r(fname);
+    r.need("[UTRLENGTH]");
+    r.comment(); const int D = r.readInt();
+    r.comment(); (void)r.readDouble();
+    r.comment(); (void)r.readInt();
+    double num[8], huge[8];
+    r.comment(); for (int i = 0; i < 8; i++) num[i] = r.readInt();
+    r.comment(); for (int i = 0; i < 8; i++) huge[i] = r.readInt();
+    r.comment();
+    const int ML = t.utr_max_exon_len, M3S = t.utr_max3single, M3T = t.utr_max3term;
+    if (D > ML || D > M3S || D > M3T) throw ConfigError("UtrModel: exonLenD is larger than a max_exon_len.");
+    const int maxLen[8] = {ML, ML, ML, ML, M3S, ML, ML, M3T};
+    std::vector<double> dist[8], lnd[8];
+    for (int i = 0; i < 8; i++) { dist[i].assign(maxLen[i] + 1, 0.0); lnd[i].assign(maxLen[i] + 1, NEG_INF); }
+    for (int i = 0; i <= D; i++) {
+        (void)r.readInt();
+        for (int c = 0; c < 8; c++) dist[c][i] = r.readDouble() / 1000;
+    }
+    for (int c = 0; c < 8; c++) fillTail(dist[c], lnd[c], D, maxLen[c], huge[c], num[c]);
+    // (the tail of the reference's LLDouble product never leaves the double range for shipped parameters; lnd[] continues in
+    //  log space if it did, the tail sums below then treat such entries as 0)
+    std::vector<double> *dst[8] = {&len5_single, &len5_initial, &len5_internal, &len5_terminal, &len3_single, &len3_initial, &len3_internal, &len3_terminal};
+    for (int c = 0; c < 8; c++) {
+        *dst[c] = lnd[c];
+        // the device evaluates every predecessor end of a window; the reference skips ends through its EOPList
+        // (src/statemodel.cc:473-520), which is the same set only if the support of the distribution is an interval
+        int first = -1, last = -1;
+        for (int i = 0; i <= maxLen[c]; i++) if (lnd[c][i] > NEG_INF) { if (first < 0) first = i; last = i; }
+        for (int i = first; first >= 0 && i <= last; i++)
+            if (!(lnd[c][i] > NEG_INF)) throw UnsupportedError("UTR length distribution with a gap in its support (EOPList order dependence); not supported");
+    }
+    auto tails = [&](const std::vector<double> &d, std::vector<double> &out) { // src/utrmodel.cc:341-360
+        const int n = (int)d.size() - 1;
+        double total = 0.0, cum = 0.0;
+        for (int i = 0; i <= n; i++) total += d[i];
+        out.assign(n + 1, NEG_INF);
+        for (int i = n; i >= 0; i--) { cum += d[i]; out[i] = lnp(cum / total); }
+    };
+    tails(dist[0], tail5_single);
+    tails(dist[4], tail3_single);
+    r.need("[AATAAA]");
+    r.comment(); const int asz = r.readInt();
+    if (asz != ipow4(t.aataaa_boxlen)) throw ConfigError("Could not read in polyA signal.\n");
+    aataaa.assign(asz, NEG_INF);
+    for (;;) {
+        r.comment();
+        if (r.peek() < 0 || r.peek() == '[') break;
+        const int pn = r.readPattern(t.aataaa_boxlen);
+        const double p = r.readDouble();
+        aataaa[pn] = lnp(p * probPolya);
+    }
+    t.ln_tts_rand = lnp((1.0 - probPolya) * (1.0 / ipow4(t.aataaa_boxlen)));
+    utr5init_emi.assign((size_t)C * NP, NEG_INF);
+    utr5_emi.assign((size_t)C * NP, NEG_INF);
+    utr3_emi.assign((size_t)C * NP, NEG_INF);
+    for (int c = 0; c < C; c++) {
+        char tag[16];
+        snprintf(tag, sizeof tag, "[%d]", c + 1);
+        r.need(tag);
+        auto readEmi = [&](const char *sec, std::vector<double> &lin) {
+            r.need(sec);
+            r.comment(); const int size = r.readInt();
+            r.comment(); const int kk = r.readInt();
+            r.comment(); (void)r.readDouble();
+            if (kk != k || size != NP) throw ConfigError("UtrModel: emission order mismatch");
+            lin.assign(NP, 0.0);
+            for (int i = 0; i < size; i++) {
+                r.comment();
+                const int pn = r.readPattern(k + 1);
+                lin[pn] = r.readDouble();
+            }
+        };
+        std::vector<double> e5i, e5, e3;
+        readEmi("[EMISSION-5INITIAL]", e5i);
+        readEmi("[EMISSION-5]", e5);
+        readEmi("[EMISSION-3]", e3);
+        r.need("[EMISSION-TSSUPWIN]");
+        r.comment(); const int usz = r.readInt();
+        r.comment(); const int uk = r.readInt();
+        r.comment(); (void)r.readDouble();
+        if (c == 0) { t.tssup_k = uk; tssup_emi.assign((size_t)C * ipow4(uk + 1), NEG_INF); }
+        else if (uk != t.tssup_k) throw ConfigError("UtrModel: tssup_k differs between GC classes");
+        if (usz != ipow4(uk + 1)) throw ConfigError("UtrModel: EMISSION-TSSUPWIN size mismatch");
+        for (int i = 0; i < usz; i++) {
+            r.comment();
+            const int pn = r.readPattern(uk + 1);
+            tssup_emi[(size_t)c * usz + pn] = lnp(r.readDouble());
+        }
+        auto readM = [&](const char *sec, std::vector<double> &out, int32_t &mn, int32_t &mk) {
+            r.need(sec);
+            Motif m = readMotif(r);
+            if (c == 0) { mn = m.n; mk = m.k; out.assign((size_t)C * m.p.size(), NEG_INF); }
+            else if (m.n != mn || m.k != mk) throw ConfigError(std::string("UtrModel: motif shape of ") + sec + " differs between GC classes");
+            for (size_t i = 0; i < m.p.size(); i++) out[(size_t)c * m.p.size() + i] = lnp(m.p[i]);
+        };
+        readM("[TSSMOTIF]", tss_motif, t.tss_n, t.tss_k);
+        readM("[TSSMOTIFTATA]", tsstata_motif, t.tsstata_n, t.tsstata_k);
+        readM("[TATAMOTIF]", tata_motif, t.tata_n, t.tata_k);
+        readM("[TTSMOTIF]", tts_motif, t.tts_n, t.tts_k);
+        // "change the content models so they are much closer to the intronmodel" (src/utrmodel.cc:681-688)
+        for (int i = 0; i < NP; i++) {
+            const double in = inEmi[(size_t)c * NP + i];
+            utr5init_emi[(size_t)c * NP + i] = lnp(e5i[i] * w5 + in * (1.0 - w5));
+            utr5_emi[(size_t)c * NP + i] = lnp(e5[i] * w5 + in * (1.0 - w5));
+            utr3_emi[(size_t)c * NP + i] = lnp(e3[i] * w3 + in * (1.0 - w3));
+        }
+    }
+}
+
 // Exact arithmetic (include/augx.h: AUGX_Q_BITS): every ln term of the model is rounded ONCE, here, to a multiple of
 // 2^-AUGX_Q_BITS.  All quantities of the decode are sums of such terms with magnitude below 2^(52 - AUGX_Q_BITS), so every
 // fp64 addition on the decode path is exact: the result does not depend on the association of the sums, and adding a
@@ -851,12 +1008,15 @@ void Model::quantiseTables() {
     const double sc = std::ldexp(1.0, AUGX_Q_BITS), inv = std::ldexp(1.0, -AUGX_Q_BITS);
     auto q = [&](double &x) { if (std::isfinite(x)) x = std::nearbyint(x * sc) * inv; };
     for (std::vector<double> *v : {&ln_trans, &ig_emi, &ig_short, &in_emi, &ex_emi, &ex_init, &ex_et, &ex_pls, &tis_motif, &ass_motif,
-                                   &tis_bin_ln, &ass_pat, &dss_pat, &len_intron, &len_single, &len_initial, &len_internal, &len_terminal})
+                                   &tis_bin_ln, &ass_pat, &dss_pat, &len_intron, &len_single, &len_initial, &len_internal, &len_terminal,
+                                   &utr5init_emi, &utr5_emi, &utr3_emi, &tssup_emi, &tss_motif, &tsstata_motif, &tata_motif, &tts_motif,
+                                   &aataaa, &len5_single, &len5_initial, &len5_internal, &len5_terminal, &len3_single, &len3_initial,
+                                   &len3_internal, &len3_terminal, &tail5_single, &tail3_single})
         for (double &x : *v) q(x);
     for (int i = 0; i < AUGX_MAX_STATES; i++) { q(t.ln_init[i]); q(t.ln_term[i]); }
     for (int i = 0; i < 64; i++) q(t.ln_startcodon[i]);
     q(t.ln_stop_ochre); q(t.ln_stop_amber); q(t.ln_stop_opal); q(t.ln_quarter); q(t.ln_n_coding); q(t.ln4);
-    q(t.ass_pat_invalid); q(t.ln_soft_bonus);
+    q(t.ass_pat_invalid); q(t.ln_soft_bonus); q(t.ln_tts_rand); q(t.ln2);
 }
 
 } // namespace augx

@@ -44,6 +44,11 @@ struct Model {
     // owning storage behind the pointers of t
     std::vector<double> ln_trans, ig_emi, ig_short, in_emi, ex_emi, ex_init, ex_et, ex_pls, tis_motif, ass_motif,
         tis_bin_bounds, tis_bin_ln, ass_pat, dss_pat, len_intron, len_single, len_initial, len_internal, len_terminal;
+    // --UTR=on (reference UtrModel::readAllParameters, src/utrmodel.cc:540-696)
+    std::vector<double> utr5init_emi, utr5_emi, utr3_emi, tssup_emi, tss_motif, tsstata_motif, tata_motif, tts_motif, aataaa,
+        len5_single, len5_initial, len5_internal, len5_terminal, len3_single, len3_initial, len3_internal, len3_terminal,
+        tail5_single, tail3_single;
+    void loadUtr(const std::string &full, const std::vector<double> &inEmiLinear);
     void load(const std::string &configPath, const std::string &species,
               const std::vector<std::pair<std::string, std::string>> &cmdline);
     void bindPointers();

@@ -49,7 +49,13 @@ enum {
     AUGX_K_SINGLE, AUGX_K_INITIAL, AUGX_K_INTERNAL, AUGX_K_TERMINAL,           /* forward coding exons  */
     AUGX_K_RSINGLE, AUGX_K_RINITIAL, AUGX_K_RINTERNAL, AUGX_K_RTERMINAL,       /* reverse coding exons  */
     AUGX_K_LESSD, AUGX_K_LONGDSS, AUGX_K_EQUALD, AUGX_K_GEOMETRIC, AUGX_K_LONGASS,      /* fwd intron  */
-    AUGX_K_RLESSD, AUGX_K_RLONGDSS, AUGX_K_REQUALD, AUGX_K_RGEOMETRIC, AUGX_K_RLONGASS  /* rev intron  */
+    AUGX_K_RLESSD, AUGX_K_RLONGDSS, AUGX_K_REQUALD, AUGX_K_RGEOMETRIC, AUGX_K_RLONGASS, /* rev intron  */
+    /* untranslated regions (reference UtrModel, src/utrmodel.cc; states_shadow_utr.cfg): kind = AUGX_K_UTR5SINGLE + (type - utr5single)
+       on the forward strand, AUGX_K_RUTR5SINGLE + (type - rutr5single) on the reverse strand */
+    AUGX_K_UTR5SINGLE, AUGX_K_UTR5INIT, AUGX_K_UTR5INTRON, AUGX_K_UTR5INTRONVAR, AUGX_K_UTR5INTERNAL, AUGX_K_UTR5TERM,
+    AUGX_K_UTR3SINGLE, AUGX_K_UTR3INIT, AUGX_K_UTR3INTRON, AUGX_K_UTR3INTRONVAR, AUGX_K_UTR3INTERNAL, AUGX_K_UTR3TERM,
+    AUGX_K_RUTR5SINGLE, AUGX_K_RUTR5INIT, AUGX_K_RUTR5INTRON, AUGX_K_RUTR5INTRONVAR, AUGX_K_RUTR5INTERNAL, AUGX_K_RUTR5TERM,
+    AUGX_K_RUTR3SINGLE, AUGX_K_RUTR3INIT, AUGX_K_RUTR3INTRON, AUGX_K_RUTR3INTRONVAR, AUGX_K_RUTR3INTERNAL, AUGX_K_RUTR3TERM
 };
 
 /*
@@ -117,6 +123,30 @@ typedef struct augx_tables {
        base is a nonexonpart hint of source RM; igenic and intron states get its bonus per covered base */
     int32_t softmasking;            /* 0/1: --softmasking                                                */
     double ln_soft_bonus;           /* ln(bonus), 1.15 in config/extrinsic/extrinsic.cfg                  */
+    /* ---- untranslated regions (--UTR=on; reference UtrModel::readAllParameters, src/utrmodel.cc:540-696, the
+     *      constants of UtrModel::init :149-260 and Constant::init, src/types.cc:303,407).  utr == 0: none of this is set ---- */
+    int32_t utr;                    /* 0/1                                                               */
+    int32_t tss_upwin;              /* /Constant/tss_upwindow_size                                        */
+    int32_t tss_start, tss_end, tata_start, tata_end, d_tss_tata_min, d_tss_tata_max;
+    int32_t d_polyasig_cleavage, aataaa_boxlen, tts_spacing;
+    int32_t utr_max_exon_len, utr_max3single, utr_max3term;   /* maxexonlength, max3singlelength, max3termlength */
+    int32_t tssup_k;                /* order of the TSS-upstream-window chain                             */
+    int32_t tss_n, tss_k, tsstata_n, tsstata_k, tata_n, tata_k, tts_n, tts_k;   /* motif widths / orders   */
+    const double *utr5init_emi;     /* [C][NP]  5' single/initial exon content, mixed with the intron table by
+                                       utr5patternweight (src/utrmodel.cc:681-688)                         */
+    const double *utr5_emi;         /* [C][NP]  5' internal/terminal exon content                         */
+    const double *utr3_emi;         /* [C][NP]  3' exon content                                           */
+    const double *tssup_emi;        /* [C][4^(tssup_k+1)]                                                  */
+    const double *tss_motif, *tsstata_motif, *tata_motif, *tts_motif;   /* [C][n][4^(k+1)]                 */
+    const double *aataaa;           /* [4^boxlen] ln(aataaa_probs * prob_polya), -inf where the file has no entry */
+    double ln_tts_rand;             /* ln((1 - prob_polya) / 4^boxlen), src/utrmodel.cc:1853,1883           */
+    const double *len5_single, *len5_initial, *len5_internal, *len5_terminal;   /* [utr_max_exon_len+1]    */
+    const double *len3_single;      /* [utr_max3single+1] */
+    const double *len3_initial, *len3_internal;                                 /* [utr_max_exon_len+1]    */
+    const double *len3_terminal;    /* [utr_max3term+1]   */
+    const double *tail5_single;     /* [utr_max_exon_len+1] tail probabilities (truncated UTR at the piece start) */
+    const double *tail3_single;     /* [utr_max3single+1]   */
+    double ln2;                     /* ln 2 (negative-length corrections pow(2.0, .), src/utrmodel.cc:1180) */
 } augx_tables;
 
 typedef struct augx_model augx_model;     /* host-side immutable model: tables + option values          */

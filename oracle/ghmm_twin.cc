@@ -744,6 +744,343 @@ struct Twin {
         if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = j - 1; }
     }
 
+
+    // ------------------------------------------------------------------------------------------
+    // UTR states: reference UtrModel::viterbiForwardAndSampling src/utrmodel.cc:796-1064, getEndPositions :1572-1643,
+    // endPartEmiProb :1072-1161, notEndPartEmiProb :1167-1548, tssProb :1761-1833, computeTtsProbs :1840-1912,
+    // SegProbs src/statemodel.cc:398-460.  Ab initio: every bonus / malus is 1 but the soft-masking bonus of the intronic
+    // parts (nonexonpart hints, :1149-1157, :1526-1545).
+    // ------------------------------------------------------------------------------------------
+    // SegProbs: cumulative sums whose term at base i is taken from the class OF THAT BASE (UtrModel::updateToLocalGC refills only
+    // the region of the new class, :766-790); P[i+1] = sum over bases 0..i, base 0 counts ln 1/4 (cumProds[0] = .25)
+    std::vector<uint64_t> u5iF, u5iR, u5F, u5R, u3F, u3R;
+    std::vector<double> ttsPlus, ttsMinus;          // ln ttsProbPlus / ttsProbMinus per aataaa box begin
+    std::vector<double> tssC[2];                    // tssProbsPlus / tssProbsMinus: cached values ...
+    std::vector<uint8_t> tssSet[2];                 // ... and whether there is one
+    int curCls = 0, prevCls = -1;                   // class of the column being filled
+    double utrEmi1(const double *tab, int c, int p, bool fwd) const { // SegProbs::getSeqProb, from == to (:437-449): the CURRENT class
+        if (fwd) {
+            if (p < k) return t.ln_quarter;
+            int pn = pat(p - k, k + 1);
+            return pn >= 0 ? tab[(size_t)c * NP + pn] : t.ln_quarter;
+        }
+        int rn = rcpat(p, k + 1); // (reads up to the terminating NUL: invalid)
+        return rn >= 0 ? tab[(size_t)c * NP + rn] : t.ln_quarter;
+    }
+    void buildUtr() {
+        auto build = [&](std::vector<uint64_t> &P, const double *tab, bool fwd) {
+            P.assign(n + 2, 0);
+            for (int i = 0; i <= n; i++) {
+                double v;
+                if (i == 0 || i >= n) v = t.ln_quarter; // cumProds[0] = .25; base n reads the terminator
+                else if (fwd) { int pn = i >= k ? pat(i - k, k + 1) : -1; v = pn >= 0 ? tab[(size_t)cls[i] * NP + pn] : t.ln_quarter; }
+                else { int rn = i < n - k ? rcpat(i, k + 1) : -1; v = rn >= 0 ? tab[(size_t)cls[i] * NP + rn] : t.ln_quarter; }
+                P[i + 1] = P[i] + fx(v);
+            }
+        };
+        build(u5iF, t.utr5init_emi, true); build(u5iR, t.utr5init_emi, false);
+        build(u5F, t.utr5_emi, true); build(u5R, t.utr5_emi, false);
+        build(u3F, t.utr3_emi, true); build(u3R, t.utr3_emi, false);
+        // computeTtsProbs(from, to) over every class region [from, to]: each box begin 1..n-1 with the class of its own base
+        ttsPlus.assign(n + 1, NINF); ttsMinus.assign(n + 1, NINF);
+        const int bl = t.aataaa_boxlen, dc = t.d_polyasig_cleavage;
+        for (int b0 = 1; b0 < n; b0++) {
+            const int c = cls[b0];
+            const double *M = t.tts_motif + (size_t)c * t.tts_n * (1 << (2 * (t.tts_k + 1)));
+            int ttspos = b0 + bl + dc - 1;
+            if (ttspos < n) {
+                int pn = pat(b0, bl);
+                double prob = pn >= 0 ? t.aataaa[pn] : NINF;
+                if (b0 % t.tts_spacing == 0 && prob == NINF) prob = t.ln_tts_rand;
+                if (prob > NINF) prob = prob + motifF(M, t.tts_n, t.tts_k, b0 + bl);
+                ttsPlus[b0] = prob;
+            }
+            ttspos = b0 - dc;
+            if (ttspos < 0 || b0 + bl - 1 >= n) ttsPlus[b0] = NINF; // (sic: the reference zeroes the PLUS entry here, :1873-1874)
+            else {
+                int rn = rcpat(b0, bl);
+                double prob = rn >= 0 ? t.aataaa[rn] : NINF;
+                if (b0 % t.tts_spacing == 0 && prob == NINF) prob = t.ln_tts_rand;
+                if (prob > NINF) prob = prob + motifRC(M, t.tts_n, t.tts_k, ttspos);
+                ttsMinus[b0] = prob;
+            }
+        }
+        for (int st = 0; st < 2; st++) { tssC[st].assign(n + 1, NINF); tssSet[st].assign(n + 1, 0); }
+    }
+    // UtrModel::updateToLocalGC(from, to): the cached TSS values of [from, to) are forgotten (:779-780)
+    void utrEnterRegion(int from) {
+        int to = from;
+        while (to + 1 < n && cls[to + 1] == cls[from]) to++;
+        for (int i = from; i < to; i++) tssSet[0][i] = tssSet[1][i] = 0;
+    }
+    double tssupSeq(int c, int left, int right, bool rev) const { // UtrModel::tssupSeqProb :1733-1750
+        const int uk = t.tssup_k;
+        const double *E = t.tssup_emi + (size_t)c * (1 << (2 * (uk + 1)));
+        double s = 0;
+        for (int p = right; p >= left; p--) {
+            int pn = -1;
+            if (!rev && p - uk >= 0) pn = pat(p - uk, uk + 1);
+            else if (rev && p >= 0 && p + uk < n) pn = rcpat(p, uk + 1);
+            s += pn >= 0 ? E[pn] : t.ln_quarter;
+        }
+        return s;
+    }
+    double tssProb(int left, bool fwd) { // :1761-1833, with the class current at the time of the first request
+        const int right = left + t.tss_upwin + t.tss_end - 1;
+        if (right >= n) return NINF;
+        if (left % t.tts_spacing != 0) return NINF;
+        const int st = fwd ? 0 : 1;
+        if (tssSet[st][left]) return tssC[st][left];
+        const int c = curCls;
+        const size_t sz0 = (size_t)1 << (2 * (t.tss_k + 1)), sz1 = (size_t)1 << (2 * (t.tsstata_k + 1)), sz2 = (size_t)1 << (2 * (t.tata_k + 1));
+        const double *Mtss = t.tss_motif + (size_t)c * t.tss_n * sz0, *Mtt = t.tsstata_motif + (size_t)c * t.tsstata_n * sz1,
+                     *Mta = t.tata_motif + (size_t)c * t.tata_n * sz2;
+        const int maxpos = t.d_tss_tata_max - t.d_tss_tata_min - 1;
+        double prob;
+        if (fwd) {
+            const int w0 = right - t.tss_end - t.d_tss_tata_max + 1;
+            int rel = -1;
+            for (int pos = 0; pos <= maxpos; pos++)
+                if (b(w0 + pos) == 3 && b(w0 + pos + 1) == 0 && b(w0 + pos + 2) == 3 && b(w0 + pos + 3) == 0 && b(w0 + pos + 5) == 0) { rel = pos; break; }
+            if (rel >= 0) {
+                const int tatapos = w0 + rel;
+                prob = motifF(Mtt, t.tsstata_n, t.tsstata_k, right - t.tss_end - t.tss_start + 1) + motifF(Mta, t.tata_n, t.tata_k, tatapos - t.tata_start) +
+                       (tssupSeq(c, left, tatapos - t.tata_start - 1, false) + tssupSeq(c, tatapos + t.tata_end, right - t.tss_end - t.tss_start, false));
+            } else
+                prob = motifF(Mtss, t.tss_n, t.tss_k, right - t.tss_end - t.tss_start + 1) + tssupSeq(c, left, right - t.tss_end - t.tss_start, false);
+        } else {
+            const int w0 = left + t.tss_end + t.d_tss_tata_max - 1;
+            int rel = 1;
+            for (int pos = 0; pos >= -maxpos; pos--)
+                if (b(w0 + pos) == 0 && b(w0 + pos - 1) == 3 && b(w0 + pos - 2) == 0 && b(w0 + pos - 3) == 3 && b(w0 + pos - 5) == 3) { rel = pos; break; }
+            if (rel <= 0) {
+                const int tatapos = w0 + rel;
+                prob = motifRC(Mtt, t.tsstata_n, t.tsstata_k, left) + motifRC(Mta, t.tata_n, t.tata_k, tatapos - t.tata_end + 1) +
+                       (tssupSeq(c, left + t.tata_end + t.tata_start - 1, tatapos - t.tata_end, true) + tssupSeq(c, tatapos + t.tata_start + 1, right, true));
+            } else
+                prob = motifRC(Mtss, t.tss_n, t.tss_k, left) + tssupSeq(c, left + t.tss_end + t.tss_start, right, true);
+        }
+        tssC[st][left] = prob; tssSet[st][left] = 1;
+        return prob;
+    }
+    // SegProbs::getSeqProb(from, to) :437-460
+    double segU(const std::vector<uint64_t> &P, const double *tab, bool fwd, int from, int to) const {
+        if (from == to) return utrEmi1(tab, curCls, to, fwd);
+        if (from > to) return 0.0;
+        if (to > n) to = n;
+        if (from < 1) return (double)(int64_t)(P[to + 1] - P[0]) * AUGX_FX_INV;
+        return (double)(int64_t)(P[to + 1] - P[from]) * AUGX_FX_INV;
+    }
+    // aSSProb as a begin / end signal of a UTR exon.  The reference answers it from a memo filled by whichever state asked first
+    // (src/intronmodel.cc:1120-1135), as a rule the longass state that ends U + As + 2 + Ae - 1 bases after `base`: the class of
+    // that base is used here (single-class pieces: no difference)
+    double assProbU(int base, bool fwd) const {
+        int q = base + t.U + t.As + 2 + t.Ae - 1;
+        if (q > n - 1) q = n - 1;
+        if (q < 0) q = 0;
+        return assProb(cls[q], base, fwd);
+    }
+    void utrCell(int s, int j) {
+        const int kind = t.state_kind[s], c = cls[j];
+        const int W = t.W, U = t.U, up = t.tss_upwin, te = t.tss_end, dc = t.d_polyasig_cleavage, bl = t.aataaa_boxlen;
+        const int assWhole = t.As + 2 + t.Ae, dssWhole = t.Ds + 2 + t.De;
+        const int ML = t.utr_max_exon_len, M3S = t.utr_max3single, M3T = t.utr_max3term;
+        double best = NINF;
+        int ba = -1, be = 0;
+        if (kind == AUGX_K_UTR5INTRONVAR || kind == AUGX_K_UTR3INTRONVAR || kind == AUGX_K_RUTR5INTRONVAR || kind == AUGX_K_RUTR3INTRONVAR)
+            return; // only introns that match a hint (:985-1041)
+        if (kind == AUGX_K_UTR5INTRON || kind == AUGX_K_UTR3INTRON || kind == AUGX_K_RUTR5INTRON || kind == AUGX_K_RUTR3INTRON) {
+            const double emi = eIn(c, j) + softB(j); // (:1260-1271,1395-1406: the intron model's emission, strand does not matter)
+            for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                int a = t.anc[s][ai];
+                double pv = Vat(j - 1, a);
+                if (pv == NINF) continue;
+                double val = pv + (lnT(c, a, s) + emi);
+                if (val > best) { best = val; ba = a; be = j - 1; }
+            }
+            if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = be; }
+            return;
+        }
+        // ---- getEndPositions :1572-1643
+        int boep, eobe; // beginOfEndPart, endOfBioExon
+        switch (kind) {
+        case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM: boep = j + 1; eobe = j + W; break;
+        case AUGX_K_RUTR5SINGLE: case AUGX_K_RUTR5INIT: boep = j - up - te + 1; eobe = j - up; break;
+        case AUGX_K_UTR5INIT: case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR3INIT: case AUGX_K_UTR3INTERNAL: boep = j - dssWhole + 1; eobe = j - t.De - 2; break;
+        case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5TERM: case AUGX_K_RUTR3INTERNAL: case AUGX_K_RUTR3TERM: boep = j - assWhole - U + 1; eobe = j - U - t.As - 2; break;
+        case AUGX_K_RUTR3SINGLE: case AUGX_K_RUTR3INIT: boep = j + 1; eobe = j; break;
+        default: // UTR3SINGLE, UTR3TERM
+            if (j != n - 1) { boep = j - dc - bl + 1; eobe = j; } else { boep = n; eobe = n - 1; }
+        }
+        // ---- window of predecessor ends :822-916
+        int lm, rm;
+        switch (kind) {
+        case AUGX_K_UTR5SINGLE: lm = j - (ML - W + up); rm = j - up - te - 1 + W + te; if (rm > j - 1) rm = j - 1; break;
+        case AUGX_K_RUTR5SINGLE: lm = j - (ML - W + up); rm = j - up - 1 + W; if (rm > j - 1) rm = j - 1; break;
+        case AUGX_K_UTR5INIT: case AUGX_K_RUTR5INIT: lm = j - (ML + 2 + t.De + up); rm = j - up - te - dssWhole; break;
+        case AUGX_K_UTR5INTERNAL: case AUGX_K_RUTR5INTERNAL: case AUGX_K_UTR3INTERNAL: case AUGX_K_RUTR3INTERNAL:
+            lm = j - (ML + 2 + t.De + U + t.As + 2); rm = j - dssWhole - U - assWhole; break;
+        case AUGX_K_UTR5TERM: case AUGX_K_RUTR5TERM:
+            lm = j - (ML - W + U + t.As + 2); rm = j - U - assWhole;
+            if (-U - assWhole + W + t.Ae < 0) rm = j - U - assWhole + W + t.Ae;
+            break;
+        case AUGX_K_UTR3SINGLE: lm = j - M3S; rm = j != n - 1 ? j - dc - bl : j - 1; break;
+        case AUGX_K_RUTR3SINGLE: lm = j - M3S; rm = j - dc - bl; break;
+        case AUGX_K_UTR3INIT: case AUGX_K_RUTR3INIT: lm = j - (ML + 2 + t.De); rm = j - t.De - 2; break;
+        case AUGX_K_UTR3TERM: lm = j - (M3T + 2 + t.As + U); rm = j != n - 1 ? j - dc - bl - assWhole - U : j - assWhole - U; break;
+        default: lm = j - (M3T + 2 + t.As + U); rm = j - dc - bl - assWhole - U; // RUTR3TERM
+        }
+        // ---- endPartEmiProb :1072-1161
+        double endP = 0.0;
+        if (boep >= 0) {
+            switch (kind) {
+            case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM:
+                if (eobe + 3 <= n - 1) { int pn = pat(eobe + 1, 3); if (!(pn == 14 || pn == 30 || pn == 62)) endP = NINF; } // GeneticCode::isStartcodon
+                break;
+            case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR5INIT: case AUGX_K_UTR3INTERNAL: case AUGX_K_UTR3INIT:
+                endP = dssProb(j - dssWhole + 1, true);
+                break;
+            case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5TERM: case AUGX_K_RUTR3INTERNAL: case AUGX_K_RUTR3TERM:
+                endP = assProb(c, j - U - assWhole + 1, false);
+                break;
+            case AUGX_K_RUTR5SINGLE: case AUGX_K_RUTR5INIT: endP = tssProb(boep, false); break;
+            case AUGX_K_UTR3SINGLE: case AUGX_K_UTR3TERM:
+                if (j == n - 1) endP = 0.0;
+                else if (boep < 0 || boep + bl - 1 >= n) endP = NINF;
+                else endP = ttsPlus[boep];
+                break;
+            default: // RUTR3SINGLE, RUTR3INIT
+                if (j + 3 > n - 1 || !isRCStop(j + 1)) endP = NINF;
+            }
+            // the part of the intron that lies inside the state (:1144-1157)
+            if (endP > NINF && kind != AUGX_K_UTR3SINGLE && kind != AUGX_K_UTR3TERM && kind != AUGX_K_RUTR5SINGLE && kind != AUGX_K_RUTR5INIT && eobe < j)
+                endP = endP + softIn(eobe + 1, j);
+        } else
+            endP = NINF;
+        if (endP == NINF) return;
+        if (kind == AUGX_K_UTR5SINGLE || kind == AUGX_K_UTR5INIT) { if (lm < -up) lm = -up; }
+        else if (kind == AUGX_K_RUTR3SINGLE || kind == AUGX_K_RUTR3TERM) { if (lm < -bl - dc) lm = -bl - dc; }
+        else if (lm < 0) lm = 0;
+        const int eom = boep - 1; // endOfMiddle
+        for (int eop = rm; eop >= lm; eop--) {
+            const int col = eop > 0 ? eop : 0;
+            bool any = false;
+            for (int ai = 0; ai < t.n_anc[s]; ai++)
+                if (Vat(col, t.anc[s][ai]) > NINF) any = true;
+            if (!any) continue;
+            // ---- notEndPartEmiProb :1167-1548
+            const int begin = eop + 1;
+            double bp = 0.0, mp = 0.0, lp = 0.0;
+            int bom, bobe = -1; // beginOfMiddle, beginOfBioExon
+            auto lenAt = [&](const double *d, int maxl, int len) { return (len >= 0 && len <= maxl) ? d[len] : NINF; };
+            switch (kind) {
+            case AUGX_K_UTR5SINGLE:
+                bom = begin + up + te;
+                mp = eom - bom + 1 >= 0 ? segU(u5iF, t.utr5init_emi, true, bom, eom) : -(eom - bom + 1) * t.ln2;
+                bobe = begin + up;
+                lp = lenAt(t.len5_single, ML, eobe - bobe + 1);
+                if (begin >= 0) bp = tssProb(begin, true);
+                else {
+                    bp = (bom - 1) * t.ln_quarter;
+                    if (begin + up == 0) lp = lenAt(t.tail5_single, ML, eom - begin + 1 + W - up);
+                }
+                break;
+            case AUGX_K_UTR5INIT:
+                bom = begin + up + te;
+                mp = segU(u5iF, t.utr5init_emi, true, bom, eom);
+                bobe = begin + up;
+                lp = lenAt(t.len5_initial, ML, eobe - bobe + 1);
+                if (begin >= 0) bp = tssProb(begin, true);
+                else {
+                    bp = (bom - 1) * t.ln_quarter;
+                    if (begin + up == 0) lp = lenAt(t.tail5_single, ML, eobe - bobe + 1);
+                }
+                break;
+            case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR3INTERNAL: case AUGX_K_UTR3TERM: case AUGX_K_UTR5TERM: {
+                bobe = begin + U + t.As + 2;
+                if (kind == AUGX_K_UTR5TERM && bobe >= n) bp = NINF;
+                else bp = assProbU(begin, true);
+                if (bp > NINF) {
+                    bom = begin + U + assWhole;
+                    const bool five = kind == AUGX_K_UTR5INTERNAL || kind == AUGX_K_UTR5TERM;
+                    if (kind == AUGX_K_UTR5TERM && eom - bom + 1 < 0) mp = -(eom - bom + 1) * t.ln4;
+                    else mp = five ? segU(u5F, t.utr5_emi, true, bom, eom) : segU(u3F, t.utr3_emi, true, bom, eom);
+                    const int len = eobe - bobe + 1;
+                    if (kind == AUGX_K_UTR5INTERNAL) lp = lenAt(t.len5_internal, ML, len);
+                    else if (kind == AUGX_K_UTR5TERM) lp = lenAt(t.len5_terminal, ML, len);
+                    else if (kind == AUGX_K_UTR3INTERNAL) lp = lenAt(t.len3_internal, ML, len);
+                    else lp = eobe != n - 1 ? lenAt(t.len3_terminal, M3T, len) : lenAt(t.tail3_single, M3S, len);
+                }
+                break;
+            }
+            case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5INIT: case AUGX_K_RUTR3INIT: case AUGX_K_RUTR3INTERNAL: {
+                bp = dssProb(begin, false);
+                bobe = begin + t.De + 2;
+                if (bp > NINF) {
+                    bom = begin + dssWhole;
+                    const int len = eobe - bobe + 1;
+                    if (kind == AUGX_K_RUTR5INTERNAL) { mp = segU(u5R, t.utr5_emi, false, bom, eom); lp = lenAt(t.len5_internal, ML, len); }
+                    else if (kind == AUGX_K_RUTR5INIT) { mp = segU(u5iR, t.utr5init_emi, false, bom, eom); lp = lenAt(t.len5_initial, ML, len); }
+                    else if (kind == AUGX_K_RUTR3INIT) {
+                        mp = eom - bom + 1 >= 0 ? segU(u3R, t.utr3_emi, false, bom, eom) : -(eom - bom + 1) * t.ln4;
+                        lp = lenAt(t.len3_initial, ML, len);
+                    } else { mp = segU(u3R, t.utr3_emi, false, bom, eom); lp = lenAt(t.len3_internal, ML, len); }
+                }
+                break;
+            }
+            case AUGX_K_RUTR5TERM:
+                bom = begin; bobe = begin - W;
+                mp = eom - bom + 1 >= 0 ? segU(u5R, t.utr5_emi, false, bom, eom) : -(eom - bom + 1) * t.ln4;
+                lp = lenAt(t.len5_terminal, ML, eobe - bobe + 1);
+                break;
+            case AUGX_K_RUTR5SINGLE:
+                bom = begin; bobe = begin - W;
+                mp = eom - bom + 1 >= 0 ? segU(u5iR, t.utr5init_emi, false, bom, eom) : -(eom - bom + 1) * t.ln2;
+                lp = lenAt(t.len5_single, ML, eobe - bobe + 1);
+                break;
+            case AUGX_K_UTR3SINGLE:
+                bom = bobe = begin;
+                mp = segU(u3F, t.utr3_emi, true, bom, eom);
+                lp = eobe != n - 1 ? lenAt(t.len3_single, M3S, eobe - bobe + 1) : lenAt(t.tail3_single, M3S, eobe - bobe + 1);
+                break;
+            case AUGX_K_RUTR3SINGLE: case AUGX_K_RUTR3TERM:
+                bobe = begin;
+                bom = begin + bl + dc;
+                if (begin > 0) {
+                    bp = ttsMinus[begin + dc <= n ? begin + dc : n];
+                    lp = kind == AUGX_K_RUTR3SINGLE ? lenAt(t.len3_single, M3S, eobe - bobe + 1) : 0.0;
+                } else {
+                    bp = (kind == AUGX_K_RUTR3TERM || bom > 0) ? (bom - 1) * t.ln_quarter : 0.0;
+                    lp = kind == AUGX_K_RUTR3SINGLE ? lenAt(t.tail3_single, M3S, eobe - bobe + 1) : 0.0;
+                }
+                if (bp > NINF) {
+                    mp = segU(u3R, t.utr3_emi, false, bom, eom);
+                    if (kind == AUGX_K_RUTR3TERM) lp = lenAt(t.len3_terminal, M3T, eobe - bobe + 1);
+                }
+                break;
+            default: // UTR3INIT
+                bom = bobe = begin;
+                mp = eom - bom + 1 >= 0 ? segU(u3F, t.utr3_emi, true, bom, eom) : -(eom - bom + 1) * t.ln4;
+                lp = lenAt(t.len3_initial, ML, eobe - bobe + 1);
+            }
+            double nep = (bp + mp) + lp;
+            if (!(nep > NINF)) continue;
+            // the part of the preceding intron that lies inside the state (:1533-1545)
+            if (kind == AUGX_K_UTR5INTERNAL || kind == AUGX_K_UTR5TERM || kind == AUGX_K_UTR3INTERNAL || kind == AUGX_K_UTR3TERM ||
+                kind == AUGX_K_RUTR5INTERNAL || kind == AUGX_K_RUTR5INIT || kind == AUGX_K_RUTR3INTERNAL || kind == AUGX_K_RUTR3INIT)
+                nep = nep + softIn(begin, bobe - 1);
+            const double emi = nep + endP;
+            for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                int a = t.anc[s][ai];
+                double pv = Vat(col, a);
+                if (pv == NINF) continue;
+                double val = pv + (lnT(c, a, s) + emi);
+                if (val > best) { best = val; ba = a; be = eop; }
+            }
+        }
+        if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = be; }
+    }
+
     int run(int init_kind, int term_kind, double *lnv, std::vector<augx_state> &path) {
         V.assign((size_t)n * S, NINF);
         bpS.assign((size_t)n * S, -1);
@@ -766,14 +1103,20 @@ struct Twin {
             useSnips = false;
             for (int j = 1; j < n && g_snippetCache; j++) useSnips = useSnips || cls[j] != cls[0];
             if (useSnips) { snips[0].assign((size_t)n, {}); snips[1].assign((size_t)n, {}); }
-            for (int j = 1; j < n; j++)
+            if (t.utr) buildUtr();
+            for (int j = 1; j < n; j++) {
+                curCls = cls[j];
+                if (t.utr && curCls != prevCls) utrEnterRegion(j);
+                prevCls = curCls;
                 for (int s = 0; s < S; s++) {
                     if (!t.reachable[s]) continue;
                     int kind = t.state_kind[s];
                     if (kind == AUGX_K_IGENIC) igenicCell(s, j);
                     else if (kind <= AUGX_K_RTERMINAL) exonCell(s, j);
-                    else intronCell(s, j);
+                    else if (kind <= AUGX_K_RLONGASS) intronCell(s, j);
+                    else utrCell(s, j);
                 }
+            }
         }
         // termination + back-tracking: reference NAMGene::getViterbiPath, src/namgene.cc:432-510
         double maxV = NINF;
@@ -801,7 +1144,8 @@ struct Twin {
         for (size_t i = path.size(); i-- > 0;) {
             const augx_state &st = path[i];
             int kind = t.state_kind[st.state];
-            bool mergeable = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC;
+            bool mergeable = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC || kind == AUGX_K_UTR5INTRON ||
+                             kind == AUGX_K_UTR3INTRON || kind == AUGX_K_RUTR5INTRON || kind == AUGX_K_RUTR3INTRON;
             if (mergeable && !out.empty() && out.back().state == st.state && out.back().end + 1 == st.begin)
                 out.back().end = st.end;
             else

@@ -153,11 +153,11 @@ int main(int argc, char *argv[]) {
                 continue;
             }
             printf("LNV %.17g\n", p->pathemiProb.log());
-            // runs of single-base igenic / geometric-intron states are merged into one record
+            // runs of single-base igenic / geometric-intron / UTR-intron states are merged into one record
             // (same merge StatePath::condenseStatePath does, src/gene.cc:977-1000); everything else is raw
             std::vector<State> recs;
             for (State *st = p->first; st; st = st->next) {
-                bool mergeable = st->type == igenic || isGeometricIntron(st->type) || isRGeometricIntron(st->type);
+                bool mergeable = st->type == igenic || isGeometricIntron(st->type) || isRGeometricIntron(st->type) || st->type == utr5intron || st->type == utr3intron || st->type == rutr5intron || st->type == rutr3intron;
                 if (mergeable && !recs.empty() && recs.back().type == st->type && recs.back().end + 1 == st->begin)
                     recs.back().end = st->end;
                 else
@@ -202,7 +202,7 @@ int main(int argc, char *argv[]) {
                     StatePath *sp = namgene.getSampledPath(cur->sequence, cur->seqname);
                     std::vector<State> sr;
                     for (State *st = sp->first; st; st = st->next) {
-                        bool mergeable = st->type == igenic || isGeometricIntron(st->type) || isRGeometricIntron(st->type);
+                        bool mergeable = st->type == igenic || isGeometricIntron(st->type) || isRGeometricIntron(st->type) || st->type == utr5intron || st->type == utr3intron || st->type == rutr5intron || st->type == rutr3intron;
                         if (mergeable && !sr.empty() && sr.back().type == st->type && sr.back().end + 1 == st->begin)
                             sr.back().end = st->end;
                         else
