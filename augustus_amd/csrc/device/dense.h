@@ -1,0 +1,936 @@
+// dense.h -- the "dense" decode kernels: models whose state graph the wavefront layout of trellisPiece (kernels.h) was not built
+// for -- first of all the 71-state model with untranslated regions (--UTR=on, reference src/utrmodel.cc).
+//
+// What differs from the 47-state path:
+//   * the ln V matrix is kept dense in HBM ([N][S], BatchView::cells; ln F in BatchView::fwd): a candidate names its predecessor
+//     by (end of predecessor, state), no value lists; the newest 64 columns also live in an LDS ring;
+//   * one kernel body, densePiece<BLK, MODE>, does the Viterbi recurrence (MODE 0: max, bit-exact) and the forward recurrence
+//     (MODE 1: ln-sum), data-driven by the state graph: fixed-lag states, early chain states (geometric introns), candidates of
+//     the variable-length states, late chain states (intergenic, UTR introns), reverse terminal exons -- in that order per block;
+//   * the candidates of the 16 exon-like UTR states are NOT materialised (they would be ~200 records per base): a UTR exon that
+//     ends at base j in state s is scored  V[eop][a] + t(a->s) + B_s[eop] + E_s[j] + lenDist_s[j - eop + c_s]  where B (begin
+//     signal minus content prefix, per begin SITE, written once by the prep kernels into short site lists) and E (end signal plus
+//     content prefix, per end base) do not depend on V -- the trellis walks the site list of the state's window
+//     (reference UtrModel::viterbiForwardAndSampling, src/utrmodel.cc:796-1064; notEndPartEmiProb :1167-1548).
+// Everything is compiled for gfx950 and, with -DAUGX_EMU, for the lane-loop emulator (tests only).
+#pragma once
+#include "kernels.h"
+
+namespace augx {
+namespace dev {
+
+AUGX_HD int baseClass(const BatchView &B, int p, int64_t g) { return B.cls[p] < 0 ? -1 : B.planeCls[p * MAXPL + B.gcPlane[g]]; }
+AUGX_HD double fxD(uint64_t v) { return (double)(int64_t)v * AUGX_FX_INV; }
+
+// =================================================================================================
+// K1 (UTR): content prefix terms and begin-site counts, one scan; signal records, end gates and the site lists
+// =================================================================================================
+// terms of the NUFX content prefix fields and the NUCNT site counts of slot g.  The term of a base comes from the class OF THAT
+// BASE (reference SegProbs::setEmiProbs is re-run over the region of every class, src/statemodel.cc:398-432, src/utrmodel.cc:784-790);
+// base 0 counts ln 1/4 (cumProds[0] = .25)
+AUGX_HD void k1UtrTermsCalc(const DevTables &T, const BatchView &B, int64_t g, uint64_t out[NUFX + NUCNT], const uint8_t *lcode = nullptr,
+                            int lLo = 0, int lHi = 0) {
+    const int p = B.chunkPiece[g / CHUNK];
+    const int64_t o = B.off[p];
+    const int q = (int)(g - o - 1), n = B.len[p];
+    for (int i = 0; i < NUFX + NUCNT; i++) out[i] = 0;
+    if (q < 0 || q >= n || B.cls[p] < 0) return;
+    Piece P;
+    P.t = &T; P.n = n; P.c = baseClass(B, p, g); P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+    P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
+    const int k = T.k, NP = T.NP, c = P.c;
+    const int pn = (q >= 1 && q >= k) ? P.pat(q - k, k + 1) : -1;
+    const int rn = (q >= 1 && q < n - k) ? P.rcpat(q, k + 1) : -1;
+    const double *t5i = AUGX_GTAB(T.utr5init_emi) + (int64_t)c * NP, *t5 = AUGX_GTAB(T.utr5_emi) + (int64_t)c * NP, *t3 = AUGX_GTAB(T.utr3_emi) + (int64_t)c * NP;
+    out[UFX_5IF] = toFx(pn >= 0 ? t5i[pn] : T.ln_quarter); out[UFX_5IR] = toFx(rn >= 0 ? t5i[rn] : T.ln_quarter);
+    out[UFX_5F] = toFx(pn >= 0 ? t5[pn] : T.ln_quarter);   out[UFX_5R] = toFx(rn >= 0 ? t5[rn] : T.ln_quarter);
+    out[UFX_3F] = toFx(pn >= 0 ? t3[pn] : T.ln_quarter);   out[UFX_3R] = toFx(rn >= 0 ? t3[rn] : T.ln_quarter);
+    // a transcript may start only at every tts_spacing-th base (src/utrmodel.cc:1785); the TSS window must fit the piece (:1768)
+    if (q % T.tts_spacing == 0 && q + T.tss_upwin + T.tss_end - 1 < n) out[NUFX + UCNT_TF] = 1;
+    // a forward single / terminal exon may end at q (stop codon q-2..q): predecessor of the forward 3' UTR
+    if (q - 2 >= 0 && P.isStop(q - 2)) {
+        const double sp = (P.b(q - 1) == 0 && P.b(q) == 0) ? T.ln_stop_ochre : (P.b(q - 1) == 0 && P.b(q) == 2) ? T.ln_stop_amber : T.ln_stop_opal;
+        if (sp > AUGX_NINF) out[NUFX + UCNT_FS] = 1;
+    }
+    // the reverse poly-A box begins at q (ttsProbMinus[q] > 0, src/utrmodel.cc:1872-1903; the state begins d_polyasig_cleavage before it)
+    if (q - T.dpc > 0 && q + T.boxlen - 1 < n) {
+        const int bn = P.rcpat(q, T.boxlen);
+        if ((bn >= 0 && AUGX_GTAB(T.aataaa)[bn] > AUGX_NINF) || q % T.tts_spacing == 0) out[NUFX + UCNT_TM] = 1;
+    }
+    // a reverse single / initial exon may end at q (reverse start codon at q-W-2): predecessor of the reverse 5' UTR
+    if (q - T.W - 2 >= 0) {
+        const int sn = P.rcpat(q - T.W - 2, 3);
+        if (sn >= 0 && T.ln_startcodon[sn] > AUGX_NINF) out[NUFX + UCNT_RT] = 1;
+    }
+}
+AUGX_HD void k1UtrTerms(const DevTables &T, const BatchView &B, int64_t g) { // (emulator: terms to memory, scanned in place)
+    uint64_t v[NUFX + NUCNT];
+    k1UtrTermsCalc(T, B, g, v);
+    for (int i = 0; i < NUFX; i++) B.ufx[fidx(g, i, NUFX)] = v[i];
+    for (int i = 0; i < NUCNT; i++) B.ucnt[fidx(g, i, NUCNT)] = (uint32_t)v[NUFX + i];
+}
+// longest UTR site list of piece p (next to k1ListCount: the lists share one capacity)
+AUGX_HD void k1UtrListCount(const BatchView &B, int p) {
+    const int64_t g = B.off[p] + B.len[p];
+    uint32_t m = (uint32_t)B.listCnt[p];
+    for (int f = 0; f < NUCNT; f++) { const uint32_t c = B.ucnt[fidx(g, f, NUCNT)]; m = c > m ? c : m; }
+    B.listCnt[p] = (int32_t)m;
+}
+
+// UtrModel::tssupSeqProb, src/utrmodel.cc:1733-1750
+AUGX_HD double tssupSeq(const Piece &P, int left, int right, bool rev) {
+    const DevTables &T = *P.t;
+    const int uk = T.tssup_k;
+    const double *E = AUGX_GTAB(T.tssup_emi) + (int64_t)P.c * (1 << (2 * (uk + 1)));
+    double s = 0;
+    for (int p = right; p >= left; p--) {
+        int pn = -1;
+        if (!rev && p - uk >= 0) pn = P.pat(p - uk, uk + 1);
+        else if (rev && p >= 0 && p + uk < P.n) pn = P.rcpat(p, uk + 1);
+        s += pn >= 0 ? E[pn] : T.ln_quarter;
+    }
+    return s;
+}
+// UtrModel::tssProb, src/utrmodel.cc:1761-1833, with the tables of class P.c (ab initio: the hint factor is 1)
+AUGX_HD double tssProbCalc(const Piece &P, int left, bool fwd) {
+    const DevTables &T = *P.t;
+    const int n = P.n, c = P.c;
+    const int right = left + T.tss_upwin + T.tss_end - 1;
+    if (right >= n || left < 0) return AUGX_NINF;
+    if (left % T.tts_spacing != 0) return AUGX_NINF;
+    const int64_t sz0 = (int64_t)1 << (2 * (T.tss_k + 1)), sz1 = (int64_t)1 << (2 * (T.tsstata_k + 1)), sz2 = (int64_t)1 << (2 * (T.tata_k + 1));
+    const double *Mtss = AUGX_GTAB(T.tss_motif) + (int64_t)c * T.tss_n * sz0, *Mtt = AUGX_GTAB(T.tsstata_motif) + (int64_t)c * T.tsstata_n * sz1,
+                 *Mta = AUGX_GTAB(T.tata_motif) + (int64_t)c * T.tata_n * sz2;
+    const int maxpos = T.d_tss_tata_max - T.d_tss_tata_min - 1;
+    if (fwd) {
+        const int w0 = right - T.tss_end - T.d_tss_tata_max + 1;
+        int rel = -1;
+        for (int pos = 0; pos <= maxpos; pos++) // UtrModel::findTATA :271-287
+            if (P.b(w0 + pos) == 3 && P.b(w0 + pos + 1) == 0 && P.b(w0 + pos + 2) == 3 && P.b(w0 + pos + 3) == 0 && P.b(w0 + pos + 5) == 0) { rel = pos; break; }
+        if (rel >= 0) {
+            const int tatapos = w0 + rel;
+            return motifF(P, Mtt, T.tsstata_n, T.tsstata_k, right - T.tss_end - T.tss_start + 1) + motifF(P, Mta, T.tata_n, T.tata_k, tatapos - T.tata_start) +
+                   (tssupSeq(P, left, tatapos - T.tata_start - 1, false) + tssupSeq(P, tatapos + T.tata_end, right - T.tss_end - T.tss_start, false));
+        }
+        return motifF(P, Mtss, T.tss_n, T.tss_k, right - T.tss_end - T.tss_start + 1) + tssupSeq(P, left, right - T.tss_end - T.tss_start, false);
+    }
+    const int w0 = left + T.tss_end + T.d_tss_tata_max - 1;
+    int rel = 1;
+    for (int pos = 0; pos >= -maxpos; pos--)
+        if (P.b(w0 + pos) == 0 && P.b(w0 + pos - 1) == 3 && P.b(w0 + pos - 2) == 0 && P.b(w0 + pos - 3) == 3 && P.b(w0 + pos - 5) == 3) { rel = pos; break; }
+    if (rel <= 0) {
+        const int tatapos = w0 + rel;
+        return motifRC(P, Mtt, T.tsstata_n, T.tsstata_k, left) + motifRC(P, Mta, T.tata_n, T.tata_k, tatapos - T.tata_end + 1) +
+               (tssupSeq(P, left + T.tata_end + T.tata_start - 1, tatapos - T.tata_end, true) + tssupSeq(P, tatapos + T.tata_start + 1, right, true));
+    }
+    return motifRC(P, Mtss, T.tss_n, T.tss_k, left) + tssupSeq(P, left + T.tss_end + T.tss_start, right, true);
+}
+// UtrModel::computeTtsProbs, src/utrmodel.cc:1840-1912, for the box beginning at b (class P.c = the class of base b)
+AUGX_HD double ttsPlusCalc(const Piece &P, int b) {
+    const DevTables &T = *P.t;
+    if (b < 1 || b + T.boxlen + T.dpc - 1 >= P.n) return AUGX_NINF;
+    if (b - T.dpc < 0 || b + T.boxlen - 1 >= P.n) return AUGX_NINF; // (sic: the reference zeroes the PLUS entry in its minus-strand branch, :1873-1874)
+    const int pn = P.pat(b, T.boxlen);
+    double prob = pn >= 0 ? AUGX_GTAB(T.aataaa)[pn] : AUGX_NINF;
+    if (b % T.tts_spacing == 0 && prob == AUGX_NINF) prob = T.ln_tts_rand;
+    if (prob > AUGX_NINF) prob = prob + motifF(P, AUGX_GTAB(T.tts_motif) + (int64_t)P.c * T.tts_n * (1 << (2 * (T.tts_k + 1))), T.tts_n, T.tts_k, b + T.boxlen);
+    return prob;
+}
+AUGX_HD double ttsMinusCalc(const Piece &P, int b) {
+    const DevTables &T = *P.t;
+    if (b < 1 || b - T.dpc < 0 || b + T.boxlen - 1 >= P.n) return AUGX_NINF;
+    const int rn = P.rcpat(b, T.boxlen);
+    double prob = rn >= 0 ? AUGX_GTAB(T.aataaa)[rn] : AUGX_NINF;
+    if (b % T.tts_spacing == 0 && prob == AUGX_NINF) prob = T.ln_tts_rand;
+    if (prob > AUGX_NINF) prob = prob + motifRC(P, AUGX_GTAB(T.tts_motif) + (int64_t)P.c * T.tts_n * (1 << (2 * (T.tts_k + 1))), T.tts_n, T.tts_k, b - T.dpc);
+    return prob;
+}
+AUGX_HD bool ttsPlusOpen(const Piece &P, int b) { // ttsProbPlus[b] > 0 without the motif product
+    const DevTables &T = *P.t;
+    if (b < 1 || b + T.boxlen + T.dpc - 1 >= P.n || b - T.dpc < 0) return false;
+    const int pn = P.pat(b, T.boxlen);
+    return (pn >= 0 && AUGX_GTAB(T.aataaa)[pn] > AUGX_NINF) || b % T.tts_spacing == 0;
+}
+
+// geometry of the 16 exon-like UTR kinds (reference getEndPositions :1572-1643, the predecessor windows :822-916, the begin / middle
+// / length parts of notEndPartEmiProb :1167-1420): which site list holds the possible begins, which of its three (signal - prefix)
+// values and which content prefix field belong to the kind, first base of the middle part and of the biological exon relative to
+// the begin of the state, the correction for a middle part of negative length, the length distribution
+struct UGeom { int8_t list, bsel, fxf, ovl, len; int cb, cbobe; };
+constexpr int UL_TF = 0, UL_LA = 1, UL_FS = 2, UL_LR = 3, UL_TM = 4, UL_RT = 5;
+AUGX_HD UGeom utrGeom(const DevTables &T, int kind) {
+    const int assWhole = T.As + 2 + T.Ae, dssWhole = T.Ds + 2 + T.De;
+    UGeom g{0, 0, 0, 0, 0, 0, 0};
+    switch (kind) {
+    case AUGX_K_UTR5SINGLE: g = {UL_TF, 0, UFX_5IF, 1, 0, T.tss_upwin + T.tss_end, T.tss_upwin}; break;
+    case AUGX_K_UTR5INIT: g = {UL_TF, 0, UFX_5IF, 0, 1, T.tss_upwin + T.tss_end, T.tss_upwin}; break;
+    case AUGX_K_UTR5INTERNAL: g = {UL_LA, 0, UFX_5F, 0, 2, T.U + assWhole, T.U + T.As + 2}; break;
+    case AUGX_K_UTR5TERM: g = {UL_LA, 0, UFX_5F, 2, 3, T.U + assWhole, T.U + T.As + 2}; break;
+    case AUGX_K_UTR3SINGLE: g = {UL_FS, 0, UFX_3F, 0, 4, 0, 0}; break;
+    case AUGX_K_UTR3INIT: g = {UL_FS, 0, UFX_3F, 2, 5, 0, 0}; break;
+    case AUGX_K_UTR3INTERNAL: g = {UL_LA, 1, UFX_3F, 0, 6, T.U + assWhole, T.U + T.As + 2}; break;
+    case AUGX_K_UTR3TERM: g = {UL_LA, 1, UFX_3F, 0, 7, T.U + assWhole, T.U + T.As + 2}; break;
+    case AUGX_K_RUTR5SINGLE: g = {UL_RT, 0, UFX_5IR, 1, 0, 0, -T.W}; break;
+    case AUGX_K_RUTR5INIT: g = {UL_LR, 1, UFX_5IR, 0, 1, dssWhole, T.De + 2}; break;
+    case AUGX_K_RUTR5INTERNAL: g = {UL_LR, 0, UFX_5R, 0, 2, dssWhole, T.De + 2}; break;
+    case AUGX_K_RUTR5TERM: g = {UL_RT, 1, UFX_5R, 2, 3, 0, -T.W}; break;
+    case AUGX_K_RUTR3SINGLE: g = {UL_TM, 0, UFX_3R, 0, 4, T.boxlen + T.dpc, 0}; break;
+    case AUGX_K_RUTR3INIT: g = {UL_LR, 2, UFX_3R, 2, 5, dssWhole, T.De + 2}; break;
+    case AUGX_K_RUTR3INTERNAL: g = {UL_LR, 2, UFX_3R, 0, 6, dssWhole, T.De + 2}; break;
+    default: g = {UL_TM, 0, UFX_3R, 0, 7, T.boxlen + T.dpc, 0}; // RUTR3TERM
+    }
+    return g;
+}
+// end of the state at j: first base of the end signal and last base of the biological exon (getEndPositions)
+AUGX_HD void utrEndPos(const DevTables &T, int kind, int j, int n, int &boep, int &eobe) {
+    const int assWhole = T.As + 2 + T.Ae, dssWhole = T.Ds + 2 + T.De;
+    switch (kind) {
+    case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM: boep = j + 1; eobe = j + T.W; break;
+    case AUGX_K_RUTR5SINGLE: case AUGX_K_RUTR5INIT: boep = j - T.tss_upwin - T.tss_end + 1; eobe = j - T.tss_upwin; break;
+    case AUGX_K_UTR5INIT: case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR3INIT: case AUGX_K_UTR3INTERNAL: boep = j - dssWhole + 1; eobe = j - T.De - 2; break;
+    case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5TERM: case AUGX_K_RUTR3INTERNAL: case AUGX_K_RUTR3TERM: boep = j - assWhole - T.U + 1; eobe = j - T.U - T.As - 2; break;
+    case AUGX_K_RUTR3SINGLE: case AUGX_K_RUTR3INIT: boep = j + 1; eobe = j; break;
+    default: if (j != n - 1) { boep = j - T.dpc - T.boxlen + 1; eobe = j; } else { boep = n; eobe = n - 1; }
+    }
+}
+// does the UTR exon state of this kind pass its end gate at base j?  (endPartEmiProb > 0, :1072-1115; values: utrDescribe)
+AUGX_HD bool utrGateOpen(const Piece &P, int kind, int j, double tssR) {
+    const DevTables &T = *P.t;
+    const int n = P.n;
+    int boep, eobe;
+    utrEndPos(T, kind, j, n, boep, eobe);
+    if (boep < 0) return false;
+    switch (kind) {
+    case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM: {
+        if (eobe + 3 > n - 1) return true;
+        const int pn = P.pat(eobe + 1, 3);
+        return pn == 14 || pn == 30 || pn == 62; // GeneticCode::isStartcodon: {a,c,t}tg
+    }
+    case AUGX_K_UTR5INIT: case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR3INIT: case AUGX_K_UTR3INTERNAL: return dssProb(P, boep, true) > AUGX_NINF;
+    case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5TERM: case AUGX_K_RUTR3INTERNAL: case AUGX_K_RUTR3TERM: return P.possRASS(boep + T.Ae);
+    case AUGX_K_RUTR5SINGLE: case AUGX_K_RUTR5INIT: return tssR > AUGX_NINF;
+    case AUGX_K_UTR3SINGLE: case AUGX_K_UTR3TERM: return j == n - 1 || (boep + T.boxlen - 1 < n && ttsPlusOpen(P, boep));
+    default: return j + 3 <= n - 1 && P.isRCStop(j + 1);
+    }
+}
+
+// per-base UTR signal record, end gates of the UTR exon states (OR-ed into B.gate) and the entries of the six site lists.
+// Runs after the scans and after k1SiteSignals (it reads SIG_ASSF / SIG_DSSR of the splice sites ending here).
+AUGX_HD void k1UtrSignals(const DevTables &T, const BatchView &B, int64_t g, const uint8_t *lcode = nullptr, int lLo = 0, int lHi = 0) {
+    const int p = B.chunkPiece[g / CHUNK];
+    const int64_t o = B.off[p];
+    const int q = (int)(g - o - 1), n = B.len[p];
+    double *us = B.usig + g * NUSIG;
+    for (int i = 0; i < NUSIG; i++) us[i] = AUGX_NINF;
+    if (q < 0 || q >= n || B.cls[p] < 0) return;
+    Piece P = makePieceAt(T, B, p, B.gcPlane[g]); // the class of base q
+    P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
+    const int up = T.tss_upwin, te = T.tss_end, dc = T.dpc, bl = T.boxlen, assWhole = T.As + 2 + T.Ae, dssWhole = T.Ds + 2 + T.De;
+    {   // forward TSS window beginning at q.  The reference computes the value when a 5' UTR state first asks for it and keeps it
+        // (tssProbsPlus, :1788-1790): with the class current THEN, as a rule that of the transcription start -- used here
+        int qc = q + up; if (qc > n - 1) qc = n - 1;
+        Piece PF = P;
+        PF.c = baseClass(B, p, o + 1 + qc);
+        us[USIG_TSSF] = tssProbCalc(PF, q, true);
+    }
+    us[USIG_TSSR] = tssProbCalc(P, q - up - te + 1, false); // the reverse TSS window ENDING at q is asked for at column q (:1098)
+    us[USIG_TTSP] = ttsPlusCalc(P, q);
+    us[USIG_TTSM] = ttsMinusCalc(P, q);
+    uint64_t gate = 0;
+    if (q >= 1)
+        for (int s = 0; s < T.S; s++) {
+            if (!T.reachable[s] || !isUtrExonKind(T.kind[s])) continue;
+            if (utrGateOpen(P, T.kind[s], q, us[USIG_TSSR])) gate |= 1ull << T.vbit[s];
+        }
+    B.gate[g] |= gate;
+    // site-list entries of the sites at q
+    const int64_t lo = listOff(B, p);
+    auto pfx = [&](int f, int pos) -> double { // content prefix up to and including base pos (pos < 0: empty)
+        if (pos < 0) return 0.0;
+        if (pos > n - 1) pos = n - 1;
+        return fxD(B.ufx[fidx(o + 1 + pos, f, NUFX)]);
+    };
+    auto ucn = [&](int f) -> uint32_t { return B.ucnt[fidx(g, f, NUCNT)]; };
+    auto ucp = [&](int f) -> uint32_t { return B.ucnt[fidx(g - 1, f, NUCNT)]; };
+    if (ucn(UCNT_TF) != ucp(UCNT_TF)) {
+        USite &e = B.tfSite[lo + ucn(UCNT_TF) - 1];
+        e.pos = q - 1; e.pad = 0; e.b[0] = us[USIG_TSSF] - pfx(UFX_5IF, q + up + te - 1); e.b[1] = e.b[2] = AUGX_NINF;
+    }
+    if (ucn(UCNT_FS) != ucp(UCNT_FS)) {
+        USite &e = B.fsSite[lo + ucn(UCNT_FS) - 1];
+        e.pos = q; e.pad = 0; e.b[0] = 0.0 - pfx(UFX_3F, q); e.b[1] = e.b[2] = AUGX_NINF;
+    }
+    if (ucn(UCNT_TM) != ucp(UCNT_TM)) {
+        USite &e = B.tmSite[lo + ucn(UCNT_TM) - 1];
+        e.pos = q - dc - 1; e.pad = 0; e.b[0] = us[USIG_TTSM] - pfx(UFX_3R, q + bl - 1); e.b[1] = e.b[2] = AUGX_NINF;
+    }
+    if (ucn(UCNT_RT) != ucp(UCNT_RT)) {
+        USite &e = B.rtSite[lo + ucn(UCNT_RT) - 1];
+        e.pos = q; e.pad = 0; e.b[0] = 0.0 - pfx(UFX_5IR, q); e.b[1] = 0.0 - pfx(UFX_5R, q); e.b[2] = AUGX_NINF;
+    }
+    const uint32_t la1 = B.cnt[fidx(g, CNT_LA, NCNT)], la0 = B.cnt[fidx(g - 1, CNT_LA, NCNT)];
+    if (la1 != la0) { // a longass state may end at q: the UTR exon after a UTR intron begins U + As + 2 + Ae - 1 bases before q
+        USite &e = B.laSite[lo + la1 - 1];
+        const double a = B.sig[g * NSIG + SIG_ASSF]; // aSSProb + the soft-masking bonus of the intronic part (the same bases, :1533-1545)
+        e.pos = q - T.U - assWhole; e.pad = 0; e.b[0] = a - pfx(UFX_5F, q); e.b[1] = a - pfx(UFX_3F, q); e.b[2] = AUGX_NINF;
+    }
+    const uint32_t lr1 = B.cnt[fidx(g, CNT_LR, NCNT)], lr0 = B.cnt[fidx(g - 1, CNT_LR, NCNT)];
+    if (lr1 != lr0) { // a reverse longdss state may end at q
+        USite &e = B.lrSite[lo + lr1 - 1];
+        const double a = B.sig[g * NSIG + SIG_DSSR];
+        e.pos = q - dssWhole; e.pad = 0; e.b[0] = a - pfx(UFX_5R, q); e.b[1] = a - pfx(UFX_5IR, q); e.b[2] = a - pfx(UFX_3R, q);
+    }
+}
+
+// =================================================================================================
+// candidates of the exon-like UTR states, evaluated where they are needed (trellis, forward, back-trace, sampler)
+// =================================================================================================
+struct UDesc {          // state s ending at base j
+    int8_t kind, list, bsel, fxf, ovl, len;
+    int16_t s;
+    int32_t j, nList, nExtra, total;
+    int32_t i1;         // one past the newest list entry (piece-local index)
+    int32_t xHi;        // predecessor end of the first extra candidate (they run downwards)
+    int32_t eom, eobe, cb, cbobe;
+    double endP, E;     // ln end signal; endP + content prefix up to the end of the middle part
+};
+// read-only view of one piece for the UTR candidates
+struct UCtx {
+    const DevTables &T;
+    const BatchView &B;
+    int p, n;
+    int64_t o, lo;
+    AUGX_HD UCtx(const DevTables &t, const BatchView &b, int pp) : T(t), B(b), p(pp) { n = B.len[p]; o = B.off[p]; lo = listOff(B, p); }
+    AUGX_HD uint32_t cntU(int f, int q) const { if (q < 0) return 0; if (q > n - 1) q = n - 1; return B.ucnt[fidx(o + 1 + q, f, NUCNT)]; }
+    AUGX_HD uint32_t cntS(int f, int q) const { if (q < 0) return 0; if (q > n - 1) q = n - 1; return B.cnt[fidx(o + 1 + q, f, NCNT)]; }
+    AUGX_HD double pfx(int f, int pos) const { if (pos < 0) return 0.0; if (pos > n - 1) pos = n - 1; return fxD(B.ufx[fidx(o + 1 + pos, f, NUFX)]); }
+    AUGX_HD int clsAt(int q) const { return baseClass(B, p, o + 1 + q); }
+    AUGX_HD const USite *list(int l) const { return (l == UL_TF ? B.tfSite : l == UL_LA ? B.laSite : l == UL_FS ? B.fsSite : l == UL_LR ? B.lrSite : l == UL_TM ? B.tmSite : B.rtSite) + lo; }
+};
+// descriptor of UTR exon state s ending at j (the gate bit says endPart > 0; the value is computed here).  total == 0: nothing to do
+AUGX_HD void utrDescribe(const UCtx &X, int s, int j, UDesc &D) {
+    const DevTables &T = X.T;
+    const BatchView &B = X.B;
+    const int kind = T.kind[s], n = X.n;
+    const UGeom g = utrGeom(T, kind);
+    D.kind = (int8_t)kind; D.list = g.list; D.bsel = g.bsel; D.fxf = g.fxf; D.ovl = g.ovl; D.len = g.len; D.cb = g.cb; D.cbobe = g.cbobe;
+    D.s = (int16_t)s; D.j = j; D.nList = D.nExtra = D.total = 0; D.i1 = 0; D.xHi = 0;
+    int boep, eobe, lm, rm;
+    utrEndPos(T, kind, j, n, boep, eobe);
+    utrWindow(T, kind, j, n, lm, rm);
+    D.eom = boep - 1; D.eobe = eobe;
+    const int assWhole = T.As + 2 + T.Ae;
+    const int64_t gj = X.o + 1 + j;
+    double endP = 0.0;
+    switch (kind) { // endPartEmiProb :1072-1161 (with the soft-masking bonus of the intronic part of the state, :1144-1157)
+    case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM: break; // (the gate was the start codon)
+    case AUGX_K_UTR5INIT: case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR3INIT: case AUGX_K_UTR3INTERNAL: {
+        Piece P = makePiece(T, B, X.p);
+        endP = dssProb(P, boep, true);
+        break;
+    }
+    case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5TERM: case AUGX_K_RUTR3INTERNAL: case AUGX_K_RUTR3TERM:
+        if (boep >= 1) endP = B.sig[gj * NSIG + SIG_ASSR]; // (= aSSProb of the window + the bonus of the same intronic bases)
+        else { // the window begins at base 0: the rlongass state cannot end here, the UTR exon can
+            Piece P = makePieceAt(T, B, X.p, B.gcPlane[gj]);
+            endP = assProb(P, boep, false);
+        }
+        break;
+    case AUGX_K_RUTR5SINGLE: case AUGX_K_RUTR5INIT: endP = B.usig[gj * NUSIG + USIG_TSSR]; break;
+    case AUGX_K_UTR3SINGLE: case AUGX_K_UTR3TERM: endP = j == n - 1 ? 0.0 : B.usig[(X.o + 1 + boep) * NUSIG + USIG_TTSP]; break;
+    default: break; // RUTR3SINGLE, RUTR3INIT: the gate was the reverse stop codon
+    }
+    if (T.soft && eobe < j && endP > AUGX_NINF &&
+        (kind == AUGX_K_UTR5INIT || kind == AUGX_K_UTR5INTERNAL || kind == AUGX_K_UTR3INIT || kind == AUGX_K_UTR3INTERNAL)) {
+        const int a = eobe + 1 < 0 ? 0 : eobe + 1;
+        endP = endP + (double)(int64_t)((uint64_t)X.cntS(CNT_SOFT, j) - (uint64_t)X.cntS(CNT_SOFT, a - 1)) * T.lnSoft;
+    }
+    if (T.soft && boep < 1 && endP > AUGX_NINF && eobe < j &&
+        (kind == AUGX_K_RUTR5INTERNAL || kind == AUGX_K_RUTR5TERM || kind == AUGX_K_RUTR3INTERNAL || kind == AUGX_K_RUTR3TERM)) {
+        const int a = eobe + 1 < 0 ? 0 : eobe + 1;
+        endP = endP + (double)(int64_t)((uint64_t)X.cntS(CNT_SOFT, j) - (uint64_t)X.cntS(CNT_SOFT, a - 1)) * T.lnSoft;
+    }
+    D.endP = endP;
+    if (!(endP > AUGX_NINF) || rm < lm) return;
+    D.E = endP + X.pfx(g.fxf, D.eom);
+    // listed candidates: the sites of the kind's list whose predecessor end lies in [lm, rm]
+    int sLo, sHi, fld = 0; // site positions (in the list's own coordinate) of the window
+    bool ownCnt = true;
+    switch (g.list) {
+    case UL_TF: sLo = (lm + 1 < 0 ? 0 : lm + 1); sHi = rm + 1; fld = UCNT_TF; break;                   // by window begin = eop + 1
+    case UL_LA: sLo = lm + T.U + assWhole; sHi = rm + T.U + assWhole; fld = CNT_LA; ownCnt = false; break; // by longass end
+    case UL_FS: sLo = lm; sHi = rm; fld = UCNT_FS; break;
+    case UL_LR: sLo = lm + T.Ds + 2 + T.De; sHi = rm + T.Ds + 2 + T.De; fld = CNT_LR; ownCnt = false; break;
+    case UL_TM: sLo = (lm < 0 ? 0 : lm) + 1 + T.dpc; sHi = rm + 1 + T.dpc; fld = UCNT_TM; break;       // by box begin = eop + 1 + dc
+    default: sLo = lm; sHi = rm; fld = UCNT_RT;
+    }
+    if (sHi >= sLo && sHi >= 0) {
+        const int64_t i0 = ownCnt ? (int64_t)X.cntU(fld, sLo - 1) : (int64_t)X.cntS(fld, sLo - 1);
+        D.i1 = (int32_t)(ownCnt ? X.cntU(fld, sHi) : X.cntS(fld, sHi));
+        D.nList = (int)((int64_t)D.i1 - i0);
+        if (D.nList < 0) D.nList = 0;
+    }
+    // candidates that are not sites of a list: truncated begins before the piece (TF, TM) and the start from column 0 (FS, RT)
+    if (g.list == UL_TF) { const int hi = rm < -2 ? rm : -2; if (hi >= lm) { D.nExtra = hi - lm + 1; D.xHi = hi; } }
+    else if (g.list == UL_TM) { const int hi = rm < -1 ? rm : -1; if (hi >= lm) { D.nExtra = hi - lm + 1; D.xHi = hi; } }
+    else if (g.list == UL_FS || g.list == UL_RT) { if (lm <= 0 && rm >= 0) { D.nExtra = 1; D.xHi = 0; } }
+    D.total = D.nList + D.nExtra;
+}
+AUGX_HD double utrLenAt(const DevTables &T, int sel, int len, bool tail3) {
+    if (len < 0) return AUGX_NINF;
+    if (tail3) return len <= T.uM3S ? AUGX_GTAB(T.tail3s)[len] : AUGX_NINF;
+    switch (sel) {
+    case 0: return len <= T.uML ? AUGX_GTAB(T.len5s)[len] : AUGX_NINF;
+    case 1: return len <= T.uML ? AUGX_GTAB(T.len5i)[len] : AUGX_NINF;
+    case 2: return len <= T.uML ? AUGX_GTAB(T.len5n)[len] : AUGX_NINF;
+    case 3: return len <= T.uML ? AUGX_GTAB(T.len5t)[len] : AUGX_NINF;
+    case 4: return len <= T.uM3S ? AUGX_GTAB(T.len3s)[len] : AUGX_NINF;
+    case 5: return len <= T.uML ? AUGX_GTAB(T.len3i)[len] : AUGX_NINF;
+    case 6: return len <= T.uML ? AUGX_GTAB(T.len3n)[len] : AUGX_NINF;
+    default: return len <= T.uM3T ? AUGX_GTAB(T.len3t)[len] : AUGX_NINF;
+    }
+}
+// single-base middle part: SegProbs::getSeqProb with from == to reads the table of the class CURRENT at the time, i.e. of the end
+// base j of the state (src/statemodel.cc:437-449)
+AUGX_HD double utrEmi1(const UCtx &X, int fxf, int cj, int pos) {
+    const DevTables &T = X.T;
+    const double *tab = AUGX_GTAB(fxf <= UFX_5IR ? T.utr5init_emi : fxf <= UFX_5R ? T.utr5_emi : T.utr3_emi) + (int64_t)cj * T.NP;
+    const bool fwd = (fxf & 1) == 0;
+    const uint8_t *code = X.B.code + X.o + 1;
+    auto bb = [&](int q) -> int { return (q >= 0 && q < X.n) ? code[q] : 4; };
+    int r = 0;
+    if (fwd) {
+        if (pos < T.k) return T.ln_quarter;
+        for (int i = 0; i <= T.k; i++) { const int c = bb(pos - T.k + i); if (c > 3) return T.ln_quarter; r = (r << 2) | c; }
+    } else
+        for (int i = 0; i <= T.k; i++) { const int c = bb(pos + i); if (c > 3) return T.ln_quarter; r |= (3 - c) << (2 * i); }
+    return tab[r];
+}
+// candidate idx (0 = the largest predecessor end) of the state described by D: te = ln emission of the state from eop + 1 to j
+// (without the transition term), eop = end of the predecessor.  false: infeasible
+AUGX_HD bool utrCand(const UCtx &X, const UDesc &D, int idx, double &te, int &eop) {
+    const DevTables &T = X.T;
+    const int n = X.n;
+    double bmix, braw = 0.0; // (begin signal) - (content prefix before the middle part); the begin signal alone
+    bool haveRaw = false;
+    if (idx < D.nList) {
+        const USite e = X.list(D.list)[D.i1 - 1 - idx];
+        eop = e.pos;
+        bmix = D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2];
+    } else {
+        eop = D.xHi - (idx - D.nList);
+        const int begin = eop + 1, bom = begin + D.cb;
+        // part of the begin signal lies before the piece (:1190-1194,1206-1210,1304-1311,1385-1389); a start from column 0
+        // of a state without begin signal
+        if (D.list == UL_TF) braw = (bom - 1) * T.ln_quarter;
+        else if (D.list == UL_TM) braw = (D.kind == AUGX_K_RUTR3TERM || bom > 0) ? (bom - 1) * T.ln_quarter : 0.0;
+        else braw = 0.0;
+        haveRaw = true;
+        bmix = braw - X.pfx(D.fxf, bom - 1);
+    }
+    if (!(bmix > AUGX_NINF)) return false;
+    const int begin = eop + 1, bom = begin + D.cb, mlen = D.eom - bom + 1;
+    double sig; // begin part + middle part + end part
+    if (mlen > 1) sig = bmix + D.E;
+    else {
+        if (!haveRaw) braw = bmix + X.pfx(D.fxf, bom - 1);
+        double mp;
+        if (mlen == 1) mp = utrEmi1(X, D.fxf, X.clsAt(D.j), D.eom);
+        else if (mlen == 0) mp = 0.0;
+        else mp = D.ovl == 1 ? -mlen * T.ln2 : D.ovl == 2 ? -mlen * T.ln4 : 0.0;
+        sig = (braw + mp) + D.endP;
+    }
+    const int bobe = begin + D.cbobe, len = D.eobe - bobe + 1;
+    bool tail3 = false;
+    if ((D.kind == AUGX_K_UTR3SINGLE || D.kind == AUGX_K_UTR3TERM) && D.eobe == n - 1) tail3 = true; // right-truncated 3' UTR (:1290-1295,1369-1372)
+    if (D.kind == AUGX_K_RUTR3SINGLE && begin <= 0) tail3 = true;                                     // left-truncated (:1312)
+    const double lp = utrLenAt(T, D.len, len, tail3);
+    if (!(lp > AUGX_NINF)) return false;
+    te = sig + lp;
+    return te > AUGX_NINF;
+}
+
+// =================================================================================================
+// the state graph as the dense kernels see it
+// =================================================================================================
+constexpr int DCH = 16;   // chain-state slots (intergenic, geometric introns, UTR introns)
+constexpr int DFIX = 24;  // fixed-lag states
+constexpr int DUV = 16;   // exon-like UTR states
+AUGX_HD bool isChainKind(int k) { return k == AUGX_K_IGENIC || k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC || isUtrIntronKind(k); }
+AUGX_HD bool isEarlyChainKind(int k) { return k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC; }
+AUGX_HD bool isFixedKind(int k) { return k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS || k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS || k == AUGX_K_EQUALD || k == AUGX_K_REQUALD; }
+AUGX_HD bool isItemKind(int k) { return (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD; }
+AUGX_HD double initLn(const DevTables &T, int initKind, int s) { return initKind == 0 ? T.ln_init[s] : (s == T.synch ? 0.0 : AUGX_NINF); }
+
+struct DenseLds {
+    double ring[WAVE][SPX];          // the newest 64 columns, [j & 63][state]
+    double cmax[8][SPX];             // variable-length cells of the block: largest candidate ...
+    unsigned long long csum[8][SPX]; // ... (forward) sum of exp(candidate - largest), fixed point
+    double tr[SPX][AUGX_MAX_ANC];    // ln t(ancestor ai -> s) of the piece's first class
+    uint8_t anc[SPX][AUGX_MAX_ANC], nanc[SPX];
+    uint8_t cellKind[SPX];           // 1: candidates from the records of kCand, 2: reverse terminal exon, 3: UTR exon, 0: none
+    double sg[2][8][NSIG];           // signal records of the block ([parity]; the next block's are staged meanwhile)
+    uint64_t gate[2][8];             // end gates of the block's bases
+    uint64_t bOff[2];
+    uint32_t bCnt[2][2];
+    int chS[DCH], chNa[DCH], chAnc[DCH][AUGX_MAX_ANC], chNd[DCH], chDead[DCH][AUGX_MAX_ANC], chDeadAi[DCH][AUGX_MAX_ANC];
+    uint8_t chLive[DCH][AUGX_MAX_ANC], chEarly[DCH];
+    double oth[DCH][8];              // [slot][base of the block]: what reaches the chain state from the other states
+    uint8_t othAi[DCH][8];
+    int uvS[DUV], nUv;               // the exon-like UTR states
+    UDesc ud[8 * DUV];               // descriptors of the block's (base, UTR exon state) pairs
+    int udPre[8 * DUV + 1];          // inclusive prefix of their candidate counts
+};
+
+// value of state a at base q for the block that begins at jb: from the ring while no base of the block has taken its column
+template <bool FWD> AUGX_KFN double denseAt(const DenseLds &L, const double *M, int S, int q, int a, int jb, int BLK) {
+    if (q < 0) q = 0;
+    if (jb + BLK - 1 - q < WAVE) return ldsLoadD(&L.ring[q & 63][a]);
+    return ldCoherent(&M[(int64_t)q * S + a]);
+}
+
+// One workgroup walks piece p block by block.  MODE 0: Viterbi (ln V into B.cells, back pointers of the chain / fixed-lag
+// states into B.bpD, score and final state of the piece); MODE 1: forward algorithm (ln F into B.fwd, ln P(sequence)).
+template <int BLK, int MODE>
+AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, int p) {
+    constexpr bool FWD = MODE == 1;
+    const int n = B.len[p], S = T.S, c0 = B.cls[p];
+    const int64_t o = B.off[p];
+    double *M = (FWD ? B.fwd : B.cells) + (o + 1) * S;
+    uint8_t *BP = B.bpD ? B.bpD + (o + 1) * S : nullptr;
+    const double *gSig = B.sig + (o + 1) * NSIG;
+    const uint64_t *gGate = B.gate + o + 1;
+    const Item *gItems = B.items;
+    const uint64_t *gBlkOff = B.blkOff;
+    const uint32_t *gBlkCnt = B.blkCnt, *gBlkSplit = B.blkSplit;
+    const uint8_t *gPlane = B.gcPlane + o + 1;
+    const int32_t *gPlaneCls = B.planeCls + p * MAXPL;
+    const int initKind = B.initKind[p], termKind = B.termKind[p], synch = T.synch;
+    if (c0 < 0) { FOR_THREADS(t) { if (t == 0) { if (FWD) B.lnFwd[p] = AUGX_NINF; else { B.lnv[p] = AUGX_NINF; B.status[p] = AUGX_E_HIP; B.finalState[p] = -1; } } } return; }
+    const bool multi = B.nPlanes[p] > 1;
+    const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U, dL = T.dStateLen;
+    auto clsAt = [&](int j) __attribute__((always_inline)) { return multi ? (int)gp(gPlaneCls)[gp(gPlane)[j]] : c0; };
+    const double *gTrans = T.ln_trans;
+    // ln t(a -> s2), a = ancestor ai of s2, with the class of the end base
+    auto trn = [&](int cc, int s2, int ai) __attribute__((always_inline)) -> double {
+        if (multi) return gp(gTrans)[((int64_t)cc * S + (*lp(&L.anc[s2][ai]))) * S + s2];
+        return ldsLoadD(&L.tr[s2][ai]);
+    };
+    UCtx UX(T, B, p);
+    bool anyNuc = false;
+    // ---- tables of the state graph in LDS; the matrix starts empty
+    FOR_THREADS(t) {
+        for (int i = t; i < WAVE * SPX; i += NT) (*lp(&L.ring[i / SPX][i % SPX])) = AUGX_NINF;
+        if (t < SPX) {
+            const int k = t < S && T.reachable[t] ? T.kind[t] : -1;
+            (*lp(&L.cellKind[t])) = k < 0 ? 0 : k == AUGX_K_RTERMINAL ? 2 : isItemKind(k) ? 1 : isUtrExonKind(k) ? 3 : 0;
+            (*lp(&L.nanc[t])) = (uint8_t)(t < S ? T.n_anc[t] : 0);
+            for (int ai = 0; ai < AUGX_MAX_ANC; ai++) {
+                const int a = (t < S && ai < T.n_anc[t]) ? T.anc[t][ai] : 0;
+                (*lp(&L.anc[t][ai])) = (uint8_t)a;
+                (*lp(&L.tr[t][ai])) = (t < S && ai < T.n_anc[t]) ? lnT(T, c0, a, t) : AUGX_NINF;
+            }
+        }
+        for (int64_t i = t; i < (int64_t)n * S; i += NT) gp(M)[i] = AUGX_NINF; // (absent cells stay -inf)
+        if (!FWD && BP) for (int64_t i = t; i < (int64_t)n * S; i += NT) gp(BP)[i] = 0xFF;
+    }
+    for (int q = 0; q < n && !anyNuc; q++) anyNuc = B.code[o + 1 + q] < 4; // (uniform; the pieces that are all N are rare and short-circuited below)
+    BLOCK_GLOBAL_SYNC();
+    FOR_THREADS(t) { // column 0 = initial probabilities (reference NAMGene::setStatesInitialProbs, src/namgene.cc:144-150)
+        if (t < S) {
+            const double v = initLn(T, initKind, t);
+            (*lp(&L.ring[0][t])) = v;
+            gp(M)[t] = v;
+        }
+    }
+    BLOCK_GLOBAL_SYNC();
+    // ---- the states by role (uniform)
+    int fixS[DFIX], nFix = 0, chS[DCH], nCh = 0, nEarly = 0, uvS[DUV], nUv = 0;
+    for (int s2 = 0; s2 < S; s2++) {
+        if (!T.reachable[s2]) continue;
+        const int k = T.kind[s2];
+        if (isFixedKind(k)) { if (nFix < DFIX) fixS[nFix++] = s2; }
+        else if (isEarlyChainKind(k)) { if (nCh < DCH) chS[nCh++] = s2; }
+    }
+    nEarly = nCh;
+    for (int s2 = 0; s2 < S; s2++) {
+        if (!T.reachable[s2]) continue;
+        const int k = T.kind[s2];
+        if (isChainKind(k) && !isEarlyChainKind(k)) { if (nCh < DCH) chS[nCh++] = s2; }
+        else if (isUtrExonKind(k)) { if (nUv < DUV) uvS[nUv++] = s2; }
+    }
+    if (!anyNuc) { // all N: everything is intergenic (reference src/namgene.cc:205-226); one thread, column after column
+        FOR_THREADS(t) {
+            if (t == 0) {
+                double v = initLn(T, initKind, synch);
+                for (int j = 1; j < n; j++) { v = v - T.ln4; gp(M)[(int64_t)j * S + synch] = v; if (!FWD && BP) gp(BP)[(int64_t)j * S + synch] = 0xFE; }
+                const double tl = termKind == 0 ? T.ln_term[synch] : 0.0;
+                if (FWD) B.lnFwd[p] = v + tl;
+                else { B.lnv[p] = v + tl; B.finalState[p] = (v + tl) > AUGX_NINF ? synch : -1; B.status[p] = (v + tl) > AUGX_NINF ? 0 : AUGX_E_NOPATH; }
+            }
+        }
+        return;
+    }
+    const int nBlocks = (n + BLK - 1) / BLK;
+    const int64_t gb0 = o / BLK;
+    // per-thread constants of the fixed-lag step (thread = (state, base of the block))
+    TV(int, fS2); TV(int, fLag); TV(int, fSg);
+    FOR_THREADS(t) {
+        TX(fS2) = -1; TX(fLag) = 1; TX(fSg) = 0;
+        if (t >= WAVE && t - WAVE < nFix * BLK) {
+            const int s2 = fixS[(t - WAVE) / BLK], k = T.kind[s2];
+            TX(fS2) = s2;
+            TX(fLag) = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
+            TX(fSg) = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
+        }
+        if (t < DCH) {
+            const int s2 = t < nCh ? chS[t] : -1;
+            (*lp(&L.chS[t])) = s2;
+            const int na = s2 >= 0 ? T.n_anc[s2] : 0;
+            (*lp(&L.chNa[t])) = na;
+            (*lp(&L.chEarly[t])) = t < nEarly;
+            int nd = 0;
+            for (int ai = 0; ai < AUGX_MAX_ANC; ai++) {
+                const int a = ai < na ? T.anc[s2][ai] : 0;
+                // an ancestor that is a chain state of the same stage is made in the same run (as a rule only the state itself)
+                const bool live = ai < na && isChainKind(T.kind[a]) && (isEarlyChainKind(T.kind[a]) == (t < nEarly));
+                (*lp(&L.chAnc[t][ai])) = a;
+                (*lp(&L.chLive[t][ai])) = live;
+                if (ai < na && !live) { (*lp(&L.chDead[t][nd])) = a; (*lp(&L.chDeadAi[t][nd])) = ai; nd++; }
+            }
+            for (int k2 = nd; k2 < AUGX_MAX_ANC; k2++) { (*lp(&L.chDead[t][k2])) = 0; (*lp(&L.chDeadAi[t][k2])) = 0; }
+            (*lp(&L.chNd[t])) = nd;
+        }
+        if (t < DUV) (*lp(&L.uvS[t])) = t < nUv ? uvS[t] : -1;
+        if (t == 0) (*lp(&L.nUv)) = nUv;
+    }
+    constexpr int NTW = NT - WAVE;
+    FOR_THREADS(t) { // block 0: offsets, signal records, gates
+        if (t == NT - 1) { (*lp(&L.bOff[0])) = gp(gBlkOff)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][0])) = gp(gBlkCnt)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][1])) = gp(gBlkSplit)[gb0 * 3 + 2]; }
+        if (t >= NT - BLK * NSIG) { const int i = t - (NT - BLK * NSIG); (*lp(&L.sg[0][i / NSIG][i % NSIG])) = i / NSIG < n ? gp(gSig)[(int64_t)(i / NSIG) * NSIG + i % NSIG] : AUGX_NINF; }
+        if (t < BLK) (*lp(&L.gate[0][t])) = t < n ? gp(gGate)[t] : 0ull;
+    }
+    BLOCK_SYNC();
+    // what reaches chain slot `slot` at base jb + dj from the states that are not made in its own run
+    auto chainOthers = [&](int slot, int dj, int jb, int par) __attribute__((always_inline)) {
+        const int s2 = (*lp(&L.chS[slot])), j = jb + dj;
+        double f = AUGX_NINF;
+        int fa = 0xFF;
+        if (s2 >= 0 && j >= 1 && j < n) {
+            const double emi = (*lp(&L.sg[par][dj][T.kind[s2] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN]));
+            const int cc = clsAt(j), nd = (*lp(&L.chNd[slot]));
+            double x[AUGX_MAX_ANC], m = AUGX_NINF;
+            int fin = 0;
+            for (int k2 = 0; k2 < AUGX_MAX_ANC; k2++) {
+                x[k2] = AUGX_NINF;
+                if (k2 < nd) {
+                    const int a = (*lp(&L.chDead[slot][k2])), ai = (*lp(&L.chDeadAi[slot][k2]));
+                    const double pv = ldsLoadD(&L.ring[(j - 1) & 63][a]);
+                    if (pv > AUGX_NINF) x[k2] = pv + (trn(cc, s2, ai) + emi);
+                    if (x[k2] > m) { m = x[k2]; fa = ai; } // (ascending ancestors, strict '>': the first of equals, as the reference)
+                    fin += x[k2] > AUGX_NINF;
+                }
+            }
+            f = m;
+            if (FWD && fin > 1) {
+                double sum = 0.0;
+                for (int k2 = 0; k2 < AUGX_MAX_ANC; k2++) sum += x[k2] > AUGX_NINF ? exp(x[k2] - m) : 0.0;
+                f = m + log(sum);
+            }
+        }
+        (*lp(&L.oth[slot][dj])) = f;
+        (*lp(&L.othAi[slot][dj])) = (uint8_t)fa;
+    };
+    // the chain state of `slot` over the bases of the block: itself (and the other chain states of its stage) from the base before
+    auto chainRun = [&](int slot, int jb, int par) __attribute__((always_inline)) {
+        const int s2 = (*lp(&L.chS[slot]));
+        if (s2 < 0) return;
+        const int na = (*lp(&L.chNa[slot])), sgi = T.kind[s2] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
+        for (int dj = 0; dj < BLK; dj++) {
+            const int j = jb + dj;
+            if (j >= n || j < 1) continue;
+            const int cc = clsAt(j);
+            const double emi = (*lp(&L.sg[par][dj][sgi]));
+            double f = (*lp(&L.oth[slot][dj]));
+            int fa = (*lp(&L.othAi[slot][dj]));
+            for (int ai = 0; ai < na; ai++) {
+                if (!(*lp(&L.chLive[slot][ai]))) continue;
+                const int a = (*lp(&L.chAnc[slot][ai]));
+                const double pv = ldsLoadD(&L.ring[(j - 1) & 63][a]);
+                if (!(pv > AUGX_NINF)) continue;
+                const double x = pv + (trn(cc, s2, ai) + emi);
+                if (FWD) f = lse2(f, x);
+                else if (x > f || (x == f && ai < fa)) { f = x; fa = ai; }
+            }
+            (*lp(&L.ring[j & 63][s2])) = f;
+            if (f > AUGX_NINF) { gp(M)[(int64_t)j * S + s2] = f; if (!FWD && BP) gp(BP)[(int64_t)j * S + s2] = (uint8_t)fa; }
+        }
+    };
+    for (int b = 0; b < nBlocks; b++) {
+        const int jb = b * BLK, par = b & 1;
+        const int64_t gb = gb0 + b;
+        // ---- A: fixed-lag states; accumulators of the variable-length cells; the next block's offsets, signal records, gates
+        FOR_THREADS(t) {
+            for (int i = t; i < BLK * SPX; i += NT) { (*lp(&L.cmax[i / SPX][i % SPX])) = AUGX_NINF; (*lp(&L.csum[i / SPX][i % SPX])) = 0ull; }
+            if (t == NT - 1 && b + 1 < nBlocks) {
+                (*lp(&L.bOff[par ^ 1])) = gp(gBlkOff)[(gb + 1) * 2 + 1]; (*lp(&L.bCnt[par ^ 1][0])) = gp(gBlkCnt)[(gb + 1) * 2 + 1]; (*lp(&L.bCnt[par ^ 1][1])) = gp(gBlkSplit)[(gb + 1) * 3 + 2];
+            }
+            if (b + 1 < nBlocks && t >= NT - BLK * NSIG) {
+                const int i = t - (NT - BLK * NSIG), dj = i / NSIG, j = jb + BLK + dj;
+                (*lp(&L.sg[par ^ 1][dj][i % NSIG])) = j < n ? gp(gSig)[(int64_t)j * NSIG + i % NSIG] : AUGX_NINF;
+            }
+            if (b + 1 < nBlocks && t < BLK) { const int j = jb + BLK + t; (*lp(&L.gate[par ^ 1][t])) = j < n ? gp(gGate)[j] : 0ull; }
+            if (TX(fS2) >= 0) {
+                const int s2 = TX(fS2), dj = (t - WAVE) % BLK, j = jb + dj;
+                if (j >= 1 && j < n) {
+                    const int lag = TX(fLag);
+                    const double emi = (*lp(&L.sg[par][dj][TX(fSg)]));
+                    double f = AUGX_NINF;
+                    int fa = 0xFF;
+                    if (j - lag >= 0 && emi > AUGX_NINF) {
+                        const int cc = clsAt(j), na = (*lp(&L.nanc[s2]));
+                        for (int ai = 0; ai < na; ai++) {
+                            const double pv = denseAt<FWD>(L, M, S, j - lag, (*lp(&L.anc[s2][ai])), jb, BLK);
+                            if (!(pv > AUGX_NINF)) continue;
+                            const double x = pv + (trn(cc, s2, ai) + emi);
+                            if (FWD) f = lse2(f, x);
+                            else if (x > f) { f = x; fa = ai; }
+                        }
+                    }
+                    (*lp(&L.ring[j & 63][s2])) = f;
+                    if (f > AUGX_NINF) { gp(M)[(int64_t)j * S + s2] = f; if (!FWD && BP) gp(BP)[(int64_t)j * S + s2] = (uint8_t)fa; }
+                }
+            }
+        }
+        BLOCK_SYNC();
+        // ---- B: early chain states (geometric introns: fed by the fixed-lag states of the base before and by themselves)
+        FOR_THREADS(t) { if (t >= WAVE && t - WAVE < nEarly * BLK) chainOthers((t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
+        BLOCK_SYNC();
+        FOR_THREADS(t) { if (t < nEarly) chainRun(t, jb, par); }
+        BLOCK_SYNC();
+        // ---- C / E: candidates of the variable-length states.  C: the records of kCand but RTERMINAL, and the UTR exon states
+        //      (their candidates are evaluated here); E: RTERMINAL (it may start from a cell of its own block)
+        const uint64_t i0 = (*lp(&L.bOff[par]));
+        const uint32_t cntAll = (*lp(&L.bCnt[par][0])), cntNonRT = (*lp(&L.bCnt[par][1]));
+        auto candValue = [&](const Item &I, int &dj, int &s2) __attribute__((always_inline)) -> double {
+            dj = (int)(I.kp >> (KEY_BITS + 7)); s2 = (int)((I.kp >> KEY_BITS) & 127);
+            if (!(I.te > AUGX_NINF)) return AUGX_NINF;
+            const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
+            const double pv = denseAt<FWD>(L, M, S, eop, (int)(I.src & 127u), jb, BLK);
+            return pv + I.te;
+        };
+        auto itemPass = [&](uint32_t lo2, uint32_t hi2, bool sumPass) __attribute__((always_inline)) {
+            FOR_THREADS(t) {
+                for (uint32_t it = lo2 + (uint32_t)(t - WAVE); t >= WAVE && it < hi2; it += NTW) {
+                    int dj, s2;
+                    const double v = candValue(ldItem(gItems + i0 + it), dj, s2);
+                    if (!(v > AUGX_NINF)) continue;
+                    if (!sumPass) ldsMaxD(&L.cmax[dj][s2], v);
+                    else ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - (*lp(&L.cmax[dj][s2]))) * FWD_FIX));
+                }
+            }
+        };
+        // the UTR exon candidates of the block: descriptors of the open (base, state) pairs, then every candidate by one thread
+        auto utrPass = [&](bool sumPass) __attribute__((always_inline)) {
+            const int total = (*lp(&L.udPre[BLK * DUV]));
+            FOR_THREADS(t) {
+                for (int it = t - WAVE; t >= WAVE && it < total; it += NTW) {
+                    int pos = 0; // the pair of candidate `it`: the number of pairs whose candidates end at or before it
+                    for (int step = 128; step >= 1; step >>= 1)
+                        if (pos + step <= BLK * DUV && (*lp(&L.udPre[pos + step])) <= it) pos += step;
+                    const UDesc D = L.ud[pos];
+                    double te; int eop;
+                    if (!utrCand(UX, D, it - (*lp(&L.udPre[pos])), te, eop)) continue;
+                    const int s2 = D.s, dj = D.j - jb, cc = clsAt(D.j), na = (*lp(&L.nanc[s2]));
+                    for (int ai = 0; ai < na; ai++) {
+                        const double pv = denseAt<FWD>(L, M, S, eop, (*lp(&L.anc[s2][ai])), jb, BLK);
+                        if (!(pv > AUGX_NINF)) continue;
+                        const double v = pv + (trn(cc, s2, ai) + te);
+                        if (!sumPass) ldsMaxD(&L.cmax[dj][s2], v);
+                        else ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - (*lp(&L.cmax[dj][s2]))) * FWD_FIX));
+                    }
+                }
+            }
+        };
+        auto cells = [&](int kindMask) __attribute__((always_inline)) { // the cells of the states whose cellKind is in the mask
+            FOR_THREADS(t) {
+                for (int i = t - WAVE; t >= WAVE && i < BLK * SPX; i += NTW) {
+                    const int dj = i / SPX, s2 = i % SPX, j = jb + dj;
+                    if (j >= 1 && j < n && ((kindMask >> (*lp(&L.cellKind[s2]))) & 1)) {
+                        double f = (*lp(&L.cmax[dj][s2]));
+                        if (FWD) f = (*lp(&L.csum[dj][s2])) > 0ull ? f + log((double)(*lp(&L.csum[dj][s2])) / FWD_FIX) : AUGX_NINF;
+                        (*lp(&L.ring[j & 63][s2])) = f;
+                        if (f > AUGX_NINF) gp(M)[(int64_t)j * S + s2] = f;
+                    }
+                }
+            }
+            BLOCK_SYNC();
+        };
+        FOR_THREADS(t) { // descriptors
+            if (t >= WAVE && t - WAVE < BLK * DUV) {
+                const int u = t - WAVE, dj = u / DUV, slot = u % DUV, j = jb + dj, s2 = (*lp(&L.uvS[slot]));
+                UDesc D;
+                D.total = 0; D.s = (int16_t)(s2 < 0 ? 0 : s2); D.j = j;
+                if (s2 >= 0 && j >= 1 && j < n && (((*lp(&L.gate[par][dj])) >> T.vbit[s2]) & 1ull)) utrDescribe(UX, s2, j, D);
+                L.ud[u] = D;
+            }
+        }
+        BLOCK_SYNC();
+        FOR_THREADS(t) { if (t == 0) { int acc = 0; (*lp(&L.udPre[0])) = 0; for (int u = 0; u < BLK * DUV; u++) { acc += L.ud[u].total; (*lp(&L.udPre[u + 1])) = acc; } } }
+        BLOCK_SYNC();
+        itemPass(0, cntNonRT, false);
+        utrPass(false);
+        BLOCK_SYNC();
+        if (FWD) { itemPass(0, cntNonRT, true); utrPass(true); BLOCK_SYNC(); }
+        cells((1 << 1) | (1 << 3));
+        // ---- D: late chain states (intergenic, UTR introns: fed by the exon cells of the base before and by themselves)
+        FOR_THREADS(t) { if (t >= WAVE && t - WAVE < (nCh - nEarly) * BLK) chainOthers(nEarly + (t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
+        BLOCK_SYNC();
+        FOR_THREADS(t) { if (t < nCh - nEarly) chainRun(nEarly + t, jb, par); }
+        BLOCK_SYNC();
+        // ---- E: reverse terminal exons
+        itemPass(cntNonRT, cntAll, false);
+        BLOCK_SYNC();
+        if (FWD) { itemPass(cntNonRT, cntAll, true); BLOCK_SYNC(); }
+        cells(1 << 2);
+        // the columns of this block reach HBM before any later block reads them from there (the ring covers 64 bases)
+        if (((b + 1) * BLK) % 32 == 0) BLOCK_GLOBAL_SYNC();
+    }
+    BLOCK_SYNC();
+    FOR_THREADS(t) { // termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-462; getSampledPath :385-392)
+        if (t == 0) {
+            double tot = AUGX_NINF;
+            int fin = -1;
+            for (int i = 0; i < S; i++) {
+                const double tl = termKind == 0 ? T.ln_term[i] : (i == synch ? 0.0 : AUGX_NINF);
+                const double v = (*lp(&L.ring[(n - 1) & 63][i])) + tl;
+                if (!(v > AUGX_NINF)) continue;
+                if (FWD) tot = lse2(tot, v);
+                else if (v > tot) { tot = v; fin = i; }
+            }
+            if (FWD) B.lnFwd[p] = tot;
+            else { B.lnv[p] = tot; B.finalState[p] = fin; B.status[p] = fin >= 0 ? 0 : AUGX_E_NOPATH; }
+        }
+    }
+}
+
+// =================================================================================================
+// back-tracking over the dense matrix (reference NAMGene::getViterbiPath, src/namgene.cc:467-506): chain and fixed-lag states
+// follow their stored ancestor; a variable-length state takes the arg-max over its candidates again (records of kCand, or the
+// UTR site list), same additions, ties to the larger predecessor end, then to the ancestor of lower index
+// =================================================================================================
+AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p) {
+    const int n = B.len[p], S = T.S;
+    const int64_t o = B.off[p];
+    const int64_t po = pathOff(B, p), cap = pathCap(B, p);
+    const double *M = B.cells + (o + 1) * S;
+    const uint8_t *BP = B.bpD + (o + 1) * S;
+    int state = B.finalState[p], base = n - 1, count = 0;
+    bool overflow = false;
+    if (state < 0 || B.status[p] != 0) { FOR_LANES(l) { if (l == 0) B.pathCount[p] = 0; } return; }
+    const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U;
+    UCtx UX(T, B, p);
+    auto colOf = [&](int eop) { return eop > 0 ? eop : 0; };
+    while (base > 0) {
+        const int kind = T.kind[state];
+        int eop, ai;
+        if (isChainKind(kind)) {
+            int selfAi = -1;
+            for (int i = 0; i < T.n_anc[state]; i++) if (T.anc[state][i] == state) selfAi = i;
+            int cur = base, w = 0xFF;
+            for (;;) { // the first base <= cur whose predecessor is not the state itself: 4 bases per lane, 256 per step
+                LV(int, flag); LV(int, wv); LV(int, hit);
+                FOR_LANES(l) {
+                    LX(flag) = 0; LX(wv) = -1; LX(hit) = 4;
+                    for (int k = 3; k >= 0; k--) {
+                        const int q = cur - 4 * l - k;
+                        const int ww = q >= 1 ? (int)BP[(int64_t)q * S + state] : -1;
+                        if (q < 1 || ww != selfAi) { LX(flag) = 1; LX(wv) = ww; LX(hit) = k; }
+                    }
+                }
+                const int first = waveFirstTrue(flag);
+                if (first < WAVE) {
+#ifdef AUGX_EMU
+                    const int hk = hit[first], hw = wv[first];
+#else
+                    const int hk = __shfl(hit[0], first, 64), hw = __shfl(wv[0], first, 64);
+#endif
+                    cur -= 4 * first + hk;
+                    w = cur >= 1 ? hw : 0xFF;
+                    break;
+                }
+                cur -= 4 * WAVE;
+            }
+            if (cur < 1) { eop = 0; ai = -1; }
+            else if (w == 0xFE) { eop = 0; ai = -1; } // (a piece of N only: intergenic from the first base)
+            else { eop = cur - 1; ai = w; }
+        } else if (isFixedKind(kind)) {
+            ai = BP[(int64_t)base * S + state];
+            if (ai == 0xFF) { overflow = true; break; }
+            eop = base - ((kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? dssWhole : (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? assLag : T.dStateLen);
+        } else if (isUtrExonKind(kind)) {
+            UDesc D;
+            utrDescribe(UX, state, base, D);
+            const int cc = UX.clsAt(base);
+            Best best{AUGX_NINF, -2147483647, -1};
+            for (int c0 = 0; c0 < D.total; c0 += WAVE) {
+                LV(double, cv); LV(int, ck); LV(int, ca);
+                FOR_LANES(l) {
+                    LX(cv) = AUGX_NINF; LX(ck) = -2147483647; LX(ca) = -1;
+                    double te; int e2;
+                    if (c0 + l < D.total && utrCand(UX, D, c0 + l, te, e2))
+                        for (int a2 = 0; a2 < T.n_anc[state]; a2++) { // (ascending, strict '>': the ancestor of lower index wins a tie)
+                            const double pv = M[(int64_t)colOf(e2) * S + T.anc[state][a2]];
+                            if (!(pv > AUGX_NINF)) continue;
+                            const double v = pv + (lnT(T, cc, T.anc[state][a2], state) + te);
+                            if (v > LX(cv)) { LX(cv) = v; LX(ck) = e2 + KEY_BIAS; LX(ca) = a2; }
+                        }
+                }
+                const Best b2 = waveArgMax(cv, ck, ca);
+                if (better(b2.v, b2.key, best.v, best.key)) best = b2;
+            }
+            if (!(best.v > AUGX_NINF)) { overflow = true; break; }
+            ai = best.aux; eop = best.key - KEY_BIAS;
+        } else {
+            const int blkSz = B.blk;
+            const int64_t gb = o / blkSz + base / blkSz;
+            const uint64_t i0 = B.blkOff[gb * 2 + 1];
+            const uint32_t cnt = B.blkCnt[gb * 2 + 1], pid = (uint32_t)(((base % blkSz) << 7) | state);
+            Best best{AUGX_NINF, -2147483647, -1};
+            for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
+                LV(double, cv); LV(int, ck); LV(int, ca);
+                FOR_LANES(l) {
+                    LX(cv) = AUGX_NINF; LX(ck) = -2147483647; LX(ca) = -1;
+                    const uint32_t it = c0 + (uint32_t)l;
+                    if (it < cnt) {
+                        const Item I = B.items[i0 + it];
+                        if ((I.kp >> KEY_BITS) == pid && I.te > AUGX_NINF) {
+                            const int e2 = (int)(I.kp & KEY_MASK) - KEY_BIAS, a = (int)(I.src & 127u);
+                            const double pv = M[(int64_t)colOf(e2) * S + a];
+                            if (pv > AUGX_NINF) {
+                                int a2 = 0;
+                                for (int i = 0; i < T.n_anc[state]; i++) if (T.anc[state][i] == a) a2 = i;
+                                // (key: the predecessor end, then the ancestor of LOWER index among equals)
+                                LX(cv) = pv + I.te; LX(ck) = (e2 + KEY_BIAS) * AUGX_MAX_ANC + (AUGX_MAX_ANC - 1 - a2); LX(ca) = a2;
+                            }
+                        }
+                    }
+                }
+                const Best b2 = waveArgMax(cv, ck, ca);
+                if (better(b2.v, b2.key, best.v, best.key)) best = b2;
+            }
+            if (!(best.v > AUGX_NINF)) { overflow = true; break; }
+            ai = best.aux; eop = best.key / AUGX_MAX_ANC - KEY_BIAS;
+        }
+        if (count >= cap) { overflow = true; break; }
+        FOR_LANES(l) { if (l == 0) { int32_t *r = B.pathRec + (po + count) * 3; r[0] = eop + 1; r[1] = base; r[2] = state; } }
+        count++;
+        base = eop;
+        if (ai < 0 || ai >= T.n_anc[state]) { if (base > 0) overflow = true; break; }
+        state = T.anc[state][ai];
+    }
+    FOR_LANES(l) { if (l == 0) { B.pathCount[p] = count; if (overflow) B.status[p] = AUGX_E_HIP; } }
+}
+
+} // namespace dev
+} // namespace augx

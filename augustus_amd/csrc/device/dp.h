@@ -32,6 +32,13 @@ namespace dev {
 
 constexpr int WAVE = 64;
 constexpr int SP = 48;          // column stride of the trellis storage (S <= SP)
+constexpr int SPX = AUGX_MAX_STATES; // column stride bound of the dense kernels (dense.h: models with UTR states, S = 71)
+constexpr int NUFX = 6;         // UTR content prefix fields: 5' single/initial fwd, rev; 5' internal/terminal fwd, rev; 3' fwd, rev
+constexpr int UFX_5IF = 0, UFX_5IR = 1, UFX_5F = 2, UFX_5R = 3, UFX_3F = 4, UFX_3R = 5;
+constexpr int NUCNT = 4;        // UTR site counts: forward TSS windows, forward stop codons, reverse poly-A boxes, reverse start codons
+constexpr int UCNT_TF = 0, UCNT_FS = 1, UCNT_TM = 2, UCNT_RT = 3;
+constexpr int NUSIG = 4;        // per-base UTR signal record: tssProb fwd (window begins here), tssProb rev (window ends here), ttsProbPlus / Minus (box begins here)
+constexpr int USIG_TSSF = 0, USIG_TSSR = 1, USIG_TTSP = 2, USIG_TTSM = 3;
 constexpr int NFX = 20;         // fixed-point prefix fields per slot: [strand 2][phase 3][table 3], inF, inR
 constexpr int FX_INF = 18, FX_INR = 19;
 constexpr int NSIG = 10;        // per-position signal record: eIg eIn dssF dssR assF assR tisF tisR eqD stopF
@@ -82,6 +89,9 @@ struct SegDesc {
 // one possible start of a short intron (entry of the LD / RD candidate lists): everything a lessD candidate needs of it,
 // in one 16-byte record (position, the two bases before the splice site, intron-content prefix at the position)
 struct IntronStart { int32_t pos; uint32_t ctx; uint64_t fx; };
+// one possible begin of a UTR exon (entry of the TF / LA / FS / LR / TM / RT site lists, dense.h): the end of the predecessor state
+// and, per content model that can follow, (ln begin signal) - (content prefix before the first base of the middle part)
+struct USite { int32_t pos; int32_t pad; double b[3]; };
 // flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
@@ -94,6 +104,14 @@ struct DevTables {
     double ln_startcodon[64];
     double ln_stop_ochre, ln_stop_amber, ln_stop_opal, ln_quarter, ln_n_coding, ln4, ass_pat_invalid;
     double gc_zus[AUGX_MAX_CLASSES][4], gc_weight_matrix[16];
+    // untranslated regions (include/augx.h: the utr block of augx_tables)
+    int utr, tss_upwin, tss_start, tss_end, tata_start, tata_end, d_tss_tata_min, d_tss_tata_max, dpc, boxlen, tts_spacing;
+    int uML, uM3S, uM3T, tssup_k, tss_n, tss_k, tsstata_n, tsstata_k, tata_n, tata_k, tts_n, tts_k;
+    double ln_tts_rand, ln2;
+    const double *utr5init_emi, *utr5_emi, *utr3_emi, *tssup_emi, *tss_motif, *tsstata_motif, *tata_motif, *tts_motif, *aataaa,
+        *len5s, *len5i, *len5n, *len5t, *len3s, *len3i, *len3n, *len3t, *tail5s, *tail3s;
+    int dense;                 // the model is decoded by the dense kernels (dense.h)
+    int vbit[AUGX_MAX_STATES]; // bit of a variable-length state in the end-gate mask (the state index itself while S <= 64)
     const double *ln_trans, *ig_emi, *ig_short, *in_emi, *ex_emi, *ex_init, *ex_et, *ex_pls, *tis_motif, *ass_motif,
         *tis_bin_bounds, *tis_bin_ln, *ass_pat, *dss_pat, *len_intron, *len_single, *len_initial, *len_internal,
         *len_terminal;
@@ -133,6 +151,12 @@ struct BatchView {
     uint64_t *gate;            // [N] bit s: variable-length state s passes its end gate at this base
     int32_t *site;             // [N][4] list index of the splice-site candidate ending here (LA, LR, LD, RD) or -1
     uint64_t *chunkTot;        // scratch [nChunks][NFX]
+    // untranslated regions (dense.h; allocated for models with UTR states only)
+    uint64_t *ufx;             // [N][NUFX] fixed-point prefix sums of the UTR content models; the term of a base comes from the class OF THAT BASE
+    uint32_t *ucnt;            // [N][NUCNT] prefix counts of the UTR begin sites
+    double *usig;              // [N][NUSIG]
+    USite *tfSite, *laSite, *fsSite, *lrSite, *tmSite, *rtSite; // [listCap] begin-site lists (laSite / lrSite run parallel to laPos / lrPos)
+    uint8_t *bpD;              // [N][S] back pointers of the chain and fixed-lag states (ancestor index, 0xFF: none)
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
     uint8_t *bpChain;          // [N][8] the back pointers of the (at most 8) single-base chain states once more, one byte each, in
@@ -189,6 +213,9 @@ struct BatchView {
 };
 
 AUGX_HD int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
+AUGX_HD bool isUtrIntronKind(int k) { return k == AUGX_K_UTR5INTRON || k == AUGX_K_UTR3INTRON || k == AUGX_K_RUTR5INTRON || k == AUGX_K_RUTR3INTRON; }
+AUGX_HD bool isUtrIntronVarKind(int k) { return k == AUGX_K_UTR5INTRONVAR || k == AUGX_K_UTR3INTRONVAR || k == AUGX_K_RUTR5INTRONVAR || k == AUGX_K_RUTR3INTRONVAR; }
+AUGX_HD bool isUtrExonKind(int k) { return k >= AUGX_K_UTR5SINGLE && k <= AUGX_K_RUTR3TERM && !isUtrIntronKind(k) && !isUtrIntronVarKind(k); }
 // scan-field arrays (cnt, nsm, fx) are stored chunk-major, field-major inside a chunk: [chunk][field][CHUNK],
 // so that the prefix scans stream contiguous rows.  g = global slot, f = field, nf = fields per slot.
 AUGX_HD int64_t fidx(int64_t g, int f, int nf) { return ((g / CHUNK) * nf + f) * CHUNK + (g % CHUNK); }
@@ -594,6 +621,43 @@ AUGX_HD bool lessDGate(const Piece &P, bool fwd, int j) {
     int eobi = fwd ? j + t.U + t.As + 2 : j + t.De + 2;
     if (eobi - 2 + 1 < P.n - 1) return fwd ? P.possASS(eobi) : P.possRDSS(eobi);
     return true;
+}
+
+// ---- exon-like UTR states (reference UtrModel::viterbiForwardAndSampling, src/utrmodel.cc)
+// window [lm, rm] of predecessor ends (:822-916, with the clamps of :941-952)
+AUGX_HD void utrWindow(const DevTables &T, int kind, int j, int n, int &lm, int &rm) {
+    const int W = T.W, U = T.U, up = T.tss_upwin, te = T.tss_end, dc = T.dpc, bl = T.boxlen, assWhole = T.As + 2 + T.Ae, dssWhole = T.Ds + 2 + T.De;
+    const int ML = T.uML, M3S = T.uM3S, M3T = T.uM3T;
+    switch (kind) {
+    case AUGX_K_UTR5SINGLE: lm = j - (ML - W + up); rm = j - up - te - 1 + W + te; if (rm > j - 1) rm = j - 1; break;
+    case AUGX_K_RUTR5SINGLE: lm = j - (ML - W + up); rm = j - up - 1 + W; if (rm > j - 1) rm = j - 1; break;
+    case AUGX_K_UTR5INIT: case AUGX_K_RUTR5INIT: lm = j - (ML + 2 + T.De + up); rm = j - up - te - dssWhole; break;
+    case AUGX_K_UTR5INTERNAL: case AUGX_K_RUTR5INTERNAL: case AUGX_K_UTR3INTERNAL: case AUGX_K_RUTR3INTERNAL:
+        lm = j - (ML + 2 + T.De + U + T.As + 2); rm = j - dssWhole - U - assWhole; break;
+    case AUGX_K_UTR5TERM: case AUGX_K_RUTR5TERM:
+        lm = j - (ML - W + U + T.As + 2); rm = j - U - assWhole;
+        if (-U - assWhole + W + T.Ae < 0) rm = j - U - assWhole + W + T.Ae;
+        break;
+    case AUGX_K_UTR3SINGLE: lm = j - M3S; rm = j != n - 1 ? j - dc - bl : j - 1; break;
+    case AUGX_K_RUTR3SINGLE: lm = j - M3S; rm = j - dc - bl; break;
+    case AUGX_K_UTR3INIT: case AUGX_K_RUTR3INIT: lm = j - (ML + 2 + T.De); rm = j - T.De - 2; break;
+    case AUGX_K_UTR3TERM: lm = j - (M3T + 2 + T.As + U); rm = j != n - 1 ? j - dc - bl - assWhole - U : j - assWhole - U; break;
+    default: lm = j - (M3T + 2 + T.As + U); rm = j - dc - bl - assWhole - U;
+    }
+    if (kind == AUGX_K_UTR5SINGLE || kind == AUGX_K_UTR5INIT) { if (lm < -up) lm = -up; }
+    else if (kind == AUGX_K_RUTR3SINGLE || kind == AUGX_K_RUTR3TERM) { if (lm < -bl - dc) lm = -bl - dc; }
+    else if (lm < 0) lm = 0;
+}
+// smallest distance j - rm of any UTR exon kind: the block size of the dense kernels must not exceed it
+AUGX_HD int utrMinLag(const DevTables &T) {
+    int m = 1 << 30;
+    for (int kind = AUGX_K_UTR5SINGLE; kind <= AUGX_K_RUTR3TERM; kind++) {
+        if (!isUtrExonKind(kind)) continue;
+        int lm, rm;
+        utrWindow(T, kind, 100000, 1 << 29, lm, rm);
+        if (100000 - rm < m) m = 100000 - rm;
+    }
+    return m;
 }
 
 } // namespace dev

@@ -363,7 +363,7 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g, const 
             case AUGX_K_RLESSD: open = rlessOpen; break;
             default: break;
             }
-            if (open) gate |= 1ull << s;
+            if (open) gate |= 1ull << T.vbit[s];
         }
     }
     B.gate[g] = gate;
@@ -532,8 +532,8 @@ __device__ inline int waveMin(const int *v, int) {
 AUGX_HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 
 // per-state constants of the variable-length states
-struct VarConst {
-    int kind, win, nanc, anc[4], ancWin[4];
+struct VarConst { // indexed by the state's bit in the end-gate mask (DevTables::vbit; the state index itself while S <= 64)
+    int kind, win, nanc, anc[4], ancWin[4], state;
     double tr[MAXPL_LDS][4]; // ln transition probability from each ancestor, per plane of the piece (the first MAXPL_LDS planes)
     ExGeom g;
 };
@@ -553,7 +553,7 @@ AUGX_HD uint32_t srcCol0(int ai, int a) { return (SRC_COL0 << 30) | ((uint32_t)a
 
 AUGX_HD void fillVarConst(const DevTables &T, const BatchView &B, int p, int l, VarConst &VC) {
     const int kind = T.kind[l];
-    VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4;
+    VC.kind = kind; VC.win = T.win[l]; VC.nanc = T.n_anc[l] < 4 ? T.n_anc[l] : 4; VC.state = l;
     const int nPl = B.cls[p] < 0 ? 0 : B.nPlanes[p];
     for (int ai = 0; ai < 4; ai++) {
         int a = ai < VC.nanc ? T.anc[l][ai] : 0;
@@ -630,7 +630,10 @@ struct CandCtx {
 };
 
 // descriptor of state s ending at base j: candidate range and end-side constants
-template <bool MULTI>
+// (s: the state's index in X.vc = its bit in the end-gate mask.  DENSE: the candidates go to the dense kernels of dense.h -- a
+//  candidate names its predecessor by state, and a state whose predecessors are not told apart by the reading frame has one
+//  candidate per predecessor end AND ancestor)
+template <bool MULTI, bool DENSE = false>
 AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
     const DevTables &T = X.T;
     const Piece &P = X.P; // (sequence, stop tables and signal records only: nothing class-dependent is read through it here)
@@ -724,6 +727,7 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
         D.extra = e.startMin == 0 ? 1 : 0; // bs = 0: left-truncated exon, predecessor column 0
     }
     D.total = D.nList + D.extra;
+    if (DENSE && D.listSel >= 4) D.total *= VC.nanc;
 }
 
 // candidate number idx (0 = newest) of the state described by D: te = ln(transition * emission) (-inf: infeasible),
@@ -733,7 +737,7 @@ AUGX_KFN void varDescribe(const CandCtx &X, int s, int j, VarDesc &D) {
 // together, a wavefront full at a time, instead of stalling 63 lanes of every chunk for the one lane that needs it
 // ONLY: 0 every kind, 1 short introns (lessD) only, 2 exon states only -- the caller has sorted the candidates by kind, the other
 // kind's code is not even compiled into that call
-template <bool MULTI, bool FASTONLY = false, int ONLY = 0>
+template <bool MULTI, bool FASTONLY = false, int ONLY = 0, bool DENSE = false>
 AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int idx, double &te, int &key, uint32_t &src, bool &needSlow) {
     needSlow = false;
     const DevTables &T = X.T;
@@ -743,7 +747,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
     const Piece P = X.pieceAt(pl); // (class-dependent reads of the general paths go through the plane of the end base)
     const ExGeom &Dg = VC.g;
     // (a piece rarely has more than MAXPL_LDS classes: those planes read the model's transition table)
-    auto trOf = [&](int ai) -> double { return pl < MAXPL_LDS ? VC.tr[pl][ai] : lnT(T, B.planeCls[X.p * MAXPL + pl], VC.anc[ai], s); };
+    auto trOf = [&](int ai) -> double { return pl < MAXPL_LDS ? VC.tr[pl][ai] : lnT(T, B.planeCls[X.p * MAXPL + pl], VC.anc[ai], VC.state); };
     te = AUGX_NINF; key = 0; src = srcCol0(0, 0);
     if (ONLY != 2 && (kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD)) {
         // written without early exits so that the loads of one candidate are all in flight together: the list entry
@@ -758,7 +762,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         e.pos = 0; e.ctx = 0x44; e.fx = 0;
         if (listed) e = ldIntronStart((D.listSel == 2 ? B.ldEnt : B.rdEnt) + X.pL(pl) + li);
         const int eop = e.pos;
-        const uint32_t sr = listed ? srcList(0, D.listSel, f, li) : srcCol0(0, VC.anc[0]);
+        const uint32_t sr = DENSE ? (uint32_t)VC.anc[0] : listed ? srcList(0, D.listSel, f, li) : srcCol0(0, VC.anc[0]);
         const int begin = eop + 1;
         const int bobi = fwd ? begin - T.De - 2 : begin - (T.U + T.As + 2);
         int bM1 = (int)(e.ctx & 15), bM2 = (int)((e.ctx >> 4) & 15);
@@ -797,8 +801,10 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         return;
     }
     if (ONLY == 1) return;
-    if (D.listSel >= 4) { // predecessor is the igenic state
-        const int a = VC.anc[0];
+    if (D.listSel >= 4) { // predecessor is the igenic state (with UTR states: the 5' / 3' UTR states next to the gene)
+        const int aiD = DENSE ? idx % VC.nanc : 0;
+        if (DENSE) idx /= VC.nanc;
+        const int a = VC.anc[aiD];
         int bs;
         double tisF = AUGX_NINF;
         double cPls = 0.0, cInit = 0.0;
@@ -815,6 +821,8 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         // eop == j reads the igenic cell of the CURRENT column (already final: the reference fills states in index
         // order and igenic is state 0); later columns do not exist yet
         if (!(eop < n && eop <= j)) return;
+        // (dense kernels: a cell of the CURRENT column exists only for a state of lower index that is made before the candidates)
+        if (DENSE && eop == j && !(T.kind[a] == AUGX_K_IGENIC && a < VC.state)) return;
         double nep;
         const int m = D.right - bs, k = T.k;
         const int bob = bs - Dg.ipo, len = D.eob - bob + 1;
@@ -858,9 +866,9 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
 #endif
         if (!fast) nep = exNotEndPart(P, kind, win, bs, D.right, D.fOR, Dg, tisF);
         if (!(nep > AUGX_NINF)) return;
-        te = (trOf(0) + D.endP) + nep;
+        te = (trOf(aiD) + D.endP) + nep;
         key = eop + KEY_BIAS;
-        src = eop <= 0 ? srcCol0(0, a) : srcVig(0, eop);
+        src = DENSE ? (uint32_t)a : eop <= 0 ? srcCol0(0, a) : srcVig(0, eop);
         return;
     }
     // predecessors are the three longass_f (forward) or rlongdss_f (reverse) states, listed per splice site
@@ -919,7 +927,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         if (win != mod3(fwd ? VC.ancWin[ai] + len : VC.ancWin[ai] - len)) continue;
         te = (trOf(ai) + D.endP) + nep;
         key = bs - Dg.bpl - 1 + KEY_BIAS;
-        src = li >= 0 ? srcList(ai, D.listSel, VC.ancWin[ai], li) : srcCol0(ai, VC.anc[ai]);
+        src = DENSE ? (uint32_t)VC.anc[ai] : li >= 0 ? srcList(ai, D.listSel, VC.ancWin[ai], li) : srcCol0(ai, VC.anc[ai]);
         break;
     }
 }
@@ -931,8 +939,8 @@ AUGX_HD void varMasks(const DevTables &T, uint64_t &maskVar, uint64_t &maskRT) {
     for (int s2 = 0; s2 < T.S; s2++) {
         if (!T.reachable[s2]) continue;
         const int kind = T.kind[s2];
-        if (kind == AUGX_K_RTERMINAL) maskRT |= 1ull << s2;
-        else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) maskVar |= 1ull << s2;
+        if (kind == AUGX_K_RTERMINAL) maskRT |= 1ull << T.vbit[s2];
+        else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) maskVar |= 1ull << T.vbit[s2];
     }
 }
 
@@ -954,7 +962,7 @@ struct CandAlloc { unsigned long long pairs, items; };
 //   reserve: one atomic add per tile hands out the range; the per-block tables (first candidate, counts) are written
 //   pass 2: evaluate and store the candidates, 64 at a time; note the pair boundaries nearest to 1/3 and 2/3 of each
 //           block's candidates (three trellis wavefronts share them)
-template <int BLK, bool MULTI>
+template <int BLK, bool MULTI, bool DENSE = false>
 AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk0, uint64_t maskLess, uint64_t maskVar, uint64_t maskRT) {
     constexpr int NB = WAVE / BLK;
     static_assert(NB <= MAXNB && DCAP >= WAVE, "tile layout");
@@ -1015,7 +1023,7 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
             if (l < nPr) {
                 const int dj = L.pairJ[w][l], s2 = L.pairS[w][l];
                 VarDesc D;
-                varDescribe<MULTI>(X, s2, j0 + dj, D);
+                varDescribe<MULTI, DENSE>(X, s2, j0 + dj, D);
                 if (r0 + l < DCAP) L.desc[w][r0 + l] = D;
                 ldsAdd(&L.cntItems[w][dj / BLK], (uint32_t)D.total);
                 if (!((maskRT >> s2) & 1)) ldsAdd(&L.cntNonRT[w][dj / BLK], (uint32_t)D.total);
@@ -1083,7 +1091,7 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
             const int l = t & 63;
             TX(tot) = 0;
             if (l < nPr) {
-                if (r0 + l >= DCAP) varDescribe<MULTI>(X, L.pairS[w][l], j0 + L.pairJ[w][l], L.desc[w][l]);
+                if (r0 + l >= DCAP) varDescribe<MULTI, DENSE>(X, L.pairS[w][l], j0 + L.pairJ[w][l], L.desc[w][l]);
                 TX(tot) = L.desc[w][r0 + l < DCAP ? r0 + l : l].total;
             }
         }
@@ -1109,12 +1117,13 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
             const int dj = L.pairJ[w][q], s2 = L.pairS[w][q];
             double te; int key; uint32_t src;
             bool needSlow;
-            varEvalItem<MULTI, MODE == 2, MODE>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - first, te, key, src, needSlow);
+            varEvalItem<MULTI, MODE == 2, MODE, DENSE>(X, s2, j0 + dj, L.desc[w][r0 + q < DCAP ? r0 + q : q], it - first, te, key, src, needSlow);
             if (needSlow) return true;
             if (key < 0 || !(te > AUGX_NINF)) { te = AUGX_NINF; key = 0; }
             else if (key - KEY_BIAS < TX(mnEop)) TX(mnEop) = key - KEY_BIAS;
             Item I;
-            I.te = te; I.kp = ((uint32_t)(((dj % BLK) << 6) | s2) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
+            // (the pair id carries the state: 6 bits of it while S <= 64, 7 in the records of the dense kernels)
+            I.te = te; I.kp = ((uint32_t)(DENSE ? (((dj % BLK) << 7) | X.vc[s2].state) : (((dj % BLK) << 6) | s2)) << KEY_BITS) | ((uint32_t)key & KEY_MASK); I.src = src;
             B.items[itemBase + itemsDone + it] = I;
             return false;
         };
@@ -1206,7 +1215,7 @@ AUGX_KFN void candTile(const CandCtx &X, CandLds &L, int w, int j0, int64_t gblk
 
 // one workgroup = NWAVES consecutive tiles of 64 bases (they belong to one piece: a chunk of CHUNK slots never spans
 // pieces), one tile per wavefront; the wavefronts share the per-state constants and nothing else
-template <int BLK, bool MULTI>
+template <int BLK, bool MULTI, bool DENSE = false>
 AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, int64_t wg) {
     constexpr int NB = WAVE / BLK;
     static_assert(CHUNK % (NWAVES * WAVE) == 0, "tiles of a workgroup lie in one chunk");
@@ -1216,7 +1225,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 #if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     uint64_t cp0 = clock64(), cp1;
 #endif
-    FOR_THREADS(t) { if (t < SP && t < T.S) fillVarConst(T, B, p, t, L.vc[t]); }
+    FOR_THREADS(t) { if (t < T.S && T.vbit[t] < SP) fillVarConst(T, B, p, t, L.vc[T.vbit[t]]); }
     const int cLo = (int)(gtile0 * WAVE - B.off[p] - 1) - WAVE; // first staged base
     FOR_THREADS(t) {
         for (int i = t; i < NWAVES * WAVE + 2 * WAVE; i += NT) {
@@ -1231,11 +1240,11 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
     varMasks(T, maskVar, maskRT);
     uint64_t maskLess = 0;
     for (int s2 = 0; s2 < X.S; s2++)
-        if (L.vc[s2].kind == AUGX_K_LESSD || L.vc[s2].kind == AUGX_K_RLESSD) maskLess |= 1ull << s2;
+        if (T.kind[s2] == AUGX_K_LESSD || T.kind[s2] == AUGX_K_RLESSD) maskLess |= 1ull << T.vbit[s2];
     maskLess &= maskVar;
     FOR_WAVES(w) {
         const int64_t gtile = gtile0 + w;
-        candTile<BLK, MULTI>(X, L, w, (int)(gtile * WAVE - X.o), gtile * NB, maskLess, maskVar, maskRT);
+        candTile<BLK, MULTI, DENSE>(X, L, w, (int)(gtile * WAVE - X.o), gtile * NB, maskLess, maskVar, maskRT);
     }
 #if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     cp1 = clock64();

@@ -273,9 +273,55 @@ inline void checkModelSupported(const augx_tables &t, int BLK) {
     if (nFixed > 24 || nVar > 32 || nChain > 8) throw std::runtime_error("augx: state graph too large for the trellis wavefront layout");
 }
 
+// models decoded by the dense kernels (dense.h): everything the wavefront layout of the trellis kernel was not built for
+inline bool modelIsDense(const augx_tables &t) { return t.utr != 0; }
+// block size of the dense kernels (dense.h): no variable-length or fixed-lag state may read a cell of its own block but through
+// the stage order of densePiece (fixed-lag states, early chains, candidates, late chains, reverse terminal exons)
+inline int chooseDenseBlock(const augx_tables &t) {
+    if (t.S > SPX) throw std::runtime_error("augx: too many states");
+    const int dssWhole = t.Ds + 2 + t.De, assLag = t.As + 2 + t.Ae + t.U, dL = t.d - 2 - t.De - t.As - 2 - t.U;
+    int lag = dssWhole < assLag ? dssWhole : assLag;
+    if (dL < lag) lag = dL;
+    int slack = t.W + t.min_exon_len - t.Ds; // single / initial exons reach back to their predecessor at least this far
+    if (t.W < slack) slack = t.W;
+    if (slack < lag) lag = slack;
+    if (t.utr) {
+        DevTables D;
+        memset(&D, 0, sizeof D);
+        D.W = t.W; D.U = t.U; D.As = t.As; D.Ae = t.Ae; D.Ds = t.Ds; D.De = t.De; D.tss_upwin = t.tss_upwin; D.tss_end = t.tss_end;
+        D.dpc = t.d_polyasig_cleavage; D.boxlen = t.aataaa_boxlen; D.uML = t.utr_max_exon_len; D.uM3S = t.utr_max3single; D.uM3T = t.utr_max3term;
+        const int ul = utrMinLag(D);
+        if (ul < lag) lag = ul;
+        if (t.tss_upwin + 2 > KEY_BIAS || t.aataaa_boxlen + t.d_polyasig_cleavage + 2 > KEY_BIAS) throw std::runtime_error("augx: UTR signal windows too long for the candidate keys");
+    }
+    int nChain = 0, nFix = 0, nUv = 0;
+    for (int s = 0; s < t.S; s++) {
+        if (!t.reachable[s]) continue;
+        const int k = t.state_kind[s];
+        const bool chain = k == AUGX_K_IGENIC || k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC || isUtrIntronKind(k);
+        const bool fixed = k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS || k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS || k == AUGX_K_EQUALD || k == AUGX_K_REQUALD;
+        nChain += chain; nFix += fixed; nUv += isUtrExonKind(k);
+        for (int a = 0; a < t.n_anc[s]; a++) {
+            const int ak = t.state_kind[t.anc[s][a]];
+            // the early chains (geometric introns) run before the candidates of their block
+            if ((k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC) && t.anc[s][a] != s &&
+                !(ak == AUGX_K_LONGDSS || ak == AUGX_K_RLONGDSS || ak == AUGX_K_LONGASS || ak == AUGX_K_RLONGASS || ak == AUGX_K_EQUALD || ak == AUGX_K_REQUALD))
+                throw std::runtime_error("augx: geometric intron state fed by a state that is not a fixed-length intron state");
+            if (chain && ak == AUGX_K_RTERMINAL) throw std::runtime_error("augx: single-base state fed by the reverse terminal exon state");
+        }
+    }
+    if (nChain > 16 || nFix > 24 || nUv > 16) throw std::runtime_error("augx: state graph too large for the dense kernels");
+    int b = 8;
+    if (const char *e = getenv("AUGX_BLK")) b = atoi(e);
+    while (b > 1 && b > lag) b /= 2;
+    if (b < 2) throw std::runtime_error("augx: signal windows too short for the dense kernels");
+    return b;
+}
+
 // block size of the candidate / trellis kernels for this model: 8 where the species' windows allow it, else 4 or 2
 // (override for tests: AUGX_BLK=4).  Throws what checkModelSupported throws for the smallest size.
 inline int chooseBlockSize(const augx_tables &t) {
+    if (modelIsDense(t)) return chooseDenseBlock(t);
     if (const char *e = getenv("AUGX_BLK")) {
         const int b = atoi(e);
         if (b != 8 && b != 4 && b != 2) throw std::runtime_error("augx: AUGX_BLK must be 8, 4 or 2");
@@ -303,6 +349,21 @@ inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
     D.tis_n = t.tis_n; D.tis_k = t.tis_k; D.ass_n = t.ass_n; D.ass_k = t.ass_k; D.tis_nbins = t.tis_nbins; D.tis_mem = t.tis_mem;
     D.synch = t.synch_state; D.gc_win = t.gc_win; D.gc_weighing_type = t.gc_weighing_type;
     D.soft = t.softmasking; D.lnSoft = t.ln_soft_bonus;
+    D.utr = t.utr; D.tss_upwin = t.tss_upwin; D.tss_start = t.tss_start; D.tss_end = t.tss_end; D.tata_start = t.tata_start; D.tata_end = t.tata_end;
+    D.d_tss_tata_min = t.d_tss_tata_min; D.d_tss_tata_max = t.d_tss_tata_max; D.dpc = t.d_polyasig_cleavage; D.boxlen = t.aataaa_boxlen;
+    D.tts_spacing = t.tts_spacing; D.uML = t.utr_max_exon_len; D.uM3S = t.utr_max3single; D.uM3T = t.utr_max3term; D.tssup_k = t.tssup_k;
+    D.tss_n = t.tss_n; D.tss_k = t.tss_k; D.tsstata_n = t.tsstata_n; D.tsstata_k = t.tsstata_k; D.tata_n = t.tata_n; D.tata_k = t.tata_k;
+    D.tts_n = t.tts_n; D.tts_k = t.tts_k; D.ln_tts_rand = t.ln_tts_rand; D.ln2 = t.ln2;
+    D.dense = modelIsDense(t);
+    {   // end-gate bits of the variable-length states: the state index while it fits a 64-bit mask, else a compact numbering
+        int nb = 0;
+        for (int s = 0; s < t.S; s++) {
+            const int k = t.state_kind[s];
+            const bool var = (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD || isUtrExonKind(k);
+            D.vbit[s] = t.S <= 64 ? s : (var ? nb++ : 63);
+        }
+        if (nb > SP) throw std::runtime_error("augx: more than 48 variable-length states");
+    }
     for (int s = 0; s < t.S; s++) {
         D.kind[s] = t.state_kind[s]; D.win[s] = t.state_win[s]; D.type[s] = t.state_type[s]; D.reachable[s] = t.reachable[s];
         D.n_anc[s] = t.n_anc[s];
@@ -341,6 +402,20 @@ inline std::vector<TableSpan> tableSpans(const augx_tables &t, DevTables &D) {
     v.push_back({t.len_initial, t.max_exon_len + 1, &D.len_initial});
     v.push_back({t.len_internal, t.max_exon_len + 1, &D.len_internal});
     v.push_back({t.len_terminal, t.max_exon_len + 1, &D.len_terminal});
+    if (t.utr) {
+        v.push_back({t.utr5init_emi, C * NP, &D.utr5init_emi}); v.push_back({t.utr5_emi, C * NP, &D.utr5_emi}); v.push_back({t.utr3_emi, C * NP, &D.utr3_emi});
+        v.push_back({t.tssup_emi, C * ((int64_t)1 << (2 * (t.tssup_k + 1))), &D.tssup_emi});
+        v.push_back({t.tss_motif, C * t.tss_n * ((int64_t)1 << (2 * (t.tss_k + 1))), &D.tss_motif});
+        v.push_back({t.tsstata_motif, C * t.tsstata_n * ((int64_t)1 << (2 * (t.tsstata_k + 1))), &D.tsstata_motif});
+        v.push_back({t.tata_motif, C * t.tata_n * ((int64_t)1 << (2 * (t.tata_k + 1))), &D.tata_motif});
+        v.push_back({t.tts_motif, C * t.tts_n * ((int64_t)1 << (2 * (t.tts_k + 1))), &D.tts_motif});
+        v.push_back({t.aataaa, (int64_t)1 << (2 * t.aataaa_boxlen), &D.aataaa});
+        v.push_back({t.len5_single, t.utr_max_exon_len + 1, &D.len5s}); v.push_back({t.len5_initial, t.utr_max_exon_len + 1, &D.len5i});
+        v.push_back({t.len5_internal, t.utr_max_exon_len + 1, &D.len5n}); v.push_back({t.len5_terminal, t.utr_max_exon_len + 1, &D.len5t});
+        v.push_back({t.len3_single, t.utr_max3single + 1, &D.len3s}); v.push_back({t.len3_initial, t.utr_max_exon_len + 1, &D.len3i});
+        v.push_back({t.len3_internal, t.utr_max_exon_len + 1, &D.len3n}); v.push_back({t.len3_terminal, t.utr_max3term + 1, &D.len3t});
+        v.push_back({t.tail5_single, t.utr_max_exon_len + 1, &D.tail5s}); v.push_back({t.tail3_single, t.utr_max3single + 1, &D.tail3s});
+    }
     return v;
 }
 

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../../augustus_amd/csrc/device/kernels.h"
+#include "../../augustus_amd/csrc/device/dense.h"
 #include "../../augustus_amd/csrc/device/layout.h"
 #include "../../augustus_amd/csrc/device/sampler.h"
 #include "../../augustus_amd/csrc/device/snipmemo.h"
@@ -40,6 +41,182 @@ static int g_nsamples = 0;
 static augx_rand *g_rand = nullptr;
 static std::vector<std::vector<std::vector<augx_state>>> g_samples;
 
+
+// ---- models decoded by the dense kernels (device/dense.h: the 71-state model with UTR states): the same prep kernels, the UTR
+//      prefix / signal / site-list kernels, the candidate records of kCand in their dense form, densePiece, denseBacktracePiece
+static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int n, double *lnv, int32_t *status, int32_t *path_out,
+                            int32_t path_cap, int32_t *path_n, double *cells_out, int32_t *cls_out, double *fwd_out, double *lnfwd_out) {
+    int blk = 4;
+    try {
+        blk = chooseDenseBlock(*t);
+    } catch (std::exception &e) {
+        fprintf(stderr, "emu: %s\n", e.what());
+        return AUGX_E_UNSUPPORTED;
+    }
+    DevTables T;
+    try { fillDevTablesScalars(*t, T); } catch (std::exception &e) { fprintf(stderr, "emu: %s\n", e.what()); return AUGX_E_UNSUPPORTED; }
+    for (auto &sp : tableSpans(*t, T)) *sp.dst = sp.src;
+    BatchLayout L;
+    L.build(pieces, n);
+    BatchSizes Z(L);
+    BatchView B;
+    memset(&B, 0, sizeof B);
+    B.nPieces = n; B.N = L.N; B.nChunks = L.nChunks;
+    B.off = L.off.data(); B.len = L.len.data(); B.initKind = L.initKind.data(); B.termKind = L.termKind.data();
+    B.chunkPiece = L.chunkPiece.data();
+    std::vector<int32_t> cls(n, -1), clsMM(2 * n);
+    B.cls = cls.data(); B.clsMinMax = clsMM.data();
+    std::vector<void *> bufs;
+    auto za = [&](int64_t count, size_t elem) { void *p = calloc((size_t)(count > 0 ? count : 1), elem); bufs.push_back(p); return p; };
+    char *raw = (char *)za(Z.N, 1);
+    for (int p = 0; p < n; p++) memcpy(raw + L.off[p] + 1, pieces[p].seq, (size_t)L.len[p]);
+    B.raw = raw;
+    B.code = (uint8_t *)za(Z.N, 1);
+    B.cnt = (uint32_t *)za(Z.N * NCNT, 4);
+    B.nsm = (uint32_t *)za(Z.N * 6, 4);
+    B.sig = (double *)za(Z.N * NSIG, 8);
+    B.gate = (uint64_t *)za(Z.N, 8);
+    B.site = (int32_t *)za(Z.N * NSITE, 4);
+    B.cells = (double *)za(Z.N * t->S, 8);
+    B.bpD = (uint8_t *)za(Z.N * t->S, 1);
+    B.gcRaw = (uint8_t *)za(Z.N, 1); B.gcPlane = (uint8_t *)za(Z.N, 1);
+    B.ufx = (uint64_t *)za(Z.N * NUFX, 8); B.ucnt = (uint32_t *)za(Z.N * NUCNT, 4); B.usig = (double *)za(Z.N * NUSIG, 8);
+    std::vector<int32_t> nPlanes(n, 1), planeCls((size_t)n * MAXPL, 0);
+    B.nPlanes = nPlanes.data(); B.planeCls = planeCls.data();
+    B.nPl = 1;
+    std::vector<int32_t> listCnt(n);
+    std::vector<int64_t> listOffs;
+    B.listCnt = listCnt.data();
+    std::vector<double> lnvv(n);
+    std::vector<int32_t> st(n), fin(n), pc(n);
+    B.lnv = lnvv.data(); B.status = st.data(); B.finalState = fin.data(); B.pathCount = pc.data();
+    B.pathRec = (int32_t *)za(Z.pathCap * 3, 4);
+    for (int64_t g = 0; g < B.N; g++) k1Encode(B, g);
+    for (int64_t g = 0; g < B.N; g++) k1SiteTerms(T, B, g);
+    scanFields<false>(B.cnt, NCNT, L);
+    scanFields<true>(B.nsm, 6, L);
+    for (int p = 0; p < n; p++) { clsMM[2 * p] = 1 << 30; clsMM[2 * p + 1] = -1; }
+    for (int64_t g = 0; g < B.N; g++) {
+        int c = k1WindowClass(T, B, g);
+        if (c >= 0) {
+            int p = B.chunkPiece[g / CHUNK];
+            if (c < clsMM[2 * p]) clsMM[2 * p] = c;
+            if (c > clsMM[2 * p + 1]) clsMM[2 * p + 1] = c;
+        }
+    }
+    for (int p = 0; p < n; p++) {
+        cls[p] = clsMM[2 * p] == clsMM[2 * p + 1] ? clsMM[2 * p] : -1;
+        planeCls[(size_t)p * MAXPL] = cls[p];
+        if (cls[p] < 0) {
+            std::vector<uint8_t> plane;
+            const int np = stairsPlanes(B.gcRaw + L.off[p] + 1, L.len[p], t->gc_win, plane, &planeCls[(size_t)p * MAXPL]);
+            if (np < 0) continue;
+            cls[p] = planeCls[(size_t)p * MAXPL];
+            nPlanes[p] = np;
+            if (np > 1) memcpy(B.gcPlane + L.off[p] + 1, plane.data(), (size_t)L.len[p]);
+            if (np > B.nPl) B.nPl = np;
+        }
+    }
+    // UTR content prefix sums and site counts (one scan), then the list sizes
+    for (int64_t g = 0; g < B.N; g++) k1UtrTerms(T, B, g);
+    scanFields<false>(B.ufx, NUFX, L);
+    scanFields<false>(B.ucnt, NUCNT, L);
+    for (int p = 0; p < n; p++) { k1ListCount(B, p); k1UtrListCount(B, p); }
+    const int64_t listCap = listOffsets(listCnt.data(), n, listOffs);
+    B.listOffs = listOffs.data(); B.listCap = listCap;
+    B.laPos = (int32_t *)za(listCap, 4); B.lrPos = (int32_t *)za(listCap, 4); B.atgPos = (int32_t *)za(listCap, 4);
+    B.rsPos = (int32_t *)za(listCap, 4); B.rsBegin = (double *)za(listCap, 8);
+    B.tfSite = (USite *)za(listCap, sizeof(USite)); B.laSite = (USite *)za(listCap, sizeof(USite)); B.fsSite = (USite *)za(listCap, sizeof(USite));
+    B.lrSite = (USite *)za(listCap, sizeof(USite)); B.tmSite = (USite *)za(listCap, sizeof(USite)); B.rtSite = (USite *)za(listCap, sizeof(USite));
+    const int64_t nPl = B.nPl;
+    B.fx = (uint64_t *)za(nPl * Z.N * NFX, 8);
+    B.plsR = (double *)za(nPl * Z.N * 3, 8);
+    B.ldEnt = (IntronStart *)za(nPl * listCap, sizeof(IntronStart)); B.rdEnt = (IntronStart *)za(nPl * listCap, sizeof(IntronStart));
+    B.laPls = (double *)za(nPl * listCap * 3, 8); B.laFx = (uint64_t *)za(nPl * listCap * 3, 8);
+    B.lrEt = (double *)za(nPl * listCap * 3, 8); B.lrFx = (uint64_t *)za(nPl * listCap * 3, 8);
+    B.atgD = (double *)za(nPl * listCap * 3, 8); B.atgFx = (uint64_t *)za(nPl * listCap, 8);
+    B.rsFx = (uint64_t *)za(nPl * listCap * 3, 8);
+    for (int pl = 0; pl < nPl; pl++) {
+        for (int64_t g = 0; g < B.N; g++) k1FxTerms(T, B, g, pl);
+        scanFields<false>(B.fx + (int64_t)pl * Z.N * NFX, NFX, L);
+    }
+    for (int64_t g = 0; g < B.N; g++) k1Signals(T, B, g);
+    for (int sel = 0; sel < 4; sel++)
+        for (int64_t t2 = 0; t2 < B.listCap; t2++) k1SiteSignals(T, B, t2, sel);
+    for (int pl = 0; pl < B.nPl; pl++)
+        for (int64_t g = 0; g < B.N; g++) k1SiteConsts(T, B, g, pl);
+    for (int64_t g = 0; g < B.N; g++) k1UtrSignals(T, B, g);
+    // candidate records of the coding exons and short introns, in their dense form
+    B.blk = blk;
+    B.nBlk = B.N / blk;
+    B.blkCnt = (uint32_t *)za(B.nBlk * 2, 4);
+    B.blkSplit = (uint32_t *)za(B.nBlk * 3, 4);
+    B.blkOff = (uint64_t *)za(B.nBlk * 2, 8);
+    CandAlloc ca;
+    B.candAlloc = &ca;
+    CandLds *cl = new CandLds();
+    const int64_t nWg = B.N / (WAVE * NWAVES);
+    B.itemCap = 64;
+    B.items = zalloc<Item>(B.itemCap + 1);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        ca.pairs = 0; ca.items = 0;
+        for (int64_t wg = 0; wg < nWg; wg++) {
+            if (B.nPl > 1) { if (blk == 8) candWorkgroup<8, true, true>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4, true, true>(T, B, *cl, wg); else candWorkgroup<2, true, true>(T, B, *cl, wg); }
+            else { if (blk == 8) candWorkgroup<8, false, true>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4, false, true>(T, B, *cl, wg); else candWorkgroup<2, false, true>(T, B, *cl, wg); }
+        }
+        if ((int64_t)ca.items <= B.itemCap) break;
+        free(B.items);
+        B.itemCap = (int64_t)ca.items;
+        B.items = zalloc<Item>(B.itemCap + 1);
+    }
+    delete cl;
+    if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu stats (dense): N=%lld block %d pairs=%lld records=%lld\n", (long long)B.N, blk, (long long)ca.pairs, (long long)ca.items);
+    std::vector<int32_t> seg0(n + 1);
+    for (int p = 0; p <= n; p++) seg0[p] = p;
+    B.pieceSeg0 = seg0.data(); B.nSegs = n;
+    DenseLds *dl = new DenseLds();
+    for (int p = 0; p < n; p++) {
+        if (blk == 8) densePiece<8, 0>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0>(T, B, *dl, p); else densePiece<2, 0>(T, B, *dl, p);
+        denseBacktracePiece(T, B, p);
+    }
+    if (fwd_out) {
+        B.fwd = (double *)za(Z.N * t->S, 8);
+        std::vector<double> lnF(n);
+        B.lnFwd = lnF.data();
+        for (int p = 0; p < n; p++) { if (blk == 8) densePiece<8, 1>(T, B, *dl, p); else if (blk == 4) densePiece<4, 1>(T, B, *dl, p); else densePiece<2, 1>(T, B, *dl, p); }
+        int64_t w = 0;
+        for (int p = 0; p < n; p++) {
+            memcpy(fwd_out + w, B.fwd + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);
+            w += (int64_t)L.len[p] * t->S;
+            if (lnfwd_out) lnfwd_out[p] = lnF[p];
+        }
+    }
+    delete dl;
+    for (int p = 0; p < n; p++) {
+        lnv[p] = lnvv[p];
+        status[p] = st[p];
+        if (cls_out) cls_out[p] = cls[p];
+        int cnt = pc[p];
+        path_n[p] = cnt;
+        int64_t po = pathOff(B, p);
+        for (int i = 0; i < cnt && i < path_cap; i++) {
+            const int32_t *r = B.pathRec + (po + (cnt - 1 - i)) * 3;
+            int32_t *o = path_out + ((int64_t)p * path_cap + i) * 3;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+        }
+    }
+    if (cells_out) {
+        int64_t w = 0;
+        for (int p = 0; p < n; p++) {
+            memcpy(cells_out + w, B.cells + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);
+            w += (int64_t)L.len[p] * t->S;
+        }
+    }
+    free(B.items);
+    for (void *p : bufs) free(p);
+    return 0;
+}
+
 extern "C" {
 void emu_set_sampling(int n, unsigned seed) {
     g_nsamples = n;
@@ -59,6 +236,7 @@ int emu_sample_get(int p, int it, int32_t *out, int cap) {
 // fwd_out (optional): the dense ln F matrices of the forward algorithm, piece after piece; lnfwd_out[n]: ln P(sequence)
 int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *lnv, int32_t *status, int32_t *path_out,
                int32_t path_cap, int32_t *path_n, double *cells_out, int32_t *cls_out, double *fwd_out, double *lnfwd_out) {
+    if (modelIsDense(*t)) return emu_decode_dense(t, pieces, n, lnv, status, path_out, path_cap, path_n, cells_out, cls_out, fwd_out, lnfwd_out);
     int blk = 8;
     try {
         blk = chooseBlockSize(*t);
