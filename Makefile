@@ -11,7 +11,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-un
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
 SRC     = augustus_amd/csrc
 HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc $(SRC)/sharded.cc
-DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/layout.h $(SRC)/device/sampler.h
+DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h
 
 all: product oracle emu
 product: augustus_amd/libaugx.so augustus_amd/bin/augustus

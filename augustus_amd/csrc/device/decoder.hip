@@ -21,6 +21,7 @@
 #include <system_error>
 #include <vector>
 #include "kernels.h"
+#include "dense.h"
 #include "layout.h"
 #include "../capi_internal.h"
 
@@ -309,12 +310,54 @@ __global__ void __launch_bounds__(64) kChunkOffsets(uint64_t *tot, BatchView B, 
     }
 }
 
+// ---- untranslated regions (dense.h): content prefix sums + begin-site counts in one fused scan, then the signal records, the
+// end gates of the UTR exon states and the entries of the site lists
+constexpr int NUF = NUFX + NUCNT;
+__global__ void __launch_bounds__(SCAN_T) kUtrScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [N / SCAN_T][NUF] */) {
+    __shared__ ScanLds<NUF> L;
+    __shared__ SlotCodes C;
+    C.load(B);
+    const int64_t g = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
+    uint64_t v[NUF];
+    k1UtrTermsCalc(*T, B, g, v, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
+    blockTotals<NUF>(v, NUF, L, tot + (int64_t)blockIdx.x * NUF);
+}
+__global__ void __launch_bounds__(SCAN_T) kUtrScanApply(const DevTables *T, BatchView B, const uint64_t *tot) {
+    __shared__ ScanLds<NUF> L;
+    __shared__ SlotCodes C;
+    C.load(B);
+    const int64_t g = (int64_t)blockIdx.x * SCAN_T + threadIdx.x;
+    uint64_t v[NUF];
+    k1UtrTermsCalc(*T, B, g, v, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
+    blockScan<NUF>(v, NUF, L, tot + (int64_t)blockIdx.x * NUF);
+#pragma unroll
+    for (int f = 0; f < NUFX; f++) B.ufx[fidx(g, f, NUFX)] = v[f];
+#pragma unroll
+    for (int f = 0; f < NUCNT; f++) B.ucnt[fidx(g, f, NUCNT)] = (uint32_t)v[NUFX + f];
+}
+__global__ void kUtrListCount(BatchView B) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < B.nPieces) k1UtrListCount(B, p);
+}
+__global__ void __launch_bounds__(256) kUtrSignals(const DevTables *T, BatchView B) {
+    __shared__ SlotCodes C;
+    C.load(B);
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < B.N) k1UtrSignals(*T, B, g, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
+}
+// the dense Viterbi / forward kernel and its back-trace (dense.h): one workgroup / one wavefront per piece
+template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kDense(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+    __shared__ DenseLds lds;
+    densePiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
+}
+__global__ void __launch_bounds__(64) kDenseBacktrace(const DevTables *T, BatchView B) { denseBacktracePiece(*T, B, blockIdx.x); }
+
 // ---- candidates of the variable-length states: one wavefront per tile of 64 bases (describe + count, reserve, evaluate) ----
 // (MULTI: some piece of the batch has more than one GC class -- the plane of every class-dependent array is then chosen per
 //  end base; batches without such a piece run the variant with the plane folded away)
-template <int BLK, bool MULTI> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView B) {
+template <int BLK, bool MULTI, bool DENSE = false> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView B) {
     __shared__ CandLds lds; // (the batch view by value: its pointers are then known to be global, not generic)
-    candWorkgroup<BLK, MULTI>(*T, B, lds, blockIdx.x);
+    candWorkgroup<BLK, MULTI, DENSE>(*T, B, lds, blockIdx.x);
 }
 
 // MODE 0: pass 1, one workgroup per segment (= per piece when no piece is cut); 1: the fix-ups; 2: continuation of pieces whose
@@ -362,6 +405,7 @@ struct augx_decoder {
     std::multimap<size_t, void *> pool;
     std::unordered_map<void *, size_t> live;
     size_t pooledBytes = 0;
+    bool dense = false;        // the model is decoded by the dense kernels (dense.h)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
@@ -398,7 +442,7 @@ void devFree(augx_decoder *d, void *p) {
 } // namespace
 
 
-constexpr int NARR = 20; // arrays managed by ensureArrays
+constexpr int NARR = 26; // arrays managed by ensureArrays
 struct augx_batch {
     augx_decoder *dec = nullptr;
     BatchLayout L;
@@ -411,7 +455,8 @@ struct augx_batch {
     int64_t listCapAlloc = 0;  // entries per plane the candidate-list arrays are allocated for
     bool listsReady = false;   // the list offsets of this batch's pieces have been computed (its first decode)
     int64_t *dListOffs = nullptr;
-    void *planeBufs[20] = {};  // (ensureArrays)
+    void *planeBufs[NARR] = {};  // (ensureArrays)
+    bool utrScanned = false;   // (dense) the UTR prefix scan of the current decode has run already (first decode: before the lists are sized)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // start, prep done, trellis done, backtrace done
     hipEvent_t evFwd = nullptr; // forward matrix complete (the sampler waits for this, not for what the stream got after it)
     uint64_t nItems = 0, nPairs = 0;
@@ -459,7 +504,11 @@ int ensureArrays(augx_batch *b, int nPl, int64_t listCap) {
         {(void **)&V.lrPos, sizeof(int32_t), LC, 1},               {(void **)&V.lrVal, sizeof(double), LC * 3, 1},
         {(void **)&V.ldVal, sizeof(double), LC * 3, 1},            {(void **)&V.rdVal, sizeof(double), LC * 3, 1},
         {(void **)&V.atgPos, sizeof(int32_t), LC, 1},              {(void **)&V.rsPos, sizeof(int32_t), LC, 1},
-        {(void **)&V.rsBegin, sizeof(double), LC, 1}};
+        {(void **)&V.rsBegin, sizeof(double), LC, 1},
+        // (dense kernels: the site lists of the UTR exon states; the value lists above are not used there)
+        {(void **)&V.tfSite, sizeof(USite), b->dec->dense ? LC : 1, 1}, {(void **)&V.laSite, sizeof(USite), b->dec->dense ? LC : 1, 1},
+        {(void **)&V.fsSite, sizeof(USite), b->dec->dense ? LC : 1, 1}, {(void **)&V.lrSite, sizeof(USite), b->dec->dense ? LC : 1, 1},
+        {(void **)&V.tmSite, sizeof(USite), b->dec->dense ? LC : 1, 1}, {(void **)&V.rtSite, sizeof(USite), b->dec->dense ? LC : 1, 1}};
     for (int i = 0; i < NARR; i++) {
         const bool isN = i < 2; // (fx, plsR: sized by the slots, they only grow with the planes)
         if (isN && nPl == b->nPlAlloc && b->planeBufs[i]) continue;
@@ -514,13 +563,14 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->model = m;
     d->device = device;
     d->blk = blk;
+    d->dense = modelIsDense(t);
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
     if (const char *ex = getenv("AUGX_EXACT_MULTICLASS")) d->exactMulti = atoi(ex) != 0;
     { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) d->nCU = cu; else (void)hipGetLastError(); }
     const int rc = [&]() -> int { // (any failure below: the half-built decoder is destroyed, nothing leaks)
         HIP_TRY(hipStreamCreate(&d->stream));
-        fillDevTablesScalars(t, d->hostT);
+        try { fillDevTablesScalars(t, d->hostT); } catch (std::exception &ex) { setLastError(ex.what()); return AUGX_E_UNSUPPORTED; }
         for (auto &sp : tableSpans(t, d->hostT)) {
             void *p = nullptr;
             size_t bytes = (size_t)(sp.count > 0 ? sp.count : 1) * sizeof(double);
@@ -558,7 +608,8 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     // up to 150 B on site-dense sequence), with head room; a model with several GC classes may need the class-dependent
     // arrays (~0.2 KB per base) once more per extra class met inside one piece: room for two extra
     freeB += d->pooledBytes; // (buffers of earlier batches kept by this decoder are free for the next one)
-    int64_t cap = (int64_t)(freeB / (d->model->m.t.n_classes > 1 ? 2000 : 1500));
+    // (dense kernels: the ln V matrix itself, 8 S bytes per base, and once more for the forward matrix when sampling)
+    int64_t cap = (int64_t)(freeB / (d->dense ? 1500 + 18 * (size_t)d->model->m.t.S : d->model->m.t.n_classes > 1 ? 2000 : 1500));
     if (cap > 128L * 1000 * 1000) cap = 128L * 1000 * 1000;
     if (cap < 1000 * 1000) cap = 1000 * 1000;
     return cap;
@@ -624,12 +675,16 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.gate, uint64_t, Z.N);
     DA(V.site, int32_t, Z.N * NSITE);
     DA(V.chunkTot, uint64_t, Z.N / SCAN_T * NFX);
-    DA(V.bp, uint16_t, Z.N * SP);
-    DA(V.bpChain, uint8_t, Z.N * 8);
-    if (d->debugCells) DA(V.cells, double, Z.N * d->hostT.S);
+    if (!d->dense) {
+        DA(V.bp, uint16_t, Z.N * SP);
+        DA(V.bpChain, uint8_t, Z.N * 8);
+    } else {
+        DA(V.bpD, uint8_t, Z.N * d->hostT.S);
+        DA(V.ufx, uint64_t, Z.N * NUFX); DA(V.ucnt, uint32_t, Z.N * NUCNT); DA(V.usig, double, Z.N * NUSIG);
+    }
+    if (d->debugCells || d->dense) DA(V.cells, double, Z.N * d->hostT.S);
     if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); if (hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8) != hipSuccess) { augx_batch_destroy(b); setLastError("augx_batch_create: hipMemset failed"); return AUGX_E_HIP; } }
-    DA(V.vig, double, Z.N);
-    DA(V.longV, double, Z.N * 6);
+    if (!d->dense) { DA(V.vig, double, Z.N); DA(V.longV, double, Z.N * 6); }
     DA(V.listCnt, int32_t, n); DA(b->dListOffs, int64_t, n + 1);
     V.listOffs = b->dListOffs;
     if ((rc = ensureArrays(b, 1, 0))) { augx_batch_destroy(b); return rc; }
@@ -640,7 +695,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
     // segments of the trellis: enough workgroups for every compute unit, none shorter than what a fix-up needs
-    b->plan = planSegments(L, d->model->m.t, d->nCU / d->share > 0 ? d->nCU / d->share : 1);
+    b->plan = planSegments(L, d->model->m.t, d->nCU / d->share > 0 ? d->nCU / d->share : 1, d->dense ? -1 : 0); // (dense kernels: one workgroup per piece)
     SegDesc *dSegs; int32_t *dSeg0;
     const int nSegs = (int)b->plan.segs.size();
     DA(dSegs, SegDesc, nSegs); DA(dSeg0, int32_t, n + 1);
@@ -691,6 +746,13 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1, NSF), dim3(64), 0, st, V.chunkTot, V, NSF, NCNT);
     hipLaunchKernelGGL(kSiteScanApply, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     if (!b->listsReady) hipLaunchKernelGGL(kListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
+    b->utrScanned = false;
+    auto utrScan = [&]() { // (dense) the UTR content prefix sums follow the class of each base: after the content stairs
+        hipLaunchKernelGGL(kUtrScanTotals, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
+        hipLaunchKernelGGL(kChunkOffsets, dim3(n, 1, NUF), dim3(64), 0, st, V.chunkTot, V, NUF, NUF);
+        hipLaunchKernelGGL(kUtrScanApply, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
+        b->utrScanned = true;
+    };
     // GC classes, planes and list sizes are properties of the batch's sequences: settled by its first decode (with one host
     // round trip); a batch decoded again re-uses them and never waits for the host
     if (!b->decoded) {
@@ -730,6 +792,12 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             HIP_TRY(hipMemcpy(V.planeCls, planeCls.data(), sizeof(int32_t) * n * MAXPL, hipMemcpyHostToDevice));
         }
         bool changed = W.nPl != nPl;
+        if (d->dense && !b->listsReady) { // the UTR site lists share the capacity of the candidate lists: count their sites first
+            utrScan();
+            hipLaunchKernelGGL(kUtrListCount, dim3((n + 63) / 64), dim3(64), 0, st, V);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         if (!b->listsReady) { // candidate lists: first entry of every piece from the counted sites
             std::vector<int32_t> lc(n);
             std::vector<int64_t> offs;
@@ -758,12 +826,14 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         b->V.chunkTot = nt;
         b->chunkTotPlanes = V.nPl;
     }
+    if (d->dense && !b->utrScanned) utrScan();
     hipLaunchKernelGGL(kFxScanTotals, dim3(nScan, V.nPl), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kChunkOffsets, dim3(n, V.nPl, NFX), dim3(64), 0, st, V.chunkTot, V, NFX, NFX);
     hipLaunchKernelGGL(kFxScanApply, dim3(nScan, V.nPl), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
     hipLaunchKernelGGL(kSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteSignals, dim3((unsigned)((V.listCap + 255) / 256), 4), dim3(256), 0, st, d->dT, V);
     hipLaunchKernelGGL(kSiteConsts, dim3(gridN, V.nPl), dim3(256), 0, st, d->dT, V);
+    if (d->dense) hipLaunchKernelGGL(kUtrSignals, dim3(gridN), dim3(256), 0, st, d->dT, V);
     HIP_TRY(hipGetLastError());
     {   // candidates of the variable-length states.  The kernel reserves buffer space tile by tile; if the buffers turn
         // out too small (first decode of a batch, unusual sequence), it reports the size needed and is run again.
@@ -793,7 +863,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
             const bool multi = W.nPl > 1;
-#define AUGX_LAUNCH_CAND(BLK_) do { if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
+#define AUGX_LAUNCH_CAND(BLK_) do { if (d->dense) { if (multi) hipLaunchKernelGGL((kCand<BLK_, true, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
+                                                       else hipLaunchKernelGGL((kCand<BLK_, false, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); } \
+                                    else if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
                                     else hipLaunchKernelGGL((kCand<BLK_, false>), dim3(nWg), dim3(NT), 0, st, d->dT, W); } while (0)
             if (d->blk == 8) AUGX_LAUNCH_CAND(8);
             else if (d->blk == 4) AUGX_LAUNCH_CAND(4);
@@ -823,6 +895,16 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     if (b->plan.cut()) hipLaunchKernelGGL(kTileCross, dim3((unsigned)((V.N / WAVE + 255) / 256)), dim3(256), 0, st, V); // how far back the future reads (fix-ups)
     HIP_TRY(hipEventRecord(b->ev[1], st));
     auto runTrellis = [&]() -> int { // the trellis passes and the back-trace (run again when candidate terms were rebuilt, see below)
+    if (d->dense) { // the dense kernels: one workgroup per piece, the matrix in HBM (dense.h)
+        if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+        else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+        else hipLaunchKernelGGL((kDense<2, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->ev[2], st));
+        hipLaunchKernelGGL(kDenseBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);
+        HIP_TRY(hipGetLastError());
+        return AUGX_OK;
+    }
     HIP_TRY(hipMemsetAsync(V.segStatus, 0, sizeof(int32_t) * V.nSegs, st));
 #define AUGX_LAUNCH_TRELLIS(MODE_, grid_) do { \
         if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
@@ -857,7 +939,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     // rebuilt and the trellis runs once more -- every Viterbi variable is then the reference's to 1e-9 there, too.  On by default:
     // a randomised soak found a record whose optimal path depends on it; AUGX_EXACT_MULTICLASS=0 trades that for
     // the second trellis run.
-    if (d->exactMulti && b->nPlAlloc > 1) {
+    if (d->exactMulti && b->nPlAlloc > 1 && !d->dense) {
         int64_t nPatched = 0;
         int rc2;
         try { rc2 = snippetCacheReplay(d, b, nPatched, true); }
@@ -996,7 +1078,11 @@ static int augx_batch_forward_launch(augx_decoder *d, augx_batch *b) {
         W.fwd = (double *)p; W.lnFwd = (double *)q;
         HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, d->stream));
     }
-    if (d->blk == 8) hipLaunchKernelGGL(kForward<8>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+    if (d->dense) {
+        if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 1>), dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+        else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 1>), dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+        else hipLaunchKernelGGL((kDense<2, 1>), dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+    } else if (d->blk == 8) hipLaunchKernelGGL(kForward<8>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     else if (d->blk == 4) hipLaunchKernelGGL(kForward<4>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     else hipLaunchKernelGGL(kForward<2>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
@@ -1170,7 +1256,7 @@ extern "C" {
 int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     int rc = augx_batch_forward_launch(d, b);
     if (rc) return rc;
-    if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO")) { // (a batch with a multi-class piece)
+    if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO") && !d->dense) { // (a batch with a multi-class piece)
         int64_t nPatched = 0;
         try { rc = snippetCacheReplay(d, b, nPatched, false); }
         catch (const std::exception &e) { setLastError(std::string("augx_batch_forward: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }

@@ -1,0 +1,62 @@
+"""GPU parity of the 71-state model with untranslated regions (--UTR=on: dense kernels, device/dense.h), through the C ABI.
+Checkers: the oracle twin (oracle/ghmm_twin.cc, pinned to the real reference cell by cell in tests/test_oracle.py) and the
+golden vectors made from the real reference (tests/golden/make_golden_utr.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import augustus_amd as ax
+from helpers import *
+
+
+@pytest.fixture(autouse=True)
+def _one_class_per_end_base(monkeypatch):
+    # (the dense kernels score a short-intron interior with the class of its end base; the twin follows this switch)
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
+
+
+@pytest.mark.parametrize("species,opts", [("human", {"UTR": "on"}), ("human", {"UTR": "on", "softmasking": "0"}), ("fly", {"sample": "0"})])
+def test_gpu_utr_cells_bit_identical_to_oracle(species, opts):
+    """every cell of the S x n matrix, the score and the state path of every golden input (genes on both strands, truncated genes,
+    N runs, soft-masked records, records with several GC classes) and of random pieces"""
+    m = ax.Model(config_path(), species, **opts)
+    assert m.n_states == 71
+    d = ax.Decoder(m, 0)
+    S = m.n_states
+    seqs = [s for _, s in golden_inputs()] + [random_dna(30000, 1), random_dna(5000, 2).lower(), random_dna(100, 3)]
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (s, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
+        assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
+        assert np.array_equal(b.cells(i), V), i
+
+
+def test_gpu_utr_interior_piece_kinds_and_batch_order():
+    m = ax.Model(config_path(), "fly", sample="0", softmasking="0")
+    d = ax.Decoder(m, 0)
+    seqs = [random_dna(20000, 31337), random_dna(7000, 5), random_dna(33000, 6)]
+    for ik, tk in [(1, 1), (0, 1), (1, 0)]:
+        res = d.decode(seqs, init_kind=ik, term_kind=tk)
+        for s, r in zip(seqs, res):
+            rc, lnv, path, _, _ = twin_decode(m.tables_ptr, s, m.n_states, init_kind=ik, term_kind=tk)
+            assert r.status == 0 and r.ln_viterbi == lnv and r.states == path
+    a = d.decode(seqs)
+    b2 = d.decode(seqs[::-1])[::-1]
+    assert [(x.ln_viterbi, x.states) for x in a] == [(x.ln_viterbi, x.states) for x in b2]
+
+
+def test_gpu_utr_full_size_piece():
+    """a piece of the fly model's own size (200 kb of real DNA with its soft-masking): score and path equal to the oracle"""
+    import tarfile, io
+    tf = tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz"))
+    name = [n for n in tf.getnames() if n.endswith("genome.fa")][0]
+    seq = "".join(l.strip() for l in io.TextIOWrapper(tf.extractfile(name)) if not l.startswith(">"))[300000:500000]
+    m = ax.Model(config_path(), "fly", sample="0")
+    d = ax.Decoder(m, 0)
+    r, = d.decode([seq])
+    rc, lnv, path, _, _ = twin_decode(m.tables_ptr, seq, m.n_states)
+    assert r.status == 0 and r.ln_viterbi == lnv and r.states == path
