@@ -1353,6 +1353,50 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     P.items.resize((size_t)(hi - lo) + 1);
     if (hi > lo) HIP_TRY(hipMemcpy(P.items.data(), V.items + lo, sizeof(Item) * (size_t)(hi - lo), hipMemcpyDeviceToHost));
     P.termKind = b->L.termKind[piece];
+    if (d->dense) { // the host view of the piece the UTR exon candidates are evaluated from (sampler.h: SamplePiece::UtrHost)
+        P.dense = true;
+        P.uh.reset(new SamplePiece::UtrHost());
+        SamplePiece::UtrHost &U = *P.uh;
+        fillDevTablesScalars(t, U.T);
+        for (auto &sp : tableSpans(t, U.T)) *sp.dst = sp.src; // (host tables)
+        const int64_t slots = b->L.off[piece + 1] - o, ch0 = o / CHUNK, nch = slots / CHUNK;
+        memset(&U.B, 0, sizeof U.B);
+        U.off = {0, slots}; U.len = {n}; U.initKind = {b->L.initKind[piece]}; U.termKind = {b->L.termKind[piece]};
+        U.chunkPiece.assign((size_t)nch, 0);
+        U.cls = {cls}; U.nPlanes = {nPl};
+        U.planeCls.assign(MAXPL, 0);
+        HIP_TRY(hipMemcpy(U.planeCls.data(), V.planeCls + (int64_t)piece * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+        U.code.resize((size_t)slots); U.gcPlane.resize((size_t)slots);
+        HIP_TRY(hipMemcpy(U.code.data(), V.code + o, (size_t)slots, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(U.gcPlane.data(), V.gcPlane + o, (size_t)slots, hipMemcpyDeviceToHost));
+        U.cnt.resize((size_t)slots * NCNT); U.ucnt.resize((size_t)slots * NUCNT); U.ufx.resize((size_t)slots * NUFX);
+        HIP_TRY(hipMemcpy(U.cnt.data(), V.cnt + ch0 * NCNT * CHUNK, sizeof(uint32_t) * U.cnt.size(), hipMemcpyDeviceToHost)); // (chunk-major: a piece's chunks are contiguous)
+        HIP_TRY(hipMemcpy(U.ucnt.data(), V.ucnt + ch0 * NUCNT * CHUNK, sizeof(uint32_t) * U.ucnt.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(U.ufx.data(), V.ufx + ch0 * NUFX * CHUNK, sizeof(uint64_t) * U.ufx.size(), hipMemcpyDeviceToHost));
+        U.usig.resize((size_t)slots * NUSIG); U.sigAll.resize((size_t)slots * NSIG);
+        HIP_TRY(hipMemcpy(U.usig.data(), V.usig + o * NUSIG, sizeof(double) * U.usig.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(U.sigAll.data(), V.sig + o * NSIG, sizeof(double) * U.sigAll.size(), hipMemcpyDeviceToHost));
+        std::vector<int64_t> lo2(2);
+        HIP_TRY(hipMemcpy(lo2.data(), b->dListOffs + piece, sizeof(int64_t) * 2, hipMemcpyDeviceToHost));
+        const int64_t nEnt = lo2[1] - lo2[0];
+        U.listOffs = {0, nEnt};
+        const USite *src[6] = {V.tfSite, V.laSite, V.fsSite, V.lrSite, V.tmSite, V.rtSite};
+        for (int k = 0; k < 6; k++) {
+            U.sites[k].resize((size_t)(nEnt > 0 ? nEnt : 1));
+            if (nEnt > 0) HIP_TRY(hipMemcpy(U.sites[k].data(), src[k] + lo2[0], sizeof(USite) * (size_t)nEnt, hipMemcpyDeviceToHost));
+        }
+        BatchView &HB = U.B;
+        HB.nPieces = 1; HB.N = slots; HB.nChunks = (int)nch;
+        HB.off = U.off.data(); HB.len = U.len.data(); HB.initKind = U.initKind.data(); HB.termKind = U.termKind.data(); HB.chunkPiece = U.chunkPiece.data();
+        HB.cls = U.cls.data(); HB.nPlanes = U.nPlanes.data(); HB.planeCls = U.planeCls.data(); HB.nPl = 1;
+        HB.listOffs = U.listOffs.data(); HB.listCap = nEnt;
+        HB.code = U.code.data(); HB.gcPlane = U.gcPlane.data(); HB.cnt = U.cnt.data(); HB.ucnt = U.ucnt.data(); HB.ufx = U.ufx.data();
+        HB.usig = U.usig.data(); HB.sig = U.sigAll.data();
+        HB.tfSite = U.sites[0].data(); HB.laSite = U.sites[1].data(); HB.fsSite = U.sites[2].data(); HB.lrSite = U.sites[3].data();
+        HB.tmSite = U.sites[4].data(); HB.rtSite = U.sites[5].data();
+        HB.blk = V.blk;
+        P.hT = &U.T; P.hB = &U.B; P.hp = 0;
+    }
     {
         std::vector<uint8_t> code((size_t)n);
         HIP_TRY(hipMemcpy(code.data(), V.code + o + 1, (size_t)n, hipMemcpyDeviceToHost));

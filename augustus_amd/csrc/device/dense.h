@@ -286,8 +286,8 @@ AUGX_HD void k1UtrSignals(const DevTables &T, const BatchView &B, int64_t g, con
 // candidates of the exon-like UTR states, evaluated where they are needed (trellis, forward, back-trace, sampler)
 // =================================================================================================
 struct UDesc {          // state s ending at base j
-    int8_t kind, list, bsel, fxf, ovl, len;
-    int16_t s;
+    int8_t kind, list, bsel, fxf, ovl, len, xFirst, pad;
+    int16_t s, pad2;
     int32_t j, nList, nExtra, total;
     int32_t i1;         // one past the newest list entry (piece-local index)
     int32_t xHi;        // predecessor end of the first extra candidate (they run downwards)
@@ -314,7 +314,7 @@ AUGX_HD void utrDescribe(const UCtx &X, int s, int j, UDesc &D) {
     const int kind = T.kind[s], n = X.n;
     const UGeom g = utrGeom(T, kind);
     D.kind = (int8_t)kind; D.list = g.list; D.bsel = g.bsel; D.fxf = g.fxf; D.ovl = g.ovl; D.len = g.len; D.cb = g.cb; D.cbobe = g.cbobe;
-    D.s = (int16_t)s; D.j = j; D.nList = D.nExtra = D.total = 0; D.i1 = 0; D.xHi = 0;
+    D.s = (int16_t)s; D.j = j; D.nList = D.nExtra = D.total = 0; D.i1 = 0; D.xHi = 0; D.xFirst = 0; D.pad = 0; D.pad2 = 0;
     int boep, eobe, lm, rm;
     utrEndPos(T, kind, j, n, boep, eobe);
     utrWindow(T, kind, j, n, lm, rm);
@@ -374,6 +374,13 @@ AUGX_HD void utrDescribe(const UCtx &X, int s, int j, UDesc &D) {
     if (g.list == UL_TF) { const int hi = rm < -2 ? rm : -2; if (hi >= lm) { D.nExtra = hi - lm + 1; D.xHi = hi; } }
     else if (g.list == UL_TM) { const int hi = rm < -1 ? rm : -1; if (hi >= lm) { D.nExtra = hi - lm + 1; D.xHi = hi; } }
     else if (g.list == UL_FS || g.list == UL_RT) { if (lm <= 0 && rm >= 0) { D.nExtra = 1; D.xHi = 0; } }
+    else if (g.list == UL_LA) {
+        // an acceptor site whose AG lies inside the piece while the longass state that would end Ae bases after it does not: not on
+        // the list, but a possible begin of the UTR exon (aSSProb then scores the cut-off pattern as unknown, src/intronmodel.cc:1178-1180).
+        // These candidates have the largest predecessor ends of the window: they come first
+        const int qLo = sLo > n ? sLo : n, qHi = sHi < n - 2 + T.Ae ? sHi : n - 2 + T.Ae;
+        if (qHi >= qLo) { D.nExtra = qHi - qLo + 1; D.xHi = qHi - (T.U + assWhole); D.xFirst = 1; }
+    }
     D.total = D.nList + D.nExtra;
 }
 AUGX_HD double utrLenAt(const DevTables &T, int sel, int len, bool tail3) {
@@ -413,16 +420,26 @@ AUGX_HD bool utrCand(const UCtx &X, const UDesc &D, int idx, double &te, int &eo
     const int n = X.n;
     double bmix, braw = 0.0; // (begin signal) - (content prefix before the middle part); the begin signal alone
     bool haveRaw = false;
-    if (idx < D.nList) {
-        const USite e = X.list(D.list)[D.i1 - 1 - idx];
+    int li = idx, xi = -1; // index among the listed / among the extra candidates
+    if (D.xFirst) { if (idx < D.nExtra) xi = idx; else li = idx - D.nExtra; }
+    else if (idx >= D.nList) xi = idx - D.nList;
+    if (xi < 0) {
+        const USite e = X.list(D.list)[D.i1 - 1 - li];
         eop = e.pos;
         bmix = D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2];
     } else {
-        eop = D.xHi - (idx - D.nList);
+        eop = D.xHi - xi;
         const int begin = eop + 1, bom = begin + D.cb;
         // part of the begin signal lies before the piece (:1190-1194,1206-1210,1304-1311,1385-1389); a start from column 0
-        // of a state without begin signal
-        if (D.list == UL_TF) braw = (bom - 1) * T.ln_quarter;
+        // of a state without begin signal; an acceptor site at the very end of the piece
+        if (D.list == UL_LA) {
+            Piece P = makePieceAt(T, X.B, X.p, X.B.gcPlane[X.o + n]); // (the class of the last base)
+            braw = assProb(P, begin, true);
+            if (T.soft && braw > AUGX_NINF) {
+                int hi = begin + D.cbobe - 1; if (hi > n - 1) hi = n - 1;
+                braw = braw + (double)(int64_t)((uint64_t)X.cntS(CNT_SOFT, hi) - (uint64_t)X.cntS(CNT_SOFT, begin - 1)) * T.lnSoft;
+            }
+        } else if (D.list == UL_TF) braw = (bom - 1) * T.ln_quarter;
         else if (D.list == UL_TM) braw = (D.kind == AUGX_K_RUTR3TERM || bom > 0) ? (bom - 1) * T.ln_quarter : 0.0;
         else braw = 0.0;
         haveRaw = true;
@@ -731,10 +748,11 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             }
         };
         // the UTR exon candidates of the block: descriptors of the open (base, state) pairs, then every candidate by one thread
-        auto utrPass = [&](bool sumPass) __attribute__((always_inline)) {
-            const int total = (*lp(&L.udPre[BLK * DUV]));
+        // (only >= 0: the candidates of that one descriptor)
+        auto utrPass = [&](bool sumPass, int only) __attribute__((always_inline)) {
+            const int first = only >= 0 ? (*lp(&L.udPre[only])) : 0, total = only >= 0 ? (*lp(&L.udPre[only + 1])) : (*lp(&L.udPre[BLK * DUV]));
             FOR_THREADS(t) {
-                for (int it = t - WAVE; t >= WAVE && it < total; it += NTW) {
+                for (int it = first + t - WAVE; t >= WAVE && it < total; it += NTW) {
                     int pos = 0; // the pair of candidate `it`: the number of pairs whose candidates end at or before it
                     for (int step = 128; step >= 1; step >>= 1)
                         if (pos + step <= BLK * DUV && (*lp(&L.udPre[pos + step])) <= it) pos += step;
@@ -779,10 +797,32 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         FOR_THREADS(t) { if (t == 0) { int acc = 0; (*lp(&L.udPre[0])) = 0; for (int u = 0; u < BLK * DUV; u++) { acc += L.ud[u].total; (*lp(&L.udPre[u + 1])) = acc; } } }
         BLOCK_SYNC();
         itemPass(0, cntNonRT, false);
-        utrPass(false);
+        utrPass(false, -1);
         BLOCK_SYNC();
-        if (FWD) { itemPass(0, cntNonRT, true); utrPass(true); BLOCK_SYNC(); }
+        if (FWD) { itemPass(0, cntNonRT, true); utrPass(true, -1); BLOCK_SYNC(); }
         cells((1 << 1) | (1 << 3));
+        // the right-truncated 3' UTR exon at the last base of the piece may begin anywhere up to that base (src/utrmodel.cc:880-884):
+        // its predecessors of this very block exist only now -- the cell is made once more, from all of them
+        if (jb + BLK > n - 1 && jb <= n - 1)
+            for (int slot = 0; slot < nUv; slot++) {
+                if (T.kind[uvS[slot]] != AUGX_K_UTR3SINGLE) continue;
+                const int u = (n - 1 - jb) * DUV + slot, s2 = uvS[slot];
+                if (L.ud[u].total == 0) continue;
+                FOR_THREADS(t) { if (t == 0) { (*lp(&L.cmax[n - 1 - jb][s2])) = AUGX_NINF; (*lp(&L.csum[n - 1 - jb][s2])) = 0ull; } }
+                BLOCK_SYNC();
+                utrPass(false, u);
+                BLOCK_SYNC();
+                if (FWD) { utrPass(true, u); BLOCK_SYNC(); }
+                FOR_THREADS(t) {
+                    if (t == 0) {
+                        double f = (*lp(&L.cmax[n - 1 - jb][s2]));
+                        if (FWD) f = (*lp(&L.csum[n - 1 - jb][s2])) > 0ull ? f + log((double)(*lp(&L.csum[n - 1 - jb][s2])) / FWD_FIX) : AUGX_NINF;
+                        (*lp(&L.ring[(n - 1) & 63][s2])) = f;
+                        gp(M)[(int64_t)(n - 1) * S + s2] = f;
+                    }
+                }
+                BLOCK_SYNC();
+            }
         // ---- D: late chain states (intergenic, UTR introns: fed by the exon cells of the base before and by themselves)
         FOR_THREADS(t) { if (t >= WAVE && t - WAVE < (nCh - nEarly) * BLK) chainOthers(nEarly + (t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
         BLOCK_SYNC();

@@ -11,6 +11,7 @@
 #include <unordered_map>
 #include <vector>
 #include "dp.h"
+#include "dense.h" // (the candidates of the UTR exon states are evaluated on the host too: utrDescribe / utrCand)
 
 // glibc's rand(): the TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31] of random_r.c, seeded by the Lehmer
 // generator 16807 * x mod 2^31-1, the first 310 outputs discarded, the result shifted right by one
@@ -63,6 +64,24 @@ struct SamplePiece {
     // filled by prepareStops (may run on another thread, ahead of the sampling): see samplePaths
     std::vector<std::vector<int32_t>> stops, stopOpt;
     bool prepared = false;
+    // models of the dense kernels (dense.h): candidate records name their predecessor by state; the candidates of the UTR exon
+    // states are evaluated from a host view of the batch (hB: the emulator's own arrays, or the mirror of one piece below)
+    bool dense = false;
+    const DevTables *hT = nullptr;
+    const BatchView *hB = nullptr;
+    int hp = 0;
+    struct UtrHost { // what utrDescribe / utrCand read of one piece, fetched from HBM, laid out as a batch of one piece
+        DevTables T;
+        BatchView B;
+        std::vector<int64_t> off, listOffs;
+        std::vector<int32_t> len, cls, nPlanes, planeCls, initKind, termKind, chunkPiece;
+        std::vector<uint8_t> code, gcPlane;
+        std::vector<uint32_t> cnt, ucnt;
+        std::vector<uint64_t> ufx;
+        std::vector<double> usig, sigAll;
+        std::vector<USite> sites[6];
+    };
+    std::shared_ptr<UtrHost> uh;
     double lnT(int j, int a, int s) const {
         const int c = plane.empty() ? cls0 : planeCls[plane[j]];
         return t->ln_trans[((int64_t)c * S + a) * S + s];
@@ -80,7 +99,7 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
     const int dssWhole = t.Ds + 2 + t.De, assLag = t.As + 2 + t.Ae + t.U, dL = t.d - 2 - t.De - t.As - 2 - t.U;
     auto Fat = [&](int q, int a) { return q < 0 ? -INFINITY : P.F[(size_t)q * S + a]; };
     L.o.clear();
-    const bool chain = kind == AUGX_K_IGENIC || kind == AUGX_K_GEOMETRIC || kind == AUGX_K_RGEOMETRIC;
+    const bool chain = isChainKind(kind);
     const bool fixed = kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS || kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS ||
                        kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD;
     if (chain || fixed) {
@@ -95,6 +114,34 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
                 const double lp = Fat(eop, a) + (P.lnT(j, a, s) + emi);
                 if (lp > -INFINITY) L.o.push_back({a, eop, lp});
             }
+    } else if (isUtrExonKind(kind)) { // UTR exon: the site list of its window, latest predecessor end first, ancestors in their order
+        UCtx X(*P.hT, *P.hB, P.hp);
+        UDesc D;
+        utrDescribe(X, s, j, D);
+        for (int idx = 0; idx < D.total; idx++) {
+            double te; int eop;
+            if (!utrCand(X, D, idx, te, eop)) continue;
+            for (int ai = 0; ai < t.n_anc[s]; ai++) {
+                const int a = t.anc[s][ai];
+                const double lp = Fat(eop > 0 ? eop : 0, a) + (P.lnT(j, a, s) + te);
+                if (lp > -INFINITY) L.o.push_back({a, eop, lp});
+            }
+        }
+    } else if (P.dense) { // coding exon / short intron of a dense model: the records of its (base, state) pair
+        const int b = j / P.blk;
+        const uint64_t i0 = P.blkOff[(size_t)b * 2 + 1] - P.item0;
+        const uint32_t cnt = P.blkCnt[(size_t)b * 2 + 1], pid = (uint32_t)(((j % P.blk) << 7) | s);
+        for (uint32_t it = 0; it < cnt; it++) {
+            const Item &I = P.items[i0 + it];
+            if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
+            const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS, a = (int)(I.src & 127u);
+            const double lp = Fat(eop > 0 ? eop : 0, a) + I.te;
+            if (lp > -INFINITY) L.o.push_back({a, eop, lp});
+        }
+        int pos[AUGX_MAX_STATES];
+        for (int q = 0; q < AUGX_MAX_STATES; q++) pos[q] = AUGX_MAX_STATES;
+        for (int ai = t.n_anc[s] - 1; ai >= 0; ai--) pos[t.anc[s][ai]] = ai;
+        std::stable_sort(L.o.begin(), L.o.end(), [&](const Opt &x, const Opt &y) { return x.base != y.base ? x.base > y.base : pos[x.state] < pos[y.state]; });
     } else { // variable-length state: the candidates of its (base, state) pair, newest first (K2a's order = the reference's loops)
         const int b = j / P.blk;
         const uint64_t i0 = P.blkOff[(size_t)b * 2 + 1] - P.item0;
@@ -159,7 +206,7 @@ inline void prepareStops(SamplePiece &P) {
     P.stopOpt.assign((size_t)S, {});
     for (int s = 0; s < S && P.anyNuc; s++) {
         const int kd = t.state_kind[s];
-        if (kd != AUGX_K_IGENIC && kd != AUGX_K_GEOMETRIC && kd != AUGX_K_RGEOMETRIC) continue;
+        if (!isChainKind(kd)) continue;
         std::vector<int32_t> &v = P.stops[s];
         const int sg = kd == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
         for (int j = 1; j < n; j++) {
@@ -210,7 +257,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
             for (int s2 = 0; s2 < S; s2++) cur[s2] = (int64_t)stops[s2].size() - 1;
             while (base > 0) {
                 const int kd = t.state_kind[state];
-                if (kd == AUGX_K_IGENIC || kd == AUGX_K_GEOMETRIC || kd == AUGX_K_RGEOMETRIC) {
+                if (isChainKind(kd)) {
                     const std::vector<int32_t> &v = stops[state];
                     // the last stop <= base: bases only fall along a path, so the cursor of the state only moves down -- a step
                     // at a time while the path stays in the state, by bisection when it comes back to it further down
@@ -250,7 +297,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
         for (size_t i = st.size(); i-- > 0;) {
             const augx_state &x = st[i];
             const int k = t.state_kind[x.state];
-            const bool chain = k == AUGX_K_IGENIC || k == AUGX_K_GEOMETRIC || k == AUGX_K_RGEOMETRIC;
+            const bool chain = isChainKind(k);
             if (chain && !m2.empty() && m2.back().state == x.state && m2.back().end + 1 == x.begin) m2.back().end = x.end;
             else m2.push_back(x);
         }

@@ -1,6 +1,7 @@
 // genes.cc -- see genes.h
 #include "genes.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -15,7 +16,16 @@ static inline bool isRInternalExon(int t) { return t >= 38 && t <= 40; }
 static inline bool isRTerminalExon(int t) { return t >= 41 && t <= 43; }
 static inline bool isCodingExon(int t) { return (t >= 1 && t <= 8) || (t >= 36 && t <= 43); }
 static inline bool isCodingIntron(int t) { return (t >= 9 && t <= 23) || (t >= 44 && t <= 58); }
-static inline bool isIntron(int t) { return isCodingIntron(t) || t == TYPE_INTRON || t == TYPE_RINTRON; }
+static inline bool is5UTR(int t) { return (t >= 24 && t <= 29) || (t >= 59 && t <= 64); }
+static inline bool is5UTRIntron(int t) { return t == 26 || t == 27 || t == 61 || t == 62; }
+static inline bool is3UTR(int t) { return (t >= 30 && t <= 35) || (t >= 65 && t <= 70); }
+static inline bool is3UTRIntron(int t) { return t == 32 || t == 33 || t == 67 || t == 68; }
+static inline bool isUtrExon(int t) { return (is5UTR(t) && !is5UTRIntron(t)) || (is3UTR(t) && !is3UTRIntron(t)); }
+static inline bool isExonType(int t) { return isCodingExon(t) || isUtrExon(t); }
+static inline bool isIntron(int t) { return isCodingIntron(t) || is5UTRIntron(t) || is3UTRIntron(t) || t == TYPE_INTRON || t == TYPE_RINTRON; }
+enum { T_UTR5SINGLE = 24, T_UTR5INIT = 25, T_UTR5INTERNAL = 28, T_UTR5TERM = 29, T_UTR3SINGLE = 30, T_UTR3INIT = 31, T_UTR3INTERNAL = 34,
+       T_UTR3TERM = 35, T_RUTR5SINGLE = 59, T_RUTR5INIT = 60, T_RUTR5INTERNAL = 63, T_RUTR5TERM = 64, T_RUTR3SINGLE = 65, T_RUTR3INIT = 66,
+       T_RUTR3INTERNAL = 69, T_RUTR3TERM = 70 };
 static inline bool isOnFStrand(int t) { return !((t >= 36 && t <= 70) || t == TYPE_RINTRON || (t >= 80 && t <= 85)); }
 enum { T_SINGLE = 1, T_TERMINAL = 8, T_RSINGLE = 36, T_RINITIAL = 37 };
 
@@ -25,10 +35,11 @@ int BioState::frame() const { return mod3(winOfType(type) + framemod); }
 static int truncFlag(int type, long begin, long end, long dnalen) {
     int tr = 0;
     long predEnd = begin - 1;
-    if (end == dnalen - 1 && (isInitialExon(type) || isInternalExon(type) || isRTerminalExon(type) || isRInternalExon(type) || isIntron(type)))
+    if (end == dnalen - 1 && (isInitialExon(type) || isInternalExon(type) || isRTerminalExon(type) || isRInternalExon(type) || isIntron(type) ||
+                              type == T_UTR3SINGLE || type == T_UTR3TERM))
         tr |= TRUNC_RIGHT;
     if ((predEnd == -1 || predEnd == 0) &&
-        (isInternalExon(type) || type == T_TERMINAL || isRInternalExon(type) || type == T_RINITIAL || isIntron(type)))
+        (isInternalExon(type) || type == T_TERMINAL || isRInternalExon(type) || type == T_RINITIAL || isIntron(type) || isUtrExon(type)))
         tr |= TRUNC_LEFT;
     return tr;
 }
@@ -43,6 +54,17 @@ static BioState bioState(const Model &m, long begin, long end, int type, int tru
     else if (isRInternalExon(type) || type == T_RINITIAL) { if (!(truncated & TRUNC_LEFT)) beginShift = -t.Ds; }
     else if (type == TYPE_INTRON) beginShift = !(truncated & TRUNC_LEFT) ? t.Ds : -1;
     else if (type == TYPE_RINTRON) beginShift = !(truncated & TRUNC_LEFT) ? t.Ae : -1;
+    else if (type == T_UTR5SINGLE || type == T_UTR5INIT) beginShift = t.tss_upwin;
+    else if (type == T_RUTR5SINGLE) beginShift = !(truncated & TRUNC_LEFT) ? -t.W : (int)-begin;
+    else if (type == T_RUTR5INIT || type == T_RUTR5INTERNAL || type == T_RUTR3INIT || type == T_RUTR3INTERNAL) beginShift = t.De + 2;
+    else if (type == T_UTR5INTERNAL || type == T_UTR3INTERNAL || type == T_UTR3TERM || type == T_UTR5TERM) beginShift = t.U + t.As + 2;
+    else if (type == T_RUTR5TERM) beginShift = -t.W;
+    else if (type == T_UTR3SINGLE) { if ((truncated & TRUNC_LEFT) && begin == 1) beginShift = -1; }
+    else if (type == T_RUTR3SINGLE || type == T_RUTR3TERM) { if (begin < 0) beginShift = (int)-begin; }
+    if (type == T_UTR5SINGLE || type == T_UTR5TERM) endShift = t.W;
+    else if (type == T_RUTR5SINGLE || type == T_RUTR5INIT) endShift = -t.tss_upwin;
+    else if (type == T_UTR5INIT || type == T_UTR5INTERNAL || type == T_UTR3INIT || type == T_UTR3INTERNAL) endShift = -t.De - 2;
+    else if (type == T_RUTR5INTERNAL || type == T_RUTR5TERM || type == T_RUTR3INTERNAL || type == T_RUTR3TERM) endShift = -t.U - t.As - 2;
     if (type == T_RSINGLE || type == T_RINITIAL) endShift = -t.W;
     else if (isInitialExon(type) || isInternalExon(type)) {
         if (!(truncated & TRUNC_RIGHT)) endShift = t.Ds; else b.framemod = mod3(-t.Ds);
@@ -69,6 +91,8 @@ bool Transcript::completeCDS() const { // reference Gene::completeCDS, src/gene.
 void Transcript::shift(long d) {
     for (auto &e : exons) { e.begin += d; e.end += d; }
     for (auto &e : introns) { e.begin += d; e.end += d; }
+    for (std::vector<BioState> *l : {&utr5exons, &utr3exons, &utr5introns, &utr3introns})
+        for (auto &e : *l) { e.begin += d; e.end += d; }
     if (transstart >= 0) transstart += d;
     if (transend >= 0) transend += d;
     codingstart += d;
@@ -87,6 +111,10 @@ void OutputOptions::fromModel(const Model &m) { // reference Gene::init, src/gen
     protein = o.getBool("protein", true);
     codingseq = o.getBool("codingseq", false);
     uniqueGeneId = o.getBool("uniqueGeneId", false);
+    print_utr = o.getBool("print_utr", false);
+    print_tss = o.getBool("tss", false);
+    print_tts = o.getBool("tts", false);
+    utr = m.t.utr != 0;
     // "# Evidence for and against" is printed when the hints machinery is on, i.e. with softmasking (default true,
     // reference src/types.cc:95, src/extrinsicinfo.cc:1722, src/gene.cc:3111) and printEvidence (default true)
     softmasking = o.getBool("softmasking", true);
@@ -115,12 +143,29 @@ std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vecto
         i++;
     }
     while (i < n) {
-        while (i < n && !isCodingExon(path[i].type)) i++;
+        while (i < n && !isExonType(path[i].type)) i++;
         if (i >= n) break;
         if (!haveGene) { g = Transcript(); haveGene = true; }
-        const int ty = path[i].type;
-        g.plus = isOnFStrand(ty);
+        g.plus = isOnFStrand(path[i].type);
         if (!g.plus) g.frame = 2;
+        // the UTR left of the coding region: the 5' UTR of a forward gene, the 3' UTR of a reverse one (src/gene.cc:473-504)
+        bool haveLeft5 = false, haveLeft3 = false;
+        if (is5UTR(path[i].type)) {
+            while (i < n && is5UTR(path[i].type)) {
+                if (!haveLeft5) { g.complete5utr = path[i].type == T_UTR5SINGLE || path[i].type == T_UTR5INIT; haveLeft5 = true; }
+                if (isExonType(path[i].type)) g.utr5exons.push_back(bioState(m, path[i].begin, path[i].end, path[i].type, tr(path[i])));
+                i++;
+            }
+        } else if (is3UTR(path[i].type)) {
+            while (i < n && is3UTR(path[i].type)) {
+                if (!haveLeft3) { g.complete3utr = path[i].type == T_RUTR3SINGLE || path[i].type == T_RUTR3TERM; haveLeft3 = true; }
+                if (isExonType(path[i].type)) g.utr3exons.push_back(bioState(m, path[i].begin, path[i].end, path[i].type, tr(path[i])));
+                i++;
+            }
+        }
+        bool last5 = false, last3 = false; // (a UTR was read to the RIGHT of the coding region: last5utrexon / last3utrexon of the reference)
+        if (i < n && isExonType(path[i].type)) {
+        const int ty = path[i].type;
         if (ty == T_SINGLE || ty == T_RSINGLE) {
             g.exons.push_back(bioState(m, path[i].begin, path[i].end, ty, tr(path[i])));
             i++;
@@ -155,10 +200,36 @@ std::vector<Transcript> projectOntoGeneSequence(const Model &m, const std::vecto
                 }
             }
         }
-        // finish construction of the gene (src/gene.cc:612-676)
+        // the UTR right of the coding region (src/gene.cc:565-596)
+        if (i < n) {
+            if (is5UTR(path[i].type)) {
+                while (i < n && is5UTR(path[i].type)) {
+                    if (!(i + 1 < n && is5UTR(path[i + 1].type))) g.complete5utr = path[i].type == T_RUTR5SINGLE || path[i].type == T_RUTR5INIT;
+                    if (isExonType(path[i].type)) { g.utr5exons.push_back(bioState(m, path[i].begin, path[i].end, path[i].type, tr(path[i]))); last5 = true; }
+                    i++;
+                }
+            } else if (is3UTR(path[i].type)) {
+                while (i < n && is3UTR(path[i].type)) {
+                    if (!(i + 1 < n && is3UTR(path[i + 1].type))) g.complete3utr = path[i].type == T_UTR3SINGLE || path[i].type == T_UTR3TERM;
+                    if (isExonType(path[i].type)) { g.utr3exons.push_back(bioState(m, path[i].begin, path[i].end, path[i].type, tr(path[i]))); last3 = true; }
+                    i++;
+                }
+            }
+        }
+        } else { // the (incomplete) gene consists just of UTR: not reported (Constant::reportUtrOnlyGenes = false, src/gene.cc:598-604)
+            haveGene = false;
+            continue;
+        }
+        // finish construction of the gene (src/gene.cc:609-676): UTR introns are the gaps between UTR exons
+        for (size_t k = 0; k + 1 < g.utr5exons.size(); k++) { BioState in; in.begin = g.utr5exons[k].end + 1; in.end = g.utr5exons[k + 1].begin - 1; in.type = TYPE_INTRON; g.utr5introns.push_back(in); }
+        for (size_t k = 0; k + 1 < g.utr3exons.size(); k++) { BioState in; in.begin = g.utr3exons[k].end + 1; in.end = g.utr3exons[k + 1].begin - 1; in.type = TYPE_INTRON; g.utr3introns.push_back(in); }
         g.clength = 0;
         for (auto &e : g.exons) g.clength += e.length();
         if (!g.plus) g.frame = mod3(g.frame - g.clength + 1);
+        if (!g.utr5exons.empty() && (g.transstart < 0 || g.transstart > g.utr5exons.front().begin)) g.transstart = g.utr5exons.front().begin;
+        if (!g.utr3exons.empty() && (g.transstart < 0 || g.transstart > g.utr3exons.front().begin)) g.transstart = g.utr3exons.front().begin;
+        if (last5 && (g.transend < 0 || g.transend < g.utr5exons.back().end)) g.transend = g.utr5exons.back().end;
+        if (last3 && (g.transend < 0 || g.transend < g.utr3exons.back().end)) g.transend = g.utr3exons.back().end;
         g.codingstart = g.exons.front().begin;
         g.codingend = g.exons.back().end;
         if (g.codingend > g.transend) g.transend = -1;
@@ -175,8 +246,8 @@ double Transcript::meanStateProb() const {
     if (!hasProbs) return 0.0;
     double p = 1.0;
     int k = 0;
-    for (const BioState &e : exons) { p *= e.apostprob; k++; }
-    for (const BioState &e : introns) { p *= e.apostprob; k++; }
+    for (const std::vector<BioState> *l : {&exons, &introns, &utr5exons, &utr3exons}) // (Gene::getExInHeads, include/gene.hh:379)
+        for (const BioState &e : *l) { p *= e.apostprob; k++; }
     return pow(p, 1.0 / k);
 }
 
@@ -262,13 +333,16 @@ void reverseTranscript(Transcript &t, long endpos) {
 
 // reference Transcript::operator==, src/gene.cc:1149-1175: the same exon and intron intervals (types and strand are not compared)
 static bool sameIntervals(const Transcript &a, const Transcript &b) {
-    if (a.exons.size() != b.exons.size() || a.introns.size() != b.introns.size()) return false;
-    for (size_t i = 0; i < a.exons.size(); i++)
-        if (a.exons[i].begin != b.exons[i].begin || a.exons[i].end != b.exons[i].end) return false;
-    for (size_t i = 0; i < a.introns.size(); i++)
-        if (a.introns[i].begin != b.introns[i].begin || a.introns[i].end != b.introns[i].end) return false;
+    const std::vector<BioState> *la[4] = {&a.exons, &a.introns, &a.utr5exons, &a.utr3exons}, *lb[4] = {&b.exons, &b.introns, &b.utr5exons, &b.utr3exons};
+    for (int k = 0; k < 4; k++) {
+        if (la[k]->size() != lb[k]->size()) return false;
+        for (size_t i = 0; i < la[k]->size(); i++)
+            if ((*la[k])[i].begin != (*lb[k])[i].begin || (*la[k])[i].end != (*lb[k])[i].end) return false;
+    }
     return true;
 }
+// the four state lists the posterior probabilities run over (Gene::getExInHeads: CDS exons, CDS introns, 5' UTR exons, 3' UTR exons)
+static std::vector<BioState> *exInList(Transcript &t, int k) { return k == 0 ? &t.exons : k == 1 ? &t.introns : k == 2 ? &t.utr5exons : &t.utr3exons; }
 // reference Transcript::updatePostProb, src/gene.cc:1204-1235
 static void mergeCount(std::vector<BioState> &x, std::vector<BioState> &y) {
     size_t i = 0, j = 0;
@@ -291,8 +365,8 @@ std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<P
         for (Transcript &g : projectOntoGeneSequence(m, path, dnalen)) {
             g.serial = serial++;
             g.apostprob = 1.0f;
-            for (BioState &e : g.exons) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
-            for (BioState &e : g.introns) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
+            for (int k = 0; k < 4; k++)
+                for (BioState &e : *exInList(g, k)) { e.apostprob = 1.0f; e.sampleCount = 1; e.hasScore = true; }
             g.hasProbs = true;
             g.viterbi = vit;
             g.throwaway = !vit && !alternatives; // (alternatives-from-sampling=false: a sampled transcript only adds to the counts)
@@ -312,8 +386,8 @@ std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<P
                 all[i].throwaway = all[i].throwaway && all[j].throwaway;
                 all[i].viterbi = all[i].viterbi || all[j].viterbi;
                 all[i].apostprob += 1.0f;
-                for (BioState &e : all[i].exons) { e.sampleCount += 1; e.apostprob += 1.0f; }
-                for (BioState &e : all[i].introns) { e.sampleCount += 1; e.apostprob += 1.0f; }
+                for (int k = 0; k < 4; k++)
+                    for (BioState &e : *exInList(all[i], k)) { e.sampleCount += 1; e.apostprob += 1.0f; }
                 dead[j] = 1;
             }
         }
@@ -327,14 +401,13 @@ std::vector<Transcript> posteriorTranscripts(const Model &m, const std::vector<P
         for (size_t i = 0; i < all.size(); i++)
             for (size_t j = i + 1; j < all.size() && all[j].geneBegin() <= all[i].geneEnd(); j++) {
                 if (all[j].geneBegin() > all[i].geneEnd() || all[i].geneBegin() > all[j].geneEnd()) continue;
-                mergeCount(all[i].exons, all[j].exons);
-                mergeCount(all[i].introns, all[j].introns);
+                for (int k = 0; k < 4; k++) mergeCount(*exInList(all[i], k), *exInList(all[j], k));
             }
         const float n = (float)sampleiterations;
         for (Transcript &g : all) {
             g.apostprob /= n;
-            for (BioState &e : g.exons) e.apostprob /= n;
-            for (BioState &e : g.introns) e.apostprob /= n;
+            for (int k = 0; k < 4; k++)
+                for (BioState &e : *exInList(g, k)) e.apostprob /= n;
         }
     }
     return all;
@@ -521,13 +594,6 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
     const char strand = t.plus ? '+' : '-';
     std::string transcript_id = t.geneid + "." + t.id;
     std::string parentstr = o.gff3 ? ("Parent=" + transcript_id) : ("transcript_id \"" + transcript_id + "\"; gene_id \"" + t.geneid + "\";");
-    if (!t.exons.empty()) {
-        const BioState &f = t.exons.front();
-        if (o.print_start && t.plus && (isInitialExon(f.type) || f.type == T_SINGLE))
-            appendf(out, "%s\t%s\tstart_codon\t%ld\t%ld\t.\t+\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
-        if (o.print_stop && !t.plus && (f.type == T_TERMINAL || f.type == T_SINGLE || isRTerminalExon(f.type) || f.type == T_RSINGLE))
-            appendf(out, "%s\t%s\tstop_codon\t%ld\t%ld\t.\t-\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
-    }
     // score column: the posterior probability with setprecision(3), "." without sampling
     auto score = [&](const BioState &e) {
         if (!e.hasScore) return std::string(".");
@@ -535,6 +601,34 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
         snprintf(b, sizeof b, "%.3g", (double)e.apostprob);
         return std::string(b);
     };
+    const std::vector<BioState> &rightUtr = t.plus ? t.utr3exons : t.utr5exons, &leftUtr = t.plus ? t.utr5exons : t.utr3exons;
+    // the UTR left of the coding region (src/gene.cc:2008-2071)
+    for (size_t k = 0; k < leftUtr.size(); k++) {
+        const BioState &e = leftUtr[k];
+        if (t.plus && k == 0 && t.complete5utr && o.print_tss)
+            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t.\t+\t.\t%s\n", seqname, source, o.gff3 ? "transcription_start_site" : "tss", e.begin + 1, e.begin + 1, parentstr.c_str());
+        if (!t.plus && k == 0 && t.complete3utr && o.print_tts)
+            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t.\t-\t.\t%s\n", seqname, source, o.gff3 ? "transcription_end_site" : "tts", e.begin + 1, e.begin + 1, parentstr.c_str());
+        if (o.print_utr) {
+            if (e.end >= e.begin) // (a UTR exon has length 0 when the start codon comes right after the splice site)
+                appendf(out, "%s\t%s\t%s\t%ld\t%ld\t%s\t%c\t.\t%s\n", seqname, source,
+                        t.plus ? (o.gff3 ? "five_prime_utr" : "5'-UTR") : (o.gff3 ? "three_prime_utr" : "3'-UTR"), e.begin + 1, e.end + 1, score(e).c_str(), strand, parentstr.c_str());
+        } else {
+            long from = e.begin + 1, to = e.end + 1;
+            if (k + 1 == leftUtr.size() && !t.exons.empty()) { // the last one runs on into the first coding exon
+                to = t.exons.front().end + 1;
+                if (t.exons.size() == 1 && !rightUtr.empty()) to = rightUtr.front().end + 1;
+            }
+            appendf(out, "%s\t%s\texon\t%ld\t%ld\t.\t%c\t.\t%s\n", seqname, source, from, to, strand, parentstr.c_str());
+        }
+    }
+    if (!t.exons.empty()) {
+        const BioState &f = t.exons.front();
+        if (o.print_start && t.plus && (isInitialExon(f.type) || f.type == T_SINGLE))
+            appendf(out, "%s\t%s\tstart_codon\t%ld\t%ld\t.\t+\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
+        if (o.print_stop && !t.plus && (f.type == T_TERMINAL || f.type == T_SINGLE || isRTerminalExon(f.type) || f.type == T_RSINGLE))
+            appendf(out, "%s\t%s\tstop_codon\t%ld\t%ld\t.\t-\t0\t%s\n", seqname, source, f.begin + 1, f.begin + 3, parentstr.c_str());
+    }
     auto frameCol = [&](const BioState &e) { return t.plus ? mod3(3 - (e.frame() - e.length())) : mod3(2 - e.frame()); };
     if (o.print_exonnames && !o.gff3)
         for (const BioState &e : t.exons) {
@@ -547,7 +641,8 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
     if (o.print_introns)
         for (const BioState &e : t.introns)
             appendf(out, "%s\t%s\tintron\t%ld\t%ld\t%s\t%c\t.\t%s\n", seqname, source, e.begin + 1, e.end + 1, score(e).c_str(), strand, parentstr.c_str());
-    for (const BioState &e : t.exons) {
+    for (size_t xi = 0; xi < t.exons.size(); xi++) {
+        const BioState &e = t.exons[xi];
         if (o.print_cds) {
             int beginmod = 0, endmod = 0;
             if (o.stopCodonExcludedFromCDS) {
@@ -561,6 +656,12 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
                 out += "\n";
             }
         }
+        // 'exon' lines: only with UTR prediction on, and when the UTRs are not printed in their own format (src/gene.cc:2166-2177)
+        if (o.utr && !o.print_utr && (xi != 0 || leftUtr.empty())) {
+            long from = e.begin + 1, to = e.end + 1;
+            if (xi + 1 == t.exons.size() && !rightUtr.empty()) to = rightUtr.front().end + 1;
+            appendf(out, "%s\t%s\texon\t%ld\t%ld\t.\t%c\t.\t%s\n", seqname, source, from, to, strand, parentstr.c_str());
+        }
     }
     if (!t.exons.empty()) {
         const BioState &l = t.exons.back();
@@ -568,6 +669,20 @@ static void printTranscriptGFF(std::string &out, const Transcript &t, const Outp
             appendf(out, "%s\t%s\tstop_codon\t%ld\t%ld\t.\t+\t0\t%s\n", seqname, source, l.end - 1, l.end + 1, parentstr.c_str());
         if (o.print_start && !t.plus && (isInitialExon(l.type) || l.type == T_SINGLE || l.type == T_RINITIAL || l.type == T_RSINGLE))
             appendf(out, "%s\t%s\tstart_codon\t%ld\t%ld\t.\t-\t0\t%s\n", seqname, source, l.end - 1, l.end + 1, parentstr.c_str());
+    }
+    // the UTR right of the coding region (src/gene.cc:2198-2250)
+    for (size_t k = 0; k < rightUtr.size(); k++) {
+        const BioState &e = rightUtr[k];
+        if (o.print_utr) {
+            if (e.end >= e.begin)
+                appendf(out, "%s\t%s\t%s\t%ld\t%ld\t%s\t%c\t.\t%s\n", seqname, source,
+                        t.plus ? (o.gff3 ? "three_prime_utr" : "3'-UTR") : (o.gff3 ? "five_prime_utr" : "5'-UTR"), e.begin + 1, e.end + 1, score(e).c_str(), strand, parentstr.c_str());
+        } else if (k != 0)
+            appendf(out, "%s\t%s\texon\t%ld\t%ld\t.\t%c\t.\t%s\n", seqname, source, e.begin + 1, e.end + 1, strand, parentstr.c_str());
+        if (k + 1 == rightUtr.size() && t.plus && t.complete3utr && o.print_tts)
+            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t.\t+\t.\t%s\n", seqname, source, o.gff3 ? "transcription_end_site" : "tts", e.end + 1, e.end + 1, parentstr.c_str());
+        if (k + 1 == rightUtr.size() && !t.plus && t.complete5utr && o.print_tss)
+            appendf(out, "%s\t%s\t%s\t%ld\t%ld\t.\t-\t.\t%s\n", seqname, source, o.gff3 ? "transcription_start_site" : "tss", e.end + 1, e.end + 1, parentstr.c_str());
     }
 }
 
@@ -645,12 +760,15 @@ void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const ch
                     bool inIntron = false;
                     for (const BioState &in : t.introns)
                         if (run.first >= in.begin && run.second <= in.end) inIntron = true;
+                    for (const std::vector<BioState> *ul : {&t.utr5exons, &t.utr3exons}) // between two UTR exons (src/gene.cc:1736,1753)
+                        for (size_t k = 1; k < ul->size(); k++)
+                            if ((*ul)[k - 1].end + 1 <= run.first && (*ul)[k].begin - 1 >= run.second) inIntron = true;
                     (inIntron ? obeyed : incompatible)++;
                 }
                 out += "# Evidence for and against this transcript:\n";
                 out += "# % of transcript supported by hints (any source): 0\n";
                 appendf(out, "# CDS exons: 0/%zu\n# CDS introns: 0/%zu\n", t.exons.size(), t.introns.size());
-                out += "# 5'UTR exons and introns: 0/0\n# 3'UTR exons and introns: 0/0\n";
+                appendf(out, "# 5'UTR exons and introns: 0/%zu\n# 3'UTR exons and introns: 0/%zu\n", t.utr5exons.size() + t.utr5introns.size(), t.utr3exons.size() + t.utr3introns.size());
                 appendf(out, "# hint groups fully obeyed: %d\n", obeyed);
                 if (obeyed) appendf(out, "# %6s:%4d \n", "RM", obeyed);
                 appendf(out, "# incompatible hint groups: %d\n", incompatible);

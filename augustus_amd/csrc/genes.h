@@ -29,6 +29,9 @@ struct BioState {
 
 struct Transcript {
     std::vector<BioState> exons, introns;
+    // untranslated regions (--UTR=on; reference Gene::utr5exons / utr3exons / utr5introns / utr3introns, include/gene.hh:405-416)
+    std::vector<BioState> utr5exons, utr3exons, utr5introns, utr3introns;
+    bool complete5utr = true, complete3utr = true;
     bool plus = true;
     int frame = 0;
     bool complete = true;
@@ -57,6 +60,7 @@ struct GeneOut {
 };
 
 struct OutputOptions {
+    bool print_utr = false, print_tss = false, print_tts = false, utr = false;
     bool print_start = true, print_stop = true, print_introns = false, print_cds = true, print_exonnames = false,
          gff3 = false, stopCodonExcludedFromCDS = false, protein = true, codingseq = false, evidence = false,
          uniqueGeneId = false, softmasking = true;

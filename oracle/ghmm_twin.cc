@@ -880,6 +880,11 @@ struct Twin {
         if (q < 0) q = 0;
         return assProb(cls[q], base, fwd);
     }
+    // (checkF != NULL: instead of the Viterbi cell, ln of the SUM over the same candidates with predecessor values taken from
+    //  checkF -- the forward recurrence of one cell, for tests of the forward matrices; result in checkOut)
+    const double *checkF = nullptr;
+    double checkOut = NINF;
+    static double lse(double a, double b2) { if (a == NINF) return b2; if (b2 == NINF) return a; return a > b2 ? a + log1p(exp(b2 - a)) : b2 + log1p(exp(a - b2)); }
     void utrCell(int s, int j) {
         const int kind = t.state_kind[s], c = cls[j];
         const int W = t.W, U = t.U, up = t.tss_upwin, te = t.tss_end, dc = t.d_polyasig_cleavage, bl = t.aataaa_boxlen;
@@ -966,7 +971,7 @@ struct Twin {
             const int col = eop > 0 ? eop : 0;
             bool any = false;
             for (int ai = 0; ai < t.n_anc[s]; ai++)
-                if (Vat(col, t.anc[s][ai]) > NINF) any = true;
+                if ((checkF ? checkF[(size_t)col * S + t.anc[s][ai]] : Vat(col, t.anc[s][ai])) > NINF) any = true;
             if (!any) continue;
             // ---- notEndPartEmiProb :1167-1548
             const int begin = eop + 1;
@@ -1072,12 +1077,14 @@ struct Twin {
             const double emi = nep + endP;
             for (int ai = 0; ai < t.n_anc[s]; ai++) {
                 int a = t.anc[s][ai];
-                double pv = Vat(col, a);
+                double pv = checkF ? checkF[(size_t)col * S + a] : Vat(col, a);
                 if (pv == NINF) continue;
                 double val = pv + (lnT(c, a, s) + emi);
+                if (checkF) { checkOut = lse(checkOut, val); continue; }
                 if (val > best) { best = val; ba = a; be = eop; }
             }
         }
+        if (checkF) return;
         if (best > NINF) { Vat(j, s) = best; bpS[(size_t)j * S + s] = ba; bpE[(size_t)j * S + s] = be; }
     }
 
@@ -1159,6 +1166,18 @@ struct Twin {
 } // namespace
 
 extern "C" {
+/* test aid: ln of the forward sum of UTR exon cell (j, s) over the twin's candidates, with predecessor values from F [len][S] */
+double twin_utr_forward_cell(const augx_tables *t, const char *seq, int64_t len, const double *F, int s, int j) {
+    Twin tw(*t, seq, (int)len);
+    tw.V.assign((size_t)len * t->S, NINF); tw.bpS.assign((size_t)len * t->S, -1); tw.bpE.assign((size_t)len * t->S, -1);
+    tw.computeStairs(); tw.buildORF();
+    for (int q = 0; q < (int)len; q++) tw.buildClass(tw.cls[q]);
+    tw.buildUtr();
+    tw.curCls = tw.cls[j];
+    tw.checkF = F; tw.checkOut = NINF;
+    tw.utrCell(s, j);
+    return tw.checkOut;
+}
 /* 1 (default): short-intron interiors through the restated SnippetProbs cache, as the reference; 0: class of the end base */
 void twin_set_snippet_cache(int on) { g_snippetCache = on; }
 /* decode one piece on the CPU.  V_out (len*S doubles) and gc_out (len int32) may be NULL.

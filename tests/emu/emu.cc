@@ -35,12 +35,13 @@ template <bool MAX, class E> void scanFields(E *a, int nf, const BatchLayout &L)
 }
 } // namespace
 
+
+
 // posterior sampling in the emulator: emu_set_sampling(n, seed) before emu_decode(..., fwd_out != NULL); the generator lives on
 // across emu_decode calls (one stream over the run, as in the reference); emu_sample_get reads sample `it` of piece p
 static int g_nsamples = 0;
 static augx_rand *g_rand = nullptr;
 static std::vector<std::vector<std::vector<augx_state>>> g_samples;
-
 
 // ---- models decoded by the dense kernels (device/dense.h: the 71-state model with UTR states): the same prep kernels, the UTR
 //      prefix / signal / site-list kernels, the candidate records of kCand in their dense form, densePiece, denseBacktracePiece
@@ -189,6 +190,31 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
             memcpy(fwd_out + w, B.fwd + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);
             w += (int64_t)L.len[p] * t->S;
             if (lnfwd_out) lnfwd_out[p] = lnF[p];
+        }
+        g_samples.assign((size_t)n, {});
+        for (int p = 0; p < n && g_nsamples > 0; p++) {
+            SamplePiece P;
+            const int len = L.len[p], S = t->S;
+            const int64_t o = L.off[p];
+            P.t = t; P.S = S; P.n = len; P.blk = blk; P.cls0 = cls[p]; P.nPlanes = B.nPlanes[p]; P.termKind = L.termKind[p];
+            P.dense = true; P.hT = &T; P.hB = &B; P.hp = p;
+            P.F = B.fwd + (o + 1) * S;
+            P.sig.assign(B.sig + (o + 1) * NSIG, B.sig + (o + 1 + len) * NSIG);
+            if (P.nPlanes > 1) {
+                P.plane.assign(B.gcPlane + o + 1, B.gcPlane + o + 1 + len);
+                P.planeCls.assign(B.planeCls + (int64_t)p * MAXPL, B.planeCls + (int64_t)(p + 1) * MAXPL);
+            }
+            const int nBlocks = (len + blk - 1) / blk;
+            const int64_t gb0 = o / blk;
+            P.blkOff.assign(B.blkOff + gb0 * 2, B.blkOff + (gb0 + nBlocks) * 2);
+            P.blkCnt.assign(B.blkCnt + gb0 * 2, B.blkCnt + (gb0 + nBlocks) * 2);
+            P.item0 = P.blkOff[1];
+            const uint64_t itemEnd = P.blkOff[(size_t)(nBlocks - 1) * 2 + 1] + P.blkCnt[(size_t)(nBlocks - 1) * 2 + 1];
+            P.items.assign(B.items + P.item0, B.items + itemEnd);
+            P.anyNuc = false;
+            for (int q = 0; q < len && !P.anyNuc; q++) P.anyNuc = B.code[o + 1 + q] < 4;
+            std::vector<int> sst;
+            samplePaths(P, g_nsamples, *g_rand, g_samples[p], sst);
         }
     }
     delete dl;
