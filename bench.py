@@ -215,6 +215,66 @@ def e2e_legs(cfg, model, local, contigs):
     return out
 
 
+def utr_leg(cfg, local, a):
+    """BASELINE config 4's model on the bench's data: --species=human --UTR=on, the 71-state trellis with untranslated regions
+    (dense kernels, device/dense.h: one workgroup per piece, ln V dense in HBM), synthetic uniform-random contigs resident in HBM,
+    EXACTLY --steps timed decodes; roofline with the algorithmic 0.25 + 20 * 71 = 1420 B/bp; the reference binary with --UTR=on
+    timed beside it on one pinned core (a bounded sample)."""
+    import augustus_amd as ax
+    import torch
+    from helpers import REF_AUGUSTUS, write_fasta
+    model = ax.Model(cfg, "human", UTR="on")
+    S = model.n_states
+    d = ax.Decoder(model, local)
+    seqs = synth_contigs(a.utr_contigs, a.utr_contig_len, SEED0 + 555)
+    bases = sum(len(x) for x in seqs)
+    b = ax.Batch(d, seqs)
+    b.decode(sync=True)
+    b.decode(sync=True)
+    for _ in range(a.warmup):
+        b.decode(sync=True)
+    torch.cuda.synchronize()
+    ms = {"trellis": [], "prep": [], "back": []}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        b.decode(sync=False)
+        k = b.kernel_ms()
+        ms["trellis"].append(k["trellis_ms"]); ms["prep"].append(k["prep_ms"]); ms["back"].append(k["backtrace_ms"])
+    ax._check(ax.lib().augx_batch_sync(d._h))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(r.status == 0 for r in b.paths()), "UTR decode failed"
+    b.close(); d.close()
+    tr_s = float(np.mean(ms["trellis"])) / 1e3
+    achieved = (0.25 + 20.0 * S) * bases / tr_s / 1e9
+    out = {"value": bases * a.steps / dt / 1e6, "unit": "Mbp/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps,
+           "config": {"workload": "synthetic uniform-random DNA, %d contigs x %d bp, --species=human --UTR=on ab initio (%d states, sample=0)"
+                                  % (a.utr_contigs, a.utr_contig_len, S)},
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                        "kernel": "kDense<4,0>", "kernel_ms": tr_s * 1e3, "prep_ms": float(np.mean(ms["prep"])), "backtrace_ms": float(np.mean(ms["back"])),
+                        "positions_per_s_per_piece": a.utr_contig_len / tr_s}}
+    if not a.no_cpu_baseline and os.path.exists(REF_AUGUSTUS):
+        env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg)
+        core = sorted(os.sched_getaffinity(0))[0]
+        with tempfile.TemporaryDirectory() as dd:
+            def run(fa):
+                t1 = time.time()
+                ok = subprocess.call(["taskset", "-c", str(core), REF_AUGUSTUS, "--species=human", "--UTR=on", fa], stdout=subprocess.DEVNULL,
+                                     stderr=subprocess.DEVNULL, env=env) == 0
+                return time.time() - t1, ok
+            tiny = os.path.join(dd, "tiny.fa")
+            write_fasta(tiny, [("tiny", synth_contigs(1, 2000, 998)[0].decode())])
+            t_load, _ = run(tiny)
+            one = os.path.join(dd, "one.fa")
+            nbp = min(a.cpu_sample_bp, 300000)
+            write_fasta(one, [("sample", synth_contigs(1, nbp, 999)[0].decode())])
+            t1, ok = run(one)
+            out["cpu_baseline"] = {"value": nbp / 1e6 / max(t1 - t_load, 1e-9), "unit": "Mbp/s", "cores": 1, "kind": "reference", "ok": ok,
+                                   "sample": "1 contig x %d bp uniform-random DNA, --species=human --UTR=on, reference binary pinned to one core, "
+                                             "wall-clock minus parameter load" % nbp}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,6 +293,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-strong", action="store_true")
+    ap.add_argument("--no-utr", action="store_true", help="skip the --UTR=on leg (the 71-state model, BASELINE config 4's trellis)")
+    ap.add_argument("--utr-contigs", type=int, default=256)
+    ap.add_argument("--utr-contig-len", type=int, default=160000)
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -388,6 +451,8 @@ def main():
                 out.update(e2e_legs(cfg, model, local, rank_contigs("weak", 0, 1, a.contigs, a.contig_len)))
             if not a.no_cpu_baseline:  # the reference's CPU path, timed beside it (rank 0, N = 1 only)
                 out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_sample_bp, a.cpu_host_sample_bp)
+            if not a.no_utr:
+                out["utr"] = utr_leg(cfg, local, a)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

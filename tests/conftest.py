@@ -9,3 +9,16 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "needs_ref: compares with the real reference built under oracle/_ref")
+
+
+def pytest_runtest_setup(item):
+    if item.get_closest_marker("needs_ref") is None:
+        return
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    if os.path.exists(os.path.join(ref, "ref_harness")) and os.path.exists(os.path.join(ref, "augustus_ref")):
+        return
+    msg = "oracle/_ref/{ref_harness,augustus_ref} missing: build them where /root/reference exists (make -C oracle) and ship the working tree"
+    if item.get_closest_marker("gpu") is not None or os.environ.get("AUGX_REQUIRE_REF") == "1":
+        pytest.fail(msg + " -- the parity suite does not pass without its checker")
+    pytest.skip(msg)

@@ -30,6 +30,12 @@ CFGS = {
     # content model (no intron model to tie it to); human: several GC classes inside a piece
     "human_intronless": ("human", ["--genemodel=intronless", "--softmasking=0"]),
     "fly_intronless": ("fly", ["--genemodel=intronless", "--UTR=off", "--sample=0"]),
+    # --UTR=on: the 71-state model with untranslated regions (dense kernels); human: two GC classes, tss / tts / exon lines;
+    # fly: UTR on is the species' default, soft-masking bonus on; the UTR lines in their own format and as GFF3
+    "human_utr": ("human", ["--UTR=on"]),
+    "human_utr_nosm": ("human", ["--UTR=on", "--softmasking=0"]),
+    "fly_utr": ("fly", ["--sample=0"]),
+    "fly_utr_print": ("fly", ["--sample=0", "--softmasking=0", "--print_utr=on", "--gff3=on", "--introns=on"]),
 }
 
 

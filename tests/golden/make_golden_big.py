@@ -37,6 +37,10 @@ BIG_CFGS = {
     "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
     "human_sampled": ("genome", "human", ["--sample=100"]),   # one 1 Mbp piece, two GC classes with ten steps, soft-masking, sampling
     "fly_single": ("genome", "fly", ["--singlestrand=true", "--UTR=off", "--sample=0"]),    # 24-state model, both runs of five 200 kb pieces
+    # BASELINE config 4 stand-in: the 71-state model with UTR states at the fly model's own 200 kb pieces
+    "fly_utr": ("genome", "fly", ["--sample=0"]),            # UTR on (the species' default), soft-masking bonus, cut chain
+    "fly_default": ("genome", "fly", []),                    # every default of the species: UTR on, sample 100, soft-masking
+    "human_utr": ("genome", "human", ["--UTR=on"]),          # one 1 Mbp piece with two GC classes
 }
 
 

@@ -19,6 +19,12 @@ REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 REF_AUGUSTUS = os.path.join(ROOT, "oracle", "_ref", "augustus_ref")
 EMU_LIB = os.path.join(ROOT, "build", "libaugx_emu.so")
 
+# tests that compare with the REAL reference (oracle/_ref, built by oracle/Makefile where /root/reference exists; the binaries
+# travel to the GPU box with the working tree).  Without them such a test is skipped on the CPU -- and FAILS in the GPU suite or
+# with AUGX_REQUIRE_REF=1 (tests/conftest.py): a parity run must not go green because its checker was missing.
+import pytest
+needs_ref = pytest.mark.needs_ref
+
 _cfg_dir = None
 
 
@@ -193,6 +199,11 @@ GOLDEN_CFGS = {
     "saccharomyces": ("saccharomyces", {"UTR": "off", "sample": "0", "softmasking": "0"}),
     "human_intronless": ("human", {"genemodel": "intronless", "softmasking": "0"}),          # 3 states; several GC classes in a piece
     "fly_intronless": ("fly", {"genemodel": "intronless", "UTR": "off", "sample": "0"}),     # with the soft-masking bonus
+    # --UTR=on: the 71-state model with untranslated regions (dense kernels, device/dense.h)
+    "human_utr": ("human", {"UTR": "on"}),
+    "human_utr_nosm": ("human", {"UTR": "on", "softmasking": "0"}),
+    "fly_utr": ("fly", {"sample": "0"}),                                                    # UTR on is the species' default
+    "fly_utr_print": ("fly", {"sample": "0", "softmasking": "0", "print_utr": "on", "gff3": "on", "introns": "on"}),
 }
 
 

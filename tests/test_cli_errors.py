@@ -27,7 +27,7 @@ CASES = [
 ]
 
 
-@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not built (needs /root/reference)")
+@needs_ref
 @pytest.mark.parametrize("args", CASES, ids=[" ".join(c) for c in CASES])
 def test_cli_errors_match_reference(tmp_path, args):
     fa = str(tmp_path / "in.fa")

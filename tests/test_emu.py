@@ -191,7 +191,7 @@ def _forward_records():
                                      "trunc_right", "trunc_both", "revcomp", "softmask_rand")]
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
+@needs_ref
 @pytest.mark.parametrize("cfg", ["human_nosm", "human", "fly", "arabidopsis"])
 def test_emulated_forward_matches_reference(tmp_path, cfg):
     """the forward algorithm (groundwork of posterior sampling; device/kernels.h: forwardPiece) against every forward variable
@@ -214,7 +214,7 @@ def test_emulated_forward_matches_reference(tmp_path, cfg):
         assert r[6] >= r[1] and r[6] - r[1] < 0.01 * len(seq) + 5
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
+@needs_ref
 def test_emulated_exact_mode_viterbi_cells_with_several_gc_classes(tmp_path, monkeypatch):
     """exact mode (augx_decoder_set_exact; AUGX_EXACT_MULTICLASS in the emulator): after a first trellis run the reference's snippet
     cache around the class steps is replayed from which donor-site values are alive, the candidate terms concerned are rebuilt and
@@ -242,7 +242,7 @@ def test_emulated_exact_mode_viterbi_cells_with_several_gc_classes(tmp_path, mon
             assert [(b, e2, emu_state_type(m.tables_ptr, st)) for b, e2, st in e[2]] == r["path"], name
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
+@needs_ref
 @pytest.mark.parametrize("seed", [901, 909, 916])
 def test_emulated_exact_mode_randomised(tmp_path, monkeypatch, seed):
     """random records of GC-shifted stretches, real DNA and N runs (two to four GC classes per record) for the human and the
@@ -402,7 +402,7 @@ def test_emulated_sampling_with_noinframestop_is_the_reference_binarys():
     assert format_gff_sampled(m, recs, paths, [r[7] for r in res]) == gold
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not built (needs /root/reference)")
+@needs_ref
 def test_emulated_forward_with_several_gc_classes_matches_reference(tmp_path, monkeypatch):
     """pieces with several GC classes: near a class step the reference's short-intron interiors are products of cached chunks scored
     under different classes (SnippetProbs is not emptied at a step); device/snipmemo.h replays the cache from which cells are alive.
@@ -480,3 +480,28 @@ def test_emulated_segments_randomised(monkeypatch, seed):
         if rc == 0:
             assert r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
             assert set(s) == {"N"} or np.array_equal(r[3], V)
+
+
+@needs_ref
+@pytest.mark.parametrize("species,opts", [("human", {"UTR": "on", "softmasking": "0"}), ("fly", {})])
+def test_emulated_utr_forward_and_sampling_match_the_reference(tmp_path, species, opts):
+    """the 71-state model through the dense kernels (device/dense.h): every forward variable of the REAL reference within 1e-9
+    (the same cells alive) and its sampled state paths, draw for draw -- UTR exon candidates are evaluated by the kernel and, for
+    the sampler, on the host from the same site lists"""
+    m = ax.Model(config_path(), species, sample="100", **opts)
+    S = m.n_states
+    assert S == 71
+    ex = dict(golden_inputs())
+    recs = [(k, ex[k]) for k in ("HS04636", "HS08198", "short600", "trunc_both", "trunc_right", "iupac")] + [("rnd", random_dna(12000, 77))]
+    fa = str(tmp_path / "x.fa")
+    write_fasta(fa, recs)
+    extra = ["--%s=%s" % kv for kv in opts.items()]
+    mats = ref_forward(fa, species, extra)
+    smp = ref_samples(fa, species, extra, n=4)
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], S, forward=True, samples=4)
+    for (name, seq), R, rs, e in zip(recs, mats, smp, res):
+        F, esm = e[5], e[7]
+        assert np.array_equal(np.isfinite(R[1:]), np.isfinite(F[1:])), name
+        both = np.isfinite(R) & np.isfinite(F)
+        assert np.all(np.abs(R[both] - F[both]) <= 1e-9 * np.abs(R[both]) + 5e-9), name
+        assert [[tuple(x) for x in r] for r in rs] == [list(p) for p in esm], name

@@ -40,6 +40,9 @@ BIG = {  # tests/golden/make_golden_big.py: BIG_CFGS
     "fly_intronless": ("genome", "fly", ["--genemodel=intronless", "--UTR=off", "--sample=100", "--softmasking=0"]),  # + sampling
     "fly_single": ("genome", "fly", ["--singlestrand=true", "--UTR=off", "--sample=0"]),    # 24-state model, both runs of five 200 kb pieces
     "human_sampled": ("genome", "human", ["--sample=100"]),   # one 1 Mbp piece, two GC classes with ten steps, soft-masking, sampling
+    # BASELINE config 4 stand-in: the 71-state model with UTR states (dense kernels) at the fly model's own 200 kb pieces
+    "fly_utr": ("genome", "fly", ["--sample=0"]),            # UTR on (the species' default), soft-masking bonus, cut chain
+    "fly_default": ("genome", "fly", []),                    # every default of the species: UTR on, sample 100, soft-masking
 }
 
 
@@ -83,7 +86,7 @@ def test_full_size_piece_cells_and_reference_score(monkeypatch, big_inputs, cfg)
     assert np.array_equal(b.cells(0), V)
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not present")
+@needs_ref
 def test_full_size_multiclass_piece_exact_mode_every_cell_is_the_references(monkeypatch, big_inputs, tmp_path):
     """the 1 Mbp real-DNA piece with the human model (two GC classes, ten class steps inside the piece) in exact mode
     (augx_decoder_set_exact: the reference's snippet cache around the steps replayed, the trellis run again): EVERY Viterbi variable
@@ -126,7 +129,7 @@ def _ladder_cases():
     }
 
 
-@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not present")
+@needs_ref
 @pytest.mark.parametrize("species,extra", [("human", []), ("fly", ["--UTR=off", "--sample=0"])])
 @pytest.mark.parametrize("maxpiece", [20000, 60000])
 def test_cli_cut_finder_ladder_matches_reference(tmp_path, species, extra, maxpiece):
@@ -176,7 +179,7 @@ def test_cli_two_devices_same_output(tmp_path):
     assert outs[0] == outs[1] and any("\tgene\t" in l for l in outs[0])
 
 
-@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not present")
+@needs_ref
 @pytest.mark.parametrize("extra", [["--uniqueGeneId=true"], ["--genemodel=complete"], ["--protein=off", "--start=off", "--stop=off"],
                                    ["--cds=off", "--introns=on"], ["--stopCodonExcludedFromCDS=true"]])
 def test_cli_more_options_match_reference(tmp_path, extra):
@@ -192,7 +195,7 @@ def test_cli_more_options_match_reference(tmp_path, extra):
     assert ours.stderr == ref.stderr
 
 
-@pytest.mark.skipif(not os.path.exists(REF_AUGUSTUS), reason="oracle/_ref not present")
+@needs_ref
 def test_cli_outfile_errfile_stdin_and_config_next_to_binary(tmp_path):
     """--outfile / --errfile, FASTA on standard input ('-'), and the config directory found relative to the executable
     (<dir of the binary>/../config, reference src/properties.cc:116-135) when neither the option nor the variable is given"""

@@ -265,7 +265,7 @@ def test_gpu_segment_parallel_trellis(monkeypatch, env, species):
         assert r.ln_viterbi == lnv and r.states == path, i
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HARNESS), reason="oracle/_ref not present")
+@needs_ref
 @pytest.mark.parametrize("cfg", ["human_nosm", "fly"])
 def test_gpu_forward_matches_reference(tmp_path, cfg):
     """the forward algorithm on the device (augx_batch_forward; groundwork of posterior sampling) against every forward variable

@@ -60,3 +60,43 @@ def test_gpu_utr_full_size_piece():
     r, = d.decode([seq])
     rc, lnv, path, _, _ = twin_decode(m.tables_ptr, seq, m.n_states)
     assert r.status == 0 and r.ln_viterbi == lnv and r.states == path
+
+
+EXE = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
+
+
+def _run_cli(args, fa):
+    import subprocess
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE] + args + [fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stderr == ""
+    return r.stdout
+
+
+def test_cli_utr_reproduces_the_golden_file_the_reference_holds(tmp_path):
+    """`augustus --species=human --UTR=on --softmasking=0 examples/example.fa`: the one golden file of this path in the reference's
+    own test suite (tests/short/examples/expected_results/test_utr_on/aug_utr_on.gff, committed as ref_held_aug_utr_on.gff),
+    compared as the reference's test does (everything from the first '# ----- prediction' line on)"""
+    recs = golden_inputs()[:2]
+    assert [r[0] for r in recs] == ["HS04636", "HS08198"]
+    fa = str(tmp_path / "example.fa")
+    write_fasta(fa, recs)
+    out = _run_cli(["--species=human", "--UTR=on", "--softmasking=0"], fa).splitlines()
+    i0 = [k for k, l in enumerate(out) if "# ----- prediction" in l][0]
+    ours = out[i0:]
+    held = open(os.path.join(GOLDEN, "ref_held_aug_utr_on.gff")).read().splitlines()
+    assert len(ours) == len(held)
+    for a, b in zip(ours, held):
+        if a != b:  # the only line that may differ is the echoed command line (paths)
+            assert b.startswith("# ") and "--species=human" in b and "--UTR=on" in b, (a, b)
+
+
+@pytest.mark.parametrize("cfg", ["human_utr", "human_utr_nosm", "fly_utr", "fly_utr_print"])
+def test_cli_utr_gff_identical_to_reference(tmp_path, cfg):
+    """the executable with UTR prediction on all golden inputs: GFF byte-identical to the reference binary's (tss / tts / exon
+    lines, UTR lines in their own format, GFF3, the evidence block with the UTR counts)"""
+    species, opts = GOLDEN_CFGS[cfg]
+    fa = os.path.join(GOLDEN, "inputs.fa")
+    out = _run_cli(["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()], fa)
+    assert gff_body(out) == golden_gff(cfg)
