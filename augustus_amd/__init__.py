@@ -20,6 +20,7 @@ AUGX_E_HIP = -4
 AUGX_E_UNSUPPORTED = -5
 AUGX_E_NOPATH = -6
 AUGX_E_NOMEM = -7
+AUGX_E_RANGE = -8
 
 
 class AugxError(RuntimeError):

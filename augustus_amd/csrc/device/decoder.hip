@@ -17,6 +17,7 @@
 #include <cstring>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <system_error>
 #include <vector>
@@ -405,36 +406,62 @@ struct augx_decoder {
     std::multimap<size_t, void *> pool;
     std::unordered_map<void *, size_t> live;
     size_t pooledBytes = 0;
+    std::mutex poolMu;        // (another decoder of the same device may empty this pool when its own allocation fails)
     bool dense = false;        // the model is decoded by the dense kernels (dense.h)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
 namespace {
 int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists); // (below, with the forward algorithm)
-void poolRelease(augx_decoder *d) {
+// every decoder of the process (several may share a device: augx_decoder_set_share, the bench's resident batches): when an
+// allocation fails, the buffers the OTHER decoders of the device keep for re-use are given back to the runtime as well
+std::mutex g_regMu;
+std::vector<augx_decoder *> g_decoders;
+constexpr size_t POOL_CAP_BYTES = (size_t)64 << 30; // a decoder keeps at most this much for re-use (288 GB of HBM per device)
+void poolReleaseLocked(augx_decoder *d) {
     for (auto &kv : d->pool) (void)hipFree(kv.second);
     d->pool.clear();
     d->pooledBytes = 0;
 }
+void poolRelease(augx_decoder *d) {
+    std::lock_guard<std::mutex> lk(d->poolMu);
+    poolReleaseLocked(d);
+}
 hipError_t devMalloc(augx_decoder *d, void **out, size_t bytes) {
     if (bytes == 0) bytes = 1;
-    auto it = d->pool.lower_bound(bytes);
-    if (it != d->pool.end() && it->first <= bytes + bytes / 4 + 4096) { // a pooled buffer that is not wastefully large
-        *out = it->second;
-        d->live[*out] = it->first;
-        d->pooledBytes -= it->first;
-        d->pool.erase(it);
-        return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(d->poolMu);
+        auto it = d->pool.lower_bound(bytes);
+        if (it != d->pool.end() && it->first <= bytes + bytes / 4 + 4096) { // a pooled buffer that is not wastefully large
+            *out = it->second;
+            d->live[*out] = it->first;
+            d->pooledBytes -= it->first;
+            d->pool.erase(it);
+            return hipSuccess;
+        }
     }
     hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess && !d->pool.empty()) { (void)hipGetLastError(); poolRelease(d); e = hipMalloc(out, bytes); }
-    if (e == hipSuccess) d->live[*out] = bytes;
+    if (e != hipSuccess) { // this decoder's pool first, then those of the other decoders on the device
+        (void)hipGetLastError();
+        poolRelease(d);
+        e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> rk(g_regMu);
+            for (augx_decoder *o : g_decoders)
+                if (o != d && o->device == d->device) poolRelease(o);
+            e = hipMalloc(out, bytes);
+        }
+    }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(d->poolMu); d->live[*out] = bytes; }
     return e;
 }
 void devFree(augx_decoder *d, void *p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lk(d->poolMu);
     auto it = d->live.find(p);
     if (it == d->live.end()) { (void)hipFree(p); return; }
+    if (d->pooledBytes + it->second > POOL_CAP_BYTES) { (void)hipFree(p); d->live.erase(it); return; } // (the pool is bounded)
     d->pool.emplace(it->second, p);
     d->pooledBytes += it->second;
     d->live.erase(it);
@@ -584,6 +611,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
         return AUGX_OK;
     }();
     if (rc) { augx_decoder_destroy(d); return rc; }
+    { std::lock_guard<std::mutex> rk(g_regMu); g_decoders.push_back(d); }
     *out = d;
     return AUGX_OK;
 }
@@ -617,6 +645,7 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
 
 void augx_decoder_destroy(augx_decoder *d) {
     if (!d) return;
+    { std::lock_guard<std::mutex> rk(g_regMu); g_decoders.erase(std::remove(g_decoders.begin(), g_decoders.end(), d), g_decoders.end()); }
     (void)hipSetDevice(d->device);
     poolRelease(d);
     for (void *p : d->tableBufs) (void)hipFree(p);
@@ -1349,9 +1378,28 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     }
     if (hi <= lo) lo = hi = 0;
     if (hi > b->nItems && b->nItems) { setLastError("augx_batch_sample: candidate ranges outside the candidate buffer"); return AUGX_E_HIP; }
-    P.item0 = lo;
-    P.items.resize((size_t)(hi - lo) + 1);
-    if (hi > lo) HIP_TRY(hipMemcpy(P.items.data(), V.items + lo, sizeof(Item) * (size_t)(hi - lo), hipMemcpyDeviceToHost));
+    uint64_t own = 0;
+    for (int q = 0; q < nBlocks; q++) own += P.blkCnt[(size_t)q * 2 + 1];
+    if (hi - lo <= 4 * own + 65536) { // the piece's ranges lie close together: one copy of the span
+        P.item0 = lo;
+        P.items.resize((size_t)(hi - lo) + 1);
+        if (hi > lo) HIP_TRY(hipMemcpy(P.items.data(), V.items + lo, sizeof(Item) * (size_t)(hi - lo), hipMemcpyDeviceToHost));
+    } else { // scattered over the batch's buffer (many pieces decoded side by side): run by run of contiguous blocks, packed
+        P.item0 = 0;
+        P.items.resize((size_t)own + 1);
+        uint64_t w = 0;
+        for (int q = 0; q < nBlocks;) {
+            const uint64_t a0 = P.blkOff[(size_t)q * 2 + 1];
+            uint64_t len = P.blkCnt[(size_t)q * 2 + 1];
+            int q2 = q + 1;
+            while (q2 < nBlocks && (P.blkCnt[(size_t)q2 * 2 + 1] == 0 || P.blkOff[(size_t)q2 * 2 + 1] == a0 + len)) { len += P.blkCnt[(size_t)q2 * 2 + 1]; q2++; }
+            if (len) HIP_TRY(hipMemcpy(P.items.data() + w, V.items + a0, sizeof(Item) * (size_t)len, hipMemcpyDeviceToHost));
+            uint64_t at = w;
+            for (int k = q; k < q2; k++) { P.blkOff[(size_t)k * 2 + 1] = at; at += P.blkCnt[(size_t)k * 2 + 1]; }
+            w += len;
+            q = q2;
+        }
+    }
     P.termKind = b->L.termKind[piece];
     if (d->dense) { // the host view of the piece the UTR exon candidates are evaluated from (sampler.h: SamplePiece::UtrHost)
         P.dense = true;

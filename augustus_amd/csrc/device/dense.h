@@ -34,7 +34,7 @@ AUGX_HD void k1UtrTermsCalc(const DevTables &T, const BatchView &B, int64_t g, u
     const int64_t o = B.off[p];
     const int q = (int)(g - o - 1), n = B.len[p];
     for (int i = 0; i < NUFX + NUCNT; i++) out[i] = 0;
-    if (q < 0 || q >= n || B.cls[p] < 0) return;
+    if (q < 0 || q >= n || B.cls[p] < 0 || !T.utr) return; // (a dense model without UTR states: nothing to count)
     Piece P;
     P.t = &T; P.n = n; P.c = baseClass(B, p, g); P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
     P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
@@ -222,7 +222,7 @@ AUGX_HD void k1UtrSignals(const DevTables &T, const BatchView &B, int64_t g, con
     const int q = (int)(g - o - 1), n = B.len[p];
     double *us = B.usig + g * NUSIG;
     for (int i = 0; i < NUSIG; i++) us[i] = AUGX_NINF;
-    if (q < 0 || q >= n || B.cls[p] < 0) return;
+    if (q < 0 || q >= n || B.cls[p] < 0 || !T.utr) return;
     Piece P = makePieceAt(T, B, p, B.gcPlane[g]); // the class of base q
     P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
     const int up = T.tss_upwin, te = T.tss_end, dc = T.dpc, bl = T.boxlen, assWhole = T.As + 2 + T.Ae, dssWhole = T.Ds + 2 + T.De;
@@ -784,6 +784,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             }
             BLOCK_SYNC();
         };
+        if (nUv > 0) {
         FOR_THREADS(t) { // descriptors
             if (t >= WAVE && t - WAVE < BLK * DUV) {
                 const int u = t - WAVE, dj = u / DUV, slot = u % DUV, j = jb + dj, s2 = (*lp(&L.uvS[slot]));
@@ -794,12 +795,19 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             }
         }
         BLOCK_SYNC();
-        FOR_THREADS(t) { if (t == 0) { int acc = 0; (*lp(&L.udPre[0])) = 0; for (int u = 0; u < BLK * DUV; u++) { acc += L.ud[u].total; (*lp(&L.udPre[u + 1])) = acc; } } }
+        {   // inclusive prefix of the candidate counts (one wavefront; BLK * DUV <= 64 pairs with UTR states: their block size is <= 4)
+            static_assert(DUV * 4 <= WAVE, "one lane per (base, UTR exon state) pair");
+            TV(int, dsc);
+            FOR_THREADS(t) { const int u = t - WAVE; TX(dsc) = (t >= WAVE && u < BLK * DUV && u < WAVE) ? L.ud[u].total : 0; }
+            FOR_WAVES(w) { if (w == 1) waveInclScan(dsc, w); }
+            FOR_THREADS(t) { const int u = t - WAVE; if (t >= WAVE && u < WAVE) { if (u == 0) (*lp(&L.udPre[0])) = 0; if (u < BLK * DUV) (*lp(&L.udPre[u + 1])) = TX(dsc); } }
+        }
         BLOCK_SYNC();
+        }
         itemPass(0, cntNonRT, false);
-        utrPass(false, -1);
+        if (nUv > 0) utrPass(false, -1);
         BLOCK_SYNC();
-        if (FWD) { itemPass(0, cntNonRT, true); utrPass(true, -1); BLOCK_SYNC(); }
+        if (FWD) { itemPass(0, cntNonRT, true); if (nUv > 0) utrPass(true, -1); BLOCK_SYNC(); }
         cells((1 << 1) | (1 << 3));
         // the right-truncated 3' UTR exon at the last base of the piece may begin anywhere up to that base (src/utrmodel.cc:880-884):
         // its predecessors of this very block exist only now -- the cell is made once more, from all of them
@@ -849,7 +857,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                 else if (v > tot) { tot = v; fin = i; }
             }
             if (FWD) B.lnFwd[p] = tot;
-            else { B.lnv[p] = tot; B.finalState[p] = fin; B.status[p] = fin >= 0 ? 0 : AUGX_E_NOPATH; }
+            else { B.lnv[p] = tot; B.finalState[p] = fin; B.status[p] = fin < 0 ? AUGX_E_NOPATH : fabs(tot) < AUGX_EXACT_LIMIT ? 0 : AUGX_E_RANGE; }
         }
     }
 }

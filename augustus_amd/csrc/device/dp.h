@@ -51,6 +51,7 @@ constexpr int LEN_WIN = 384;    // exon length-distribution entries cached in LD
 constexpr int LENI_MAX = 1024;  // intron length distribution cached in LDS when d < LENI_MAX
 
 #define AUGX_NINF (-INFINITY)
+#define AUGX_EXACT_LIMIT 4194304.0 /* 2^(53 - AUGX_Q_BITS): below it every sum of model terms is exact in fp64 */
 
 // one candidate of a variable-length state: everything but the predecessor's Viterbi value (kCandidates -> kTrellis)
 struct Item {

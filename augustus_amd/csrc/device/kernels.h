@@ -2752,7 +2752,12 @@ AUGX_KFN void forwardPiece(const DevTables &T, const BatchView &B, FwdLds &L, in
 // =================================================================================================
 AUGX_KFN void segFinalizePiece(const BatchView &B, int p) {
     const int s0 = B.pieceSeg0[p], K = B.pieceSeg0[p + 1] - s0, n = B.len[p];
-    if (K <= 1) { B.brkPos[s0] = n - 1; B.brkOff[s0] = 0.0; return; }
+    if (K <= 1) {
+        B.brkPos[s0] = n - 1; B.brkOff[s0] = 0.0;
+        // every addition of the decode is exact only while |ln V| < 2^(53 - AUGX_Q_BITS): a piece that improbable is an error
+        if (B.status[p] == 0 && !(fabs(B.lnv[p]) < AUGX_EXACT_LIMIT)) B.status[p] = AUGX_E_RANGE;
+        return;
+    }
     // frame k = the values segment k computed in pass 1 (frame 0 = the true values).  Fix-up k rewrote the tiles up to segStop[k]
     // in the frame of what lies before it and measured D = (that frame) - (frame behind): every converged run ends a region,
     // and the region after it is off by D more.  A fix-up that gave up was continued by pass 3 (segStop2 / segD2) -- possibly
@@ -2780,6 +2785,7 @@ AUGX_KFN void segFinalizePiece(const BatchView &B, int p) {
     for (; r < K; r++) { B.brkPos[s0 + r] = n - 1; B.brkOff[s0 + r] = off; }
     if (B.status[p] == 0) B.lnv[p] = B.lnv[p] + off;
     if (abortAny) B.status[p] = AUGX_E_HIP;
+    if (B.status[p] == 0 && !(fabs(B.lnv[p]) < AUGX_EXACT_LIMIT)) B.status[p] = AUGX_E_RANGE;
 }
 
 // =================================================================================================

@@ -274,7 +274,11 @@ inline void checkModelSupported(const augx_tables &t, int BLK) {
 }
 
 // models decoded by the dense kernels (dense.h): everything the wavefront layout of the trellis kernel was not built for
-inline bool modelIsDense(const augx_tables &t) { return t.utr != 0; }
+inline bool modelIsDense(const augx_tables &t) {
+    int nIg = 0; // (two intergenic states: --genemodel=atleastone / exactlyone)
+    for (int s = 0; s < t.S; s++) nIg += t.state_kind[s] == AUGX_K_IGENIC;
+    return t.utr != 0 || nIg > 1;
+}
 // block size of the dense kernels (dense.h): no variable-length or fixed-lag state may read a cell of its own block but through
 // the stage order of densePiece (fixed-lag states, early chains, candidates, late chains, reverse terminal exons)
 inline int chooseDenseBlock(const augx_tables &t) {
@@ -313,6 +317,7 @@ inline int chooseDenseBlock(const augx_tables &t) {
     if (nChain > 16 || nFix > 24 || nUv > 16) throw std::runtime_error("augx: state graph too large for the dense kernels");
     int b = 8;
     if (const char *e = getenv("AUGX_BLK")) b = atoi(e);
+    if (t.utr && b > 4) b = 4; // (densePiece holds one descriptor per (base, UTR exon state) pair of a block in one wavefront)
     while (b > 1 && b > lag) b /= 2;
     if (b < 2) throw std::runtime_error("augx: signal windows too short for the dense kernels");
     return b;

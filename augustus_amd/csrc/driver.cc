@@ -259,6 +259,7 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
             if (pr.status != 0) {
                 errmsg = pr.status == AUGX_E_UNSUPPORTED ? "piece outside what the MI355X path decodes"
                          : pr.status == AUGX_E_NOPATH    ? "No feasible path found in HMM"
+                         : pr.status == AUGX_E_RANGE     ? "piece too improbable for the exact arithmetic of the MI355X path; lower --maxDNAPieceSize"
                                                          : "device decode failed (HIP error or kernel abort; not a property of the input)";
                 continue;
             }

@@ -447,8 +447,7 @@ struct AltGeneBuild { // reference AltGene, src/gene.cc:2676-2731
 // SequenceFeatureCollection::joinGenesFromPredRuns with its one run of an ab initio prediction, src/extrinsicinfo.cc:1616-1657;
 // NAMGene::doViterbiPiecewise, src/namgene.cc:627-650): --maxtracks, overlapping transcripts of one strand and reading frame
 // become the alternatives of one gene, the genes are sorted by coding start, the transcripts of a gene by their mean state
-// probability.  (AltGene::deleteSuboptimalTranscripts drops nothing here: without hints every "% supported" is 0, and two
-// transcripts with the same CDS and no UTR are the same transcript.)
+// probability.  (AltGene::deleteSuboptimalTranscripts: see below; without UTR it drops nothing.)
 // Where the reference's order rests on the addresses of its Transcript objects (list<Transcript*>::sort() without a comparison in
 // groupTranscriptsToGenes, src/gene.cc:3196) the order of creation -- Viterbi path first, then the sampled paths -- is used: it
 // decides between transcripts of one gene with EQUAL mean state probability only.
@@ -487,19 +486,69 @@ std::vector<GeneOut> groupToGenes(const Model &m, const std::vector<Transcript> 
         }
     }
     // groupTranscriptsToGenes, src/gene.cc:3191-3240
-    std::stable_sort(list.begin(), list.end(), [](const Transcript *a, const Transcript *b) { return a->serial < b->serial; });
-    std::vector<AltGeneBuild> agl;
-    for (const Transcript *t : list) {
-        long first = -1;
-        for (size_t i = 0; i < agl.size();) {
-            if (!agl[i].overlaps(t)) { i++; continue; }
-            if (first < 0) { agl[i].add(t); first = (long)i; i++; }
-            else { // the transcript ties another gene to the first one
-                for (const Transcript *o : agl[i].tx) agl[(size_t)first].add(o);
-                agl.erase(agl.begin() + (long)i);
+    auto group = [](std::vector<const Transcript *> &list) {
+        std::stable_sort(list.begin(), list.end(), [](const Transcript *a, const Transcript *b) { return a->serial < b->serial; });
+        std::vector<AltGeneBuild> agl;
+        for (const Transcript *t : list) {
+            long first = -1;
+            for (size_t i = 0; i < agl.size();) {
+                if (!agl[i].overlaps(t)) { i++; continue; }
+                if (first < 0) { agl[i].add(t); first = (long)i; i++; }
+                else { // the transcript ties another gene to the first one
+                    for (const Transcript *o : agl[i].tx) agl[(size_t)first].add(o);
+                    agl.erase(agl.begin() + (long)i);
+                }
             }
+            if (first < 0) { agl.emplace_back(); agl.back().add(t); }
         }
-        if (first < 0) { agl.emplace_back(); agl.back().add(t); }
+        return agl;
+    };
+    std::vector<AltGeneBuild> agl = group(list);
+    // AltGene::deleteSuboptimalTranscripts, src/gene.cc:2789-2840 (src/extrinsicinfo.cc:1643-1651): without hints no transcript is
+    // better supported than another; what goes is a transcript ALMOST identical to a more probable one of its gene -- the same
+    // coding exons, the same UTR exons but for a transcription start / end within almost_identical_maxdiff bases -- or, with
+    // --uniqueCDS, one with the coding exons of a more probable one.  Then the rest is grouped again.
+    {
+        const bool uniqueCDS = m.opt.getBool("uniqueCDS", false);
+        const long maxdiff = m.opt.getInt("/Constant/almost_identical_maxdiff", 10);
+        auto sameCDS = [](const Transcript &a, const Transcript &b) {
+            if (a.exons.size() != b.exons.size()) return false;
+            for (size_t i = 0; i < a.exons.size(); i++)
+                if (a.exons[i].begin != b.exons[i].begin || a.exons[i].end != b.exons[i].end) return false;
+            return true;
+        };
+        // (the end that may differ: the begin of the first exon of the UTR the transcript starts with on its strand, the end of
+        // the last exon of the UTR it ends with)
+        auto nearUtr = [&](const std::vector<BioState> &a, const std::vector<BioState> &b, bool firstBeginFree, bool lastEndFree) {
+            if (a.size() != b.size()) return false;
+            for (size_t i = 0; i < a.size(); i++) {
+                if (a[i].begin != b[i].begin && !(firstBeginFree && i == 0 && std::labs(a[i].begin - b[i].begin) <= maxdiff)) return false;
+                if (a[i].end != b[i].end && !(lastEndFree && i + 1 == a.size() && std::labs(a[i].end - b[i].end) <= maxdiff)) return false;
+            }
+            return true;
+        };
+        auto almostIdentical = [&](const Transcript &a, const Transcript &b) { // Gene::almostIdenticalTo, src/gene.cc:1475-1512
+            return a.plus == b.plus && sameCDS(a, b) && nearUtr(a.utr5exons, b.utr5exons, a.plus, !a.plus) &&
+                   nearUtr(a.utr3exons, b.utr3exons, !a.plus, a.plus);
+        };
+        std::vector<const Transcript *> kept;
+        bool dropped = false;
+        for (const AltGeneBuild &ag : agl) {
+            std::vector<char> dead(ag.tx.size(), 0);
+            for (size_t i = 0; i < ag.tx.size(); i++)
+                for (size_t j = 0; j < ag.tx.size(); j++) {
+                    if (i == j) continue;
+                    const Transcript &a = *ag.tx[i], &b = *ag.tx[j];
+                    const double p1 = a.meanStateProb(), p2 = b.meanStateProb();
+                    const long lengthdiff = (a.geneEnd() - a.geneBegin()) - (b.geneEnd() - b.geneBegin());
+                    const bool better = p1 > p2 || (p1 == p2 && lengthdiff > 0);
+                    if (better && (almostIdentical(a, b) || (uniqueCDS && sameCDS(a, b)))) dead[j] = 1;
+                }
+            for (size_t i = 0; i < ag.tx.size(); i++)
+                if (dead[i]) dropped = true;
+                else kept.push_back(ag.tx[i]);
+        }
+        if (dropped) agl = group(kept);
     }
     std::stable_sort(agl.begin(), agl.end(), [](const AltGeneBuild &a, const AltGeneBuild &b) { return a.mincodstart < b.mincodstart; });
     std::vector<GeneOut> genes;

@@ -329,8 +329,8 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     if (utr && (singleStrand || !(genemodel == "partial" || genemodel == "complete")))
         throw ConfigError("UTR only implemented with shadow and partial or complete."); // (reference src/properties.cc:363-365)
     if (nc) throw UnsupportedError("--nc=on is outside the MI355X hot path");
-    if (genemodel != "partial" && genemodel != "complete" && genemodel != "intronless")
-        throw UnsupportedError("--genemodel=" + genemodel + " is outside the MI355X hot path (partial|complete|intronless only)");
+    if (genemodel == "bacterium")
+        throw UnsupportedError("--genemodel=bacterium (overlapping genes, Constant::overlapmode) is outside the MI355X hot path");
     if (opt.has("hintsfile")) throw UnsupportedError("--hintsfile (extrinsic evidence) is outside the MI355X ab-initio hot path");
     if (opt.has("proteinprofile")) throw UnsupportedError("--proteinprofile (PPX) is outside the MI355X ab-initio hot path");
     if (opt.getBool("mea", false)) throw UnsupportedError("--mea=1 is outside the MI355X ab-initio hot path");
@@ -346,7 +346,9 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     std::string strandName = singleStrand ? "singlestrand" : "shadow";
     std::string transFile = "trans_" + strandName + "_" + genemodel + (utr ? "_utr" : "") + ".pbl";
     opt.set("/NAMGene/TransFile", transFile);
-    opt.readFile(configPath + "model/states_" + strandName + (genemodel == "intronless" ? "_intronless" : utr ? "_utr" : "") + ".cfg", configPath);
+    // (reference src/properties.cc:376-392: two intergenic states for atleastone / exactlyone)
+    const bool twoIgenic = genemodel == "atleastone" || genemodel == "exactlyone";
+    opt.readFile(configPath + "model/states_" + strandName + (twoIgenic ? "_2igenic" : genemodel == "intronless" ? "_intronless" : utr ? "_utr" : "") + ".cfg", configPath);
     t.utr = utr ? 1 : 0;
 
     // ---- constants (reference Constant::init, src/types.cc:208-450; defaults src/types.cc:20-116)

@@ -50,7 +50,7 @@ int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *
     if (rc) return rc;
     std::vector<int> rcs(n_dec, 0);
     std::vector<std::string> errs(n_dec);
-    auto work = [&](int d) {
+    auto workBody = [&](int d) {
         // pieces of this device in input order, decoded in batches bounded by what the device's free memory holds
         std::vector<int> mine;
         for (int i = 0; i < n; i++)
@@ -74,6 +74,11 @@ int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *
             for (size_t k = 0; k < batch.size(); k++) out[mine[i + k]] = res[k];
             i = j;
         }
+    };
+    // (an exception on a worker thread -- allocation, thread creation -- becomes this device's error, not the end of the process)
+    auto work = [&](int d) {
+        try { workBody(d); }
+        catch (const std::exception &e) { rcs[d] = AUGX_E_NOMEM; errs[d] = std::string("augx_decode_sharded: ") + e.what(); }
     };
     if (n_dec == 1)
         work(0);
@@ -118,10 +123,10 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
     std::mutex mu;
     std::condition_variable cv;
     int turn = 0;
-    bool failed = false;
+    std::atomic<bool> failed{false}; // (read outside the lock by the workers)
     std::vector<int> rcs(n_dec, 0);
     std::vector<std::string> errs(n_dec);
-    auto work = [&](int d) {
+    auto workBody = [&](int d) {
         for (size_t k = (size_t)d; k < batches.size(); k += (size_t)n_dec) {
             const int first = batches[k].first, cnt = batches[k].second - batches[k].first;
             augx_batch *b = nullptr;
@@ -133,13 +138,14 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
             // (it does not depend on the draws), also while earlier batches are still being sampled
             const int AHEAD = 4;
-            std::vector<std::future<std::pair<int, augx_sample_prep *>>> prep((size_t)cnt);
+            struct Prep { int rc; augx_sample_prep *h; std::string err; }; // (augx_last_error is thread-local: the text travels with the result)
+            std::vector<std::future<Prep>> prep((size_t)cnt);
             auto launch = [&](int p) {
                 if (p >= cnt || rc || !n_samples || out[first + p].status != AUGX_OK) return;
                 auto job = [&, p]() {
                     augx_sample_prep *h = nullptr;
-                    const int r = augx_batch_sample_prepare(decs[d], b, p, &h);
-                    return std::make_pair(r, h);
+                    const int r2 = augx_batch_sample_prepare(decs[d], b, p, &h);
+                    return Prep{r2, h, r2 ? std::string(augx_last_error()) : std::string()};
                 };
                 try {
                     prep[p] = std::async(std::launch::async, job);
@@ -153,17 +159,17 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
                 cv.wait(lk, [&] { return turn == (int)k || failed; });
                 for (int p = 0; p < cnt; p++) {
                     if (!prep[p].valid()) { launch(p + AHEAD); continue; } // (no path: nothing is drawn)
-                    std::pair<int, augx_sample_prep *> pr = prep[p].get();
+                    Prep pr = prep[p].get();
                     launch(p + AHEAD);
                     if (!rc && !failed) {
-                        rc = pr.first;
-                        if (rc) errs[d] = augx_last_error(); // (thread-local: set again below if it was another thread's)
+                        rc = pr.rc;
+                        if (rc) errs[d] = pr.err;
                         if (!rc) {
-                            rc = augx_sample_prep_run(pr.second, n_samples, r, samples + (int64_t)(first + p) * n_samples);
+                            rc = augx_sample_prep_run(pr.h, n_samples, r, samples + (int64_t)(first + p) * n_samples);
                             if (rc) errs[d] = augx_last_error();
                         }
                     }
-                    augx_sample_prep_destroy(pr.second);
+                    augx_sample_prep_destroy(pr.h);
                 }
                 if (rc) { rcs[d] = rc; failed = true; if (errs[d].empty()) errs[d] = "augx_decode_sampled: fetching a piece for the sampler failed"; }
                 turn = (int)k + 1;
@@ -171,6 +177,17 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             cv.notify_all();
             if (b) augx_batch_destroy(b);
             if (rc || failed) return;
+        }
+    };
+    auto work = [&](int d) {
+        try { workBody(d); }
+        catch (const std::exception &e) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                rcs[d] = AUGX_E_NOMEM; errs[d] = std::string("augx_decode_sampled: ") + e.what();
+                failed = true;
+            }
+            cv.notify_all();
         }
     };
     if (n_dec == 1)

@@ -40,7 +40,9 @@ enum {
     AUGX_E_HIP = -4,        /* HIP runtime error                                                        */
     AUGX_E_UNSUPPORTED = -5,/* model feature outside the implemented hot path (fails loudly)            */
     AUGX_E_NOPATH = -6,     /* "No feasible path found in HMM" (reference src/namgene.cc:455-457)       */
-    AUGX_E_NOMEM = -7       /* device memory exhausted (decode fewer bases per batch)                   */
+    AUGX_E_NOMEM = -7,      /* device memory exhausted (decode fewer bases per batch)                   */
+    AUGX_E_RANGE = -8       /* |ln V| of a piece left the range in which every fp64 addition is exact (AUGX_Q_BITS): the
+                               piece is too improbable for its length -- lower --maxDNAPieceSize                  */
 };
 
 /* state kinds of the GHMM (derived from the reference's StateType, include/types.hh:492-512) */
@@ -66,7 +68,7 @@ enum {
  * significant (reference Seq2Int, include/geneticcode.hh:163-241).  NP = 4^(k+1).
  */
 typedef struct augx_tables {
-    int32_t S;                      /* number of states (47 for human/fly without UTR)                  */
+    int32_t S;                      /* number of states (47 for human/fly without UTR, 71 with, 48 with two intergenic states) */
     int32_t n_classes;              /* GC-content classes (decomp_num_steps)                            */
     int32_t k;                      /* order of the exon/intron/igenic Markov chains (all equal)        */
     int32_t W, U, As, Ae, Ds, De;   /* trans_init_window, ass_upwindow_size, ass_start/end, dss_start/end */
@@ -230,8 +232,8 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
 int augx_batch_cells(augx_decoder *d, augx_batch *b, int piece, double *out);
 /* forward algorithm of a decoded batch (reference NAMGene::viterbiAndForward with needForwardTable, src/namgene.cc:168-365,
  * the per-state `fwdsum`s): the dense ln F matrix stays on the device for the posterior sampling; the second call copies the
- * len*S matrix of one piece (-inf = absent) and ln P(sequence) to the host (tests; groundwork of --sample > 0, which the
- * executable still rejects) */
+ * len*S matrix of one piece (-inf = absent) and ln P(sequence) to the host (tests; the executable's --sample > 0 goes through
+ * augx_decode_sampled) */
 int augx_batch_forward(augx_decoder *d, augx_batch *b);
 int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *out, double *ln_p);
 /* posterior sampling (reference NAMGene::getSampledPath, src/namgene.cc:367-426, OptionsList::sample, src/vitmatrix.cc:295-320):
@@ -239,7 +241,7 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
  * every step lists its options in the reference's order, sorts them by probability and draws with
  * rand() / RAND_MAX * sum * 0.99999.  The reference draws from glibc's rand() (never seeded: seed 1), one call per step, over
  * the whole run: augx_rand is that generator (the TYPE_3 additive-feedback generator of glibc, restated), kept by the caller
- * across pieces in input order.  (Groundwork of --sample > 0, which the executable still rejects.) */
+ * across pieces in input order (the executable: one generator per run, augx_decode_sampled). */
 typedef struct augx_rand augx_rand;
 augx_rand *augx_rand_create(unsigned seed);
 int augx_rand_next(augx_rand *r);               /* == rand() of glibc after srand(seed) */

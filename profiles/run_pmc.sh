@@ -5,16 +5,18 @@
 set -e
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# hash of the kernel / host sources the profile was taken with: bench.py only quotes a profile whose hash is that of the tree it runs in
+SRC_SHA=$(python "$ROOT/profiles/source_sha.py")
 mkdir -p "$ROOT/gpurun_out"
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o t1 -- python "$ROOT/bench.py" --no-cpu-baseline --no-e2e --steps 1 --warmup 0 --inflight 1 "$@" > /tmp/pmc_$C.out 2> /tmp/pmc_$C.err || true
+  rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_$C -o t1 -- python "$ROOT/bench.py" --no-cpu-baseline --no-e2e --no-product --no-utr --steps 1 --warmup 0 --inflight 1 "$@" > /tmp/pmc_$C.out 2> /tmp/pmc_$C.err || true
 done
 F=$(find /tmp/pmc_FETCH_SIZE -name '*results.db' | head -1)
 W=$(find /tmp/pmc_WRITE_SIZE -name '*results.db' | head -1)
-python "$ROOT/profiles/summarize_pmc.py" "$F" "$W" 100000000 > "$ROOT/gpurun_out/${TAG}_hbm_traffic.json"
+python "$ROOT/profiles/summarize_pmc.py" "$F" "$W" 100000000 "$SRC_SHA" > "$ROOT/gpurun_out/${TAG}_hbm_traffic.json"
 python - "$ROOT/gpurun_out/${TAG}_hbm_traffic.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -5,14 +5,17 @@
 set -e
 TAG=$1; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# hash of the kernel / host sources the profile was taken with: bench.py only quotes a profile whose hash is that of the tree it runs in
+SRC_SHA=$(python "$ROOT/profiles/source_sha.py")
 mkdir -p "$ROOT/gpurun_out"
 export TMPDIR=/tmp
 OUT=/tmp/prof_$TAG
 rm -rf "$OUT"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT" -o t1 -- python "$ROOT/bench.py" --no-cpu-baseline --no-e2e "$@" > "$ROOT/gpurun_out/${TAG}_bench.json" 2> "$ROOT/gpurun_out/${TAG}_bench.err" || true
+rocprofv3 --kernel-trace --stats -d "$OUT" -o t1 -- python "$ROOT/bench.py" --no-cpu-baseline --no-e2e --no-product --no-utr "$@" > "$ROOT/gpurun_out/${TAG}_bench.json" 2> "$ROOT/gpurun_out/${TAG}_bench.err" || true
 DB=$(find "$OUT" -name '*results.db' | head -1)
 python "$ROOT/profiles/summarize_rocpd.py" "$DB" > "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
-echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-e2e $*" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-e2e --no-product --no-utr $*" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+echo "# source_sha: $SRC_SHA" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 cat "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 tail -1 "$ROOT/gpurun_out/${TAG}_bench.json" | cut -c1-600

@@ -121,7 +121,31 @@ def single():
         print(cfg, len(body), "gff lines")
 
 
+def genemodels():
+    """golden_genemodel_<cfg>.gff / golden_genemodel_paths_<cfg>.json: the reference with two intergenic states
+    (helpers.GENEMODEL_CFGS) on the records of inputs.fa in which such a model has a feasible path"""
+    import tempfile
+    recs = genemodel_records()
+    fa = os.path.join(tempfile.mkdtemp(), "gm.fa")
+    write_fasta(fa, recs)
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
+    for cfg, (species, opts) in GENEMODEL_CFGS.items():
+        extra = ["--%s=%s" % kv for kv in opts.items()]
+        res, err = ref_harness(fa, species, [e for e in extra if not e.startswith("--sample")] + ["--sample=0"], cfg="/root/reference/config/")
+        assert len(res) == len(recs) and all(r["lnv"] is not None for r in res), (cfg, err)
+        json.dump({"records": [{"name": r["name"], "n": r["n"], "lnv": repr(r["lnv"]), "path": r["path"]} for r in res]},
+                  open(os.path.join(HERE, "golden_genemodel_paths_%s.json" % cfg), "w"))
+        txt = subprocess.run([REF_AUGUSTUS, "--species=" + species] + extra + [fa], capture_output=True, text=True, env=env)
+        assert txt.returncode == 0 and txt.stderr == "", txt.stderr
+        body = gff_body(txt.stdout)
+        open(os.path.join(HERE, "golden_genemodel_%s.gff" % cfg), "w").write("\n".join(body) + "\n")
+        print(cfg, len(res), "records", len(body), "gff lines")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "genemodels":
+        genemodels()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "single":
         single()
         sys.exit(0)

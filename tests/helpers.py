@@ -219,6 +219,19 @@ MORE_CFGS = {
 }
 
 
+# gene models with two intergenic states (--genemodel=atleastone / exactlyone: states_shadow_2igenic.cfg, the synch state is the
+# second intergenic state; dense kernels).  Records in which such a model has no feasible path (no room for a gene) are left out:
+# the reference ends the whole run with an error there (tests/test_cli_errors.py)
+GENEMODEL_CFGS = {
+    "human_atleastone": ("human", {"genemodel": "atleastone"}),                                   # soft-masking bonus on
+    "fly_exactlyone": ("fly", {"genemodel": "exactlyone", "UTR": "off", "softmasking": "0"}),    # sample = 100 (the species' default)
+}
+
+
+def genemodel_records():
+    return [(n, s) for n, s in golden_inputs() if n not in ("allN", "short7", "short100")]
+
+
 def more_inputs():
     return read_fasta(os.path.join(GOLDEN, "inputs_more.fa"))
 

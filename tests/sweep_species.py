@@ -3,6 +3,8 @@
 kernels on the lane-loop emulator + the host gene stage against the REAL reference, species after species.
     python tests/sweep_species.py sampled [K N]     each species at its defaults (--UTR=off; sample 100 where that is the default):
                                                     GFF incl. posterior probabilities against the reference binary, four records
+    python tests/sweep_species.py utr [K N]         the species that ship UTR parameters with --UTR=on (71 states, dense kernels), at their
+                                                    own sample setting: GFF against the reference binary, four records
     python tests/sweep_species.py alternatives [K N]  the same with --alternatives-from-sampling=true --maxtracks=4 --noInFrameStop=true --sample=60
     python tests/sweep_species.py variants [K N]    --singlestrand=true / --genemodel=intronless / complete / soft-masking on:
                                                     state paths and ln Viterbi against the reference harness, three records
@@ -29,14 +31,18 @@ def species_list(k, nw):
             yield sp
 
 
-def sampled(k, nw, alt=False):
+def sampled(k, nw, alt=False, utr=False):
     byname = dict(golden_inputs())
-    recs = [(n, byname[n]) for n in ("HS04636", "multigc_levels", "rand20k_b", "trunc_both")]
+    recs = [(n, byname[n]) for n in (("HS04636", "rand20k_b", "trunc_both", "revcomp") if utr else ("HS04636", "multigc_levels", "rand20k_b", "trunc_both"))]
     fa = "/tmp/sweep_sampled_%d.fa" % k
     write_fasta(fa, recs)
     env = dict(os.environ, AUGUSTUS_CONFIG_PATH=CFG)
     for sp in species_list(k, nw):
         opts = {"UTR": "off", "softmasking": "0"}
+        if utr:  # every species that ships UTR parameters, with the 71-state model (dense kernels), at its own sample setting
+            if not any(f.endswith("utr_probs.pbl") for f in os.listdir(CFG + "species/" + sp)):
+                continue
+            opts = {"UTR": "on", "softmasking": "0"}
         if alt:
             opts.update({"alternatives-from-sampling": "true", "maxtracks": "4", "noInFrameStop": "true", "sample": "60"})
         try:
@@ -142,6 +148,8 @@ if __name__ == "__main__":
     os.environ.setdefault("AUGX_EXACT_MULTICLASS", "1")
     if what == "sampled":
         sampled(k, nw)
+    elif what == "utr":
+        sampled(k, nw, utr=True)
     elif what == "alternatives":
         sampled(k, nw, alt=True)
     elif what == "segments":

@@ -27,8 +27,8 @@ def test_model_tables_human():
 
 
 def test_unsupported_features_fail_loudly():
-    for opts in ({"UTR": "on"}, {"singlestrand": "true", "genemodel": "atleastone"}, {"hintsfile": "x.gff"}, {"genemodel": "bacterium"},
-                 {"genemodel": "exactlyone"}, {"mea": "1"}, {"contentmodels": "false"}):
+    for opts in ({"singlestrand": "true", "genemodel": "atleastone"}, {"hintsfile": "x.gff"}, {"genemodel": "bacterium"},
+                 {"mea": "1"}, {"contentmodels": "false"}, {"nc": "on", "UTR": "on"}):
         with pytest.raises(ax.AugxError) as e:
             ax.Model(config_path(), "human", **opts)
         assert e.value.code == ax.AUGX_E_UNSUPPORTED
@@ -37,6 +37,12 @@ def test_unsupported_features_fail_loudly():
     # the single-strand and the intron-less model load (24 and 3 states)
     assert ax.Model(config_path(), "human", singlestrand="true").n_states == 24
     assert ax.Model(config_path(), "human", genemodel="intronless").n_states == 3
+    # the model with untranslated regions (71 states) and the ones with two intergenic states (48)
+    assert ax.Model(config_path(), "human", UTR="on").n_states == 71
+    assert ax.Model(config_path(), "human", genemodel="exactlyone").n_states == 48
+    with pytest.raises(ax.AugxError) as e:  # (the reference's own error: src/properties.cc:363-365)
+        ax.Model(config_path(), "human", UTR="on", genemodel="exactlyone")
+    assert e.value.code == -2 and "UTR only implemented" in str(e.value)  # AUGX_E_CONFIG
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")

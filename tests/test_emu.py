@@ -505,3 +505,61 @@ def test_emulated_utr_forward_and_sampling_match_the_reference(tmp_path, species
         both = np.isfinite(R) & np.isfinite(F)
         assert np.all(np.abs(R[both] - F[both]) <= 1e-9 * np.abs(R[both]) + 5e-9), name
         assert [[tuple(x) for x in r] for r in rs] == [list(p) for p in esm], name
+
+
+@pytest.mark.parametrize("cfg", list(GENEMODEL_CFGS))
+def test_emulated_two_intergenic_states(cfg):
+    """--genemodel=atleastone / exactlyone through the dense kernels: every cell, score, path and status equal to the oracle's
+    (records without a feasible path included), and the GFF of the sampled run the reference binary's"""
+    species, opts = GENEMODEL_CFGS[cfg]
+    m = ax.Model(config_path(), species, **dict(opts, sample="0"))
+    S = m.n_states
+    recs = golden_inputs()
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], S, cells=True)
+    for (name, seq), (st, lnv, path, V, cls) in zip(recs, res):
+        rc, lnv2, path2, V2, gc = twin_decode(m.tables_ptr, seq, S, cells=True)
+        assert st == rc and (rc != 0 or (lnv == lnv2 and path == [(b, e, s) for b, e, s, t in path2])), name
+        assert np.array_equal(V, V2), name
+    assert sum(r[0] == ax.AUGX_E_NOPATH for r in res) == 3
+    # the species' defaults through the host stage (fly: sample = 100)
+    m2 = ax.Model(config_path(), species, **opts)
+    ns = int(m2.option("sample") or 0)
+    recs = genemodel_records()
+    res = emu_decode(m2.tables_ptr, [s for _, s in recs], S, samples=max(ns - 1, 0)) if ns > 1 else emu_decode(m2.tables_ptr, [s for _, s in recs], S)
+    tys = [emu_state_type(m2.tables_ptr, s) for s in range(S)]
+    paths = [[(b, e, s, tys[s]) for b, e, s in r[2]] for r in res]
+    gold = open(os.path.join(GOLDEN, "golden_genemodel_%s.gff" % cfg)).read().splitlines()
+    out = format_gff_sampled(m2, recs, paths, [r[7] for r in res]) if ns > 1 else format_gff(m2, recs, paths)
+    assert out == gold
+
+
+@needs_ref
+@pytest.mark.parametrize("species,maxdiff", [("fly", None), ("human", None), ("human", "0")])
+def test_emulated_utr_alternatives_drop_almost_identical_transcripts(tmp_path, species, maxdiff):
+    """--UTR=on --alternatives-from-sampling=true: alternatives with the coding exons of a more probable one and a transcription
+    start / end within /Constant/almost_identical_maxdiff bases of its are dropped (AltGene::deleteSuboptimalTranscripts); the
+    same transcripts as the reference binary's (human: 329 of 393 survive), in its order but for alternatives of EQUAL mean state
+    probability"""
+    import re, subprocess
+    opts = {"UTR": "on", "alternatives-from-sampling": "true", "sample": "100", "softmasking": "0"}
+    if maxdiff is not None:
+        opts["/Constant/almost_identical_maxdiff"] = maxdiff
+    m = ax.Model(config_path(), species, **opts)
+    S = m.n_states
+    ex = dict(golden_inputs())
+    recs = [(k, ex[k]) for k in ("HS04636", "HS08198")] + [("rnd", random_dna(30000, 5))]
+    fa = str(tmp_path / "x.fa")
+    write_fasta(fa, recs)
+    res = emu_decode(m.tables_ptr, [s for _, s in recs], S, samples=99)
+    tys = [emu_state_type(m.tables_ptr, s) for s in range(S)]
+    paths = [[(b, e, s, tys[s]) for b, e, s in r[2]] for r in res]
+    out = format_gff_sampled(m, recs, paths, [r[7] for r in res])
+    ref = subprocess.run([REF_AUGUSTUS, "--AUGUSTUS_CONFIG_PATH=" + config_path(), "--species=" + species] +
+                         ["--%s=%s" % kv for kv in opts.items()] + [fa], capture_output=True, text=True).stdout
+    refl = gff_body(ref)
+    norm = lambda ls: sorted(re.sub(r"g(\d+)\.t\d+", r"g\1.tX", l) for l in ls if not l.startswith("#"))
+    assert sum("\ttranscript\t" in l for l in out) >= 10
+    if species == "fly":
+        assert out == refl
+    else:
+        assert norm(out) == norm(refl)

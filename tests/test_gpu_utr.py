@@ -100,3 +100,24 @@ def test_cli_utr_gff_identical_to_reference(tmp_path, cfg):
     fa = os.path.join(GOLDEN, "inputs.fa")
     out = _run_cli(["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()], fa)
     assert gff_body(out) == golden_gff(cfg)
+
+
+@pytest.mark.parametrize("cfg", list(GENEMODEL_CFGS))
+def test_gpu_two_intergenic_states(tmp_path, cfg):
+    """--genemodel=atleastone / exactlyone (dense kernels): cells, scores, paths and statuses equal to the oracle; the executable's
+    GFF the reference binary's"""
+    species, opts = GENEMODEL_CFGS[cfg]
+    m = ax.Model(config_path(), species, **dict(opts, sample="0"))
+    d = ax.Decoder(m, 0)
+    S = m.n_states
+    recs = golden_inputs()
+    b = ax.Batch(d, [s for _, s in recs])
+    b.decode()
+    for i, ((name, s), r) in enumerate(zip(recs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
+        assert r.status == rc and (rc != 0 or (r.ln_viterbi == lnv and r.states == path)), name
+        assert np.array_equal(b.cells(i), V), name
+    fa = str(tmp_path / "gm.fa")
+    write_fasta(fa, genemodel_records())
+    out = _run_cli(["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()], fa)
+    assert gff_body(out) == open(os.path.join(GOLDEN, "golden_genemodel_%s.gff" % cfg)).read().splitlines()
