@@ -20,6 +20,7 @@
 #include <mutex>
 #include <string>
 #include <system_error>
+#include <chrono>
 #include <vector>
 #include "kernels.h"
 #include "dense.h"
@@ -346,6 +347,10 @@ __global__ void __launch_bounds__(256) kUtrSignals(const DevTables *T, BatchView
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1UtrSignals(*T, B, g, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
+template <int BLK> __global__ void __launch_bounds__(NT) kUtrDesc(const DevTables *__restrict__ T, const BatchView B) {
+    __shared__ UDescLds lds;
+    utrDescGroup<BLK>(*T, B, lds, blockIdx.x);
+}
 // the dense Viterbi / forward kernel and its back-trace (dense.h): one workgroup / one wavefront per piece
 template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kDense(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ DenseLds lds;
@@ -488,6 +493,8 @@ struct augx_batch {
     hipEvent_t evFwd = nullptr; // forward matrix complete (the sampler waits for this, not for what the stream got after it)
     uint64_t nItems = 0, nPairs = 0;
     void *itemBuf = nullptr; // candidate buffer, sized per decode (kept while large enough)
+    void *udBuf = nullptr;   // (dense, UTR) descriptor buffer, sized like the candidate buffer
+    uint64_t nDescs = 0;
     bool decoded = false;
     bool itemsVerified = false; // the candidate buffer in use has held all candidates of this batch once
     SegPlan plan;            // segments of the trellis (layout.h: planSegments)
@@ -661,6 +668,7 @@ void augx_batch_destroy(augx_batch *b) {
     for (void *p : b->planeBufs)
         if (p) devFree(b->dec, p);
     if (b->itemBuf) devFree(b->dec, b->itemBuf);
+    if (b->udBuf) devFree(b->dec, b->udBuf);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
     if (b->evFwd) (void)hipEventDestroy(b->evFwd);
@@ -721,6 +729,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     V.nBlk = Z.N / V.blk;
     DA(V.blkCnt, uint32_t, V.nBlk * 2); DA(V.blkSplit, uint32_t, V.nBlk * 3); DA(V.blkOff, uint64_t, V.nBlk * 2);
     DA(V.candAlloc, CandAlloc, 1);
+    if (d->dense && d->hostT.utr) { DA(V.udOff, uint64_t, V.nBlk); DA(V.udCnt, uint32_t, V.nBlk); }
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
     DA(V.pathRec, int32_t, Z.pathCap * 3);
     // segments of the trellis: enough workgroups for every compute unit, none shorter than what a fix-up needs
@@ -886,12 +895,30 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             W.items = (Item *)b->itemBuf;
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
+        const bool utrDesc = d->dense && d->hostT.utr;
+        if (utrDesc && !b->udBuf) { // descriptors of the UTR exon cells: uniform-random DNA has 0.35 per base with the human parameters
+            W.udCap = b->nDescs > 0 ? (int64_t)(b->nDescs + 64) : W.N / 2 + 65536;
+            if (devMalloc(d, &b->udBuf, (size_t)W.udCap * sizeof(UDesc)) != hipSuccess) {
+                (void)hipGetLastError();
+                b->udBuf = nullptr;
+                setLastError("augx_batch_decode: out of device memory for the UTR descriptors; decode fewer bases per batch");
+                return AUGX_E_NOMEM;
+            }
+            W.ud = (UDesc *)b->udBuf;
+            HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
+        }
         // (steady: the batch has been decoded with this very buffer before -- the same sequences give the same candidates, no
         //  need to read the count back)
         const bool steady = b->decoded && b->itemBuf && b->nItems > 0 && (uint64_t)W.itemCap >= b->nItems && b->itemsVerified;
         for (int attempt = 0;; attempt++) {
             HIP_TRY(hipMemsetAsync(W.candAlloc, 0, sizeof(CandAlloc), st));
             const bool multi = W.nPl > 1;
+            if (utrDesc) {
+                const unsigned nGrp = (unsigned)(W.N / (NT / 16));
+                if (d->blk == 8) hipLaunchKernelGGL((kUtrDesc<8>), dim3(nGrp), dim3(NT), 0, st, d->dT, W);
+                else if (d->blk == 4) hipLaunchKernelGGL((kUtrDesc<4>), dim3(nGrp), dim3(NT), 0, st, d->dT, W);
+                else hipLaunchKernelGGL((kUtrDesc<2>), dim3(nGrp), dim3(NT), 0, st, d->dT, W);
+            }
 #define AUGX_LAUNCH_CAND(BLK_) do { if (d->dense) { if (multi) hipLaunchKernelGGL((kCand<BLK_, true, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
                                                        else hipLaunchKernelGGL((kCand<BLK_, false, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); } \
                                     else if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
@@ -905,19 +932,34 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             CandAlloc tot;
             HIP_TRY(hipMemcpyAsync(&tot, W.candAlloc, sizeof tot, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            b->nPairs = tot.pairs; b->nItems = tot.items;
-            if ((int64_t)tot.items <= W.itemCap) { b->itemsVerified = true; break; }
+            b->nPairs = tot.pairs; b->nItems = tot.items; b->nDescs = tot.descs;
+            const bool itemsFit = (int64_t)tot.items <= W.itemCap, descsFit = !utrDesc || (int64_t)tot.descs <= W.udCap;
+            if (itemsFit && descsFit) { b->itemsVerified = true; break; }
             if (attempt > 0) { setLastError("augx_batch_decode: candidate buffers overflowed twice"); return AUGX_E_HIP; }
-            devFree(d, b->itemBuf);
-            b->itemBuf = nullptr;
-            W.itemCap = (int64_t)tot.items + 64;
-            if (devMalloc(d, &b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
-                (void)hipGetLastError();
+            if (!itemsFit) {
+                devFree(d, b->itemBuf);
                 b->itemBuf = nullptr;
-                setLastError("augx_batch_decode: out of device memory for the candidate buffer (" + std::to_string(tot.items) + " candidates); decode fewer bases per batch");
-                return AUGX_E_NOMEM;
+                W.itemCap = (int64_t)tot.items + 64;
+                if (devMalloc(d, &b->itemBuf, (size_t)W.itemCap * sizeof(Item)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    b->itemBuf = nullptr;
+                    setLastError("augx_batch_decode: out of device memory for the candidate buffer (" + std::to_string(tot.items) + " candidates); decode fewer bases per batch");
+                    return AUGX_E_NOMEM;
+                }
+                W.items = (Item *)b->itemBuf;
             }
-            W.items = (Item *)b->itemBuf;
+            if (!descsFit) {
+                devFree(d, b->udBuf);
+                b->udBuf = nullptr;
+                W.udCap = (int64_t)tot.descs + 64;
+                if (devMalloc(d, &b->udBuf, (size_t)W.udCap * sizeof(UDesc)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    b->udBuf = nullptr;
+                    setLastError("augx_batch_decode: out of device memory for the UTR descriptors; decode fewer bases per batch");
+                    return AUGX_E_NOMEM;
+                }
+                W.ud = (UDesc *)b->udBuf;
+            }
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
     }
@@ -998,7 +1040,18 @@ int augx_batch_kernel_ms(augx_decoder *d, augx_batch *b, float *prep_ms, float *
     if (prep_ms) *prep_ms = a;
     if (trellis_ms) *trellis_ms = c;
     if (back_ms) *back_ms = e;
-    if (b->V.prof) { // developer aid (AUGX_PROF=1): cycle counters of the four trellis wavefronts, averaged over pieces
+    if (b->V.prof && d->dense) { // developer aid (AUGX_PROF=1): cycles per stage of the dense kernel, averaged over pieces
+        std::vector<uint64_t> h((size_t)b->L.nPieces * 56 + 64);
+        HIP_TRY(hipMemcpy(h.data(), b->V.prof, h.size() * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "kDense Mcycles/piece:");
+        for (int i = 0; i < 11; i++) {
+            double sum = 0;
+            for (int p = 0; p < b->L.nPieces; p++) sum += (double)h[(size_t)p * 56 + i];
+            fprintf(stderr, " [%d]=%.2f", i, sum / b->L.nPieces / 1e6);
+        }
+        fprintf(stderr, "  (wavefront 1: 0 loop, 1 stage 1: fixed-lag states + staging, 2 ... wait for the UTR units, 3 stage 2: records + early chains' inputs, 4 forward sums, "
+                        "5 stage 3: cells + early chain runs, 6 last-base redo, 7 stage 4: late chains, 8 RTERMINAL records, 9 their cells, 10 fence)\n");
+    } else if (b->V.prof) { // developer aid (AUGX_PROF=1): cycle counters of the four trellis wavefronts, averaged over pieces
         std::vector<uint64_t> h((size_t)b->L.nPieces * 56 + 64);
         HIP_TRY(hipMemcpy(h.data(), b->V.prof, h.size() * 8, hipMemcpyDeviceToHost));
         static const char *role[5] = {"work0", "work1", "work2", "chain", "far"};
@@ -1488,12 +1541,28 @@ int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, 
 }
 
 int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out) {
+    // AUGX_TIMING=1 (developer aid): the phases of the batch on stderr
+    const bool timing = getenv("AUGX_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = timing ? now() : 0.0;
     augx_batch *b = nullptr;
     int rc = augx_batch_create(d, pieces, n, &b);
     if (rc) return rc;
+    const double t1 = timing ? now() : 0.0;
     rc = augx_batch_decode(d, b);
+    if (!rc && timing) (void)hipStreamSynchronize(d->stream);
+    const double t2 = timing ? now() : 0.0;
     if (!rc) rc = augx_batch_paths(d, b, out);
+    const double t3 = timing ? now() : 0.0;
     augx_batch_destroy(b);
+    if (timing) {
+        int64_t bases = 0;
+        for (int i = 0; i < n; i++) bases += pieces[i].len;
+        size_t freeB = 0, totalB = 0;
+        (void)hipMemGetInfo(&freeB, &totalB);
+        fprintf(stderr, "augx timing:   batch on device %d: %d pieces, %lld bases: create + upload %.3f s, decode %.3f s, paths %.3f s, destroy %.3f s (device memory free %.1f of %.1f GB)\n",
+                d->device, n, (long long)bases, t1 - t0, t2 - t1, t3 - t2, now() - t3, freeB / 1e9, totalB / 1e9);
+    }
     return rc;
 }
 

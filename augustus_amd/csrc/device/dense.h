@@ -286,13 +286,17 @@ AUGX_HD void k1UtrSignals(const DevTables &T, const BatchView &B, int64_t g, con
 // candidates of the exon-like UTR states, evaluated where they are needed (trellis, forward, back-trace, sampler)
 // =================================================================================================
 struct UDesc {          // state s ending at base j
-    int8_t kind, list, bsel, fxf, ovl, len, xFirst, pad;
+    int8_t kind, list, bsel, fxf, ovl, len, xFirst, nPre;
     int16_t s, pad2;
     int32_t j, nList, nExtra, total;
     int32_t i1;         // one past the newest list entry (piece-local index)
     int32_t xHi;        // predecessor end of the first extra candidate (they run downwards)
     int32_t eom, eobe, cb, cbobe;
     double endP, E;     // ln end signal; endP + content prefix up to the end of the middle part
+    // the first nPre listed candidates -- the ones with a middle part of at most one base, the expensive case of utrCandPre --
+    // evaluated once by the descriptor kernel (kUtrDesc; 0 where a descriptor is made on the spot: back-trace, sampler)
+    int32_t preEop[3], pad3;
+    double preTe[3];
 };
 // read-only view of one piece for the UTR candidates
 struct UCtx {
@@ -314,7 +318,8 @@ AUGX_HD void utrDescribe(const UCtx &X, int s, int j, UDesc &D) {
     const int kind = T.kind[s], n = X.n;
     const UGeom g = utrGeom(T, kind);
     D.kind = (int8_t)kind; D.list = g.list; D.bsel = g.bsel; D.fxf = g.fxf; D.ovl = g.ovl; D.len = g.len; D.cb = g.cb; D.cbobe = g.cbobe;
-    D.s = (int16_t)s; D.j = j; D.nList = D.nExtra = D.total = 0; D.i1 = 0; D.xHi = 0; D.xFirst = 0; D.pad = 0; D.pad2 = 0;
+    D.s = (int16_t)s; D.j = j; D.nList = D.nExtra = D.total = 0; D.i1 = 0; D.xHi = 0; D.xFirst = 0; D.nPre = 0; D.pad2 = 0; D.pad3 = 0;
+    for (int i = 0; i < 3; i++) { D.preEop[i] = 0; D.preTe[i] = AUGX_NINF; }
     int boep, eobe, lm, rm;
     utrEndPos(T, kind, j, n, boep, eobe);
     utrWindow(T, kind, j, n, lm, rm);
@@ -415,18 +420,25 @@ AUGX_HD double utrEmi1(const UCtx &X, int fxf, int cj, int pos) {
 }
 // candidate idx (0 = the largest predecessor end) of the state described by D: te = ln emission of the state from eop + 1 to j
 // (without the transition term), eop = end of the predecessor.  false: infeasible
-AUGX_HD bool utrCand(const UCtx &X, const UDesc &D, int idx, double &te, int &eop) {
+// (candidate idx is entry D.i1 - 1 - li of the kind's site list, or -- xi >= 0 -- the xi-th candidate that is not on a list)
+AUGX_HD void utrCandIndex(const UDesc &D, int idx, int &li, int &xi) {
+    li = idx; xi = -1;
+    if (D.xFirst) { if (idx < D.nExtra) xi = idx; else li = idx - D.nExtra; }
+    else if (idx >= D.nList) xi = idx - D.nList;
+}
+// everything of the candidate but its length term: sig = begin + middle + end part, len / tail3 = argument of the length distribution
+// (sitePos, siteB: predecessor end and (begin signal - content prefix) of the candidate's site record, for a listed candidate)
+// Returns 0: infeasible, 1: done, 2 (deferRare only): one of the rare, expensive cases -- a candidate that is not on a site list, or
+// a middle part of at most one base -- which the caller evaluates apart from the common ones.
+AUGX_HD int utrCandPre(const UCtx &X, const UDesc &D, int xi, int sitePos, double siteB, double &sig, int &len, bool &tail3, int &eop, bool deferRare = false) {
     const DevTables &T = X.T;
     const int n = X.n;
     double bmix, braw = 0.0; // (begin signal) - (content prefix before the middle part); the begin signal alone
     bool haveRaw = false;
-    int li = idx, xi = -1; // index among the listed / among the extra candidates
-    if (D.xFirst) { if (idx < D.nExtra) xi = idx; else li = idx - D.nExtra; }
-    else if (idx >= D.nList) xi = idx - D.nList;
+    if (deferRare && xi >= 0) return 2;
     if (xi < 0) {
-        const USite e = X.list(D.list)[D.i1 - 1 - li];
-        eop = e.pos;
-        bmix = D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2];
+        eop = sitePos;
+        bmix = siteB;
     } else {
         eop = D.xHi - xi;
         const int begin = eop + 1, bom = begin + D.cb;
@@ -445,10 +457,10 @@ AUGX_HD bool utrCand(const UCtx &X, const UDesc &D, int idx, double &te, int &eo
         haveRaw = true;
         bmix = braw - X.pfx(D.fxf, bom - 1);
     }
-    if (!(bmix > AUGX_NINF)) return false;
+    if (!(bmix > AUGX_NINF)) return 0;
     const int begin = eop + 1, bom = begin + D.cb, mlen = D.eom - bom + 1;
-    double sig; // begin part + middle part + end part
-    if (mlen > 1) sig = bmix + D.E;
+    if (deferRare && mlen <= 1) return 2;
+    if (mlen > 1) sig = bmix + D.E; // begin part + middle part + end part
     else {
         if (!haveRaw) braw = bmix + X.pfx(D.fxf, bom - 1);
         double mp;
@@ -457,14 +469,28 @@ AUGX_HD bool utrCand(const UCtx &X, const UDesc &D, int idx, double &te, int &eo
         else mp = D.ovl == 1 ? -mlen * T.ln2 : D.ovl == 2 ? -mlen * T.ln4 : 0.0;
         sig = (braw + mp) + D.endP;
     }
-    const int bobe = begin + D.cbobe, len = D.eobe - bobe + 1;
-    bool tail3 = false;
+    const int bobe = begin + D.cbobe;
+    len = D.eobe - bobe + 1;
+    tail3 = false;
     if ((D.kind == AUGX_K_UTR3SINGLE || D.kind == AUGX_K_UTR3TERM) && D.eobe == n - 1) tail3 = true; // right-truncated 3' UTR (:1290-1295,1369-1372)
     if (D.kind == AUGX_K_RUTR3SINGLE && begin <= 0) tail3 = true;                                     // left-truncated (:1312)
-    const double lp = utrLenAt(T, D.len, len, tail3);
+    return 1;
+}
+AUGX_HD bool utrCandFrom(const UCtx &X, const UDesc &D, int xi, const USite &e, double &te, int &eop) {
+    double sig; int len; bool tail3;
+    if (!utrCandPre(X, D, xi, e.pos, D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2], sig, len, tail3, eop)) return false;
+    const double lp = utrLenAt(X.T, D.len, len, tail3);
     if (!(lp > AUGX_NINF)) return false;
     te = sig + lp;
     return te > AUGX_NINF;
+}
+AUGX_HD bool utrCand(const UCtx &X, const UDesc &D, int idx, double &te, int &eop) {
+    int li, xi;
+    utrCandIndex(D, idx, li, xi);
+    USite e;
+    e.pos = 0; e.pad = 0; e.b[0] = e.b[1] = e.b[2] = AUGX_NINF;
+    if (xi < 0) e = X.list(D.list)[D.i1 - 1 - li];
+    return utrCandFrom(X, D, xi, e, te, eop);
 }
 
 // =================================================================================================
@@ -479,24 +505,123 @@ AUGX_HD bool isFixedKind(int k) { return k == AUGX_K_LONGDSS || k == AUGX_K_RLON
 AUGX_HD bool isItemKind(int k) { return (k >= AUGX_K_SINGLE && k <= AUGX_K_RTERMINAL) || k == AUGX_K_LESSD || k == AUGX_K_RLESSD; }
 AUGX_HD double initLn(const DevTables &T, int initKind, int s) { return initKind == 0 ? T.ln_init[s] : (s == T.synch ? 0.0 : AUGX_NINF); }
 
+// a value that is the same in every lane of the wavefront, moved to a scalar register: what is computed from it is scalar
+// arithmetic, a branch on it a scalar branch
+#ifdef AUGX_EMU
+inline int uni(int v) { return v; }
+inline UDesc uniDesc(const UDesc &d) { return d; }
+#else
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ UDesc uniDesc(const UDesc &d) {
+    union { UDesc d; int w[sizeof(UDesc) / 4]; } a, r;
+    a.d = d;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(UDesc) / 4); i++) r.w[i] = __builtin_amdgcn_readfirstlane(a.w[i]);
+    return r.d;
+}
+#endif
+#ifdef AUGX_EMU
+inline USite ldUSite(const USite *p) { return *p; }
+#else
+__device__ __forceinline__ USite ldUSite(const USite *p) { // two 16-byte global loads
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i a = ((const AUGX_GLOBAL v4i *)p)[0], c = ((const AUGX_GLOBAL v4i *)p)[1];
+    USite e;
+    e.pos = a.x; e.pad = a.y; e.b[0] = __hiloint2double(a.w, a.z); e.b[1] = __hiloint2double(c.y, c.x); e.b[2] = __hiloint2double(c.w, c.z);
+    return e;
+}
+#endif
+constexpr int UDW = 14;    // 64-bit words of a descriptor
+constexpr int UDCAP = 64;  // descriptors of a block staged in LDS (a block with more reads the rest from HBM)
+static_assert(sizeof(UDesc) == UDW * 8, "UDesc is copied word by word");
+
+// ---- descriptors of the open (end base, UTR exon state) pairs, once per decode: they depend on the sequence only, not on ln V.
+// One workgroup per 32 bases, thread = (base, state); the descriptors with candidates are packed, block by block, into B.ud
+// (space handed out by one atomic add per workgroup, like the candidate records of kCand: the order of the blocks in the buffer is
+// whatever it happens to be, the trellis takes maxima and sums integers).
+struct UDescLds { int has[NT]; int gpre[WAVE + 1]; unsigned long long base; };
+template <int BLK>
+AUGX_KFN void utrDescGroup(const DevTables &T, const BatchView &B, UDescLds &L, int64_t wg) {
+    constexpr int NBASE = NT / 16;
+    static_assert(DUV == 16 && NBASE % BLK == 0 && (BLK * 16) % 8 == 0, "thread = (base, slot)");
+    const int64_t g0 = wg * NBASE; // slot off + j of the group's first base
+    const int p = B.chunkPiece[g0 / CHUNK];
+    const int64_t o = B.off[p];
+    const int n = B.len[p], j0 = (int)(g0 - o);
+    if (!T.utr || j0 >= n || B.cls[p] < 0) return; // (blocks past the end of a piece are never read)
+    UCtx X(T, B, p);
+    TV(UDesc, dd);
+    FOR_THREADS(t) {
+        const int dj = t / 16, slot = t % 16, j = j0 + dj;
+        UDesc &D = TX(dd);
+        D.total = 0;
+        const int s2 = slot < T.nUv ? T.uvS[slot] : -1;
+        if (s2 >= 0 && j >= 1 && j < n && ((B.gate[o + 1 + j] >> T.vbit[s2]) & 1ull)) {
+            utrDescribe(X, s2, j, D);
+            for (int li = 0; li < 3 && li < D.nList; li++) { // the leading listed candidates while they are of the expensive kind
+                const int idx = D.xFirst ? D.nExtra + li : li;
+                const USite e = X.list(D.list)[D.i1 - 1 - li];
+                double sig; int len, eop; bool tail3;
+                if (utrCandPre(X, D, -1, e.pos, D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2], sig, len, tail3, eop, true) != 2) break;
+                double te = AUGX_NINF;
+                if (!utrCand(X, D, idx, te, eop)) te = AUGX_NINF;
+                D.preEop[li] = e.pos; D.preTe[li] = te; D.nPre = (int8_t)(li + 1);
+            }
+        }
+        L.has[t] = D.total > 0;
+    }
+    BLOCK_SYNC();
+    TV(int, g8);
+    FOR_THREADS(t) {
+        int c = 0;
+        if (t < WAVE) for (int k = 0; k < 8; k++) c += L.has[t * 8 + k];
+        TX(g8) = c;
+    }
+    FOR_WAVES(w) { if (w == 0) waveInclScan(g8, w); }
+    FOR_THREADS(t) { if (t < WAVE) L.gpre[t + 1] = TX(g8); if (t == 0) L.gpre[0] = 0; }
+    BLOCK_SYNC();
+    FOR_THREADS(t) {
+        if (t == 0) {
+            const unsigned long long total = (unsigned long long)L.gpre[WAVE];
+#ifdef AUGX_EMU
+            L.base = B.candAlloc->descs; B.candAlloc->descs += total;
+#else
+            L.base = atomicAdd(&B.candAlloc->descs, total);
+#endif
+        }
+    }
+    BLOCK_SYNC();
+    const uint64_t base = L.base;
+    const bool fits = base + (uint64_t)L.gpre[WAVE] <= (uint64_t)B.udCap; // (else the host re-runs the kernel with a buffer of the size the counter reports)
+    FOR_THREADS(t) {
+        int rank = L.gpre[t / 8];
+        for (int k = 0; k < t % 8; k++) rank += L.has[(t / 8) * 8 + k];
+        if (fits && L.has[t]) B.ud[base + (uint64_t)rank] = TX(dd);
+        if (t % (BLK * 16) == 0) {
+            const int64_t gb = o / BLK + (j0 + t / 16) / BLK;
+            B.udOff[gb] = base + (uint64_t)L.gpre[t / 8];
+            B.udCnt[gb] = fits ? (uint32_t)(L.gpre[(t + BLK * 16) / 8] - L.gpre[t / 8]) : 0u;
+        }
+    }
+}
+
 struct DenseLds {
     double ring[WAVE][SPX];          // the newest 64 columns, [j & 63][state]
-    double cmax[8][SPX];             // variable-length cells of the block: largest candidate ...
-    unsigned long long csum[8][SPX]; // ... (forward) sum of exp(candidate - largest), fixed point
+    double cmax[2][8][SPX];             // variable-length cells of the block ([parity]): largest candidate ...
+    unsigned long long csum[2][8][SPX]; // ... (forward) sum of exp(candidate - largest), fixed point
     double tr[SPX][AUGX_MAX_ANC];    // ln t(ancestor ai -> s) of the piece's first class
     uint8_t anc[SPX][AUGX_MAX_ANC], nanc[SPX];
     uint8_t cellKind[SPX];           // 1: candidates from the records of kCand, 2: reverse terminal exon, 3: UTR exon, 0: none
     double sg[2][8][NSIG];           // signal records of the block ([parity]; the next block's are staged meanwhile)
-    uint64_t gate[2][8];             // end gates of the block's bases
     uint64_t bOff[2];
     uint32_t bCnt[2][2];
-    int chS[DCH], chNa[DCH], chAnc[DCH][AUGX_MAX_ANC], chNd[DCH], chDead[DCH][AUGX_MAX_ANC], chDeadAi[DCH][AUGX_MAX_ANC];
+    uint64_t uOff[2];                // descriptors of the block's UTR exon cells: first, count
+    uint32_t uCnt[2];
+    int chS[DCH], chNa[DCH], chAnc[DCH][AUGX_MAX_ANC], chNd[DCH], chDead[DCH][AUGX_MAX_ANC], chDeadAi[DCH][AUGX_MAX_ANC], chSgi[DCH];
     uint8_t chLive[DCH][AUGX_MAX_ANC], chEarly[DCH];
     double oth[DCH][8];              // [slot][base of the block]: what reaches the chain state from the other states
     uint8_t othAi[DCH][8];
-    int uvS[DUV], nUv;               // the exon-like UTR states
-    UDesc ud[8 * DUV];               // descriptors of the block's (base, UTR exon state) pairs
-    int udPre[8 * DUV + 1];          // inclusive prefix of their candidate counts
+    uint64_t ud[2][UDCAP * UDW];     // the descriptors themselves ([parity])
 };
 
 // value of state a at base q for the block that begins at jb: from the ring while no base of the block has taken its column
@@ -506,6 +631,11 @@ template <bool FWD> AUGX_KFN double denseAt(const DenseLds &L, const double *M, 
     return ldCoherent(&M[(int64_t)q * S + a]);
 }
 
+#if defined(AUGX_EMU) || !defined(AUGX_PROFILE)
+#define DPROF(k) do {} while (0)
+#else // (developer build -DAUGX_PROFILE, AUGX_PROF=1: cycles of the first lane of wavefront 1 per stage; it passes every barrier)
+#define DPROF(k) do { if (B.prof && threadIdx.x == WAVE) { const uint64_t now_ = clock64(); dpAcc[k] += now_ - dpLast; dpLast = now_; } } while (0)
+#endif
 // One workgroup walks piece p block by block.  MODE 0: Viterbi (ln V into B.cells, back pointers of the chain / fixed-lag
 // states into B.bpD, score and final state of the piece); MODE 1: forward algorithm (ln F into B.fwd, ln P(sequence)).
 template <int BLK, int MODE>
@@ -516,7 +646,9 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     double *M = (FWD ? B.fwd : B.cells) + (o + 1) * S;
     uint8_t *BP = B.bpD ? B.bpD + (o + 1) * S : nullptr;
     const double *gSig = B.sig + (o + 1) * NSIG;
-    const uint64_t *gGate = B.gate + o + 1;
+    const uint64_t *gUdOff = B.udOff;
+    const uint32_t *gUdCnt = B.udCnt;
+    const uint64_t *gUd = (const uint64_t *)B.ud;
     const Item *gItems = B.items;
     const uint64_t *gBlkOff = B.blkOff;
     const uint32_t *gBlkCnt = B.blkCnt, *gBlkSplit = B.blkSplit;
@@ -538,6 +670,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     // ---- tables of the state graph in LDS; the matrix starts empty
     FOR_THREADS(t) {
         for (int i = t; i < WAVE * SPX; i += NT) (*lp(&L.ring[i / SPX][i % SPX])) = AUGX_NINF;
+        for (int i = t; i < 8 * SPX; i += NT) { (*lp(&L.cmax[0][i / SPX][i % SPX])) = AUGX_NINF; (*lp(&L.csum[0][i / SPX][i % SPX])) = 0ull; }
         if (t < SPX) {
             const int k = t < S && T.reachable[t] ? T.kind[t] : -1;
             (*lp(&L.cellKind[t])) = k < 0 ? 0 : k == AUGX_K_RTERMINAL ? 2 : isItemKind(k) ? 1 : isUtrExonKind(k) ? 3 : 0;
@@ -562,7 +695,8 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     }
     BLOCK_GLOBAL_SYNC();
     // ---- the states by role (uniform)
-    int fixS[DFIX], nFix = 0, chS[DCH], nCh = 0, nEarly = 0, uvS[DUV], nUv = 0;
+    int fixS[DFIX], nFix = 0, chS[DCH], nCh = 0, nEarly = 0;
+    const int nUv = T.nUv;
     for (int s2 = 0; s2 < S; s2++) {
         if (!T.reachable[s2]) continue;
         const int k = T.kind[s2];
@@ -574,7 +708,6 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         if (!T.reachable[s2]) continue;
         const int k = T.kind[s2];
         if (isChainKind(k) && !isEarlyChainKind(k)) { if (nCh < DCH) chS[nCh++] = s2; }
-        else if (isUtrExonKind(k)) { if (nUv < DUV) uvS[nUv++] = s2; }
     }
     if (!anyNuc) { // all N: everything is intergenic (reference src/namgene.cc:205-226); one thread, column after column
         FOR_THREADS(t) {
@@ -592,10 +725,14 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     const int64_t gb0 = o / BLK;
     // per-thread constants of the fixed-lag step (thread = (state, base of the block))
     TV(int, fS2); TV(int, fLag); TV(int, fSg);
+    // per-thread constants of the chain runs (thread = slot): the state, its own ancestor index, whether the only chain state of its
+    // stage among its ancestors is the state itself (then its run over the block is a recurrence in registers)
+    TV(int, cS2); TV(int, cSelf); TV(int, cFast); TV(int, cSgi);
     FOR_THREADS(t) {
         TX(fS2) = -1; TX(fLag) = 1; TX(fSg) = 0;
-        if (t >= WAVE && t - WAVE < nFix * BLK) {
-            const int s2 = fixS[(t - WAVE) / BLK], k = T.kind[s2];
+        TX(cS2) = -1; TX(cSelf) = -1; TX(cFast) = 0; TX(cSgi) = SIG_EIN;
+        if (t < nFix * BLK) {
+            const int s2 = fixS[t / BLK], k = T.kind[s2];
             TX(fS2) = s2;
             TX(fLag) = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
             TX(fSg) = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
@@ -606,26 +743,39 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             const int na = s2 >= 0 ? T.n_anc[s2] : 0;
             (*lp(&L.chNa[t])) = na;
             (*lp(&L.chEarly[t])) = t < nEarly;
-            int nd = 0;
+            (*lp(&L.chSgi[t])) = (s2 >= 0 && T.kind[s2] == AUGX_K_IGENIC) ? SIG_EIG : SIG_EIN;
+            int nd = 0, nLive = 0, selfAi = -1;
+            bool onlySelf = true;
             for (int ai = 0; ai < AUGX_MAX_ANC; ai++) {
                 const int a = ai < na ? T.anc[s2][ai] : 0;
                 // an ancestor that is a chain state of the same stage is made in the same run (as a rule only the state itself)
                 const bool live = ai < na && isChainKind(T.kind[a]) && (isEarlyChainKind(T.kind[a]) == (t < nEarly));
                 (*lp(&L.chAnc[t][ai])) = a;
                 (*lp(&L.chLive[t][ai])) = live;
+                if (live) { nLive++; if (a == s2) selfAi = ai; else onlySelf = false; }
                 if (ai < na && !live) { (*lp(&L.chDead[t][nd])) = a; (*lp(&L.chDeadAi[t][nd])) = ai; nd++; }
             }
             for (int k2 = nd; k2 < AUGX_MAX_ANC; k2++) { (*lp(&L.chDead[t][k2])) = 0; (*lp(&L.chDeadAi[t][k2])) = 0; }
             (*lp(&L.chNd[t])) = nd;
+            TX(cS2) = s2; TX(cSelf) = selfAi; TX(cFast) = s2 >= 0 && onlySelf && nLive <= 1;
+            TX(cSgi) = (s2 >= 0 && T.kind[s2] == AUGX_K_IGENIC) ? SIG_EIG : SIG_EIN;
         }
-        if (t < DUV) (*lp(&L.uvS[t])) = t < nUv ? uvS[t] : -1;
-        if (t == 0) (*lp(&L.nUv)) = nUv;
     }
     constexpr int NTW = NT - WAVE;
+    // stage 1: the threads below A1T make the fixed-lag states and stage the next block; the wavefronts from UW0 on take the UTR units
+    constexpr int UW0 = BLK == 8 ? 3 : 2, A1T = UW0 * WAVE;
+    constexpr int UH = 2; // candidates a lane of a UTR unit has in flight (three spill registers)
+    static_assert(DFIX * BLK <= A1T && 8 * NSIG <= 2 * WAVE, "roles of stage 1");
     FOR_THREADS(t) { // block 0: offsets, signal records, gates
         if (t == NT - 1) { (*lp(&L.bOff[0])) = gp(gBlkOff)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][0])) = gp(gBlkCnt)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][1])) = gp(gBlkSplit)[gb0 * 3 + 2]; }
         if (t >= NT - BLK * NSIG) { const int i = t - (NT - BLK * NSIG); (*lp(&L.sg[0][i / NSIG][i % NSIG])) = i / NSIG < n ? gp(gSig)[(int64_t)(i / NSIG) * NSIG + i % NSIG] : AUGX_NINF; }
-        if (t < BLK) (*lp(&L.gate[0][t])) = t < n ? gp(gGate)[t] : 0ull;
+        if (nUv > 0) { // the descriptors of block 0
+            const uint64_t uo = gp(gUdOff)[gb0];
+            const uint32_t uc = gp(gUdCnt)[gb0];
+            if (t == 0) { (*lp(&L.uOff[0])) = uo; (*lp(&L.uCnt[0])) = uc; }
+            const uint32_t words = (uc < (uint32_t)UDCAP ? uc : (uint32_t)UDCAP) * UDW;
+            for (uint32_t i = (uint32_t)t; i < words; i += NT) (*lp(&L.ud[0][i])) = gp(gUd)[uo * UDW + i];
+        }
     }
     BLOCK_SYNC();
     // what reaches chain slot `slot` at base jb + dj from the states that are not made in its own run
@@ -634,7 +784,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         double f = AUGX_NINF;
         int fa = 0xFF;
         if (s2 >= 0 && j >= 1 && j < n) {
-            const double emi = (*lp(&L.sg[par][dj][T.kind[s2] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN]));
+            const double emi = (*lp(&L.sg[par][dj][(*lp(&L.chSgi[slot]))]));
             const int cc = clsAt(j), nd = (*lp(&L.chNd[slot]));
             double x[AUGX_MAX_ANC], m = AUGX_NINF;
             int fin = 0;
@@ -662,7 +812,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     auto chainRun = [&](int slot, int jb, int par) __attribute__((always_inline)) {
         const int s2 = (*lp(&L.chS[slot]));
         if (s2 < 0) return;
-        const int na = (*lp(&L.chNa[slot])), sgi = T.kind[s2] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
+        const int na = (*lp(&L.chNa[slot])), sgi = (*lp(&L.chSgi[slot]));
         for (int dj = 0; dj < BLK; dj++) {
             const int j = jb + dj;
             if (j >= n || j < 1) continue;
@@ -683,22 +833,182 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             if (f > AUGX_NINF) { gp(M)[(int64_t)j * S + s2] = f; if (!FWD && BP) gp(BP)[(int64_t)j * S + s2] = (uint8_t)fa; }
         }
     };
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    uint64_t dpAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dpLast = clock64();
+#endif
+    // the same when the state's only chain ancestor of its stage is the state itself: the previous value stays in a register
+    auto chainRunSelf = [&](int slot, int s2, int selfAi, int sgi, int jb, int par) __attribute__((always_inline)) {
+        double em[BLK], ot[BLK];
+        int oa[BLK];
+        _Pragma("unroll") for (int dj = 0; dj < BLK; dj++) { em[dj] = (*lp(&L.sg[par][dj][sgi])); ot[dj] = (*lp(&L.oth[slot][dj])); oa[dj] = (*lp(&L.othAi[slot][dj])); }
+        const int jp = (jb >= 1 ? jb : 1) - 1;
+        double prev = ldsLoadD(&L.ring[jp & 63][s2]);
+        const double tSelf = (selfAi >= 0 && !multi) ? ldsLoadD(&L.tr[s2][selfAi]) : 0.0;
+        _Pragma("unroll") for (int dj = 0; dj < BLK; dj++) {
+            const int j = jb + dj;
+            if (j >= n || j < 1) continue;
+            double f = ot[dj];
+            int fa = oa[dj];
+            if (selfAi >= 0 && prev > AUGX_NINF) {
+                const double x = prev + ((multi ? trn(clsAt(j), s2, selfAi) : tSelf) + em[dj]);
+                if (FWD) f = lse2(f, x);
+                else if (x > f || (x == f && selfAi < fa)) { f = x; fa = selfAi; }
+            }
+            (*lp(&L.ring[j & 63][s2])) = f;
+            if (f > AUGX_NINF) { gp(M)[(int64_t)j * S + s2] = f; if (!FWD && BP) gp(BP)[(int64_t)j * S + s2] = (uint8_t)fa; }
+            prev = f;
+        }
+    };
     for (int b = 0; b < nBlocks; b++) {
         const int jb = b * BLK, par = b & 1;
         const int64_t gb = gb0 + b;
-        // ---- A: fixed-lag states; accumulators of the variable-length cells; the next block's offsets, signal records, gates
+        DPROF(0);
+        const uint64_t i0 = (*lp(&L.bOff[par]));
+        const uint32_t cntAll = (*lp(&L.bCnt[par][0])), cntNonRT = (*lp(&L.bCnt[par][1]));
+        auto candValue = [&](const Item &I, int &dj, int &s2) __attribute__((always_inline)) -> double {
+            dj = (int)(I.kp >> (KEY_BITS + 7)); s2 = (int)((I.kp >> KEY_BITS) & 127);
+            if (!(I.te > AUGX_NINF)) return AUGX_NINF;
+            const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
+#ifdef AUGX_EMU // (stage 2 relies on it: a predecessor inside the block is a fixed-lag state, made in stage 1)
+            if (eop >= jb && T.kind[s2] != AUGX_K_RTERMINAL && !isFixedKind(T.kind[I.src & 127u]) && getenv("AUGX_EMU_CHECK_LAG"))
+                fprintf(stderr, "emu: in-block predecessor that is not a fixed-lag state: state %d kind %d j %d eop %d jb %d src %d\n", s2, T.kind[s2], jb + dj, eop, jb, (int)(I.src & 127u));
+#endif
+            const double pv = denseAt<FWD>(L, M, S, eop, (int)(I.src & 127u), jb, BLK);
+            return pv + I.te;
+        };
+        auto itemPass = [&](uint32_t lo2, uint32_t hi2, bool sumPass) __attribute__((always_inline)) {
+            FOR_THREADS(t) {
+                for (uint32_t it = lo2 + (uint32_t)(t - WAVE); t >= WAVE && it < hi2; it += NTW) {
+                    int dj, s2;
+                    const double v = candValue(ldItem(gItems + i0 + it), dj, s2);
+                    if (!(v > AUGX_NINF)) continue;
+                    if (!sumPass) ldsMaxD(&L.cmax[par][dj][s2], v);
+                    else ldsAddU(&L.csum[par][dj][s2], (unsigned long long)(exp(v - (*lp(&L.cmax[par][dj][s2]))) * FWD_FIX));
+                }
+            }
+        };
+        // the UTR exon candidates of the block: its descriptors (kUtrDesc) are cut into units of 128 candidates, the units dealt to the
+        // candidate wavefronts; within a unit the descriptor is the same for every lane, a lane takes two candidates and has the
+        // loads of both in flight before it needs either (only >= 0: that one descriptor only)
+        auto utrPass = [&](bool sumPass, int only, bool defer) __attribute__((always_inline)) {
+            const uint32_t nd = (uint32_t)uni((int)(*lp(&L.uCnt[par])));
+            const uint64_t uo = (*lp(&L.uOff[par]));
+            FOR_WAVES(w) {
+                if (w >= UW0) {
+                    uint32_t wi = 0;
+                    for (uint32_t d = only >= 0 ? (uint32_t)only : 0u; d < (only >= 0 ? (uint32_t)only + 1u : nd); d++) {
+                        const int total = uni(d < (uint32_t)UDCAP ? ((const UDesc *)&L.ud[par][d * UDW])->total : B.ud[uo + d].total);
+                        const int nun = (total + UH * WAVE - 1) / (UH * WAVE);
+                        const int mine = (int)((uint32_t)(w - UW0 + (NWAVES - UW0) - (int)(wi % (NWAVES - UW0))) % (NWAVES - UW0)); // first unit of this descriptor that is this wavefront's
+                        wi += (uint32_t)nun;
+                        if (mine >= nun) continue;
+                        const UDesc D = d < (uint32_t)UDCAP ? *(const UDesc *)&L.ud[par][d * UDW] : B.ud[uo + d];
+                        const int s2 = D.s, dj = D.j - jb, cc = clsAt(D.j), na = (*lp(&L.nanc[s2]));
+                        const USite *sites = UX.list(D.list);
+                        for (int c = mine; c < nun; c += NWAVES - UW0) {
+                            FOR_WLANES(t, w) {
+                                int xi[UH], eop[UH], len[UH], lis[UH];
+                                bool act[UH], tail3[UH], pre[UH];
+                                int sPos[UH];
+                                double sB[UH], sig[UH], lnLen[UH];
+                                // the loads that depend on nothing: the site records of both candidates
+                                _Pragma("unroll") for (int h = 0; h < UH; h++) {
+                                    const int idx = c * UH * WAVE + h * WAVE + (t & 63);
+                                    int li;
+                                    act[h] = idx < total;
+                                    utrCandIndex(D, idx, li, xi[h]);
+                                    lis[h] = li;
+                                    pre[h] = act[h] && xi[h] < 0 && li < D.nPre;
+                                    sPos[h] = 0; sB[h] = AUGX_NINF;
+                                    if (act[h] && xi[h] < 0 && !pre[h]) {
+                                        USite e;
+                                        e = ldUSite(sites + ((int64_t)D.i1 - 1 - li));
+                                        sPos[h] = e.pos; sB[h] = D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2];
+                                    }
+                                }
+                                // the length terms (they depend on the site's position); the rare cases go to the list of stage 2
+                                _Pragma("unroll") for (int h = 0; h < UH; h++) {
+                                    lnLen[h] = AUGX_NINF;
+                                    if (pre[h]) { // (evaluated by the descriptor kernel)
+                                        sig[h] = lis[h] == 0 ? D.preTe[0] : lis[h] == 1 ? D.preTe[1] : D.preTe[2];
+                                        eop[h] = lis[h] == 0 ? D.preEop[0] : lis[h] == 1 ? D.preEop[1] : D.preEop[2];
+                                        lnLen[h] = 0.0;
+                                        act[h] = sig[h] > AUGX_NINF;
+                                    } else if (act[h]) {
+                                        const int r = utrCandPre(UX, D, xi[h], sPos[h], sB[h], sig[h], len[h], tail3[h], eop[h], defer);
+                                        act[h] = r == 1;
+                                    }
+                                    if (act[h] && !pre[h]) lnLen[h] = utrLenAt(T, D.len, len[h], tail3[h]);
+                                }
+                                // the predecessors' values: every load in flight before the first is used
+                                double pv[UH][4];
+                                _Pragma("unroll") for (int h = 0; h < UH; h++)
+                                    _Pragma("unroll") for (int ai = 0; ai < 4; ai++)
+                                        pv[h][ai] = (act[h] && ai < na) ? denseAt<FWD>(L, M, S, eop[h], (*lp(&L.anc[s2][ai])), jb, BLK) : AUGX_NINF;
+                                // every candidate of the unit belongs to one cell: the lane combines its own (largest / sum), then one atomic
+                                double vmax = AUGX_NINF;
+                                unsigned long long vsum = 0ull;
+                                const double cm = sumPass ? (*lp(&L.cmax[par][dj][s2])) : 0.0;
+                                _Pragma("unroll") for (int h = 0; h < UH; h++) {
+                                    if (!act[h] || !(lnLen[h] > AUGX_NINF)) continue;
+                                    const double te = sig[h] + lnLen[h];
+                                    if (!(te > AUGX_NINF)) continue;
+#ifdef AUGX_EMU
+                                    if (eop[h] >= jb && only < 0 && getenv("AUGX_EMU_CHECK_LAG")) fprintf(stderr, "emu: in-block predecessor of a UTR exon: state %d j %d eop %d jb %d\n", s2, D.j, eop[h], jb);
+#endif
+                                    _Pragma("unroll") for (int ai = 0; ai < 4; ai++) {
+                                        if (ai >= na || !(pv[h][ai] > AUGX_NINF)) continue;
+                                        const double v = pv[h][ai] + (trn(cc, s2, ai) + te);
+                                        if (!sumPass) vmax = v > vmax ? v : vmax;
+                                        else vsum += (unsigned long long)(exp(v - cm) * FWD_FIX);
+                                    }
+                                    for (int ai = 4; ai < na; ai++) { // (no UTR exon state of the reference's models has more than four ancestors)
+                                        const double pw = denseAt<FWD>(L, M, S, eop[h], (*lp(&L.anc[s2][ai])), jb, BLK);
+                                        if (!(pw > AUGX_NINF)) continue;
+                                        const double v = pw + (trn(cc, s2, ai) + te);
+                                        if (!sumPass) vmax = v > vmax ? v : vmax;
+                                        else vsum += (unsigned long long)(exp(v - cm) * FWD_FIX);
+                                    }
+                                }
+                                if (!sumPass) { if (vmax > AUGX_NINF) ldsMaxD(&L.cmax[par][dj][s2], vmax); }
+                                else if (vsum) ldsAddU(&L.csum[par][dj][s2], vsum);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        auto cellsOf = [&](int t, int kindMask) __attribute__((always_inline)) { // (thread t >= WAVE) the cells of the states whose cellKind is in the mask
+            for (int i = t - WAVE; i < BLK * SPX; i += NTW) {
+                const int dj = i / SPX, s2 = i % SPX, j = jb + dj;
+                if (j >= 1 && j < n && ((kindMask >> (*lp(&L.cellKind[s2]))) & 1)) {
+                    double f = (*lp(&L.cmax[par][dj][s2]));
+                    if (FWD) f = (*lp(&L.csum[par][dj][s2])) > 0ull ? f + log((double)(*lp(&L.csum[par][dj][s2])) / FWD_FIX) : AUGX_NINF;
+                    (*lp(&L.ring[j & 63][s2])) = f;
+                    if (f > AUGX_NINF) gp(M)[(int64_t)j * S + s2] = f;
+                }
+            }
+        };
+        // ---- 1: fixed-lag states; the UTR exon candidates (their predecessors end before the block); the accumulators, offsets,
+        //         signal records and descriptors of the NEXT block
         FOR_THREADS(t) {
-            for (int i = t; i < BLK * SPX; i += NT) { (*lp(&L.cmax[i / SPX][i % SPX])) = AUGX_NINF; (*lp(&L.csum[i / SPX][i % SPX])) = 0ull; }
-            if (t == NT - 1 && b + 1 < nBlocks) {
+            for (int i = t; t < A1T && i < BLK * SPX; i += A1T) { (*lp(&L.cmax[par ^ 1][i / SPX][i % SPX])) = AUGX_NINF; (*lp(&L.csum[par ^ 1][i / SPX][i % SPX])) = 0ull; }
+            if (t == A1T - 1 && b + 1 < nBlocks) {
                 (*lp(&L.bOff[par ^ 1])) = gp(gBlkOff)[(gb + 1) * 2 + 1]; (*lp(&L.bCnt[par ^ 1][0])) = gp(gBlkCnt)[(gb + 1) * 2 + 1]; (*lp(&L.bCnt[par ^ 1][1])) = gp(gBlkSplit)[(gb + 1) * 3 + 2];
             }
-            if (b + 1 < nBlocks && t >= NT - BLK * NSIG) {
-                const int i = t - (NT - BLK * NSIG), dj = i / NSIG, j = jb + BLK + dj;
+            if (b + 1 < nBlocks && t >= A1T - BLK * NSIG && t < A1T) {
+                const int i = t - (A1T - BLK * NSIG), dj = i / NSIG, j = jb + BLK + dj;
                 (*lp(&L.sg[par ^ 1][dj][i % NSIG])) = j < n ? gp(gSig)[(int64_t)j * NSIG + i % NSIG] : AUGX_NINF;
             }
-            if (b + 1 < nBlocks && t < BLK) { const int j = jb + BLK + t; (*lp(&L.gate[par ^ 1][t])) = j < n ? gp(gGate)[j] : 0ull; }
+            if (nUv > 0 && b + 1 < nBlocks && t < A1T) { // the next block's descriptors
+                const uint64_t uo = gp(gUdOff)[gb + 1];
+                const uint32_t uc = gp(gUdCnt)[gb + 1];
+                if (t == 0) { (*lp(&L.uOff[par ^ 1])) = uo; (*lp(&L.uCnt[par ^ 1])) = uc; }
+                const uint32_t words = (uc < (uint32_t)UDCAP ? uc : (uint32_t)UDCAP) * UDW;
+                for (uint32_t i = (uint32_t)t; i < words; i += A1T) (*lp(&L.ud[par ^ 1][i])) = gp(gUd)[uo * UDW + i];
+            }
             if (TX(fS2) >= 0) {
-                const int s2 = TX(fS2), dj = (t - WAVE) % BLK, j = jb + dj;
+                const int s2 = TX(fS2), dj = t % BLK, j = jb + dj;
                 if (j >= 1 && j < n) {
                     const int lag = TX(fLag);
                     const double emi = (*lp(&L.sg[par][dj][TX(fSg)]));
@@ -719,131 +1029,72 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                 }
             }
         }
+        DPROF(1);
+        if (nUv > 0) utrPass(false, -1, false);
         BLOCK_SYNC();
-        // ---- B: early chain states (geometric introns: fed by the fixed-lag states of the base before and by themselves)
+        DPROF(2);
+        // ---- 2: the records of kCand but RTERMINAL (their predecessors: earlier blocks, or fixed-lag states of this one); the early chain
+        //         states (geometric introns: fed by the fixed-lag states of the base before and by themselves)
+        itemPass(0, cntNonRT, false);
         FOR_THREADS(t) { if (t >= WAVE && t - WAVE < nEarly * BLK) chainOthers((t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
         BLOCK_SYNC();
-        FOR_THREADS(t) { if (t < nEarly) chainRun(t, jb, par); }
-        BLOCK_SYNC();
-        // ---- C / E: candidates of the variable-length states.  C: the records of kCand but RTERMINAL, and the UTR exon states
-        //      (their candidates are evaluated here); E: RTERMINAL (it may start from a cell of its own block)
-        const uint64_t i0 = (*lp(&L.bOff[par]));
-        const uint32_t cntAll = (*lp(&L.bCnt[par][0])), cntNonRT = (*lp(&L.bCnt[par][1]));
-        auto candValue = [&](const Item &I, int &dj, int &s2) __attribute__((always_inline)) -> double {
-            dj = (int)(I.kp >> (KEY_BITS + 7)); s2 = (int)((I.kp >> KEY_BITS) & 127);
-            if (!(I.te > AUGX_NINF)) return AUGX_NINF;
-            const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
-            const double pv = denseAt<FWD>(L, M, S, eop, (int)(I.src & 127u), jb, BLK);
-            return pv + I.te;
-        };
-        auto itemPass = [&](uint32_t lo2, uint32_t hi2, bool sumPass) __attribute__((always_inline)) {
-            FOR_THREADS(t) {
-                for (uint32_t it = lo2 + (uint32_t)(t - WAVE); t >= WAVE && it < hi2; it += NTW) {
-                    int dj, s2;
-                    const double v = candValue(ldItem(gItems + i0 + it), dj, s2);
-                    if (!(v > AUGX_NINF)) continue;
-                    if (!sumPass) ldsMaxD(&L.cmax[dj][s2], v);
-                    else ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - (*lp(&L.cmax[dj][s2]))) * FWD_FIX));
-                }
-            }
-        };
-        // the UTR exon candidates of the block: descriptors of the open (base, state) pairs, then every candidate by one thread
-        // (only >= 0: the candidates of that one descriptor)
-        auto utrPass = [&](bool sumPass, int only) __attribute__((always_inline)) {
-            const int first = only >= 0 ? (*lp(&L.udPre[only])) : 0, total = only >= 0 ? (*lp(&L.udPre[only + 1])) : (*lp(&L.udPre[BLK * DUV]));
-            FOR_THREADS(t) {
-                for (int it = first + t - WAVE; t >= WAVE && it < total; it += NTW) {
-                    int pos = 0; // the pair of candidate `it`: the number of pairs whose candidates end at or before it
-                    for (int step = 128; step >= 1; step >>= 1)
-                        if (pos + step <= BLK * DUV && (*lp(&L.udPre[pos + step])) <= it) pos += step;
-                    const UDesc D = L.ud[pos];
-                    double te; int eop;
-                    if (!utrCand(UX, D, it - (*lp(&L.udPre[pos])), te, eop)) continue;
-                    const int s2 = D.s, dj = D.j - jb, cc = clsAt(D.j), na = (*lp(&L.nanc[s2]));
-                    for (int ai = 0; ai < na; ai++) {
-                        const double pv = denseAt<FWD>(L, M, S, eop, (*lp(&L.anc[s2][ai])), jb, BLK);
-                        if (!(pv > AUGX_NINF)) continue;
-                        const double v = pv + (trn(cc, s2, ai) + te);
-                        if (!sumPass) ldsMaxD(&L.cmax[dj][s2], v);
-                        else ldsAddU(&L.csum[dj][s2], (unsigned long long)(exp(v - (*lp(&L.cmax[dj][s2]))) * FWD_FIX));
-                    }
-                }
-            }
-        };
-        auto cells = [&](int kindMask) __attribute__((always_inline)) { // the cells of the states whose cellKind is in the mask
-            FOR_THREADS(t) {
-                for (int i = t - WAVE; t >= WAVE && i < BLK * SPX; i += NTW) {
-                    const int dj = i / SPX, s2 = i % SPX, j = jb + dj;
-                    if (j >= 1 && j < n && ((kindMask >> (*lp(&L.cellKind[s2]))) & 1)) {
-                        double f = (*lp(&L.cmax[dj][s2]));
-                        if (FWD) f = (*lp(&L.csum[dj][s2])) > 0ull ? f + log((double)(*lp(&L.csum[dj][s2])) / FWD_FIX) : AUGX_NINF;
-                        (*lp(&L.ring[j & 63][s2])) = f;
-                        if (f > AUGX_NINF) gp(M)[(int64_t)j * S + s2] = f;
-                    }
-                }
-            }
-            BLOCK_SYNC();
-        };
-        if (nUv > 0) {
-        FOR_THREADS(t) { // descriptors
-            if (t >= WAVE && t - WAVE < BLK * DUV) {
-                const int u = t - WAVE, dj = u / DUV, slot = u % DUV, j = jb + dj, s2 = (*lp(&L.uvS[slot]));
-                UDesc D;
-                D.total = 0; D.s = (int16_t)(s2 < 0 ? 0 : s2); D.j = j;
-                if (s2 >= 0 && j >= 1 && j < n && (((*lp(&L.gate[par][dj])) >> T.vbit[s2]) & 1ull)) utrDescribe(UX, s2, j, D);
-                L.ud[u] = D;
-            }
+        DPROF(3);
+        if (FWD) { itemPass(0, cntNonRT, true); if (nUv > 0) utrPass(true, -1, false); BLOCK_SYNC(); }
+        DPROF(4);
+        // ---- 3: the cells of the variable-length states; the early chain states over the block
+        FOR_THREADS(t) {
+            if (t >= WAVE) cellsOf(t, (1 << 1) | (1 << 3));
+                if (t < nEarly) { if (TX(cFast)) chainRunSelf(t, TX(cS2), TX(cSelf), TX(cSgi), jb, par); else chainRun(t, jb, par); }
         }
         BLOCK_SYNC();
-        {   // inclusive prefix of the candidate counts (one wavefront; BLK * DUV <= 64 pairs with UTR states: their block size is <= 4)
-            static_assert(DUV * 4 <= WAVE, "one lane per (base, UTR exon state) pair");
-            TV(int, dsc);
-            FOR_THREADS(t) { const int u = t - WAVE; TX(dsc) = (t >= WAVE && u < BLK * DUV && u < WAVE) ? L.ud[u].total : 0; }
-            FOR_WAVES(w) { if (w == 1) waveInclScan(dsc, w); }
-            FOR_THREADS(t) { const int u = t - WAVE; if (t >= WAVE && u < WAVE) { if (u == 0) (*lp(&L.udPre[0])) = 0; if (u < BLK * DUV) (*lp(&L.udPre[u + 1])) = TX(dsc); } }
-        }
-        BLOCK_SYNC();
-        }
-        itemPass(0, cntNonRT, false);
-        if (nUv > 0) utrPass(false, -1);
-        BLOCK_SYNC();
-        if (FWD) { itemPass(0, cntNonRT, true); if (nUv > 0) utrPass(true, -1); BLOCK_SYNC(); }
-        cells((1 << 1) | (1 << 3));
+        DPROF(5);
         // the right-truncated 3' UTR exon at the last base of the piece may begin anywhere up to that base (src/utrmodel.cc:880-884):
         // its predecessors of this very block exist only now -- the cell is made once more, from all of them
-        if (jb + BLK > n - 1 && jb <= n - 1)
-            for (int slot = 0; slot < nUv; slot++) {
-                if (T.kind[uvS[slot]] != AUGX_K_UTR3SINGLE) continue;
-                const int u = (n - 1 - jb) * DUV + slot, s2 = uvS[slot];
-                if (L.ud[u].total == 0) continue;
-                FOR_THREADS(t) { if (t == 0) { (*lp(&L.cmax[n - 1 - jb][s2])) = AUGX_NINF; (*lp(&L.csum[n - 1 - jb][s2])) = 0ull; } }
+        if (nUv > 0 && jb + BLK > n - 1 && jb <= n - 1) {
+            const uint32_t nd = (*lp(&L.uCnt[par]));
+            const uint64_t uo = (*lp(&L.uOff[par]));
+            for (uint32_t d = 0; d < nd; d++) {
+                const UDesc D = d < (uint32_t)UDCAP ? *(const UDesc *)&L.ud[par][d * UDW] : B.ud[uo + d];
+                if (D.kind != AUGX_K_UTR3SINGLE || D.j != n - 1 || D.total == 0) continue;
+                const int s2 = D.s;
+                FOR_THREADS(t) { if (t == 0) { (*lp(&L.cmax[par][n - 1 - jb][s2])) = AUGX_NINF; (*lp(&L.csum[par][n - 1 - jb][s2])) = 0ull; } }
                 BLOCK_SYNC();
-                utrPass(false, u);
+                utrPass(false, (int)d, false);
                 BLOCK_SYNC();
-                if (FWD) { utrPass(true, u); BLOCK_SYNC(); }
+                if (FWD) { utrPass(true, (int)d, false); BLOCK_SYNC(); }
                 FOR_THREADS(t) {
                     if (t == 0) {
-                        double f = (*lp(&L.cmax[n - 1 - jb][s2]));
-                        if (FWD) f = (*lp(&L.csum[n - 1 - jb][s2])) > 0ull ? f + log((double)(*lp(&L.csum[n - 1 - jb][s2])) / FWD_FIX) : AUGX_NINF;
+                        double f = (*lp(&L.cmax[par][n - 1 - jb][s2]));
+                        if (FWD) f = (*lp(&L.csum[par][n - 1 - jb][s2])) > 0ull ? f + log((double)(*lp(&L.csum[par][n - 1 - jb][s2])) / FWD_FIX) : AUGX_NINF;
                         (*lp(&L.ring[(n - 1) & 63][s2])) = f;
                         gp(M)[(int64_t)(n - 1) * S + s2] = f;
                     }
                 }
                 BLOCK_SYNC();
             }
-        // ---- D: late chain states (intergenic, UTR introns: fed by the exon cells of the base before and by themselves)
+        }
+        DPROF(6);
+        // ---- 4: late chain states (intergenic, UTR introns: fed by the exon cells of the base before and by themselves)
         FOR_THREADS(t) { if (t >= WAVE && t - WAVE < (nCh - nEarly) * BLK) chainOthers(nEarly + (t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
         BLOCK_SYNC();
-        FOR_THREADS(t) { if (t < nCh - nEarly) chainRun(nEarly + t, jb, par); }
+        FOR_THREADS(t) { if (t >= nEarly && t < nCh) { if (TX(cFast)) chainRunSelf(t, TX(cS2), TX(cSelf), TX(cSgi), jb, par); else chainRun(t, jb, par); } }
         BLOCK_SYNC();
-        // ---- E: reverse terminal exons
+        DPROF(7);
+        // ---- 5: reverse terminal exons (they may start from a cell of their own block)
         itemPass(cntNonRT, cntAll, false);
         BLOCK_SYNC();
         if (FWD) { itemPass(cntNonRT, cntAll, true); BLOCK_SYNC(); }
-        cells(1 << 2);
+        DPROF(8);
+        FOR_THREADS(t) { if (t >= WAVE) cellsOf(t, 1 << 2); }
+        BLOCK_SYNC();
+        DPROF(9);
         // the columns of this block reach HBM before any later block reads them from there (the ring covers 64 bases)
         if (((b + 1) * BLK) % 32 == 0) BLOCK_GLOBAL_SYNC();
+        DPROF(10);
     }
+#if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
+    if (B.prof && threadIdx.x == WAVE) for (int k = 0; k < 12; k++) B.prof[(int64_t)p * 56 + k] = dpAcc[k];
+#endif
     BLOCK_SYNC();
     FOR_THREADS(t) { // termination (reference NAMGene::getViterbiPath, src/namgene.cc:442-462; getSampledPath :385-392)
         if (t == 0) {

@@ -113,6 +113,7 @@ struct DevTables {
         *len5s, *len5i, *len5n, *len5t, *len3s, *len3i, *len3n, *len3t, *tail5s, *tail3s;
     int dense;                 // the model is decoded by the dense kernels (dense.h)
     int vbit[AUGX_MAX_STATES]; // bit of a variable-length state in the end-gate mask (the state index itself while S <= 64)
+    int uvS[16], nUv;          // the exon-like UTR states, ascending (dense.h: slot of a state in the descriptor kernel)
     const double *ln_trans, *ig_emi, *ig_short, *in_emi, *ex_emi, *ex_init, *ex_et, *ex_pls, *tis_motif, *ass_motif,
         *tis_bin_bounds, *tis_bin_ln, *ass_pat, *dss_pat, *len_intron, *len_single, *len_initial, *len_internal,
         *len_terminal;
@@ -158,6 +159,10 @@ struct BatchView {
     double *usig;              // [N][NUSIG]
     USite *tfSite, *laSite, *fsSite, *lrSite, *tmSite, *rtSite; // [listCap] begin-site lists (laSite / lrSite run parallel to laPos / lrPos)
     uint8_t *bpD;              // [N][S] back pointers of the chain and fixed-lag states (ancestor index, 0xFF: none)
+    struct UDesc *ud;          // [udCap] descriptors of the open (end base, UTR exon state) pairs, the pairs of a block contiguous (kUtrDesc)
+    int64_t udCap;
+    uint64_t *udOff;           // [nBlk] first descriptor of the block
+    uint32_t *udCnt;           // [nBlk] descriptors of the block
     // trellis
     uint16_t *bp;              // [N][SP] back pointers
     uint8_t *bpChain;          // [N][8] the back pointers of the (at most 8) single-base chain states once more, one byte each, in

@@ -952,7 +952,7 @@ __device__ inline void ldsAdd(uint32_t *p, uint32_t v) { __hip_atomic_fetch_add(
 #endif
 
 // global allocation state of the candidate buffer (one per batch)
-struct CandAlloc { unsigned long long pairs, items; };
+struct CandAlloc { unsigned long long pairs, items, descs; };
 
 // Candidates of one tile of 64 bases (first base j0, first block gblk0 in the batch's block tables) of piece X.p, by ONE
 // wavefront: lane = base while the pairs are collected, lane = pair while they are described, lane = candidate while

@@ -317,7 +317,6 @@ inline int chooseDenseBlock(const augx_tables &t) {
     if (nChain > 16 || nFix > 24 || nUv > 16) throw std::runtime_error("augx: state graph too large for the dense kernels");
     int b = 8;
     if (const char *e = getenv("AUGX_BLK")) b = atoi(e);
-    if (t.utr && b > 4) b = 4; // (densePiece holds one descriptor per (base, UTR exon state) pair of a block in one wavefront)
     while (b > 1 && b > lag) b /= 2;
     if (b < 2) throw std::runtime_error("augx: signal windows too short for the dense kernels");
     return b;
@@ -375,6 +374,10 @@ inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
         for (int a = 0; a < AUGX_MAX_ANC; a++) D.anc[s][a] = t.anc[s][a];
         D.ln_init[s] = t.ln_init[s]; D.ln_term[s] = t.ln_term[s];
     }
+    D.nUv = 0;
+    for (int s = 0; s < 16; s++) D.uvS[s] = -1;
+    for (int s = 0; s < t.S; s++)
+        if (t.reachable[s] && isUtrExonKind(t.state_kind[s]) && D.nUv < 16) D.uvS[D.nUv++] = s;
     for (int i = 0; i < 64; i++) D.ln_startcodon[i] = t.ln_startcodon[i];
     D.ln_stop_ochre = t.ln_stop_ochre; D.ln_stop_amber = t.ln_stop_amber; D.ln_stop_opal = t.ln_stop_opal;
     D.ln_quarter = t.ln_quarter; D.ln_n_coding = t.ln_n_coding; D.ln4 = t.ln4; D.ass_pat_invalid = t.ass_pat_invalid;

