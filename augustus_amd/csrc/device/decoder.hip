@@ -1380,6 +1380,7 @@ extern "C" {
 
 augx_rand *augx_rand_create(unsigned seed) { return new augx_rand(seed); }
 int augx_rand_next(augx_rand *r) { return r ? r->next() : -1; }
+void augx_rand_skip(augx_rand *r, int64_t n) { if (r && n > 0) r->skip(n); }
 void augx_rand_destroy(augx_rand *r) { delete r; }
 
 // everything the host sampler reads of one piece, fetched from HBM, and the sampler's look-up tables: independent of the draws,

@@ -33,7 +33,27 @@ struct augx_rand {
         k = 34;
         for (int i = 34; i < 344; i++) (void)step();
     }
-    void skip(int64_t n) { for (int64_t i = 0; i < n; i++) (void)step(); }
+    // n draws spent without being looked at (a path running through an intergenic region draws once per base): the recurrence
+    // over a linear buffer, three independent additions per turn (the shortest lag is 3), instead of the ring one step at a time
+    void skip(int64_t n) {
+        if (n < 96) { for (int64_t i = 0; i < n; i++) (void)step(); return; }
+        constexpr int LAG = 31, CH = 3 * 1024;
+        uint32_t x[LAG + CH + 3];
+        for (int i = 0; i < LAG; i++) x[i] = r[(k - LAG + (unsigned)i) & 63];
+        while (n > 0) {
+            const int m = n > CH ? CH : (int)n;
+            int i = LAG;
+            for (; i + 2 < LAG + m; i += 3) { // (x[i + 2] reads x[i - 1]: written a turn ago)
+                const uint32_t a = x[i - 31] + x[i - 3], b = x[i - 30] + x[i - 2], c = x[i - 29] + x[i - 1];
+                x[i] = a; x[i + 1] = b; x[i + 2] = c;
+            }
+            for (; i < LAG + m; i++) x[i] = x[i - 31] + x[i - 3];
+            for (int q = 0; q < LAG; q++) x[q] = x[m + q];
+            n -= m;
+            k += (unsigned)m;
+        }
+        for (int i = 0; i < LAG; i++) r[(k - LAG + (unsigned)i) & 63] = x[i];
+    }
     uint32_t step() { // r[k] = r[k-31] + r[k-3]
         const uint32_t v = r[(k - 31) & 63] + r[(k - 3) & 63];
         r[k & 63] = v;
@@ -222,6 +242,9 @@ inline void prepareStops(SamplePiece &P) {
         P.stopOpt[s].assign(v.size(), -1);
     }
     P.prepared = true;
+#ifdef AUGX_EMU
+    if (getenv("AUGX_EMU_STATS")) for (int s = 0; s < S; s++) if (!P.stops[s].empty()) fprintf(stderr, "emu sampler: chain state %d: %zu stops over %d bases\n", s, P.stops[s].size(), n);
+#endif
 }
 
 // n_samples paths of one piece, 5'->3', runs of the single-base chain states merged (as the Viterbi path is delivered)

@@ -6,9 +6,11 @@
 // piece loop (reference src/namgene.cc:575-676) and of the cut finder's exam windows over devices.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <future>
 #include <mutex>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <string>
@@ -126,14 +128,21 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
     std::atomic<bool> failed{false}; // (read outside the lock by the workers)
     std::vector<int> rcs(n_dec, 0);
     std::vector<std::string> errs(n_dec);
+    const bool timing = getenv("AUGX_TIMING") != nullptr; // (developer aid: the phases of every batch on stderr)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto workBody = [&](int d) {
         for (size_t k = (size_t)d; k < batches.size(); k += (size_t)n_dec) {
             const int first = batches[k].first, cnt = batches[k].second - batches[k].first;
             augx_batch *b = nullptr;
+            const double t0 = timing ? now() : 0.0;
             int rc = augx_batch_create(decs[d], pieces + first, cnt, &b);
             if (!rc) rc = augx_batch_decode(decs[d], b);
             if (!rc) rc = augx_batch_paths(decs[d], b, out + first);
+            const double t1 = timing ? now() : 0.0;
             if (!rc && n_samples) rc = augx_batch_forward(decs[d], b);
+            if (!rc && timing) (void)augx_batch_sync(decs[d]);
+            const double t2 = timing ? now() : 0.0;
+            double tWaitTurn = 0, tWaitPrep = 0, tRun = 0;
             if (rc) errs[d] = augx_last_error();
             // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
             // (it does not depend on the draws), also while earlier batches are still being sampled
@@ -156,10 +165,15 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             for (int p = 0; p < AHEAD; p++) launch(p);
             {
                 std::unique_lock<std::mutex> lk(mu);
+                const double w0 = timing ? now() : 0.0;
                 cv.wait(lk, [&] { return turn == (int)k || failed; });
+                if (timing) tWaitTurn = now() - w0;
                 for (int p = 0; p < cnt; p++) {
                     if (!prep[p].valid()) { launch(p + AHEAD); continue; } // (no path: nothing is drawn)
+                    const double p0 = timing ? now() : 0.0;
                     Prep pr = prep[p].get();
+                    const double p1 = timing ? now() : 0.0;
+                    tWaitPrep += p1 - p0;
                     launch(p + AHEAD);
                     if (!rc && !failed) {
                         rc = pr.rc;
@@ -169,12 +183,19 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
                             if (rc) errs[d] = augx_last_error();
                         }
                     }
+                    if (timing) tRun += now() - p1;
                     augx_sample_prep_destroy(pr.h);
                 }
                 if (rc) { rcs[d] = rc; failed = true; if (errs[d].empty()) errs[d] = "augx_decode_sampled: fetching a piece for the sampler failed"; }
                 turn = (int)k + 1;
             }
             cv.notify_all();
+            if (timing) {
+                int64_t bases = 0;
+                for (int p = 0; p < cnt; p++) bases += pieces[first + p].len;
+                fprintf(stderr, "augx timing:   sampled batch on decoder %d: %d pieces, %lld bases: decode + paths %.3f s, forward %.3f s, wait for the batch before %.3f s, "
+                                "wait for the sampler's inputs %.3f s, %d paths per piece drawn in %.3f s\n", d, cnt, (long long)bases, t1 - t0, t2 - t1, tWaitTurn, tWaitPrep, n_samples, tRun);
+            }
             if (b) augx_batch_destroy(b);
             if (rc || failed) return;
         }

@@ -219,7 +219,7 @@ def e2e_legs(cfg, model, local, contigs):
                                                  "excluded: process start, parameter load, HIP context / decoder create, teardown (laps_s of cli)"}
             # ---- the same executable with posterior sampling (the default of 162 of the reference's species): forward algorithm on the
             #      device, 99 sampled paths per contig on the host, posterior probabilities in the GFF
-            ns = min(n, 8)
+            ns = min(n, 32)
             fa2 = os.path.join(d, "bench_s.fa")
             with open(fa2, "wb") as f:
                 for nm, s in list(zip(names, contigs))[:ns]:
@@ -228,7 +228,14 @@ def e2e_legs(cfg, model, local, contigs):
             r = subprocess.run([exe, "--species=human", "--sample=100", "--outfile=" + os.path.join(d, "out_s.gff"), fa2], capture_output=True, env=env)
             dt = time.perf_counter() - t0
             b2 = sum(len(c) for c in contigs[:ns])
-            out["cli_sampled"] = {"value": b2 / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "contigs": ns,
+            laps = {}
+            for line in r.stderr.decode(errors="replace").splitlines():
+                if line.startswith("augx timing:   "):
+                    laps.setdefault("batches", []).append(line[len("augx timing:"):].strip())
+                elif line.startswith("augx timing:"):
+                    w = line[len("augx timing:"):].rsplit(None, 2)
+                    laps[w[0].strip()] = float(w[1])
+            out["cli_sampled"] = {"value": b2 / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "contigs": ns, "laps_s": laps,
                                   "region": "augustus --species=human --sample=100 (Viterbi + forward on 1 GPU, 99 sampled paths per contig on the host, "
                                             "posterior probabilities in the GFF)"}
     return out

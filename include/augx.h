@@ -245,6 +245,7 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
 typedef struct augx_rand augx_rand;
 augx_rand *augx_rand_create(unsigned seed);
 int augx_rand_next(augx_rand *r);               /* == rand() of glibc after srand(seed) */
+void augx_rand_skip(augx_rand *r, int64_t n);   /* n draws spent unseen (a sampled path draws once per base of an intergenic run)  */
 void augx_rand_destroy(augx_rand *r);
 int augx_batch_sample(augx_decoder *d, augx_batch *b, int piece, int n_samples, augx_rand *r, augx_path *out /* array[n_samples] */);
 /* decode + sample n pieces on n_dec devices: out[i] = the Viterbi path of piece i, samples[i * n_samples + k] = its k-th sampled

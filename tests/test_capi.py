@@ -51,3 +51,26 @@ def test_no_cpu_fallback():
     with pytest.raises(ax.AugxError) as e:
         ax.Decoder(m, 0)
     assert e.value.code == ax.AUGX_E_NODEVICE
+
+
+def test_rand_is_glibc_rand_also_after_skips():
+    """augx_rand restates glibc's rand() (the reference never seeds it: its draws are srand(1)'s); augx_rand_skip spends draws in
+    blocks -- the next value after any skip is the one glibc gives after as many calls"""
+    import ctypes
+    L = ax.lib()
+    libc = ctypes.CDLL("libc.so.6")
+    L.augx_rand_create.restype = ctypes.c_void_p
+    L.augx_rand_next.argtypes = [ctypes.c_void_p]
+    L.augx_rand_skip.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.augx_rand_destroy.argtypes = [ctypes.c_void_p]
+    r = L.augx_rand_create(1)
+    libc.srand(1)
+    try:
+        for n in [0, 1, 5, 95, 96, 97, 200, 3071, 3072, 3073, 3075, 10000, 6144, 3, 31, 64, 100000]:
+            L.augx_rand_skip(r, n)
+            for _ in range(n):
+                libc.rand()
+            for _ in range(3):
+                assert L.augx_rand_next(r) == libc.rand(), n
+    finally:
+        L.augx_rand_destroy(r)
