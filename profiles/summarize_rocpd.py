@@ -14,7 +14,7 @@ try:
     seen = set()
     for row in c.execute("select name,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels "
                          "where name like '%kTrellis%' or name like '%kCand%' or name like '%kDense%' or name like '%kForward%' or name like '%kSignals%' "
-                         "or name like '%kBacktrace%' or name like '%Scan%' or name like '%kSiteConsts%' order by name"):
+                         "or name like '%kBacktrace%' or name like '%Scan%' or name like '%kSiteConsts%' or name like '%kUtr%' order by name"):
         key = (row[0], row[2], row[3])
         if key in seen:
             continue
