@@ -1375,6 +1375,10 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
 #include "sampler.h"
 
 struct augx_sample_prep { SamplePiece P; };
+namespace {
+std::mutex g_fPoolMu;
+std::vector<std::pair<size_t, double *>> g_fPool; // host buffers of forward matrices, kept for the next piece (at most 16; freed with the process)
+}
 
 extern "C" {
 
@@ -1405,7 +1409,22 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     HIP_TRY(hipMemcpy(&cls, V.cls + piece, 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&nPl, V.nPlanes + piece, 4, hipMemcpyDeviceToHost));
     P.cls0 = cls; P.nPlanes = nPl;
-    P.Fown.reset(new double[(size_t)n * S]);
+    {   // the host copy of the piece's forward matrix (hundreds of MB): buffers go round between the pieces of a run instead of
+        // being mapped, faulted in and unmapped once per piece
+        const size_t need = (size_t)n * S;
+        std::pair<size_t, double *> got{0, nullptr};
+        {
+            std::lock_guard<std::mutex> lk(g_fPoolMu);
+            for (size_t i = 0; i < g_fPool.size(); i++)
+                if (g_fPool[i].first >= need && g_fPool[i].first <= need + need / 2) { got = g_fPool[i]; g_fPool.erase(g_fPool.begin() + (long)i); break; }
+        }
+        if (!got.second) got = {need, new double[need]};
+        const size_t cap = got.first;
+        P.Fown = std::shared_ptr<double>(got.second, [cap](double *q) {
+            std::lock_guard<std::mutex> lk(g_fPoolMu);
+            if (g_fPool.size() < 16) g_fPool.push_back({cap, q}); else delete[] q;
+        });
+    }
     P.F = P.Fown.get();
     HIP_TRY(hipMemcpy(P.Fown.get(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)n * S, hipMemcpyDeviceToHost));
     P.sig.resize((size_t)n * NSIG);

@@ -16,8 +16,12 @@
 // glibc's rand(): the TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31] of random_r.c, seeded by the Lehmer
 // generator 16807 * x mod 2^31-1, the first 310 outputs discarded, the result shifted right by one
 struct augx_rand {
-    uint32_t r[64]; // ring of the last 64 values (34 are needed)
-    unsigned k = 0;
+    // The outputs are made CH at a time into a linear buffer -- three independent additions per turn (the shortest lag is 3), 0.3 ns
+    // a value -- and handed out by position: a draw that is spent without being looked at (a sampled path draws once per base of an
+    // intergenic run, the reference draws for a list of one option too) costs an increment.
+    static constexpr int LAG = 31, CH = 3 * 2048;
+    uint32_t x[LAG + CH]; // x[LAG + i]: the i-th output still to come; x[0 .. LAG): the 31 before them
+    int pos = CH;         // outputs of the buffer handed out (CH: none made yet)
     explicit augx_rand(unsigned seed) {
         int32_t st[34];
         st[0] = seed == 0 ? 1 : (int32_t)seed;
@@ -28,37 +32,32 @@ struct augx_rand {
             st[i] = (int32_t)w;
         }
         for (int i = 31; i < 34; i++) st[i] = st[i - 31];
-        for (int i = 0; i < 64; i++) r[i] = 0;
-        for (int i = 0; i < 34; i++) r[i] = (uint32_t)st[i];
-        k = 34;
-        for (int i = 34; i < 344; i++) (void)step();
+        // r[0 .. 34) = st; the next value is r[34] = r[3] + r[31]: the 31 values before it are r[3 .. 34)
+        for (int i = 0; i < LAG; i++) x[CH + i] = (uint32_t)st[3 + i];
+        pos = CH;
+        skip(310); // (random_r.c discards the first 310 outputs)
     }
-    // n draws spent without being looked at (a path running through an intergenic region draws once per base): the recurrence
-    // over a linear buffer, three independent additions per turn (the shortest lag is 3), instead of the ring one step at a time
-    void skip(int64_t n) {
-        if (n < 96) { for (int64_t i = 0; i < n; i++) (void)step(); return; }
-        constexpr int LAG = 31, CH = 3 * 1024;
-        uint32_t x[LAG + CH + 3];
-        for (int i = 0; i < LAG; i++) x[i] = r[(k - LAG + (unsigned)i) & 63];
-        while (n > 0) {
-            const int m = n > CH ? CH : (int)n;
-            int i = LAG;
-            for (; i + 2 < LAG + m; i += 3) { // (x[i + 2] reads x[i - 1]: written a turn ago)
-                const uint32_t a = x[i - 31] + x[i - 3], b = x[i - 30] + x[i - 2], c = x[i - 29] + x[i - 1];
-                x[i] = a; x[i + 1] = b; x[i + 2] = c;
-            }
-            for (; i < LAG + m; i++) x[i] = x[i - 31] + x[i - 3];
-            for (int q = 0; q < LAG; q++) x[q] = x[m + q];
-            n -= m;
-            k += (unsigned)m;
+    void refill() { // the next CH outputs from the last 31
+        for (int q = 0; q < LAG; q++) x[q] = x[CH + q];
+        int i = LAG;
+        for (; i + 2 < LAG + CH; i += 3) { // (x[i + 2] reads x[i - 1]: written a turn ago)
+            const uint32_t a = x[i - 31] + x[i - 3], b = x[i - 30] + x[i - 2], c = x[i - 29] + x[i - 1];
+            x[i] = a; x[i + 1] = b; x[i + 2] = c;
         }
-        for (int i = 0; i < LAG; i++) r[(k - LAG + (unsigned)i) & 63] = x[i];
+        for (; i < LAG + CH; i++) x[i] = x[i - 31] + x[i - 3];
+        pos = 0;
     }
-    uint32_t step() { // r[k] = r[k-31] + r[k-3]
-        const uint32_t v = r[(k - 31) & 63] + r[(k - 3) & 63];
-        r[k & 63] = v;
-        k++;
-        return v;
+    void skip(int64_t n) {
+        while (n > 0) {
+            if (pos == CH) refill();
+            const int64_t m = n < (int64_t)(CH - pos) ? n : (int64_t)(CH - pos);
+            pos += (int)m;
+            n -= m;
+        }
+    }
+    uint32_t step() {
+        if (pos == CH) refill();
+        return x[LAG + pos++];
     }
     int next() { return (int)(step() >> 1); }
 };
@@ -70,7 +69,7 @@ struct SamplePiece {
     int n = 0, S = 0, blk = 8, nPlanes = 1;
     const augx_tables *t = nullptr;
     const double *F = nullptr;    // [n][S] ln forward
-    std::unique_ptr<double[]> Fown; // (the device library keeps its host copy here)
+    std::shared_ptr<double> Fown;   // (the device library keeps its host copy here; the deleter hands the buffer back for the next piece)
     std::vector<double> sig;      // [n][NSIG]
     std::vector<uint8_t> plane;   // [n] (empty: one class)
     std::vector<int32_t> planeCls;
@@ -82,7 +81,12 @@ struct SamplePiece {
     int igS = -1, termKind = 0;
     bool anyNuc = true;
     // filled by prepareStops (may run on another thread, ahead of the sampling): see samplePaths
-    std::vector<std::vector<int32_t>> stops, stopOpt;
+    std::vector<std::vector<int32_t>> stops;
+    // per chain state and stop: the options of the stop, and -- flat, for the loop that runs down a chain state -- their total, the
+    // probability of the most probable one and whether that one is the state itself at the base before
+    std::vector<std::vector<struct OptList>> stopList;
+    std::vector<std::vector<double>> stopCum, stopP0;
+    std::vector<std::vector<uint8_t>> stopSelf;
     bool prepared = false;
     // models of the dense kernels (dense.h): candidate records name their predecessor by state; the candidates of the UTR exon
     // states are evaluated from a host view of the batch (hB: the emulator's own arrays, or the mirror of one piece below)
@@ -223,7 +227,7 @@ inline void prepareStops(SamplePiece &P) {
     const augx_tables &t = *P.t;
     const int n = P.n, S = P.S;
     P.stops.assign((size_t)S, {});
-    P.stopOpt.assign((size_t)S, {});
+    P.stopList.assign((size_t)S, {}); P.stopCum.assign((size_t)S, {}); P.stopP0.assign((size_t)S, {}); P.stopSelf.assign((size_t)S, {});
     for (int s = 0; s < S && P.anyNuc; s++) {
         const int kd = t.state_kind[s];
         if (!isChainKind(kd)) continue;
@@ -239,7 +243,15 @@ inline void prepareStops(SamplePiece &P) {
                 }
             if (!(cnt == 1 && self)) v.push_back(j);
         }
-        P.stopOpt[s].assign(v.size(), -1);
+        // the options of every stop (the same for every sampled path; made here, ahead of the sampling and on another thread)
+        P.stopList[s].resize(v.size()); P.stopCum[s].resize(v.size()); P.stopP0[s].resize(v.size()); P.stopSelf[s].resize(v.size());
+        for (size_t c = 0; c < v.size(); c++) {
+            OptList &L = P.stopList[s][c];
+            buildOptions(P, s, v[c], L);
+            P.stopCum[s][c] = L.cum;
+            P.stopP0[s][c] = L.p.empty() ? 0.0 : L.p[0];
+            P.stopSelf[s][c] = !L.o.empty() && L.o[0].state == s && L.o[0].base == v[c] - 1;
+        }
     }
     P.prepared = true;
 #ifdef AUGX_EMU
@@ -258,8 +270,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
     std::unordered_map<uint64_t, OptList> memo; // the options of a (base, state) pair are the same for every sample
     std::vector<augx_state> st;
     if (!P.prepared) prepareStops(P);
-    std::vector<std::vector<int32_t>> &stops = P.stops, &stopOpt = P.stopOpt;
-    std::deque<OptList> pool;
+    std::vector<std::vector<int32_t>> &stops = P.stops;
     std::vector<int64_t> cur((size_t)S, 0); // per sample: index of the last stop <= the base the path was last at in this state
     for (int it = 0; it < n_samples; it++) {
         st.clear();
@@ -290,20 +301,35 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                         if (c >= 1 && v[c - 1] <= base) c--;
                         else c = (int64_t)(std::upper_bound(v.begin(), v.begin() + c, base) - v.begin()) - 1;
                     }
-                    cur[state] = c;
-                    const int stop = c < 0 ? 0 : v[c];
-                    if (stop < base) {
-                        R.skip(base - stop);
-                        st.push_back({stop + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
-                        base = stop;
-                        continue;
+                    // down the state, stop after stop: between two stops a draw per base decides nothing; at a stop the draw is
+                    // compared with the most probable option first -- as a rule the state itself, and the run goes on
+                    const int top = base;
+                    const double *cumA = P.stopCum[state].data(), *p0A = P.stopP0[state].data();
+                    const uint8_t *selfA = P.stopSelf[state].data();
+                    const Opt *x = nullptr;
+                    for (;;) {
+                        const int stop = c < 0 ? 0 : v[c];
+                        if (stop < base) { R.skip(base - stop); base = stop; }
+                        if (base == 0) break;
+                        const OptList &L = P.stopList[state][(size_t)c];
+                        if (L.o.empty() || !(L.cum > 0)) { bad = true; break; }
+                        const double z = (double)R.next() / 2147483647.0 * cumA[c] * 0.99999; // (reference OptionsList::sample, as drawOption)
+                        if (selfA[c] && z < p0A[c]) { base--; c--; if (base == 0) break; continue; }
+                        double cumsum = 0;
+                        x = &L.o[0];
+                        for (size_t i = 0; i < L.o.size(); i++) {
+                            cumsum += L.p[i];
+                            if (z < cumsum) { x = &L.o[i]; break; }
+                        }
+                        break;
                     }
-                    int32_t &oi = stopOpt[state][c];
-                    if (oi < 0) { pool.emplace_back(); oi = (int32_t)pool.size() - 1; buildOptions(P, state, base, pool[oi]); }
-                    const Opt *x = drawOption(pool[oi], R);
-                    if (!x) { bad = true; break; }
-                    st.push_back({x->base + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
-                    base = x->base; state = x->state;
+                    cur[state] = c;
+                    if (bad) break;
+                    // (st runs 3'->5'; the steps of the run are one entry: the merged form the path is delivered in)
+                    const int from = x ? x->base + 1 : 1;
+                    if (!st.empty() && st.back().state == (int16_t)state && st.back().begin == top + 1) st.back().begin = from;
+                    else st.push_back({from, top, (int16_t)state, (int16_t)t.state_type[state]});
+                    if (x) { base = x->base; state = x->state; }
                     continue;
                 }
                 const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;

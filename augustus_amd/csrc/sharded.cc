@@ -142,13 +142,14 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             if (!rc && n_samples) rc = augx_batch_forward(decs[d], b);
             if (!rc && timing) (void)augx_batch_sync(decs[d]);
             const double t2 = timing ? now() : 0.0;
-            double tWaitTurn = 0, tWaitPrep = 0, tRun = 0;
+            double tWaitTurn = 0, tWaitPrep = 0, tRun = 0, tFree = 0;
             if (rc) errs[d] = augx_last_error();
             // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
             // (it does not depend on the draws), also while earlier batches are still being sampled
-            const int AHEAD = 4;
+            const int AHEAD = 8;
             struct Prep { int rc; augx_sample_prep *h; std::string err; }; // (augx_last_error is thread-local: the text travels with the result)
             std::vector<std::future<Prep>> prep((size_t)cnt);
+            std::vector<std::future<void>> frees;
             auto launch = [&](int p) {
                 if (p >= cnt || rc || !n_samples || out[first + p].status != AUGX_OK) return;
                 auto job = [&, p]() {
@@ -183,18 +184,24 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
                             if (rc) errs[d] = augx_last_error();
                         }
                     }
-                    if (timing) tRun += now() - p1;
-                    augx_sample_prep_destroy(pr.h);
+                    const double p2 = timing ? now() : 0.0;
+                    tRun += p2 - p1;
+                    // (hundreds of MB per piece go back to the allocator: not on the thread every later piece waits for)
+                    augx_sample_prep *hh = pr.h;
+                    try { frees.push_back(std::async(std::launch::async, [hh] { augx_sample_prep_destroy(hh); })); }
+                    catch (const std::system_error &) { augx_sample_prep_destroy(hh); }
+                    if (timing) tFree += now() - p2;
                 }
                 if (rc) { rcs[d] = rc; failed = true; if (errs[d].empty()) errs[d] = "augx_decode_sampled: fetching a piece for the sampler failed"; }
                 turn = (int)k + 1;
             }
             cv.notify_all();
+            for (auto &f : frees) f.get();
             if (timing) {
                 int64_t bases = 0;
                 for (int p = 0; p < cnt; p++) bases += pieces[first + p].len;
                 fprintf(stderr, "augx timing:   sampled batch on decoder %d: %d pieces, %lld bases: decode + paths %.3f s, forward %.3f s, wait for the batch before %.3f s, "
-                                "wait for the sampler's inputs %.3f s, %d paths per piece drawn in %.3f s\n", d, cnt, (long long)bases, t1 - t0, t2 - t1, tWaitTurn, tWaitPrep, n_samples, tRun);
+                                "wait for the sampler's inputs %.3f s, %d paths per piece drawn in %.3f s, inputs freed in %.3f s\n", d, cnt, (long long)bases, t1 - t0, t2 - t1, tWaitTurn, tWaitPrep, n_samples, tRun, tFree);
             }
             if (b) augx_batch_destroy(b);
             if (rc || failed) return;

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 #include "../../augustus_amd/csrc/device/kernels.h"
 #include "../../augustus_amd/csrc/device/dense.h"
@@ -237,7 +238,12 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
             P.anyNuc = false;
             for (int q = 0; q < len && !P.anyNuc; q++) P.anyNuc = B.code[o + 1 + q] < 4;
             std::vector<int> sst;
+            const auto ts0 = std::chrono::steady_clock::now();
+            prepareStops(P);
+            const auto ts1 = std::chrono::steady_clock::now();
             samplePaths(P, g_nsamples, *g_rand, g_samples[p], sst);
+            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
+                                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count());
         }
     }
     delete dl;
@@ -591,7 +597,12 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             P.anyNuc = false;
             for (int q = 0; q < len && !P.anyNuc; q++) P.anyNuc = B.code[o + 1 + q] < 4;
             std::vector<int> sst;
+            const auto ts0 = std::chrono::steady_clock::now();
+            prepareStops(P);
+            const auto ts1 = std::chrono::steady_clock::now();
             samplePaths(P, g_nsamples, *g_rand, g_samples[p], sst);
+            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
+                                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count());
         }
         free(B.fwd);
     }
