@@ -422,7 +422,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
 // allocation fails, the buffers the OTHER decoders of the device keep for re-use are given back to the runtime as well
 std::mutex g_regMu;
 std::vector<augx_decoder *> g_decoders;
-constexpr size_t POOL_CAP_BYTES = (size_t)64 << 30; // a decoder keeps at most this much for re-use (288 GB of HBM per device)
+constexpr size_t POOL_CAP_BYTES = (size_t)128 << 30; // a decoder keeps at most this much for re-use (288 GB of HBM per device; a batch of 100 Mbp takes 80)
 void poolReleaseLocked(augx_decoder *d) {
     for (auto &kv : d->pool) (void)hipFree(kv.second);
     d->pool.clear();

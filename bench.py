@@ -40,6 +40,24 @@ def synth_contigs(n_contigs, length, seed0):
     return out
 
 
+def synth_isochore_contigs(n_contigs, length, seed0):
+    """contigs whose GC content changes in runs of 50-300 kb between 34 % and 62 % -- the isochores of a vertebrate genome in
+    caricature: pieces then run through several of the model's GC-content classes (class steps inside a piece, several planes of
+    the class-dependent arrays, the reference's snippet cache replayed), which uniform-random DNA never does"""
+    out = []
+    for i in range(n_contigs):
+        rng = np.random.default_rng(seed0 + i)
+        parts, total = [], 0
+        while total < length:
+            run = int(rng.integers(50000, 300000))
+            gc = float(rng.choice([0.34, 0.40, 0.46, 0.52, 0.58, 0.62]))
+            p = [(1 - gc) / 2, gc / 2, gc / 2, (1 - gc) / 2]  # A C G T
+            parts.append(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=run, p=p))
+            total += run
+        out.append(np.concatenate(parts)[:length].tobytes())
+    return out
+
+
 def rank_contigs(mode, rank, world, n_contigs, length, batch=0):
     """The contigs rank `rank` of `world` decodes.
     weak:   its own n_contigs contigs (seeds disjoint from every other rank's and batch's)
@@ -177,6 +195,23 @@ def e2e_legs(cfg, model, local, contigs):
     out["e2e"] = {"value": bases / 1e6 / (best[0] + best[1]), "unit": "Mbp/s", "decode_s": best[0], "genes_gff_s": best[1],
                   "gff_bytes": len(buf.value),
                   "region": "host buffers -> augx_decode_batch (H2D + all kernels + path D2H) -> gene structures -> GFF text; model load excluded"}
+    # ---- the same call on contigs with GC-content steps inside every piece (what real genomes look like to the model)
+    iso = synth_isochore_contigs(n, len(contigs[0]), SEED0 + 4242)
+    P2 = (ax._Piece * n)()
+    for i, s in enumerate(iso):
+        P2[i].seq, P2[i].len, P2[i].init_kind, P2[i].term_kind = s, len(s), 0, 0
+    tb = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        ax._check(L.augx_decode_batch(dec._h, P2, n, paths))
+        tb = time.perf_counter() - t0
+        for i in range(n):
+            L.augx_path_free(ctypes.byref(paths[i]))
+    out["gc_steps"] = {"value": sum(len(c) for c in iso) / 1e6 / tb, "unit": "Mbp/s", "decode_s": tb,
+                       "workload": "%d contigs x %d bp whose GC content changes in runs of 50-300 kb between 34 %% and 62 %%: several GC-content "
+                                   "classes per piece" % (n, len(iso[0])),
+                       "region": "host buffers -> augx_decode_batch (H2D, classification incl. its host round trip, all kernels, the replay of the "
+                                 "reference's snippet cache and the second trellis run it asks for, path D2H); second of two calls"}
     dec.close()
     # ---- cli: the augustus executable on the same contigs as a FASTA file (includes process start, parameter load, FASTA parse)
     exe = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
