@@ -898,6 +898,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         const bool utrDesc = d->dense && d->hostT.utr;
         if (utrDesc && !b->udBuf) { // descriptors of the UTR exon cells: uniform-random DNA has 0.35 per base with the human parameters
             W.udCap = b->nDescs > 0 ? (int64_t)(b->nDescs + 64) : W.N / 2 + 65536;
+            if (const char *e = getenv("AUGX_UD_CAP")) { if (b->nDescs == 0) W.udCap = atol(e) > 0 ? atol(e) : 1; } // (tests: a first estimate that is too small)
             if (devMalloc(d, &b->udBuf, (size_t)W.udCap * sizeof(UDesc)) != hipSuccess) {
                 (void)hipGetLastError();
                 b->udBuf = nullptr;

@@ -121,3 +121,21 @@ def test_gpu_two_intergenic_states(tmp_path, cfg):
     write_fasta(fa, genemodel_records())
     out = _run_cli(["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()], fa)
     assert gff_body(out) == open(os.path.join(GOLDEN, "golden_genemodel_%s.gff" % cfg)).read().splitlines()
+
+
+def test_gpu_utr_descriptor_buffer_grows(monkeypatch):
+    """the descriptors of the UTR exon cells (kUtrDesc) go into a buffer sized by an estimate; one that turns out too small (forced:
+    16 entries) is reported by the kernel's counter and the kernel runs again with a buffer of the size it needs -- same cells,
+    also when the batch is decoded again"""
+    monkeypatch.setenv("AUGX_UD_CAP", "16")
+    m = ax.Model(config_path(), "human", UTR="on", softmasking="0")
+    S = m.n_states
+    d = ax.Decoder(m, 0)
+    seqs = [s for n, s in golden_inputs() if n in ("HS04636", "HS08198", "trunc_both")] + [random_dna(30000, 1)]
+    b = ax.Batch(d, seqs)
+    for rep in range(2):
+        b.decode()
+        for i, (s, r) in enumerate(zip(seqs, b.paths())):
+            rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
+            assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, (rep, i)
+            assert np.array_equal(b.cells(i), V), (rep, i)
