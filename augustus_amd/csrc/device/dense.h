@@ -724,18 +724,26 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     const int nBlocks = (n + BLK - 1) / BLK;
     const int64_t gb0 = o / BLK;
     // per-thread constants of the fixed-lag step (thread = (state, base of the block))
-    TV(int, fS2); TV(int, fLag); TV(int, fSg);
+    // stage 1: the threads below A1T make the fixed-lag states and stage the next block; the wavefronts from UW0 on take the UTR units
+    // (blocks of up to 4 bases: one wavefront for the former, two (state, base) pairs per thread, seven for the latter)
+    constexpr int UW0 = BLK == 8 ? 3 : 1, A1T = UW0 * WAVE, FR = (DFIX * BLK + A1T - 1) / A1T;
+    static_assert(BLK * NSIG <= A1T, "roles of stage 1");
+    constexpr int UH = 2; // candidates a lane of a UTR unit has in flight (three spill registers)
+    TV2(int, fS2, FR); TV2(int, fLag, FR); TV2(int, fSg, FR);
     // per-thread constants of the chain runs (thread = slot): the state, its own ancestor index, whether the only chain state of its
     // stage among its ancestors is the state itself (then its run over the block is a recurrence in registers)
     TV(int, cS2); TV(int, cSelf); TV(int, cFast); TV(int, cSgi);
     FOR_THREADS(t) {
-        TX(fS2) = -1; TX(fLag) = 1; TX(fSg) = 0;
         TX(cS2) = -1; TX(cSelf) = -1; TX(cFast) = 0; TX(cSgi) = SIG_EIN;
-        if (t < nFix * BLK) {
-            const int s2 = fixS[t / BLK], k = T.kind[s2];
-            TX(fS2) = s2;
-            TX(fLag) = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
-            TX(fSg) = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
+        for (int r = 0; r < FR; r++) {
+            const int f = t + r * A1T;
+            fS2[r][TI] = -1; fLag[r][TI] = 1; fSg[r][TI] = 0;
+            if (t < A1T && f < nFix * BLK) {
+                const int s2 = fixS[f / BLK], k = T.kind[s2];
+                fS2[r][TI] = s2;
+                fLag[r][TI] = (k == AUGX_K_LONGDSS || k == AUGX_K_RLONGDSS) ? dssWhole : (k == AUGX_K_LONGASS || k == AUGX_K_RLONGASS) ? assLag : dL;
+                fSg[r][TI] = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
+            }
         }
         if (t < DCH) {
             const int s2 = t < nCh ? chS[t] : -1;
@@ -762,10 +770,6 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         }
     }
     constexpr int NTW = NT - WAVE;
-    // stage 1: the threads below A1T make the fixed-lag states and stage the next block; the wavefronts from UW0 on take the UTR units
-    constexpr int UW0 = BLK == 8 ? 3 : 2, A1T = UW0 * WAVE;
-    constexpr int UH = 2; // candidates a lane of a UTR unit has in flight (three spill registers)
-    static_assert(DFIX * BLK <= A1T && 8 * NSIG <= 2 * WAVE, "roles of stage 1");
     FOR_THREADS(t) { // block 0: offsets, signal records, gates
         if (t == NT - 1) { (*lp(&L.bOff[0])) = gp(gBlkOff)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][0])) = gp(gBlkCnt)[gb0 * 2 + 1]; (*lp(&L.bCnt[0][1])) = gp(gBlkSplit)[gb0 * 3 + 2]; }
         if (t >= NT - BLK * NSIG) { const int i = t - (NT - BLK * NSIG); (*lp(&L.sg[0][i / NSIG][i % NSIG])) = i / NSIG < n ? gp(gSig)[(int64_t)(i / NSIG) * NSIG + i % NSIG] : AUGX_NINF; }
@@ -1007,11 +1011,12 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                 const uint32_t words = (uc < (uint32_t)UDCAP ? uc : (uint32_t)UDCAP) * UDW;
                 for (uint32_t i = (uint32_t)t; i < words; i += A1T) (*lp(&L.ud[par ^ 1][i])) = gp(gUd)[uo * UDW + i];
             }
-            if (TX(fS2) >= 0) {
-                const int s2 = TX(fS2), dj = t % BLK, j = jb + dj;
+            _Pragma("unroll") for (int r = 0; r < FR; r++)
+            if (fS2[r][TI] >= 0) {
+                const int s2 = fS2[r][TI], dj = (t + r * A1T) % BLK, j = jb + dj;
                 if (j >= 1 && j < n) {
-                    const int lag = TX(fLag);
-                    const double emi = (*lp(&L.sg[par][dj][TX(fSg)]));
+                    const int lag = fLag[r][TI];
+                    const double emi = (*lp(&L.sg[par][dj][fSg[r][TI]]));
                     double f = AUGX_NINF;
                     int fa = 0xFF;
                     if (j - lag >= 0 && emi > AUGX_NINF) {
