@@ -622,6 +622,11 @@ struct DenseLds {
     double oth[DCH][8];              // [slot][base of the block]: what reaches the chain state from the other states
     uint8_t othAi[DCH][8];
     uint64_t ud[2][UDCAP * UDW];     // the descriptors themselves ([parity])
+    // the tables a UTR candidate reads, by number (a pointer taken from the model or batch structure is a scalar load from HBM and a
+    // wait each time): the eight length distributions + the tail distribution of the truncated 3' UTR, their last entries; the six site lists
+    const double *lenTab[9];
+    int lenMax[9];
+    const USite *siteTab[6];
 };
 
 // value of state a at base q for the block that begins at jb: from the ring while no base of the block has taken its column
@@ -745,6 +750,12 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                 fSg[r][TI] = k == AUGX_K_LONGDSS ? SIG_DSSF : k == AUGX_K_RLONGDSS ? SIG_DSSR : k == AUGX_K_LONGASS ? SIG_ASSF : k == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
             }
         }
+        if (t == NT - 1 && T.utr) {
+            const double *lt[9] = {T.len5s, T.len5i, T.len5n, T.len5t, T.len3s, T.len3i, T.len3n, T.len3t, T.tail3s};
+            const int lm[9] = {T.uML, T.uML, T.uML, T.uML, T.uM3S, T.uML, T.uML, T.uM3T, T.uM3S};
+            for (int i = 0; i < 9; i++) { (*lp(&L.lenTab[i])) = lt[i]; (*lp(&L.lenMax[i])) = lm[i]; }
+            for (int i = 0; i < 6; i++) (*lp(&L.siteTab[i])) = UX.list(i);
+        }
         if (t < DCH) {
             const int s2 = t < nCh ? chS[t] : -1;
             (*lp(&L.chS[t])) = s2;
@@ -783,7 +794,9 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
     }
     BLOCK_SYNC();
     // what reaches chain slot `slot` at base jb + dj from the states that are not made in its own run
-    auto chainOthers = [&](int slot, int dj, int jb, int par) __attribute__((always_inline)) {
+    // (acc: the other states are variable-length states whose cells of this block still sit in the accumulators -- the value of the
+    //  base before is taken from there, as cellsOf makes it, so that this step need not wait for the cells)
+    auto chainOthers = [&](int slot, int dj, int jb, int par, bool acc) __attribute__((always_inline)) {
         const int s2 = (*lp(&L.chS[slot])), j = jb + dj;
         double f = AUGX_NINF;
         int fa = 0xFF;
@@ -796,7 +809,11 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                 x[k2] = AUGX_NINF;
                 if (k2 < nd) {
                     const int a = (*lp(&L.chDead[slot][k2])), ai = (*lp(&L.chDeadAi[slot][k2]));
-                    const double pv = ldsLoadD(&L.ring[(j - 1) & 63][a]);
+                    double pv;
+                    if (acc && dj >= 1 && j - 1 >= 1) {
+                        pv = (*lp(&L.cmax[par][dj - 1][a]));
+                        if (FWD) pv = (*lp(&L.csum[par][dj - 1][a])) > 0ull ? pv + log((double)(*lp(&L.csum[par][dj - 1][a])) / FWD_FIX) : AUGX_NINF;
+                    } else pv = ldsLoadD(&L.ring[(j - 1) & 63][a]);
                     if (pv > AUGX_NINF) x[k2] = pv + (trn(cc, s2, ai) + emi);
                     if (x[k2] > m) { m = x[k2]; fa = ai; } // (ascending ancestors, strict '>': the first of equals, as the reference)
                     fin += x[k2] > AUGX_NINF;
@@ -863,10 +880,20 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             prev = f;
         }
     };
+    bool lateAcc = true; // (uniform) every state that feeds a late chain state from outside its stage is a variable-length state of stage 2
+    for (int slot = nEarly; slot < nCh; slot++) {
+        const int s2 = chS[slot];
+        for (int ai = 0; ai < T.n_anc[s2]; ai++) {
+            const int a = T.anc[s2][ai], ka = T.kind[a];
+            const bool live = isChainKind(ka) && !isEarlyChainKind(ka);
+            if (!live && !((isItemKind(ka) && ka != AUGX_K_RTERMINAL) || isUtrExonKind(ka))) lateAcc = false;
+        }
+    }
     for (int b = 0; b < nBlocks; b++) {
         const int jb = b * BLK, par = b & 1;
         const int64_t gb = gb0 + b;
         DPROF(0);
+        const bool redoBlock = nUv > 0 && jb + BLK > n - 1 && jb <= n - 1; // (the block of the last base: one of its cells is made twice, below)
         const uint64_t i0 = (*lp(&L.bOff[par]));
         const uint32_t cntAll = (*lp(&L.bCnt[par][0])), cntNonRT = (*lp(&L.bCnt[par][1]));
         auto candValue = [&](const Item &I, int &dj, int &s2) __attribute__((always_inline)) -> double {
@@ -908,7 +935,8 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                         if (mine >= nun) continue;
                         const UDesc D = d < (uint32_t)UDCAP ? *(const UDesc *)&L.ud[par][d * UDW] : B.ud[uo + d];
                         const int s2 = D.s, dj = D.j - jb, cc = clsAt(D.j), na = (*lp(&L.nanc[s2]));
-                        const USite *sites = UX.list(D.list);
+                        const USite *sites = (*lp(&L.siteTab[D.list]));
+                        const int lsel = D.len;
                         for (int c = mine; c < nun; c += NWAVES - UW0) {
                             FOR_WLANES(t, w) {
                                 int xi[UH], eop[UH], len[UH], lis[UH];
@@ -942,7 +970,10 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                                         const int r = utrCandPre(UX, D, xi[h], sPos[h], sB[h], sig[h], len[h], tail3[h], eop[h], defer);
                                         act[h] = r == 1;
                                     }
-                                    if (act[h] && !pre[h]) lnLen[h] = utrLenAt(T, D.len, len[h], tail3[h]);
+                                    if (act[h] && !pre[h]) { // (utrLenAt, from the tables in LDS)
+                                        const int ti = tail3[h] ? 8 : lsel;
+                                        lnLen[h] = (len[h] >= 0 && len[h] <= (*lp(&L.lenMax[ti]))) ? gp((*lp(&L.lenTab[ti])))[len[h]] : AUGX_NINF;
+                                    }
                                 }
                                 // the predecessors' values: every load in flight before the first is used
                                 double pv[UH][4];
@@ -1041,7 +1072,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         // ---- 2: the records of kCand but RTERMINAL (their predecessors: earlier blocks, or fixed-lag states of this one); the early chain
         //         states (geometric introns: fed by the fixed-lag states of the base before and by themselves)
         itemPass(0, cntNonRT, false);
-        FOR_THREADS(t) { if (t >= WAVE && t - WAVE < nEarly * BLK) chainOthers((t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
+        FOR_THREADS(t) { if (t >= WAVE && t - WAVE < nEarly * BLK) chainOthers((t - WAVE) / BLK, (t - WAVE) % BLK, jb, par, false); }
         BLOCK_SYNC();
         DPROF(3);
         if (FWD) { itemPass(0, cntNonRT, true); if (nUv > 0) utrPass(true, -1, false); BLOCK_SYNC(); }
@@ -1050,6 +1081,8 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         FOR_THREADS(t) {
             if (t >= WAVE) cellsOf(t, (1 << 1) | (1 << 3));
                 if (t < nEarly) { if (TX(cFast)) chainRunSelf(t, TX(cS2), TX(cSelf), TX(cSgi), jb, par); else chainRun(t, jb, par); }
+            // (what reaches the late chain states, where it can be read from the accumulators: beside the cells instead of after them)
+            if (lateAcc && !redoBlock && t >= NT - (nCh - nEarly) * BLK) { const int u = t - (NT - (nCh - nEarly) * BLK); chainOthers(nEarly + u / BLK, u % BLK, jb, par, true); }
         }
         BLOCK_SYNC();
         DPROF(5);
@@ -1080,8 +1113,10 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         }
         DPROF(6);
         // ---- 4: late chain states (intergenic, UTR introns: fed by the exon cells of the base before and by themselves)
-        FOR_THREADS(t) { if (t >= WAVE && t - WAVE < (nCh - nEarly) * BLK) chainOthers(nEarly + (t - WAVE) / BLK, (t - WAVE) % BLK, jb, par); }
-        BLOCK_SYNC();
+        if (!(lateAcc && !redoBlock)) {
+            FOR_THREADS(t) { if (t >= WAVE && t - WAVE < (nCh - nEarly) * BLK) chainOthers(nEarly + (t - WAVE) / BLK, (t - WAVE) % BLK, jb, par, false); }
+            BLOCK_SYNC();
+        }
         FOR_THREADS(t) { if (t >= nEarly && t < nCh) { if (TX(cFast)) chainRunSelf(t, TX(cS2), TX(cSelf), TX(cSgi), jb, par); else chainRun(t, jb, par); } }
         BLOCK_SYNC();
         DPROF(7);
