@@ -1423,7 +1423,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         const size_t cap = got.first;
         P.Fown = std::shared_ptr<double>(got.second, [cap](double *q) {
             std::lock_guard<std::mutex> lk(g_fPoolMu);
-            if (g_fPool.size() < 16) g_fPool.push_back({cap, q}); else delete[] q;
+            if (g_fPool.size() < 24) g_fPool.push_back({cap, q}); else delete[] q;
         });
     }
     P.F = P.Fown.get();

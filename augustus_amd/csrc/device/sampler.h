@@ -243,15 +243,25 @@ inline void prepareStops(SamplePiece &P) {
                 }
             if (!(cnt == 1 && self)) v.push_back(j);
         }
-        // the options of every stop (the same for every sampled path; made here, ahead of the sampling and on another thread)
-        P.stopList[s].resize(v.size()); P.stopCum[s].resize(v.size()); P.stopP0[s].resize(v.size()); P.stopSelf[s].resize(v.size());
+        // the options of every stop (the same for every sampled path; made here, ahead of the sampling and on another thread).
+        // A stop whose most probable option is the state itself with everything else below 1e-5 of the total decides nothing
+        // either: the draw is z = rand() / RAND_MAX * total * 0.99999 <= total * 0.99999, and the state itself is taken whenever
+        // z < p(itself) -- with total * 0.99999 < p(itself) that is every draw (same expression, same rounding: the product is
+        // monotone in rand()).  Such stops are dropped: the path runs through them as through any other base of the run.
+        std::vector<int32_t> kept;
         for (size_t c = 0; c < v.size(); c++) {
-            OptList &L = P.stopList[s][c];
+            OptList L;
             buildOptions(P, s, v[c], L);
-            P.stopCum[s][c] = L.cum;
-            P.stopP0[s][c] = L.p.empty() ? 0.0 : L.p[0];
-            P.stopSelf[s][c] = !L.o.empty() && L.o[0].state == s && L.o[0].base == v[c] - 1;
+            const bool selfFirst = !L.o.empty() && L.o[0].state == s && L.o[0].base == v[c] - 1;
+            const double p0 = L.p.empty() ? 0.0 : L.p[0];
+            if (selfFirst && L.cum > 0 && 1.0 * L.cum * 0.99999 < p0) continue;
+            kept.push_back(v[c]);
+            P.stopCum[s].push_back(L.cum);
+            P.stopP0[s].push_back(p0);
+            P.stopSelf[s].push_back(selfFirst);
+            P.stopList[s].push_back(std::move(L));
         }
+        v.swap(kept);
     }
     P.prepared = true;
 #ifdef AUGX_EMU

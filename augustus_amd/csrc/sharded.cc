@@ -146,7 +146,7 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             if (rc) errs[d] = augx_last_error();
             // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
             // (it does not depend on the draws), also while earlier batches are still being sampled
-            const int AHEAD = 8;
+            const int AHEAD = 12;
             struct Prep { int rc; augx_sample_prep *h; std::string err; }; // (augx_last_error is thread-local: the text travels with the result)
             std::vector<std::future<Prep>> prep((size_t)cnt);
             std::vector<std::future<void>> frees;
