@@ -59,7 +59,18 @@ def main():
         opts = {"UTR": "off", "sample": rng.choice(["0", "20", "50", "100"])}
         if rng.random() < 0.5:
             opts["softmasking"] = "0"
-        if rng.random() < 0.2:
+        dense = os.environ.get("AUGX_SOAK_DENSE") and rng.random() < 0.7
+        if dense:  # the models of the dense kernels: UTR states (one-class species: see DESIGN.md 6 for the others) / two intergenic states
+            if rng.random() < 0.6:
+                species = rng.choice(["fly", "arabidopsis"])
+                opts["UTR"] = "on"
+                if rng.random() < 0.3:
+                    opts["print_utr"] = "on"
+                if rng.random() < 0.3:
+                    opts["genemodel"] = "complete"
+            else:
+                opts["genemodel"] = rng.choice(["atleastone", "exactlyone"])
+        elif rng.random() < 0.2:
             opts["genemodel"] = rng.choice(["intronless", "complete"])
         if rng.random() < 0.25:
             opts["strand"] = rng.choice(["forward", "backward"])
