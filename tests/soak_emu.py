@@ -89,6 +89,8 @@ def main():
                 opts["keep_viterbi"] = rng.choice(["true", "false"])
         fa = os.path.join(d, "c%d.fa" % seed)
         write_fasta(fa, recs)
+        if os.environ.get("AUGX_SOAK_KEEP"):  # (to look at a case: its FASTA file stays)
+            write_fasta(os.environ["AUGX_SOAK_KEEP"], recs)
         ref = subprocess.run([REF_AUGUSTUS, "--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa], capture_output=True, text=True, env=env)
         verdict = None
         try:
