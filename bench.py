@@ -363,10 +363,23 @@ def utr_leg(cfg, local, a):
     b.close(); d.close()
     tr_s = float(np.mean(ms["trellis"])) / 1e3
     achieved = (0.25 + 20.0 * S) * bases / tr_s / 1e9
+    # HBM bytes of the kernel from the PMC passes of profiles/run_pmc.sh, taken with this very tree (as for the headline kernel)
+    traffic, tsrc = None, "no profiles/*_utr_hbm_traffic.json was taken with this source tree: run profiles/run_pmc.sh"
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from source_sha import source_sha
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_utr_hbm_traffic.json"):
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                tj = json.load(fh)
+            kd = [v for k, v in tj.get("kernels", {}).items() if k.startswith("kDense") and k.endswith("0>")]
+            if tj.get("source_sha") == source_sha() and kd:
+                traffic, tsrc = kd[0]["traffic_bytes_per_bp"] * bases, "profiles/" + name
+                break
     out = {"value": bases * a.steps / dt / 1e6, "unit": "Mbp/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps,
            "config": {"workload": "synthetic uniform-random DNA, %d contigs x %d bp, --species=human --UTR=on ab initio (%d states, sample=0)"
                                   % (a.utr_contigs, a.utr_contig_len, S)},
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                        "traffic_unit": "bytes per launch (PMC, %s)" % tsrc,
                         "kernel": "kDense<4,0>", "kernel_ms": tr_s * 1e3, "prep_ms": float(np.mean(ms["prep"])), "backtrace_ms": float(np.mean(ms["back"])),
                         "positions_per_s_per_piece": a.utr_contig_len / tr_s}}
     if not a.no_cpu_baseline and os.path.exists(REF_AUGUSTUS):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""sha256 (first 16 hex digits) over the sources a profile depends on: the device and host code of libaugx.so and bench.py.
+"""sha256 (first 16 hex digits) over the sources a profile depends on: the device and host code of libaugx.so and the Makefile.
 Printed by profiles/run_profile.sh / run_pmc.sh into what they write; bench.py quotes a profile only when the hash of the tree it
 runs in is the same (there is no .git on the GPU box)."""
 import hashlib
