@@ -412,6 +412,7 @@ struct augx_decoder {
     std::unordered_map<void *, size_t> live;
     size_t pooledBytes = 0;
     std::mutex poolMu;        // (another decoder of the same device may empty this pool when its own allocation fails)
+    std::vector<hipStream_t> copyStreams; // (snippetCacheReplay: one per piece replayed at a time)
     bool dense = false;        // the model is decoded by the dense kernels (dense.h)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
@@ -658,6 +659,7 @@ void augx_decoder_destroy(augx_decoder *d) {
     for (void *p : d->tableBufs) (void)hipFree(p);
     if (d->dT) (void)hipFree(d->dT);
     if (d->stream) (void)hipStreamDestroy(d->stream);
+    for (hipStream_t cs : d->copyStreams) if (cs) (void)hipStreamDestroy(cs);
     delete d;
 }
 
@@ -1014,10 +1016,19 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     if (d->exactMulti && b->nPlAlloc > 1 && !d->dense) {
         int64_t nPatched = 0;
         int rc2;
+        const bool timing = getenv("AUGX_TIMING") != nullptr; // (developer aid)
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        if (timing) (void)hipStreamSynchronize(st);
+        const double t0 = timing ? now() : 0.0;
         try { rc2 = snippetCacheReplay(d, b, nPatched, true); }
         catch (const std::exception &e) { setLastError(std::string("augx_batch_decode: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc2) return rc2;
+        const double t1 = timing ? now() : 0.0;
         if (nPatched > 0 && (rc2 = runTrellis())) return rc2;
+        if (timing) {
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "augx timing:     pieces with several GC classes: snippet-cache replay %.3f s (%lld candidate terms rebuilt), second trellis run %.3f s\n", t1 - t0, (long long)nPatched, now() - t1);
+        }
     }
     HIP_TRY(hipEventRecord(b->ev[3], st));
     return AUGX_OK;
@@ -1190,7 +1201,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     HIP_TRY(hipMemcpy(nPl.data(), V.nPlanes, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     std::vector<uint64_t> pIdx;
     std::vector<double> pTe;
-    // what the replay of one piece reads, fetched from HBM; the replays themselves run side by side on host threads, eight pieces
+    // what the replay of one piece reads, fetched from HBM; the replays themselves run side by side on host threads, 32 pieces
     // at a time (each holds its piece's candidate records: 0.23 GB per Mbp)
     struct PieceData {
         SnippetReplay R;
@@ -1199,7 +1210,16 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
         std::vector<int32_t> planeCls;
         std::vector<uint64_t> blkOff;
         std::vector<uint32_t> blkCnt;
+        hipStream_t st = nullptr; // the copies of one window are queued on a stream of the piece's own and waited for once (a window is
+                                  // dozens of small copies: one wait each, on the one default stream of the process, was most of the replay's time)
     };
+    constexpr int GROUP = 32; // pieces replayed side by side
+    if (d->copyStreams.empty()) { // (made once per decoder: creating a stream takes milliseconds)
+        d->copyStreams.assign(GROUP, nullptr);
+        for (int i = 0; i < GROUP; i++)
+            if (hipStreamCreateWithFlags(&d->copyStreams[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); d->copyStreams[i] = nullptr; }
+    }
+    hipStream_t *copySt = d->copyStreams.data();
     auto fetch = [&](int p, PieceData &D) -> int {
         SnippetReplay &R = D.R;
         const int len = b->L.len[p];
@@ -1241,6 +1261,8 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
         // the slots of the intron content prefix from d bases before it on
         R.fetch = [=](int t0, int t1) -> int {
             SnippetReplay &R2 = DP->R;
+            const hipStream_t cst = DP->st;
+            auto cpy = [cst](void *dst, const void *src, size_t bytes) { return cst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cst) : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
             if (t0 < 0) t0 = 0;
             if (t1 > len - 1) t1 = len - 1;
             const int r0 = t0 - R2.d - 2 > 0 ? t0 - R2.d - 2 : 0;
@@ -1259,14 +1281,14 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
                     if (DP->blkCnt[(size_t)q1 * 2 + 1]) { R2.blkPool[(size_t)q1] = (int64_t)(w + (a1 - a0)); a1 += DP->blkCnt[(size_t)q1 * 2 + 1]; }
                     q1++;
                 }
-                if (a1 > a0) HIP_TRY(hipMemcpy(R2.pool.data() + w, V.items + a0, sizeof(Item) * (size_t)(a1 - a0), hipMemcpyDeviceToHost));
+                if (a1 > a0) HIP_TRY(cpy(R2.pool.data() + w, V.items + a0, sizeof(Item) * (size_t)(a1 - a0)));
                 w += (size_t)(a1 - a0);
                 if (q1 == q) q1 = q + 1; // (cannot happen: the first block of a run always joins it)
                 q = q1;
             }
             if (!fromLists) {
                 DP->F.resize((size_t)(t1 - r0 + 1) * S);
-                HIP_TRY(hipMemcpy(DP->F.data(), V.fwd + (o + 1 + r0) * S, sizeof(double) * DP->F.size(), hipMemcpyDeviceToHost));
+                HIP_TRY(cpy(DP->F.data(), V.fwd + (o + 1 + r0) * S, sizeof(double) * DP->F.size()));
                 R2.F = DP->F.data(); R2.fRow0 = r0;
             }
             // prefix slots r0 .. t1 + 1 (slot g = prefix up to base g - 1) of both strands and every plane: field rows of CHUNK slots
@@ -1281,10 +1303,11 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
                         int cnt = (int)((ch + 1) * CHUNK - slot);
                         if (cnt > g1 - g + 1) cnt = g1 - g + 1;
                         const uint64_t *src = V.fx + (int64_t)pl * V.N * NFX + (ch * NFX + (rev ? FX_INR : FX_INF)) * CHUNK + slot % CHUNK;
-                        HIP_TRY(hipMemcpy(dst.data() + (g - g0), src, sizeof(uint64_t) * (size_t)cnt, hipMemcpyDeviceToHost));
+                        HIP_TRY(cpy(dst.data() + (g - g0), src, sizeof(uint64_t) * (size_t)cnt));
                         g += cnt;
                     }
                 }
+            if (cst) HIP_TRY(hipStreamSynchronize(cst));
             return AUGX_OK;
         };
         return AUGX_OK;
@@ -1292,14 +1315,21 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     std::vector<int> todo;
     for (int p = 0; p < n; p++)
         if (nPl[p] > 1) todo.push_back(p);
-    for (size_t g0 = 0; g0 < todo.size(); g0 += 8) {
-        const size_t g1 = g0 + 8 < todo.size() ? g0 + 8 : todo.size();
+    const bool timing = getenv("AUGX_TIMING") != nullptr; // (developer aid)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tFetch = 0, tRun = 0;
+    for (size_t g0 = 0; g0 < todo.size(); g0 += GROUP) {
+        const size_t g1 = g0 + GROUP < todo.size() ? g0 + GROUP : todo.size();
         std::vector<std::unique_ptr<PieceData>> grp;
+        const double tf0 = timing ? now() : 0.0;
         for (size_t k = g0; k < g1; k++) {
             grp.emplace_back(new PieceData());
+            grp.back()->st = copySt[k - g0];
             const int rc = fetch(todo[k], *grp.back());
             if (rc) return rc;
         }
+        const double tf1 = timing ? now() : 0.0;
+        tFetch += tf1 - tf0;
         std::vector<std::future<int>> runs;
         int rcRun = 0;
         for (auto &D : grp) {
@@ -1311,11 +1341,13 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
             }
         }
         for (auto &f : runs) { const int r1 = f.get(); if (r1 && !rcRun) rcRun = r1; }
+        if (timing) tRun += now() - tf1;
         if (rcRun) { setLastError("augx: fetching the data of a snippet-cache window failed"); return rcRun; }
         for (auto &D : grp)
             for (const MemoPatch &mp : D->R.patches) { pIdx.push_back(mp.item); pTe.push_back(mp.te); }
     }
     nPatched = (int64_t)pIdx.size();
+    if (timing) fprintf(stderr, "augx timing:       replay of %zu pieces: per-piece tables fetched in %.3f s, windows replayed (%d pieces side by side) in %.3f s\n", todo.size(), tFetch, GROUP, tRun);
     if (pIdx.empty()) return AUGX_OK;
     void *dIdx = nullptr, *dTe = nullptr;
     if (devMalloc(d, &dIdx, sizeof(uint64_t) * pIdx.size()) != hipSuccess || devMalloc(d, &dTe, sizeof(double) * pTe.size()) != hipSuccess) {
