@@ -1201,7 +1201,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     HIP_TRY(hipMemcpy(nPl.data(), V.nPlanes, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
     std::vector<uint64_t> pIdx;
     std::vector<double> pTe;
-    // what the replay of one piece reads, fetched from HBM; the replays themselves run side by side on host threads, 32 pieces
+    // what the replay of one piece reads, fetched from HBM; the replays themselves run side by side on host threads, 48 pieces
     // at a time (each holds its piece's candidate records: 0.23 GB per Mbp)
     struct PieceData {
         SnippetReplay R;
@@ -1213,7 +1213,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
         hipStream_t st = nullptr; // the copies of one window are queued on a stream of the piece's own and waited for once (a window is
                                   // dozens of small copies: one wait each, on the one default stream of the process, was most of the replay's time)
     };
-    constexpr int GROUP = 32; // pieces replayed side by side
+    constexpr int GROUP = 48; // pieces replayed side by side
     if (d->copyStreams.empty()) { // (made once per decoder: creating a stream takes milliseconds)
         d->copyStreams.assign(GROUP, nullptr);
         for (int i = 0; i < GROUP; i++)
@@ -1222,34 +1222,38 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     hipStream_t *copySt = d->copyStreams.data();
     auto fetch = [&](int p, PieceData &D) -> int {
         SnippetReplay &R = D.R;
+        const hipStream_t fst = D.st; // (the piece's own stream: queued, waited for once)
+        auto cp = [fst](void *dst, const void *src, size_t bytes) { return fst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, fst) : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
         const int len = b->L.len[p];
         const int64_t o = b->L.off[p];
         R.t = &d->model->m.t; R.n = len; R.S = S; R.blk = V.blk; R.d = d->model->m.t.d; R.nPlanes = nPl[p];
         if (!fromLists) { // (the rows of F a window reads are fetched with the window; the initial column now)
             D.F0.resize((size_t)S);
-            HIP_TRY(hipMemcpy(D.F0.data(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)S, hipMemcpyDeviceToHost));
+            HIP_TRY(cp(D.F0.data(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)S));
         } else { // (after a Viterbi run: what the trellis left at the donor sites of the short introns, and the initial column)
             int64_t lo2[2] = {0, 0};
-            HIP_TRY(hipMemcpy(lo2, V.listOffs + p, sizeof(int64_t) * 2, hipMemcpyDeviceToHost));
+            HIP_TRY(cp(lo2, V.listOffs + p, sizeof(int64_t) * 2));
+            if (D.st) HIP_TRY(hipStreamSynchronize(D.st));
             const size_t cnt = (size_t)(lo2[1] - lo2[0]) * 3;
             D.ldV.resize(cnt + 1); D.rdV.resize(cnt + 1);
             if (cnt) {
-                HIP_TRY(hipMemcpy(D.ldV.data(), V.ldVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-                HIP_TRY(hipMemcpy(D.rdV.data(), V.rdVal + lo2[0] * 3, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+                HIP_TRY(cp(D.ldV.data(), V.ldVal + lo2[0] * 3, sizeof(double) * cnt));
+                HIP_TRY(cp(D.rdV.data(), V.rdVal + lo2[0] * 3, sizeof(double) * cnt));
             }
             D.col0.resize((size_t)S);
             for (int s2 = 0; s2 < S; s2++) D.col0[s2] = b->L.initKind[p] == 0 ? d->hostT.ln_init[s2] : (s2 == d->hostT.synch ? 0.0 : -INFINITY);
         }
         D.plane.resize((size_t)len);
-        HIP_TRY(hipMemcpy(D.plane.data(), V.gcPlane + o + 1, (size_t)len, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(D.plane.data(), V.gcPlane + o + 1, (size_t)len));
         D.planeCls.resize(MAXPL);
-        HIP_TRY(hipMemcpy(D.planeCls.data(), V.planeCls + (int64_t)p * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(D.planeCls.data(), V.planeCls + (int64_t)p * MAXPL, sizeof(int32_t) * MAXPL));
         const int nBlocks = (len + V.blk - 1) / V.blk;
         const int64_t gb0 = o / V.blk;
         D.blkOff.resize((size_t)nBlocks * 2);
         D.blkCnt.resize((size_t)nBlocks * 2);
-        HIP_TRY(hipMemcpy(D.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * D.blkOff.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(D.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * D.blkCnt.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(cp(D.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * D.blkOff.size()));
+        HIP_TRY(cp(D.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * D.blkCnt.size()));
+        if (D.st) HIP_TRY(hipStreamSynchronize(D.st));
         R.F = nullptr; R.F0 = fromLists ? nullptr : D.F0.data(); R.ldVal = D.ldV.data(); R.rdVal = D.rdV.data(); R.col0 = D.col0.data();
         R.plane = D.plane.data(); R.planeCls = D.planeCls.data(); R.blkOff = D.blkOff.data(); R.blkCnt = D.blkCnt.data();
         R.items = nullptr; R.item0 = 0;
@@ -1325,18 +1329,19 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
         for (size_t k = g0; k < g1; k++) {
             grp.emplace_back(new PieceData());
             grp.back()->st = copySt[k - g0];
-            const int rc = fetch(todo[k], *grp.back());
-            if (rc) return rc;
         }
         const double tf1 = timing ? now() : 0.0;
         tFetch += tf1 - tf0;
         std::vector<std::future<int>> runs;
         int rcRun = 0;
-        for (auto &D : grp) {
+        for (size_t k = g0; k < g1; k++) { // (the piece's tables are fetched by its own thread, too)
+            PieceData *D = grp[k - g0].get();
+            const int p = todo[k];
+            auto job = [&fetch, D, p, d]() { (void)hipSetDevice(d->device); const int r0 = fetch(p, *D); return r0 ? r0 : D->R.run(); };
             try {
-                runs.push_back(std::async(std::launch::async, [&D, d]() { (void)hipSetDevice(d->device); return D->R.run(); }));
+                runs.push_back(std::async(std::launch::async, job));
             } catch (const std::system_error &) { // (no more threads to be had: this piece on the calling thread)
-                const int r1 = D->R.run();
+                const int r1 = job();
                 if (r1 && !rcRun) rcRun = r1;
             }
         }
@@ -1347,7 +1352,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
             for (const MemoPatch &mp : D->R.patches) { pIdx.push_back(mp.item); pTe.push_back(mp.te); }
     }
     nPatched = (int64_t)pIdx.size();
-    if (timing) fprintf(stderr, "augx timing:       replay of %zu pieces: per-piece tables fetched in %.3f s, windows replayed (%d pieces side by side) in %.3f s\n", todo.size(), tFetch, GROUP, tRun);
+    if (timing) fprintf(stderr, "augx timing:       replay of %zu pieces: set up in %.3f s, tables fetched and windows replayed (%d pieces side by side) in %.3f s\n", todo.size(), tFetch, GROUP, tRun);
     if (pIdx.empty()) return AUGX_OK;
     void *dIdx = nullptr, *dTe = nullptr;
     if (devMalloc(d, &dIdx, sizeof(uint64_t) * pIdx.size()) != hipSuccess || devMalloc(d, &dTe, sizeof(double) * pTe.size()) != hipSuccess) {
