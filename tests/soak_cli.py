@@ -49,7 +49,19 @@ def main():
         opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
         if rng.random() < 0.4:
             opts["softmasking"] = "0"
-        if rng.random() < 0.3:
+        dense = os.environ.get("AUGX_SOAK_DENSE") and rng.random() < 0.7
+        if dense:  # the models of the dense kernels: UTR states (fly: one GC class, see DESIGN.md 6 for the others) / two intergenic states
+            if rng.random() < 0.6:
+                species = "fly"
+                opts["UTR"] = "on"
+                if rng.random() < 0.3:
+                    opts["print_utr"] = "on"
+                if rng.random() < 0.3:
+                    opts["genemodel"] = "complete"
+            else:
+                species = rng.choice(["fly", "arabidopsis", "saccharomyces"])  # (one class each: the dense kernels do not replay the snippet cache)
+                opts["genemodel"] = rng.choice(["atleastone", "exactlyone"])
+        elif rng.random() < 0.3:
             opts["singlestrand"] = "true"
         elif rng.random() < 0.2:
             opts["genemodel"] = rng.choice(["intronless", "complete"])
