@@ -6,6 +6,8 @@ in the build container, untracked, and let gpurun carry it:
     (cd /root/reference && tar -czf /root/repo/tmp_all_config.tar.gz config/species config/model config/extrinsic/extrinsic.cfg \
          config/parameters/aug_cmdln_parameters.json)
     gpurun -- python tests/sweep_species_gpu.py K N SECONDS       (every N-th species from K on, for at most SECONDS)
+    gpurun -- python tests/sweep_species_gpu.py K N SECONDS utr   (the species that ship UTR parameters, with --UTR=on: the dense kernels;
+                                                                   records without GC-class steps)
 Round 2: 148 of 148 species that load byte-identical; the other 19 are refused by name (bacterium gene model, window sizes
 outside the trellis kernel's scheduling, missing files of the distribution)."""
 import sys, os, subprocess, tarfile, tempfile, time
@@ -15,7 +17,8 @@ d=tempfile.mkdtemp()
 with tarfile.open("tmp_all_config.tar.gz") as t: t.extractall(d)
 cfg=os.path.join(d,"config")+"/"
 byname=dict(golden_inputs())
-recs=[(n,byname[n]) for n in ("HS04636","multigc_levels","softmask_gene","trunc_both","rand20k_b")]
+utr=len(sys.argv)>4 and sys.argv[4]=="utr"
+recs=[(n,byname[n]) for n in (("HS04636","rand20k_b","trunc_both","revcomp") if utr else ("HS04636","multigc_levels","softmask_gene","trunc_both","rand20k_b"))]
 fa=os.path.join(d,"in.fa"); write_fasta(fa,recs)
 env=dict(os.environ,AUGUSTUS_CONFIG_PATH=cfg)
 k,nw=int(sys.argv[1]),int(sys.argv[2])
@@ -23,7 +26,8 @@ t0=time.time(); nok=nfail=0
 for i,sp in enumerate(sorted(os.listdir(cfg+"species"))):
     if i%nw!=k or not os.path.exists(cfg+"species/%s/%s_parameters.cfg"%(sp,sp)): continue
     if time.time()-t0>float(sys.argv[3]): break
-    args=["--species="+sp,"--UTR=off","--maxDNAPieceSize=30000",fa]
+    if utr and not any(f.endswith("utr_probs.pbl") for f in os.listdir(cfg+"species/"+sp)): continue
+    args=["--species="+sp,"--UTR=on","--softmasking=0",fa] if utr else ["--species="+sp,"--UTR=off","--maxDNAPieceSize=30000",fa]
     ours=subprocess.run(["augustus_amd/bin/augustus"]+args,capture_output=True,text=True,env=env)
     if ours.returncode!=0:
         print(sp,"ours rc",ours.returncode,ours.stderr.strip().splitlines()[-1][:90] if ours.stderr.strip() else "",flush=True); continue
