@@ -39,12 +39,11 @@ struct augx_rand {
     }
     void refill() { // the next CH outputs from the last 31
         for (int q = 0; q < LAG; q++) x[q] = x[CH + q];
-        int i = LAG;
-        for (; i + 2 < LAG + CH; i += 3) { // (x[i + 2] reads x[i - 1]: written a turn ago)
+        static_assert(CH % 3 == 0, "three values per turn");
+        for (int i = LAG; i < LAG + CH; i += 3) { // (x[i + 2] reads x[i - 1]: written a turn ago)
             const uint32_t a = x[i - 31] + x[i - 3], b = x[i - 30] + x[i - 2], c = x[i - 29] + x[i - 1];
             x[i] = a; x[i + 1] = b; x[i + 2] = c;
         }
-        for (; i < LAG + CH; i++) x[i] = x[i - 31] + x[i - 3];
         pos = 0;
     }
     void skip(int64_t n) {
