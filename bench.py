@@ -85,6 +85,70 @@ def max_over_ranks(dt, dist):
     return float(tt.item())
 
 
+LINE_LIMIT = 5400   # the driver keeps an 8 KB tail of stdout: the JSON line must fit it with room to spare
+
+
+def parse_timing(stderr_text):
+    """The executable's AUGX_TIMING laps as {lap: seconds}; the per-batch lines (one per cut-finder round: hundreds on a long
+    contig) are COUNTED, never kept -- round 3 printed 175 of them into the JSON line and the driver could not parse it."""
+    laps, n_batches = {}, 0
+    for line in stderr_text.splitlines():
+        if not line.startswith("augx timing:"):
+            continue
+        body = line[len("augx timing:"):]
+        if body.startswith("   "):
+            n_batches += 1
+            continue
+        w = body.rsplit(None, 2)
+        try:
+            laps[w[0].strip()] = float(w[1])
+        except (IndexError, ValueError):
+            pass
+    if n_batches:
+        laps["batches"] = n_batches
+    return laps
+
+
+def bounded_line(out, limit=LINE_LIMIT):
+    """json.dumps(out) made to fit `limit` bytes: floats to 6 significant digits, then -- only while it is still too long -- the
+    descriptive strings of the secondary legs go (longest first), then whole secondary legs (last added first).  The contract keys
+    (metric, value, ..., config, roofline, cpu_baseline) are never touched.  The untrimmed object goes to gpurun_out/bench_full.json."""
+    def rnd(x):
+        if isinstance(x, float):
+            return float("%.6g" % x)
+        if isinstance(x, dict):
+            return {k: rnd(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [rnd(v) for v in x]
+        return x
+    out = rnd(out)
+    keep = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline"}
+    def strings(o, path=()):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if isinstance(v, str) and len(v) > 40 and (not path or path[0] not in keep or path[0] == "cpu_baseline" and len(path) > 1):
+                    yield len(v), path + (k,)
+                else:
+                    yield from strings(v, path + (k,))
+    while len(json.dumps(out)) >= limit:
+        cand = sorted(strings(out), reverse=True)
+        if cand:
+            _, pth = cand[0]
+            o = out
+            for k in pth[:-1]:
+                o = o[k]
+            del o[pth[-1]]
+            continue
+        extra = [k for k in out if k not in keep]
+        if not extra:
+            break
+        del out[extra[-1]]
+    line = json.dumps(out)
+    assert len(line) < limit, "bench line of %d bytes" % len(line)
+    return line
+
+
 def cpu_model_string():
     try:
         for line in open("/proc/cpuinfo"):
@@ -233,13 +297,7 @@ def e2e_legs(cfg, model, local, contigs):
                 t0 = time.perf_counter()
                 r = subprocess.run([exe, "--species=human", "--outfile=" + os.path.join(d, "out.gff"), fa], capture_output=True, env=env)
                 dt = time.perf_counter() - t0
-                laps = {}
-                for line in r.stderr.decode(errors="replace").splitlines():
-                    if line.startswith("augx timing:   batch"):
-                        laps.setdefault("batches", []).append(line[len("augx timing:"):].strip())
-                    elif line.startswith("augx timing:"):
-                        w = line[len("augx timing:"):].rsplit(None, 2)
-                        laps[w[0].strip()] = float(w[1])
+                laps = parse_timing(r.stderr.decode(errors="replace"))
                 if best is None or dt < best[0]:
                     best = (dt, laps, r.returncode)
             dt, laps, rcode = best
@@ -263,13 +321,7 @@ def e2e_legs(cfg, model, local, contigs):
             r = subprocess.run([exe, "--species=human", "--sample=100", "--outfile=" + os.path.join(d, "out_s.gff"), fa2], capture_output=True, env=env)
             dt = time.perf_counter() - t0
             b2 = sum(len(c) for c in contigs[:ns])
-            laps = {}
-            for line in r.stderr.decode(errors="replace").splitlines():
-                if line.startswith("augx timing:   "):
-                    laps.setdefault("batches", []).append(line[len("augx timing:"):].strip())
-                elif line.startswith("augx timing:"):
-                    w = line[len("augx timing:"):].rsplit(None, 2)
-                    laps[w[0].strip()] = float(w[1])
+            laps = parse_timing(r.stderr.decode(errors="replace"))
             out["cli_sampled"] = {"value": b2 / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "contigs": ns, "laps_s": laps,
                                   "region": "augustus --species=human --sample=100 (Viterbi + forward on 1 GPU, 99 sampled paths per contig on the host, "
                                             "posterior probabilities in the GFF)"}
@@ -302,13 +354,7 @@ def product_leg(cfg, a, n_dev):
                 t0 = time.perf_counter()
                 r = subprocess.run([exe] + args + ["--outfile=" + os.path.join(d, "o.gff"), fa], capture_output=True, env=env)
                 dt = time.perf_counter() - t0
-                laps = {}
-                for line in r.stderr.decode(errors="replace").splitlines():
-                    if line.startswith("augx timing:   batch"):
-                        laps.setdefault("batches", []).append(line[len("augx timing:"):].strip())
-                    elif line.startswith("augx timing:"):
-                        w = line[len("augx timing:"):].rsplit(None, 2)
-                        laps[w[0].strip()] = float(w[1])
+                laps = parse_timing(r.stderr.decode(errors="replace"))
                 if best is None or dt < best["wall_s"]:
                     best = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "laps_s": laps}
             return best
@@ -598,7 +644,13 @@ def main():
                 out["utr"] = utr_leg(cfg, local, a)
         if not a.no_product:  # (rank 0 drives every device from one process, as the executable does; the other ranks wait in the barrier)
             out["product"] = product_leg(cfg, a, world)
-        print(json.dumps(out))
+        try:  # the whole object, untrimmed, beside the line (gpurun_out/ is merged back from the GPU box)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as fh:
+                json.dump(out, fh, indent=1)
+        except OSError:
+            pass
+        print(bounded_line(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
