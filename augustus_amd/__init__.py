@@ -287,6 +287,38 @@ def decode_sampled(decoders, seqs, n_samples, rand, init_kind=0, term_kind=0):
     return res
 
 
+class _Cut(ctypes.Structure):
+    _fields_ = [("record", ctypes.c_int32), ("status", ctypes.c_int32), ("begin", ctypes.c_int64), ("end", ctypes.c_int64),
+                ("init_kind", ctypes.c_int32), ("term_kind", ctypes.c_int32)]
+
+
+class _CutStats(ctypes.Structure):
+    _fields_ = [("scout_tiles", ctypes.c_int32), ("batches", ctypes.c_int32), ("windows_decoded", ctypes.c_int32), ("windows_used", ctypes.c_int32)]
+
+
+DECODE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(_Piece), ctypes.c_int, ctypes.POINTER(_Path))
+
+
+def find_cuts(model, seqs, decode_fn, scout=-1):
+    """``augx_find_cuts``: the pieces [(record, status, begin, end, init_kind, term_kind)] the records are cut into, the exam windows
+    decoded through ``decode_fn(user, pieces, n, out_paths) -> rc`` (a DECODE_FN); also returns the statistics of the run."""
+    L = lib()
+    L.augx_find_cuts.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int64), DECODE_FN, ctypes.c_void_p,
+                                 ctypes.c_int, ctypes.POINTER(ctypes.POINTER(_Cut)), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_CutStats)]
+    L.augx_cuts_free.argtypes = [ctypes.POINTER(_Cut)]
+    keep = [s.encode() if isinstance(s, str) else s for s in seqs]
+    n = len(keep)
+    c_seqs = (ctypes.c_char_p * n)(*keep)
+    c_lens = (ctypes.c_int64 * n)(*[len(s) for s in keep])
+    out = ctypes.POINTER(_Cut)()
+    n_out = ctypes.c_int()
+    st = _CutStats()
+    _check(L.augx_find_cuts(model._h, n, c_seqs, c_lens, decode_fn, None, scout, ctypes.byref(out), ctypes.byref(n_out), ctypes.byref(st)))
+    res = [(out[i].record, out[i].status, out[i].begin, out[i].end, out[i].init_kind, out[i].term_kind) for i in range(n_out.value)]
+    L.augx_cuts_free(out)
+    return res, {"scout_tiles": st.scout_tiles, "batches": st.batches, "windows_decoded": st.windows_decoded, "windows_used": st.windows_used}
+
+
 def device_count():
     return lib().augx_device_count()
 

@@ -12,8 +12,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <iostream>
+#include <map>
+#include <queue>
+#include <set>
+#include <tuple>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -206,14 +211,13 @@ std::vector<std::pair<long, long>> lowerRuns(const char *seq, long n) {
 // exam windows: to = examEnd + 10000, src/namgene.cc:1051).  A lower-case run that continues beyond `limit` therefore
 // gives no bonus inside the piece: the piece is decoded from a copy whose trailing run is upper-cased.
 // Returns the pointer to decode from (the record itself, or the copy appended to `copies`).
-const char *pieceSequence(const std::string &seq, long begin, long end, long limit, std::vector<std::string> &copies) {
-    const long n = (long)seq.size();
+const char *pieceSequence(const char *seq, long n, long begin, long end, long limit, std::vector<std::string> &copies) {
     auto lower = [&](long i) { return seq[i] >= 'a' && seq[i] <= 'z'; };
-    if (end + 1 >= n || !lower(end) || !lower(end + 1)) return seq.data() + begin;
+    if (end + 1 >= n || !lower(end) || !lower(end + 1)) return seq + begin;
     long e = end + 1;
     while (e + 1 < n && e <= limit && lower(e + 1)) e++;
-    if (e <= limit) return seq.data() + begin; // the run ends within the limit: its feature is kept
-    copies.emplace_back(seq, (size_t)begin, (size_t)(end - begin + 1));
+    if (e <= limit) return seq + begin; // the run ends within the limit: its feature is kept
+    copies.emplace_back(seq + begin, (size_t)(end - begin + 1));
     std::string &c = copies.back();
     for (long i = (long)c.size() - 1; i >= 0 && c[i] >= 'a' && c[i] <= 'z'; i--) c[i] = (char)(c[i] - 'a' + 'A');
     return c.data();
@@ -322,6 +326,305 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
         if (!any) out += "# (none)\n";
     }
     return 0;
+}
+
+// ---- the cut finder: where the records are cut into pieces (reference NAMGene::getNextCutEndPoint, src/namgene.cc:973-1133, as
+//      called by the piece loop of doViterbiPiecewise, :575-603).  Inside a record the cuts are a serial chain: the exam window
+//      of round k+1 starts where the piece of round k ended.  Every cut that is accepted comes from the decode of exactly the
+//      window the reference decodes (same bases, same initial / terminal kinds) -- but the windows are decoded AHEAD of the
+//      chain, many per batch: a scout decode of the long records in overlapping tiles tells where the intergenic regions lie,
+//      the chain is run on that map as a FORECAST -- with the alternatives the map cannot decide: a gene cut by a window's edge
+//      may vanish from the window's path or shrink to a variant that fits -- every window any forecast asks for is decoded in
+//      one batch (windows are independent of each other), and the true chain then walks through the decoded windows until it
+//      needs one that nobody foresaw.  A cut is the centre of an intergenic region, so the alternatives meet again after a round
+//      or two and their number stays small.  The forecast decides only WHICH windows are decoded early, never a result.
+struct PieceRef { int rec; long begin, end; int initKind, termKind; };
+struct CutFinderStats { double scoutSeconds = 0; int tiles = 0, batches = 0, windows = 0, used = 0; };
+using DecodeFn = std::function<bool(const std::vector<augx_piece> &, std::vector<Decoded> &)>;
+
+bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long maxstep, bool soft, int scoutMode /* -1: decide here */, int nDevices,
+                   const DecodeFn &decode, std::vector<std::vector<PieceRef>> &recPieces, std::vector<int> &failStatus, CutFinderStats &stats) {
+    struct CutState {
+        long beginPos = 0;
+        int prevInit = 0, prevTerm = 0; // init/term kinds in effect while the exam window is decoded (state leak, src/namgene.cc:576 vs 594-603)
+        int attempt = 0;
+        long examChunk = 0, es = 0, ee = 0;
+        bool done = false;
+    };
+    struct WinKey {
+        int rec; long es, ee; int ik, tk;
+        bool operator<(const WinKey &o) const { return std::tie(rec, es, ee, ik, tk) < std::tie(o.rec, o.es, o.ee, o.ik, o.tk); }
+    };
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    recPieces.assign(recs.size(), {});
+    failStatus.assign(recs.size(), 0);
+    std::vector<CutState> cs(recs.size());
+    // one step of the chain of record r on state c: the pieces it can emit without a window, then the window it needs next
+    // (false: the record is finished)
+    auto emitPiece = [&](size_t r, CutState &c, long endPos, std::vector<PieceRef> *emit) {
+        const long seqlen = recs[r].len;
+        PieceRef pr;
+        pr.rec = (int)r; pr.begin = c.beginPos; pr.end = endPos;
+        pr.initKind = c.beginPos == 0 ? 0 : 1;
+        pr.termKind = endPos == seqlen - 1 ? 0 : 1;
+        if (emit) emit->push_back(pr);
+        c.prevInit = pr.initKind; c.prevTerm = pr.termKind;
+        c.beginPos = endPos + 1;
+        c.attempt = 0;
+        if (c.beginPos >= seqlen) c.done = true;
+    };
+    auto nextWindow = [&](size_t r, CutState &c, std::vector<PieceRef> *emit) -> bool {
+        const long seqlen = recs[r].len;
+        while (!c.done && seqlen - c.beginPos <= maxstep) emitPiece(r, c, seqlen - 1, emit); // the rest fits one piece
+        if (c.done) return false;
+        if (c.attempt == 0) {
+            c.examChunk = 50000;
+            if (c.examChunk < 0.2 * maxstep) c.examChunk = (long)(0.2 * maxstep);
+            if (c.examChunk > 150000) c.examChunk = 150000;
+        } else { c.examChunk *= 2; if (c.examChunk > maxstep) c.examChunk = maxstep; }
+        const long gapStart = 1, gapEnd = seqlen;
+        const long center = (gapEnd - gapStart < c.examChunk) ? (gapEnd + gapStart) / 2 : gapEnd - c.examChunk / 2;
+        if (c.attempt == 0 && c.examChunk > maxstep) { c.es = c.beginPos; c.ee = c.beginPos + maxstep - 1; }
+        else {
+            c.es = center - c.examChunk / 2;
+            c.ee = center + c.examChunk / 2;
+            if (c.ee >= c.beginPos + maxstep) { c.es -= (c.ee - (c.beginPos + maxstep - 1)); c.ee = c.beginPos + maxstep - 1; }
+            if (c.es < c.beginPos) { c.ee += c.beginPos - c.es; c.es = c.beginPos; }
+        }
+        return true;
+    };
+    // what the chain does with the path of its window (attempt = 1 afterwards: the same round once more with a window twice as long)
+    auto applyWindow = [&](size_t r, CutState &c, const std::vector<PathState> &path, std::vector<PieceRef> *emit) {
+        const long gapStart = 1, gapEnd = recs[r].len;
+        long cut = tryFindCutEndPoint(path, c.es, c.ee, true, gapStart, gapEnd, true);
+        if (cut == -1 && c.attempt == 0) { c.attempt = 1; return; }
+        if (cut == -1) {
+            cut = tryFindCutEndPoint(path, c.es, c.ee, true, gapStart, gapEnd, false);
+            if (cut == -1) cut = tryFindCutEndPoint(path, c.es, c.ee, false, 0, 0, false);
+            if (cut == -1) cut = c.beginPos + maxstep - 1;
+        }
+        if (cut <= c.beginPos + 0.05 * maxstep || cut <= c.beginPos + 5000) cut = c.beginPos + maxstep - 1;
+        emitPiece(r, c, cut, emit);
+    };
+
+    // ---- the scout: intergenic regions of the long records, from a decode in overlapping tiles.  Worth its time when the
+    //      chains are long and few (one chromosome: 115 serial rounds on one compute unit each, against one pass over the
+    //      record at the speed of the whole chip); not when many records' chains already run side by side.
+    std::vector<std::vector<std::pair<long, long>>> igenic(recs.size());
+    std::vector<char> scouted(recs.size(), 0);
+    {
+        long longBases = 0, maxRounds = 0;
+        int nLong = 0;
+        for (size_t r = 0; r < recs.size(); r++)
+            if (recs[r].len > maxstep) { longBases += recs[r].len; nLong++; maxRounds = std::max(maxRounds, recs[r].len / maxstep); }
+        long chunk = std::min<long>(150000, std::max<long>(50000, (long)(0.2 * maxstep)));
+        if (chunk > maxstep) chunk = maxstep;
+        int nIgenic = 0;
+        for (int q = 0; q < M.t.S; q++) nIgenic += M.t.state_kind[q] == AUGX_K_IGENIC;
+        const bool denseModel = M.t.utr != 0 || nIgenic > 1; // (the models of device/dense.h: one workgroup per piece)
+        // serial: rounds x 1.5 windows (every other first try fails on gene-poor DNA) at the speed of one workgroup;
+        // scout: the long records once at the speed of the chip
+        const double perPiece = denseModel ? 0.36e6 : 3.5e6, chip = (denseModel ? 60e6 : 300e6) * (double)std::max(1, nDevices);
+        const double tSerial = (double)maxRounds * 1.5 * (double)chunk / perPiece, tScout = (double)longBases / chip + 0.02;
+        bool want = maxRounds >= 3 && tScout < 0.5 * tSerial;
+        if (scoutMode >= 0) want = scoutMode != 0;
+        if (want && nLong > 0) {
+            const double t0 = now();
+            const long margin = 25000;
+            long tile = longBases / (256 * (long)std::max(1, nDevices));
+            tile = std::max<long>(200000, std::min<long>(1000000, tile));
+            std::vector<augx_piece> tp;
+            struct TileRef { size_t rec; long b, e; };
+            std::vector<TileRef> tr;
+            for (size_t r = 0; r < recs.size(); r++) {
+                const long n = recs[r].len;
+                if (n <= maxstep) continue;
+                for (long b = 0; b < n; b += tile) {
+                    const long tb = std::max<long>(0, b - margin), te = std::min<long>(n - 1, b + tile - 1 + margin);
+                    augx_piece p;
+                    p.seq = recs[r].seq + tb; p.len = te - tb + 1; p.init_kind = tb == 0 ? 0 : 1; p.term_kind = te == n - 1 ? 0 : 1;
+                    tp.push_back(p);
+                    tr.push_back({r, tb, te});
+                }
+                scouted[r] = 1;
+            }
+            std::vector<Decoded> dd;
+            if (!decode(tp, dd)) return false;
+            for (size_t k = 0; k < tr.size(); k++) {
+                if (dd[k].status != 0) continue; // (no forecast from this tile; the chain decodes its windows as it goes)
+                const long n = recs[tr[k].rec].len;
+                // the part of the record this tile speaks for: its own stretch without the margins
+                const long lo = tr[k].b == 0 ? 0 : tr[k].b + margin, hi = tr[k].e == n - 1 ? n - 1 : tr[k].e - margin;
+                auto &v = igenic[tr[k].rec];
+                for (const PathState &st : dd[k].path) {
+                    if (st.type != 0) continue;
+                    const long b = std::max(lo, tr[k].b + st.begin), e = std::min(hi, tr[k].b + st.end);
+                    if (b > e) continue;
+                    if (!v.empty() && v.back().second + 1 >= b) v.back().second = std::max(v.back().second, e);
+                    else v.push_back({b, e});
+                }
+            }
+            stats.tiles = (int)tp.size();
+            stats.scoutSeconds = now() - t0;
+        }
+    }
+    // the paths a window [es, ee] of record r is EXPECTED to have, as far as the cut finder looks at them: intergenic runs
+    // (type 0) and whatever lies between them (type 1).  A window begins (ends) in the intergenic state when its initial
+    // (terminal) kind is the synchronisation state alone, and a gene the map shows across that edge cannot be in the window's
+    // path: either it vanishes -- the run at the edge reaches to the next intergenic region of the map -- or a variant of it
+    // that fits takes its place and the map's next intergenic region stays a run of its own.  Both, at both edges: up to four paths.
+    auto forecasts = [&](size_t r, long es, long ee, int ik, int tk) {
+        const auto &v = igenic[r];
+        std::vector<std::pair<long, long>> runs;
+        for (auto it = std::partition_point(v.begin(), v.end(), [&](const std::pair<long, long> &a) { return a.second < es; }); it != v.end() && it->first <= ee; ++it)
+            runs.push_back({std::max(es, it->first), std::min(ee, it->second)});
+        const bool openL = ik == 1 && (runs.empty() || runs.front().first > es), openR = tk == 1 && (runs.empty() || runs.back().second < ee);
+        std::vector<std::vector<PathState>> out;
+        // (the order is by how often each was right on uniform-random DNA: a variant of the gene at both edges first)
+        for (int vl = openL ? 1 : 0; vl >= 0; vl--)
+            for (int vr = openR ? 1 : 0; vr >= 0; vr--) {
+                std::vector<std::pair<long, long>> ru = runs;
+                if (ru.empty()) { // the window lies inside one gene of the map: all intergenic, or a variant of the gene between two edge runs
+                    if (openL && openR && vl == 0 && vr == 0) ru.push_back({es, ee});
+                    else { if (ik == 1) ru.push_back({es, es}); if (tk == 1) ru.push_back({ee, ee}); }
+                } else {
+                    if (openL) { if (vl == 0) ru.front().first = es; else ru.insert(ru.begin(), {es, es}); }
+                    if (openR) { if (vr == 0) ru.back().second = ee; else ru.push_back({ee, ee}); }
+                }
+                std::vector<PathState> path;
+                long pos = es;
+                for (auto &x : ru) {
+                    if (x.first < pos) continue; // (a window inside one gene of the map: the two edge runs)
+                    if (x.first > pos) path.push_back({pos - es, x.first - 1 - es, 1});
+                    path.push_back({x.first - es, x.second - es, 0});
+                    pos = x.second + 1;
+                }
+                if (pos <= ee) path.push_back({pos - es, ee - es, 1});
+                if (std::find_if(out.begin(), out.end(), [&](const std::vector<PathState> &o) {
+                        return o.size() == path.size() && std::equal(o.begin(), o.end(), path.begin(), [](const PathState &a, const PathState &b) { return a.begin == b.begin && a.end == b.end && a.type == b.type; });
+                    }) == out.end())
+                    out.push_back(std::move(path));
+            }
+        return out;
+    };
+
+    std::map<WinKey, Decoded> cache;
+    int breadth = 1; // (measured, 23 Mbp of uniform-random DNA, fly model: 1 -> 8 batches of ~55 windows; 5 -> 5 batches of ~215, slower)
+    if (const char *e = getenv("AUGX_CUT_BREADTH")) breadth = atoi(e);
+    long nearShift = 3000;
+    if (const char *e = getenv("AUGX_CUT_NEAR")) nearShift = atol(e);
+    size_t maxAsk = 256 * (size_t)std::max(1, nDevices); // windows per batch: one wave of workgroups
+    if (const char *e = getenv("AUGX_CUT_ASK")) maxAsk = (size_t)atol(e);
+    // windows per batch (a bound on the forecast's breadth; the nearest rounds come first)
+    for (;;) {
+        std::vector<WinKey> keys;
+        std::set<WinKey> asked;
+        size_t nOpen = 0;
+        for (size_t r = 0; r < recs.size(); r++) nOpen += !cs[r].done;
+        for (size_t r = 0; r < recs.size(); r++) {
+            CutState &c = cs[r];
+            if (c.done) continue;
+            // the true chain, as far as the decoded windows carry it
+            for (;;) {
+                CutState probe = c;
+                std::vector<PieceRef> emitted;
+                const bool more = nextWindow(r, probe, &emitted);
+                auto hit = more ? cache.find(WinKey{(int)r, probe.es, probe.ee, probe.prevInit, probe.prevTerm}) : cache.end();
+                if (more && hit == cache.end()) break;
+                c = probe;
+                recPieces[r].insert(recPieces[r].end(), emitted.begin(), emitted.end());
+                if (!more) break;
+                stats.used++;
+                if (hit->second.status != 0) { failStatus[r] = hit->second.status; c.done = true; break; } // the record's error
+                applyWindow(r, c, hit->second.path, &recPieces[r]);
+            }
+            if (c.done) continue;
+            // the forecast chains from here: every window they ask for that has not been decoded yet.  Limited-discrepancy order:
+            // first the chain of first guesses to the end of the record, then the chains that leave it once (nearest round first),
+            // twice, ... while the batch has room -- a wrong guess at the nearest undecoded round is what ends a batch's use
+            struct Sim { int disc, depth; CutState st; };
+            auto later = [](const Sim &a, const Sim &b) { return a.disc != b.disc ? a.disc > b.disc : a.depth > b.depth; };
+            std::priority_queue<Sim, std::vector<Sim>, decltype(later)> queue(later);
+            queue.push({0, 0, c});
+            std::set<std::tuple<long, int, int, int>> seen{{c.beginPos, c.attempt, c.prevInit, c.prevTerm}};
+            const size_t room = keys.size() + maxAsk / std::max<size_t>(1, nOpen);
+            while (!queue.empty() && keys.size() < room) {
+                Sim cur = queue.top();
+                queue.pop();
+                CutState sim = cur.st;
+                if (!nextWindow(r, sim, nullptr)) continue;
+                const WinKey k{(int)r, sim.es, sim.ee, sim.prevInit, sim.prevTerm};
+                auto push = [&](const std::vector<PathState> &path, int extra) {
+                    CutState nx = sim;
+                    applyWindow(r, nx, path, nullptr);
+                    if (!nx.done && seen.insert({nx.beginPos, nx.attempt, nx.prevInit, nx.prevTerm}).second) queue.push({cur.disc + extra, cur.depth + 1, nx});
+                };
+                auto hit = cache.find(k);
+                if (hit != cache.end()) {
+                    if (hit->second.status == 0) push(hit->second.path, 0);
+                    continue;
+                }
+                if (asked.insert(k).second) keys.push_back(k);
+                if (!scouted[r]) break; // no map: one window per round, as the reference goes
+                int nv = 0;
+                // a decoded window of the same size a few hundred bases away is the best guess there is (the chain left the forecast by
+                // that much a round ago): its path, as far as it covers this window, with intergenic edges
+                {
+                    auto lo = cache.lower_bound(WinKey{(int)r, sim.es - nearShift, 0, 0, 0});
+                    const Decoded *best = nullptr;
+                    long bestShift = nearShift + 1, bestEs = 0;
+                    for (auto it = lo; it != cache.end() && it->first.rec == (int)r && it->first.es <= sim.es + nearShift; ++it)
+                        if (it->first.ee - it->first.es == sim.ee - sim.es && it->first.ik == sim.prevInit && it->first.tk == sim.prevTerm && it->second.status == 0 &&
+                            std::labs(it->first.es - sim.es) < bestShift) { best = &it->second; bestShift = std::labs(it->first.es - sim.es); bestEs = it->first.es; }
+                    if (best) {
+                        std::vector<PathState> path;
+                        for (const PathState &st : best->path) {
+                            const long b2 = std::max(sim.es, bestEs + st.begin), e2 = std::min(sim.ee, bestEs + st.end);
+                            if (b2 > e2) continue;
+                            if (path.empty() && b2 > sim.es) path.push_back({0, b2 - 1 - sim.es, 0});
+                            if (!path.empty() && path.back().type == 0 && st.type == 0) path.back().end = e2 - sim.es;
+                            else path.push_back({b2 - sim.es, e2 - sim.es, st.type});
+                        }
+                        if (!path.empty() && path.back().end < sim.ee - sim.es) {
+                            if (path.back().type == 0) path.back().end = sim.ee - sim.es; else path.push_back({path.back().end + 1, sim.ee - sim.es, 0});
+                        }
+                        if (!path.empty()) push(path, nv++ ? 1 : 0);
+                    }
+                }
+                for (auto &path : forecasts(r, sim.es, sim.ee, sim.prevInit, sim.prevTerm)) { if (nv >= breadth) break; push(path, nv++ ? 1 : 0); }
+            }
+        }
+        if (keys.empty()) break;
+        std::vector<augx_piece> ex;
+        std::vector<std::string> copies;
+        copies.reserve(keys.size());
+        for (const WinKey &k : keys) {
+            augx_piece p;
+            p.seq = soft ? pieceSequence(recs[k.rec].seq, recs[k.rec].len, k.es, k.ee, k.ee + 10000, copies) : recs[k.rec].seq + k.es;
+            p.len = k.ee - k.es + 1; p.init_kind = k.ik; p.term_kind = k.tk;
+            ex.push_back(p);
+        }
+        std::vector<Decoded> dd;
+        if (!decode(ex, dd)) return false;
+        stats.batches++;
+        stats.windows += (int)ex.size();
+        for (size_t k = 0; k < keys.size(); k++) cache[keys[k]] = std::move(dd[k]);
+    }
+    if (const char *dbg = getenv("AUGX_CUT_DEBUG")) { // developer aid: the scout's map, every decoded window and the pieces, for work on the forecast
+        if (FILE *f = fopen(dbg, "w")) {
+            for (size_t r = 0; r < recs.size(); r++)
+                for (auto &x : igenic[r]) fprintf(f, "M %zu %ld %ld\n", r, x.first, x.second);
+            for (auto &kv : cache) {
+                fprintf(f, "W %d %ld %ld %d %d %d %zu", kv.first.rec, kv.first.es, kv.first.ee, kv.first.ik, kv.first.tk, kv.second.status, kv.second.path.size());
+                for (auto &st : kv.second.path) fprintf(f, " %ld %ld %d", st.begin, st.end, st.type);
+                fprintf(f, "\n");
+            }
+            for (size_t r = 0; r < recs.size(); r++)
+                for (auto &pr : recPieces[r]) fprintf(f, "C %zu %ld %ld\n", r, pr.begin, pr.end);
+            fclose(f);
+        }
+    }
+    return true;
 }
 
 } // namespace
@@ -557,89 +860,26 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     }
     const bool soft = S.oo.softmasking;
 
-    // ---- phase 1: find the cut points of all records (reference src/namgene.cc:973-1133).  Inside a record the cuts are a
-    //      serial chain (the next exam window starts where the last piece ended), but records are independent: every round
-    //      decodes the pending exam window of EVERY unfinished record, fanned over the devices.
-    struct PieceRef { int rec; long begin, end; int initKind, termKind; };
-    struct CutState {
-        long beginPos = 0;
-        int prevInit = 0, prevTerm = 0; // init/term kinds in effect while the exam window is decoded (state leak, src/namgene.cc:576 vs 594-603)
-        int attempt = 0;
-        long examChunk = 0, es = 0, ee = 0;
-        bool done = false;
-        int failStatus = 0;             // an exam window of this record could not be decoded: the record's error
-    };
-    std::vector<std::vector<PieceRef>> recPieces(recs.size());
-    std::vector<CutState> cs(recs.size());
+    // ---- phase 1: find the cut points of all records (findCutPoints above; every exam window is decoded on the GPUs)
+    std::vector<std::vector<PieceRef>> recPieces;
+    std::vector<int> recFail;
     {
-        auto pushPiece = [&](size_t r, long endPos) {
-            const long seqlen = (long)recs[r].seq.size();
-            CutState &c = cs[r];
-            PieceRef pr;
-            pr.rec = (int)r; pr.begin = c.beginPos; pr.end = endPos;
-            pr.initKind = c.beginPos == 0 ? 0 : 1;
-            pr.termKind = endPos == seqlen - 1 ? 0 : 1;
-            recPieces[r].push_back(pr);
-            c.prevInit = pr.initKind; c.prevTerm = pr.termKind;
-            c.beginPos = endPos + 1;
-            c.attempt = 0;
-            if (c.beginPos >= seqlen) c.done = true;
-        };
-        for (;;) {
-            std::vector<augx_piece> ex;
-            std::vector<size_t> who;
-            std::vector<std::string> copies;
-            copies.reserve(recs.size());
-            for (size_t r = 0; r < recs.size(); r++) {
-                CutState &c = cs[r];
-                const long seqlen = (long)recs[r].seq.size();
-                while (!c.done && seqlen - c.beginPos <= maxstep) pushPiece(r, seqlen - 1); // the rest fits one piece
-                if (c.done) continue;
-                if (c.attempt == 0) {
-                    c.examChunk = 50000;
-                    if (c.examChunk < 0.2 * maxstep) c.examChunk = (long)(0.2 * maxstep);
-                    if (c.examChunk > 150000) c.examChunk = 150000;
-                } else { c.examChunk *= 2; if (c.examChunk > maxstep) c.examChunk = maxstep; }
-                const long gapStart = 1, gapEnd = seqlen;
-                const long center = (gapEnd - gapStart < c.examChunk) ? (gapEnd + gapStart) / 2 : gapEnd - c.examChunk / 2;
-                if (c.attempt == 0 && c.examChunk > maxstep) { c.es = c.beginPos; c.ee = c.beginPos + maxstep - 1; }
-                else {
-                    c.es = center - c.examChunk / 2;
-                    c.ee = center + c.examChunk / 2;
-                    if (c.ee >= c.beginPos + maxstep) { c.es -= (c.ee - (c.beginPos + maxstep - 1)); c.ee = c.beginPos + maxstep - 1; }
-                    if (c.es < c.beginPos) { c.ee += c.beginPos - c.es; c.es = c.beginPos; }
-                }
-                augx_piece p;
-                p.seq = soft ? pieceSequence(recs[r].seq, c.es, c.ee, c.ee + 10000, copies) : recs[r].seq.data() + c.es;
-                p.len = c.ee - c.es + 1; p.init_kind = c.prevInit; p.term_kind = c.prevTerm;
-                ex.push_back(p);
-                who.push_back(r);
-            }
-            if (ex.empty()) break;
-            std::vector<Decoded> dd;
-            if (!S.decode(ex, dd)) { restore(); return fail(S.err); }
-            for (size_t k = 0; k < who.size(); k++) {
-                const size_t r = who[k];
-                CutState &c = cs[r];
-                const long seqlen = (long)recs[r].seq.size();
-                const long gapStart = 1, gapEnd = seqlen;
-                if (dd[k].status != 0) { c.failStatus = dd[k].status; c.done = true; continue; } // the record's error (reported in input order below)
-                long cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, true, gapStart, gapEnd, true);
-                if (cut == -1 && c.attempt == 0) { c.attempt = 1; continue; } // once more with a window twice as long
-                if (cut == -1) {
-                    cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, true, gapStart, gapEnd, false);
-                    if (cut == -1) cut = tryFindCutEndPoint(dd[k].path, c.es, c.ee, false, 0, 0, false);
-                    if (cut == -1) cut = c.beginPos + maxstep - 1;
-                }
-                if (cut <= c.beginPos + 0.05 * maxstep || cut <= c.beginPos + 5000) cut = c.beginPos + maxstep - 1;
-                pushPiece(r, cut);
-            }
-        }
+        std::vector<RecordView> views;
+        for (auto &r : recs) views.push_back({r.name.c_str(), r.seq.data(), (long)r.seq.size()});
+        int scoutMode = -1;
+        if (const char *e = getenv("AUGX_SCOUT")) scoutMode = atoi(e) != 0;
+        CutFinderStats st;
+        std::string cfErr;
+        auto decodeFn = [&](const std::vector<augx_piece> &ps, std::vector<Decoded> &dd) { if (S.decode(ps, dd)) return true; cfErr = S.err; return false; };
+        if (!findCutPoints(M, views, maxstep, soft, scoutMode, (int)S.decs.size(), decodeFn, recPieces, recFail, st)) { restore(); return fail(cfErr); }
+        if (timing)
+            fprintf(stderr, "augx timing:   cut finder: scout %.3f s (%d tiles), %d batches, %d windows decoded, %d used\n", st.scoutSeconds, st.tiles, st.batches, st.windows,
+                    st.used);
     }
     lap("cut finder");
     std::vector<PieceRef> allPieces;
     for (size_t r = 0; r < recs.size(); r++)
-        if (!cs[r].failStatus) allPieces.insert(allPieces.end(), recPieces[r].begin(), recPieces[r].end());
+        if (!recFail[r]) allPieces.insert(allPieces.end(), recPieces[r].begin(), recPieces[r].end());
     if (M.opt.getBool("progress", false))
         for (auto &pr : allPieces)
             std::cerr << "examining piece " << pr.begin + S.oo.offset + 1 << ".." << pr.end + S.oo.offset + 1 << " (" << (pr.end - pr.begin + 1) << " bp)" << std::endl;
@@ -661,7 +901,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (size_t i = 0; i < allPieces.size(); i++) {
             const PieceRef &pr = allPieces[i];
             augx_piece p;
-            p.seq = soft ? pieceSequence(recs[pr.rec].seq, pr.begin, pr.end, pr.end, copies) : recs[pr.rec].seq.data() + pr.begin;
+            p.seq = soft ? pieceSequence(recs[pr.rec].seq.data(), (long)recs[pr.rec].seq.size(), pr.begin, pr.end, pr.end, copies) : recs[pr.rec].seq.data() + pr.begin;
             p.len = pr.end - pr.begin + 1;
             p.init_kind = pr.initKind;
             p.term_kind = pr.termKind;
@@ -712,7 +952,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         po.push_back(o);
     }
     for (size_t r = 0; r < recs.size(); r++)
-        if (cs[r].failStatus) { PieceOut o{(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, cs[r].failStatus}; po.push_back(o); }
+        if (recFail[r]) { PieceOut o{(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, recFail[r]}; po.push_back(o); }
     std::string text, errText, fatal;
     if (formatRecords(M, S.oo, rv, po, verbosity, S.geneid, text, errText, fatal, S.sampleiterations)) {
         std::cout << text;
@@ -826,3 +1066,61 @@ extern "C" int augx_format_records(const augx_model *m, int n_records, const cha
         return AUGX_E_CONFIG;
     }
 }
+
+// ---- the cut finder on its own, over any decode function (reference NAMGene::getNextCutEndPoint as driven by the piece loop of
+//      doViterbiPiecewise, src/namgene.cc:575-603, 973-1133).  augx_main runs it over augx_decode_sharded; a caller that owns the
+//      piece loop can run it over its own decoders.  scout: -1 = decide from the chain length, 0 = one window
+//      per round as the reference goes, 1 = scout decode + windows decoded ahead of the chain (same cuts, fewer batches).
+extern "C" int augx_find_cuts(const augx_model *m, int n_records, const char *const *seqs, const int64_t *lens, augx_decode_fn fn, void *user, int scout,
+                              augx_cut **out, int *n_out, augx_cut_stats *stats) {
+    if (!m || n_records < 0 || (n_records && (!seqs || !lens)) || !fn || !out || !n_out) { setLastError("augx_find_cuts: bad argument"); return AUGX_E_ARG; }
+    *out = nullptr;
+    *n_out = 0;
+    try {
+        const Model &M = m->m;
+        const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
+        if (maxstep < 1000) { setLastError("maxDNAPieceSize is too small"); return AUGX_E_CONFIG; }
+        OutputOptions oo;
+        oo.fromModel(M);
+        std::vector<RecordView> views;
+        for (int r = 0; r < n_records; r++) views.push_back({"", seqs[r], (long)lens[r]});
+        int rcDecode = 0;
+        auto decodeFn = [&](const std::vector<augx_piece> &ps, std::vector<Decoded> &dd) {
+            std::vector<augx_path> paths(ps.size());
+            for (auto &p : paths) { p.states = nullptr; p.n_states = 0; p.status = AUGX_E_ARG; p.ln_viterbi = 0; }
+            rcDecode = fn(user, ps.data(), (int)ps.size(), paths.data());
+            if (rcDecode) return false;
+            dd.resize(ps.size());
+            for (size_t i = 0; i < ps.size(); i++) {
+                dd[i].lnv = paths[i].ln_viterbi;
+                dd[i].status = paths[i].status;
+                dd[i].path.clear();
+                for (int k = 0; k < paths[i].n_states; k++) dd[i].path.push_back({paths[i].states[k].begin, paths[i].states[k].end, paths[i].states[k].type});
+                augx_path_free(&paths[i]);
+            }
+            return true;
+        };
+        std::vector<std::vector<PieceRef>> recPieces;
+        std::vector<int> recFail;
+        CutFinderStats st;
+        if (!findCutPoints(M, views, maxstep, oo.softmasking, scout, 1, decodeFn, recPieces, recFail, st)) return rcDecode ? rcDecode : AUGX_E_HIP;
+        // (a record whose exam window could not be decoded: its pieces so far, then one entry with that status and no range)
+        for (int r = 0; r < n_records; r++)
+            if (recFail[r]) recPieces[r].push_back(PieceRef{r, -1, -1, -recFail[r], 0});
+        size_t n = 0;
+        for (auto &v : recPieces) n += v.size();
+        augx_cut *res = (augx_cut *)malloc(sizeof(augx_cut) * (n ? n : 1));
+        if (!res) return AUGX_E_NOMEM;
+        size_t k = 0;
+        for (int r = 0; r < n_records; r++)
+            for (auto &pr : recPieces[r]) res[k++] = pr.begin < 0 ? augx_cut{r, -pr.initKind, -1, -1, 0, 0} : augx_cut{r, 0, pr.begin, pr.end, pr.initKind, pr.termKind};
+        *out = res;
+        *n_out = (int)n;
+        if (stats) { stats->scout_tiles = st.tiles; stats->batches = st.batches; stats->windows_decoded = st.windows; stats->windows_used = st.used; }
+        return AUGX_OK;
+    } catch (std::exception &e) {
+        setLastError(e.what());
+        return AUGX_E_CONFIG;
+    }
+}
+extern "C" void augx_cuts_free(augx_cut *c) { free(c); }

@@ -219,6 +219,28 @@ void augx_path_free(augx_path *p);
 int augx_partition_lpt(const int64_t *lens, int n, int n_bins, int32_t *bin_of /* [n] */);
 int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
 
+/* ---- the cut finder: where a record longer than maxDNAPieceSize is cut into pieces.  Replaces NAMGene::getNextCutEndPoint /
+ *      tryFindCutEndPoint as driven by the piece loop of doViterbiPiecewise (reference src/namgene.cc:575-603, 973-1210): per
+ *      round an exam window at the end of the range is decoded and the record is cut at the centre of the largest intergenic
+ *      region of its path (second try with a window twice as long, then the fall-backs of :1100-1133).  The chain of cuts is
+ *      serial in the reference; here the windows are decoded through `fn` in batches that run ahead of the chain (a scout decode
+ *      of the record forecasts where the cuts will fall; every cut still comes from the decode of exactly the window the
+ *      reference decodes).  `fn` decodes n independent pieces (e.g. augx_decode_batch / augx_decode_sharded on the caller's
+ *      decoders) and returns 0 or an AUGX_E_* code.  Result: the pieces of all records in order, with the initial / terminal
+ *      kinds the piece loop gives them (:584-603); free with augx_cuts_free. ---- */
+typedef int (*augx_decode_fn)(void *user, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
+typedef struct augx_cut {
+    int32_t record;
+    int32_t status;      /* 0, or the status of the exam window of this record that could not be decoded (then the record has no further pieces) */
+    int64_t begin, end;  /* 0-based, inclusive */
+    int32_t init_kind, term_kind;
+} augx_cut;
+typedef struct augx_cut_stats { int32_t scout_tiles, batches, windows_decoded, windows_used; } augx_cut_stats;
+int augx_find_cuts(const augx_model *m, int n_records, const char *const *seqs, const int64_t *lens, augx_decode_fn fn, void *user,
+                   int scout /* -1: decide from the chain length, 0: one window per round, 1: decode ahead */, augx_cut **out, int *n_out,
+                   augx_cut_stats *stats /* may be NULL */);
+void augx_cuts_free(augx_cut *c);
+
 /* ---- device-resident batch interface (bench / multi-GPU driver): the batch is staged once, decode can be
  *      repeated and timed with the inputs resident in HBM ---- */
 typedef struct augx_batch augx_batch;

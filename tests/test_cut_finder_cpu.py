@@ -1,0 +1,75 @@
+"""The cut finder (driver.cc: findCutPoints, C ABI augx_find_cuts; reference NAMGene::getNextCutEndPoint, src/namgene.cc:973-1133) decodes its
+exam windows AHEAD of the serial chain of cuts, from a forecast.  The forecast may only decide which windows are decoded early, never a
+cut: with the decode function of the test (the lane-loop emulator of the kernel source) the pieces must be those of the plain chain, one
+window per round, whatever the forecast guessed.  (On the device the same is checked against the reference binary's own cuts:
+test_cli_cut_finder_ladder_matches_reference, test_cli_piece_cutting_matches_reference.)"""
+import ctypes
+
+import pytest
+
+import augustus_amd as ax
+from helpers import config_path, emu_decode, emu_state_type, golden_inputs, random_dna
+
+libc = ctypes.CDLL("libc.so.6")
+libc.malloc.restype = ctypes.c_void_p
+libc.malloc.argtypes = [ctypes.c_size_t]
+
+
+def emulator_decode_fn(model, log):
+    S = model.n_states
+    tp = model.tables_ptr
+
+    def fn(user, pieces, n, out):
+        seqs = [ctypes.string_at(pieces[i].seq, pieces[i].len) for i in range(n)]
+        res = emu_decode(tp, seqs, S, init_kind=[pieces[i].init_kind for i in range(n)], term_kind=[pieces[i].term_kind for i in range(n)])
+        log.append([(len(s), pieces[i].init_kind, pieces[i].term_kind) for i, s in enumerate(seqs)])
+        for i, r in enumerate(res):
+            status, lnv, path = r[0], r[1], r[2]
+            out[i].status, out[i].ln_viterbi, out[i].n_states = status, lnv, len(path)
+            mem = libc.malloc(max(1, len(path)) * ctypes.sizeof(ax._State))  # (augx_path_free releases it with free())
+            arr = ctypes.cast(mem, ctypes.POINTER(ax._State))
+            for k, (b, e, st) in enumerate(path):
+                arr[k].begin, arr[k].end, arr[k].state, arr[k].type = b, e, st, emu_state_type(tp, st)
+            out[i].states = arr
+        return 0
+    return ax.DECODE_FN(fn)
+
+
+def records():
+    ex = dict(golden_inputs())["HS04636"]
+    sm = list(random_dna(260000, 77))
+    for a, b in [(15000, 48000), (55000, 61000), (70000, 125000), (139000, 140500), (170000, 259000)]:
+        for i in range(a, b):
+            sm[i] = sm[i].lower()
+    return [random_dna(520000, 555),
+            random_dna(50000, 557) + ex + random_dna(45000, 558) + ex + random_dna(30000, 559) + ex[700:9000] * 6 + random_dna(90000, 560),
+            random_dna(30000, 556),            # needs no cut
+            "".join(sm)]                       # soft-masked runs across the cuts and the window ends
+
+
+@pytest.mark.parametrize("species,opts", [("human", {"maxDNAPieceSize": "60000"}), ("fly", {"UTR": "off", "sample": "0", "maxDNAPieceSize": "70000"})])
+def test_windows_decoded_ahead_give_the_cuts_of_the_serial_chain(species, opts):
+    m = ax.Model(config_path(), species, **opts)
+    recs = records()
+    log0, log1 = [], []
+    serial, st0 = ax.find_cuts(m, recs, emulator_decode_fn(m, log0), scout=0)
+    ahead, st1 = ax.find_cuts(m, recs, emulator_decode_fn(m, log1), scout=1)
+    assert serial == ahead
+    # the pieces tile every record, cut kinds as the piece loop sets them (src/namgene.cc:584-603)
+    for r, s in enumerate(recs):
+        ps = [c for c in serial if c[0] == r]
+        assert ps[0][2] == 0 and ps[-1][3] == len(s) - 1 and all(a[3] + 1 == b[2] for a, b in zip(ps, ps[1:]))
+        assert all(c[1] == 0 and c[4] == (0 if c[2] == 0 else 1) and c[5] == (0 if c[3] == len(s) - 1 else 1) for c in ps)
+        assert all(c[3] - c[2] + 1 <= int(opts["maxDNAPieceSize"]) for c in ps)
+    assert len([c for c in serial if c[0] == 0]) >= 9 and len([c for c in serial if c[0] == 2]) == 1
+    # serial: every batch holds at most one window per unfinished record, all of them used; ahead: a scout decode, then fewer batches
+    assert st0["scout_tiles"] == 0 and st0["windows_decoded"] == st0["windows_used"] and all(len(b) <= 3 for b in log0)
+    assert st1["scout_tiles"] > 0 and st1["windows_used"] == st0["windows_used"]
+    assert st1["batches"] < st0["batches"], (st0, st1)
+
+
+def test_decode_failure_is_reported():
+    m = ax.Model(config_path(), "human", maxDNAPieceSize="60000")
+    fn = ax.DECODE_FN(lambda user, pieces, n, out: ax.AUGX_E_HIP)
+    with pytest.raises(ax.AugxError):
+        ax.find_cuts(m, [random_dna(200000, 1)], fn, scout=0)
