@@ -96,6 +96,12 @@ def parse_timing(stderr_text):
         if not line.startswith("augx timing:"):
             continue
         body = line[len("augx timing:"):]
+        if body.strip().startswith("cut finder: scout"):  # "cut finder: scout 0.123 s (115 tiles), 8 batches, 423 windows decoded, 174 used"
+            import re
+            mt = re.search(r"scout ([0-9.]+) s \((\d+) tiles\), (\d+) batches, (\d+) windows decoded, (\d+) used", body)
+            if mt:
+                laps["cut_scout_s"], laps["cut_batches"], laps["cut_windows"], laps["cut_windows_used"] = float(mt.group(1)), int(mt.group(3)), int(mt.group(4)), int(mt.group(5))
+            continue
         if body.startswith("   "):
             n_batches += 1
             continue
@@ -347,10 +353,10 @@ def product_leg(cfg, a, n_dev):
                     if k < len(arr):
                         f.write(arr[k:].tobytes() + b"\n")
 
-        def run(args, fa, bases):
+        def run(args, fa, bases, reps=2):
             env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg, AUGX_DEVICES=str(n_dev), AUGX_TIMING="1")
             best = None
-            for _ in range(2):
+            for _ in range(reps):
                 t0 = time.perf_counter()
                 r = subprocess.run([exe] + args + ["--outfile=" + os.path.join(d, "o.gff"), fa], capture_output=True, env=env)
                 dt = time.perf_counter() - t0
@@ -366,14 +372,34 @@ def product_leg(cfg, a, n_dev):
         big = synth_contigs(1, a.long_contig_len, SEED0 + 77)
         fb = os.path.join(d, "long.fa")
         write(fb, ["long"], big)
-        r2 = run(["--species=fly", "--UTR=off", "--sample=0", "--softmasking=0"], fb, a.long_contig_len)
-        cut = r2["laps_s"].get("cut finder")
         rounds = (a.long_contig_len + 199999) // 200000
-        r2["workload"] = "1 contig x %d bp, --species=fly --UTR=off --sample=0 (200 kb pieces: about %d serial cut-finder rounds), %d device(s)" % (a.long_contig_len, rounds, n_dev)
-        if cut is not None:
-            r2["cut_finder_rounds"] = rounds
-            r2["ms_per_round"] = cut / rounds * 1e3
-        out["long_contig"] = r2
+        from helpers import REF_AUGUSTUS
+        core = sorted(os.sched_getaffinity(0))[0]
+
+        def ref_rate(flags, nbp):
+            """the reference binary on the first nbp bases of the same contig (> one 200 kb piece: a cut-finder round included),
+            pinned to one core, parameter load (the same call on 2 kb) subtracted"""
+            env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg)
+            def t(fa):
+                t0 = time.time()
+                ok = subprocess.call(["taskset", "-c", str(core), REF_AUGUSTUS] + flags + [fa], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env) == 0
+                return time.time() - t0, ok
+            tiny, smp = os.path.join(d, "tiny.fa"), os.path.join(d, "smp.fa")
+            write(tiny, ["tiny"], [big[0][:2000]])
+            write(smp, ["smp"], [big[0][:nbp]])
+            t_load, _ = t(tiny)
+            t1, ok = t(smp)
+            return {"value": nbp / 1e6 / max(t1 - t_load, 1e-9), "unit": "Mbp/s", "cores": 1, "kind": "reference", "ok": ok, "sample_bp": nbp}
+        for key, flags, nbp in (("long_contig", ["--species=fly", "--UTR=off", "--sample=0", "--softmasking=0"], 400000),
+                                ("long_contig_utr", ["--species=fly", "--UTR=on", "--sample=0", "--softmasking=0"], 250000)):
+            if key == "long_contig_utr" and a.no_long_utr:
+                continue
+            r2 = run(flags, fb, a.long_contig_len, reps=2 if key == "long_contig" else 1)
+            r2["workload"] = "1 contig x %d bp uniform-random, %s (200 kb pieces, ~%d cut-finder rounds), %d device(s)" % (a.long_contig_len, " ".join(flags), rounds, n_dev)
+            if not a.no_cpu_baseline and os.path.exists(REF_AUGUSTUS):
+                r2["cpu_baseline"] = ref_rate(flags, nbp)
+                r2["x_cpu"] = r2["value"] / r2["cpu_baseline"]["value"]
+            out[key] = r2
     return out
 
 
@@ -472,6 +498,7 @@ def main():
                     help="do not time the product's own multi-GPU path (the executable over --gpus devices in ONE process) on the 100-contig "
                          "FASTA and on one 23 Mbp contig at the fly model's 200 kb pieces")
     ap.add_argument("--long-contig-len", type=int, default=23000000)
+    ap.add_argument("--no-long-utr", action="store_true", help="skip the 23 Mbp contig with --UTR=on (BASELINE config 4's shape)")
     ap.add_argument("--no-utr", action="store_true", help="skip the --UTR=on leg (the 71-state model, BASELINE config 4's trellis)")
     ap.add_argument("--utr-contigs", type=int, default=256)
     ap.add_argument("--utr-contig-len", type=int, default=160000)
