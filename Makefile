@@ -4,20 +4,23 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
 # -ffp-contract=off: the decode path must round exactly like the CPU oracle (no FMA contraction)
-# -DAUGX_PROFILE: the trellis wavefronts' cycle counters (printed with AUGX_PROF=1) are compiled in.  They cost nothing when
-# off (uniform branches) -- and the kernel measured 3 % FASTER with them than without (260.7 vs 268.8 ms per launch,
-# reproducibly: code layout / register allocation), so they stay in the product build
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -DAUGX_PROFILE
+# (the cycle counters of the trellis wavefronts, AUGX_PROF=1, are a developer build: `make prof` -> augustus_amd/libaugx_prof.so,
+#  loaded instead of the product library when AUGX_LIB names it; the product is built without them)
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
 SRC     = augustus_amd/csrc
 HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc $(SRC)/sharded.cc
-DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h
+DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/densev.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h
 
 all: product oracle emu
 product: augustus_amd/libaugx.so augustus_amd/bin/augustus
 
 augustus_amd/libaugx.so: $(HOSTSRC) $(SRC)/device/decoder.hip $(DEVHDR) $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HOSTSRC) $(SRC)/device/decoder.hip
+
+prof: augustus_amd/libaugx_prof.so
+augustus_amd/libaugx_prof.so: $(HOSTSRC) $(SRC)/device/decoder.hip $(DEVHDR) $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
+	$(HIPCC) $(HIPFLAGS) -DAUGX_PROFILE -shared -o $@ $(HOSTSRC) $(SRC)/device/decoder.hip
 
 augustus_amd/bin/augustus: $(SRC)/augustus_main.cc augustus_amd/libaugx.so
 	@mkdir -p augustus_amd/bin
@@ -43,4 +46,4 @@ ref:
 
 clean:
 	rm -rf build augustus_amd/libaugx.so augustus_amd/bin oracle/libghmm_twin.so
-.PHONY: all product oracle emu ref clean
+.PHONY: all product prof oracle emu ref clean

@@ -24,6 +24,7 @@
 #include <vector>
 #include "kernels.h"
 #include "dense.h"
+#include "densev.h"
 #include "layout.h"
 #include "../capi_internal.h"
 
@@ -356,6 +357,12 @@ template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kDense(const 
     __shared__ DenseLds lds;
     densePiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
 }
+// the Viterbi pass with the candidates of block b + 1 evaluated while block b runs (densev.h); kDense<BLK, 0> is the same pass
+// without the work done ahead (AUGX_DENSE_PIPE=0), kDense<BLK, 1> the forward pass
+template <int BLK> __global__ void __launch_bounds__(VNT) kDenseV(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+    __shared__ DenseLdsV<BLK> lds;
+    densePieceV<BLK>(*T, *B, lds, blockIdx.x);
+}
 __global__ void __launch_bounds__(64) kDenseBacktrace(const DevTables *T, BatchView B) { denseBacktracePiece(*T, B, blockIdx.x); }
 
 // ---- candidates of the variable-length states: one wavefront per tile of 64 bases (describe + count, reserve, evaluate) ----
@@ -410,10 +417,14 @@ struct augx_decoder {
     // many large ones: dozens of hipMalloc / hipFree per batch otherwise); given back to the runtime when an allocation fails
     std::multimap<size_t, void *> pool;
     std::unordered_map<void *, size_t> live;
-    size_t pooledBytes = 0;
+    std::atomic<size_t> pooledBytes{0};
     std::mutex poolMu;        // (another decoder of the same device may empty this pool when its own allocation fails)
     std::vector<hipStream_t> copyStreams; // (snippetCacheReplay: one per piece replayed at a time)
     bool dense = false;        // the model is decoded by the dense kernels (dense.h)
+    bool densePipe = false;    // AUGX_DENSE_PIPE=1: its Viterbi pass by densePieceV (densev.h: the candidates of a block evaluated while the block
+                               // before runs, loads through LDS landing pads).  Bit-identical, measured SLOWER than densePiece<BLK, 0> on MI355X
+                               // (166 against 112 ms, 256 x 40 kb): kept as the tested record of that design, off by default
+    int64_t denseMultiForward = 0; // forward runs of the dense kernels over batches with a multi-class piece: no replay of the reference's caches there (augx_decoder_unreplayed_batches)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
@@ -423,7 +434,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
 // allocation fails, the buffers the OTHER decoders of the device keep for re-use are given back to the runtime as well
 std::mutex g_regMu;
 std::vector<augx_decoder *> g_decoders;
-constexpr size_t POOL_CAP_BYTES = (size_t)128 << 30; // a decoder keeps at most this much for re-use (288 GB of HBM per device; a batch of 100 Mbp takes 80)
+constexpr size_t POOL_CAP_BYTES = (size_t)128 << 30; // the decoders of ONE DEVICE together keep at most this much for re-use (288 GB of HBM per device; a batch of 100 Mbp takes 80)
 void poolReleaseLocked(augx_decoder *d) {
     for (auto &kv : d->pool) (void)hipFree(kv.second);
     d->pool.clear();
@@ -464,10 +475,16 @@ hipError_t devMalloc(augx_decoder *d, void **out, size_t bytes) {
 }
 void devFree(augx_decoder *d, void *p) {
     if (!p) return;
+    size_t onDevice = 0; // what the decoders of this device hold in their pools (lock order: registry, then pool -- as devMalloc)
+    {
+        std::lock_guard<std::mutex> rk(g_regMu);
+        for (augx_decoder *o : g_decoders)
+            if (o->device == d->device) onDevice += o->pooledBytes.load();
+    }
     std::lock_guard<std::mutex> lk(d->poolMu);
     auto it = d->live.find(p);
     if (it == d->live.end()) { (void)hipFree(p); return; }
-    if (d->pooledBytes + it->second > POOL_CAP_BYTES) { (void)hipFree(p); d->live.erase(it); return; } // (the pool is bounded)
+    if (onDevice + it->second > POOL_CAP_BYTES) { (void)hipFree(p); d->live.erase(it); return; } // (the pools of a device are bounded together)
     d->pool.emplace(it->second, p);
     d->pooledBytes += it->second;
     d->live.erase(it);
@@ -599,6 +616,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->device = device;
     d->blk = blk;
     d->dense = modelIsDense(t);
+    if (const char *e = getenv("AUGX_DENSE_PIPE")) d->densePipe = atoi(e) != 0;
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
     if (const char *ex = getenv("AUGX_EXACT_MULTICLASS")) d->exactMulti = atoi(ex) != 0;
@@ -630,6 +648,7 @@ int augx_decoder_set_share(augx_decoder *d, int n) {
     return AUGX_OK;
 }
 
+int64_t augx_decoder_unreplayed_batches(const augx_decoder *d) { return d ? d->denseMultiForward : 0; }
 int augx_decoder_set_exact(augx_decoder *d, int on) {
     if (!d) return AUGX_E_ARG;
     d->exactMulti = on != 0;
@@ -651,9 +670,12 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     return cap;
 }
 
+void augx_release_host_pools();
 void augx_decoder_destroy(augx_decoder *d) {
     if (!d) return;
-    { std::lock_guard<std::mutex> rk(g_regMu); g_decoders.erase(std::remove(g_decoders.begin(), g_decoders.end(), d), g_decoders.end()); }
+    bool last;
+    { std::lock_guard<std::mutex> rk(g_regMu); g_decoders.erase(std::remove(g_decoders.begin(), g_decoders.end(), d), g_decoders.end()); last = g_decoders.empty(); }
+    if (last) augx_release_host_pools();
     (void)hipSetDevice(d->device);
     poolRelease(d);
     for (void *p : d->tableBufs) (void)hipFree(p);
@@ -970,7 +992,11 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     HIP_TRY(hipEventRecord(b->ev[1], st));
     auto runTrellis = [&]() -> int { // the trellis passes and the back-trace (run again when candidate terms were rebuilt, see below)
     if (d->dense) { // the dense kernels: one workgroup per piece, the matrix in HBM (dense.h)
-        if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+        if (d->densePipe) {
+            if (d->blk == 8) hipLaunchKernelGGL((kDenseV<8>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
+            else if (d->blk == 4) hipLaunchKernelGGL((kDenseV<4>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
+            else hipLaunchKernelGGL((kDenseV<2>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
+        } else if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
         else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
         else hipLaunchKernelGGL((kDense<2, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
         HIP_TRY(hipGetLastError());
@@ -1382,7 +1408,8 @@ int augx_batch_forward(augx_decoder *d, augx_batch *b) {
         catch (const std::exception &e) { setLastError(std::string("augx_batch_forward: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc) return rc;
         if (nPatched > 0 && (rc = augx_batch_forward_launch(d, b))) return rc;
-    }
+    } else if (b->nPlAlloc > 1 && d->dense)
+        d->denseMultiForward++; // (the caller is told: augx_decoder_unreplayed_batches; the executable prints a note)
     if (!b->evFwd) HIP_TRY(hipEventCreateWithFlags(&b->evFwd, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->evFwd, d->stream));
     return AUGX_OK;
@@ -1415,7 +1442,15 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
 struct augx_sample_prep { SamplePiece P; };
 namespace {
 std::mutex g_fPoolMu;
-std::vector<std::pair<size_t, double *>> g_fPool; // host buffers of forward matrices, kept for the next piece (at most 16; freed with the process)
+std::vector<std::pair<size_t, double *>> g_fPool; // host buffers of forward matrices, kept for the next piece: at most 24 and FPOOL_CAP_BYTES, released with the last decoder
+size_t g_fPoolBytes = 0;
+constexpr size_t FPOOL_CAP_BYTES = (size_t)8 << 30;
+}
+void augx_release_host_pools() { // (augx_decoder_destroy, when the last decoder goes)
+    std::lock_guard<std::mutex> lk(g_fPoolMu);
+    for (auto &e : g_fPool) delete[] e.second;
+    g_fPool.clear();
+    g_fPoolBytes = 0;
 }
 
 extern "C" {
@@ -1454,13 +1489,13 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         {
             std::lock_guard<std::mutex> lk(g_fPoolMu);
             for (size_t i = 0; i < g_fPool.size(); i++)
-                if (g_fPool[i].first >= need && g_fPool[i].first <= need + need / 2) { got = g_fPool[i]; g_fPool.erase(g_fPool.begin() + (long)i); break; }
+                if (g_fPool[i].first >= need && g_fPool[i].first <= need + need / 2) { got = g_fPool[i]; g_fPoolBytes -= got.first * sizeof(double); g_fPool.erase(g_fPool.begin() + (long)i); break; }
         }
         if (!got.second) got = {need, new double[need]};
         const size_t cap = got.first;
         P.Fown = std::shared_ptr<double>(got.second, [cap](double *q) {
             std::lock_guard<std::mutex> lk(g_fPoolMu);
-            if (g_fPool.size() < 24) g_fPool.push_back({cap, q}); else delete[] q;
+            if (g_fPool.size() < 24 && g_fPoolBytes + cap * sizeof(double) <= FPOOL_CAP_BYTES) { g_fPool.push_back({cap, q}); g_fPoolBytes += cap * sizeof(double); } else delete[] q;
         });
     }
     P.F = P.Fown.get();

@@ -931,6 +931,13 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (size_t k = 0; k < dd.size(); k++) decoded[slot[k]] = std::move(dd[k]);
     }
 
+    if (S.sampleiterations > 0) { // (said once, on stderr: the one input class where the sampled probabilities are not the reference's)
+        int64_t nUn = 0;
+        for (augx_decoder *d : S.decs) nUn += augx_decoder_unreplayed_batches(d);
+        if (nUn > 0)
+            std::cerr << "augustus (MI355X): note: pieces with more than one GC-content class were sampled with the UTR / two-intergenic-state model; the posterior probabilities near the "
+                         "class steps may differ slightly from the CPU reference's (the predicted genes do not)." << std::endl;
+    }
     lap("decode of the pieces");
     // ---- phase 3: gene structures + GFF, in input order
     std::vector<RecordView> rv;

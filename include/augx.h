@@ -205,6 +205,14 @@ int augx_decoder_set_share(augx_decoder *d, int n_decoders_on_device);
  * a randomised soak found a record where the optimal path depends on it.  exact = 0 saves the second trellis run on batches
  * with such pieces.  The forward algorithm (augx_batch_forward) always replays it. */
 int augx_decoder_set_exact(augx_decoder *d, int exact);
+/* number of forward runs (posterior sampling) this decoder made with the dense kernels (UTR states, two intergenic states) over a
+ * batch that holds a piece with more than one GC-content class: the reference's call-history caches (SnippetProbs,
+ * src/statemodel.cc:312-342; tssProbsPlus, src/utrmodel.cc:748-790; the aSSProb memo, src/intronmodel.cc:1120-1135) are not
+ * replayed there, the forward variables within a few hundred bases after a class step -- and with them the sampled posterior
+ * probabilities -- may differ from the reference's.  The Viterbi path is not affected on any input tried. */
+int64_t augx_decoder_unreplayed_batches(const augx_decoder *d);
+/* host buffers kept between sampled pieces (forward matrices, at most 8 GB) are released when the last decoder is destroyed, or here */
+void augx_release_host_pools(void);
 int64_t augx_decoder_batch_capacity(augx_decoder *d);
 
 /* replaces viterbiAndForward + getViterbiPath for a batch of independent pieces */

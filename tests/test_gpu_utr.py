@@ -1,6 +1,6 @@
 """GPU parity of the 71-state model with untranslated regions (--UTR=on: dense kernels, device/dense.h), through the C ABI.
 Checkers: the oracle twin (oracle/ghmm_twin.cc, pinned to the real reference cell by cell in tests/test_oracle.py) and the
-golden vectors made from the real reference (tests/golden/make_golden_utr.py)."""
+golden vectors made from the real reference (tests/golden/make_golden.py: the `human_utr`, `fly_utr`, ... configurations)."""
 import os
 
 import numpy as np
@@ -33,6 +33,23 @@ def test_gpu_utr_cells_bit_identical_to_oracle(species, opts):
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
         assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
         assert np.array_equal(b.cells(i), V), i
+
+
+@pytest.mark.parametrize("species,opts", [("human", {"UTR": "on"}), ("fly", {"sample": "0"}), ("human", {"genemodel": "exactlyone", "sample": "0"})])
+def test_gpu_dense_viterbi_with_the_work_done_ahead(monkeypatch, species, opts):
+    """AUGX_DENSE_PIPE=1: the Viterbi pass that evaluates the candidates of block b + 1 while block b runs (device/densev.h, loads
+    through LDS landing pads): every cell, score and path equal to the oracle's, i.e. to the default pass'"""
+    monkeypatch.setenv("AUGX_DENSE_PIPE", "1")
+    m = ax.Model(config_path(), species, **opts)
+    d = ax.Decoder(m, 0)
+    S = m.n_states
+    seqs = [s for _, s in golden_inputs()] + [random_dna(60000, 11), random_dna(5000, 12).lower(), random_dna(100, 13), "N" * 3000 + random_dna(9000, 14)]
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (s, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
+        assert r.status == rc and (rc != 0 or (r.ln_viterbi == lnv and r.states == path)), i
+        assert rc != 0 or np.array_equal(b.cells(i), V), i
 
 
 def test_gpu_utr_interior_piece_kinds_and_batch_order():
