@@ -424,6 +424,8 @@ struct augx_decoder {
     bool densePipe = false;    // AUGX_DENSE_PIPE=1: its Viterbi pass by densePieceV (densev.h: the candidates of a block evaluated while the block
                                // before runs, loads through LDS landing pads).  Bit-identical, measured SLOWER than densePiece<BLK, 0> on MI355X
                                // (166 against 112 ms, 256 x 40 kb): kept as the tested record of that design, off by default
+    bool countNearTies = false;    // the back-trace counts the near ties on the chosen paths (AUGX_TIMING, AUGX_NEAR_TIES=1, augx_decoder_count_near_ties)
+    int64_t nearTies = 0, nearTiePieces = 0; // ... summed over the batches whose paths were fetched
     int64_t denseMultiForward = 0; // forward runs of the dense kernels over batches with a multi-class piece: no replay of the reference's caches there (augx_decoder_unreplayed_batches)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
@@ -617,6 +619,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->blk = blk;
     d->dense = modelIsDense(t);
     if (const char *e = getenv("AUGX_DENSE_PIPE")) d->densePipe = atoi(e) != 0;
+    d->countNearTies = getenv("AUGX_TIMING") != nullptr || (getenv("AUGX_NEAR_TIES") && atoi(getenv("AUGX_NEAR_TIES")) != 0);
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
     if (const char *ex = getenv("AUGX_EXACT_MULTICLASS")) d->exactMulti = atoi(ex) != 0;
@@ -649,6 +652,8 @@ int augx_decoder_set_share(augx_decoder *d, int n) {
 }
 
 int64_t augx_decoder_unreplayed_batches(const augx_decoder *d) { return d ? d->denseMultiForward : 0; }
+int augx_decoder_count_near_ties(augx_decoder *d, int on) { if (!d) return AUGX_E_ARG; d->countNearTies = on != 0; return AUGX_OK; }
+int64_t augx_decoder_near_ties(const augx_decoder *d, int64_t *pieces) { if (pieces) *pieces = d ? d->nearTiePieces : 0; return d ? d->nearTies : 0; }
 int augx_decoder_set_exact(augx_decoder *d, int on) {
     if (!d) return AUGX_E_ARG;
     d->exactMulti = on != 0;
@@ -744,6 +749,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
         DA(V.ufx, uint64_t, Z.N * NUFX); DA(V.ucnt, uint32_t, Z.N * NUCNT); DA(V.usig, double, Z.N * NUSIG);
     }
     if (d->debugCells || d->dense) DA(V.cells, double, Z.N * d->hostT.S);
+    if (d->countNearTies) DA(V.nearTie, int32_t, n);
     if (getenv("AUGX_PROF")) { DA(V.prof, uint64_t, (int64_t)n * 56 + 64); if (hipMemset(V.prof, 0, ((size_t)n * 56 + 64) * 8) != hipSuccess) { augx_batch_destroy(b); setLastError("augx_batch_create: hipMemset failed"); return AUGX_E_HIP; } }
     if (!d->dense) { DA(V.vig, double, Z.N); DA(V.longV, double, Z.N * 6); }
     DA(V.listCnt, int32_t, n); DA(b->dListOffs, int64_t, n + 1);
@@ -1130,6 +1136,12 @@ int augx_batch_paths(augx_decoder *d, augx_batch *b, augx_path *out) {
     HIP_TRY(hipMemcpy(lnv.data(), V.lnv, sizeof(double) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(status.data(), V.status, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(count.data(), V.pathCount, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (V.nearTie) { // near ties on the chosen paths of this batch (dp.h: AUGX_NEAR_TIE), summed on the decoder
+        std::vector<int32_t> nt(n);
+        HIP_TRY(hipMemcpy(nt.data(), V.nearTie, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        for (int p = 0; p < n; p++)
+            if (status[p] == 0 && nt[p] > 0) { d->nearTies += nt[p]; d->nearTiePieces++; }
+    }
     const augx_tables &t = d->model->m.t;
     for (int p = 0; p < n; p++) {
         out[p].states = nullptr;

@@ -1164,9 +1164,9 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
     const int64_t po = pathOff(B, p), cap = pathCap(B, p);
     const double *M = B.cells + (o + 1) * S;
     const uint8_t *BP = B.bpD + (o + 1) * S;
-    int state = B.finalState[p], base = n - 1, count = 0;
+    int state = B.finalState[p], base = n - 1, count = 0, nearTies = 0;
     bool overflow = false;
-    if (state < 0 || B.status[p] != 0) { FOR_LANES(l) { if (l == 0) B.pathCount[p] = 0; } return; }
+    if (state < 0 || B.status[p] != 0) { FOR_LANES(l) { if (l == 0) { B.pathCount[p] = 0; if (B.nearTie) B.nearTie[p] = 0; } } return; }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U;
     UCtx UX(T, B, p);
     auto colOf = [&](int eop) { return eop > 0 ? eop : 0; };
@@ -1212,6 +1212,8 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
             utrDescribe(UX, state, base, D);
             const int cc = UX.clsAt(base);
             Best best{AUGX_NINF, -2147483647, -1};
+            double runnerUp = AUGX_NINF; // (pass 1, only when near ties are counted: the largest (predecessor end, ancestor) that is not the winner)
+            for (int pass = 0; pass < (B.nearTie ? 2 : 1); pass++)
             for (int c0 = 0; c0 < D.total; c0 += WAVE) {
                 LV(double, cv); LV(int, ck); LV(int, ca);
                 FOR_LANES(l) {
@@ -1221,13 +1223,16 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
                         for (int a2 = 0; a2 < T.n_anc[state]; a2++) { // (ascending, strict '>': the ancestor of lower index wins a tie)
                             const double pv = M[(int64_t)colOf(e2) * S + T.anc[state][a2]];
                             if (!(pv > AUGX_NINF)) continue;
+                            if (pass == 1 && e2 + KEY_BIAS == best.key && a2 == best.aux) continue; // (the winner itself)
                             const double v = pv + (lnT(T, cc, T.anc[state][a2], state) + te);
                             if (v > LX(cv)) { LX(cv) = v; LX(ck) = e2 + KEY_BIAS; LX(ca) = a2; }
                         }
                 }
                 const Best b2 = waveArgMax(cv, ck, ca);
-                if (better(b2.v, b2.key, best.v, best.key)) best = b2;
+                if (pass == 0) { if (better(b2.v, b2.key, best.v, best.key)) best = b2; }
+                else if (b2.v > runnerUp) runnerUp = b2.v;
             }
+            if (B.nearTie && runnerUp > AUGX_NINF && best.v - runnerUp < AUGX_NEAR_TIE && best.v != runnerUp) nearTies++; // (an exact tie is decided by the reference's own rule, the same in both)
             if (!(best.v > AUGX_NINF)) { overflow = true; break; }
             ai = best.aux; eop = best.key - KEY_BIAS;
         } else {
@@ -1236,6 +1241,8 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
             const uint64_t i0 = B.blkOff[gb * 2 + 1];
             const uint32_t cnt = B.blkCnt[gb * 2 + 1], pid = (uint32_t)(((base % blkSz) << 7) | state);
             Best best{AUGX_NINF, -2147483647, -1};
+            double runnerUp = AUGX_NINF;
+            for (int pass = 0; pass < (B.nearTie ? 2 : 1); pass++)
             for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
                 LV(double, cv); LV(int, ck); LV(int, ca);
                 FOR_LANES(l) {
@@ -1251,13 +1258,16 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
                                 for (int i = 0; i < T.n_anc[state]; i++) if (T.anc[state][i] == a) a2 = i;
                                 // (key: the predecessor end, then the ancestor of LOWER index among equals)
                                 LX(cv) = pv + I.te; LX(ck) = (e2 + KEY_BIAS) * AUGX_MAX_ANC + (AUGX_MAX_ANC - 1 - a2); LX(ca) = a2;
+                                if (pass == 1 && LX(ck) == best.key) LX(cv) = AUGX_NINF; // (the winner itself)
                             }
                         }
                     }
                 }
                 const Best b2 = waveArgMax(cv, ck, ca);
-                if (better(b2.v, b2.key, best.v, best.key)) best = b2;
+                if (pass == 0) { if (better(b2.v, b2.key, best.v, best.key)) best = b2; }
+                else if (b2.v > runnerUp) runnerUp = b2.v;
             }
+            if (B.nearTie && runnerUp > AUGX_NINF && best.v - runnerUp < AUGX_NEAR_TIE && best.v != runnerUp) nearTies++; // (an exact tie is decided by the reference's own rule, the same in both)
             if (!(best.v > AUGX_NINF)) { overflow = true; break; }
             ai = best.aux; eop = best.key / AUGX_MAX_ANC - KEY_BIAS;
         }
@@ -1268,7 +1278,7 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
         if (ai < 0 || ai >= T.n_anc[state]) { if (base > 0) overflow = true; break; }
         state = T.anc[state][ai];
     }
-    FOR_LANES(l) { if (l == 0) { B.pathCount[p] = count; if (overflow) B.status[p] = AUGX_E_HIP; } }
+    FOR_LANES(l) { if (l == 0) { B.pathCount[p] = count; if (B.nearTie) B.nearTie[p] = nearTies; if (overflow) B.status[p] = AUGX_E_HIP; } }
 }
 
 } // namespace dev

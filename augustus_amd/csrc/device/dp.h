@@ -59,6 +59,10 @@ struct Item {
     uint32_t kp;    // [31:22] the (base, state) pair: (base offset in the block << 6) | state, [21:0] tie-break key = eop + KEY_BIAS
     uint32_t src;   // where the predecessor value lives: [31:30] tag, [29:28] ancestor index, [27:0] payload
 };
+// two candidates of a cell closer than this in ln are a NEAR TIE: the model terms are rounded to 2^-31 once, a few hundred
+// of them can move the difference of two alternative paths by up to ~1e-7, so the reference -- which rounds differently -- may decide such a
+// cell the other way.  The back-trace counts the cells on the chosen path where that can have happened.
+constexpr double AUGX_NEAR_TIE = 2e-7;
 constexpr int KEY_BITS = 22;                 // pieces on the device path are shorter than 2^22 bases
 constexpr uint32_t KEY_MASK = (1u << KEY_BITS) - 1;
 constexpr int KEY_BIAS = 64;                 // key = eop + KEY_BIAS >= 0 (eop >= -(3 + W) - 1 for a left-truncated initial exon)
@@ -170,6 +174,7 @@ struct BatchView {
     double *cells;             // [N][S] dense ln V (debug/test only) or NULL
     double *fwd;               // [N][S] dense ln of the forward variables (only when posterior sampling is asked for) or NULL
     double *lnFwd;             // [nPieces] ln P(sequence) = the sum over all paths
+    int32_t *nearTie;          // [nPieces] arg-max decisions on the chosen path whose runner-up lies within AUGX_NEAR_TIE of the winner (AUGX_TIMING / AUGX_NEAR_TIES) or NULL
     uint64_t *prof;            // [nPieces][4][8] cycle counters of the trellis wavefronts (AUGX_PROF=1) or NULL
     double *vig;               // [N] ln V of the igenic state (gathered by start-codon / reverse-stop candidates)
     double *longV;             // [N][6] ln V of longdss_f (0..2) and rlongass_f (3..5): read back at lag dStateLen by equalD

@@ -2812,10 +2812,10 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
     const int64_t po = pathOff(B, p), cap = pathCap(B, p);
     int state = B.finalState[p];
     int base = n - 1;
-    int count = 0;
+    int count = 0, nearTies = 0;
     bool overflow = false;
     if (state < 0 || B.status[p] != 0) {
-        FOR_LANES(l) { if (l == 0) B.pathCount[p] = 0; }
+        FOR_LANES(l) { if (l == 0) { B.pathCount[p] = 0; if (B.nearTie) B.nearTie[p] = 0; } }
         return;
     }
     const int dssWhole = T.Ds + 2 + T.De, assLag = T.As + 2 + T.Ae + T.U;
@@ -2871,6 +2871,8 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
             const uint64_t i0 = B.blkOff[gb * 2 + 1];
             const uint32_t cnt = B.blkCnt[gb * 2 + 1], pid = (uint32_t)(((base % blkSz) << 6) | state);
             Best best{AUGX_NINF, -2147483647, -1};
+            double runnerUp = AUGX_NINF; // (pass 1, only when near ties are counted: the largest candidate that is not the winner)
+            for (int pass = 0; pass < (B.nearTie ? 2 : 1); pass++)
             for (uint32_t c0 = 0; c0 < cnt; c0 += WAVE) {
                 LV(double, cv);
                 LV(int, ck);
@@ -2901,12 +2903,15 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
                                 pv = B.initKind[p] == 0 ? T.ln_init[a0] : (a0 == T.synch ? 0.0 : AUGX_NINF);
                             }
                             LX(cv) = pv + I.te; LX(ck) = (int)(I.kp & KEY_MASK); LX(ca) = (int)((sr >> 28) & 3);
+                            if (pass == 1 && LX(ck) == best.key && LX(ca) == best.aux) LX(cv) = AUGX_NINF; // (the winner itself)
                         }
                     }
                 }
                 const Best b2 = waveArgMax(cv, ck, ca);
-                if (better(b2.v, b2.key, best.v, best.key)) best = b2;
+                if (pass == 0) { if (better(b2.v, b2.key, best.v, best.key)) best = b2; }
+                else if (b2.v > runnerUp) runnerUp = b2.v;
             }
+            if (B.nearTie && runnerUp > AUGX_NINF && best.v - runnerUp < AUGX_NEAR_TIE && best.v != runnerUp) nearTies++; // (an exact tie is decided by the reference's own rule, the same in both)
             if (!(best.v > AUGX_NINF)) { overflow = true; break; }
             ai = best.aux;
             eop = best.key - KEY_BIAS;
@@ -2939,6 +2944,7 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
     FOR_LANES(l) {
         if (l == 0) {
             B.pathCount[p] = count;
+            if (B.nearTie) B.nearTie[p] = nearTies;
             if (overflow) B.status[p] = AUGX_E_HIP;
         }
     }

@@ -509,7 +509,12 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
     };
 
     std::map<WinKey, Decoded> cache;
-    int breadth = 1; // (measured, 23 Mbp of uniform-random DNA, fly model: 1 -> 8 batches of ~55 windows; 5 -> 5 batches of ~215, slower)
+    // guesses followed per undecoded window.  Measured on 23 Mbp of uniform-random DNA, fly model: 47 states (a batch costs what its
+    // bases cost): 1 -> 8 batches of ~55 windows, 5 -> 5 batches of ~215, slower.  71 states (one workgroup per window, a batch costs
+    // what its longest window costs while there are compute units to spare): 1 -> 26 batches, 5 -> 18
+    int nIgenicStates = 0;
+    for (int q = 0; q < M.t.S; q++) nIgenicStates += M.t.state_kind[q] == AUGX_K_IGENIC;
+    int breadth = (M.t.utr != 0 || nIgenicStates > 1) ? 5 : 1;
     if (const char *e = getenv("AUGX_CUT_BREADTH")) breadth = atoi(e);
     long nearShift = 3000;
     if (const char *e = getenv("AUGX_CUT_NEAR")) nearShift = atol(e);
@@ -937,6 +942,11 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         if (nUn > 0)
             std::cerr << "augustus (MI355X): note: pieces with more than one GC-content class were sampled with the UTR / two-intergenic-state model; the posterior probabilities near the "
                          "class steps may differ slightly from the CPU reference's (the predicted genes do not)." << std::endl;
+    }
+    if (timing) {
+        int64_t nt = 0, np = 0;
+        for (augx_decoder *d : S.decs) { int64_t q = 0; nt += augx_decoder_near_ties(d, &q); np += q; }
+        fprintf(stderr, "augx timing:   near ties on the chosen paths (exam windows and pieces): %lld cells in %lld decodes\n", (long long)nt, (long long)np);
     }
     lap("decode of the pieces");
     // ---- phase 3: gene structures + GFF, in input order

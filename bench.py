@@ -102,6 +102,12 @@ def parse_timing(stderr_text):
             if mt:
                 laps["cut_scout_s"], laps["cut_batches"], laps["cut_windows"], laps["cut_windows_used"] = float(mt.group(1)), int(mt.group(3)), int(mt.group(4)), int(mt.group(5))
             continue
+        if body.strip().startswith("near ties on the chosen paths"):  # "... : 3 cells in 2 decodes"
+            import re
+            mt = re.search(r": (\d+) cells in (\d+) decodes", body)
+            if mt:
+                laps["near_ties"] = int(mt.group(1))
+            continue
         if body.startswith("   "):
             n_batches += 1
             continue

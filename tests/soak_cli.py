@@ -15,70 +15,80 @@ from helpers import *  # noqa
 EXE = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
 
 
-def main():
-    seed0, n = int(sys.argv[1]), int(sys.argv[2])
+def make_case(seed, g):
+    """the records, species and options of soak case `seed` (g: the 1 Mbp of real DNA of tests/golden/big_inputs.tar.gz)"""
+    rng = random.Random(seed)
+
+    def gc_dna(k, gc):
+        return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(k))
+    recs = []
+    for k in range(rng.randint(1, 4)):
+        parts = []
+        for _ in range(rng.randint(1, 5)):
+            L = rng.choice([800, 3000, 7000, 15000, 40000])
+            r = rng.random()
+            if r < (0.9 if os.environ.get("SOAK_REAL") else 0.45): # (SOAK_REAL=1: nine parts in ten are slices of real DNA)
+                st = rng.randrange(0, len(g) - L)
+                s = g[st:st + L]
+                if rng.random() < 0.5:
+                    s = s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+                parts.append(s)
+            elif r < 0.8:
+                parts.append(gc_dna(L, rng.choice([0.3, 0.4, 0.45, 0.5, 0.6, 0.7])))
+            else:
+                parts.append(gc_dna(L // 2, 0.45) + "N" * rng.choice([1, 50, 900]) + gc_dna(L // 2, 0.55).lower())
+        recs.append(("r%d" % k, "".join(parts)))
+    species = rng.choice(["human", "fly", "arabidopsis", "saccharomyces", "human", "fly"])
+    opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
+    if rng.random() < 0.4:
+        opts["softmasking"] = "0"
+    dense = os.environ.get("AUGX_SOAK_DENSE") and rng.random() < 0.7
+    if dense:  # the models of the dense kernels: UTR states (fly: one GC class, see DESIGN.md 6 for the others) / two intergenic states
+        if rng.random() < 0.6:
+            species = "fly"
+            opts["UTR"] = "on"
+            if rng.random() < 0.3:
+                opts["print_utr"] = "on"
+            if rng.random() < 0.3:
+                opts["genemodel"] = "complete"
+        else:
+            species = rng.choice(["fly", "arabidopsis", "saccharomyces"])  # (one class each: the dense kernels do not replay the snippet cache)
+            opts["genemodel"] = rng.choice(["atleastone", "exactlyone"])
+    elif rng.random() < 0.3:
+        opts["singlestrand"] = "true"
+    elif rng.random() < 0.2:
+        opts["genemodel"] = rng.choice(["intronless", "complete"])
+    if rng.random() < 0.3:
+        opts["strand"] = rng.choice(["forward", "backward"])
+    if rng.random() < 0.4:
+        opts["maxDNAPieceSize"] = rng.choice(["20000", "50000"])
+    if rng.random() < 0.2:
+        opts["gff3"] = "on"
+    if rng.random() < 0.2:
+        opts["introns"] = "on"
+    if rng.random() < 0.15:
+        opts["noInFrameStop"] = "true"
+    if opts["sample"] != "0" and rng.random() < 0.2: # (the order of alternatives with EQUAL mean state probability follows heap
+        opts["alternatives-from-sampling"] = "true"  #  addresses in the reference, DESIGN.md section 6: a FAIL that only swaps
+        if rng.random() < 0.5:                       #  two t-numbers of a gene is that)
+            opts["maxtracks"] = rng.choice(["1", "2", "3"])
+    return recs, species, opts
+
+
+def real_dna():
     d = tempfile.mkdtemp()
     with tarfile.open(os.path.join(GOLDEN, "big_inputs.tar.gz")) as t:
         t.extractall(d)
-    g = read_fasta(os.path.join(d, "genome.fa"))[0][1]
+    return d, read_fasta(os.path.join(d, "genome.fa"))[0][1]
+
+
+def main():
+    seed0, n = int(sys.argv[1]), int(sys.argv[2])
+    d, g = real_dna()
     env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
     fails = 0
     for seed in range(seed0, seed0 + n):
-        rng = random.Random(seed)
-
-        def gc_dna(k, gc):
-            return "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(k))
-        recs = []
-        for k in range(rng.randint(1, 4)):
-            parts = []
-            for _ in range(rng.randint(1, 5)):
-                L = rng.choice([800, 3000, 7000, 15000, 40000])
-                r = rng.random()
-                if r < (0.9 if os.environ.get("SOAK_REAL") else 0.45): # (SOAK_REAL=1: nine parts in ten are slices of real DNA)
-                    st = rng.randrange(0, len(g) - L)
-                    s = g[st:st + L]
-                    if rng.random() < 0.5:
-                        s = s[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
-                    parts.append(s)
-                elif r < 0.8:
-                    parts.append(gc_dna(L, rng.choice([0.3, 0.4, 0.45, 0.5, 0.6, 0.7])))
-                else:
-                    parts.append(gc_dna(L // 2, 0.45) + "N" * rng.choice([1, 50, 900]) + gc_dna(L // 2, 0.55).lower())
-            recs.append(("r%d" % k, "".join(parts)))
-        species = rng.choice(["human", "fly", "arabidopsis", "saccharomyces", "human", "fly"])
-        opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
-        if rng.random() < 0.4:
-            opts["softmasking"] = "0"
-        dense = os.environ.get("AUGX_SOAK_DENSE") and rng.random() < 0.7
-        if dense:  # the models of the dense kernels: UTR states (fly: one GC class, see DESIGN.md 6 for the others) / two intergenic states
-            if rng.random() < 0.6:
-                species = "fly"
-                opts["UTR"] = "on"
-                if rng.random() < 0.3:
-                    opts["print_utr"] = "on"
-                if rng.random() < 0.3:
-                    opts["genemodel"] = "complete"
-            else:
-                species = rng.choice(["fly", "arabidopsis", "saccharomyces"])  # (one class each: the dense kernels do not replay the snippet cache)
-                opts["genemodel"] = rng.choice(["atleastone", "exactlyone"])
-        elif rng.random() < 0.3:
-            opts["singlestrand"] = "true"
-        elif rng.random() < 0.2:
-            opts["genemodel"] = rng.choice(["intronless", "complete"])
-        if rng.random() < 0.3:
-            opts["strand"] = rng.choice(["forward", "backward"])
-        if rng.random() < 0.4:
-            opts["maxDNAPieceSize"] = rng.choice(["20000", "50000"])
-        if rng.random() < 0.2:
-            opts["gff3"] = "on"
-        if rng.random() < 0.2:
-            opts["introns"] = "on"
-        if rng.random() < 0.15:
-            opts["noInFrameStop"] = "true"
-        if opts["sample"] != "0" and rng.random() < 0.2: # (the order of alternatives with EQUAL mean state probability follows heap
-            opts["alternatives-from-sampling"] = "true"  #  addresses in the reference, DESIGN.md section 6: a FAIL that only swaps
-            if rng.random() < 0.5:                       #  two t-numbers of a gene is that)
-                opts["maxtracks"] = rng.choice(["1", "2", "3"])
+        recs, species, opts = make_case(seed, g)
         fa = os.path.join(d, "c%d.fa" % seed)
         write_fasta(fa, recs)
         args = ["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa]
