@@ -431,7 +431,7 @@ struct augx_decoder {
 };
 
 namespace {
-int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists); // (below, with the forward algorithm)
+int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists, const double *mat); // (below, with the forward algorithm)
 // every decoder of the process (several may share a device: augx_decoder_set_share, the bench's resident batches): when an
 // allocation fails, the buffers the OTHER decoders of the device keep for re-use are given back to the runtime as well
 std::mutex g_regMu;
@@ -1045,14 +1045,14 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     // rebuilt and the trellis runs once more -- every Viterbi variable is then the reference's to 1e-9 there, too.  On by default:
     // a randomised soak found a record whose optimal path depends on it; AUGX_EXACT_MULTICLASS=0 trades that for
     // the second trellis run.
-    if (d->exactMulti && b->nPlAlloc > 1 && !d->dense) {
+    if (d->exactMulti && b->nPlAlloc > 1) {
         int64_t nPatched = 0;
         int rc2;
         const bool timing = getenv("AUGX_TIMING") != nullptr; // (developer aid)
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (timing) (void)hipStreamSynchronize(st);
         const double t0 = timing ? now() : 0.0;
-        try { rc2 = snippetCacheReplay(d, b, nPatched, true); }
+        try { rc2 = d->dense ? snippetCacheReplay(d, b, nPatched, false, b->V.cells) : snippetCacheReplay(d, b, nPatched, true, nullptr); }
         catch (const std::exception &e) { setLastError(std::string("augx_batch_decode: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc2) return rc2;
         const double t1 = timing ? now() : 0.0;
@@ -1230,7 +1230,9 @@ namespace {
 // cached chunks scored under different classes (snipmemo.h).  Which chunks depends on which predecessor cells are alive, and
 // that the first forward run has just told: the terms of the candidates concerned are rebuilt on the host and written back into
 // the candidate records.  Returns the number of rebuilt terms (> 0: the forward kernel has to run once more).
-int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists) {
+// (mat: the dense matrix that tells which cells are alive -- ln F after a forward run, ln V after a Viterbi run of the dense kernels;
+//  fromLists: after a Viterbi run of the 47-state kernels, which keep no matrix, the values left at the donor sites instead)
+int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists, const double *mat) {
     nPatched = 0;
     const BatchView &V = b->V;
     const int n = V.nPieces, S = d->hostT.S;
@@ -1264,10 +1266,10 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
         auto cp = [fst](void *dst, const void *src, size_t bytes) { return fst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, fst) : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
         const int len = b->L.len[p];
         const int64_t o = b->L.off[p];
-        R.t = &d->model->m.t; R.n = len; R.S = S; R.blk = V.blk; R.d = d->model->m.t.d; R.nPlanes = nPl[p];
+        R.t = &d->model->m.t; R.n = len; R.S = S; R.blk = V.blk; R.d = d->model->m.t.d; R.nPlanes = nPl[p]; R.dense = d->dense;
         if (!fromLists) { // (the rows of F a window reads are fetched with the window; the initial column now)
             D.F0.resize((size_t)S);
-            HIP_TRY(cp(D.F0.data(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)S));
+            HIP_TRY(cp(D.F0.data(), mat + (o + 1) * S, sizeof(double) * (size_t)S));
         } else { // (after a Viterbi run: what the trellis left at the donor sites of the short introns, and the initial column)
             int64_t lo2[2] = {0, 0};
             HIP_TRY(cp(lo2, V.listOffs + p, sizeof(int64_t) * 2));
@@ -1330,7 +1332,7 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
             }
             if (!fromLists) {
                 DP->F.resize((size_t)(t1 - r0 + 1) * S);
-                HIP_TRY(cpy(DP->F.data(), V.fwd + (o + 1 + r0) * S, sizeof(double) * DP->F.size()));
+                HIP_TRY(cpy(DP->F.data(), mat + (o + 1 + r0) * S, sizeof(double) * DP->F.size()));
                 R2.F = DP->F.data(); R2.fRow0 = r0;
             }
             // prefix slots r0 .. t1 + 1 (slot g = prefix up to base g - 1) of both strands and every plane: field rows of CHUNK slots
@@ -1414,14 +1416,14 @@ extern "C" {
 int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     int rc = augx_batch_forward_launch(d, b);
     if (rc) return rc;
-    if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO") && !d->dense) { // (a batch with a multi-class piece)
+    if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO")) { // (a batch with a multi-class piece)
         int64_t nPatched = 0;
-        try { rc = snippetCacheReplay(d, b, nPatched, false); }
+        try { rc = snippetCacheReplay(d, b, nPatched, false, b->V.fwd); }
         catch (const std::exception &e) { setLastError(std::string("augx_batch_forward: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc) return rc;
         if (nPatched > 0 && (rc = augx_batch_forward_launch(d, b))) return rc;
-    } else if (b->nPlAlloc > 1 && d->dense)
-        d->denseMultiForward++; // (the caller is told: augx_decoder_unreplayed_batches; the executable prints a note)
+        if (d->dense && d->hostT.utr) d->denseMultiForward++; // (UTR states: two more caches of the reference are not replayed; the caller is told)
+    }
     if (!b->evFwd) HIP_TRY(hipEventCreateWithFlags(&b->evFwd, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->evFwd, d->stream));
     return AUGX_OK;

@@ -32,6 +32,8 @@ struct MemoPatch { uint64_t item; double te; }; // global index of the candidate
 struct SnippetReplay {
     const augx_tables *t = nullptr;
     int n = 0, S = 0, blk = 8, d = 0;
+    bool dense = false;                   // the candidate records are those of the dense kernels (dense.h): the pair is (base of the block << 7) | state,
+                                          // `src` names the predecessor state, a start from column 0 has predecessor end 0; aliveness from the dense matrix F
     // which predecessor cells are alive, from a first run: the ln forward matrix F [n][S], or -- after a Viterbi run, which keeps no
     // matrix -- the values the trellis left at the donor sites (ldVal / rdVal: [entry][3 frames]) and the initial column col0 [S]
     const double *F = nullptr;
@@ -131,17 +133,18 @@ struct SnippetReplay {
             for (int st = 0; st < 2; st++) {
                 const std::vector<int> &states = st == 0 ? lessF : lessR;
                 for (int s : states) {
-                    const uint32_t pid = (uint32_t)(((j % blk) << 6) | s);
+                    const uint32_t pid = dense ? (uint32_t)(((j % blk) << 7) | s) : (uint32_t)(((j % blk) << 6) | s);
                     const int a = t->anc[s][0];
                     reqs.clear();
                     for (uint32_t it = 0; it < cnt; it++) {
                         const Item &I = bi[it];
                         if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
                         const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
-                        const uint32_t tag = I.src >> 30;
+                        const uint32_t tag = dense ? (eop <= 0 ? SRC_COL0 : SRC_LIST) : I.src >> 30;
                         // (a request is made only where a predecessor cell is alive; column 0 holds the initial probabilities)
                         double pv;
-                        if (F) pv = tag == SRC_COL0 ? (F0 ? F0 : F)[(size_t)(I.src & 0x3Fu)] : (eop >= fRow0 ? F[(size_t)(eop - fRow0) * S2 + a] : -INFINITY);
+                        if (dense) pv = eop <= 0 ? (F0 ? F0 : F)[(size_t)(I.src & 127u)] : (eop >= fRow0 ? F[(size_t)(eop - fRow0) * S2 + (I.src & 127u)] : -INFINITY);
+                        else if (F) pv = tag == SRC_COL0 ? (F0 ? F0 : F)[(size_t)(I.src & 0x3Fu)] : (eop >= fRow0 ? F[(size_t)(eop - fRow0) * S2 + a] : -INFINITY);
                         else if (tag == SRC_COL0) pv = col0[I.src & 0x3Fu];
                         else pv = (((I.src >> 26) & 3) == 2 ? ldVal : rdVal)[(size_t)(I.src & 0xFFFFFFu) * 3 + ((I.src >> 24) & 3)];
                         if (!(pv > -INFINITY)) continue;

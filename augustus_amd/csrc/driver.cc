@@ -940,7 +940,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         int64_t nUn = 0;
         for (augx_decoder *d : S.decs) nUn += augx_decoder_unreplayed_batches(d);
         if (nUn > 0)
-            std::cerr << "augustus (MI355X): note: pieces with more than one GC-content class were sampled with the UTR / two-intergenic-state model; the posterior probabilities near the "
+            std::cerr << "augustus (MI355X): note: pieces with more than one GC-content class were sampled with the UTR model; a few posterior probabilities near the "
                          "class steps may differ slightly from the CPU reference's (the predicted genes do not)." << std::endl;
     }
     if (timing) {

@@ -205,11 +205,11 @@ int augx_decoder_set_share(augx_decoder *d, int n_decoders_on_device);
  * a randomised soak found a record where the optimal path depends on it.  exact = 0 saves the second trellis run on batches
  * with such pieces.  The forward algorithm (augx_batch_forward) always replays it. */
 int augx_decoder_set_exact(augx_decoder *d, int exact);
-/* number of forward runs (posterior sampling) this decoder made with the dense kernels (UTR states, two intergenic states) over a
- * batch that holds a piece with more than one GC-content class: the reference's call-history caches (SnippetProbs,
- * src/statemodel.cc:312-342; tssProbsPlus, src/utrmodel.cc:748-790; the aSSProb memo, src/intronmodel.cc:1120-1135) are not
- * replayed there, the forward variables within a few hundred bases after a class step -- and with them the sampled posterior
- * probabilities -- may differ from the reference's.  The Viterbi path is not affected on any input tried. */
+/* number of forward runs (posterior sampling) this decoder made with the UTR model over a batch that holds a piece with more than
+ * one GC-content class.  The reference's snippet cache (SnippetProbs, src/statemodel.cc:312-342) is replayed for every model; two
+ * more call-history caches that only UTR states use (tssProbsPlus, src/utrmodel.cc:748-790; the aSSProb memo,
+ * src/intronmodel.cc:1120-1135) are not: a few forward variables within some dozen bases of a class step may be up to 1e-3 off in
+ * ln (the sampled paths of every multi-class record tried are the reference's).  The Viterbi path is not affected. */
 int64_t augx_decoder_unreplayed_batches(const augx_decoder *d);
 /* Near ties.  Every model term is rounded once to 2^-31 (AUGX_Q_BITS), which is what makes the decode exact and order-free; two
  * alternative candidates of a cell whose scores differ by less than ~2e-7 in ln may therefore be decided the other way by the

@@ -205,16 +205,54 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     DenseLdsV<4> *dv4 = new DenseLdsV<4>();
     DenseLdsV<2> *dv2 = new DenseLdsV<2>();
     const bool pipe = getenv("AUGX_DENSE_PIPE") && atoi(getenv("AUGX_DENSE_PIPE")) != 0; // (the product's switch: 1 = the Viterbi pass with the work done ahead, densev.h)
-    for (int p = 0; p < n; p++) {
+    // the reference's snippet cache around the class steps of a piece (snipmemo.h), from which cells of the matrix `mat` are alive:
+    // the candidate terms concerned are rebuilt in place; true: some were, the pass has to run once more
+    auto snippetReplay = [&](int p, const double *mat) -> bool {
+        if (B.nPlanes[p] <= 1) return false;
+        SnippetReplay R;
+        const int len = L.len[p], S = t->S;
+        const int64_t o = L.off[p];
+        R.t = t; R.n = len; R.S = S; R.blk = blk; R.d = t->d; R.dense = true;
+        R.F = mat + (o + 1) * S;
+        R.plane = B.gcPlane + o + 1;
+        R.planeCls = B.planeCls + (int64_t)p * MAXPL;
+        R.nPlanes = B.nPlanes[p];
+        const int nBlocks = (len + blk - 1) / blk;
+        const int64_t gb0 = o / blk;
+        R.blkOff = B.blkOff + gb0 * 2; R.blkCnt = B.blkCnt + gb0 * 2;
+        uint64_t lo = ~0ull;
+        for (int q = 0; q < nBlocks; q++) if (R.blkCnt[(size_t)q * 2 + 1] && R.blkOff[(size_t)q * 2 + 1] < lo) lo = R.blkOff[(size_t)q * 2 + 1];
+        if (lo == ~0ull) lo = 0;
+        R.item0 = lo; R.items = B.items + lo;
+        R.fxF.assign((size_t)R.nPlanes, {}); R.fxR.assign((size_t)R.nPlanes, {});
+        for (int pl = 0; pl < R.nPlanes; pl++) {
+            R.fxF[pl].resize((size_t)len + 1); R.fxR[pl].resize((size_t)len + 1);
+            const uint64_t *fx = B.fx + (int64_t)pl * B.N * NFX;
+            for (int g = 0; g <= len; g++) { R.fxF[pl][g] = fx[fidx(o + g, FX_INF, NFX)]; R.fxR[pl][g] = fx[fidx(o + g, FX_INR, NFX)]; }
+        }
+        R.run();
+        if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu stats (dense): piece %d: %zu candidate terms rebuilt from the reference's snippet cache\n", p, R.patches.size());
+        return !R.patches.empty();
+    };
+    const bool exact = !getenv("AUGX_EXACT_MULTICLASS") || atoi(getenv("AUGX_EXACT_MULTICLASS")) != 0; // (augx_decoder_set_exact, on by default)
+    auto viterbiPiece = [&](int p) {
         if (pipe) { if (blk == 8) densePieceV<8>(T, B, *dv8, p); else if (blk == 4) densePieceV<4>(T, B, *dv4, p); else densePieceV<2>(T, B, *dv2, p); }
         else if (blk == 8) densePiece<8, 0>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0>(T, B, *dl, p); else densePiece<2, 0>(T, B, *dl, p);
+    };
+    for (int p = 0; p < n; p++) {
+        viterbiPiece(p);
+        if (exact && snippetReplay(p, B.cells)) viterbiPiece(p);
         denseBacktracePiece(T, B, p);
     }
     if (fwd_out) {
         B.fwd = (double *)za(Z.N * t->S, 8);
         std::vector<double> lnF(n);
         B.lnFwd = lnF.data();
-        for (int p = 0; p < n; p++) { if (blk == 8) densePiece<8, 1>(T, B, *dl, p); else if (blk == 4) densePiece<4, 1>(T, B, *dl, p); else densePiece<2, 1>(T, B, *dl, p); }
+        auto fwdPiece = [&](int p) { if (blk == 8) densePiece<8, 1>(T, B, *dl, p); else if (blk == 4) densePiece<4, 1>(T, B, *dl, p); else densePiece<2, 1>(T, B, *dl, p); };
+        for (int p = 0; p < n; p++) {
+            fwdPiece(p);
+            if (!getenv("AUGX_NO_MEMO") && snippetReplay(p, B.fwd)) fwdPiece(p);
+        }
         int64_t w = 0;
         for (int p = 0; p < n; p++) {
             memcpy(fwd_out + w, B.fwd + (L.off[p] + 1) * t->S, sizeof(double) * (size_t)L.len[p] * t->S);

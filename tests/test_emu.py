@@ -586,3 +586,49 @@ def test_emulated_dense_viterbi_with_the_work_done_ahead(monkeypatch, knobs):
                 assert (r[0] == 0) == (rc == 0)
                 if rc == 0:
                     assert r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path] and np.array_equal(r[3], V)
+
+
+@needs_ref
+@pytest.mark.parametrize("opts,exact", [({"genemodel": "exactlyone", "softmasking": "0"}, True), ({"UTR": "on", "softmasking": "0"}, False)])
+def test_emulated_dense_kernels_with_several_gc_classes_against_the_reference(tmp_path, opts, exact):
+    """the dense kernels on pieces with several GC classes, with the reference's snippet cache replayed from the dense matrix
+    (snipmemo.h `dense`): the same cells alive as in the REAL reference and its sampled state paths, draw for draw.  Two intergenic
+    states: every forward variable within 1e-9 (before the replay was wired to the dense kernels: up to 4e-4 off, another 14th path).
+    UTR states: two more call-history caches of the reference (tssProbsPlus, the aSSProb memo) are not replayed -- a few cells after a
+    class step stay up to 1e-3 off in ln F; the six sampled paths of every record are the reference's all the same."""
+    byname = dict(golden_inputs())
+    recs = [(k, byname[k]) for k in ("multigc_gene", "multigc_two", "multigc_rand", "multigc_levels")]
+    fa = str(tmp_path / "f.fa")
+    write_fasta(fa, recs)
+    extra = ["--%s=%s" % kv for kv in opts.items()]
+    Fref = ref_forward(fa, "human", extra)
+    smp = ref_samples(fa, "human", extra, n=6)
+    m = ax.Model(config_path(), "human", sample="100", **opts)
+    res = emu_decode(m.tables_ptr, [s.upper() for _, s in recs], m.n_states, forward=True, samples=6)
+    for (name, seq), fr, rs, r in zip(recs, Fref, smp, res):
+        F = r[5]
+        assert np.array_equal(np.isfinite(F[1:]), np.isfinite(fr[1:])), name
+        both = np.isfinite(F) & np.isfinite(fr)
+        rel = np.abs(F[both] - fr[both]) / (np.abs(fr[both]) + 1e-300)
+        assert np.all(np.abs(F[both] - fr[both]) <= (1e-9 if exact else 1e-3) * np.abs(fr[both]) + 5e-9), (name, float(rel.max()))
+        assert [[tuple(x) for x in q] for q in rs] == [list(p) for p in r[7]], name
+
+
+def test_emulated_dense_exact_mode_is_the_oracle_bit_for_bit(monkeypatch):
+    """default mode of the dense kernels on multi-class records: emulator (replay after the run, from the dense matrix) == twin
+    (cache inside the loop), every cell; and the replay changes cells"""
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "1")
+    byname = dict(golden_inputs())
+    seqs = [byname[k].upper() for k in ("multigc_gene", "multigc_rand")] + [s for _, s in _multiclass_records(5)[:2]]
+    for opts in ({"UTR": "on", "sample": "0", "softmasking": "0"}, {"genemodel": "atleastone", "sample": "0", "softmasking": "0"}):
+        m = ax.Model(config_path(), "human", **opts)
+        S = m.n_states
+        res = emu_decode(m.tables_ptr, seqs, S, cells=True)
+        differs = 0
+        for s, r in zip(seqs, res):
+            rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True, cache=True)
+            assert r[0] == rc
+            if rc == 0:
+                assert r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path] and np.array_equal(r[3], V)
+                differs += int(not np.array_equal(twin_decode(m.tables_ptr, s, S, cells=True, cache=False)[3], V))
+        assert differs > 0

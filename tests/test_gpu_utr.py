@@ -12,10 +12,8 @@ import augustus_amd as ax
 from helpers import *
 
 
-@pytest.fixture(autouse=True)
-def _one_class_per_end_base(monkeypatch):
-    # (the dense kernels score a short-intron interior with the class of its end base; the twin follows this switch)
-    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
+# (the decoder's default, exact mode: on pieces with several GC classes the reference's snippet cache is replayed for the dense kernels
+#  too -- device/snipmemo.h from the dense ln V matrix -- and the oracle twin runs the same cache inside its loop)
 
 
 @pytest.mark.parametrize("species,opts", [("human", {"UTR": "on"}), ("human", {"UTR": "on", "softmasking": "0"}), ("fly", {"sample": "0"})])
@@ -40,6 +38,7 @@ def test_gpu_dense_viterbi_with_the_work_done_ahead(monkeypatch, species, opts):
     """AUGX_DENSE_PIPE=1: the Viterbi pass that evaluates the candidates of block b + 1 while block b runs (device/densev.h, loads
     through LDS landing pads): every cell, score and path equal to the oracle's, i.e. to the default pass'"""
     monkeypatch.setenv("AUGX_DENSE_PIPE", "1")
+    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")  # (this pass on its own)
     m = ax.Model(config_path(), species, **opts)
     d = ax.Decoder(m, 0)
     S = m.n_states

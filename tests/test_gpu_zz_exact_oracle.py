@@ -71,3 +71,31 @@ def test_cli_noinframestop_matches_reference(tmp_path, cfg):
     r = subprocess.run([exe, "--species=fly"] + ["--%s=%s" % kv for kv in NOINFRAMESTOP_CFGS[cfg].items()] + [fa], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and r.stderr == "", r.stderr
     assert gff_body(r.stdout) == open(os.path.join(GOLDEN, "golden_noinframestop_%s.gff" % cfg)).read().splitlines()
+
+
+@pytest.mark.parametrize("opts", [{"UTR": "on"}, {"genemodel": "exactlyone", "UTR": "off"}, {"genemodel": "atleastone", "UTR": "off"}])
+def test_gpu_dense_kernels_default_mode_is_the_oracle_bit_for_bit_on_multiclass_pieces(monkeypatch, opts):
+    """the dense kernels (UTR states; two intergenic states) on pieces with several GC classes, default mode: the snippet cache of the
+    reference replayed from the dense ln V matrix (device/snipmemo.h, `dense`), the terms rebuilt, the Viterbi pass run again -- every
+    cell, score and path equal to the twin that runs the cache inside its loop; and the replay is what does it"""
+    from test_emu import _multiclass_records
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    monkeypatch.delenv("AUGX_EXACT_MULTICLASS", raising=False)
+    m = ax.Model(config_path(), "human", softmasking="0", sample="0", **opts)
+    d = ax.Decoder(m, 0)
+    byname = dict(golden_inputs())
+    recs = _multiclass_records(21)[:4] + [(k, byname[k].upper()) for k in ("multigc_gene", "multigc_two", "multigc_rand", "multigc_levels")]
+    b = ax.Batch(d, [s for _, s in recs])
+    b.decode()
+    multi = differs = 0
+    for i, ((name, seq), r) in enumerate(zip(recs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, seq, m.n_states, cells=True, cache=True)
+        assert rc == r.status, name
+        if rc != 0:
+            continue
+        multi += int(len(set(gc.tolist())) > 1)
+        assert r.ln_viterbi == lnv and r.states == path, name
+        assert np.array_equal(b.cells(i), V), name
+        V0 = twin_decode(m.tables_ptr, seq, m.n_states, cells=True, cache=False)[3]
+        differs += int(not np.array_equal(V0, V))
+    assert multi >= 2 and differs > 0, (multi, differs)
