@@ -936,7 +936,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (size_t k = 0; k < dd.size(); k++) decoded[slot[k]] = std::move(dd[k]);
     }
 
-    if (S.sampleiterations > 0) { // (said once, on stderr: the one input class where the sampled probabilities are not the reference's)
+    if (S.sampleiterations > 0) { // (said once, on stderr: the one input class where sampled probabilities may not be the reference's)
         int64_t nUn = 0;
         for (augx_decoder *d : S.decs) nUn += augx_decoder_unreplayed_batches(d);
         if (nUn > 0)

@@ -41,6 +41,7 @@ BIG_CFGS = {
     "fly_utr": ("genome", "fly", ["--sample=0"]),            # UTR on (the species' default), soft-masking bonus, cut chain
     "fly_default": ("genome", "fly", []),                    # every default of the species: UTR on, sample 100, soft-masking
     "human_utr": ("genome", "human", ["--UTR=on"]),          # one 1 Mbp piece with two GC classes
+    "human_utr_sampled": ("genome", "human", ["--UTR=on", "--sample=100"]),  # ... with the forward pass and 99 sampled paths
 }
 
 

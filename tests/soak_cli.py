@@ -43,16 +43,17 @@ def make_case(seed, g):
     if rng.random() < 0.4:
         opts["softmasking"] = "0"
     dense = os.environ.get("AUGX_SOAK_DENSE") and rng.random() < 0.7
-    if dense:  # the models of the dense kernels: UTR states (fly: one GC class, see DESIGN.md 6 for the others) / two intergenic states
+    if dense:  # the models of the dense kernels: UTR states / two intergenic states (AUGX_SOAK_DENSE=2: human, several GC classes, as well)
+        multi = os.environ.get("AUGX_SOAK_DENSE") == "2"
         if rng.random() < 0.6:
-            species = "fly"
+            species = rng.choice(["fly", "human", "human"]) if multi else "fly"
             opts["UTR"] = "on"
             if rng.random() < 0.3:
                 opts["print_utr"] = "on"
             if rng.random() < 0.3:
                 opts["genemodel"] = "complete"
         else:
-            species = rng.choice(["fly", "arabidopsis", "saccharomyces"])  # (one class each: the dense kernels do not replay the snippet cache)
+            species = rng.choice(["fly", "arabidopsis", "saccharomyces"] + (["human", "human"] if multi else []))
             opts["genemodel"] = rng.choice(["atleastone", "exactlyone"])
     elif rng.random() < 0.3:
         opts["singlestrand"] = "true"
