@@ -195,7 +195,7 @@ struct BatchSizes {
 };
 
 inline void checkModelSupported(const augx_tables &t, int BLK) {
-    if (t.S > SP) throw std::runtime_error("augx: model has more than 48 states (UTR/nc models are not on the device path yet)");
+    if (t.S > SP) throw std::runtime_error("augx: model has more than 48 states: not for the wavefront layout of the trellis kernel (models with UTR states or two intergenic states go to the dense kernels, modelIsDense below)");
     int dL = t.d - 2 - t.De - t.As - 2 - t.U;
     if (dL >= LONG_RING || dL <= BLK || (dL > WAVE - BLK && dL < WAVE)) throw std::runtime_error("augx: intron d out of the supported range");
     // (a near fixed-lag state of block b is computed when the candidates of block b-1 are done: its lag must reach back past
