@@ -438,7 +438,21 @@ def utr_leg(cfg, local, a):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert all(r.status == 0 for r in b.paths()), "UTR decode failed"
-    b.close(); d.close()
+    b.close()
+    # the same with FEW pieces (a genome of 24 contigs): the dense kernels run one workgroup per piece, so 24 pieces use 24 of the 256 compute
+    # units -- the rate a batch of few pieces sees, next to the one that fills the chip
+    few_n = min(24, a.utr_contigs)
+    bf = ax.Batch(d, seqs[:few_n])
+    bf.decode(sync=True); bf.decode(sync=True)
+    kf = []
+    tf0 = time.perf_counter()
+    for _ in range(min(a.steps, 4)):
+        bf.decode(sync=False)
+        kf.append(bf.kernel_ms()["trellis_ms"])
+    ax._check(ax.lib().augx_batch_sync(d._h))
+    tfd = time.perf_counter() - tf0
+    few = {"value": few_n * a.utr_contig_len * len(kf) / tfd / 1e6, "unit": "Mbp/s", "pieces": few_n, "kernel_ms": float(np.mean(kf))}
+    bf.close(); d.close()
     tr_s = float(np.mean(ms["trellis"])) / 1e3
     achieved = (0.25 + 20.0 * S) * bases / tr_s / 1e9
     # HBM bytes of the kernel from the PMC passes of profiles/run_pmc.sh, taken with this very tree (as for the headline kernel)
@@ -459,7 +473,8 @@ def utr_leg(cfg, local, a):
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                         "traffic_unit": "bytes per launch (PMC, %s)" % tsrc,
                         "kernel": "kDense<4,0>", "kernel_ms": tr_s * 1e3, "prep_ms": float(np.mean(ms["prep"])), "backtrace_ms": float(np.mean(ms["back"])),
-                        "positions_per_s_per_piece": a.utr_contig_len / tr_s}}
+                        "positions_per_s_per_piece": a.utr_contig_len / tr_s},
+           "few_pieces": few}
     if not a.no_cpu_baseline and os.path.exists(REF_AUGUSTUS):
         env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg)
         core = sorted(os.sched_getaffinity(0))[0]

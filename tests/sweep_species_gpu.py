@@ -18,7 +18,7 @@ with tarfile.open("tmp_all_config.tar.gz") as t: t.extractall(d)
 cfg=os.path.join(d,"config")+"/"
 byname=dict(golden_inputs())
 utr=len(sys.argv)>4 and sys.argv[4]=="utr"
-recs=[(n,byname[n]) for n in (("HS04636","rand20k_b","trunc_both","revcomp") if utr else ("HS04636","multigc_levels","softmask_gene","trunc_both","rand20k_b"))]
+recs=[(n,byname[n]) for n in (("HS04636","rand20k_b","trunc_both","revcomp","multigc_levels") if utr else ("HS04636","multigc_levels","softmask_gene","trunc_both","rand20k_b"))]
 fa=os.path.join(d,"in.fa"); write_fasta(fa,recs)
 env=dict(os.environ,AUGUSTUS_CONFIG_PATH=cfg)
 k,nw=int(sys.argv[1]),int(sys.argv[2])
