@@ -4,6 +4,7 @@ cut: with the decode function of the test (the lane-loop emulator of the kernel 
 window per round, whatever the forecast guessed.  (On the device the same is checked against the reference binary's own cuts:
 test_cli_cut_finder_ladder_matches_reference, test_cli_piece_cutting_matches_reference.)"""
 import ctypes
+import os
 
 import pytest
 
@@ -47,10 +48,14 @@ def records():
             "".join(sm)]                       # soft-masked runs across the cuts and the window ends
 
 
-@pytest.mark.parametrize("species,opts", [("human", {"maxDNAPieceSize": "60000"}), ("fly", {"UTR": "off", "sample": "0", "maxDNAPieceSize": "70000"})])
-def test_windows_decoded_ahead_give_the_cuts_of_the_serial_chain(species, opts):
+@pytest.mark.parametrize("species,opts", [("human", {"maxDNAPieceSize": "60000"}), ("fly", {"UTR": "off", "sample": "0", "maxDNAPieceSize": "70000"}),
+                                          ("fly", {"sample": "0", "maxDNAPieceSize": "60000"})])   # (fly's default: UTR states, the dense kernels, five guesses per window)
+def test_windows_decoded_ahead_give_the_cuts_of_the_serial_chain(monkeypatch, species, opts):
     m = ax.Model(config_path(), species, **opts)
     recs = records()
+    if m.n_states > 48:  # (the emulated 71-state decode takes 16 s per Mbp: fewer records, smaller batches of guesses)
+        monkeypatch.setenv("AUGX_CUT_ASK", "16")
+        recs = [recs[0][:330000], recs[2], recs[3][:150000]]
     log0, log1 = [], []
     serial, st0 = ax.find_cuts(m, recs, emulator_decode_fn(m, log0), scout=0)
     ahead, st1 = ax.find_cuts(m, recs, emulator_decode_fn(m, log1), scout=1)
@@ -61,11 +66,12 @@ def test_windows_decoded_ahead_give_the_cuts_of_the_serial_chain(species, opts):
         assert ps[0][2] == 0 and ps[-1][3] == len(s) - 1 and all(a[3] + 1 == b[2] for a, b in zip(ps, ps[1:]))
         assert all(c[1] == 0 and c[4] == (0 if c[2] == 0 else 1) and c[5] == (0 if c[3] == len(s) - 1 else 1) for c in ps)
         assert all(c[3] - c[2] + 1 <= int(opts["maxDNAPieceSize"]) for c in ps)
-    assert len([c for c in serial if c[0] == 0]) >= 9 and len([c for c in serial if c[0] == 2]) == 1
+    assert len([c for c in serial if c[0] == 0]) >= 5 and len([c for c in serial if len(recs[c[0]]) <= int(opts["maxDNAPieceSize"])]) == 1
     # serial: every batch holds at most one window per unfinished record, all of them used; ahead: a scout decode, then fewer batches
     assert st0["scout_tiles"] == 0 and st0["windows_decoded"] == st0["windows_used"] and all(len(b) <= 3 for b in log0)
     assert st1["scout_tiles"] > 0 and st1["windows_used"] == st0["windows_used"]
     assert st1["batches"] < st0["batches"], (st0, st1)
+    assert st1["windows_decoded"] <= int(os.environ.get("AUGX_CUT_ASK", "256")) * st1["batches"]   # (the forecast's breadth is bounded per batch)
 
 
 def test_decode_failure_is_reported():
