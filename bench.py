@@ -99,13 +99,13 @@ def parse_timing(stderr_text):
         if body.strip().startswith("cut finder: scout"):  # "cut finder: scout 0.123 s (115 tiles), 8 batches, 423 windows decoded, 174 used"
             import re
             mt = re.search(r"scout ([0-9.]+) s \((\d+) tiles\), (\d+) batches, (\d+) windows decoded, (\d+) used", body)
-            if mt:
+            if mt and int(mt.group(4)) > 0:  # (a run without a cut finder round says nothing here)
                 laps["cut_scout_s"], laps["cut_batches"], laps["cut_windows"], laps["cut_windows_used"] = float(mt.group(1)), int(mt.group(3)), int(mt.group(4)), int(mt.group(5))
             continue
         if body.strip().startswith("near ties on the chosen paths"):  # "... : 3 cells in 2 decodes"
             import re
             mt = re.search(r": (\d+) cells in (\d+) decodes", body)
-            if mt:
+            if mt and int(mt.group(1)) > 0:
                 laps["near_ties"] = int(mt.group(1))
             continue
         if body.startswith("   "):
