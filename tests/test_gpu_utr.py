@@ -51,6 +51,35 @@ def test_gpu_dense_viterbi_with_the_work_done_ahead(monkeypatch, species, opts):
         assert rc != 0 or np.array_equal(b.cells(i), V), i
 
 
+@needs_ref
+@pytest.mark.parametrize("species,opts,multi", [("fly", {}, False), ("human", {"UTR": "on", "softmasking": "0"}, False),
+                                                ("human", {"genemodel": "exactlyone", "softmasking": "0"}, True)])
+def test_gpu_dense_forward_matches_reference(tmp_path, species, opts, multi):
+    """the forward pass of the dense kernels (kDense<BLK, 1>: UTR states; two intergenic states) on the device against every forward
+    variable of the REAL reference, run live: the same cells alive, ln F within 1e-9 relative.  Two intergenic states: also on the
+    records with several GC classes (snippet cache replayed from the dense ln F matrix); UTR states on one-class records (the two
+    caches that are not replayed only matter next to class steps)."""
+    ex = dict(golden_inputs())
+    names = ["HS04636", "HS08198", "short600", "trunc_both", "trunc_right", "iupac"] + (["multigc_gene", "multigc_rand"] if multi else [])
+    recs = [(k, ex[k]) for k in names] + [("rnd", random_dna(12000, 77))]
+    fa = str(tmp_path / "x.fa")
+    write_fasta(fa, recs)
+    Fref = ref_forward(fa, species, ["--%s=%s" % kv for kv in opts.items()])
+    m = ax.Model(config_path(), species, sample="100", **opts)
+    d = ax.Decoder(m, 0)
+    b = ax.Batch(d, [s for _, s in recs])
+    b.decode()
+    b.forward()
+    for i, ((name, seq), fr, r) in enumerate(zip(recs, Fref, b.paths())):
+        if r.status != 0:
+            continue
+        F, lnp = b.forward_cells(i)
+        assert np.array_equal(np.isfinite(F[1:]), np.isfinite(fr[1:])), name
+        both = np.isfinite(F) & np.isfinite(fr)
+        assert np.all(np.abs(F[both] - fr[both]) <= 1e-9 * np.abs(fr[both]) + 5e-9), name
+        assert lnp >= r.ln_viterbi
+
+
 def test_gpu_utr_interior_piece_kinds_and_batch_order():
     m = ax.Model(config_path(), "fly", sample="0", softmasking="0")
     d = ax.Decoder(m, 0)
