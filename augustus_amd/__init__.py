@@ -368,6 +368,18 @@ class Decoder:
         """``augx_decoder_set_exact``: replay the reference's snippet cache on pieces with several GC classes for the Viterbi run, too"""
         _check(lib().augx_decoder_set_exact(self._h, 1 if on else 0))
 
+    def count_near_ties(self, on=True):
+        """``augx_decoder_count_near_ties``: batches created from now on count the near ties on their chosen paths"""
+        _check(lib().augx_decoder_count_near_ties(self._h, 1 if on else 0))
+
+    def near_ties(self):
+        """``augx_decoder_near_ties``: (cells, pieces) summed over the paths fetched so far"""
+        L = lib()
+        L.augx_decoder_near_ties.restype = ctypes.c_int64
+        L.augx_decoder_near_ties.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+        np_ = ctypes.c_int64()
+        return int(L.augx_decoder_near_ties(self._h, ctypes.byref(np_))), int(np_.value)
+
     def set_share(self, n):
         """n decoders (streams) work on this device at the same time: plan the trellis segments for 1/n of its compute units"""
         _check(lib().augx_decoder_set_share(self._h, n))

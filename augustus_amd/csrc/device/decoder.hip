@@ -353,9 +353,9 @@ template <int BLK> __global__ void __launch_bounds__(NT) kUtrDesc(const DevTable
     utrDescGroup<BLK>(*T, B, lds, blockIdx.x);
 }
 // the dense Viterbi / forward kernel and its back-trace (dense.h): one workgroup / one wavefront per piece
-template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kDense(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+template <int BLK, int MODE, bool TIES = false> __global__ void __launch_bounds__(NT) kDense(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ DenseLds lds;
-    densePiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
+    densePiece<BLK, MODE, TIES>(*T, *B, lds, blockIdx.x);
 }
 // the Viterbi pass with the candidates of block b + 1 evaluated while block b runs (densev.h); kDense<BLK, 0> is the same pass
 // without the work done ahead (AUGX_DENSE_PIPE=0), kDense<BLK, 1> the forward pass
@@ -375,9 +375,9 @@ template <int BLK, bool MULTI, bool DENSE = false> __global__ void __launch_boun
 
 // MODE 0: pass 1, one workgroup per segment (= per piece when no piece is cut); 1: the fix-ups; 2: continuation of pieces whose
 // fix-up gave up, one workgroup per piece (kernels.h: trellisPiece)
-template <int BLK, int MODE> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+template <int BLK, int MODE, bool TIES = false> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
-    trellisPiece<BLK, MODE>(*T, *B, lds, blockIdx.x);
+    trellisPiece<BLK, MODE, TIES>(*T, *B, lds, blockIdx.x);
 }
 __global__ void __launch_bounds__(256) kTileCross(BatchView B) {
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1002,6 +1002,10 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             if (d->blk == 8) hipLaunchKernelGGL((kDenseV<8>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
             else if (d->blk == 4) hipLaunchKernelGGL((kDenseV<4>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
             else hipLaunchKernelGGL((kDenseV<2>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
+        } else if (V.nearTie) { // (near ties are counted: the build whose chain runs flag them)
+            if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+            else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+            else hipLaunchKernelGGL((kDense<2, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
         } else if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
         else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
         else hipLaunchKernelGGL((kDense<2, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
@@ -1013,7 +1017,11 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     }
     HIP_TRY(hipMemsetAsync(V.segStatus, 0, sizeof(int32_t) * V.nSegs, st));
 #define AUGX_LAUNCH_TRELLIS(MODE_, grid_) do { \
-        if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
+        if (V.nearTie) { /* (near ties are counted: the build of the kernel whose chain wavefront flags them) */ \
+            if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_, true>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
+            else if (d->blk == 4) hipLaunchKernelGGL((kTrellis<4, MODE_, true>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
+            else hipLaunchKernelGGL((kTrellis<2, MODE_, true>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
+        } else if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
         else if (d->blk == 4) hipLaunchKernelGGL((kTrellis<4, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
         else hipLaunchKernelGGL((kTrellis<2, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); } while (0)
     AUGX_LAUNCH_TRELLIS(0, V.nSegs);                 // pass 1: every segment at once (one workgroup per piece when no piece is cut)

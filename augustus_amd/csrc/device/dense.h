@@ -643,7 +643,7 @@ template <bool FWD> AUGX_KFN double denseAt(const DenseLds &L, const double *M, 
 #endif
 // One workgroup walks piece p block by block.  MODE 0: Viterbi (ln V into B.cells, back pointers of the chain / fixed-lag
 // states into B.bpD, score and final state of the piece); MODE 1: forward algorithm (ln F into B.fwd, ln P(sequence)).
-template <int BLK, int MODE>
+template <int BLK, int MODE, bool TIES = false> // TIES (MODE 0): the chain runs flag near ties (dp.h: AUGX_NEAR_TIE) -- a build of its own
 AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, int p) {
     constexpr bool FWD = MODE == 1;
     const int n = B.len[p], S = T.S, c0 = B.cls[p];
@@ -839,7 +839,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             if (j >= n || j < 1) continue;
             const int cc = clsAt(j);
             const double emi = (*lp(&L.sg[par][dj][sgi]));
-            double f = (*lp(&L.oth[slot][dj]));
+            double f = (*lp(&L.oth[slot][dj])), f2 = AUGX_NINF; // (f2: the runner-up, for the near-tie flag)
             int fa = (*lp(&L.othAi[slot][dj]));
             for (int ai = 0; ai < na; ai++) {
                 if (!(*lp(&L.chLive[slot][ai]))) continue;
@@ -848,9 +848,12 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                 if (!(pv > AUGX_NINF)) continue;
                 const double x = pv + (trn(cc, s2, ai) + emi);
                 if (FWD) f = lse2(f, x);
-                else if (x > f || (x == f && ai < fa)) { f = x; fa = ai; }
+                else if (x > f || (x == f && ai < fa)) { if (TIES) f2 = f; f = x; fa = ai; }
+                else if (TIES && x > f2) f2 = x;
             }
             (*lp(&L.ring[j & 63][s2])) = f;
+            // (near ties are being counted, dp.h: AUGX_NEAR_TIE: bit 6 of the back pointer says that the runner-up was that close)
+            if (TIES && !FWD && fa < 8 && f2 > AUGX_NINF && f - f2 < AUGX_NEAR_TIE) fa |= 0x40;
             if (f > AUGX_NINF) { gp(M)[(int64_t)j * S + s2] = f; if (!FWD && BP) gp(BP)[(int64_t)j * S + s2] = (uint8_t)fa; }
         }
     };
@@ -868,13 +871,15 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
         _Pragma("unroll") for (int dj = 0; dj < BLK; dj++) {
             const int j = jb + dj;
             if (j >= n || j < 1) continue;
-            double f = ot[dj];
+            double f = ot[dj], f2 = AUGX_NINF;
             int fa = oa[dj];
             if (selfAi >= 0 && prev > AUGX_NINF) {
                 const double x = prev + ((multi ? trn(clsAt(j), s2, selfAi) : tSelf) + em[dj]);
                 if (FWD) f = lse2(f, x);
-                else if (x > f || (x == f && selfAi < fa)) { f = x; fa = selfAi; }
+                else if (x > f || (x == f && selfAi < fa)) { if (TIES) f2 = f; f = x; fa = selfAi; }
+                else if (TIES) f2 = x;
             }
+            if (TIES && !FWD && fa < 8 && f2 > AUGX_NINF && f - f2 < AUGX_NEAR_TIE) fa |= 0x40;
             (*lp(&L.ring[j & 63][s2])) = f;
             if (f > AUGX_NINF) { gp(M)[(int64_t)j * S + s2] = f; if (!FWD && BP) gp(BP)[(int64_t)j * S + s2] = (uint8_t)fa; }
             prev = f;
@@ -1183,7 +1188,8 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
                     LX(flag) = 0; LX(wv) = -1; LX(hit) = 4;
                     for (int k = 3; k >= 0; k--) {
                         const int q = cur - 4 * l - k;
-                        const int ww = q >= 1 ? (int)BP[(int64_t)q * S + state] : -1;
+                        const int raw = q >= 1 ? (int)BP[(int64_t)q * S + state] : -1;
+                        const int ww = raw < 0 || raw >= 0xFE ? raw : (raw & 0x3F); // (bit 6: the decision of that cell was a near tie)
                         if (q < 1 || ww != selfAi) { LX(flag) = 1; LX(wv) = ww; LX(hit) = k; }
                     }
                 }
@@ -1199,6 +1205,13 @@ AUGX_KFN void denseBacktracePiece(const DevTables &T, const BatchView &B, int p)
                     break;
                 }
                 cur -= 4 * WAVE;
+            }
+            if (B.nearTie) { // the cells of this run whose decision (stay / come in from another state) was a near tie
+                for (int q0 = cur < 1 ? 1 : cur; q0 <= base; q0 += WAVE) {
+                    LV(int, fl);
+                    FOR_LANES(l) { const int q = q0 + l; const int raw = q <= base ? (int)BP[(int64_t)q * S + state] : 0xFF; LX(fl) = (raw < 0xFE && (raw & 0x40)) ? 1 : 0; }
+                    nearTies += waveCount(fl);
+                }
             }
             if (cur < 1) { eop = 0; ai = -1; }
             else if (w == 0xFE) { eop = 0; ai = -1; } // (a piece of N only: intergenic from the first base)

@@ -1599,7 +1599,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
 // MODE 2: pass 3 -- sg is a PIECE: its first fix-up that gave up and has not been redone continues from where it stopped, still
 // comparing, with no limit (one per launch; the piece's runs of this pass must not overlap);  MODE 3: such a fix-up continues
 // to the end of the piece without comparing (what is left after the launches of pass 3).
-template <int BLK, int MODE = 0>
+template <int BLK, int MODE = 0, bool TIES = false> // TIES: the chain wavefront flags near ties (dp.h: AUGX_NEAR_TIE) -- a build of its own, the default kernel pays nothing for it
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int sg) {
     constexpr int NB = WAVE / BLK;  // blocks per tile
     constexpr int SPR = WAVE / BLK; // state slots per round of 64 lanes: lane = (slot, base of the block)
@@ -2009,18 +2009,24 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         FOR_WLANES(t, w) {
             const double vs = TX(psS) + TX(teS);
             double best = TX(bB);
-            int bai = TX(aB);
-            if (vs > best) { best = vs; bai = TX(cSelf); }
-            if (TX(bA) > best) { best = TX(bA); bai = TX(aA); }
+            int bai = TX(aB), gw = 0; // gw: which of the three won -- an ancestor before the state itself, the state itself, one after it
+            if (vs > best) { best = vs; bai = TX(cSelf); gw = 1; }
+            if (TX(bA) > best) { best = TX(bA); bai = TX(aA); gw = 2; }
             TX(rai) = bai;
+            if (TIES && bai >= 0) { // near ties are being counted (dp.h: AUGX_NEAR_TIE): was the runner-up among (best way in from an earlier
+                                         // ancestor, staying, best way in from a later ancestor) that close?  Bit 7 of the compact back pointer says so
+                const double o1 = gw == 0 ? vs : TX(bB), o2 = gw == 2 ? vs : TX(bA);
+                const double m2 = o1 > o2 ? o1 : o2;
+                if (m2 > AUGX_NINF && best - m2 < AUGX_NEAR_TIE) TX(rai) = bai | 0x80;
+            }
         }
         FOR_WLANES(t, w) {
             const int j = TX(jj);
             if (TX(cS) >= 0 && j >= 1 && j < n) {
                 const int s2 = TX(cS);
                 L.ring[j & 63][s2] = TX(res);
-                L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai)) : BP_NONE;
-                L.bpc[buf][j & 63][(t & 63) / BLK] = TX(res) > AUGX_NINF ? (uint8_t)TX(rai) : (uint8_t)0xFF; // (chain slot = lane / BLK, see the set-up above)
+                L.bp[buf][j & 63][s2] = TX(res) > AUGX_NINF ? bpFixed(TX(rai) & 0x7F) : BP_NONE;
+                L.bpc[buf][j & 63][(t & 63) / BLK] = TX(res) > AUGX_NINF ? (uint8_t)TX(rai) : (uint8_t)0xFF; // (chain slot = lane / BLK, see the set-up above; bit 7: near tie)
                 if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = TX(res);
                 if (TX(cIsIg)) L.vigw[j & (VIG_WIN - 1)] = TX(res); // (HBM copy: flushed with the tile)
             }
@@ -2794,12 +2800,14 @@ AUGX_KFN void segFinalizePiece(const BatchView &B, int p) {
 // a time by the whole wavefront and emitted as one merged record.  Records are written 3'->5'.
 // =================================================================================================
 #ifdef AUGX_EMU
+inline int waveCount(const int *flag) { int c = 0; for (int l = 0; l < WAVE; l++) c += flag[l] != 0; return c; }
 inline int waveFirstTrue(const int *flag) {
     for (int l = 0; l < WAVE; l++)
         if (flag[l]) return l;
     return WAVE;
 }
 #else
+__device__ inline int waveCount(const int *flag) { return __popcll(__ballot(flag[0] != 0)); }
 __device__ inline int waveFirstTrue(const int *flag) {
     unsigned long long m = __ballot(flag[0] != 0);
     return m ? (int)__ffsll((long long)m) - 1 : WAVE;
@@ -2842,7 +2850,8 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
 #pragma unroll
                     for (int k = 3; k >= 0; k--) { // (descending k: the hit nearest to cur is kept)
                         const int q = cur - 4 * l - k;
-                        const int ww = q >= 1 ? (int)B.bpChain[(o + 1 + q) * 8 + cslot] : -1;
+                        const int raw = q >= 1 ? (int)B.bpChain[(o + 1 + q) * 8 + cslot] : -1;
+                        const int ww = raw < 0 || raw == 0xFF ? raw : (raw & 0x7F); // (bit 7: the decision of that cell was a near tie)
                         if (q < 1 || ww != selfAi) { LX(flag) = 1; LX(wv) = ww; LX(hit) = k; }
                     }
                 }
@@ -2860,6 +2869,14 @@ AUGX_KFN void backtracePiece(const DevTables &T, const BatchView &B, int p) {
                 cur -= 4 * WAVE;
             }
             // bases cur..base are in `state`; base `cur` was entered from another state (or cur < 1: sequence start)
+            if (B.nearTie) { // the cells of this run whose decision (stay / come in from another state) was a near tie
+                const int lo2 = cur < 1 ? 1 : cur;
+                for (int q0 = lo2; q0 <= base; q0 += WAVE) {
+                    LV(int, fl);
+                    FOR_LANES(l) { const int q = q0 + l; LX(fl) = (q <= base && B.bpChain[(o + 1 + q) * 8 + cslot] != 0xFF && (B.bpChain[(o + 1 + q) * 8 + cslot] & 0x80)) ? 1 : 0; }
+                    nearTies += waveCount(fl);
+                }
+            }
             if (cur < 1) { eop = 0; ai = -1; }
             else { eop = cur - 1; ai = w; }
         } else if ((kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) || kind == AUGX_K_LESSD || kind == AUGX_K_RLESSD) {

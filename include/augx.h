@@ -214,9 +214,11 @@ int64_t augx_decoder_unreplayed_batches(const augx_decoder *d);
 /* Near ties.  Every model term is rounded once to 2^-31 (AUGX_Q_BITS), which is what makes the decode exact and order-free; two
  * alternative candidates of a cell whose scores differ by less than ~2e-7 in ln may therefore be decided the other way by the
  * reference, whose own rounding is finer (seen once in 315 randomised runs).  With counting on (also: AUGX_TIMING or
- * AUGX_NEAR_TIES=1 in the environment when the decoder is created) the back-trace counts the cells of the variable-length states ON THE
- * CHOSEN PATH whose runner-up lies within 2e-7 of the winner; augx_decoder_near_ties returns the sum over the paths fetched so far
- * (and the number of pieces with at least one).  0 = no decision of the path was that close. */
+ * AUGX_NEAR_TIES=1 in the environment when the decoder is created) the trellis flags the cells of the single-base chain states where staying
+ * and the best way in from another state were within 2e-7 of each other, and the back-trace counts those ON THE CHOSEN PATH together with
+ * the cells of the variable-length states on it whose runner-up candidate lies within 2e-7 of the winner; augx_decoder_near_ties returns the
+ * sum over the paths fetched so far (and the number of pieces with at least one).  0 = no decision of the path was that close.  Counting
+ * runs a build of the kernels of its own (about 1.5 % slower); off by default. */
 int augx_decoder_count_near_ties(augx_decoder *d, int on);
 int64_t augx_decoder_near_ties(const augx_decoder *d, int64_t *pieces /* may be NULL */);
 /* host buffers kept between sampled pieces (forward matrices, at most 8 GB) are released when the last decoder is destroyed, or here */

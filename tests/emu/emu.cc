@@ -17,6 +17,7 @@
 #include "../../augustus_amd/csrc/device/layout.h"
 #include "../../augustus_amd/csrc/device/sampler.h"
 #include "../../augustus_amd/csrc/device/snipmemo.h"
+static std::vector<int32_t> g_nearTies; // near ties on the chosen path of every piece of the last decode (dp.h: AUGX_NEAR_TIE)
 
 using namespace augx::dev;
 
@@ -94,6 +95,8 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     std::vector<int32_t> st(n), fin(n), pc(n);
     B.lnv = lnvv.data(); B.status = st.data(); B.finalState = fin.data(); B.pathCount = pc.data();
     B.pathRec = (int32_t *)za(Z.pathCap * 3, 4);
+    g_nearTies.assign((size_t)n, 0);
+    B.nearTie = g_nearTies.data();
     for (int64_t g = 0; g < B.N; g++) k1Encode(B, g);
     for (int64_t g = 0; g < B.N; g++) k1SiteTerms(T, B, g);
     scanFields<false>(B.cnt, NCNT, L);
@@ -237,7 +240,7 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     const bool exact = !getenv("AUGX_EXACT_MULTICLASS") || atoi(getenv("AUGX_EXACT_MULTICLASS")) != 0; // (augx_decoder_set_exact, on by default)
     auto viterbiPiece = [&](int p) {
         if (pipe) { if (blk == 8) densePieceV<8>(T, B, *dv8, p); else if (blk == 4) densePieceV<4>(T, B, *dv4, p); else densePieceV<2>(T, B, *dv2, p); }
-        else if (blk == 8) densePiece<8, 0>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0>(T, B, *dl, p); else densePiece<2, 0>(T, B, *dl, p);
+        else if (blk == 8) densePiece<8, 0, true>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0, true>(T, B, *dl, p); else densePiece<2, 0, true>(T, B, *dl, p);
     };
     for (int p = 0; p < n; p++) {
         viterbiPiece(p);
@@ -317,6 +320,7 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
 }
 
 extern "C" {
+int emu_near_ties(int p) { return p >= 0 && p < (int)g_nearTies.size() ? g_nearTies[p] : -1; }
 void emu_set_sampling(int n, unsigned seed) {
     g_nsamples = n;
     delete g_rand;
@@ -381,6 +385,8 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
     std::vector<int32_t> st(n), fin(n), pc(n);
     B.lnv = lnvv.data(); B.status = st.data(); B.finalState = fin.data(); B.pathCount = pc.data();
     B.pathRec = zalloc<int32_t>(Z.pathCap * 3);
+    g_nearTies.assign((size_t)n, 0);
+    B.nearTie = g_nearTies.data();
 
     // ---- K1
     for (int64_t g = 0; g < B.N; g++) k1Encode(B, g);
@@ -517,7 +523,7 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
         B.ckCol = zalloc<double>(Z.N / WAVE * SP);
     }
     TrellisLds *lds = new TrellisLds();
-#define EMU_TRELLIS(MODE_, idx) do { if (blk == 8) trellisPiece<8, MODE_>(T, B, *lds, idx); else if (blk == 4) trellisPiece<4, MODE_>(T, B, *lds, idx); else trellisPiece<2, MODE_>(T, B, *lds, idx); } while (0)
+#define EMU_TRELLIS(MODE_, idx) do { if (blk == 8) trellisPiece<8, MODE_, true>(T, B, *lds, idx); else if (blk == 4) trellisPiece<4, MODE_, true>(T, B, *lds, idx); else trellisPiece<2, MODE_, true>(T, B, *lds, idx); } while (0)
     auto runTrellis = [&]() {
         std::fill(segStop.begin(), segStop.end(), -1); std::fill(segStop2.begin(), segStop2.end(), -1); std::fill(segStatus.begin(), segStatus.end(), 0);
         std::fill(pieceCovered.begin(), pieceCovered.end(), -1);

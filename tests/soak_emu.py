@@ -62,7 +62,7 @@ def main():
         dense = os.environ.get("AUGX_SOAK_DENSE") and rng.random() < 0.7
         if dense:  # the models of the dense kernels: UTR states (one-class species: see DESIGN.md 6 for the others) / two intergenic states
             if rng.random() < 0.6:
-                species = rng.choice(["fly", "arabidopsis"])
+                species = rng.choice(["fly", "arabidopsis"] + (["human", "human"] if os.environ.get("AUGX_SOAK_DENSE") == "2" else []))  # (2: several GC classes as well)
                 opts["UTR"] = "on"
                 if rng.random() < 0.3:
                     opts["print_utr"] = "on"

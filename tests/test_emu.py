@@ -632,3 +632,24 @@ def test_emulated_dense_exact_mode_is_the_oracle_bit_for_bit(monkeypatch):
                 assert r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path] and np.array_equal(r[3], V)
                 differs += int(not np.array_equal(twin_decode(m.tables_ptr, s, S, cells=True, cache=False)[3], V))
         assert differs > 0
+
+
+def test_emulated_near_tie_counter_flags_the_soak_case():
+    """the exam window of soak case 5010 (tests/soak_cli.py): two copies of one single-exon gene 164 bases apart -- in exact arithmetic a tie
+    between staying intergenic and coming out of the second copy; the reference's rounding and ours decide it differently.  The chain
+    wavefront flags the cell, the back-trace counts it; the reference's examples and random DNA have no such cell"""
+    import ctypes
+    import soak_cli
+    _, g = soak_cli.real_dna()
+    recs, species, opts = soak_cli.make_case(5010, g)
+    m = ax.Model(config_path(), "human", softmasking="0")
+    ex = dict(golden_inputs())
+    seqs = [recs[1][1][:50000].upper(), ex["HS04636"], ex["HS08198"], random_dna(60000, 3)]
+    emu_decode(m.tables_ptr, seqs, m.n_states)
+    E = ctypes.CDLL(EMU_LIB)
+    assert [E.emu_near_ties(i) for i in range(4)] == [1, 0, 0, 0]
+    # the same stretch through the dense kernels (two intergenic states): flagged in their chain runs, counted by their back-trace
+    m2 = ax.Model(config_path(), "human", softmasking="0", genemodel="atleastone", sample="0")
+    res = emu_decode(m2.tables_ptr, [seqs[0][8000:16000], ex["HS04636"]], m2.n_states)
+    assert [E.emu_near_ties(i) for i in range(2)] == [1, 0]
+    assert res[0][2] == [(b, e, s) for b, e, s, t in twin_decode(m2.tables_ptr, seqs[0][8000:16000], m2.n_states)[2]]

@@ -309,3 +309,24 @@ def test_gpu_exact_mode_decides_a_path():
     r0, = b.paths()
     rc, lnv0, path0, _, _ = twin_decode(m.tables_ptr, seq.upper(), m.n_states)
     assert r0.states == path0 and r0.ln_viterbi == lnv0 and [(bb, e, t) for bb, e, s, t in r0.states] != path
+
+
+@pytest.mark.parametrize("opts,lo,hi", [({}, 0, 50000), ({"genemodel": "atleastone", "sample": "0"}, 8000, 16000)])
+def test_gpu_near_ties_are_counted_through_the_c_abi(opts, lo, hi):
+    """augx_decoder_count_near_ties / augx_decoder_near_ties on the device, both kernel families: the stretch of soak case 5010 with two
+    overlapping copies of a single-exon gene has one near tie on its path (a chain-state decision), the reference's example none;
+    the paths are the oracle's with the counter on"""
+    import soak_cli
+    _, g = soak_cli.real_dna()
+    recs, _, _ = soak_cli.make_case(5010, g)
+    m = ax.Model(config_path(), "human", softmasking="0", **opts)
+    d = ax.Decoder(m, 0)
+    d.count_near_ties(True)
+    seqs = [recs[1][1][:50000].upper()[lo:hi], dict(golden_inputs())["HS04636"]]
+    res = d.decode(seqs[:1])
+    assert d.near_ties() == (1, 1)
+    res += d.decode(seqs[1:])
+    assert d.near_ties() == (1, 1)
+    for s, r in zip(seqs, res):
+        rc, lnv, path, _, _ = twin_decode(m.tables_ptr, s, m.n_states)
+        assert r.status == 0 and r.ln_viterbi == lnv and r.states == path
