@@ -998,10 +998,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     HIP_TRY(hipEventRecord(b->ev[1], st));
     auto runTrellis = [&]() -> int { // the trellis passes and the back-trace (run again when candidate terms were rebuilt, see below)
     if (d->dense) { // the dense kernels: one workgroup per piece, the matrix in HBM (dense.h)
-        if (d->densePipe) {
-            if (d->blk == 8) hipLaunchKernelGGL((kDenseV<8>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
-            else if (d->blk == 4) hipLaunchKernelGGL((kDenseV<4>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
-            else hipLaunchKernelGGL((kDenseV<2>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
+        if (d->densePipe && d->blk == 4 && !V.nearTie) { // (the experimental pass is built for the block size of the UTR species only)
+            hipLaunchKernelGGL((kDenseV<4>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
         } else if (V.nearTie) { // (near ties are counted: the build whose chain runs flag them)
             if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
             else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
