@@ -1462,9 +1462,9 @@ int augx_batch_forward_cells(augx_decoder *d, augx_batch *b, int piece, double *
 struct augx_sample_prep { SamplePiece P; };
 namespace {
 std::mutex g_fPoolMu;
-std::vector<std::pair<size_t, double *>> g_fPool; // host buffers of forward matrices, kept for the next piece: at most 24 and FPOOL_CAP_BYTES, released with the last decoder
+std::vector<std::pair<size_t, double *>> g_fPool; // host buffers of forward matrices, kept for the next piece: at most 36 and FPOOL_CAP_BYTES, released with the last decoder
 size_t g_fPoolBytes = 0;
-constexpr size_t FPOOL_CAP_BYTES = (size_t)8 << 30;
+constexpr size_t FPOOL_CAP_BYTES = (size_t)12 << 30;
 }
 void augx_release_host_pools() { // (augx_decoder_destroy, when the last decoder goes)
     std::lock_guard<std::mutex> lk(g_fPoolMu);
@@ -1515,7 +1515,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         const size_t cap = got.first;
         P.Fown = std::shared_ptr<double>(got.second, [cap](double *q) {
             std::lock_guard<std::mutex> lk(g_fPoolMu);
-            if (g_fPool.size() < 24 && g_fPoolBytes + cap * sizeof(double) <= FPOOL_CAP_BYTES) { g_fPool.push_back({cap, q}); g_fPoolBytes += cap * sizeof(double); } else delete[] q;
+            if (g_fPool.size() < 36 && g_fPoolBytes + cap * sizeof(double) <= FPOOL_CAP_BYTES) { g_fPool.push_back({cap, q}); g_fPoolBytes += cap * sizeof(double); } else delete[] q;
         });
     }
     P.F = P.Fown.get();

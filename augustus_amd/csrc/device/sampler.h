@@ -7,7 +7,11 @@
 #include <cmath>
 #include <cstdint>
 #include <deque>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <system_error>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "dp.h"
@@ -16,12 +20,30 @@
 // glibc's rand(): the TYPE_3 additive-feedback generator r[i] = r[i-3] + r[i-31] of random_r.c, seeded by the Lehmer
 // generator 16807 * x mod 2^31-1, the first 310 outputs discarded, the result shifted right by one
 struct augx_rand {
-    // The outputs are made CH at a time into a linear buffer -- three independent additions per turn (the shortest lag is 3), 0.3 ns
-    // a value -- and handed out by position: a draw that is spent without being looked at (a sampled path draws once per base of an
-    // intergenic run, the reference draws for a list of one option too) costs an increment.
-    static constexpr int LAG = 31, CH = 3 * 2048;
-    uint32_t x[LAG + CH]; // x[LAG + i]: the i-th output still to come; x[0 .. LAG): the 31 before them
-    int pos = CH;         // outputs of the buffer handed out (CH: none made yet)
+    // The outputs are made a buffer at a time and handed out by position: a draw that is spent without being looked at (a sampled
+    // path draws once per base of an intergenic run, the reference draws for a list of one option too) costs an increment.  Making
+    // them is three independent additions per turn (the shortest lag is 3), 0.3 ns a value on one core -- with 99 paths per piece
+    // that was half of the time of the one thread every sampled piece of a run waits for.  The recurrence is linear over Z / 2^32,
+    // so the 31 values before any position follow from the 31 before the buffer by one matrix product (jumpMatrix: A^L by
+    // squaring, 31 x 31): a large buffer is cut into parts that are filled side by side by helper threads of the generator's own
+    // (started when the first large buffer is due, waiting on a condition variable in between).  The buffer grows from 6 144
+    // values (a run that draws little pays little, and starts no thread) to 1.5 M (6 MB: it stays in the caches -- one of 50 MB was
+    // measured slower than the single-core loop, bound by memory).
+    static constexpr int LAG = 31;
+    static constexpr int64_t CH0 = 3 * 2048, CHMAX = 3 * 524288, PART = 3 * 32768;
+    std::unique_ptr<uint32_t[]> buf; // x[LAG + i]: the i-th output of the buffer; x[0 .. LAG): the 31 before them
+    uint32_t *x = nullptr;           // = buf.get()
+    int64_t ch = 0, pos = 0;         // outputs in the buffer / handed out
+    std::vector<uint32_t> jump;      // A^PART, row-major 31 x 31 (made when the first buffer is cut into parts)
+    std::vector<uint32_t> seeds;     // [parts][31]: the values before every part
+    // helper threads: `gen` counts the buffers handed to them, `left` the helpers still at work on the current one
+    std::vector<std::thread> helpers;
+    std::mutex mu;
+    std::condition_variable cvGo, cvDone;
+    uint64_t gen = 0;
+    int left = 0, nth = 1;
+    int64_t parts = 0;
+    bool quit = false;
     explicit augx_rand(unsigned seed) {
         int32_t st[34];
         st[0] = seed == 0 ? 1 : (int32_t)seed;
@@ -33,32 +55,144 @@ struct augx_rand {
         }
         for (int i = 31; i < 34; i++) st[i] = st[i - 31];
         // r[0 .. 34) = st; the next value is r[34] = r[3] + r[31]: the 31 values before it are r[3 .. 34)
-        for (int i = 0; i < LAG; i++) x[CH + i] = (uint32_t)st[3 + i];
-        pos = CH;
+        buf.reset(new uint32_t[LAG]);
+        x = buf.get();
+        for (int i = 0; i < LAG; i++) x[i] = (uint32_t)st[3 + i];
+        ch = 0; pos = 0;
         skip(310); // (random_r.c discards the first 310 outputs)
     }
-    void refill() { // the next CH outputs from the last 31
-        for (int q = 0; q < LAG; q++) x[q] = x[CH + q];
-        static_assert(CH % 3 == 0, "three values per turn");
-        for (int i = LAG; i < LAG + CH; i += 3) { // (x[i + 2] reads x[i - 1]: written a turn ago)
-            const uint32_t a = x[i - 31] + x[i - 3], b = x[i - 30] + x[i - 2], c = x[i - 29] + x[i - 1];
-            x[i] = a; x[i + 1] = b; x[i + 2] = c;
+    ~augx_rand() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
         }
+        cvGo.notify_all();
+        for (auto &t2 : helpers) t2.join();
+    }
+    augx_rand(const augx_rand &) = delete;
+    augx_rand &operator=(const augx_rand &) = delete;
+    // n outputs after the 31 values at p[-31 .. -1] (n a multiple of 3)
+    static void fill(uint32_t *p, int64_t n) {
+        for (int64_t i = 0; i < n; i += 3) { // (p[i + 2] reads p[i - 1]: written a turn ago)
+            const uint32_t a = p[i - 31] + p[i - 3], b = p[i - 30] + p[i - 2], c = p[i - 29] + p[i - 1];
+            p[i] = a; p[i + 1] = b; p[i + 2] = c;
+        }
+    }
+    // A^n for the step (s[0..30]) -> (s[1..30], s[0] + s[28]) on the 31 values before a position
+    static std::vector<uint32_t> jumpMatrix(int64_t n) {
+        auto mul = [](const std::vector<uint32_t> &P, const std::vector<uint32_t> &Q) {
+            std::vector<uint32_t> R((size_t)LAG * LAG, 0u);
+            for (int i = 0; i < LAG; i++)
+                for (int k = 0; k < LAG; k++) {
+                    const uint32_t pv = P[(size_t)i * LAG + k];
+                    if (!pv) continue;
+                    for (int j = 0; j < LAG; j++) R[(size_t)i * LAG + j] += pv * Q[(size_t)k * LAG + j];
+                }
+            return R;
+        };
+        std::vector<uint32_t> A((size_t)LAG * LAG, 0u), R((size_t)LAG * LAG, 0u);
+        for (int k = 0; k + 1 < LAG; k++) A[(size_t)k * LAG + k + 1] = 1u;
+        A[(size_t)(LAG - 1) * LAG + 0] = 1u; A[(size_t)(LAG - 1) * LAG + 28] = 1u;
+        for (int k = 0; k < LAG; k++) R[(size_t)k * LAG + k] = 1u;
+        for (; n > 0; n >>= 1) {
+            if (n & 1) R = mul(R, A);
+            A = mul(A, A);
+        }
+        return R;
+    }
+    // the parts w, w + nth, ... of the buffer: each starts from its own 31 values (the part before is being written meanwhile)
+    void fillParts(int w) {
+        for (int64_t k = w; k < parts; k += nth) {
+            uint32_t *p = x + LAG + k * PART;
+            uint32_t h2[LAG + 33]; // the first 33 outputs of the part from its seed values alone (a multiple of 3 that covers the lag), the rest in place
+            for (int q = 0; q < LAG; q++) h2[q] = seeds[(size_t)k * LAG + q];
+            fill(h2 + LAG, 33);
+            for (int i = 0; i < 33; i++) p[i] = h2[LAG + i];
+            fill(p + 33, PART - 33);
+        }
+    }
+    void helperLoop(int w) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cvGo.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+            }
+            fillParts(w);
+            std::lock_guard<std::mutex> lk(mu);
+            if (--left == 0) cvDone.notify_one();
+        }
+    }
+#ifdef AUGX_EMU
+    double refillSeconds = 0; // (developer aid, emulator builds: AUGX_EMU_STATS)
+    void refill() {
+        const auto t0 = std::chrono::steady_clock::now();
+        refillBody();
+        refillSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void refillBody() {
+#else
+    void refill() { // the next buffer of outputs from the last 31
+#endif
+        uint32_t last[LAG];
+        for (int q = 0; q < LAG; q++) last[q] = x[ch + q];
+        const int64_t next = ch == 0 ? CH0 : (ch * 4 < CHMAX ? ch * 4 : CHMAX);
+        if (next != ch) { buf.reset(new uint32_t[(size_t)(LAG + next)]); x = buf.get(); ch = next; } // (not zeroed: every value is written below)
+        for (int q = 0; q < LAG; q++) x[q] = last[q];
         pos = 0;
+        if (ch < 2 * PART) { fill(x + LAG, ch); return; }
+        // in parts: the 31 values before part k + 1 are A^PART times those before part k
+        if (jump.empty()) {
+            jump = jumpMatrix(PART);
+            const unsigned hw = std::thread::hardware_concurrency();
+            nth = hw >= 32 ? 8 : hw >= 8 ? 4 : hw >= 4 ? 2 : 1;
+            for (int w = 1; w < nth; w++) {
+                try { helpers.emplace_back(&augx_rand::helperLoop, this, w); }
+                catch (const std::system_error &) { break; } // (no more threads to be had: the parts are dealt to those there are)
+            }
+            nth = (int)helpers.size() + 1;
+        }
+        parts = ch / PART; // (every buffer size from 2 PART on is a multiple of PART)
+        seeds.resize((size_t)parts * LAG);
+        for (int q = 0; q < LAG; q++) seeds[(size_t)q] = last[q];
+        for (int64_t k = 1; k < parts; k++)
+            for (int i = 0; i < LAG; i++) {
+                uint32_t acc = 0;
+                for (int j = 0; j < LAG; j++) acc += jump[(size_t)i * LAG + j] * seeds[(size_t)(k - 1) * LAG + j];
+                seeds[(size_t)k * LAG + i] = acc;
+            }
+        if (nth > 1) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                gen++;
+                left = nth - 1;
+            }
+            cvGo.notify_all();
+        }
+        fillParts(0);
+        if (nth > 1) {
+            std::unique_lock<std::mutex> lk(mu);
+            cvDone.wait(lk, [&] { return left == 0; });
+        }
     }
     void skip(int64_t n) {
         while (n > 0) {
-            if (pos == CH) refill();
-            const int64_t m = n < (int64_t)(CH - pos) ? n : (int64_t)(CH - pos);
-            pos += (int)m;
+            if (pos == ch) refill();
+            const int64_t m = n < ch - pos ? n : ch - pos;
+            pos += m;
             n -= m;
         }
     }
     uint32_t step() {
-        if (pos == CH) refill();
+        if (pos == ch) refill();
         return x[LAG + pos++];
     }
     int next() { return (int)(step() >> 1); }
+    void prefetch(int64_t ahead) const { // the output `ahead` positions after the next one, if it lies in this buffer
+        if (pos + ahead < ch) __builtin_prefetch(x + LAG + pos + ahead);
+    }
 };
 
 namespace augx {
@@ -81,11 +215,11 @@ struct SamplePiece {
     bool anyNuc = true;
     // filled by prepareStops (may run on another thread, ahead of the sampling): see samplePaths
     std::vector<std::vector<int32_t>> stops;
-    // per chain state and stop: the options of the stop, and -- flat, for the loop that runs down a chain state -- their total, the
-    // probability of the most probable one and whether that one is the state itself at the base before
+    // per chain state and stop: the options of the stop, and -- flat, for the loop that runs down a chain state -- their total and
+    // the draws that take the state itself at the base before: rand() < stopThr (0: the draw is looked at in full)
     std::vector<std::vector<struct OptList>> stopList;
-    std::vector<std::vector<double>> stopCum, stopP0;
-    std::vector<std::vector<uint8_t>> stopSelf;
+    std::vector<std::vector<double>> stopCum;
+    std::vector<std::vector<uint32_t>> stopThr;
     bool prepared = false;
     // models of the dense kernels (dense.h): candidate records name their predecessor by state; the candidates of the UTR exon
     // states are evaluated from a host view of the batch (hB: the emulator's own arrays, or the mirror of one piece below)
@@ -222,17 +356,30 @@ inline void sortOptions(OptList &L) {
 // Most steps of a path are a single-base state (intergenic region, long intron) following itself with no alternative: the
 // draw is spent (the reference draws for a list of one, too) but decides nothing.  stops[s] = the bases, in increasing order,
 // where chain state s has anything but that one option; between two of them a path runs through without looking.
+// the draws r = rand() that take the first option of a stop -- r / RAND_MAX * total * 0.99999 < p0, the expression of
+// OptionsList::sample as drawOption evaluates it, monotone in r -- are 0 .. stayThreshold - 1
+inline uint32_t stayThreshold(double cum, double p0) {
+    uint32_t lo = 0, hi = 2147483648u;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((double)(int)mid / 2147483647.0 * cum * 0.99999 < p0) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 inline void prepareStops(SamplePiece &P) {
     const augx_tables &t = *P.t;
     const int n = P.n, S = P.S;
     P.stops.assign((size_t)S, {});
-    P.stopList.assign((size_t)S, {}); P.stopCum.assign((size_t)S, {}); P.stopP0.assign((size_t)S, {}); P.stopSelf.assign((size_t)S, {});
-    for (int s = 0; s < S && P.anyNuc; s++) {
-        const int kd = t.state_kind[s];
-        if (!isChainKind(kd)) continue;
-        std::vector<int32_t> &v = P.stops[s];
-        const int sg = kd == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
-        for (int j = 1; j < n; j++) {
+    P.stopList.assign((size_t)S, {}); P.stopCum.assign((size_t)S, {});
+    P.stopThr.assign((size_t)S, {});
+    std::vector<int> chains;
+    for (int s = 0; s < S && P.anyNuc; s++)
+        if (isChainKind(t.state_kind[s])) chains.push_back(s);
+    for (int j = 1; j < n; j++) // (one pass over the rows of F for all chain states: the matrix is 376 B a base, the pass is bound by reading it)
+        for (int s : chains) {
+            const int sg = t.state_kind[s] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
             int cnt = 0;
             bool self = false;
             if (P.sig[(size_t)j * NSIG + sg] > -INFINITY)
@@ -240,13 +387,17 @@ inline void prepareStops(SamplePiece &P) {
                     const int a = t.anc[s][ai];
                     if (P.F[(size_t)(j - 1) * S + a] > -INFINITY && P.lnT(j, a, s) > -INFINITY) { cnt++; self = self || a == s; }
                 }
-            if (!(cnt == 1 && self)) v.push_back(j);
+            if (!(cnt == 1 && self)) P.stops[s].push_back(j);
         }
+    for (int s : chains) {
+        std::vector<int32_t> &v = P.stops[s];
         // the options of every stop (the same for every sampled path; made here, ahead of the sampling and on another thread).
         // A stop whose most probable option is the state itself with everything else below 1e-5 of the total decides nothing
         // either: the draw is z = rand() / RAND_MAX * total * 0.99999 <= total * 0.99999, and the state itself is taken whenever
         // z < p(itself) -- with total * 0.99999 < p(itself) that is every draw (same expression, same rounding: the product is
         // monotone in rand()).  Such stops are dropped: the path runs through them as through any other base of the run.
+        // At the others the same comparison is turned into a threshold on rand() itself (stayThreshold): the loop that runs down
+        // a chain state compares two integers per stop.
         std::vector<int32_t> kept;
         for (size_t c = 0; c < v.size(); c++) {
             OptList L;
@@ -256,8 +407,7 @@ inline void prepareStops(SamplePiece &P) {
             if (selfFirst && L.cum > 0 && 1.0 * L.cum * 0.99999 < p0) continue;
             kept.push_back(v[c]);
             P.stopCum[s].push_back(L.cum);
-            P.stopP0[s].push_back(p0);
-            P.stopSelf[s].push_back(selfFirst);
+            P.stopThr[s].push_back(selfFirst && L.cum > 0 ? stayThreshold(L.cum, p0) : 0u);
             P.stopList[s].push_back(std::move(L));
         }
         v.swap(kept);
@@ -313,17 +463,25 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                     // down the state, stop after stop: between two stops a draw per base decides nothing; at a stop the draw is
                     // compared with the most probable option first -- as a rule the state itself, and the run goes on
                     const int top = base;
-                    const double *cumA = P.stopCum[state].data(), *p0A = P.stopP0[state].data();
-                    const uint8_t *selfA = P.stopSelf[state].data();
+                    const double *cumA = P.stopCum[state].data();
+                    const uint32_t *thrA = P.stopThr[state].data();
                     const Opt *x = nullptr;
                     for (;;) {
                         const int stop = c < 0 ? 0 : v[c];
                         if (stop < base) { R.skip(base - stop); base = stop; }
                         if (base == 0) break;
+                        // (the draws of the stops to come lie a cache line or more apart in the generator's buffer, which helper
+                        //  threads have just written: the one eight stops down is asked for now)
+                        if (c >= 8) R.prefetch((int64_t)(base - v[c - 8]));
+                        int r = -1;
+                        if (thrA[c]) { // (the stop has options and the state itself first among them)
+                            r = R.next();
+                            if ((uint32_t)r < thrA[c]) { base--; c--; if (base == 0) break; continue; }
+                        }
                         const OptList &L = P.stopList[state][(size_t)c];
                         if (L.o.empty() || !(L.cum > 0)) { bad = true; break; }
-                        const double z = (double)R.next() / 2147483647.0 * cumA[c] * 0.99999; // (reference OptionsList::sample, as drawOption)
-                        if (selfA[c] && z < p0A[c]) { base--; c--; if (base == 0) break; continue; }
+                        if (r < 0) r = R.next();
+                        const double z = (double)r / 2147483647.0 * cumA[c] * 0.99999; // (reference OptionsList::sample, as drawOption)
                         double cumsum = 0;
                         x = &L.o[0];
                         for (size_t i = 0; i < L.o.size(); i++) {

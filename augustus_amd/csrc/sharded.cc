@@ -101,6 +101,23 @@ int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *
 // Decode + sample.  The draws come from ONE stream over the run, piece after piece in input order (the reference never seeds
 // rand(), src/vitmatrix.cc:312), so the pieces are batched in input order, batch k on device k mod n_dec: the devices decode
 // and run the forward algorithm of their batches concurrently, the host sampling of batch k waits for batch k-1's.
+static int aheadPieces(int64_t bytesPerPiece) {
+    int64_t avail = (int64_t)16 << 30; // (no /proc/meminfo: assume 16 GB to spare)
+    if (FILE *f = fopen("/proc/meminfo", "r")) {
+        char line[256];
+        while (fgets(line, sizeof line, f)) {
+            long long kb = 0;
+            if (sscanf(line, "MemAvailable: %lld kB", &kb) == 1) { avail = (int64_t)kb << 10; break; }
+        }
+        fclose(f);
+    }
+    int64_t a = avail / 4 / (bytesPerPiece > 0 ? bytesPerPiece : 1);
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw && a > (int64_t)hw / 2) a = hw / 2;
+    if (const char *e = getenv("AUGX_SAMPLE_AHEAD")) a = atol(e); // (developer aid)
+    return (int)std::max<int64_t>(2, std::min<int64_t>(32, a));
+}
+
 int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, int n_samples, augx_rand *r,
                         augx_path *out, augx_path *samples) {
     if (!decs || n_dec < 1 || !pieces || n < 0 || n_samples < 0 || !r || !out || (n_samples && !samples)) {
@@ -146,7 +163,12 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             if (rc) errs[d] = augx_last_error();
             // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
             // (it does not depend on the draws), also while earlier batches are still being sampled
-            const int AHEAD = 12;
+            // How many: a prepared piece holds its forward matrix and candidate records on the host (0.75 KB per base), and the draws
+            // of a piece take tens of milliseconds where its preparation takes most of a second -- up to 32 pieces, a quarter of
+            // the memory the host has to spare and half of its cores
+            int64_t longest = 1;
+            for (int p = 0; p < cnt; p++) longest = std::max<int64_t>(longest, pieces[first + p].len);
+            const int AHEAD = aheadPieces(longest * 768);
             struct Prep { int rc; augx_sample_prep *h; std::string err; }; // (augx_last_error is thread-local: the text travels with the result)
             std::vector<std::future<Prep>> prep((size_t)cnt);
             std::vector<std::future<void>> frees;

@@ -289,8 +289,8 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
             prepareStops(P);
             const auto ts1 = std::chrono::steady_clock::now();
             samplePaths(P, g_nsamples, *g_rand, g_samples[p], sst);
-            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
-                                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count());
+            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s (the generator's buffers so far: %.3f s)\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
+                                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count(), g_rand->refillSeconds);
         }
     }
     delete dl;
@@ -327,6 +327,21 @@ void emu_set_sampling(int n, unsigned seed) {
     g_rand = n > 0 ? new augx_rand(seed) : nullptr;
 }
 int emu_state_type(const augx_tables *t, int s) { return s >= 0 && s < t->S ? t->state_type[s] : -1; }
+// augx_rand against glibc's rand() after srand(seed): n draws, every `stride`-th one looked at, the others spent with skip();
+// returns the index of the first draw that differs, -1: none
+long long emu_rand_check(unsigned seed, long long n, int stride) {
+    augx_rand R(seed);
+    srand(seed);
+    for (long long i = 0; i < n;) {
+        const int gap = stride > 1 ? (int)((i * 7 + 3) % stride) : 0;
+        for (int q = 0; q < gap; q++) (void)rand();
+        R.skip(gap);
+        i += gap;
+        if (R.next() != rand()) return i;
+        i++;
+    }
+    return -1;
+}
 int emu_sample_get(int p, int it, int32_t *out, int cap) {
     if (p < 0 || p >= (int)g_samples.size() || it < 0 || it >= (int)g_samples[p].size()) return -1;
     const std::vector<augx_state> &v = g_samples[p][it];
@@ -651,8 +666,8 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
             prepareStops(P);
             const auto ts1 = std::chrono::steady_clock::now();
             samplePaths(P, g_nsamples, *g_rand, g_samples[p], sst);
-            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
-                                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count());
+            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s (the generator's buffers so far: %.3f s)\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
+                                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count(), g_rand->refillSeconds);
         }
         free(B.fwd);
     }

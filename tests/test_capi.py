@@ -74,3 +74,16 @@ def test_rand_is_glibc_rand_also_after_skips():
                 assert L.augx_rand_next(r) == libc.rand(), n
     finally:
         L.augx_rand_destroy(r)
+
+
+def test_rand_buffers_filled_in_parts_are_glibc_rand():
+    """From 393 216 values on a buffer of the generator is cut into parts, each started from the 31 values before it -- the
+    matrix power A^PART times those before the buffer -- and filled by helper threads (sampler.h: augx_rand::refill): 60 million
+    draws, one in about twenty looked at, against glibc (the emulator library carries the comparison loop: 60 million calls
+    through ctypes would take minutes), and a second generator in the same process"""
+    import ctypes
+    E = ctypes.CDLL(EMU_LIB)
+    E.emu_rand_check.restype = ctypes.c_longlong
+    E.emu_rand_check.argtypes = [ctypes.c_uint, ctypes.c_longlong, ctypes.c_int]
+    assert E.emu_rand_check(1, 60_000_000, 40) == -1
+    assert E.emu_rand_check(20260927, 8_000_000, 1) == -1
