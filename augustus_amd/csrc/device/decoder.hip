@@ -9,6 +9,7 @@
 //   backtrace    : one wavefront per piece
 // There is no CPU fallback anywhere in this file: without a HIP device augx_decoder_create fails.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <algorithm>
 #include <map>
 #include <unordered_map>
@@ -18,6 +19,7 @@
 #include <future>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <system_error>
 #include <chrono>
@@ -1229,6 +1231,29 @@ static int augx_batch_forward_launch(augx_decoder *d, augx_batch *b) {
 
 } // extern "C"
 
+namespace {
+// The copies of a piece (0.7 KB per base, into pageable memory: 11-13 GB/s however many run) are let through three pieces at a
+// time, the piece the sampling thread will ask for first before the others: the pieces of a batch are prepared side by side on
+// many threads, and with all of them copying at once the first piece arrived when all had (measured, 32 x 1 Mbp: 1.7 s
+// against 0.5 s).
+std::mutex g_copyMu;
+std::condition_variable g_copyCv;
+int g_copyFree = getenv("AUGX_COPY_SLOTS") ? atoi(getenv("AUGX_COPY_SLOTS")) : 3; // (the variable: developer aid)
+std::multiset<int> g_copyWaiting;
+struct CopySlot {
+    explicit CopySlot(int piece) {
+        std::unique_lock<std::mutex> lk(g_copyMu);
+        auto me = g_copyWaiting.insert(piece);
+        g_copyCv.wait(lk, [&] { return g_copyFree > 0 && *g_copyWaiting.begin() >= piece; });
+        g_copyWaiting.erase(me);
+        g_copyFree--;
+        lk.unlock();
+        g_copyCv.notify_all(); // (the next in line may have been waiting for this one to go first)
+    }
+    ~CopySlot() { { std::lock_guard<std::mutex> lk(g_copyMu); g_copyFree++; } g_copyCv.notify_all(); }
+};
+}
+
 #include "snipmemo.h"
 
 namespace {
@@ -1260,10 +1285,11 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
                                   // dozens of small copies: one wait each, on the one default stream of the process, was most of the replay's time)
     };
     constexpr int GROUP = 48; // pieces replayed side by side
-    if (d->copyStreams.empty()) { // (made once per decoder: creating a stream takes milliseconds)
-        d->copyStreams.assign(GROUP, nullptr);
+    {   // (made once per decoder: creating a stream takes milliseconds; augx_batch_sample_prepare shares the table)
+        std::lock_guard<std::mutex> lk(g_copyMu);
+        if (d->copyStreams.empty()) d->copyStreams.assign(GROUP, nullptr);
         for (int i = 0; i < GROUP; i++)
-            if (hipStreamCreateWithFlags(&d->copyStreams[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); d->copyStreams[i] = nullptr; }
+            if (!d->copyStreams[i] && hipStreamCreateWithFlags(&d->copyStreams[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); d->copyStreams[i] = nullptr; }
     }
     hipStream_t *copySt = d->copyStreams.data();
     auto fetch = [&](int p, PieceData &D) -> int {
@@ -1466,11 +1492,27 @@ std::vector<std::pair<size_t, double *>> g_fPool; // host buffers of forward mat
 size_t g_fPoolBytes = 0;
 constexpr size_t FPOOL_CAP_BYTES = (size_t)12 << 30;
 }
+// The other host buffers of a prepared piece (candidate records 230 B, signal terms 64 B per base, ...) go round with the
+// augx_sample_prep object itself: its vectors keep their memory for the next piece (at most 36 objects wait here).
+namespace {
+std::vector<augx_sample_prep *> g_prepPool;
+}
+// a forward matrix on the host: 2 MB pages where the kernel grants them (a piece's matrix is hundreds of MB; in 4 KB pages its
+// first touch and its release were each a tenth of a second of page-table work per GB)
+static double *hugeAlloc(size_t n) {
+    void *q = nullptr;
+    const size_t bytes = ((n * sizeof(double) + ((size_t)2 << 20) - 1) >> 21) << 21;
+    if (posix_memalign(&q, (size_t)2 << 20, bytes) != 0 || !q) throw std::bad_alloc();
+    (void)madvise(q, bytes, MADV_HUGEPAGE);
+    return (double *)q;
+}
 void augx_release_host_pools() { // (augx_decoder_destroy, when the last decoder goes)
     std::lock_guard<std::mutex> lk(g_fPoolMu);
-    for (auto &e : g_fPool) delete[] e.second;
+    for (auto &e : g_fPool) free(e.second);
     g_fPool.clear();
     g_fPoolBytes = 0;
+    for (augx_sample_prep *h : g_prepPool) delete h;
+    g_prepPool.clear();
 }
 
 extern "C" {
@@ -1489,18 +1531,43 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     }
     *out = nullptr;
     HIP_TRY(hipSetDevice(d->device));
-    if (b->evFwd) HIP_TRY(hipEventSynchronize(b->evFwd)); else HIP_TRY(hipStreamSynchronize(d->stream));
+    // Everything but the forward matrix is there before the forward kernel runs (the candidate records are final when
+    // augx_batch_forward returns: it waits for the replay of the snippet cache): it is copied while the kernel runs, on a stream
+    // that does not wait for the decoder's, and the matrix when the kernel has finished.
+    hipStream_t cst = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_copyMu);
+        if (d->copyStreams.empty()) d->copyStreams.assign(48, nullptr);
+        hipStream_t &slotSt = d->copyStreams[(size_t)piece % d->copyStreams.size()];
+        if (!slotSt && hipStreamCreateWithFlags(&slotSt, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); slotSt = nullptr; }
+        cst = slotSt;
+    }
+    if (!cst) { if (b->evFwd) HIP_TRY(hipEventSynchronize(b->evFwd)); else HIP_TRY(hipStreamSynchronize(d->stream)); } // (no stream to be had: after the kernel, on the default stream)
+    auto cp = [cst](void *dst, const void *src, size_t bytes) { return cst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cst) : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
+    auto flush = [cst]() { return cst ? hipStreamSynchronize(cst) : hipSuccess; };
     const BatchView &V = b->V;
     const augx_tables &t = d->model->m.t;
     try {
-    std::unique_ptr<augx_sample_prep> H(new augx_sample_prep());
+    std::unique_ptr<augx_sample_prep> H;
+    {
+        std::lock_guard<std::mutex> lk(g_fPoolMu);
+        if (!g_prepPool.empty()) { H.reset(g_prepPool.back()); g_prepPool.pop_back(); }
+    }
+    if (!H) H.reset(new augx_sample_prep());
     SamplePiece &P = H->P;
+    {   // (an object that comes round: everything a piece sets only under a condition goes back to its default)
+        P.plane.clear(); P.planeCls.clear(); P.uh.reset(); P.dense = false; P.hT = nullptr; P.hB = nullptr; P.hp = 0;
+        P.igS = -1; P.termKind = 0; P.anyNuc = true; P.prepared = false; P.item0 = 0;
+        P.buildSeconds = 0; P.nBuilt = P.nStops = P.nVar = 0; P.tkChain = P.tkVar = P.tkTail = 0;
+    }
     P.t = &t; P.S = t.S; P.n = b->L.len[piece]; P.blk = V.blk;
     const int n = P.n, S = P.S;
     const int64_t o = b->L.off[piece];
     int32_t cls = 0, nPl = 1;
-    HIP_TRY(hipMemcpy(&cls, V.cls + piece, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&nPl, V.nPlanes + piece, 4, hipMemcpyDeviceToHost));
+    std::unique_ptr<CopySlot> slot(new CopySlot(piece));
+    HIP_TRY(cp(&cls, V.cls + piece, 4));
+    HIP_TRY(cp(&nPl, V.nPlanes + piece, 4));
+    HIP_TRY(flush());
     P.cls0 = cls; P.nPlanes = nPl;
     {   // the host copy of the piece's forward matrix (hundreds of MB): buffers go round between the pieces of a run instead of
         // being mapped, faulted in and unmapped once per piece
@@ -1511,28 +1578,28 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
             for (size_t i = 0; i < g_fPool.size(); i++)
                 if (g_fPool[i].first >= need && g_fPool[i].first <= need + need / 2) { got = g_fPool[i]; g_fPoolBytes -= got.first * sizeof(double); g_fPool.erase(g_fPool.begin() + (long)i); break; }
         }
-        if (!got.second) got = {need, new double[need]};
+        if (!got.second) got = {need, hugeAlloc(need)};
         const size_t cap = got.first;
         P.Fown = std::shared_ptr<double>(got.second, [cap](double *q) {
             std::lock_guard<std::mutex> lk(g_fPoolMu);
-            if (g_fPool.size() < 36 && g_fPoolBytes + cap * sizeof(double) <= FPOOL_CAP_BYTES) { g_fPool.push_back({cap, q}); g_fPoolBytes += cap * sizeof(double); } else delete[] q;
+            if (g_fPool.size() < 36 && g_fPoolBytes + cap * sizeof(double) <= FPOOL_CAP_BYTES) { g_fPool.push_back({cap, q}); g_fPoolBytes += cap * sizeof(double); } else free(q);
         });
     }
     P.F = P.Fown.get();
-    HIP_TRY(hipMemcpy(P.Fown.get(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)n * S, hipMemcpyDeviceToHost));
     P.sig.resize((size_t)n * NSIG);
-    HIP_TRY(hipMemcpy(P.sig.data(), V.sig + (o + 1) * NSIG, sizeof(double) * P.sig.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(cp(P.sig.data(), V.sig + (o + 1) * NSIG, sizeof(double) * P.sig.size()));
     if (nPl > 1) {
         P.plane.resize((size_t)n);
-        HIP_TRY(hipMemcpy(P.plane.data(), V.gcPlane + o + 1, (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(P.plane.data(), V.gcPlane + o + 1, (size_t)n));
         P.planeCls.resize(MAXPL);
-        HIP_TRY(hipMemcpy(P.planeCls.data(), V.planeCls + (int64_t)piece * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(P.planeCls.data(), V.planeCls + (int64_t)piece * MAXPL, sizeof(int32_t) * MAXPL));
     }
     const int nBlocks = (n + V.blk - 1) / V.blk;
     const int64_t gb0 = o / V.blk;
     P.blkOff.resize((size_t)nBlocks * 2); P.blkCnt.resize((size_t)nBlocks * 2);
-    HIP_TRY(hipMemcpy(P.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * P.blkOff.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(P.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * P.blkCnt.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(cp(P.blkOff.data(), V.blkOff + gb0 * 2, sizeof(uint64_t) * P.blkOff.size()));
+    HIP_TRY(cp(P.blkCnt.data(), V.blkCnt + gb0 * 2, sizeof(uint32_t) * P.blkCnt.size()));
+    HIP_TRY(flush());
     // (K2a hands out the candidate ranges of the blocks through an atomic counter: a piece's candidates lie wherever its work
     //  groups were served, so the span between its lowest and highest range is fetched)
     uint64_t lo = ~0ull, hi = 0;
@@ -1549,7 +1616,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     if (hi - lo <= 4 * own + 65536) { // the piece's ranges lie close together: one copy of the span
         P.item0 = lo;
         P.items.resize((size_t)(hi - lo) + 1);
-        if (hi > lo) HIP_TRY(hipMemcpy(P.items.data(), V.items + lo, sizeof(Item) * (size_t)(hi - lo), hipMemcpyDeviceToHost));
+        if (hi > lo) HIP_TRY(cp(P.items.data(), V.items + lo, sizeof(Item) * (size_t)(hi - lo)));
     } else { // scattered over the batch's buffer (many pieces decoded side by side): run by run of contiguous blocks, packed
         P.item0 = 0;
         P.items.resize((size_t)own + 1);
@@ -1559,7 +1626,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
             uint64_t len = P.blkCnt[(size_t)q * 2 + 1];
             int q2 = q + 1;
             while (q2 < nBlocks && (P.blkCnt[(size_t)q2 * 2 + 1] == 0 || P.blkOff[(size_t)q2 * 2 + 1] == a0 + len)) { len += P.blkCnt[(size_t)q2 * 2 + 1]; q2++; }
-            if (len) HIP_TRY(hipMemcpy(P.items.data() + w, V.items + a0, sizeof(Item) * (size_t)len, hipMemcpyDeviceToHost));
+            if (len) HIP_TRY(cp(P.items.data() + w, V.items + a0, sizeof(Item) * (size_t)len));
             uint64_t at = w;
             for (int k = q; k < q2; k++) { P.blkOff[(size_t)k * 2 + 1] = at; at += P.blkCnt[(size_t)k * 2 + 1]; }
             w += len;
@@ -1579,25 +1646,26 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         U.chunkPiece.assign((size_t)nch, 0);
         U.cls = {cls}; U.nPlanes = {nPl};
         U.planeCls.assign(MAXPL, 0);
-        HIP_TRY(hipMemcpy(U.planeCls.data(), V.planeCls + (int64_t)piece * MAXPL, sizeof(int32_t) * MAXPL, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(U.planeCls.data(), V.planeCls + (int64_t)piece * MAXPL, sizeof(int32_t) * MAXPL));
         U.code.resize((size_t)slots); U.gcPlane.resize((size_t)slots);
-        HIP_TRY(hipMemcpy(U.code.data(), V.code + o, (size_t)slots, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(U.gcPlane.data(), V.gcPlane + o, (size_t)slots, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(U.code.data(), V.code + o, (size_t)slots));
+        HIP_TRY(cp(U.gcPlane.data(), V.gcPlane + o, (size_t)slots));
         U.cnt.resize((size_t)slots * NCNT); U.ucnt.resize((size_t)slots * NUCNT); U.ufx.resize((size_t)slots * NUFX);
-        HIP_TRY(hipMemcpy(U.cnt.data(), V.cnt + ch0 * NCNT * CHUNK, sizeof(uint32_t) * U.cnt.size(), hipMemcpyDeviceToHost)); // (chunk-major: a piece's chunks are contiguous)
-        HIP_TRY(hipMemcpy(U.ucnt.data(), V.ucnt + ch0 * NUCNT * CHUNK, sizeof(uint32_t) * U.ucnt.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(U.ufx.data(), V.ufx + ch0 * NUFX * CHUNK, sizeof(uint64_t) * U.ufx.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(cp(U.cnt.data(), V.cnt + ch0 * NCNT * CHUNK, sizeof(uint32_t) * U.cnt.size())); // (chunk-major: a piece's chunks are contiguous)
+        HIP_TRY(cp(U.ucnt.data(), V.ucnt + ch0 * NUCNT * CHUNK, sizeof(uint32_t) * U.ucnt.size()));
+        HIP_TRY(cp(U.ufx.data(), V.ufx + ch0 * NUFX * CHUNK, sizeof(uint64_t) * U.ufx.size()));
         U.usig.resize((size_t)slots * NUSIG); U.sigAll.resize((size_t)slots * NSIG);
-        HIP_TRY(hipMemcpy(U.usig.data(), V.usig + o * NUSIG, sizeof(double) * U.usig.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(U.sigAll.data(), V.sig + o * NSIG, sizeof(double) * U.sigAll.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(cp(U.usig.data(), V.usig + o * NUSIG, sizeof(double) * U.usig.size()));
+        HIP_TRY(cp(U.sigAll.data(), V.sig + o * NSIG, sizeof(double) * U.sigAll.size()));
         std::vector<int64_t> lo2(2);
-        HIP_TRY(hipMemcpy(lo2.data(), b->dListOffs + piece, sizeof(int64_t) * 2, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(lo2.data(), b->dListOffs + piece, sizeof(int64_t) * 2));
+        HIP_TRY(flush());
         const int64_t nEnt = lo2[1] - lo2[0];
         U.listOffs = {0, nEnt};
         const USite *src[6] = {V.tfSite, V.laSite, V.fsSite, V.lrSite, V.tmSite, V.rtSite};
         for (int k = 0; k < 6; k++) {
             U.sites[k].resize((size_t)(nEnt > 0 ? nEnt : 1));
-            if (nEnt > 0) HIP_TRY(hipMemcpy(U.sites[k].data(), src[k] + lo2[0], sizeof(USite) * (size_t)nEnt, hipMemcpyDeviceToHost));
+            if (nEnt > 0) HIP_TRY(cp(U.sites[k].data(), src[k] + lo2[0], sizeof(USite) * (size_t)nEnt));
         }
         BatchView &HB = U.B;
         HB.nPieces = 1; HB.N = slots; HB.nChunks = (int)nch;
@@ -1613,25 +1681,46 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     }
     {
         std::vector<uint8_t> code((size_t)n);
-        HIP_TRY(hipMemcpy(code.data(), V.code + o + 1, (size_t)n, hipMemcpyDeviceToHost));
+        HIP_TRY(cp(code.data(), V.code + o + 1, (size_t)n));
+        HIP_TRY(flush());
         P.anyNuc = false;
         for (int q = 0; q < n && !P.anyNuc; q++) P.anyNuc = code[q] < 4;
     }
+    slot.reset(); // (the wait for the kernel holds no slot)
+    if (b->evFwd) HIP_TRY(hipEventSynchronize(b->evFwd)); else HIP_TRY(hipStreamSynchronize(d->stream));
+    slot.reset(new CopySlot(piece));
+    HIP_TRY(cp(P.Fown.get(), V.fwd + (o + 1) * S, sizeof(double) * (size_t)n * S));
+    HIP_TRY(flush());
+    slot.reset();
     prepareStops(P);
     *out = H.release();
     return AUGX_OK;
     } catch (const std::exception &e) { setLastError(std::string("augx_batch_sample: ") + e.what() + " (out of host memory?)"); return AUGX_E_NOMEM; }
 }
 
-void augx_sample_prep_destroy(augx_sample_prep *h) { delete h; }
+void augx_sample_prep_destroy(augx_sample_prep *h) {
+    if (!h) return;
+    h->P.Fown.reset(); // (the forward matrix goes back to its own pool)
+    h->P.F = nullptr;
+    h->P.uh.reset();
+    {
+        std::lock_guard<std::mutex> lk(g_fPoolMu);
+        if (g_prepPool.size() < 36) { g_prepPool.push_back(h); return; }
+    }
+    delete h;
+}
 
 int augx_sample_prep_run(augx_sample_prep *h, int n_samples, augx_rand *R, augx_path *out) {
     if (!h || !R || !out || n_samples < 0) { setLastError("augx_sample_prep_run: bad argument"); return AUGX_E_ARG; }
     for (int i = 0; i < n_samples; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = 0; out[i].ln_viterbi = 0; }
     std::vector<std::vector<augx_state>> paths;
     std::vector<int> status;
+    const double gen0 = R->refillSeconds;
     try { samplePaths(h->P, n_samples, *R, paths, status); }
     catch (const std::exception &e) { setLastError(std::string("augx_batch_sample: ") + e.what() + " (out of host memory?)"); return AUGX_E_NOMEM; }
+    if (getenv("AUGX_TIMING_SAMPLER")) // (developer aid)
+        fprintf(stderr, "augx timing:     sampler, piece of %d bases: generator %.4f s, %ld option lists built in %.4f s, %ld stops passed, %ld draws at other states; Mticks: chain runs %.1f, other states %.1f, paths put together %.1f\n", h->P.n,
+                R->refillSeconds - gen0, h->P.nBuilt, h->P.buildSeconds, h->P.nStops, h->P.nVar, h->P.tkChain / 1e6, h->P.tkVar / 1e6, h->P.tkTail / 1e6);
     for (int it = 0; it < n_samples; it++) {
         out[it].status = status[it];
         if (status[it] != AUGX_OK) continue;

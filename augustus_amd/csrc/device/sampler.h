@@ -5,6 +5,9 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <new>
+#include <sys/mman.h>
 #include <cstdint>
 #include <deque>
 #include <condition_variable>
@@ -26,24 +29,28 @@ struct augx_rand {
     // that was half of the time of the one thread every sampled piece of a run waits for.  The recurrence is linear over Z / 2^32,
     // so the 31 values before any position follow from the 31 before the buffer by one matrix product (jumpMatrix: A^L by
     // squaring, 31 x 31): a large buffer is cut into parts that are filled side by side by helper threads of the generator's own
-    // (started when the first large buffer is due, waiting on a condition variable in between).  The buffer grows from 6 144
-    // values (a run that draws little pays little, and starts no thread) to 1.5 M (6 MB: it stays in the caches -- one of 50 MB was
-    // measured slower than the single-core loop, bound by memory).
+    // (started when the first large buffer is due), and it is filled AHEAD: while the draws of one buffer are handed out the
+    // helpers make the next, so the drawing thread as a rule finds it ready (a helper that has to be woken takes 0.1-0.3 ms, as
+    // long as the drawing thread takes for a third of a buffer).  The buffer grows from 6 144 values (a run that draws little
+    // pays little, and starts no thread) to 1.5 M (6 MB: it stays in the caches -- one of 50 MB was measured slower than the
+    // single-core loop, bound by memory).
     static constexpr int LAG = 31;
     static constexpr int64_t CH0 = 3 * 2048, CHMAX = 3 * 524288, PART = 3 * 32768;
-    std::unique_ptr<uint32_t[]> buf; // x[LAG + i]: the i-th output of the buffer; x[0 .. LAG): the 31 before them
-    uint32_t *x = nullptr;           // = buf.get()
-    int64_t ch = 0, pos = 0;         // outputs in the buffer / handed out
-    std::vector<uint32_t> jump;      // A^PART, row-major 31 x 31 (made when the first buffer is cut into parts)
-    std::vector<uint32_t> seeds;     // [parts][31]: the values before every part
-    // helper threads: `gen` counts the buffers handed to them, `left` the helpers still at work on the current one
+    std::unique_ptr<uint32_t[]> buf, bufNext; // x[LAG + i]: the i-th output of the buffer; x[0 .. LAG): the 31 before them
+    uint32_t *x = nullptr;                    // = buf.get()
+    int64_t ch = 0, pos = 0;                  // outputs in the buffer / handed out
+    std::vector<uint32_t> jump;               // A^PART, row-major 31 x 31 (made when the first buffer is cut into parts)
+    std::vector<uint32_t> seeds;              // [parts][31]: the values before every part of the buffer being made
+    // helper threads: `gen` counts the buffers asked for, `left` the helpers still at work on the one being made (0: it is ready)
     std::vector<std::thread> helpers;
     std::mutex mu;
     std::condition_variable cvGo, cvDone;
     uint64_t gen = 0;
-    int left = 0, nth = 1;
+    int left = 0;
+    uint32_t *xMake = nullptr; // the buffer being made
     int64_t parts = 0;
-    bool quit = false;
+    bool quit = false, ahead = false; // ahead: bufNext is being made or ready
+    double refillSeconds = 0; // (AUGX_TIMING / AUGX_EMU_STATS: what the drawing thread spent on buffers so far)
     explicit augx_rand(unsigned seed) {
         int32_t st[34];
         st[0] = seed == 0 ? 1 : (int32_t)seed;
@@ -100,10 +107,10 @@ struct augx_rand {
         }
         return R;
     }
-    // the parts w, w + nth, ... of the buffer: each starts from its own 31 values (the part before is being written meanwhile)
-    void fillParts(int w) {
+    // the parts w, w + nth, ... of the buffer being made: each starts from its own 31 values (the part before is being written meanwhile)
+    void fillParts(int w, int nth) {
         for (int64_t k = w; k < parts; k += nth) {
-            uint32_t *p = x + LAG + k * PART;
+            uint32_t *p = xMake + LAG + k * PART;
             uint32_t h2[LAG + 33]; // the first 33 outputs of the part from its seed values alone (a multiple of 3 that covers the lag), the rest in place
             for (int q = 0; q < LAG; q++) h2[q] = seeds[(size_t)k * LAG + q];
             fill(h2 + LAG, 33);
@@ -114,67 +121,78 @@ struct augx_rand {
     void helperLoop(int w) {
         uint64_t seen = 0;
         for (;;) {
+            int nth;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cvGo.wait(lk, [&] { return quit || gen != seen; });
                 if (quit) return;
                 seen = gen;
+                nth = (int)helpers.size();
             }
-            fillParts(w);
+            fillParts(w, nth);
             std::lock_guard<std::mutex> lk(mu);
             if (--left == 0) cvDone.notify_one();
         }
     }
-#ifdef AUGX_EMU
-    double refillSeconds = 0; // (developer aid, emulator builds: AUGX_EMU_STATS)
-    void refill() {
-        const auto t0 = std::chrono::steady_clock::now();
-        refillBody();
-        refillSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    }
-    void refillBody() {
-#else
-    void refill() { // the next buffer of outputs from the last 31
-#endif
-        uint32_t last[LAG];
-        for (int q = 0; q < LAG; q++) last[q] = x[ch + q];
-        const int64_t next = ch == 0 ? CH0 : (ch * 4 < CHMAX ? ch * 4 : CHMAX);
-        if (next != ch) { buf.reset(new uint32_t[(size_t)(LAG + next)]); x = buf.get(); ch = next; } // (not zeroed: every value is written below)
-        for (int q = 0; q < LAG; q++) x[q] = last[q];
-        pos = 0;
-        if (ch < 2 * PART) { fill(x + LAG, ch); return; }
-        // in parts: the 31 values before part k + 1 are A^PART times those before part k
-        if (jump.empty()) {
-            jump = jumpMatrix(PART);
-            const unsigned hw = std::thread::hardware_concurrency();
-            nth = hw >= 32 ? 8 : hw >= 8 ? 4 : hw >= 4 ? 2 : 1;
-            for (int w = 1; w < nth; w++) {
-                try { helpers.emplace_back(&augx_rand::helperLoop, this, w); }
-                catch (const std::system_error &) { break; } // (no more threads to be had: the parts are dealt to those there are)
-            }
-            nth = (int)helpers.size() + 1;
-        }
-        parts = ch / PART; // (every buffer size from 2 PART on is a multiple of PART)
+    // ask the helpers for the CHMAX outputs after the 31 values `last`, into bufNext
+    void makeNext(const uint32_t *last) {
+        parts = CHMAX / PART;
         seeds.resize((size_t)parts * LAG);
         for (int q = 0; q < LAG; q++) seeds[(size_t)q] = last[q];
-        for (int64_t k = 1; k < parts; k++)
+        for (int64_t k = 1; k < parts; k++) // the 31 values before part k + 1 are A^PART times those before part k
             for (int i = 0; i < LAG; i++) {
                 uint32_t acc = 0;
                 for (int j = 0; j < LAG; j++) acc += jump[(size_t)i * LAG + j] * seeds[(size_t)(k - 1) * LAG + j];
                 seeds[(size_t)k * LAG + i] = acc;
             }
-        if (nth > 1) {
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                gen++;
-                left = nth - 1;
-            }
-            cvGo.notify_all();
+        xMake = bufNext.get();
+        for (int q = 0; q < LAG; q++) xMake[q] = last[q];
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            gen++;
+            left = (int)helpers.size();
         }
-        fillParts(0);
-        if (nth > 1) {
-            std::unique_lock<std::mutex> lk(mu);
-            cvDone.wait(lk, [&] { return left == 0; });
+        cvGo.notify_all();
+        ahead = true;
+    }
+    void refill() {
+        const auto t0 = std::chrono::steady_clock::now();
+        refillBody();
+        refillSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void refillBody() { // the next buffer of outputs from the last 31
+        uint32_t last[LAG];
+        for (int q = 0; q < LAG; q++) last[q] = x[ch + q];
+        if (ahead) { // the buffer the helpers were asked for: wait for it (as a rule it is there), take it, ask for the one after
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cvDone.wait(lk, [&] { return left == 0; });
+            }
+            buf.swap(bufNext);
+            x = buf.get();
+            pos = 0;
+            for (int q = 0; q < LAG; q++) last[q] = x[ch + q];
+            makeNext(last);
+            return;
+        }
+        const int64_t next = ch == 0 ? CH0 : (ch * 4 < CHMAX ? ch * 4 : CHMAX);
+        if (next == CHMAX && helpers.empty() && jump.empty()) { // the first buffer of full size: helpers, if there are cores for them
+            jump = jumpMatrix(PART);
+            const unsigned hw = std::thread::hardware_concurrency();
+            const int want = hw >= 32 ? 8 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
+            for (int w = 0; w < want; w++) {
+                try { helpers.emplace_back(&augx_rand::helperLoop, this, w); }
+                catch (const std::system_error &) { break; } // (no more threads to be had: the parts are dealt to those there are)
+            }
+        }
+        if (next != ch) { buf.reset(new uint32_t[(size_t)(LAG + next)]); x = buf.get(); ch = next; } // (not zeroed: every value is written below)
+        for (int q = 0; q < LAG; q++) x[q] = last[q];
+        pos = 0;
+        fill(x + LAG, ch); // (on this thread: the sizes on the way up, and every buffer when there are no helpers)
+        if (ch == CHMAX && !helpers.empty()) {
+            bufNext.reset(new uint32_t[(size_t)(LAG + CHMAX)]);
+            for (int q = 0; q < LAG; q++) last[q] = x[ch + q];
+            makeNext(last);
         }
     }
     void skip(int64_t n) {
@@ -190,24 +208,46 @@ struct augx_rand {
         return x[LAG + pos++];
     }
     int next() { return (int)(step() >> 1); }
-    void prefetch(int64_t ahead) const { // the output `ahead` positions after the next one, if it lies in this buffer
-        if (pos + ahead < ch) __builtin_prefetch(x + LAG + pos + ahead);
+    void prefetch(int64_t ahead2) const { // the output `ahead2` positions after the next one, if it lies in this buffer
+        if (pos + ahead2 < ch) __builtin_prefetch(x + LAG + pos + ahead2);
     }
 };
 
 namespace augx {
 namespace dev {
+// the large arrays of a piece on the host (hundreds of MB): 2 MB pages where the kernel grants them -- in 4 KB pages the first
+// touch and the release of a GB were each a tenth of a second of page-table work
+template <class T> struct HugeAllocator {
+    using value_type = T;
+    HugeAllocator() = default;
+    template <class U> HugeAllocator(const HugeAllocator<U> &) {}
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        void *q = nullptr;
+        if (bytes < ((size_t)4 << 20)) q = malloc(bytes ? bytes : 1);
+        else {
+            const size_t rounded = ((bytes + ((size_t)2 << 20) - 1) >> 21) << 21;
+            if (posix_memalign(&q, (size_t)2 << 20, rounded) != 0) q = nullptr;
+            else (void)madvise(q, rounded, MADV_HUGEPAGE);
+        }
+        if (!q) throw std::bad_alloc();
+        return (T *)q;
+    }
+    void deallocate(T *q, size_t) { free(q); }
+    template <class U> bool operator==(const HugeAllocator<U> &) const { return true; }
+    template <class U> bool operator!=(const HugeAllocator<U> &) const { return false; }
+};
 // everything of one piece the sampler reads, on the host
 struct SamplePiece {
     int n = 0, S = 0, blk = 8, nPlanes = 1;
     const augx_tables *t = nullptr;
     const double *F = nullptr;    // [n][S] ln forward
     std::shared_ptr<double> Fown;   // (the device library keeps its host copy here; the deleter hands the buffer back for the next piece)
-    std::vector<double> sig;      // [n][NSIG]
+    std::vector<double, HugeAllocator<double>> sig; // [n][NSIG]
     std::vector<uint8_t> plane;   // [n] (empty: one class)
     std::vector<int32_t> planeCls;
     int cls0 = 0;
-    std::vector<Item> items;      // candidates of the piece
+    std::vector<Item, HugeAllocator<Item>> items;   // candidates of the piece
     std::vector<uint64_t> blkOff; // [nBlocks][2] (relative item offsets are blkOff[.][1] - item0)
     std::vector<uint32_t> blkCnt; // [nBlocks][2]
     uint64_t item0 = 0;
@@ -221,6 +261,9 @@ struct SamplePiece {
     std::vector<std::vector<double>> stopCum;
     std::vector<std::vector<uint32_t>> stopThr;
     bool prepared = false;
+    double buildSeconds = 0; // (AUGX_TIMING: option lists built while drawing)
+    long nBuilt = 0, nStops = 0, nVar = 0;
+    uint64_t tkChain = 0, tkVar = 0, tkTail = 0; // (TSC ticks: runs down chain states / draws at other states / paths put together)
     // models of the dense kernels (dense.h): candidate records name their predecessor by state; the candidates of the UTR exon
     // states are evaluated from a host view of the batch (hB: the emulator's own arrays, or the mirror of one piece below)
     bool dense = false;
@@ -288,6 +331,12 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
         const int b = j / P.blk;
         const uint64_t i0 = P.blkOff[(size_t)b * 2 + 1] - P.item0;
         const uint32_t cnt = P.blkCnt[(size_t)b * 2 + 1], pid = (uint32_t)(((j % P.blk) << 7) | s);
+        for (uint32_t it = 0; it < cnt; it++) { // (the predecessor cells lie all over a matrix of hundreds of MB: asked for first, read in the loop below)
+            const Item &I = P.items[i0 + it];
+            if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
+            const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
+            __builtin_prefetch(&P.F[(size_t)(eop > 0 ? eop : 0) * S + (I.src & 127u)]);
+        }
         for (uint32_t it = 0; it < cnt; it++) {
             const Item &I = P.items[i0 + it];
             if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
@@ -303,6 +352,12 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
         const int b = j / P.blk;
         const uint64_t i0 = P.blkOff[(size_t)b * 2 + 1] - P.item0;
         const uint32_t cnt = P.blkCnt[(size_t)b * 2 + 1], pid = (uint32_t)(((j % P.blk) << 6) | s);
+        for (uint32_t it = 0; it < cnt; it++) { // (the predecessor cells lie all over a matrix of hundreds of MB: asked for first, read in the loop below)
+            const Item &I = P.items[i0 + it];
+            if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY) || (I.src >> 30) == SRC_COL0) continue;
+            const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;
+            if (eop >= 0) __builtin_prefetch(&P.F[(size_t)eop * S + ((I.src >> 30) == SRC_VIG ? P.igS : t.anc[s][(I.src >> 28) & 3])]);
+        }
         for (uint32_t it = 0; it < cnt; it++) {
             const Item &I = P.items[i0 + it];
             if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
@@ -418,6 +473,51 @@ inline void prepareStops(SamplePiece &P) {
 #endif
 }
 
+// What the drawing thread keeps between the pieces of a run: the option lists of the (base, state) pairs a path came through --
+// the same for every sample of a piece -- in two flat arrays behind an open-addressing table, and the work vectors.  Nothing is
+// given back to the allocator between pieces: the thread every sampled piece waits for took page faults on fresh heap pages
+// behind the helper threads that map and unmap the pieces' buffers (hundreds of MB each, one lock per process) -- up to 100 ms
+// in a piece whose draws take 25.
+struct SamplerScratch {
+    struct Ent { uint64_t key; uint32_t first, cnt; double cum; }; // key: ((base << 8) | state) + 1, 0: free
+    std::vector<Ent> table;
+    std::vector<Opt> o;
+    std::vector<double> p;
+    size_t used = 0;
+    OptList tmp;
+    std::vector<augx_state> st;
+    void reset() {
+        if (table.empty()) table.assign(1u << 15, Ent{0, 0, 0, 0.0});
+        else if (used) std::fill(table.begin(), table.end(), Ent{0, 0, 0, 0.0});
+        used = 0; o.clear(); p.clear();
+    }
+    static size_t slotOf(uint64_t key, size_t mask) { return (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & mask; }
+    Ent *find(uint64_t key) {
+        const size_t mask = table.size() - 1;
+        for (size_t i = slotOf(key, mask);; i = (i + 1) & mask) {
+            if (table[i].key == key) return &table[i];
+            if (table[i].key == 0) return nullptr;
+        }
+    }
+    Ent *insert(uint64_t key, const OptList &L) {
+        if ((used + 1) * 2 > table.size()) { // grow: twice the slots, every entry put again
+            std::vector<Ent> old((size_t)table.size() * 2, Ent{0, 0, 0, 0.0});
+            old.swap(table);
+            const size_t mask = table.size() - 1;
+            for (const Ent &e : old)
+                if (e.key) { size_t i = slotOf(e.key, mask); while (table[i].key) i = (i + 1) & mask; table[i] = e; }
+        }
+        const size_t mask = table.size() - 1;
+        size_t i = slotOf(key, mask);
+        while (table[i].key) i = (i + 1) & mask;
+        table[i] = Ent{key, (uint32_t)o.size(), (uint32_t)L.o.size(), L.cum};
+        o.insert(o.end(), L.o.begin(), L.o.end());
+        p.insert(p.end(), L.p.begin(), L.p.end());
+        used++;
+        return &table[i];
+    }
+};
+
 // n_samples paths of one piece, 5'->3', runs of the single-base chain states merged (as the Viterbi path is delivered)
 inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector<std::vector<augx_state>> &paths, std::vector<int> &status) {
     const augx_tables &t = *P.t;
@@ -426,8 +526,10 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
         if (t.state_kind[s2] == AUGX_K_IGENIC && P.igS < 0) P.igS = s2;
     paths.assign((size_t)n_samples, {});
     status.assign((size_t)n_samples, AUGX_OK);
-    std::unordered_map<uint64_t, OptList> memo; // the options of a (base, state) pair are the same for every sample
-    std::vector<augx_state> st;
+    static thread_local SamplerScratch scratch; // (the options of a (base, state) pair are the same for every sample)
+    SamplerScratch &M = scratch;
+    M.reset();
+    std::vector<augx_state> &st = M.st;
     if (!P.prepared) prepareStops(P);
     std::vector<std::vector<int32_t>> &stops = P.stops;
     std::vector<int64_t> cur((size_t)S, 0); // per sample: index of the last stop <= the base the path was last at in this state
@@ -456,12 +558,14 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                     // at a time while the path stays in the state, by bisection when it comes back to it further down
                     int64_t c = cur[state];
                     if (c >= (int64_t)v.size()) c = (int64_t)v.size() - 1;
-                    if (c >= 0 && v[c] > base) {
-                        if (c >= 1 && v[c - 1] <= base) c--;
-                        else c = (int64_t)(std::upper_bound(v.begin(), v.begin() + c, base) - v.begin()) - 1;
+                    if (c >= 0 && v[c] > base) { // (by doubling steps from where the cursor is: the path comes back a gene further down, a few dozen stops)
+                        int64_t hi = c, stepDown = 1;
+                        while (c >= 0 && v[c] > base) { hi = c; c -= stepDown; stepDown <<= 1; }
+                        c = (int64_t)(std::upper_bound(v.begin() + (c < 0 ? 0 : c), v.begin() + hi, base) - v.begin()) - 1;
                     }
                     // down the state, stop after stop: between two stops a draw per base decides nothing; at a stop the draw is
                     // compared with the most probable option first -- as a rule the state itself, and the run goes on
+                    const uint64_t tk0 = __builtin_ia32_rdtsc();
                     const int top = base;
                     const double *cumA = P.stopCum[state].data();
                     const uint32_t *thrA = P.stopThr[state].data();
@@ -474,6 +578,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                         //  threads have just written: the one eight stops down is asked for now)
                         if (c >= 8) R.prefetch((int64_t)(base - v[c - 8]));
                         int r = -1;
+                        P.nStops++;
                         if (thrA[c]) { // (the stop has options and the state itself first among them)
                             r = R.next();
                             if ((uint32_t)r < thrA[c]) { base--; c--; if (base == 0) break; continue; }
@@ -491,6 +596,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                         break;
                     }
                     cur[state] = c;
+                    P.tkChain += __builtin_ia32_rdtsc() - tk0;
                     if (bad) break;
                     // (st runs 3'->5'; the steps of the run are one entry: the merged form the path is delivered in)
                     const int from = x ? x->base + 1 : 1;
@@ -499,16 +605,37 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                     if (x) { base = x->base; state = x->state; }
                     continue;
                 }
+                const uint64_t tk1 = __builtin_ia32_rdtsc();
                 const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;
-                auto f = memo.find(key);
-                if (f == memo.end()) { f = memo.emplace(key, OptList()).first; buildOptions(P, state, base, f->second); }
-                const Opt *x = drawOption(f->second, R);
+                SamplerScratch::Ent *f = M.find(key + 1);
+                P.nVar++;
+                if (!f) {
+                    const auto tb0 = std::chrono::steady_clock::now();
+                    buildOptions(P, state, base, M.tmp);
+                    f = M.insert(key + 1, M.tmp);
+                    P.buildSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count();
+                    P.nBuilt++;
+                }
+                // (reference OptionsList::sample, as drawOption)
+                const Opt *x = nullptr;
+                if (f->cnt && f->cum > 0) {
+                    const double z = (double)R.next() / 2147483647.0 * f->cum * 0.99999;
+                    const double *pp = M.p.data() + f->first;
+                    x = M.o.data() + f->first;
+                    double cumsum = 0;
+                    for (uint32_t i = 0; i < f->cnt; i++) {
+                        cumsum += pp[i];
+                        if (z < cumsum) { x = M.o.data() + f->first + i; break; }
+                    }
+                }
                 if (!x) { bad = true; break; }
                 st.push_back({x->base + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
                 base = x->base; state = x->state;
+                P.tkVar += __builtin_ia32_rdtsc() - tk1;
             }
             if (bad) { status[it] = AUGX_E_NOPATH; continue; }
         }
+        const uint64_t tk2 = __builtin_ia32_rdtsc();
         std::vector<augx_state> &m2 = paths[it];
         for (size_t i = st.size(); i-- > 0;) {
             const augx_state &x = st[i];
@@ -517,6 +644,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
             if (chain && !m2.empty() && m2.back().state == x.state && m2.back().end + 1 == x.begin) m2.back().end = x.end;
             else m2.push_back(x);
         }
+        P.tkTail += __builtin_ia32_rdtsc() - tk2;
     }
 }
 } // namespace dev

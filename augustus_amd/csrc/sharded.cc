@@ -115,7 +115,7 @@ static int aheadPieces(int64_t bytesPerPiece) {
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && a > (int64_t)hw / 2) a = hw / 2;
     if (const char *e = getenv("AUGX_SAMPLE_AHEAD")) a = atol(e); // (developer aid)
-    return (int)std::max<int64_t>(2, std::min<int64_t>(32, a));
+    return (int)std::max<int64_t>(2, std::min<int64_t>(12, a));
 }
 
 int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, int n_samples, augx_rand *r,
@@ -164,7 +164,7 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
             // what the sampler reads of a piece is fetched and indexed on helper threads, a few pieces ahead of the sampling
             // (it does not depend on the draws), also while earlier batches are still being sampled
             // How many: a prepared piece holds its forward matrix and candidate records on the host (0.75 KB per base), and the draws
-            // of a piece take tens of milliseconds where its preparation takes most of a second -- up to 32 pieces, a quarter of
+            // of a piece take tens of milliseconds where its preparation takes most of a second, and all but the forward matrix is copied while the forward kernel still runs -- up to 12 pieces (what they hold is touched once and then goes round: more of them is more page-table work at both ends), a quarter of
             // the memory the host has to spare and half of its cores
             int64_t longest = 1;
             for (int p = 0; p < cnt; p++) longest = std::max<int64_t>(longest, pieces[first + p].len);
