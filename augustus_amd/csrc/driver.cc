@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,11 +17,15 @@
 #include <future>
 #include <iostream>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <queue>
 #include <set>
 #include <tuple>
 #include <sstream>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 #include "capi_internal.h"
 #include "genes.h"
@@ -239,10 +244,95 @@ struct PieceOut {
 int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<RecordView> &recs, std::vector<PieceOut> pieces,
                   int verbosity, int &geneid, std::string &out, std::string &err, std::string &fatal, int sampleiterations = 0) {
     std::stable_sort(pieces.begin(), pieces.end(), [](const PieceOut &a, const PieceOut &b) { return a.rec != b.rec ? a.rec < b.rec : a.begin < b.begin; });
-    size_t pi = 0;
     int successful = 0;
     const bool noInFrameStop = M.opt.getBool("noInFrameStop", false);
-    char buf[256];
+    // The gene structures of a piece (with sampling: the posterior probabilities from 99 paths) and its GFF text depend on nothing
+    // but the piece -- except the gene numbers, which count through the run.  Four steps: the genes of every piece, side by side
+    // on host threads; the numbers, in order; the text of every piece, side by side; the blocks put together in order.
+    const size_t np = pieces.size();
+    std::vector<std::vector<GeneOut>> pieceGenes(np);
+    std::vector<std::string> pieceErr(np), pieceText(np);
+    std::vector<int> firstId(np, 0);
+    auto overPieces = [&](const std::function<void(size_t)> &job) {
+        unsigned hw = std::thread::hardware_concurrency();
+        const size_t nth = std::min<size_t>(np, std::min<size_t>(32, hw > 3 ? hw / 2 : 1));
+        if (nth <= 1) { for (size_t i = 0; i < np; i++) job(i); return; }
+        std::atomic<size_t> nextPiece{0};
+        auto body = [&]() { for (size_t i; (i = nextPiece.fetch_add(1)) < np;) job(i); };
+        std::vector<std::thread> th;
+        for (size_t w = 1; w < nth; w++) {
+            try { th.emplace_back(body); } catch (const std::system_error &) { break; } // (no more threads to be had: fewer of them)
+        }
+        body();
+        for (auto &t2 : th) t2.join();
+    };
+    overPieces([&](size_t i) {
+        const PieceOut &pr = pieces[i];
+        if (pr.status != 0) return;
+        const RecordView &rec = recs[(size_t)pr.rec];
+        std::vector<GeneOut> &genes = pieceGenes[i];
+        const long plen = pr.end - pr.begin + 1;
+        auto run = [&](const std::vector<PathState> &path, const std::vector<std::vector<PathState>> *smp, bool anyStrand, const char *runSeq) {
+            return groupToGenes(M, sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand, runSeq)
+                                                               : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand, runSeq));
+        };
+        try {
+            if (!pr.single) genes = run(*pr.path, pr.samples, false, rec.seq + pr.begin);
+            else { // reference NAMGene::doViterbiPiecewise, src/namgene.cc:611-626: the genes of the forward run, then those of the
+                   // run on the reverse complement mapped back (reverseGeneList); sorted by coding start
+                if (pr.path) genes = run(*pr.path, pr.samples, true, rec.seq + pr.begin);
+                if (pr.pathR) {
+                    std::string rc; // (the sequence of the second run is read by --noInFrameStop=true only)
+                    if (noInFrameStop) {
+                        rc.assign(rec.seq + pr.begin, (size_t)plen);
+                        std::reverse(rc.begin(), rc.end());
+                        for (char &c : rc) {
+                            const char l = (char)tolower((unsigned char)c);
+                            c = l == 'a' ? 't' : l == 'c' ? 'g' : l == 'g' ? 'c' : l == 't' ? 'a' : 'n';
+                        }
+                    }
+                    std::vector<GeneOut> rv = run(*pr.pathR, pr.samplesR, true, noInFrameStop ? rc.c_str() : nullptr);
+                    reverseGenes(rv, plen - 1);
+                    for (GeneOut &g : rv) genes.push_back(std::move(g));
+                }
+                std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
+            }
+        } catch (std::exception &e) { pieceErr[i] = e.what(); if (pieceErr[i].empty()) pieceErr[i] = "error"; genes.clear(); }
+    });
+    for (size_t i = 0; i < np; i++) { firstId[i] = geneid; geneid += (int)pieceGenes[i].size(); }
+    // (the hint groups of the evidence block need the soft-masked runs of the record: made once per record, by whichever piece asks first)
+    std::vector<std::vector<std::pair<long, long>>> recRuns(recs.size());
+    std::unique_ptr<std::once_flag[]> recRunsOnce(new std::once_flag[recs.size() ? recs.size() : 1]);
+    overPieces([&](size_t i) {
+        const PieceOut &pr = pieces[i];
+        std::vector<GeneOut> &genes = pieceGenes[i];
+        if (pr.status != 0 || !pieceErr[i].empty()) return;
+        const RecordView &rec = recs[(size_t)pr.rec];
+        char buf[256];
+        int id = firstId[i];
+        for (GeneOut &g : genes) {
+            g.seqname = rec.name;
+            if (oo.uniqueGeneId) { snprintf(buf, sizeof buf, "%.30s.g%d", rec.name, id); g.id = buf; }
+            else g.id = "g" + std::to_string(id);
+            int tid = 1;
+            for (Transcript &t : g.transcripts) {
+                t.shift(pr.begin);
+                t.seqname = rec.name;
+                t.id = "t" + std::to_string(tid++);
+                t.geneid = g.id;
+            }
+            id++;
+        }
+        std::vector<std::pair<long, long>> pieceRuns;
+        if (oo.evidence && oo.softmasking && !genes.empty()) {
+            // the hint groups of the evidence block: the soft-masked runs that END inside the piece (see pieceSequence)
+            std::call_once(recRunsOnce[(size_t)pr.rec], [&] { recRuns[(size_t)pr.rec] = lowerRuns(rec.seq, rec.len); });
+            for (auto &ru : recRuns[(size_t)pr.rec])
+                if (ru.second >= pr.begin && ru.second <= pr.end) pieceRuns.push_back(ru);
+        }
+        printGeneList(pieceText[i], genes, rec.seq, rec.len, oo, &pieceRuns);
+    });
+    size_t pi = 0;
     for (size_t r = 0; r < recs.size(); r++) {
         const RecordView &rec = recs[r];
         if (verbosity) {
@@ -256,9 +346,7 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
         }
         bool any = false;
         std::string errmsg;
-        std::vector<std::pair<long, long>> runs, pieceRuns;
-        bool haveRuns = false;
-        for (; pi < pieces.size() && pieces[pi].rec == (int)r; pi++) {
+        for (; pi < np && pieces[pi].rec == (int)r; pi++) {
             const PieceOut &pr = pieces[pi];
             if (pr.status != 0) {
                 errmsg = pr.status == AUGX_E_UNSUPPORTED ? "piece outside what the MI355X path decodes"
@@ -267,56 +355,9 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
                                                          : "device decode failed (HIP error or kernel abort; not a property of the input)";
                 continue;
             }
-            std::vector<GeneOut> genes;
-            const long plen = pr.end - pr.begin + 1;
-            auto run = [&](const std::vector<PathState> &path, const std::vector<std::vector<PathState>> *smp, bool anyStrand, const char *runSeq) {
-                return groupToGenes(M, sampleiterations > 0 && smp ? filterTranscripts(M, posteriorTranscripts(M, path, *smp, plen, sampleiterations), anyStrand, runSeq)
-                                                                   : filterTranscripts(M, projectOntoGeneSequence(M, path, plen), anyStrand, runSeq));
-            };
-            try {
-                if (!pr.single) genes = run(*pr.path, pr.samples, false, rec.seq + pr.begin);
-                else { // reference NAMGene::doViterbiPiecewise, src/namgene.cc:611-626: the genes of the forward run, then those of the
-                       // run on the reverse complement mapped back (reverseGeneList); sorted by coding start
-                    if (pr.path) genes = run(*pr.path, pr.samples, true, rec.seq + pr.begin);
-                    if (pr.pathR) {
-                        std::string rc; // (the sequence of the second run is read by --noInFrameStop=true only)
-                        if (noInFrameStop) {
-                            rc.assign(rec.seq + pr.begin, (size_t)plen);
-                            std::reverse(rc.begin(), rc.end());
-                            for (char &c : rc) {
-                                const char l = (char)tolower((unsigned char)c);
-                                c = l == 'a' ? 't' : l == 'c' ? 'g' : l == 'g' ? 'c' : l == 't' ? 'a' : 'n';
-                            }
-                        }
-                        std::vector<GeneOut> rv = run(*pr.pathR, pr.samplesR, true, noInFrameStop ? rc.c_str() : nullptr);
-                        reverseGenes(rv, plen - 1);
-                        for (GeneOut &g : rv) genes.push_back(std::move(g));
-                    }
-                    std::stable_sort(genes.begin(), genes.end(), [](const GeneOut &a, const GeneOut &b) { return a.mincodstart < b.mincodstart; });
-                }
-            } catch (std::exception &e) { errmsg = e.what(); continue; }
-            for (GeneOut &g : genes) {
-                g.seqname = rec.name;
-                if (oo.uniqueGeneId) { snprintf(buf, sizeof buf, "%.30s.g%d", rec.name, geneid); g.id = buf; }
-                else g.id = "g" + std::to_string(geneid);
-                int tid = 1;
-                for (Transcript &t : g.transcripts) {
-                    t.shift(pr.begin);
-                    t.seqname = rec.name;
-                    t.id = "t" + std::to_string(tid++);
-                    t.geneid = g.id;
-                }
-                geneid++;
-                any = true;
-            }
-            if (oo.evidence && oo.softmasking && !genes.empty()) {
-                // the hint groups of the evidence block: the soft-masked runs that END inside the piece (see pieceSequence)
-                if (!haveRuns) { runs = lowerRuns(rec.seq, rec.len); haveRuns = true; }
-                pieceRuns.clear();
-                for (auto &ru : runs)
-                    if (ru.second >= pr.begin && ru.second <= pr.end) pieceRuns.push_back(ru);
-            }
-            printGeneList(out, genes, rec.seq, rec.len, oo, &pieceRuns);
+            if (!pieceErr[pi].empty()) { errmsg = pieceErr[pi]; continue; }
+            any = any || !pieceGenes[pi].empty();
+            out += pieceText[pi];
         }
         if (!errmsg.empty()) {
             if (successful < 1) { fatal = errmsg; return 1; }

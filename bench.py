@@ -324,7 +324,7 @@ def e2e_legs(cfg, model, local, contigs):
                                                  "excluded: process start, parameter load, HIP context / decoder create, teardown (laps_s of cli)"}
             # ---- the same executable with posterior sampling (the default of 162 of the reference's species): forward algorithm on the
             #      device, 99 sampled paths per contig on the host, posterior probabilities in the GFF
-            ns = min(n, 32)
+            ns = n  # (round 3 timed 32 of the contigs; with 100 the decoder takes two batches, 64 + 36 Mbp: the forward matrix halves what fits)
             fa2 = os.path.join(d, "bench_s.fa")
             with open(fa2, "wb") as f:
                 for nm, s in list(zip(names, contigs))[:ns]:
