@@ -17,6 +17,7 @@ import argparse
 import ctypes
 import json
 import os
+import re
 import subprocess
 import sys
 import tempfile
@@ -329,14 +330,28 @@ def e2e_legs(cfg, model, local, contigs):
             with open(fa2, "wb") as f:
                 for nm, s in list(zip(names, contigs))[:ns]:
                     f.write(b">" + nm.encode() + b"\n" + s + b"\n")
-            t0 = time.perf_counter()
-            r = subprocess.run([exe, "--species=human", "--sample=100", "--outfile=" + os.path.join(d, "out_s.gff"), fa2], capture_output=True, env=env)
-            dt = time.perf_counter() - t0
+            best = None
+            for rep2 in range(2):  # (the faster of two runs, as for `cli`: the box is one GPU of a shared 8-GPU node, and a run of 6 s was seen to take 10)
+                # (a process that starts while the driver still clears the 100+ GB of HBM the process before it gave back waits in its
+                #  first allocations -- "decode + paths" of the first batch 3.2 s instead of 0.19 s: a pause outside the timed region)
+                time.sleep(4.0)
+                t0 = time.perf_counter()
+                r2 = subprocess.run([exe, "--species=human", "--sample=100", "--outfile=" + os.path.join(d, "out_s.gff"), fa2], capture_output=True, env=env)
+                dt2 = time.perf_counter() - t0
+                if best is None or (r2.returncode == 0 and dt2 < best[0]) or best[1].returncode != 0:
+                    best = (dt2, r2)
+            dt, r = best
             b2 = sum(len(c) for c in contigs[:ns])
             laps = parse_timing(r.stderr.decode(errors="replace"))
+            try:  # (the per-batch lines of the run, for whoever reads the number: gpurun_out/ is scratch)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "cli_sampled.err"), "wb") as f:
+                    f.write(r.stderr)
+            except OSError:
+                pass
             out["cli_sampled"] = {"value": b2 / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "contigs": ns, "laps_s": laps,
                                   "region": "augustus --species=human --sample=100 (Viterbi + forward on 1 GPU, 99 sampled paths per contig on the host, "
-                                            "posterior probabilities in the GFF)"}
+                                            "posterior probabilities in the GFF); the faster of two runs"}
     return out
 
 
@@ -463,7 +478,7 @@ def utr_leg(cfg, local, a):
         if name.endswith("_utr_hbm_traffic.json"):
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 tj = json.load(fh)
-            kd = [v for k, v in tj.get("kernels", {}).items() if k.startswith("kDense") and k.endswith("0>")]
+            kd = [v for k, v in tj.get("kernels", {}).items() if re.match(r"kDense<\d+, 0[,>]", k)]  # (the Viterbi pass: kDense<BLK, 0, TIES>)
             if tj.get("source_sha") == source_sha() and kd:
                 traffic, tsrc = kd[0]["traffic_bytes_per_bp"] * bases, "profiles/" + name
                 break
