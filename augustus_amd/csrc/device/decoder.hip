@@ -1543,6 +1543,9 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         cst = slotSt;
     }
     if (!cst) { if (b->evFwd) HIP_TRY(hipEventSynchronize(b->evFwd)); else HIP_TRY(hipStreamSynchronize(d->stream)); } // (no stream to be had: after the kernel, on the default stream)
+    // (the copy stream has no order of its own against the decoder's: what it reads is written by the kernels of the decode,
+    //  whose end is ev[3]; the terms the replay rebuilds are in place when augx_batch_forward returns, it waits for them)
+    else if (b->decoded && b->ev[3]) HIP_TRY(hipStreamWaitEvent(cst, b->ev[3], 0));
     auto cp = [cst](void *dst, const void *src, size_t bytes) { return cst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, cst) : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost); };
     auto flush = [cst]() { return cst ? hipStreamSynchronize(cst) : hipSuccess; };
     const BatchView &V = b->V;
