@@ -42,6 +42,7 @@ BIG_CFGS = {
     "fly_default": ("genome", "fly", []),                    # every default of the species: UTR on, sample 100, soft-masking
     "human_utr": ("genome", "human", ["--UTR=on"]),          # one 1 Mbp piece with two GC classes
     "human_utr_sampled": ("genome", "human", ["--UTR=on", "--sample=100"]),  # ... with the forward pass and 99 sampled paths
+    "synth_sampled": ("synth", "human", ["--sample=100"]),   # the bench contig with sampling: 99 paths of a 1 Mbp piece, 10^8 draws of the one generator
 }
 
 

@@ -45,6 +45,7 @@ BIG = {  # tests/golden/make_golden_big.py: BIG_CFGS
     "fly_default": ("genome", "fly", []),                    # every default of the species: UTR on, sample 100, soft-masking
     "human_utr": ("genome", "human", ["--UTR=on"]),          # the 71-state model on one 1 Mbp piece with two GC classes (ten steps): snippet cache replayed for the dense kernels
     "human_utr_sampled": ("genome", "human", ["--UTR=on", "--sample=100"]),   # ... and its forward pass + 99 sampled paths
+    "synth_sampled": ("synth", "human", ["--sample=100"]),   # the bench contig with sampling: 10^8 draws (the generator's buffers made in parts, ahead), 12 000 option lists
 }
 
 
