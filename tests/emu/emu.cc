@@ -327,6 +327,24 @@ void emu_set_sampling(int n, unsigned seed) {
     g_rand = n > 0 ? new augx_rand(seed) : nullptr;
 }
 int emu_state_type(const augx_tables *t, int s) { return s >= 0 && s < t->S ? t->state_type[s] : -1; }
+// stayThreshold (sampler.h) against the expression it stands for: for n random (total, p0) pairs the draws below the threshold take the
+// first option and the threshold itself does not; returns the number of pairs where that fails
+int emu_stay_threshold_check(unsigned seed, int n) {
+    augx_rand R(seed);
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        // totals between 1 and 3 (the largest option has probability 1 by construction), p0 anywhere in (0, total]; some pairs at the edges
+        const double cum = 1.0 + 2.0 * (double)R.next() / 2147483647.0;
+        double p0 = (i % 7 == 0) ? cum : (i % 11 == 0) ? cum * 0.99999 : cum * (double)(R.next() + 1) / 2147483648.0;
+        if (i % 13 == 0) p0 = 1e-300;
+        const uint32_t thr = augx::dev::stayThreshold(cum, p0);
+        auto takesFirst = [&](uint32_t r) { return (double)(int)r / 2147483647.0 * cum * 0.99999 < p0; };
+        if (thr > 0 && !takesFirst(thr - 1)) bad++;
+        if (thr < 2147483648u && takesFirst(thr)) bad++;
+        if (thr > 1 && !takesFirst(thr / 2)) bad++; // (monotone: everything below takes it)
+    }
+    return bad;
+}
 // augx_rand against glibc's rand() after srand(seed): n draws, every `stride`-th one looked at, the others spent with skip();
 // returns the index of the first draw that differs, -1: none
 long long emu_rand_check(unsigned seed, long long n, int stride) {

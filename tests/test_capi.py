@@ -87,3 +87,15 @@ def test_rand_buffers_filled_in_parts_are_glibc_rand():
     E.emu_rand_check.argtypes = [ctypes.c_uint, ctypes.c_longlong, ctypes.c_int]
     assert E.emu_rand_check(1, 60_000_000, 40) == -1
     assert E.emu_rand_check(20260927, 8_000_000, 1) == -1
+
+
+def test_stop_thresholds_are_the_draw_rule():
+    """At a stop of a chain state the sampler compares rand() with an integer threshold instead of evaluating
+    z = rand() / RAND_MAX * total * 0.99999 < p(first option) (reference OptionsList::sample, src/vitmatrix.cc:295-320): the
+    threshold is found by bisection over that very expression, so for every pair (total, p) the draws below it take the first
+    option and the threshold itself does not -- 200 000 random pairs, incl. p = total, p = total * 0.99999 and p tiny"""
+    import ctypes
+    E = ctypes.CDLL(EMU_LIB)
+    E.emu_stay_threshold_check.argtypes = [ctypes.c_uint, ctypes.c_int]
+    assert E.emu_stay_threshold_check(1, 200000) == 0
+
