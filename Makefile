@@ -10,17 +10,43 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-un
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
 SRC     = augustus_amd/csrc
 HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc $(SRC)/sharded.cc
-DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/densev.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h
+DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h $(SRC)/device/launch.h
+HOSTHDR = $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
 
 all: product oracle emu
 product: augustus_amd/libaugx.so augustus_amd/bin/augustus
 
-augustus_amd/libaugx.so: $(HOSTSRC) $(SRC)/device/decoder.hip $(DEVHDR) $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HOSTSRC) $(SRC)/device/decoder.hip
+# The heavy kernel families are translation units of their own, one object per block size (device/launch.h), so that `make -j`
+# compiles them side by side (the whole library: ~1.5 min on 8 cores instead of ~4.5) and a kernel change rebuilds one family.
+OBJ     = build/obj
+FAMILIES = trellis cand forward dense
+KOBJS   = $(foreach f,$(FAMILIES),$(foreach b,8 4 2,$(OBJ)/k_$(f)_$(b).o))
+HOSTOBJS = $(patsubst $(SRC)/%.cc,$(OBJ)/%.o,$(HOSTSRC))
+PRODFLAGS =
 
-prof: augustus_amd/libaugx_prof.so
-augustus_amd/libaugx_prof.so: $(HOSTSRC) $(SRC)/device/decoder.hip $(DEVHDR) $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
-	$(HIPCC) $(HIPFLAGS) -DAUGX_PROFILE -shared -o $@ $(HOSTSRC) $(SRC)/device/decoder.hip
+define KRULE
+$(OBJ)/k_$(1)_$(2).o: $(SRC)/device/k_$(1).hip $(DEVHDR) include/augx.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $$(PRODFLAGS) -DAUGX_TU_BLK=$(2) -c -o $$@ $$<
+endef
+$(foreach f,$(FAMILIES),$(foreach b,8 4 2,$(eval $(call KRULE,$(f),$(b)))))
+
+$(OBJ)/decoder.o: $(SRC)/device/decoder.hip $(DEVHDR) $(HOSTHDR)
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $(PRODFLAGS) -c -o $@ $<
+$(OBJ)/%.o: $(SRC)/%.cc $(HOSTHDR) $(SRC)/device/layout.h $(SRC)/device/dp.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) $(PRODFLAGS) -c -o $@ $<
+
+augustus_amd/libaugx.so: $(HOSTOBJS) $(OBJ)/decoder.o $(KOBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
+
+# developer build with the cycle counters of the trellis wavefronts (AUGX_PROF=1): objects of its own
+prof:
+	$(MAKE) OBJ=build/obj_prof PRODFLAGS=-DAUGX_PROFILE build/obj_prof/libaugx_prof.so
+	cp build/obj_prof/libaugx_prof.so augustus_amd/libaugx_prof.so
+build/obj_prof/libaugx_prof.so: $(HOSTOBJS) $(OBJ)/decoder.o $(KOBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
 
 augustus_amd/bin/augustus: $(SRC)/augustus_main.cc augustus_amd/libaugx.so
 	@mkdir -p augustus_amd/bin

@@ -26,8 +26,8 @@
 #include <vector>
 #include "kernels.h"
 #include "dense.h"
-#include "densev.h"
 #include "layout.h"
+#include "launch.h"
 #include "../capi_internal.h"
 
 using namespace augx;
@@ -350,37 +350,9 @@ __global__ void __launch_bounds__(256) kUtrSignals(const DevTables *T, BatchView
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1UtrSignals(*T, B, g, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
-template <int BLK> __global__ void __launch_bounds__(NT) kUtrDesc(const DevTables *__restrict__ T, const BatchView B) {
-    __shared__ UDescLds lds;
-    utrDescGroup<BLK>(*T, B, lds, blockIdx.x);
-}
-// the dense Viterbi / forward kernel and its back-trace (dense.h): one workgroup / one wavefront per piece
-template <int BLK, int MODE, bool TIES = false> __global__ void __launch_bounds__(NT) kDense(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
-    __shared__ DenseLds lds;
-    densePiece<BLK, MODE, TIES>(*T, *B, lds, blockIdx.x);
-}
-// the Viterbi pass with the candidates of block b + 1 evaluated while block b runs (densev.h); kDense<BLK, 0> is the same pass
-// without the work done ahead (AUGX_DENSE_PIPE=0), kDense<BLK, 1> the forward pass
-template <int BLK> __global__ void __launch_bounds__(VNT) kDenseV(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
-    __shared__ DenseLdsV<BLK> lds;
-    densePieceV<BLK>(*T, *B, lds, blockIdx.x);
-}
+// (kUtrDesc, kDense: k_dense.hip; kCand: k_cand.hip; kTrellis: k_trellis.hip; kForward: k_forward.hip -- launch.h)
 __global__ void __launch_bounds__(64) kDenseBacktrace(const DevTables *T, BatchView B) { denseBacktracePiece(*T, B, blockIdx.x); }
 
-// ---- candidates of the variable-length states: one wavefront per tile of 64 bases (describe + count, reserve, evaluate) ----
-// (MULTI: some piece of the batch has more than one GC class -- the plane of every class-dependent array is then chosen per
-//  end base; batches without such a piece run the variant with the plane folded away)
-template <int BLK, bool MULTI, bool DENSE = false> __global__ void __launch_bounds__(NT, 4) kCand(const DevTables *__restrict__ T, const BatchView B) {
-    __shared__ CandLds lds; // (the batch view by value: its pointers are then known to be global, not generic)
-    candWorkgroup<BLK, MULTI, DENSE>(*T, B, lds, blockIdx.x);
-}
-
-// MODE 0: pass 1, one workgroup per segment (= per piece when no piece is cut); 1: the fix-ups; 2: continuation of pieces whose
-// fix-up gave up, one workgroup per piece (kernels.h: trellisPiece)
-template <int BLK, int MODE, bool TIES = false> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
-    __shared__ TrellisLds lds;
-    trellisPiece<BLK, MODE, TIES>(*T, *B, lds, blockIdx.x);
-}
 __global__ void __launch_bounds__(256) kTileCross(BatchView B) {
     const int64_t gt = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (gt < B.N / WAVE) tileCrossOne(B, gt);
@@ -396,10 +368,17 @@ __global__ void __launch_bounds__(256) kPatchItems(BatchView B, const uint64_t *
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) B.items[idx[i]].te = te[i];
 }
-template <int BLK> __global__ void __launch_bounds__(NT) kForward(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
-    __shared__ FwdLds lds;
-    forwardPiece<BLK>(*T, *B, lds, blockIdx.x);
-}
+
+// ---- launch.h: the family of a block size lives in its own translation unit ----
+namespace augx { namespace dev {
+#define AUGX_BY_BLK(f, ...) do { if (blk == 8) f##8(__VA_ARGS__); else if (blk == 4) f##4(__VA_ARGS__); else f##2(__VA_ARGS__); } while (0)
+void launchTrellis(int blk, int mode, bool ties, unsigned grid, hipStream_t st, const DevTables *T, const BatchView *B) { AUGX_BY_BLK(launchTrellis_, mode, ties, grid, st, T, B); }
+void launchCand(int blk, bool multi, bool dense, unsigned grid, hipStream_t st, const DevTables *T, const BatchView &W) { AUGX_BY_BLK(launchCand_, multi, dense, grid, st, T, W); }
+void launchForward(int blk, unsigned grid, hipStream_t st, const DevTables *T, const BatchView *B) { AUGX_BY_BLK(launchForward_, grid, st, T, B); }
+void launchDense(int blk, int mode, bool ties, unsigned grid, hipStream_t st, const DevTables *T, const BatchView *B) { AUGX_BY_BLK(launchDense_, mode, ties, grid, st, T, B); }
+void launchUtrDesc(int blk, unsigned grid, hipStream_t st, const DevTables *T, const BatchView &W) { AUGX_BY_BLK(launchUtrDesc_, grid, st, T, W); }
+#undef AUGX_BY_BLK
+}} // namespace
 
 // ---------------------------------------------------------------------------------------------------
 // host objects
@@ -423,10 +402,7 @@ struct augx_decoder {
     std::mutex poolMu;        // (another decoder of the same device may empty this pool when its own allocation fails)
     std::vector<hipStream_t> copyStreams; // (snippetCacheReplay: one per piece replayed at a time)
     bool dense = false;        // the model is decoded by the dense kernels (dense.h)
-    bool densePipe = false;    // AUGX_DENSE_PIPE=1: its Viterbi pass by densePieceV (densev.h: the candidates of a block evaluated while the block
-                               // before runs, loads through LDS landing pads).  Bit-identical, measured SLOWER than densePiece<BLK, 0> on MI355X
-                               // (166 against 112 ms, 256 x 40 kb): kept as the tested record of that design, off by default
-    bool countNearTies = false;    // the back-trace counts the near ties on the chosen paths (AUGX_TIMING, AUGX_NEAR_TIES=1, augx_decoder_count_near_ties)
+    bool countNearTies = false;    // the back-trace counts the near ties on the chosen paths (AUGX_NEAR_TIES=1, augx_decoder_count_near_ties)
     int64_t nearTies = 0, nearTiePieces = 0; // ... summed over the batches whose paths were fetched
     int64_t denseMultiForward = 0; // forward runs of the dense kernels over batches with a multi-class piece: no replay of the reference's caches there (augx_decoder_unreplayed_batches)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
@@ -620,8 +596,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
     d->device = device;
     d->blk = blk;
     d->dense = modelIsDense(t);
-    if (const char *e = getenv("AUGX_DENSE_PIPE")) d->densePipe = atoi(e) != 0;
-    d->countNearTies = getenv("AUGX_TIMING") != nullptr || (getenv("AUGX_NEAR_TIES") && atoi(getenv("AUGX_NEAR_TIES")) != 0);
+    d->countNearTies = getenv("AUGX_NEAR_TIES") && atoi(getenv("AUGX_NEAR_TIES")) != 0; // (NOT implied by AUGX_TIMING: timing runs time the product's default kernels)
     const char *dbg = getenv("AUGX_DEBUG_CELLS");
     d->debugCells = dbg && atoi(dbg) != 0;
     if (const char *ex = getenv("AUGX_EXACT_MULTICLASS")) d->exactMulti = atoi(ex) != 0;
@@ -948,18 +923,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             const bool multi = W.nPl > 1;
             if (utrDesc) {
                 const unsigned nGrp = (unsigned)(W.N / (NT / 16));
-                if (d->blk == 8) hipLaunchKernelGGL((kUtrDesc<8>), dim3(nGrp), dim3(NT), 0, st, d->dT, W);
-                else if (d->blk == 4) hipLaunchKernelGGL((kUtrDesc<4>), dim3(nGrp), dim3(NT), 0, st, d->dT, W);
-                else hipLaunchKernelGGL((kUtrDesc<2>), dim3(nGrp), dim3(NT), 0, st, d->dT, W);
+                launchUtrDesc(d->blk, nGrp, st, d->dT, W);
             }
-#define AUGX_LAUNCH_CAND(BLK_) do { if (d->dense) { if (multi) hipLaunchKernelGGL((kCand<BLK_, true, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
-                                                       else hipLaunchKernelGGL((kCand<BLK_, false, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); } \
-                                    else if (multi) hipLaunchKernelGGL((kCand<BLK_, true>), dim3(nWg), dim3(NT), 0, st, d->dT, W); \
-                                    else hipLaunchKernelGGL((kCand<BLK_, false>), dim3(nWg), dim3(NT), 0, st, d->dT, W); } while (0)
-            if (d->blk == 8) AUGX_LAUNCH_CAND(8);
-            else if (d->blk == 4) AUGX_LAUNCH_CAND(4);
-            else AUGX_LAUNCH_CAND(2);
-#undef AUGX_LAUNCH_CAND
+            launchCand(d->blk, multi, d->dense, nWg, st, d->dT, W);
             HIP_TRY(hipGetLastError());
             if (steady) break;
             CandAlloc tot;
@@ -1000,15 +966,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     HIP_TRY(hipEventRecord(b->ev[1], st));
     auto runTrellis = [&]() -> int { // the trellis passes and the back-trace (run again when candidate terms were rebuilt, see below)
     if (d->dense) { // the dense kernels: one workgroup per piece, the matrix in HBM (dense.h)
-        if (d->densePipe && d->blk == 4 && !V.nearTie) { // (the experimental pass is built for the block size of the UTR species only)
-            hipLaunchKernelGGL((kDenseV<4>), dim3(n), dim3(VNT), 0, st, d->dT, b->dV);
-        } else if (V.nearTie) { // (near ties are counted: the build whose chain runs flag them)
-            if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-            else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-            else hipLaunchKernelGGL((kDense<2, 0, true>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-        } else if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-        else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
-        else hipLaunchKernelGGL((kDense<2, 0>), dim3(n), dim3(NT), 0, st, d->dT, b->dV);
+        launchDense(d->blk, 0, V.nearTie, (unsigned)n, st, d->dT, b->dV); // (near ties counted: the build whose chain runs flag them)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(b->ev[2], st));
         hipLaunchKernelGGL(kDenseBacktrace, dim3(n), dim3(64), 0, st, d->dT, V);
@@ -1016,14 +974,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         return AUGX_OK;
     }
     HIP_TRY(hipMemsetAsync(V.segStatus, 0, sizeof(int32_t) * V.nSegs, st));
-#define AUGX_LAUNCH_TRELLIS(MODE_, grid_) do { \
-        if (V.nearTie) { /* (near ties are counted: the build of the kernel whose chain wavefront flags them) */ \
-            if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_, true>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
-            else if (d->blk == 4) hipLaunchKernelGGL((kTrellis<4, MODE_, true>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
-            else hipLaunchKernelGGL((kTrellis<2, MODE_, true>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
-        } else if (d->blk == 8) hipLaunchKernelGGL((kTrellis<8, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
-        else if (d->blk == 4) hipLaunchKernelGGL((kTrellis<4, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); \
-        else hipLaunchKernelGGL((kTrellis<2, MODE_>), dim3(grid_), dim3(NT), 0, st, d->dT, b->dV); } while (0)
+#define AUGX_LAUNCH_TRELLIS(MODE_, grid_) launchTrellis(d->blk, MODE_, V.nearTie, (unsigned)(grid_), st, d->dT, b->dV) // (near ties counted: the build whose chain wavefront flags them)
     AUGX_LAUNCH_TRELLIS(0, V.nSegs);                 // pass 1: every segment at once (one workgroup per piece when no piece is cut)
     if (b->plan.cut()) {
         HIP_TRY(hipMemsetAsync(V.segStop2, 0xFF, sizeof(int32_t) * V.nSegs, st));
@@ -1218,13 +1169,8 @@ static int augx_batch_forward_launch(augx_decoder *d, augx_batch *b) {
         W.fwd = (double *)p; W.lnFwd = (double *)q;
         HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, d->stream));
     }
-    if (d->dense) {
-        if (d->blk == 8) hipLaunchKernelGGL((kDense<8, 1>), dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
-        else if (d->blk == 4) hipLaunchKernelGGL((kDense<4, 1>), dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
-        else hipLaunchKernelGGL((kDense<2, 1>), dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
-    } else if (d->blk == 8) hipLaunchKernelGGL(kForward<8>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
-    else if (d->blk == 4) hipLaunchKernelGGL(kForward<4>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
-    else hipLaunchKernelGGL(kForward<2>, dim3(W.nPieces), dim3(NT), 0, d->stream, d->dT, b->dV);
+    if (d->dense) launchDense(d->blk, 1, false, (unsigned)W.nPieces, d->stream, d->dT, b->dV);
+    else launchForward(d->blk, (unsigned)W.nPieces, d->stream, d->dT, b->dV);
     HIP_TRY(hipGetLastError());
     return AUGX_OK;
 }
@@ -1558,6 +1504,9 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     }
     if (!H) H.reset(new augx_sample_prep());
     SamplePiece &P = H->P;
+    // (declared after H, so it runs BEFORE H is freed on every early return: copies still in flight on the non-blocking stream must
+    //  not land in host buffers that have been given back; on the way out of a successful call the stream is idle already)
+    struct CopyDrain { hipStream_t s; ~CopyDrain() { if (s) (void)hipStreamSynchronize(s); } } copyDrain{cst};
     {   // (an object that comes round: everything a piece sets only under a condition goes back to its default)
         P.plane.clear(); P.planeCls.clear(); P.uh.reset(); P.dense = false; P.hT = nullptr; P.hB = nullptr; P.hp = 0;
         P.igS = -1; P.termKind = 0; P.anyNuc = true; P.prepared = false; P.item0 = 0;

@@ -47,7 +47,8 @@ namespace dev {
 #define GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define AUGX_KFN __device__ __forceinline__
 #define FOR_THREADS(t) for (int t = (int)threadIdx.x, _once = 1; _once; _once = 0)
-#define FOR_WAVES(w) for (int w = (int)(threadIdx.x >> 6), _oncew = 1; _oncew; _oncew = 0)
+constexpr int RW = -1; // (EXPERIMENT: shadowed by a template parameter where the wavefront's index is a compile-time constant)
+#define FOR_WAVES(w) for (int w = (RW >= 0 ? RW : (int)(threadIdx.x >> 6)), _oncew = 1; _oncew; _oncew = 0)
 #define FOR_WLANES(t, w) for (int t = (int)threadIdx.x, _once = 1; _once; _once = 0)
 #define TV(T, name) T name[1]
 #define TV2(T, name, K) T name[K][1]
@@ -1599,7 +1600,7 @@ AUGX_KFN void trellisItems(TrellisCtx &X, int w, int buf, int blk, int jb, int l
 // MODE 2: pass 3 -- sg is a PIECE: its first fix-up that gave up and has not been redone continues from where it stopped, still
 // comparing, with no limit (one per launch; the piece's runs of this pass must not overlap);  MODE 3: such a fix-up continues
 // to the end of the piece without comparing (what is left after the launches of pass 3).
-template <int BLK, int MODE = 0, bool TIES = false> // TIES: the chain wavefront flags near ties (dp.h: AUGX_NEAR_TIE) -- a build of its own, the default kernel pays nothing for it
+template <int BLK, int MODE = 0, bool TIES = false, int RW = -1> // TIES: the chain wavefront flags near ties (dp.h: AUGX_NEAR_TIE) -- a build of its own, the default kernel pays nothing for it
 AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L, int sg) {
     constexpr int NB = WAVE / BLK;  // blocks per tile
     constexpr int SPR = WAVE / BLK; // state slots per round of 64 lanes: lane = (slot, base of the block)

@@ -213,6 +213,17 @@ struct augx_rand {
     }
 };
 
+// cycle counter of the draw loop's developer timing (AUGX_TIMING_SAMPLER=1 turns it on before the first piece; off: the loop pays one
+// predictable branch).  x86: the time-stamp counter; elsewhere: the steady clock in nanoseconds.
+inline bool &samplerTimingOn() { static bool on = getenv("AUGX_TIMING_SAMPLER") != nullptr; return on; }
+inline uint64_t samplerTicks() {
+    if (!samplerTimingOn()) return 0;
+#if defined(__x86_64__) || defined(__i386__)
+    return __builtin_ia32_rdtsc();
+#else
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+#endif
+}
 namespace augx {
 namespace dev {
 // the large arrays of a piece on the host (hundreds of MB): 2 MB pages where the kernel grants them -- in 4 KB pages the first
@@ -565,7 +576,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                     }
                     // down the state, stop after stop: between two stops a draw per base decides nothing; at a stop the draw is
                     // compared with the most probable option first -- as a rule the state itself, and the run goes on
-                    const uint64_t tk0 = __builtin_ia32_rdtsc();
+                    const uint64_t tk0 = samplerTicks();
                     const int top = base;
                     const double *cumA = P.stopCum[state].data();
                     const uint32_t *thrA = P.stopThr[state].data();
@@ -596,7 +607,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                         break;
                     }
                     cur[state] = c;
-                    P.tkChain += __builtin_ia32_rdtsc() - tk0;
+                    P.tkChain += samplerTicks() - tk0;
                     if (bad) break;
                     // (st runs 3'->5'; the steps of the run are one entry: the merged form the path is delivered in)
                     const int from = x ? x->base + 1 : 1;
@@ -605,7 +616,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                     if (x) { base = x->base; state = x->state; }
                     continue;
                 }
-                const uint64_t tk1 = __builtin_ia32_rdtsc();
+                const uint64_t tk1 = samplerTicks();
                 const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;
                 SamplerScratch::Ent *f = M.find(key + 1);
                 P.nVar++;
@@ -631,11 +642,11 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                 if (!x) { bad = true; break; }
                 st.push_back({x->base + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
                 base = x->base; state = x->state;
-                P.tkVar += __builtin_ia32_rdtsc() - tk1;
+                P.tkVar += samplerTicks() - tk1;
             }
             if (bad) { status[it] = AUGX_E_NOPATH; continue; }
         }
-        const uint64_t tk2 = __builtin_ia32_rdtsc();
+        const uint64_t tk2 = samplerTicks();
         std::vector<augx_state> &m2 = paths[it];
         for (size_t i = st.size(); i-- > 0;) {
             const augx_state &x = st[i];
@@ -644,7 +655,7 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
             if (chain && !m2.empty() && m2.back().state == x.state && m2.back().end + 1 == x.begin) m2.back().end = x.end;
             else m2.push_back(x);
         }
-        P.tkTail += __builtin_ia32_rdtsc() - tk2;
+        P.tkTail += samplerTicks() - tk2;
     }
 }
 } // namespace dev

@@ -565,12 +565,10 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
     for (;;) {
         std::vector<WinKey> keys;
         std::set<WinKey> asked;
-        size_t nOpen = 0;
-        for (size_t r = 0; r < recs.size(); r++) nOpen += !cs[r].done;
+        // the true chains first, as far as the decoded windows carry them ...
         for (size_t r = 0; r < recs.size(); r++) {
             CutState &c = cs[r];
             if (c.done) continue;
-            // the true chain, as far as the decoded windows carry it
             for (;;) {
                 CutState probe = c;
                 std::vector<PieceRef> emitted;
@@ -584,6 +582,13 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
                 if (hit->second.status != 0) { failStatus[r] = hit->second.status; c.done = true; break; } // the record's error
                 applyWindow(r, c, hit->second.path, &recPieces[r]);
             }
+        }
+        // ... then the batch's room is shared among the records that still wait for a window (short records finished above and
+        // do not count; every open record gets at least one window, however many there are: a chain must always advance)
+        size_t nOpen = 0;
+        for (size_t r = 0; r < recs.size(); r++) nOpen += !cs[r].done;
+        for (size_t r = 0; r < recs.size(); r++) {
+            CutState &c = cs[r];
             if (c.done) continue;
             // the forecast chains from here: every window they ask for that has not been decoded yet.  Limited-discrepancy order:
             // first the chain of first guesses to the end of the record, then the chains that leave it once (nearest round first),
@@ -593,7 +598,7 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
             std::priority_queue<Sim, std::vector<Sim>, decltype(later)> queue(later);
             queue.push({0, 0, c});
             std::set<std::tuple<long, int, int, int>> seen{{c.beginPos, c.attempt, c.prevInit, c.prevTerm}};
-            const size_t room = keys.size() + maxAsk / std::max<size_t>(1, nOpen);
+            const size_t room = keys.size() + std::max<size_t>(1, maxAsk / std::max<size_t>(1, nOpen));
             while (!queue.empty() && keys.size() < room) {
                 Sim cur = queue.top();
                 queue.pop();
@@ -640,7 +645,11 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
                 for (auto &path : forecasts(r, sim.es, sim.ee, sim.prevInit, sim.prevTerm)) { if (nv >= breadth) break; push(path, nv++ ? 1 : 0); }
             }
         }
-        if (keys.empty()) break;
+        if (keys.empty()) {
+            for (size_t r = 0; r < recs.size(); r++)
+                if (!cs[r].done) { setLastError("cut finder: no exam window could be asked for record " + std::to_string(r) + " (internal error)"); return false; }
+            break;
+        }
         std::vector<augx_piece> ex;
         std::vector<std::string> copies;
         copies.reserve(keys.size());
@@ -984,7 +993,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             std::cerr << "augustus (MI355X): note: pieces with more than one GC-content class were sampled with the UTR model; a few posterior probabilities near the "
                          "class steps may differ slightly from the CPU reference's (the predicted genes do not)." << std::endl;
     }
-    if (timing) {
+    if (timing && getenv("AUGX_NEAR_TIES") && atoi(getenv("AUGX_NEAR_TIES")) != 0) { // (counted by a kernel build of its own: asked for by name, not implied by AUGX_TIMING)
         int64_t nt = 0, np = 0;
         for (augx_decoder *d : S.decs) { int64_t q = 0; nt += augx_decoder_near_ties(d, &q); np += q; }
         fprintf(stderr, "augx timing:   near ties on the chosen paths (exam windows and pieces): %lld cells in %lld decodes\n", (long long)nt, (long long)np);

@@ -221,7 +221,7 @@ int64_t augx_decoder_unreplayed_batches(const augx_decoder *d);
  * runs a build of the kernels of its own (about 1.5 % slower); off by default. */
 int augx_decoder_count_near_ties(augx_decoder *d, int on);
 int64_t augx_decoder_near_ties(const augx_decoder *d, int64_t *pieces /* may be NULL */);
-/* host buffers kept between sampled pieces (forward matrices, at most 8 GB) are released when the last decoder is destroyed, or here */
+/* host buffers kept between sampled pieces (forward matrices, at most 12 GB) are released when the last decoder is destroyed, or here */
 void augx_release_host_pools(void);
 int64_t augx_decoder_batch_capacity(augx_decoder *d);
 

@@ -13,7 +13,6 @@
 #include <vector>
 #include "../../augustus_amd/csrc/device/kernels.h"
 #include "../../augustus_amd/csrc/device/dense.h"
-#include "../../augustus_amd/csrc/device/densev.h"
 #include "../../augustus_amd/csrc/device/layout.h"
 #include "../../augustus_amd/csrc/device/sampler.h"
 #include "../../augustus_amd/csrc/device/snipmemo.h"
@@ -204,10 +203,6 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     for (int p = 0; p <= n; p++) seg0[p] = p;
     B.pieceSeg0 = seg0.data(); B.nSegs = n;
     DenseLds *dl = new DenseLds();
-    DenseLdsV<8> *dv8 = new DenseLdsV<8>();
-    DenseLdsV<4> *dv4 = new DenseLdsV<4>();
-    DenseLdsV<2> *dv2 = new DenseLdsV<2>();
-    const bool pipe = getenv("AUGX_DENSE_PIPE") && atoi(getenv("AUGX_DENSE_PIPE")) != 0; // (the product's switch: 1 = the Viterbi pass with the work done ahead, densev.h)
     // the reference's snippet cache around the class steps of a piece (snipmemo.h), from which cells of the matrix `mat` are alive:
     // the candidate terms concerned are rebuilt in place; true: some were, the pass has to run once more
     auto snippetReplay = [&](int p, const double *mat) -> bool {
@@ -239,8 +234,7 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     };
     const bool exact = !getenv("AUGX_EXACT_MULTICLASS") || atoi(getenv("AUGX_EXACT_MULTICLASS")) != 0; // (augx_decoder_set_exact, on by default)
     auto viterbiPiece = [&](int p) {
-        if (pipe) { if (blk == 8) densePieceV<8>(T, B, *dv8, p); else if (blk == 4) densePieceV<4>(T, B, *dv4, p); else densePieceV<2>(T, B, *dv2, p); }
-        else if (blk == 8) densePiece<8, 0, true>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0, true>(T, B, *dl, p); else densePiece<2, 0, true>(T, B, *dl, p);
+        if (blk == 8) densePiece<8, 0, true>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0, true>(T, B, *dl, p); else densePiece<2, 0, true>(T, B, *dl, p);
     };
     for (int p = 0; p < n; p++) {
         viterbiPiece(p);

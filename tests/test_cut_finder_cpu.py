@@ -79,3 +79,37 @@ def test_decode_failure_is_reported():
     fn = ax.DECODE_FN(lambda user, pieces, n, out: ax.AUGX_E_HIP)
     with pytest.raises(ax.AugxError):
         ax.find_cuts(m, [random_dna(200000, 1)], fn, scout=0)
+
+
+def all_intergenic_decode_fn(log):
+    """a decode function that calls every piece one intergenic run (state 0, type 0): the chain logic alone"""
+    def fn(user, pieces, n, out):
+        log.append(n)
+        for i in range(n):
+            out[i].status, out[i].ln_viterbi, out[i].n_states = 0, -1.0, 1
+            arr = ctypes.cast(libc.malloc(ctypes.sizeof(ax._State)), ctypes.POINTER(ax._State))
+            arr[0].begin, arr[0].end, arr[0].state, arr[0].type = 0, pieces[i].len - 1, 0, 0
+            out[i].states = arr
+        return 0
+    return ax.DECODE_FN(fn)
+
+
+@pytest.mark.parametrize("scout", [0, 1, -1])
+@pytest.mark.parametrize("ask,recs", [(None, ["A" * 1000] * 300 + ["C" * 200000]),      # more open records than a batch has room for
+                                      ("1", ["A" * 150000, "C" * 200000, "G" * 500]),   # room for one window, two long records
+                                      (None, ["A" * 1000] * 200 + ["C" * 400000])])    # short records must not eat the long one's share
+def test_every_open_record_gets_a_window(monkeypatch, scout, ask, recs):
+    """round-4 advisor finding: `room = maxAsk / nOpen` was 0 with more than maxAsk unfinished records (short ones included), no
+    window was asked, and the long records were left without pieces while the call returned success"""
+    if ask:
+        monkeypatch.setenv("AUGX_CUT_ASK", ask)
+    m = ax.Model(config_path(), "human", maxDNAPieceSize="60000")
+    log = []
+    cuts, st = ax.find_cuts(m, recs, all_intergenic_decode_fn(log), scout=scout)
+    for r, s in enumerate(recs):
+        ps = [c for c in cuts if c[0] == r]
+        assert ps and ps[0][2] == 0 and ps[-1][3] == len(s) - 1 and all(a[3] + 1 == b[2] for a, b in zip(ps, ps[1:])), r
+        assert all(c[3] - c[2] + 1 <= 60000 for c in ps)
+    assert st["windows_used"] >= sum(len(s) // 60000 for s in recs if len(s) > 60000)
+    if ask is None and scout == 0 and len(recs) == 201:
+        assert st["batches"] == st["windows_decoded"] == st["windows_used"] == 10   # (one window per round for the one open record: cuts every 35 kb)

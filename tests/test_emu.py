@@ -565,29 +565,6 @@ def test_emulated_utr_alternatives_drop_almost_identical_transcripts(tmp_path, s
         assert norm(out) == norm(refl)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"AUGX_EMU_DQCAP": "1"}, {"AUGX_EMU_ITEMCAP": "20", "AUGX_EMU_UDCAP": "2"}])
-def test_emulated_dense_viterbi_with_the_work_done_ahead(monkeypatch, knobs):
-    """device/densev.h (AUGX_DENSE_PIPE=1): the candidates of block b + 1 evaluated while block b runs, through landing pads and a
-    queue of the candidates whose predecessor is too near -- every cell equal to the oracle's, also when the queue, the descriptor
-    stage or the records per thread run over and a block falls back to evaluating in place (the emulator's knobs force that)"""
-    monkeypatch.setenv("AUGX_DENSE_PIPE", "1")
-    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
-    ex = dict(golden_inputs())
-    for species, opts in (("fly", {"sample": "0"}), ("human", {"UTR": "on", "sample": "0"}), ("human", {"genemodel": "atleastone", "sample": "0"})):
-        m = ax.Model(config_path(), species, **opts)
-        S = m.n_states
-        seqs = [ex["HS04636"], ex["trunc_both"], random_dna(14000, 5), "N" * 700 + random_dna(5000, 6) + "N" * 90, random_dna(23, 7)]
-        for ik, tk in ((0, 0), (1, 1)):
-            res = emu_decode(m.tables_ptr, seqs, S, cells=True, init_kind=ik, term_kind=tk)
-            for s, r in zip(seqs, res):
-                rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True, init_kind=ik, term_kind=tk)
-                assert (r[0] == 0) == (rc == 0)
-                if rc == 0:
-                    assert r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path] and np.array_equal(r[3], V)
-
-
 @needs_ref
 @pytest.mark.parametrize("opts,exact", [({"genemodel": "exactlyone", "softmasking": "0"}, True), ({"UTR": "on", "softmasking": "0"}, False)])
 def test_emulated_dense_kernels_with_several_gc_classes_against_the_reference(tmp_path, opts, exact):

@@ -322,7 +322,7 @@ def test_cli_near_tie_counter(tmp_path):
     """DESIGN.md 6, near ties: every model term is rounded once to 2^-31, so two alternatives whose scores are closer than ~2e-7 may be
     decided the other way by the reference.  The trellis flags the cells of the chain states (intergenic, geometric introns) where
     staying and coming in from another state were that close, the back-trace counts those on the chosen path and, for the
-    variable-length states on it, the cells whose runner-up candidate was that close (AUGX_TIMING prints the sum; C ABI
+    variable-length states on it, the cells whose runner-up candidate was that close (AUGX_NEAR_TIES=1 AUGX_TIMING=1 prints the sum; C ABI
     augx_decoder_near_ties).  The reference's own example has none and the same GFF.  The one input known to differ from the reference
     (tests/soak_cli.py, case 5010: two copies of one single-exon gene 164 bases apart, in exact arithmetic a tie) IS counted."""
     import re
@@ -332,7 +332,7 @@ def test_cli_near_tie_counter(tmp_path):
     fa2 = str(tmp_path / "ex.fa")
     write_fasta(fa2, ex)
     ref2 = subprocess.run([REF_AUGUSTUS, "--species=human", fa2], capture_output=True, text=True, env=env)
-    ours2 = subprocess.run([EXE, "--species=human", fa2], capture_output=True, text=True, env=dict(env, AUGX_TIMING="1"))
+    ours2 = subprocess.run([EXE, "--species=human", fa2], capture_output=True, text=True, env=dict(env, AUGX_TIMING="1", AUGX_NEAR_TIES="1"))
     m2 = re.search(r"near ties on the chosen paths[^:]*: (\d+) cells", ours2.stderr)
     assert gff_body(ours2.stdout) == gff_body(ref2.stdout) and m2 and int(m2.group(1)) == 0
     _, g = soak_cli.real_dna()
@@ -341,7 +341,7 @@ def test_cli_near_tie_counter(tmp_path):
     write_fasta(fa, recs)
     args = ["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()] + [fa]
     ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
-    ours = subprocess.run([EXE] + args, capture_output=True, text=True, env=dict(env, AUGX_TIMING="1"))
+    ours = subprocess.run([EXE] + args, capture_output=True, text=True, env=dict(env, AUGX_TIMING="1", AUGX_NEAR_TIES="1"))
     assert ref.returncode == 0 and ours.returncode == 0, ours.stderr[-400:]
     m = re.search(r"near ties on the chosen paths[^:]*: (\d+) cells in (\d+) decodes", ours.stderr)
     assert m, ours.stderr[-400:]

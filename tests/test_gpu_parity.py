@@ -103,11 +103,10 @@ def test_cli_gff_identical_to_reference(tmp_path):
         assert gff_body(r.stdout) == golden_gff(cfg) and r.stderr == ""
 
 
+@needs_ref
 def test_cli_piece_cutting_matches_reference(tmp_path):
     """contig longer than maxDNAPieceSize: cut chain + synch-state pieces + global gene numbering"""
     exe = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
-    if not os.path.exists(REF_AUGUSTUS):
-        pytest.skip("oracle/_ref not present")
     fa = str(tmp_path / "long.fa")
     ex = dict(golden_inputs())["HS04636"]
     # two records with cut chains of different length (the exam windows of all unfinished records are decoded together),
@@ -126,12 +125,11 @@ def test_cli_piece_cutting_matches_reference(tmp_path):
 @pytest.mark.parametrize("extra", [["--strand=forward"], ["--strand=backward"], ["--predictionStart=2001", "--predictionEnd=8000"],
                                    ["--predictionStart=3000"], ["--gff3=on", "--introns=on", "--strand=minus"], ["--gff3=on", "--introns=on", "--strand=backward"],
                                    ["--softmasking=0", "--codingseq=on", "--exonnames=on"]])
+@needs_ref
 def test_cli_options_match_reference(tmp_path, extra):
     """command-line options of the path (strand filter, prediction range with coordinate offset, output variants):
     stdout of the prediction part byte-identical to the reference binary, empty stderr"""
     exe = os.path.join(ROOT, "augustus_amd", "bin", "augustus")
-    if not os.path.exists(REF_AUGUSTUS):
-        pytest.skip("oracle/_ref not present")
     recs = golden_inputs()
     byname = dict(recs)
     fa = str(tmp_path / "opt.fa")

@@ -33,24 +33,6 @@ def test_gpu_utr_cells_bit_identical_to_oracle(species, opts):
         assert np.array_equal(b.cells(i), V), i
 
 
-@pytest.mark.parametrize("species,opts", [("human", {"UTR": "on"}), ("fly", {"sample": "0"})])   # (built for the UTR species' block size, 4)
-def test_gpu_dense_viterbi_with_the_work_done_ahead(monkeypatch, species, opts):
-    """AUGX_DENSE_PIPE=1: the Viterbi pass that evaluates the candidates of block b + 1 while block b runs (device/densev.h, loads
-    through LDS landing pads): every cell, score and path equal to the oracle's, i.e. to the default pass'"""
-    monkeypatch.setenv("AUGX_DENSE_PIPE", "1")
-    monkeypatch.setenv("AUGX_EXACT_MULTICLASS", "0")  # (this pass on its own)
-    m = ax.Model(config_path(), species, **opts)
-    d = ax.Decoder(m, 0)
-    S = m.n_states
-    seqs = [s for _, s in golden_inputs()] + [random_dna(60000, 11), random_dna(5000, 12).lower(), random_dna(100, 13), "N" * 3000 + random_dna(9000, 14)]
-    b = ax.Batch(d, seqs)
-    b.decode()
-    for i, (s, r) in enumerate(zip(seqs, b.paths())):
-        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
-        assert r.status == rc and (rc != 0 or (r.ln_viterbi == lnv and r.states == path)), i
-        assert rc != 0 or np.array_equal(b.cells(i), V), i
-
-
 @needs_ref
 @pytest.mark.parametrize("species,opts,multi", [("fly", {}, False), ("human", {"UTR": "on", "softmasking": "0"}, False),
                                                 ("human", {"genemodel": "exactlyone", "softmasking": "0"}, True)])
