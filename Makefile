@@ -41,11 +41,15 @@ $(OBJ)/%.o: $(SRC)/%.cc $(HOSTHDR) $(SRC)/device/layout.h $(SRC)/device/dp.h
 augustus_amd/libaugx.so: $(HOSTOBJS) $(OBJ)/decoder.o $(KOBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
 
-# developer build with the cycle counters of the trellis wavefronts (AUGX_PROF=1): objects of its own
+# developer builds, objects of their own, loaded instead of the product library when AUGX_LIB names them:
+#   make prof                                   cycle counters of the trellis wavefronts (AUGX_PROF=1) -> augustus_amd/libaugx_prof.so
+#   make variant NAME=x FLAGS="-DAUGX_..."      any other set of build-time switches             -> augustus_amd/libaugx_x.so
 prof:
-	$(MAKE) OBJ=build/obj_prof PRODFLAGS=-DAUGX_PROFILE build/obj_prof/libaugx_prof.so
-	cp build/obj_prof/libaugx_prof.so augustus_amd/libaugx_prof.so
-build/obj_prof/libaugx_prof.so: $(HOSTOBJS) $(OBJ)/decoder.o $(KOBJS)
+	$(MAKE) variant NAME=prof FLAGS=-DAUGX_PROFILE
+variant:
+	$(MAKE) OBJ=build/obj_$(NAME) PRODFLAGS="$(FLAGS)" build/obj_$(NAME)/libaugx_variant.so
+	cp build/obj_$(NAME)/libaugx_variant.so augustus_amd/libaugx_$(NAME).so
+$(OBJ)/libaugx_variant.so: $(HOSTOBJS) $(OBJ)/decoder.o $(KOBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
 
 augustus_amd/bin/augustus: $(SRC)/augustus_main.cc augustus_amd/libaugx.so
@@ -72,4 +76,4 @@ ref:
 
 clean:
 	rm -rf build augustus_amd/libaugx.so augustus_amd/bin oracle/libghmm_twin.so
-.PHONY: all product prof oracle emu ref clean
+.PHONY: all product prof variant oracle emu ref clean

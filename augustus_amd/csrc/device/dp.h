@@ -46,7 +46,18 @@ constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4
 constexpr int CHUNK = 1024;     // slots per scan chunk; every piece is padded to a multiple of CHUNK
 constexpr int LONG_RING = 1024; // ring depth for the states consumed at lag dStateLen (must exceed it)
 constexpr uint16_t BP_NONE = 0xFFFF;
-constexpr int CODE_WIN = 1024, NS_WIN = 128, CNT_WIN = 1024, VIG_WIN = 512, LIST_WIN = 256, FX_WIN = 128, ATG_WIN = 64; // LDS window sizes (powers of 2)
+// LDS window sizes (powers of 2).  The trellis' windows (igenic column, list values, staged candidates) may be set at build time
+// (experiments with the LDS footprint of kTrellis: what does not fit a window is read back from HBM, the paths exist and are tested)
+#ifndef AUGX_VIG_WIN
+#define AUGX_VIG_WIN 512
+#endif
+#ifndef AUGX_LIST_WIN
+#define AUGX_LIST_WIN 256
+#endif
+#ifndef AUGX_ITEM_CAP
+#define AUGX_ITEM_CAP 2048
+#endif
+constexpr int CODE_WIN = 1024, NS_WIN = 128, CNT_WIN = 1024, VIG_WIN = AUGX_VIG_WIN, LIST_WIN = AUGX_LIST_WIN, FX_WIN = 128, ATG_WIN = 64;
 constexpr int LEN_WIN = 384;    // exon length-distribution entries cached in LDS (longer exons read the HBM table)
 constexpr int LENI_MAX = 1024;  // intron length distribution cached in LDS when d < LENI_MAX
 

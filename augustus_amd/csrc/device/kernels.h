@@ -1265,7 +1265,7 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 // =================================================================================================
 constexpr int NWORK = 3, W_C = 3, W_X = 4, W_I = 5, W_LOAD = 6; // trellis workgroup: wavefronts 0..2 workers, 3 near/late + geometric states, 4 far fixed-lag states, 5 igenic, 6.. loaders
 constexpr int LOAD_T = (8 - W_LOAD) * WAVE;                     // threads of the loader wavefronts
-constexpr int ITEM_CAP = 2048;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
+constexpr int ITEM_CAP = AUGX_ITEM_CAP;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
 
 struct TrellisLds {
     double ring[WAVE][SP];          // ln V of the last 64 columns, [j & 63][state]

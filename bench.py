@@ -374,16 +374,36 @@ def product_leg(cfg, a, n_dev):
                     if k < len(arr):
                         f.write(arr[k:].tobytes() + b"\n")
 
-        def run(args, fa, bases, reps=2):
+        def run(args, fa, bases, reps=2, golden=None):
+            """golden: key of tests/golden/golden_long.json -- the run is made with --progress=true and its cut points + GFF are
+            compared (sha256) with what the REFERENCE binary printed for the same input (tests/golden/make_golden_long.py)"""
             env = dict(os.environ, AUGUSTUS_CONFIG_PATH=cfg, AUGX_DEVICES=str(n_dev), AUGX_TIMING="1")
             best = None
+            want = None
+            if golden:
+                try:
+                    want = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_long.json"))).get(golden)
+                except OSError:
+                    want = None
             for _ in range(reps):
                 t0 = time.perf_counter()
-                r = subprocess.run([exe] + args + ["--outfile=" + os.path.join(d, "o.gff"), fa], capture_output=True, env=env)
+                r = subprocess.run([exe] + args + (["--progress=true"] if want else []) + ["--outfile=" + os.path.join(d, "o.gff"), fa], capture_output=True, env=env)
                 dt = time.perf_counter() - t0
-                laps = parse_timing(r.stderr.decode(errors="replace"))
-                if best is None or dt < best["wall_s"]:
+                err = r.stderr.decode(errors="replace")
+                laps = parse_timing(err)
+                parity = None
+                if want and r.returncode == 0:
+                    import hashlib
+                    from helpers import gff_body
+                    txt = "\n".join([l for l in err.splitlines() if l.startswith("examining piece")] + gff_body(open(os.path.join(d, "o.gff")).read())) + "\n"
+                    parity = hashlib.sha256(txt.encode()).hexdigest() == want["sha256"]
+                if best is None or dt < best["wall_s"] or parity is False:
                     best = {"value": bases / 1e6 / dt, "unit": "Mbp/s", "wall_s": dt, "returncode": r.returncode, "laps_s": laps}
+                    if want:
+                        best["parity"] = parity
+                        best["parity_against"] = "reference binary's cut points + GFF on the same %d bp contig (tests/golden/golden_long.json: %s)" % (bases, golden)
+                if parity is False:
+                    break
             return best
         contigs = synth_contigs(a.contigs, a.contig_len, SEED0)
         fa = os.path.join(d, "c3.fa")
@@ -415,7 +435,8 @@ def product_leg(cfg, a, n_dev):
                                 ("long_contig_utr", ["--species=fly", "--UTR=on", "--sample=0", "--softmasking=0"], 250000)):
             if key == "long_contig_utr" and a.no_long_utr:
                 continue
-            r2 = run(flags, fb, a.long_contig_len, reps=2 if key == "long_contig" else 1)
+            r2 = run(flags, fb, a.long_contig_len, reps=2 if key == "long_contig" else 1,
+                     golden=({"long_contig": "long", "long_contig_utr": "long_utr"}[key] if a.long_contig_len == 23000000 else None))
             r2["workload"] = "1 contig x %d bp uniform-random, %s (200 kb pieces, ~%d cut-finder rounds), %d device(s)" % (a.long_contig_len, " ".join(flags), rounds, n_dev)
             if not a.no_cpu_baseline and os.path.exists(REF_AUGUSTUS):
                 r2["cpu_baseline"] = ref_rate(flags, nbp)

@@ -17,7 +17,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 TWIN_LIB = os.path.join(ROOT, "oracle", "libghmm_twin.so")
 REF_HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 REF_AUGUSTUS = os.path.join(ROOT, "oracle", "_ref", "augustus_ref")
-EMU_LIB = os.path.join(ROOT, "build", "libaugx_emu.so")
+EMU_LIB = os.environ.get("AUGX_EMU_LIB") or os.path.join(ROOT, "build", "libaugx_emu.so")  # (AUGX_EMU_LIB: the emulator built with other build-time switches)
 
 # tests that compare with the REAL reference (oracle/_ref, built by oracle/Makefile where /root/reference exists; the binaries
 # travel to the GPU box with the working tree).  Without them such a test is skipped on the CPU -- and FAILS in the GPU suite or
