@@ -1285,7 +1285,7 @@ struct TrellisLds {
     double col0[SP];                // column 0 (initial probabilities)
     uint8_t gcw[2][WAVE];           // plane (GC class) of the bases of the current / next tile (multi-class pieces only)
     int flagSum;                     // sum of flagI[]: the workers are never more than one block apart, so flagSum >= NWORK * k <=> every flagI >= k
-    int flagF[NWORK], flagI[NWORK], flagL, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
+    int flagF[NWORK], flagI[NWORK], flagG, flagNr, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     int abortFlag;
     // fix-up pass of a segment (trellisPiece<BLK, 1>): what pass 1 left at the end of the current tile, the offsets new - old
     // of the last tiles, and the last tile whose retired values did not all differ from the old ones by the tile's offset
@@ -1682,6 +1682,18 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     bool geoLight = true; // every geometric intron state has at most two ancestors (the usual graph: equalD and itself)
     for (int s2 = 0; s2 < S; s2++)
         if (T.reachable[s2] && (T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC) && T.n_anc[s2] > 2) geoLight = false;
+    // a geometric intron state fed by a NEAR fixed-lag state (equalD with a short dStateLen): its pass over a block then follows
+    // the near step of that block, which the workers do (below); no shipped species with the standard graph at block size 8
+    bool nearFeedsGeo = false;
+    for (int s2 = 0; s2 < S; s2++) {
+        if (!T.reachable[s2] || !(T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC)) continue;
+        for (int ai = 0; ai < T.n_anc[s2]; ai++) {
+            const int ak = T.kind[T.anc[s2][ai]];
+            const int lagA = (ak == AUGX_K_LONGDSS || ak == AUGX_K_RLONGDSS) ? dssWhole : (ak == AUGX_K_LONGASS || ak == AUGX_K_RLONGASS) ? assLag
+                             : (ak == AUGX_K_EQUALD || ak == AUGX_K_REQUALD) ? dL : 1 << 20;
+            if (lagA < 3 * BLK) nearFeedsGeo = true;
+        }
+    }
     // the far step of block b reads cells back to base b*BLK + BLK-1 - farMinLag; among them RTERMINAL cells, which exist
     // only once the igenic cells of their own block do: igenic must be complete up to that block (farNeedC)
     int farMinLag = 1 << 20;
@@ -1779,7 +1791,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         if (t == 0) { // (the progress counters count blocks / tiles of the PIECE: a run that starts at tile tStart starts them there)
             const int gb0 = tStart * NB;
             for (int i = 0; i < NWORK; i++) { L.flagF[i] = gb0; L.flagI[i] = gb0; }
-            L.flagL = gb0; L.flagC = gb0; L.flagN = gb0; L.flagR = tStart; L.staged = (NWAVES - W_LOAD) * tStart; L.rtPub = 0; L.abortFlag = 0; L.flagSum = NWORK * gb0;
+            L.flagG = gb0; L.flagNr = gb0; L.flagC = gb0; L.flagN = gb0; L.flagR = tStart; L.staged = (NWAVES - W_LOAD) * tStart; L.rtPub = 0; L.abortFlag = 0; L.flagSum = NWORK * gb0;
             L.lastBad = tStart - 1;
             for (int i = 0; i < 4; i++) L.segDt[i] = 0.0;
         }
@@ -2114,15 +2126,18 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // ---- the trellis wavefronts walk the blocks of the tile, each at its own pace (progress flags in LDS).  Block b:
         //   far wavefront    (0) fixed-lag states that read blocks <= b-3 only (lag >= 24, equalD) and the cell resets of b;
         //                        runs up to two blocks ahead of the workers
-        //   chain wavefront  (1) near and late fixed-lag states of b (longdss: exon cells at lag 9; rlongdss: also a chain
-        //                        state at lag 9), after the candidates of b-1
-        //   chain wavefront  (3) one pass over the chain states: geometric introns of b (after (0): they are fed by equalD
-        //                        only) and igenic of b-1 (fed by the exon cells of b-1) -- igenic lags one block because
-        //                        no candidate reads an igenic cell less than igSlack >= 2 blocks back (else: safe mode)
-        //   workers 0..2     (4) a third each of the candidates of b, after (0) and (1)
+        //   chain wavefront  (3) the geometric intron states of b (after (0): they are fed by far fixed-lag states and
+        //                        themselves only), off the cycle
+        //   igenic wavefront (3') igenic of b-1 (fed by the exon cells of b-1) -- igenic lags one block because no candidate
+        //                        reads an igenic cell less than igSlack >= 2 blocks back (else: safe mode)
+        //   workers 0..2     (1) the near and late fixed-lag states of b (longdss: exon cells at lag 9; rlongdss: also a chain
+        //                        state at lag 9), EVERY worker for itself -- they read nothing of block b, so the three get the
+        //                        same bits and store them to the same cells --, then (4) a third each of the candidates of b
         //   far wavefront        also does the RTERMINAL candidates (they may start at an igenic cell of their own block)
         //                        of every block whose igenic cells are complete
-        // so that the cycle is candidates(b) -> near/late fixed-lag(b+1) -> candidates(b+1), with the chain states off it.
+        // so that the cycle is  workers done with b (flagSum) -> near/late fixed-lag(b+1) -> candidates(b+1)  on the workers
+        // alone: ONE hand-off per block.  (Rounds 1-4 had the near step on the chain wavefront: candidates(b) -> hand-off -> near
+        // step -> hand-off -> candidates(b+1), 5.1 k cycles per block of which 2.5 k the near step and its two hand-offs.)
         PROF_MARK(X, 0);
         int nb = 0;
         for (int blk = 0; blk < NB && j0 + blk * BLK < n; blk++) {
@@ -2134,6 +2149,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (w == W_X && gbk >= farPre) { // (0) far fixed-lag states (lag >= 3 blocks, equalD) and cell resets of block b: may run two blocks ahead
                     waitFlag(L, &L.flagSum, NWORK * (gbk - 2));
                     PROF_MARK(X, 1);
+                    waitFlag(L, &L.flagG, gbk - 2);       // (the chain cells it reads lie in blocks <= b-3)
                     waitFlag(L, &L.flagC, farNeedC(gbk)); // (lag 40 at block size 8: b-4, implied by the wait above; lag 39: b-3)
                     rtCatchUp(w, buf, tile, readFlag(&L.flagC), jb); // RTERMINAL candidates of the blocks whose igenic cells are complete
                     PROF_MARK(X, 3);
@@ -2143,30 +2159,24 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
             }
             FOR_WAVES(w) {
-                if (w == W_C) { // (1)
-                    waitFlag(L, &L.flagSum, NWORK * gbk); // (one poll instead of three: this hand-off is on the critical cycle)
-                    if (wantCells && blk > 0) dumpVarCells(w, jb - BLK, false);
-                    PROF_MARK(X, 1);
-                    PROF_STAMP(X, gbk, 6);
-                    fixedStep(w, buf, jb, 3, 0, nearRounds); // near (class 0) and late (class 1) states
-                    waitFlag(L, &L.flagN, gbk + 1); // (the far step runs ahead: flagL then also tells the workers that it is done)
-                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */ setFlag(&L.flagL, gbk + 1);
-                    PROF_STAMP(X, gbk, 7);
-                    PROF_MARK(X, 2);
+                if (w == W_C && wantCells && blk > 0) { // (debug cells) the variable-length cells of block b-1 are final
+                    waitFlag(L, &L.flagSum, NWORK * gbk);
+                    dumpVarCells(w, jb - BLK, false);
                 }
             }
-            FOR_WAVES(w) {
-                if (w == W_C) { // (3) geometric intron states of block b (fed by fixed-lag states and themselves only)
-                    waitFlag(L, &L.flagN, gbk + 1);
-                    PROF_MARK(X, 1);
-                    PROF_STAMP(X, gbk, 8);
-                    if (geoLight) chainPass(std::integral_constant<int, 2>{}, w, buf, -1, jb);
-                    else chainPass(std::integral_constant<int, 5>{}, w, buf, -1, jb);
-                    if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */
-                    PROF_STAMP(X, gbk, 9);
-                    PROF_MARK(X, 3);
-                }
-            }
+            auto geoStep = [&](int w) { // (3) geometric intron states of block b
+                waitFlag(L, &L.flagN, gbk + 1);
+                if (nearFeedsGeo) waitFlag(L, &L.flagNr, gbk + 1);
+                PROF_MARK(X, 1);
+                PROF_STAMP(X, gbk, 8);
+                if (geoLight) chainPass(std::integral_constant<int, 2>{}, w, buf, -1, jb);
+                else chainPass(std::integral_constant<int, 5>{}, w, buf, -1, jb);
+                if (wantCells) drainStores(); /* debug cells: keep the global stores of different wavefronts to one cell in order */
+                setFlag(&L.flagG, gbk + 1);
+                PROF_STAMP(X, gbk, 9);
+                PROF_MARK(X, 3);
+            };
+            FOR_WAVES(w) { if (w == W_C && !nearFeedsGeo) geoStep(w); }
             FOR_WAVES(w) {
                 if (w == W_I) { // (3') igenic of block b-1, fed by its exon cells: off the cycle, on a wavefront of its own
                     waitFlag(L, &L.flagSum, NWORK * gbk);
@@ -2176,8 +2186,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 }
             }
             FOR_WAVES(w) {
-                if (w < NWORK) { // (4)
-                    waitFlag(L, &L.flagL, gbk + 1); // (implies flagN >= gbk + 1, see (1))
+                if (w < NWORK) { // (1) + (4)
+                    waitFlag(L, &L.flagSum, NWORK * gbk); // every worker is done with block b-1: the one hand-off of the cycle
+                    waitFlag(L, &L.flagG, gbk);           // (late states: chain cells of blocks <= b-1)
+                    PROF_MARK(X, 1);
+                    if (w == 0) PROF_STAMP(X, gbk, 6);
+                    fixedStep(w, buf, jb, 3, 0, nearRounds); // near (class 0) and late (class 1) states
+                    if (nearFeedsGeo && w == 0) setFlag(&L.flagNr, gbk + 1);
+                    if (w == 0) PROF_STAMP(X, gbk, 7);
+                    PROF_MARK(X, 2);
+                    waitFlag(L, &L.flagN, gbk + 1); // the far step of the block (cell resets) is done; it runs ahead
                     waitFlag(L, &L.flagC, safeIg ? gbk : gbk - 1); // igenic: no candidate reads a cell less than two blocks back (safe mode: one)
                     PROF_MARK(X, 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 2 : 4);
@@ -2189,6 +2207,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     PROF_MARK(X, 2);
                 }
             }
+            FOR_WAVES(w) { if (w == W_C && nearFeedsGeo) geoStep(w); } // (after the near step of the block, which feeds it)
         }
         FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 10); }
         // ---- end of the tile: igenic of the last block, then the RTERMINAL candidates of the last two blocks
@@ -2217,6 +2236,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 if (!CMP && tile + 1 < tEnd && jbN < n) { // (a fix-up may stop after any tile: it must not touch the next one)
                     waitFlag(L, &L.staged, (NWAVES - W_LOAD) * (tile + 1));
                     waitFlag(L, &L.flagSum, NWORK * (gN - 2));
+                    waitFlag(L, &L.flagG, gN - 2);
                     waitFlag(L, &L.flagC, farNeedC(gN));
                     rtCatchUp(w, buf, tile, readFlag(&L.flagC), j0 + nb * BLK);
                     farStep(w, buf ^ 1, jbN);

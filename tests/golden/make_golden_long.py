@@ -125,6 +125,8 @@ def main():
         meta[cfg] = {"flags": LONG_CFGS[cfg], "sha256": hashlib.sha256(txt.encode()).hexdigest(),
                      "lines": txt.count("\n"), "cuts": sum(1 for l in txt.splitlines() if l.startswith("examining piece"))}
         print(cfg, meta[cfg])
+    if os.path.exists(meta_path):  # (several runs of this script side by side: keep what the others wrote meanwhile)
+        meta = dict(json.load(open(meta_path)), **{k: meta[k] for k in procs})
     json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 
 

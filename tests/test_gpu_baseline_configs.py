@@ -349,3 +349,49 @@ def test_cli_near_tie_counter(tmp_path):
     #  another, equally valid sample -- and the counter says where to look)
     assert int(m.group(1)) >= 1
     assert gff_body(ours.stdout) == gff_body(ref.stdout) or int(m.group(1)) >= 1
+
+
+def _first_difference(ours, gold):
+    a, b = ours.splitlines(), gold.splitlines()
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x != y:
+            return "line %d of %d / %d:\n  ours %s\n  ref  %s" % (i, len(a), len(b), x, y)
+    return "lengths %d / %d" % (len(a), len(b))
+
+
+@pytest.mark.parametrize("cfg", ["long", "long_utr"])
+def test_cli_long_contig_matches_reference(tmp_path, cfg):
+    """BASELINE configs 2 / 4 in shape and at full size -- ONE contig of 23 Mbp at the fly model's 200 kb pieces, UTR off and on:
+    exactly the contig bench.py times as product.long_contig / long_contig_utr (bench.synth_contigs(1, 23000000, SEED0 + 77)).
+    The 140 cut points (found with the scout / forecast cut finder, driver.cc: findCutPoints) and the GFF equal what the
+    reference binary printed for it (tests/golden/make_golden_long.py: 11 / 29 minutes on one core there)"""
+    import gzip
+    sys.path.insert(0, GOLDEN)
+    from make_golden_long import LONG_CFGS, golden_text, long_contig
+    fa = str(tmp_path / "long.fa")
+    write_fasta(fa, [("long", long_contig())])
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE] + LONG_CFGS[cfg] + ["--progress=true", fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ours = golden_text(r.stdout, r.stderr)
+    gold = gzip.open(os.path.join(GOLDEN, "golden_%s.gff.gz" % cfg), "rt").read()
+    assert ours == gold, _first_difference(ours, gold)
+    assert json.load(open(os.path.join(GOLDEN, "golden_long.json")))[cfg]["cuts"] >= 115
+
+
+def test_cli_genome_like_big_matches_reference(big_inputs, tmp_path):
+    """BASELINE config 5 in shape (GRCh38 primary contigs), from what the container has: three records of 48 / 30 / 22 Mbp tiled from
+    real soft-masked DNA in both orientations, GC-shifted stretches (several GC classes inside the human model's 2 Mbp pieces: exact
+    mode's replay on nearly every piece), N runs of 0.1-5 Mbp (all-N pieces, cuts next to them), five scaffolds of 10-200 kb;
+    --species=human at default flags.  58 cut points and 150 000 GFF lines equal the reference binary's (make_golden_long.py)"""
+    import gzip
+    sys.path.insert(0, GOLDEN)
+    from make_golden_long import LONG_CFGS, genome_like_big_records, golden_text
+    fa = str(tmp_path / "genome_like_big.fa")
+    write_fasta(fa, genome_like_big_records(read_fasta(big_inputs["genome"])[0][1]))
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE] + LONG_CFGS["genome_like_big"] + ["--progress=true", fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ours = golden_text(r.stdout, r.stderr)
+    gold = gzip.open(os.path.join(GOLDEN, "golden_genome_like_big.gff.gz"), "rt").read()
+    assert ours == gold, _first_difference(ours, gold)
