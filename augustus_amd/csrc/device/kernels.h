@@ -1285,8 +1285,8 @@ struct TrellisLds {
     double col0[SP];                // column 0 (initial probabilities)
     uint8_t gcw[2][WAVE];           // plane (GC class) of the bases of the current / next tile (multi-class pieces only)
     int flagSum;                     // sum of flagI[]: the workers are never more than one block apart, so flagSum >= NWORK * k <=> every flagI >= k
-    int flagF[NWORK], flagI[NWORK], flagG, flagNr, flagC, flagN, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
-    int abortFlag;
+    int flagG, flagN, flagC, abortFlag; // (with flagSum: what the workers poll, side by side)
+    int flagF[NWORK], flagI[NWORK], flagNr, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     // fix-up pass of a segment (trellisPiece<BLK, 1>): what pass 1 left at the end of the current tile, the offsets new - old
     // of the last tiles, and the last tile whose retired values did not all differ from the old ones by the tile's offset
     double oldCol[SP];
@@ -1315,6 +1315,7 @@ __device__ inline bool waveAnyTrue(const int *flag, int) { return __ballot(flag[
 // progress flags between the trellis wavefronts of one workgroup (all resident on one CU: spinning is safe)
 #ifdef AUGX_EMU
 inline void waitFlag(TrellisLds &L, const int *f, int target) { if (*f < target) { fprintf(stderr, "emu: trellis wavefront dependency violated\n"); abort(); } (void)L; }
+inline void waitFlags4(TrellisLds &L, int tSum, int tG, int tN, int tC) { waitFlag(L, &L.flagSum, tSum); waitFlag(L, &L.flagG, tG); waitFlag(L, &L.flagN, tN); waitFlag(L, &L.flagC, tC); }
 inline void setFlag(int *f, int v) { *f = v; }
 inline void drainStores() {}
 inline int readFlag(const int *f) { return *f; }
@@ -1324,6 +1325,18 @@ inline void bumpFlag(int *f) { *f += 1; }
 __device__ inline void waitFlag(TrellisLds &L, const int *f, int target) {
     int spins = 0;
     while (*(const volatile AUGX_LDS int *)f < target && !*(const volatile AUGX_LDS int *)&L.abortFlag) {
+        if (++spins > (1 << 22)) *(volatile AUGX_LDS int *)&L.abortFlag = 1; // never expected: turns a logic error into an error status
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __asm__ volatile("" ::: "memory");
+}
+// the workers' one wait of the block: all four counters with one trip to the LDS per poll
+__device__ inline void waitFlags4(TrellisLds &L, int tSum, int tG, int tN, int tC) {
+    int spins = 0;
+    for (;;) {
+        const int a = *(const volatile AUGX_LDS int *)&L.flagSum, b = *(const volatile AUGX_LDS int *)&L.flagG, c = *(const volatile AUGX_LDS int *)&L.flagN,
+                  d = *(const volatile AUGX_LDS int *)&L.flagC, ab = *(const volatile AUGX_LDS int *)&L.abortFlag;
+        if ((a >= tSum && b >= tG && c >= tN && d >= tC) || ab) break;
         if (++spins > (1 << 22)) *(volatile AUGX_LDS int *)&L.abortFlag = 1; // never expected: turns a logic error into an error status
         __builtin_amdgcn_s_sleep(1);
     }
@@ -2187,16 +2200,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             }
             FOR_WAVES(w) {
                 if (w < NWORK) { // (1) + (4)
-                    waitFlag(L, &L.flagSum, NWORK * gbk); // every worker is done with block b-1: the one hand-off of the cycle
-                    waitFlag(L, &L.flagG, gbk);           // (late states: chain cells of blocks <= b-1)
+                    // every worker is done with block b-1: the one hand-off of the cycle.  With it (one poll): the chain cells of
+                    // blocks <= b-1 (late states), the far step of the block (cell resets; it runs ahead), igenic two blocks back
+                    waitFlags4(L, NWORK * gbk, gbk, gbk + 1, safeIg ? -(1 << 30) : gbk - 1);
                     PROF_MARK(X, 1);
                     if (w == 0) PROF_STAMP(X, gbk, 6);
                     fixedStep(w, buf, jb, 3, 0, nearRounds); // near (class 0) and late (class 1) states
                     if (nearFeedsGeo && w == 0) setFlag(&L.flagNr, gbk + 1);
                     if (w == 0) PROF_STAMP(X, gbk, 7);
                     PROF_MARK(X, 2);
-                    waitFlag(L, &L.flagN, gbk + 1); // the far step of the block (cell resets) is done; it runs ahead
-                    waitFlag(L, &L.flagC, safeIg ? gbk : gbk - 1); // igenic: no candidate reads a cell less than two blocks back (safe mode: one)
+                    if (safeIg) waitFlag(L, &L.flagC, gbk); // igenic: no candidate reads a cell less than two blocks back (safe mode: one)
                     PROF_MARK(X, 1);
                     if (w < 2) PROF_STAMP(X, gbk, w == 0 ? 2 : 4);
                     const int vigLo = jb - 1 - VIG_WIN > -1 ? jb - 1 - VIG_WIN : -1;

@@ -442,7 +442,50 @@ def product_leg(cfg, a, n_dev):
                 r2["cpu_baseline"] = ref_rate(flags, nbp)
                 r2["x_cpu"] = r2["value"] / r2["cpu_baseline"]["value"]
             out[key] = r2
+        if not a.no_genome_like:
+            out["genome_like"] = genome_like_leg(cfg, a, n_dev, d, exe, run)
     return out
+
+
+def genome_like_leg(cfg, a, n_dev, d, exe, run):
+    """BASELINE config 5 in shape: the ~100 Mbp GRCh38-like stand-in (tests/golden/make_golden_long.py: genome_like_big_records --
+    chromosome-scale records of real soft-masked DNA tiled in both orientations, isochores, megabase N runs, scaffolds) through the
+    executable at --species=human default flags, FASTA file -> GFF file; cut points + GFF compared with the reference binary's
+    golden; host peak RSS of the process and the HBM high-water mark (device-wide, sampled every 50 ms) beside the rate."""
+    import resource
+    import tarfile
+    import threading
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from helpers import read_fasta, write_fasta
+    from make_golden_long import genome_like_big_records
+    with tarfile.open(os.path.join(ROOT, "tests", "golden", "big_inputs.tar.gz")) as t:
+        t.extractall(d)
+    recs = genome_like_big_records(read_fasta(os.path.join(d, "genome.fa"))[0][1])
+    fa = os.path.join(d, "genome_like_big.fa")
+    write_fasta(fa, recs)
+    bases = sum(len(s) for _, s in recs)
+    free0 = [torch.cuda.mem_get_info(i)[0] for i in range(n_dev)]
+    low = list(free0)
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            for i in range(n_dev):
+                low[i] = min(low[i], torch.cuda.mem_get_info(i)[0])
+            stop.wait(0.05)
+    th = threading.Thread(target=watch)
+    th.start()
+    rss0 = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    try:
+        r = run(["--species=human"], fa, bases, reps=1, golden="genome_like_big")
+    finally:
+        stop.set()
+        th.join()
+    r["workload"] = "%d records, %.1f Mbp (%.1f Mbp of N), --species=human default flags, %d device(s)" % (len(recs), bases / 1e6, sum(s.count("N") for _, s in recs) / 1e6, n_dev)
+    r["hbm_high_water_gb"] = max(f - l for f, l in zip(free0, low)) / 1e9
+    r["host_peak_rss_gb"] = max(resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss, rss0) / 1e6  # (largest child so far: this run is the largest input)
+    return r
 
 
 def utr_leg(cfg, local, a):
@@ -556,6 +599,7 @@ def main():
                          "FASTA and on one 23 Mbp contig at the fly model's 200 kb pieces")
     ap.add_argument("--long-contig-len", type=int, default=23000000)
     ap.add_argument("--no-long-utr", action="store_true", help="skip the 23 Mbp contig with --UTR=on (BASELINE config 4's shape)")
+    ap.add_argument("--no-genome-like", action="store_true", help="skip the ~100 Mbp GRCh38-shaped genome through the executable (BASELINE config 5's shape)")
     ap.add_argument("--no-utr", action="store_true", help="skip the --UTR=on leg (the 71-state model, BASELINE config 4's trellis)")
     ap.add_argument("--utr-contigs", type=int, default=256)
     ap.add_argument("--utr-contig-len", type=int, default=160000)
