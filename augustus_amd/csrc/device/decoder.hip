@@ -631,6 +631,7 @@ int augx_decoder_set_share(augx_decoder *d, int n) {
 int64_t augx_decoder_unreplayed_batches(const augx_decoder *d) { return d ? d->denseMultiForward : 0; }
 int augx_decoder_count_near_ties(augx_decoder *d, int on) { if (!d) return AUGX_E_ARG; d->countNearTies = on != 0; return AUGX_OK; }
 int64_t augx_decoder_near_ties(const augx_decoder *d, int64_t *pieces) { if (pieces) *pieces = d ? d->nearTiePieces : 0; return d ? d->nearTies : 0; }
+int augx_decoder_exact(const augx_decoder *d) { return d && d->exactMulti ? 1 : 0; }
 int augx_decoder_set_exact(augx_decoder *d, int on) {
     if (!d) return AUGX_E_ARG;
     d->exactMulti = on != 0;
@@ -1708,14 +1709,18 @@ int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_pat
     const double t2 = timing ? now() : 0.0;
     if (!rc) rc = augx_batch_paths(d, b, out);
     const double t3 = timing ? now() : 0.0;
+    float kPrep = 0, kTrellis = 0, kBack = 0;
+    int planes = 0;
+    long long nItems = 0;
+    if (timing && !rc) { (void)augx_batch_kernel_ms(d, b, &kPrep, &kTrellis, &kBack); planes = b->V.nPl; nItems = (long long)b->nItems; }
     augx_batch_destroy(b);
     if (timing) {
         int64_t bases = 0;
         for (int i = 0; i < n; i++) bases += pieces[i].len;
         size_t freeB = 0, totalB = 0;
         (void)hipMemGetInfo(&freeB, &totalB);
-        fprintf(stderr, "augx timing:   batch on device %d: %d pieces, %lld bases: create + upload %.3f s, decode %.3f s, paths %.3f s, destroy %.3f s (device memory free %.1f of %.1f GB)\n",
-                d->device, n, (long long)bases, t1 - t0, t2 - t1, t3 - t2, now() - t3, freeB / 1e9, totalB / 1e9);
+        fprintf(stderr, "augx timing:   batch on device %d: %d pieces, %lld bases: create + upload %.3f s, decode %.3f s (on the device: prep %.0f ms, trellis passes%s %.0f ms, back-trace %.0f ms; %d plane(s), %lld candidates), paths %.3f s, destroy %.3f s (device memory free %.1f of %.1f GB)\n",
+                d->device, n, (long long)bases, t1 - t0, t2 - t1, kPrep, planes > 1 && d->exactMulti ? " + replay + second run" : "", kTrellis, kBack, planes, nItems, t3 - t2, now() - t3, freeB / 1e9, totalB / 1e9);
     }
     return rc;
 }

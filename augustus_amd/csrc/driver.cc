@@ -381,7 +381,9 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
 //      or two and their number stays small.  The forecast decides only WHICH windows are decoded early, never a result.
 struct PieceRef { int rec; long begin, end; int initKind, termKind; };
 struct CutFinderStats { double scoutSeconds = 0; int tiles = 0, batches = 0, windows = 0, used = 0; };
-using DecodeFn = std::function<bool(const std::vector<augx_piece> &, std::vector<Decoded> &)>;
+// (scout = true: the paths only feed the cut finder's FORECAST -- which windows to decode early, never a cut --, so the decode may
+//  skip what makes a multi-class piece exactly the reference's: the replay of the snippet cache and the second trellis run)
+using DecodeFn = std::function<bool(const std::vector<augx_piece> &, std::vector<Decoded> &, bool scout)>;
 
 bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long maxstep, bool soft, int scoutMode /* -1: decide here */, int nDevices,
                    const DecodeFn &decode, std::vector<std::vector<PieceRef>> &recPieces, std::vector<int> &failStatus, CutFinderStats &stats) {
@@ -490,7 +492,7 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
                 scouted[r] = 1;
             }
             std::vector<Decoded> dd;
-            if (!decode(tp, dd)) return false;
+            if (!decode(tp, dd, true)) return false;
             for (size_t k = 0; k < tr.size(); k++) {
                 if (dd[k].status != 0) continue; // (no forecast from this tile; the chain decodes its windows as it goes)
                 const long n = recs[tr[k].rec].len;
@@ -660,7 +662,7 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
             ex.push_back(p);
         }
         std::vector<Decoded> dd;
-        if (!decode(ex, dd)) return false;
+        if (!decode(ex, dd, false)) return false;
         stats.batches++;
         stats.windows += (int)ex.size();
         for (size_t k = 0; k < keys.size(); k++) cache[keys[k]] = std::move(dd[k]);
@@ -925,7 +927,15 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         if (const char *e = getenv("AUGX_SCOUT")) scoutMode = atoi(e) != 0;
         CutFinderStats st;
         std::string cfErr;
-        auto decodeFn = [&](const std::vector<augx_piece> &ps, std::vector<Decoded> &dd) { if (S.decode(ps, dd)) return true; cfErr = S.err; return false; };
+        auto decodeFn = [&](const std::vector<augx_piece> &ps, std::vector<Decoded> &dd, bool scout) {
+            std::vector<int> was;
+            if (scout) for (augx_decoder *d : S.decs) { was.push_back(augx_decoder_exact(d)); augx_decoder_set_exact(d, 0); }
+            const bool ok = S.decode(ps, dd);
+            if (scout) for (size_t i = 0; i < S.decs.size(); i++) augx_decoder_set_exact(S.decs[i], was[i]);
+            if (ok) return true;
+            cfErr = S.err;
+            return false;
+        };
         if (!findCutPoints(M, views, maxstep, soft, scoutMode, (int)S.decs.size(), decodeFn, recPieces, recFail, st)) { restore(); return fail(cfErr); }
         if (timing)
             fprintf(stderr, "augx timing:   cut finder: scout %.3f s (%d tiles), %d batches, %d windows decoded, %d used\n", st.scoutSeconds, st.tiles, st.batches, st.windows,
@@ -1152,7 +1162,7 @@ extern "C" int augx_find_cuts(const augx_model *m, int n_records, const char *co
         std::vector<RecordView> views;
         for (int r = 0; r < n_records; r++) views.push_back({"", seqs[r], (long)lens[r]});
         int rcDecode = 0;
-        auto decodeFn = [&](const std::vector<augx_piece> &ps, std::vector<Decoded> &dd) {
+        auto decodeFn = [&](const std::vector<augx_piece> &ps, std::vector<Decoded> &dd, bool /*scout: the caller's decode function decides*/) {
             std::vector<augx_path> paths(ps.size());
             for (auto &p : paths) { p.states = nullptr; p.n_states = 0; p.status = AUGX_E_ARG; p.ln_viterbi = 0; }
             rcDecode = fn(user, ps.data(), (int)ps.size(), paths.data());

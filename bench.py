@@ -390,6 +390,13 @@ def product_leg(cfg, a, n_dev):
                 r = subprocess.run([exe] + args + (["--progress=true"] if want else []) + ["--outfile=" + os.path.join(d, "o.gff"), fa], capture_output=True, env=env)
                 dt = time.perf_counter() - t0
                 err = r.stderr.decode(errors="replace")
+                if golden:  # (developer aid: the executable's own phase and per-batch timing lines of the full-size runs)
+                    try:
+                        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                        with open(os.path.join(ROOT, "gpurun_out", "timing_%s.txt" % golden), "w") as fh:
+                            fh.write("\n".join(l for l in err.splitlines() if l.startswith("augx timing")) + "\n")
+                    except OSError:
+                        pass
                 laps = parse_timing(err)
                 parity = None
                 if want and r.returncode == 0:

@@ -205,6 +205,7 @@ int augx_decoder_set_share(augx_decoder *d, int n_decoders_on_device);
  * a randomised soak found a record where the optimal path depends on it.  exact = 0 saves the second trellis run on batches
  * with such pieces.  The forward algorithm (augx_batch_forward) always replays it. */
 int augx_decoder_set_exact(augx_decoder *d, int exact);
+int augx_decoder_exact(const augx_decoder *d); /* the current setting (1 / 0) */
 /* number of forward runs (posterior sampling) this decoder made with the UTR model over a batch that holds a piece with more than
  * one GC-content class.  The reference's snippet cache (SnippetProbs, src/statemodel.cc:312-342) is replayed for every model; two
  * more call-history caches that only UTR states use (tssProbsPlus, src/utrmodel.cc:748-790; the aSSProb memo,
