@@ -405,6 +405,7 @@ struct augx_decoder {
     bool countNearTies = false;    // the back-trace counts the near ties on the chosen paths (AUGX_NEAR_TIES=1, augx_decoder_count_near_ties)
     int64_t nearTies = 0, nearTiePieces = 0; // ... summed over the batches whose paths were fetched
     int64_t denseMultiForward = 0; // forward runs of the dense kernels over batches with a multi-class piece: no replay of the reference's caches there (augx_decoder_unreplayed_batches)
+    double mallocSeconds = 0, mallocBytes = 0; // hipMalloc calls of this decoder so far (AUGX_TIMING; guarded by nothing: one host thread drives a decoder)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
@@ -437,7 +438,10 @@ hipError_t devMalloc(augx_decoder *d, void **out, size_t bytes) {
             return hipSuccess;
         }
     }
+    const auto tm0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
+    d->mallocSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count(); // (developer aid: printed under AUGX_TIMING)
+    d->mallocBytes += (double)bytes;
     if (e != hipSuccess) { // this decoder's pool first, then those of the other decoders on the device
         (void)hipGetLastError();
         poolRelease(d);
@@ -755,6 +759,7 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     }
 #undef DA
     rc = [&]() -> int { // (any failure below: the batch is destroyed with everything it owns)
+    const double tAlloc = getenv("AUGX_TIMING") ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
     HIP_TRY(hipMemcpy(dOff, L.off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dLen, L.len.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dIk, L.initKind.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
@@ -769,6 +774,8 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     { void *pv = nullptr; HIP_TRY(devMalloc(d, &pv, sizeof(BatchView))); b->bufs.push_back(pv); b->dV = (BatchView *)pv; }
     HIP_TRY(hipMemcpy(b->dV, &V, sizeof(BatchView), hipMemcpyHostToDevice));
     for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    if (tAlloc > 0) fprintf(stderr, "augx timing:       batch created: uploads + events %.3f s after the allocations (hipMalloc calls of this decoder so far: %.3f s for %.1f GB)\n",
+                            std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tAlloc, d->mallocSeconds, d->mallocBytes / 1e9);
     return AUGX_OK;
     }();
     if (rc) { augx_batch_destroy(b); return rc; }
@@ -786,6 +793,11 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     HIP_TRY(hipEventRecord(b->ev[0], st));
     hipLaunchKernelGGL(kEncode, dim3(gridN), dim3(256), 0, st, V);
     int rc;
+    // (developer aid, AUGX_TIMING: where the host spends the first decode of a batch -- classes, list sizes, array allocation)
+    const bool timingFirst = !b->decoded && getenv("AUGX_TIMING") != nullptr;
+    auto nowS = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tf[6] = {0, 0, 0, 0, 0, 0};
+    if (timingFirst) tf[0] = nowS();
     // site counts and stop positions: terms and prefix scans fused (the prefix arrays are written once, never read back here)
     const unsigned nScan = (unsigned)(V.N / SCAN_T);
     hipLaunchKernelGGL(kSiteScanTotals, dim3(nScan), dim3(SCAN_T), 0, st, d->dT, V, V.chunkTot);
@@ -815,6 +827,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         HIP_TRY(hipMemcpyAsync(info, b->stairInfo, sizeof info, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         int nPl = info[0] > 1 ? info[0] : 1;
+        if (timingFirst) tf[1] = nowS();
         if (info[1] > 0) { // a piece with more class changes than the kernel holds (thousands): its stairs on the host
             std::vector<int32_t> cls(n), nPlanes(n), planeCls((size_t)n * MAXPL);
             HIP_TRY(hipMemcpy(cls.data(), V.cls, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
@@ -854,7 +867,9 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             changed = true;
         }
         const void *fxBefore = W.fx;
+        if (timingFirst) tf[2] = nowS();
         if ((rc = ensureArrays(b, nPl, W.listCap))) return rc;
+        if (timingFirst) tf[3] = nowS();
         if (changed || fxBefore != W.fx) {
             W.nPl = nPl;
             HIP_TRY(hipMemcpy(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice));
@@ -962,6 +977,12 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             }
             HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
         }
+    }
+    if (timingFirst) {
+        tf[4] = nowS();
+        fprintf(stderr, "augx timing:       first decode of the batch, host side: class kernels + stairs %.3f s, stairs on the host + list sizes %.3f s, per-class / list arrays (%d planes) %.3f s, "
+                        "prep launches + candidate buffer + candidates counted %.3f s (hipMalloc so far: %.3f s for %.1f GB)\n", tf[1] - tf[0], tf[2] - tf[1], b->V.nPl, tf[3] - tf[2], tf[4] - tf[3],
+                d->mallocSeconds, d->mallocBytes / 1e9);
     }
     if (b->plan.cut()) hipLaunchKernelGGL(kTileCross, dim3((unsigned)((V.N / WAVE + 255) / 256)), dim3(256), 0, st, V); // how far back the future reads (fix-ups)
     HIP_TRY(hipEventRecord(b->ev[1], st));

@@ -489,6 +489,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
 // src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
 // =================================================================================================
 #ifdef AUGX_EMU
+static long long g_emuQuietTiles = 0; // tiles the trellis took as chain-only tiles (trellisPiece)
 static long long g_emuSlowA = 0, g_emuSlowB = 0, g_emuSlowVig = 0, g_emuSlowList = 0, g_emuSlowWaves = 0, g_emuItemWaves = 0; // emulator statistics: candidates taking the general evaluation path
 #endif
 struct VarDesc { // 64 bytes (kind, frame and geometry of the state are per-state constants: VarConst)
@@ -1286,6 +1287,7 @@ struct TrellisLds {
     uint8_t gcw[2][WAVE];           // plane (GC class) of the bases of the current / next tile (multi-class pieces only)
     int flagSum;                     // sum of flagI[]: the workers are never more than one block apart, so flagSum >= NWORK * k <=> every flagI >= k
     int flagG, flagN, flagC, abortFlag; // (with flagSum: what the workers poll, side by side)
+    int quietBad;                    // a tile without candidates: something in it or before it keeps it from being a chain-only tile (see trellisPiece)
     int flagF[NWORK], flagI[NWORK], flagNr, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     // fix-up pass of a segment (trellisPiece<BLK, 1>): what pass 1 left at the end of the current tile, the offsets new - old
     // of the last tiles, and the last tile whose retired values did not all differ from the old ones by the tile's offset
@@ -1707,6 +1709,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (lagA < 3 * BLK) nearFeedsGeo = true;
         }
     }
+    uint64_t chainMask = 0; // the single-base states (S <= SP = 48)
+    for (int s2 = 0; s2 < S; s2++)
+        if (T.kind[s2] == AUGX_K_IGENIC || T.kind[s2] == AUGX_K_GEOMETRIC || T.kind[s2] == AUGX_K_RGEOMETRIC) chainMask |= 1ull << s2;
     // the far step of block b reads cells back to base b*BLK + BLK-1 - farMinLag; among them RTERMINAL cells, which exist
     // only once the igenic cells of their own block do: igenic must be complete up to that block (farNeedC)
     int farMinLag = 1 << 20;
@@ -2153,6 +2158,82 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // step -> hand-off -> candidates(b+1), 5.1 k cycles per block of which 2.5 k the near step and its two hand-offs.)
         PROF_MARK(X, 0);
         int nb = 0;
+        // ---- a QUIET tile: no candidate ends in it, no fixed-lag state can emit in it (every splice-site signal is -inf: a run
+        // of N, or of bases without GT / AG) and nothing but chain states (intergenic, geometric introns) is alive in the column
+        // before it.  Then every cell of the tile but the chain states' is -inf whatever the wavefronts do, the chain states
+        // follow themselves alone, and nothing in the tile waits for anything: the far wavefront writes the fixed-lag and
+        // variable-length cells of all its blocks, the chain and igenic wavefronts run their states down the tile, no hand-offs (the
+        // ring holds nothing else alive either: a slot read before its new column is written says the same, -inf) --
+        // the same code as in the block loop below, so the same bits, at a quarter of the time.  (Runs of N are otherwise walked at
+        // the pace of the hand-off cycle, 2 us per 8 bases -- by a fix-up that cannot converge inside them, alone on its piece:
+        // 1.8 of 2.9 s of device time on a 100 Mbp genome with 11 % N, profiles/r05_genome_like_*.)
+        bool quiet = false;
+        if (j0 > 0 && L.blkItem[buf][NB] == 0) { // (uniform: LDS values staged before the last barrier)
+            FOR_THREADS(t) { if (t == 0) L.quietBad = 0; }
+            BLOCK_SYNC(); // (the loader wavefronts join when the next tile is staged)
+            FOR_THREADS(t) {
+                bool bad = false;
+                if (t < WAVE && j0 + t < n) {
+                    const double *sg = L.sig[buf][t];
+                    bad = sg[SIG_DSSF] > AUGX_NINF || sg[SIG_DSSR] > AUGX_NINF || sg[SIG_ASSF] > AUGX_NINF || sg[SIG_ASSR] > AUGX_NINF;
+                    for (int k = 0; k < NSITE; k++) bad |= L.site[buf][t][k] >= 0;
+                    bool eqDead = dL >= 2 * WAVE; // (equalD reads its predecessors from the staged copy: all dead?)
+                    for (int k = 0; k < 6; k++) eqDead &= !(L.eqPrev[buf][t][k] > AUGX_NINF);
+                    bad |= sg[SIG_EQD] > AUGX_NINF && !eqDead;
+                }
+                // the ring -- the 64 columns before the tile, whose slots the tile's columns take over: the wavefronts of a quiet tile
+                // do not wait for one another, so what a slot still holds must be what it will hold
+                for (int i = t; i < WAVE * SP; i += NT) {
+                    const int s2 = i % SP;
+                    if (s2 < S && !((chainMask >> s2) & 1) && L.ring[i / SP][s2] > AUGX_NINF) bad = true;
+                }
+                if (bad) ldsMaxI(&L.quietBad, 1);
+            }
+            BLOCK_SYNC();
+            quiet = L.quietBad == 0;
+        }
+        if (quiet) {
+#ifdef AUGX_EMU
+            g_emuQuietTiles++;
+#endif
+            for (int blk = 0; blk < NB && j0 + blk * BLK < n; blk++) {
+                nb = blk + 1;
+                const int jb = j0 + blk * BLK;
+                FOR_WAVES(w) {
+                    if (w == W_X) { // every fixed-lag state (near, late and far classes) and the cell resets of the block
+                        fixedStep(w, buf, jb, 7, 0, FR);
+                        FOR_WLANES(t, w) {
+                            const int j = jb + (t & 63) % BLK;
+#pragma unroll
+                            for (int r = 0; r < VR; r++) {
+                                const int s2 = vS[r][TI];
+                                if (s2 < 0 || j < 1 || j >= n) continue;
+                                L.ring[j & 63][s2] = AUGX_NINF;
+                                if (wantCells) gp(B.cells)[(o + 1 + j) * S + s2] = AUGX_NINF;
+                            }
+                        }
+                    }
+                    if (w == W_C) {
+                        if (geoLight) chainPass(std::integral_constant<int, 2>{}, w, buf, -1, jb);
+                        else chainPass(std::integral_constant<int, 5>{}, w, buf, -1, jb);
+                    }
+                    if (w == W_I) chainPass(std::integral_constant<int, 5>{}, w, buf, jb, -1);
+                }
+            }
+            const int gEnd = tile * NB + nb;
+            rtNext = gEnd;
+            FOR_WAVES(w) {
+                if (w == W_X) { // the progress counters as a completed tile leaves them (nobody polls them before the barrier below)
+                    if (wantCells) drainStores();
+                    FOR_WLANES(t, w) {
+                        if ((t & 63) == 0) {
+                            for (int i = 0; i < NWORK; i++) { L.flagF[i] = gEnd; L.flagI[i] = gEnd; }
+                            L.flagSum = NWORK * gEnd; L.flagG = gEnd; L.flagNr = gEnd; L.flagN = gEnd; L.flagC = gEnd; L.flagR = tile + 1; L.rtPub = gEnd;
+                        }
+                    }
+                }
+            }
+        } else {
         for (int blk = 0; blk < NB && j0 + blk * BLK < n; blk++) {
             nb = blk + 1;
             const int jb = j0 + blk * BLK, gbk = tile * NB + blk;
@@ -2281,6 +2362,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 PROF_TSTAMP(X, tile == 124, 14);
             }
         }
+        } // (not a quiet tile)
         BLOCK_GLOBAL_SYNC(); // stores of this tile are visible to later (coherent) loads; the staged tile is complete
         FOR_WAVES(w) { if (w == 0) PROF_TSTAMP(X, tile == 124, 15); }
         tLast = tile;
