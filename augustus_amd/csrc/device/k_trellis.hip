@@ -13,7 +13,7 @@ using namespace augx::dev;
 // scratch for <8, 0> (profiles/EXPERIMENTS.md, round 4/5).
 template <int BLK, int MODE, bool TIES> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
-    if constexpr (!TIES && MODE <= 1) {
+    if constexpr (!TIES) {
         const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         switch (w) {
             case 0: trellisPiece<BLK, MODE, TIES, 0>(*T, *B, lds, blockIdx.x); break;

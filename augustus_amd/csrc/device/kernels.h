@@ -489,7 +489,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
 // src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
 // =================================================================================================
 #ifdef AUGX_EMU
-static long long g_emuQuietTiles = 0; // tiles the trellis took as chain-only tiles (trellisPiece)
+static long long g_emuQuietTiles = 0, g_emuJumpTiles = 0; // tiles the trellis took as chain-only tiles / jumped over in a run of N (trellisPiece)
 static long long g_emuSlowA = 0, g_emuSlowB = 0, g_emuSlowVig = 0, g_emuSlowList = 0, g_emuSlowWaves = 0, g_emuItemWaves = 0; // emulator statistics: candidates taking the general evaluation path
 #endif
 struct VarDesc { // 64 bytes (kind, frame and geometry of the state are per-state constants: VarConst)
@@ -1288,6 +1288,10 @@ struct TrellisLds {
     int flagSum;                     // sum of flagI[]: the workers are never more than one block apart, so flagSum >= NWORK * k <=> every flagI >= k
     int flagG, flagN, flagC, abortFlag; // (with flagSum: what the workers poll, side by side)
     int quietBad;                    // a tile without candidates: something in it or before it keeps it from being a chain-only tile (see trellisPiece)
+    // jump over a run of N (trellisPiece): the chain states by slot -- state, signal record, ancestor index of the state itself,
+    // transition term into itself, value in the column before the jump -- and the first thread whose stretch holds a nucleotide
+    int jcState[8], jcSig[8], jcSelf[8], jumpFirst;
+    double jcTr[8], jcV0[8];
     int flagF[NWORK], flagI[NWORK], flagNr, flagR, staged, rtPub; // blocks completed by the trellis wavefronts (see trellisPiece)
     // fix-up pass of a segment (trellisPiece<BLK, 1>): what pass 1 left at the end of the current tile, the offsets new - old
     // of the last tiles, and the last tile whose retired values did not all differ from the old ones by the tile's offset
@@ -1643,6 +1647,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     }
     if (MODE >= 2) tEnd = nTiles;
     const bool mayEndPiece = tEnd == nTiles; // a run that completes the last tile of the piece does the termination step
+    int tResume = tStart; // first tile of the stretch being computed tile by tile (after a jump over a run of N: the tile it landed on)
     if (c < 0) { // multi-class piece: not decoded by this version
         FOR_THREADS(t) { if (t == 0 && mayEndPiece) { B.status[p] = AUGX_E_UNSUPPORTED; B.lnv[p] = AUGX_NINF; B.finalState[p] = -1; } }
         return;
@@ -1906,7 +1911,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                 // tile -- not computed yet when eqPrev was staged: it is read from that tile's own long-lag rows, which stay in
                 // LDS (the other half of the double buffer) until the next tile starts.  (The first tile of a run has no tile
                 // before it in LDS; its eqPrev was staged before anything ran, from values an earlier run completed.)
-                const bool inPrevTile = lg && dL < 2 * WAVE && jp >= (jb / WAVE) * WAVE - WAVE && jb / WAVE > tStart;
+                const bool inPrevTile = lg && dL < 2 * WAVE && jp >= (jb / WAVE) * WAVE - WAVE && jb / WAVE > tResume;
                 const double *p0 = lg ? (inPrevTile ? &L.longW[buf ^ 1][jp & 63][fAnc0[r][TI]] : &L.eqPrev[buf][j & 63][fAnc0[r][TI]]) : &L.ring[jp & 63][fAnc0[r][TI]];
                 const double *p1 = lg ? (inPrevTile ? &L.longW[buf ^ 1][jp & 63][fAnc1[r][TI]] : &L.eqPrev[buf][j & 63][fAnc1[r][TI]]) : &L.ring[jp & 63][fAnc1[r][TI]];
                 emi[r] = L.sig[buf][j & 63][fSig[r][TI]];
@@ -2117,6 +2122,8 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
 #endif
     int tLast = tStart - 1;  // last tile this run completed
     bool gaveUp = false;     // (fix-up pass) stopped at its limit without having converged
+    bool quiet = false;      // the tile about to be computed is a chain-only tile (settled at the end of the tile before it)
+    int quietRun = 0;        // ... and so many tiles before it were
     for (int tile = tStart; tile < tEnd; tile++) {
         const int buf = tile & 1, j0 = tile * WAVE;
         FOR_WAVES(w) {
@@ -2135,8 +2142,8 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                             L.needPos = m;
                         }
                     }
-                    if (tile + 1 < tEnd || (CMP && tile + 1 < nTiles)) loadTileThread<BLK, CMP>(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= tStart + 1);
-                    if (tile >= tStart + 1) flushBpThread<CMP>(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
+                    if (tile + 1 < tEnd || (CMP && tile + 1 < nTiles)) loadTileThread<BLK, CMP>(X, tile + 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE, tile >= tResume + 1);
+                    if (tile >= tResume + 1) flushBpThread<CMP>(X, tile - 1, buf ^ 1, t - W_LOAD * WAVE, NT - W_LOAD * WAVE);
                 }
                 addFlag(&L.staged); // (NWAVES - W_LOAD) counts per tile: the next tile is staged, its buffers are retired
             }
@@ -2167,31 +2174,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // the same code as in the block loop below, so the same bits, at a quarter of the time.  (Runs of N are otherwise walked at
         // the pace of the hand-off cycle, 2 us per 8 bases -- by a fix-up that cannot converge inside them, alone on its piece:
         // 1.8 of 2.9 s of device time on a 100 Mbp genome with 11 % N, profiles/r05_genome_like_*.)
-        bool quiet = false;
-        if (j0 > 0 && L.blkItem[buf][NB] == 0) { // (uniform: LDS values staged before the last barrier)
-            FOR_THREADS(t) { if (t == 0) L.quietBad = 0; }
-            BLOCK_SYNC(); // (the loader wavefronts join when the next tile is staged)
-            FOR_THREADS(t) {
-                bool bad = false;
-                if (t < WAVE && j0 + t < n) {
-                    const double *sg = L.sig[buf][t];
-                    bad = sg[SIG_DSSF] > AUGX_NINF || sg[SIG_DSSR] > AUGX_NINF || sg[SIG_ASSF] > AUGX_NINF || sg[SIG_ASSR] > AUGX_NINF;
-                    for (int k = 0; k < NSITE; k++) bad |= L.site[buf][t][k] >= 0;
-                    bool eqDead = dL >= 2 * WAVE; // (equalD reads its predecessors from the staged copy: all dead?)
-                    for (int k = 0; k < 6; k++) eqDead &= !(L.eqPrev[buf][t][k] > AUGX_NINF);
-                    bad |= sg[SIG_EQD] > AUGX_NINF && !eqDead;
-                }
-                // the ring -- the 64 columns before the tile, whose slots the tile's columns take over: the wavefronts of a quiet tile
-                // do not wait for one another, so what a slot still holds must be what it will hold
-                for (int i = t; i < WAVE * SP; i += NT) {
-                    const int s2 = i % SP;
-                    if (s2 < S && !((chainMask >> s2) & 1) && L.ring[i / SP][s2] > AUGX_NINF) bad = true;
-                }
-                if (bad) ldsMaxI(&L.quietBad, 1);
-            }
-            BLOCK_SYNC();
-            quiet = L.quietBad == 0;
-        }
+        // (whether this tile is one was settled at the end of the tile before, below)
         if (quiet) {
 #ifdef AUGX_EMU
             g_emuQuietTiles++;
@@ -2406,6 +2389,183 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (lb < needTile && (tile - 1) - lb >= win && !atSeam) break;
             if (MODE == 1 && tile + 1 == tEnd) gaveUp = true;
         }
+        // ---- is the NEXT tile a quiet one?  No candidate ends in it, no fixed-lag state can emit in it (every splice-site signal
+        // is -inf, no list site: a run of N), equalD's staged predecessors are dead, and nothing but chain states is alive in the
+        // ring (the 64 columns before it, whose slots its columns take over: the wavefronts of a quiet tile do not wait for one
+        // another, so what a slot still holds must be what it will hold).  (Here, not at the head of the next iteration: every
+        // wavefront is at this point anyway, and the loaders have nothing in flight.)
+        quietRun = quiet ? quietRun + 1 : 0;
+        quiet = false;
+        if (tile + 1 < tEnd && L.blkItem[buf ^ 1][NB] == 0) { // (uniform: staged before the barrier of this tile)
+            const int jn0 = j0 + WAVE;
+            FOR_THREADS(t) { if (t == 0) L.quietBad = 0; }
+            BLOCK_SYNC();
+            FOR_THREADS(t) {
+                bool bad = false;
+                if (t < WAVE && jn0 + t < n) {
+                    const double *sg = L.sig[buf ^ 1][t];
+                    bad = sg[SIG_DSSF] > AUGX_NINF || sg[SIG_DSSR] > AUGX_NINF || sg[SIG_ASSF] > AUGX_NINF || sg[SIG_ASSR] > AUGX_NINF;
+                    for (int k = 0; k < NSITE; k++) bad |= L.site[buf ^ 1][t][k] >= 0;
+                    bool eqDead = dL >= 2 * WAVE; // (equalD reads its predecessors from the staged copy: all dead?)
+                    for (int k = 0; k < 6; k++) eqDead &= !(L.eqPrev[buf ^ 1][t][k] > AUGX_NINF);
+                    bad |= sg[SIG_EQD] > AUGX_NINF && !eqDead;
+                }
+                for (int i = t; i < WAVE * SP; i += NT) {
+                    const int s2 = i % SP;
+                    if (s2 < S && !((chainMask >> s2) & 1) && L.ring[i / SP][s2] > AUGX_NINF) bad = true;
+                }
+                if (bad) ldsMaxI(&L.quietBad, 1);
+            }
+            BLOCK_SYNC();
+            quiet = L.quietBad == 0;
+        }
+        // ---- JUMP over a run of N.  Deep inside one -- the last jumpAfter tiles were quiet, so every look-back of the tiles ahead
+        // (64 columns, dStateLen) lies in verified quiet tiles, and the prefix counts say no nucleotide follows for a stretch -- the
+        // columns ahead are known without walking them: the chain states follow themselves, v(j) = v(j-1) + (ln t(s,s) + emission(j)),
+        // every other cell is -inf.  All additions of the decode are exact, so the sums may be taken in any order: every
+        // thread sums a stretch, the stretches are chained, and the threads write what the tiles would have retired -- back pointers,
+        // the igenic column, the long-lag cells, the column at the end of every tile -- straight to HBM, 1 ms per Mbp instead of the
+        // 170 ms of the block loop.  The run resumes tile by tile at least two tiles before the first nucleotide.  (A fix-up or a
+        // continuation cannot converge inside a run of N -- the true run carries intron states through it that a dead start does
+        // not have -- so it is they who walk the long runs, alone on their piece: 1.8 of 2.9 s of device time on a 100 Mbp genome
+        // with 11 % N before this, profiles/r05_*.)  In the comparing passes the jumped tiles count as not verified.
+        constexpr int JUMP_MIN = 32; // tiles worth the fixed cost of a jump
+        const int jumpAfter = (dL + 3 * WAVE - 1) / WAVE + 1;
+        if (quiet && quietRun >= jumpAfter && tEnd - 1 - (tile + 1) >= JUMP_MIN) {
+            const int jS = (tile + 1) * WAVE;
+            const int hi = (tEnd - 1) * WAVE < n ? (tEnd - 1) * WAVE : n; // (the last tile of the run is always walked)
+            const int step = (hi - jS + NT - 1) / NT;
+            auto nucAt = [&](int q) { uint32_t c4 = 0; for (int i = 0; i < 4; i++) c4 += gp(B.cnt)[fidx(o + 1 + q, i, NCNT)]; return c4; };
+            auto sitesAt = [&](int q) { uint32_t c4 = 0; for (int i = CNT_ATG; i <= CNT_RS; i++) c4 += gp(B.cnt)[fidx(o + 1 + q, i, NCNT)]; return c4; };
+            FOR_THREADS(t) { if (t == 0) L.jumpFirst = -NT; }
+            BLOCK_SYNC();
+            FOR_THREADS(t) { // the first stretch with a nucleotide (or a list site: there is none without one, but the jump rests on it)
+                const int qa = jS + t * step, qb = jS + (t + 1) * step < hi ? jS + (t + 1) * step : hi;
+                if (qa < qb && (nucAt(qb - 1) != nucAt(qa - 1) || sitesAt(qb - 1) != sitesAt(qa - 1))) ldsMaxI(&L.jumpFirst, -t);
+            }
+            BLOCK_SYNC();
+            const int fT = -L.jumpFirst;
+            int jN = jS + fT * step; // [jS, jN) holds no nucleotide
+            if (jN > hi) jN = hi;
+            const int tJ = (jN - 2 * WAVE) / WAVE; // land two tiles before what may hold one
+            BLOCK_SYNC();
+            if (tJ - (tile + 1) >= JUMP_MIN) {
+                const int jE = tJ * WAVE, len = jE - jS, per = (len + NT - 1) / NT;
+                double *part = (double *)&L.items[0][0]; // [NT][8] sums of the stretches (the staged candidates are not needed: the run re-stages where it lands)
+                static_assert(sizeof(L.items) >= sizeof(double) * NT * 8, "scratch of the jump");
+                // retire the last tile walked (its back pointers, igenic cells, long-lag cells; quiet tiles have no list sites)
+                FOR_THREADS(t) {
+                    flushBpThread(X, tile, buf, t, NT);
+                    if (t < WAVE && (t & 63) % BLK == 0 && (t & 63) / BLK < 8) { // the chain states by slot (lane = slot * BLK of any wavefront holds the slot's constants)
+                        const int slot = (t & 63) / BLK, self = TX(cSelf), s2 = TX(cS);
+                        const bool live = s2 >= 0 && self < 5;
+                        // (the transition term of the plane the run of N lies in -- not the lane's copy: only the chain wavefronts keep theirs current)
+                        const int cc = X.multi ? B.planeCls[p * MAXPL + (int)B.gcPlane[o + 1 + jS - 1]] : c;
+                        L.jcState[slot] = live ? s2 : -1; L.jcSig[slot] = TX(cSig); L.jcSelf[slot] = self;
+                        L.jcTr[slot] = live ? lnT(T, cc, s2, s2) : AUGX_NINF;
+                        L.jcV0[slot] = live ? L.ring[(jS - 1) & 63][s2] : AUGX_NINF;
+                    }
+                    if (t == 0) L.quietBad = 0;
+                }
+                BLOCK_SYNC();
+                constexpr int NC = 8;
+                FOR_THREADS(t) { // sums of the stretches; with several GC classes the transition terms follow the plane: one plane only
+                    const int qa = jS + t * per, qb = jS + (t + 1) * per < jE ? jS + (t + 1) * per : jE;
+                    double acc[NC];
+                    for (int c = 0; c < NC; c++) acc[c] = 0.0;
+                    const int pl0 = X.multi ? (int)gp(B.gcPlane)[o + 1 + jS - 1] : 0;
+                    bool bad = false;
+                    for (int q = qa; q < qb; q++) {
+                        const double eIg = gp(B.sig)[(o + 1 + q) * NSIG + SIG_EIG], eIn = gp(B.sig)[(o + 1 + q) * NSIG + SIG_EIN];
+                        for (int c = 0; c < NC; c++) acc[c] += L.jcTr[c] + (L.jcSig[c] == SIG_EIG ? eIg : eIn);
+                        if (X.multi && (int)gp(B.gcPlane)[o + 1 + q] != pl0) bad = true;
+                    }
+                    for (int c = 0; c < NC; c++) part[t * NC + c] = acc[c];
+                    if (bad) ldsMaxI(&L.quietBad, 1);
+                }
+                BLOCK_SYNC();
+                const bool onePlane = L.quietBad == 0;
+                BLOCK_SYNC();
+                if (onePlane) {
+#ifdef AUGX_EMU
+                    g_emuJumpTiles += tJ - (tile + 1);
+#endif
+                    FOR_THREADS(t) {
+                        const int qa = jS + t * per, qb = jS + (t + 1) * per < jE ? jS + (t + 1) * per : jE;
+                        double v[NC];
+                        for (int c = 0; c < NC; c++) {
+                            double a = L.jcV0[c];
+                            for (int u = 0; u < t; u++) a += part[u * NC + c];
+                            v[c] = L.jcState[c] >= 0 ? a : AUGX_NINF;
+                        }
+                        int igC = -1;
+                        for (int c = 0; c < NC; c++) if (L.jcState[c] >= 0 && L.jcSig[c] == SIG_EIG) igC = c;
+                        uint64_t rowW[SP / 4], bpcW = ~0ull;
+                        int rowOf = -1;
+                        for (int q = qa; q < qb; q++) {
+                            const int64_t g = o + 1 + q;
+                            const double eIg = gp(B.sig)[g * NSIG + SIG_EIG], eIn = gp(B.sig)[g * NSIG + SIG_EIN];
+                            int alive = 0;
+                            for (int c = 0; c < NC; c++) {
+                                if (L.jcState[c] < 0) continue;
+                                v[c] += L.jcTr[c] + (L.jcSig[c] == SIG_EIG ? eIg : eIn);
+                                alive |= (v[c] > AUGX_NINF ? 1 : 0) << c;
+                            }
+                            if (alive != rowOf) { // the row of back pointers (8-byte words, as flushBpThread moves them) changes only when a state dies
+                                rowOf = alive;
+                                bpcW = ~0ull;
+#pragma unroll
+                                for (int wd = 0; wd < SP / 4; wd++) rowW[wd] = 0x0001000100010001ull * (uint64_t)BP_NONE;
+                                for (int c = 0; c < NC; c++) {
+                                    if (!((alive >> c) & 1)) continue;
+                                    const int s2 = L.jcState[c];
+                                    bpcW = (bpcW & ~(0xFFull << (8 * c))) | ((uint64_t)(uint8_t)L.jcSelf[c] << (8 * c));
+#pragma unroll
+                                    for (int wd = 0; wd < SP / 4; wd++)
+                                        if (wd == s2 / 4) rowW[wd] = (rowW[wd] & ~(0xFFFFull << (16 * (s2 % 4)))) | ((uint64_t)bpFixed(L.jcSelf[c]) << (16 * (s2 % 4)));
+                                }
+                            }
+#pragma unroll
+                            for (int wd = 0; wd < SP / 4; wd++) gp((uint64_t *)B.bp)[g * (SP / 4) + wd] = rowW[wd];
+                            gp((uint64_t *)B.bpChain)[g] = bpcW;
+                            double vIg = AUGX_NINF;
+#pragma unroll
+                            for (int c = 0; c < NC; c++) vIg = c == igC ? v[c] : vIg;
+                            gp(B.vig)[g] = vIg;
+                            for (int k = 0; k < 6; k++) gp(B.longV)[g * 6 + k] = AUGX_NINF;
+                            if (wantCells) {
+                                for (int s2 = 0; s2 < S; s2++) gp(B.cells)[g * S + s2] = AUGX_NINF;
+                                for (int c = 0; c < NC; c++) if (L.jcState[c] >= 0) gp(B.cells)[g * S + L.jcState[c]] = v[c];
+                            }
+                            if (B.ckCol && (q & 63) == 63) { // the column at the end of a tile
+                                for (int s2 = 0; s2 < SP; s2++) gp(B.ckCol)[(o / WAVE + q / WAVE) * SP + s2] = AUGX_NINF;
+                                for (int c = 0; c < NC; c++) if (L.jcState[c] >= 0) gp(B.ckCol)[(o / WAVE + q / WAVE) * SP + L.jcState[c]] = v[c];
+                            }
+                            if (q >= jE - WAVE) { // what the ring holds where the run lands
+                                for (int s2 = 0; s2 < SP; s2++) L.ring[q & 63][s2] = AUGX_NINF;
+                                for (int c = 0; c < NC; c++) if (L.jcState[c] >= 0) L.ring[q & 63][L.jcState[c]] = v[c];
+                            }
+                            if (q >= jE - VIG_WIN) L.vigw[q & (VIG_WIN - 1)] = vIg;
+                        }
+                        for (int i = t; i < 2 * WAVE * 6; i += NT) L.longW[i / (WAVE * 6)][(i / 6) % WAVE][i % 6] = AUGX_NINF;
+                        if (t == 0) { // the progress counters as a run that starts at tile tJ has them; in the comparing passes the tiles jumped count as not verified
+                            const int gbJ = tJ * NB;
+                            for (int i = 0; i < NWORK; i++) { L.flagF[i] = gbJ; L.flagI[i] = gbJ; }
+                            L.flagSum = NWORK * gbJ; L.flagG = gbJ; L.flagNr = gbJ; L.flagN = gbJ; L.flagC = gbJ; L.flagR = tJ; L.rtPub = 0;
+                            L.staged = (NWAVES - W_LOAD) * tJ;
+                            if (CMP && L.lastBad < tJ - 1) L.lastBad = tJ - 1;
+                        }
+                    }
+                    BLOCK_GLOBAL_SYNC();
+                    FOR_THREADS(t) { loadTileThread<BLK>(X, tJ, tJ & 1, t, NT, false); }
+                    BLOCK_GLOBAL_SYNC();
+                    rtNext = tJ * NB; farPre = 0;
+                    tResume = tJ; tLast = tJ - 1;
+                    quiet = false; quietRun = 0;
+                    tile = tJ - 1; // (the loop goes on with tile tJ)
+                }
+            }
+        }
     }
 #if !defined(AUGX_EMU) && defined(AUGX_PROFILE)
     if (B.prof && (threadIdx.x & 63) == 0 && threadIdx.x < 5 * WAVE)
@@ -2421,7 +2581,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             const bool otherIsNext = CMP && tLast + 1 < nTiles;
             for (int i = t; i < 2 * WAVE * NSITE; i += NT) {
                 const int bsel = i / (WAVE * NSITE), l = (i / NSITE) % WAVE, sel = i % NSITE;
-                if (bsel == 1 && (tLast - tStart + 1 < 2 || otherIsNext)) continue; // (the other buffer was never loaded)
+                if (bsel == 1 && (tLast - tResume + 1 < 2 || otherIsNext)) continue; // (the other buffer was never loaded)
                 const int si = L.site[(tLast & 1) ^ bsel][l][sel];
                 if (si >= 0) {
                     double *a = sel == 0 ? B.laVal : sel == 1 ? B.lrVal : sel == 2 ? B.ldVal : B.rdVal;

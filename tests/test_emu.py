@@ -180,10 +180,12 @@ def test_emulated_segment_parallel_trellis(monkeypatch, env):
     from helpers import EMU_LIB
     E = ctypes.CDLL(EMU_LIB)
     E.emu_quiet_tiles.restype = ctypes.c_longlong
-    q0 = E.emu_quiet_tiles()
+    E.emu_jump_tiles.restype = ctypes.c_longlong
+    q0, j0 = E.emu_quiet_tiles(), E.emu_jump_tiles()
     res = emu_decode(m.tables_ptr, seqs, S, cells=True)
-    # (the run of 150 000 N is walked as chain-only tiles -- by pass 1 and again by the fix-ups that cannot converge inside it)
-    assert E.emu_quiet_tiles() - q0 >= 2000
+    # (the run of 150 000 N: a dozen chain-only tiles, then a jump to its end -- by pass 1 and again by the fix-ups and continuations
+    #  that cannot converge inside it; with one workgroup per piece one jump, with segments one per segment that lies in it)
+    assert E.emu_quiet_tiles() - q0 >= 10 and E.emu_jump_tiles() - j0 >= 2000
     for seq, (st, lnv, path, V, cls) in zip(seqs, res):
         rc, lnv2, path2, V2, _ = twin_decode(m.tables_ptr, seq, S, cells=True)
         assert st == 0 and rc == 0 and lnv == lnv2, len(seq)
