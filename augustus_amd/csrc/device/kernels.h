@@ -489,6 +489,7 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
 // src/intronmodel.cc:585-629); the tie-break "larger key wins" is the reference's descending loop with strict '>'.
 // =================================================================================================
 #ifdef AUGX_EMU
+static long long g_emuJumpProbes = 0, g_emuJumps = 0, g_emuQuietChecks = 0;
 static long long g_emuQuietTiles = 0, g_emuJumpTiles = 0; // tiles the trellis took as chain-only tiles / jumped over in a run of N (trellisPiece)
 static long long g_emuSlowA = 0, g_emuSlowB = 0, g_emuSlowVig = 0, g_emuSlowList = 0, g_emuSlowWaves = 0, g_emuItemWaves = 0; // emulator statistics: candidates taking the general evaluation path
 #endif
@@ -2124,6 +2125,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
     bool gaveUp = false;     // (fix-up pass) stopped at its limit without having converged
     bool quiet = false;      // the tile about to be computed is a chain-only tile (settled at the end of the tile before it)
     int quietRun = 0;        // ... and so many tiles before it were
+    int jumpRetry = 0;       // no probe for a jump over a run of N before this tile (the last one found too little to jump over)
     for (int tile = tStart; tile < tEnd; tile++) {
         const int buf = tile & 1, j0 = tile * WAVE;
         FOR_WAVES(w) {
@@ -2398,6 +2400,9 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         quiet = false;
         if (tile + 1 < tEnd && L.blkItem[buf ^ 1][NB] == 0) { // (uniform: staged before the barrier of this tile)
             const int jn0 = j0 + WAVE;
+#ifdef AUGX_EMU
+            g_emuQuietChecks++;
+#endif
             FOR_THREADS(t) { if (t == 0) L.quietBad = 0; }
             BLOCK_SYNC();
             FOR_THREADS(t) {
@@ -2431,7 +2436,10 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
         // with 11 % N before this, profiles/r05_*.)  In the comparing passes the jumped tiles count as not verified.
         constexpr int JUMP_MIN = 32; // tiles worth the fixed cost of a jump
         const int jumpAfter = (dL + 3 * WAVE - 1) / WAVE + 1;
-        if (quiet && quietRun >= jumpAfter && tEnd - 1 - (tile + 1) >= JUMP_MIN) {
+        if (quiet && quietRun >= jumpAfter && tile >= jumpRetry && tEnd - 1 - (tile + 1) >= JUMP_MIN) {
+#ifdef AUGX_EMU
+            g_emuJumpProbes++;
+#endif
             const int jS = (tile + 1) * WAVE;
             const int hi = (tEnd - 1) * WAVE < n ? (tEnd - 1) * WAVE : n; // (the last tile of the run is always walked)
             const int step = (hi - jS + NT - 1) / NT;
@@ -2439,9 +2447,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             auto sitesAt = [&](int q) { uint32_t c4 = 0; for (int i = CNT_ATG; i <= CNT_RS; i++) c4 += gp(B.cnt)[fidx(o + 1 + q, i, NCNT)]; return c4; };
             FOR_THREADS(t) { if (t == 0) L.jumpFirst = -NT; }
             BLOCK_SYNC();
-            FOR_THREADS(t) { // the first stretch with a nucleotide (or a list site: there is none without one, but the jump rests on it)
+            FOR_THREADS(t) { // the first stretch with a nucleotide (or a list site: there is none without one, but the jump rests on it),
+                             // or, in a piece with several GC classes, with a base of another plane than the one the run of N is in now
+                             // (the transition terms follow the plane: a jump stays in one)
                 const int qa = jS + t * step, qb = jS + (t + 1) * step < hi ? jS + (t + 1) * step : hi;
-                if (qa < qb && (nucAt(qb - 1) != nucAt(qa - 1) || sitesAt(qb - 1) != sitesAt(qa - 1))) ldsMaxI(&L.jumpFirst, -t);
+                bool stop = qa < qb && (nucAt(qb - 1) != nucAt(qa - 1) || sitesAt(qb - 1) != sitesAt(qa - 1));
+                if (X.multi && qa < qb && !stop) {
+                    const uint8_t pl0 = gp(B.gcPlane)[o + 1 + jS - 1];
+                    for (int q = qa; q < qb; q++) stop |= gp(B.gcPlane)[o + 1 + q] != pl0;
+                }
+                if (stop) ldsMaxI(&L.jumpFirst, -t);
             }
             BLOCK_SYNC();
             const int fT = -L.jumpFirst;
@@ -2449,6 +2464,7 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             if (jN > hi) jN = hi;
             const int tJ = (jN - 2 * WAVE) / WAVE; // land two tiles before what may hold one
             BLOCK_SYNC();
+            jumpRetry = tile + 16; // (no jump from here: the probe is not repeated at every tile of the run's tail)
             if (tJ - (tile + 1) >= JUMP_MIN) {
                 const int jE = tJ * WAVE, len = jE - jS, per = (len + NT - 1) / NT;
                 double *part = (double *)&L.items[0][0]; // [NT][8] sums of the stretches (the staged candidates are not needed: the run re-stages where it lands)
@@ -2465,7 +2481,6 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                         L.jcTr[slot] = live ? lnT(T, cc, s2, s2) : AUGX_NINF;
                         L.jcV0[slot] = live ? L.ring[(jS - 1) & 63][s2] : AUGX_NINF;
                     }
-                    if (t == 0) L.quietBad = 0;
                 }
                 BLOCK_SYNC();
                 constexpr int NC = 8;
@@ -2473,22 +2488,16 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
                     const int qa = jS + t * per, qb = jS + (t + 1) * per < jE ? jS + (t + 1) * per : jE;
                     double acc[NC];
                     for (int c = 0; c < NC; c++) acc[c] = 0.0;
-                    const int pl0 = X.multi ? (int)gp(B.gcPlane)[o + 1 + jS - 1] : 0;
-                    bool bad = false;
                     for (int q = qa; q < qb; q++) {
                         const double eIg = gp(B.sig)[(o + 1 + q) * NSIG + SIG_EIG], eIn = gp(B.sig)[(o + 1 + q) * NSIG + SIG_EIN];
                         for (int c = 0; c < NC; c++) acc[c] += L.jcTr[c] + (L.jcSig[c] == SIG_EIG ? eIg : eIn);
-                        if (X.multi && (int)gp(B.gcPlane)[o + 1 + q] != pl0) bad = true;
                     }
                     for (int c = 0; c < NC; c++) part[t * NC + c] = acc[c];
-                    if (bad) ldsMaxI(&L.quietBad, 1);
                 }
                 BLOCK_SYNC();
-                const bool onePlane = L.quietBad == 0;
-                BLOCK_SYNC();
-                if (onePlane) {
+                {
 #ifdef AUGX_EMU
-                    g_emuJumpTiles += tJ - (tile + 1);
+                    g_emuJumpTiles += tJ - (tile + 1); g_emuJumps++;
 #endif
                     FOR_THREADS(t) {
                         const int qa = jS + t * per, qb = jS + (t + 1) * per < jE ? jS + (t + 1) * per : jE;

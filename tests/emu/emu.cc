@@ -314,6 +314,9 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
 }
 
 extern "C" {
+long long emu_jump_probes() { return g_emuJumpProbes; }
+long long emu_jumps() { return g_emuJumps; }
+long long emu_quiet_checks() { return g_emuQuietChecks; }
 long long emu_jump_tiles() { return g_emuJumpTiles; }   // (tests: runs of N were jumped over)
 long long emu_quiet_tiles() { return g_emuQuietTiles; } // (tests: the chain-only path of trellisPiece was taken)
 int emu_near_ties(int p) { return p >= 0 && p < (int)g_nearTies.size() ? g_nearTies[p] : -1; }
