@@ -18,6 +18,7 @@
 #include <map>
 #include <vector>
 #include <algorithm>
+#include <utility>
 #include "dp.h"
 
 namespace augx {
@@ -47,6 +48,9 @@ struct SnippetReplay {
     // the candidate records of its blocks (pool / blkPool), the rows fRow0.. of F, the prefix slots fx0.. .  Whole mode (the
     // emulator, whose arrays are host memory anyway): fetch is empty, everything above points at the whole piece.
     std::function<int(int, int)> fetch;   // (t0, t1) -> 0, or an error code that run() hands on
+    // (optional) told every window of the piece before the first one is replayed -- {t0, t1} in the order run() takes them --, so
+    // that what they read can come from HBM in one go; fetch then only has to pick the window's part
+    std::function<int(const std::vector<std::pair<int, int>> &)> prefetch;
     std::vector<Item> pool;
     std::vector<int64_t> blkPool;         // [nBlocks] first record of the block in pool, -1: not fetched
     const double *F0 = nullptr;           // row 0 of F (the initial column), windowed mode
@@ -185,15 +189,24 @@ struct SnippetReplay {
         std::vector<int> steps;
         for (int j = 1; j < n; j++)
             if (plane[j] != plane[j - 1]) steps.push_back(j);
-        size_t i = 0;
-        while (i < steps.size()) {
+        std::vector<std::pair<int, int>> wins; // {first step, t1} of every window
+        for (size_t i = 0; i < steps.size();) {
             const int first = steps[i];
             int t1 = first + 2 * d + 64;
             size_t k = i + 1;
             while (k < steps.size() && steps[k] - d - 64 <= t1) { t1 = steps[k] + 2 * d + 64; k++; }
-            if (fetch) { const int rc = fetch(first - d - 64, t1); if (rc) return rc; }
-            window(first - d - 64, t1, first);
+            wins.push_back({first, t1});
             i = k;
+        }
+        if (prefetch) {
+            std::vector<std::pair<int, int>> tt;
+            for (auto &w : wins) tt.push_back({w.first - d - 64, w.second});
+            const int rc = prefetch(tt);
+            if (rc) return rc;
+        }
+        for (auto &w : wins) {
+            if (fetch) { const int rc = fetch(w.first - d - 64, w.second); if (rc) return rc; }
+            window(w.first - d - 64, w.second, w.first);
         }
         return 0;
     }
