@@ -4,9 +4,12 @@
 // Launch shapes (MI355X: 256 CUs, wave64):
 //   prep kernels : one thread per slot, 256-thread blocks, grid = N/256  (HBM-streaming, fully coalesced rows)
 //   scans        : grid (chunks x fields), 256 threads x 4 slots, rows of CHUNK=1024 contiguous uint64
-//   candidates   : one wavefront per tile of 64 bases, 8 tiles per workgroup, 2 workgroups per CU (76 KB LDS, 128 VGPRs)
-//   trellis      : one workgroup of 8 wavefronts per piece = one CU per piece (155 KB LDS), position-sequential
+//   candidates   : one wavefront per tile of 64 bases, 8 tiles per workgroup, 2 workgroups per CU (77 KB LDS, 64 VGPRs)   [k_cand.hip]
+//   trellis      : one workgroup of 8 role-specialised wavefronts per SEGMENT of a piece = one CU per segment (156 KB LDS),
+//                  position-sequential inside it; fix-ups and continuations in further launches                           [k_trellis.hip]
+//   dense        : one workgroup per piece (models with UTR states / two intergenic states)                                [k_dense.hip]
 //   backtrace    : one wavefront per piece
+// The heavy kernel families are translation units of their own (launch.h); this file keeps the prep kernels and the host objects.
 // There is no CPU fallback anywhere in this file: without a HIP device augx_decoder_create fails.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>

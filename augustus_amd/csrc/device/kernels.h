@@ -47,7 +47,7 @@ namespace dev {
 #define GLOBAL_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 #define AUGX_KFN __device__ __forceinline__
 #define FOR_THREADS(t) for (int t = (int)threadIdx.x, _once = 1; _once; _once = 0)
-constexpr int RW = -1; // (EXPERIMENT: shadowed by a template parameter where the wavefront's index is a compile-time constant)
+constexpr int RW = -1; // (shadowed by trellisPiece's template parameter where the wavefront's index is a compile-time constant: one instantiation per role)
 #define FOR_WAVES(w) for (int w = (RW >= 0 ? RW : (int)(threadIdx.x >> 6)), _oncew = 1; _oncew; _oncew = 0)
 #define FOR_WLANES(t, w) for (int t = (int)threadIdx.x, _once = 1; _once; _once = 0)
 #define TV(T, name) T name[1]
@@ -1259,13 +1259,16 @@ AUGX_KFN void candWorkgroup(const DevTables &T, const BatchView &B, CandLds &L, 
 }
 
 // =================================================================================================
-// K2b  trellis: one workgroup of NWAVES wavefronts per piece.  Five wavefronts (three candidate workers, the chain
-// wavefront, the far wavefront) walk the piece block by block, synchronised by progress counters in LDS, with no
-// workgroup barrier inside a tile of 64 bases; the loader wavefronts stage the next tile (signal records, candidates)
-// into the second half of the LDS buffers and retire the previous one (back pointers, igenic column, long-lag cells,
-// list values) to HBM.  See trellisPiece for the schedule and DESIGN.md section 5 for the reasoning.
+// K2b  trellis: one workgroup of NWAVES wavefronts per run of tiles of a piece (a segment).  Six wavefronts walk it block by
+// block, synchronised by progress counters in LDS, with no workgroup barrier inside a tile of 64 bases: three workers (the near
+// fixed-lag states of the block, then a third each of its candidates: the one hand-off of the cycle is among them), the chain
+// wavefront (geometric intron states), the far wavefront (far fixed-lag states, cell resets, RTERMINAL candidates) and the igenic
+// wavefront; two loader wavefronts stage the next tile (signal records, candidates) into the second half of the LDS buffers and
+// retire the previous one (back pointers, igenic column, long-lag cells, list values) to HBM.  Every wavefront runs the
+// instantiation of trellisPiece made for its role (k_trellis.hip: RW).  Runs of N are not walked: chain-only ("quiet") tiles, then
+// a jump.  See trellisPiece for the schedule and DESIGN.md section 5 for the reasoning.
 // =================================================================================================
-constexpr int NWORK = 3, W_C = 3, W_X = 4, W_I = 5, W_LOAD = 6; // trellis workgroup: wavefronts 0..2 workers, 3 near/late + geometric states, 4 far fixed-lag states, 5 igenic, 6.. loaders
+constexpr int NWORK = 3, W_C = 3, W_X = 4, W_I = 5, W_LOAD = 6; // trellis workgroup: wavefronts 0..2 workers (near / late fixed-lag states + candidates), 3 geometric states, 4 far fixed-lag states, 5 igenic, 6.. loaders
 constexpr int LOAD_T = (8 - W_LOAD) * WAVE;                     // threads of the loader wavefronts
 constexpr int ITEM_CAP = AUGX_ITEM_CAP;   // candidates of one tile staged in LDS (the rest, if any, is read from HBM; a tile of random DNA has ~940)
 

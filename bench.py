@@ -484,6 +484,9 @@ def genome_like_leg(cfg, a, n_dev, d, exe, run):
     th = threading.Thread(target=watch)
     th.start()
     rss0 = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    # (a process that starts while the driver still clears the 100+ GB of HBM its predecessors gave back waits seconds in its first
+    #  allocations -- 4 s measured in ensureArrays here, 2 ms on a quiet device: a pause, as before the sampled leg)
+    time.sleep(6.0)
     try:
         r = run(["--species=human"], fa, bases, reps=1, golden="genome_like_big")
     finally:
