@@ -567,7 +567,10 @@ AUGX_HD void fillVarConst(const DevTables &T, const BatchView &B, int p, int l, 
     VC.g = exGeom(T, (kind >= AUGX_K_SINGLE && kind <= AUGX_K_RTERMINAL) ? kind : AUGX_K_INTERNAL);
 }
 
-constexpr int DCAP = 96; // descriptors of a tile that stay in LDS between the counting and the emitting pass (>= WAVE)
+#ifndef AUGX_DCAP
+#define AUGX_DCAP 96
+#endif
+constexpr int DCAP = AUGX_DCAP; // descriptors of a tile that stay in LDS between the counting and the emitting pass (>= WAVE)
 struct CandLds {
     VarConst vc[SP];
     VarDesc desc[NWAVES][DCAP];                          // per wavefront (= tile): descriptors of its (base, state) pairs

@@ -37,6 +37,8 @@ def make_case(seed, g):
                 parts.append(gc_dna(L, rng.choice([0.3, 0.4, 0.45, 0.5, 0.6, 0.7])))
             else:
                 parts.append(gc_dna(L // 2, 0.45) + "N" * rng.choice([1, 50, 900]) + gc_dna(L // 2, 0.55).lower())
+            if os.environ.get("SOAK_NRUNS") and rng.random() < 0.5:  # (SOAK_NRUNS=1: long runs of N -- chain-only tiles and jumps of the trellis kernel)
+                parts.append("N" * rng.choice([3000, 12000, 50000, 150000]))
         recs.append(("r%d" % k, "".join(parts)))
     species = rng.choice(["human", "fly", "arabidopsis", "saccharomyces", "human", "fly"])
     opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
