@@ -844,26 +844,31 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     else std::cout << " Using default transition matrix.";
     std::cout << std::endl;
 
-    // The input is read on a helper thread while THIS thread brings the decoders up (HIP context, streams, tables: 0.1-0.2 s, as
-    // long as reading 100 Mbp takes).  (The other way round -- decoders on the helper thread -- was tried in round 2: the decode that
-    // followed on the main thread took 1.6-2.4 s instead of 0.25 s.)  Errors are reported in the reference's order: input first.
     std::vector<Record> recs;
-    int fastaState = 0; // 1: could not open, 2: format not recognised
-    std::thread fastaThread([&]() {
+    {
         bool ok;
         if (queryfile == "-") ok = readFasta(std::cin, recs);
         else {
             std::ifstream in(queryfile.c_str());
-            if (!in) { fastaState = 1; return; }
+            if (!in) { restore(); return fail("Could not open input file \"" + queryfile + "\"!"); }
             ok = readFasta(in, recs);
         }
-        if (!ok) fastaState = 2;
-    });
+        if (!ok) { restore(); return fail("File format of " + queryfile + " not recognized (only FASTA input is supported on the MI355X path)."); }
+    }
+    lap("FASTA read");
+    if (verbosity > 2) {
+        if (queryfile == "-") std::cout << "# Reading sequences from standard input. Assuming fasta format." << std::endl;
+        else std::cout << "# Looks like " << queryfile << " is in fasta format." << std::endl;
+    }
+    if (verbosity > 0) std::cout << "# We have hints for 0 sequences and for 0 of the sequences in the input set." << std::endl;
+
     const long maxstep = M.opt.getInt("maxDNAPieceSize", 1000000);
-    std::string devErr;
+    if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); S.destroy(); return 1; }
     {   // ---- devices: every visible GPU, or the ones named by AUGX_DEVICES ("0,2,5"; a single number N = the first N);
         //      AUGX_DEVICE (one index) is kept for single-device runs.  (Bringing the decoders up on a thread of their own while
-        //      the input is read was tried: the decode that followed, on the main thread, took 1.6-2.4 s instead of 0.25 s.)
+        //      the input is read was tried: the decode that followed, on the main thread, took 1.6-2.4 s instead of 0.25 s.  Round 5
+        //      tried it the other way round -- the input read on a helper thread, the decoders on this one: the same, 2.5 s, three
+        //      batches instead of one.  Whatever a second thread touches first, the uploads that follow crawl; the two stay in sequence.)
         std::vector<int> devs;
         const int ndev = augx_device_count();
         if (const char *e = getenv("AUGX_DEVICES")) {
@@ -878,22 +883,12 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (int dv : devs) {
             augx_decoder *d = nullptr;
             rc = augx_decoder_create(S.model, dv, &d);
-            if (rc) { devErr = augx_last_error(); break; }
+            if (rc) { restore(); return fail(augx_last_error()); }
             S.decs.push_back(d);
         }
     }
+
     lap("device / decoder create");
-    fastaThread.join();
-    if (fastaState == 1) { restore(); return fail("Could not open input file \"" + queryfile + "\"!"); }
-    if (fastaState == 2) { restore(); return fail("File format of " + queryfile + " not recognized (only FASTA input is supported on the MI355X path)."); }
-    lap("FASTA read"); // (what of it was not hidden under the decoder create)
-    if (verbosity > 2) {
-        if (queryfile == "-") std::cout << "# Reading sequences from standard input. Assuming fasta format." << std::endl;
-        else std::cout << "# Looks like " << queryfile << " is in fasta format." << std::endl;
-    }
-    if (verbosity > 0) std::cout << "# We have hints for 0 sequences and for 0 of the sequences in the input set." << std::endl;
-    if (maxstep < 1000) { std::cerr << "maxDNAPieceSize is too small: " << maxstep << std::endl; restore(); S.destroy(); return 1; }
-    if (!devErr.empty()) { restore(); return fail(devErr); }
 
     // --predictionStart / --predictionEnd: predict on a piece of the first sequence only and shift the printed coordinates
     // (reference cutRelevantPiece, src/augustus.cc:552-602)

@@ -318,13 +318,11 @@ def e2e_legs(cfg, model, local, contigs):
                           "region": "augustus --species=human bench.fa (process start, parameter load, FASTA parse, decode on 1 GPU, GFF file written); the faster of two runs (a run that starts while the driver still clears the device memory of the process before it waits seconds in its first allocations)"}
             # first byte of FASTA read -> last byte of GFF written, the one-time model create (parameter files, HIP
             # context, table upload) excluded: the laps of the executable's own clock (AUGX_TIMING)
-            # (round 5: the input is read on a helper thread WHILE the decoders come up, so the span from the first byte read to the last
-            #  byte written now holds the decoder create -- "device / decoder create" + what of the read was not hidden under it)
-            core = [laps.get(k2) for k2 in ("device / decoder create", "FASTA read", "cut finder", "decode of the pieces", "genes + GFF")]
+            core = [laps.get(k2) for k2 in ("FASTA read", "cut finder", "decode of the pieces", "genes + GFF")]
             if all(x is not None for x in core):
                 out["fasta_to_gff"] = {"value": bases / 1e6 / sum(core), "unit": "Mbp/s", "seconds": sum(core),
-                                       "region": "first byte of the FASTA file read -> last byte of the GFF file written, 1 GPU (the input is read while the HIP context / "
-                                                 "decoders come up: both are in the span); excluded: process start, parameter load, teardown (laps_s of cli)"}
+                                       "region": "FASTA file read + cut finder + decode of all pieces on 1 GPU + gene structures + GFF file written; "
+                                                 "excluded: process start, parameter load, HIP context / decoder create, teardown (laps_s of cli)"}
             # ---- the same executable with posterior sampling (the default of 162 of the reference's species): forward algorithm on the
             #      device, 99 sampled paths per contig on the host, posterior probabilities in the GFF
             ns = n  # (round 3 timed 32 of the contigs; with 100 the decoder takes two batches, 64 + 36 Mbp: the forward matrix halves what fits)
