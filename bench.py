@@ -153,10 +153,30 @@ def bounded_line(out, limit=LINE_LIMIT):
                 o = o[k]
             del o[pth[-1]]
             continue
+        # then the lap tables of the executable's runs (largest first), then whole secondary legs -- the ones that carry a parity
+        # flag against the reference's goldens (product) last
+        laps = []
+        def find_laps(o, path=()):
+            if isinstance(o, dict):
+                for k, v in o.items():
+                    if k == "laps_s" and isinstance(v, dict):
+                        laps.append((len(json.dumps(v)), path + (k,)))
+                    else:
+                        find_laps(v, path + (k,))
+        find_laps(out)
+        if laps:
+            _, pth = max(laps)
+            o = out
+            for k in pth[:-1]:
+                o = o[k]
+            del o[pth[-1]]
+            continue
         extra = [k for k in out if k not in keep]
         if not extra:
             break
-        del out[extra[-1]]
+        order = ["cli_sampled", "cli", "e2e", "two_batches_in_flight", "fasta_to_gff", "gc_steps", "strong", "timed_region", "utr", "product"]
+        extra.sort(key=lambda k: order.index(k) if k in order else -1)
+        del out[extra[0]]
     line = json.dumps(out)
     assert len(line) < limit, "bench line of %d bytes" % len(line)
     return line
