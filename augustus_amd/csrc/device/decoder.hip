@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) kEncode(BatchView B) {
 }
 // (min, max) of the window classes of every 256 slots (no atomics: tens of thousands of wavefronts of one piece hammering the
 // same two words cost more than the rest of the kernel); kClassFinal folds them per piece
-__global__ void __launch_bounds__(256) kWindowClass(const DevTables *T, BatchView B, int32_t *blkMinMax) {
+__global__ void __launch_bounds__(256) kWindowClass(const DevTables *__restrict__ T, BatchView B, int32_t *blkMinMax) {
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int c = g < B.N ? k1WindowClass(*T, B, g) : -1;
     // all slots of a block belong to one piece (pieces are CHUNK-aligned, 256 | CHUNK): reduce in the wave first
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(64) kClassFinal(BatchView B, const int32_t *bl
 // between two runs of one class is dissolved, classes are numbered by first appearance (planes), every base gets its plane.
 // One workgroup per piece; a piece with more runs than STAIR_RUNS is left to the host (info[1] is set).
 constexpr int STAIR_RUNS = 4096;
-__global__ void __launch_bounds__(256) kStairs(const DevTables *T, BatchView B, int32_t *info /* [0] max planes, [1] pieces left to the host */) {
+__global__ void __launch_bounds__(256) kStairs(const DevTables *__restrict__ T, BatchView B, int32_t *info /* [0] max planes, [1] pieces left to the host */) {
     const int p = blockIdx.x, t = threadIdx.x;
     if (B.cls[p] >= 0) return; // all windows agree: one class, plane 0 (gcPlane is zero)
     __shared__ int st[STAIR_RUNS];
@@ -175,16 +175,16 @@ __global__ void kListCount(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < B.nPieces) k1ListCount(B, p);
 }
-__global__ void __launch_bounds__(256) kSignals(const DevTables *T, BatchView B) {
+__global__ void __launch_bounds__(256) kSignals(const DevTables *__restrict__ T, BatchView B) {
     __shared__ SlotCodes C;
     C.load(B);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1Signals(*T, B, g, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
-__global__ void __launch_bounds__(256) kSiteSignals(const DevTables *T, BatchView B) {
+__global__ void __launch_bounds__(256) kSiteSignals(const DevTables *__restrict__ T, BatchView B) {
     k1SiteSignals(*T, B, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y);
 }
-__global__ void __launch_bounds__(256) kSiteConsts(const DevTables *T, BatchView B) { // grid.y = plane
+__global__ void __launch_bounds__(256) kSiteConsts(const DevTables *__restrict__ T, BatchView B) { // grid.y = plane
     __shared__ SlotCodes C;
     C.load(B);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -250,7 +250,7 @@ template <int NF> __device__ inline void blockScan(uint64_t (&v)[NF], int nSum, 
     }
 }
 constexpr int NSF = NCNT + 6; // site scans: 11 counts (sums) then 6 stop positions (maxima)
-__global__ void __launch_bounds__(SCAN_T) kSiteScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [N / SCAN_T][NSF] */) {
+__global__ void __launch_bounds__(SCAN_T) kSiteScanTotals(const DevTables *__restrict__ T, BatchView B, uint64_t *tot /* [N / SCAN_T][NSF] */) {
     __shared__ ScanLds<NSF> L;
     __shared__ SlotCodes C;
     C.load(B);
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(SCAN_T) kSiteScanTotals(const DevTables *T, Ba
     k1SiteTermsCalc(*T, B, g, v, v + NCNT, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
     blockTotals<NSF>(v, NCNT, L, tot + (int64_t)blockIdx.x * NSF);
 }
-__global__ void __launch_bounds__(SCAN_T) kSiteScanApply(const DevTables *T, BatchView B, const uint64_t *tot) {
+__global__ void __launch_bounds__(SCAN_T) kSiteScanApply(const DevTables *__restrict__ T, BatchView B, const uint64_t *tot) {
     __shared__ ScanLds<NSF> L;
     __shared__ SlotCodes C;
     C.load(B);
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(SCAN_T) kSiteScanApply(const DevTables *T, Bat
 #pragma unroll
     for (int f = 0; f < 6; f++) B.nsm[fidx(g, f, 6)] = (uint32_t)v[NCNT + f];
 }
-__global__ void __launch_bounds__(SCAN_T) kFxScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [nPl][N / SCAN_T][NFX] */) { // grid.y = plane
+__global__ void __launch_bounds__(SCAN_T) kFxScanTotals(const DevTables *__restrict__ T, BatchView B, uint64_t *tot /* [nPl][N / SCAN_T][NFX] */) { // grid.y = plane
     __shared__ ScanLds<NFX> L;
     __shared__ SlotCodes C;
     C.load(B);
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(SCAN_T) kFxScanTotals(const DevTables *T, Batc
     if (!k1FxTermsCalc(*T, B, g, blockIdx.y, v, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO)) return; // (uniform over the block: it belongs to one piece)
     blockTotals<NFX>(v, NFX, L, tot + ((int64_t)blockIdx.y * (B.N / SCAN_T) + blockIdx.x) * NFX);
 }
-__global__ void __launch_bounds__(SCAN_T) kFxScanApply(const DevTables *T, BatchView B, const uint64_t *tot) { // grid.y = plane
+__global__ void __launch_bounds__(SCAN_T) kFxScanApply(const DevTables *__restrict__ T, BatchView B, const uint64_t *tot) { // grid.y = plane
     __shared__ ScanLds<NFX> L;
     __shared__ SlotCodes C;
     C.load(B);
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(64) kChunkOffsets(uint64_t *tot, BatchView B, 
 // ---- untranslated regions (dense.h): content prefix sums + begin-site counts in one fused scan, then the signal records, the
 // end gates of the UTR exon states and the entries of the site lists
 constexpr int NUF = NUFX + NUCNT;
-__global__ void __launch_bounds__(SCAN_T) kUtrScanTotals(const DevTables *T, BatchView B, uint64_t *tot /* [N / SCAN_T][NUF] */) {
+__global__ void __launch_bounds__(SCAN_T) kUtrScanTotals(const DevTables *__restrict__ T, BatchView B, uint64_t *tot /* [N / SCAN_T][NUF] */) {
     __shared__ ScanLds<NUF> L;
     __shared__ SlotCodes C;
     C.load(B);
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(SCAN_T) kUtrScanTotals(const DevTables *T, Bat
     k1UtrTermsCalc(*T, B, g, v, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
     blockTotals<NUF>(v, NUF, L, tot + (int64_t)blockIdx.x * NUF);
 }
-__global__ void __launch_bounds__(SCAN_T) kUtrScanApply(const DevTables *T, BatchView B, const uint64_t *tot) {
+__global__ void __launch_bounds__(SCAN_T) kUtrScanApply(const DevTables *__restrict__ T, BatchView B, const uint64_t *tot) {
     __shared__ ScanLds<NUF> L;
     __shared__ SlotCodes C;
     C.load(B);
@@ -347,7 +347,7 @@ __global__ void kUtrListCount(BatchView B) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < B.nPieces) k1UtrListCount(B, p);
 }
-__global__ void __launch_bounds__(256) kUtrSignals(const DevTables *T, BatchView B) {
+__global__ void __launch_bounds__(256) kUtrSignals(const DevTables *__restrict__ T, BatchView B) {
     __shared__ SlotCodes C;
     C.load(B);
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -656,7 +656,7 @@ int augx_decoder_create(const augx_model *m, int device, augx_decoder **out) {
             HIP_TRY(hipMalloc(&p, bytes));
             d->tableBufs.push_back(p);
             if (sp.count > 0) HIP_TRY(hipMemcpy(p, sp.src, (size_t)sp.count * sizeof(double), hipMemcpyHostToDevice));
-            *sp.dst = (const double *)p;
+            *sp.dst = (TabPtr)p;
         }
         HIP_TRY(hipMalloc((void **)&d->dT, sizeof(DevTables)));
         HIP_TRY(hipMemcpy(d->dT, &d->hostT, sizeof(DevTables), hipMemcpyHostToDevice));
@@ -1675,7 +1675,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         P.uh.reset(new SamplePiece::UtrHost());
         SamplePiece::UtrHost &U = *P.uh;
         fillDevTablesScalars(t, U.T);
-        for (auto &sp : tableSpans(t, U.T)) *sp.dst = sp.src; // (host tables)
+        for (auto &sp : tableSpans(t, U.T)) *sp.dst = (TabPtr)sp.src; // (host tables)
         const int64_t slots = b->L.off[piece + 1] - o, ch0 = o / CHUNK, nch = slots / CHUNK;
         memset(&U.B, 0, sizeof U.B);
         U.off = {0, slots}; U.len = {n}; U.initKind = {b->L.initKind[piece]}; U.termKind = {b->L.termKind[piece]};

@@ -22,7 +22,7 @@
 // a table pointer read from a struct is generic to the compiler, and a load through it a flat load (slower, and it holds up the
 // LDS wait counter as well): the tables live in HBM, say so
 #if defined(__HIP_DEVICE_COMPILE__)
-#define AUGX_GTAB(p) ((const __attribute__((address_space(1))) double *)(p))
+#define AUGX_GTAB(p) (p) /* (the table pointers carry their address space themselves: TabPtr below) */
 #else
 #define AUGX_GTAB(p) (p)
 #endif
@@ -109,6 +109,16 @@ struct IntronStart { int32_t pos; uint32_t ctx; uint64_t fx; };
 // and, per content model that can follow, (ln begin signal) - (content prefix before the first base of the middle part)
 struct USite { int32_t pos; int32_t pad; double b[3]; };
 // flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
+// Pointers to the MODEL TABLES (ln probabilities of the species' parameter files, read-only for the lifetime of a decoder).  In
+// device code they point into the constant address space: a table look-up may then be moved across the kernel's own stores and
+// several look-ups be in flight together -- with a generic pointer the compiler must assume that a store to a record array
+// changes the tables (kSignals waited 78 % of its time for single loads in flight: 14.4 -> 9.2 ms when its stores moved to the
+// end of the function, round 5).  Same size and layout on the host.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(AUGX_EMU)
+typedef const __attribute__((address_space(4))) double *TabPtr;
+#else
+typedef const double *TabPtr;
+#endif
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
     int tis_n, tis_k, ass_n, ass_k, tis_nbins, tis_mem, synch, gc_win, gc_weighing_type;
@@ -124,14 +134,14 @@ struct DevTables {
     int utr, tss_upwin, tss_start, tss_end, tata_start, tata_end, d_tss_tata_min, d_tss_tata_max, dpc, boxlen, tts_spacing;
     int uML, uM3S, uM3T, tssup_k, tss_n, tss_k, tsstata_n, tsstata_k, tata_n, tata_k, tts_n, tts_k;
     double ln_tts_rand, ln2;
-    const double *utr5init_emi, *utr5_emi, *utr3_emi, *tssup_emi, *tss_motif, *tsstata_motif, *tata_motif, *tts_motif, *aataaa,
-        *len5s, *len5i, *len5n, *len5t, *len3s, *len3i, *len3n, *len3t, *tail5s, *tail3s;
+    TabPtr utr5init_emi, utr5_emi, utr3_emi, tssup_emi, tss_motif, tsstata_motif, tata_motif, tts_motif, aataaa,
+        len5s, len5i, len5n, len5t, len3s, len3i, len3n, len3t, tail5s, tail3s;
     int dense;                 // the model is decoded by the dense kernels (dense.h)
     int vbit[AUGX_MAX_STATES]; // bit of a variable-length state in the end-gate mask (the state index itself while S <= 64)
     int uvS[16], nUv;          // the exon-like UTR states, ascending (dense.h: slot of a state in the descriptor kernel)
-    const double *ln_trans, *ig_emi, *ig_short, *in_emi, *ex_emi, *ex_init, *ex_et, *ex_pls, *tis_motif, *ass_motif,
-        *tis_bin_bounds, *tis_bin_ln, *ass_pat, *dss_pat, *len_intron, *len_single, *len_initial, *len_internal,
-        *len_terminal;
+    TabPtr ln_trans, ig_emi, ig_short, in_emi, ex_emi, ex_init, ex_et, ex_pls, tis_motif, ass_motif,
+        tis_bin_bounds, tis_bin_ln, ass_pat, dss_pat, len_intron, len_single, len_initial, len_internal,
+        len_terminal;
 };
 
 // a batch of pieces laid out in one slot space.  Piece p owns slots [off[p], off[p+1]); slot off[p] is the

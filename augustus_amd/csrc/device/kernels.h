@@ -309,44 +309,42 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g, const 
     int p = B.chunkPiece[g / CHUNK];
     int64_t o = B.off[p];
     int q = (int)(g - o - 1);
-    double *sg = B.sig + g * NSIG;
-    for (int i = 0; i < NSIG; i++) sg[i] = AUGX_NINF;
-    B.gate[g] = 0;
-    int32_t *st = B.site + g * NSITE;
-    for (int i = 0; i < NSITE; i++) st[i] = -1;
-    if (q < 0 || q >= B.len[p] || B.cls[p] < 0) return;
+    // (everything is computed into registers first and stored in one burst at the end: a store to the records between two table
+    //  look-ups keeps the compiler from having the look-ups in flight together -- it cannot know that the tables and the records
+    //  do not overlap -- and this kernel waits for its loads 78 % of the time, profiles/r05_sq.txt)
+    double e[NSIG];
+    for (int i = 0; i < NSIG; i++) e[i] = AUGX_NINF;
+    int32_t stv[NSITE];
+    for (int i = 0; i < NSITE; i++) stv[i] = -1;
+    uint64_t gate = 0;
+    int64_t atgIdx = -1;
+    const bool inPiece = !(q < 0 || q >= B.len[p] || B.cls[p] < 0);
+    int64_t lo = 0;
+    if (inPiece) {
     Piece P = makePieceAt(T, B, p, B.gcPlane[g]); // everything ending at q is scored with the class of q
     P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;    // (device: the bases around the workgroup's slots, staged in LDS)
-    const int dssWhole = T.Ds + 2 + T.De, assWhole = T.As + 2 + T.Ae;
     const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0; // (src/igenicmodel.cc:306-326)
-    sg[SIG_EIG] = q >= 1 ? eIg(P, q) + softB : AUGX_NINF;
-    sg[SIG_EIN] = eIn(P, q) + softB;
+    e[SIG_EIG] = q >= 1 ? eIg(P, q) + softB : AUGX_NINF;
+    e[SIG_EIN] = eIn(P, q) + softB;
     // fixed-length intron states ending at q: gate && emission (reference src/intronmodel.cc:690-717,861-923)
     // (the splice-site records SIG_DSSF/DSSR/ASSF/ASSR are filled by k1SiteSignals, one thread per site instead of one
     //  per base: their motif loops would otherwise run with one lane in sixteen active.  SIG_TISF is not used: the
     //  start-codon records carry the translation-initiation term, see k1SiteConsts)
-    (void)dssWhole; (void)assWhole;
-    sg[SIG_TISR] = tisRev(P, q);
-    sg[SIG_STOPF] = exEndPart(P, AUGX_K_TERMINAL, 0, q, AUGX_NINF); // ln P(stop codon ending at q), -inf if none
+    e[SIG_TISR] = tisRev(P, q);
+    e[SIG_STOPF] = exEndPart(P, AUGX_K_TERMINAL, 0, q, AUGX_NINF); // ln P(stop codon ending at q), -inf if none
     // list index of the site ending at q (prefix count - 1), -1 if q is not such a site
     uint64_t cn[NCNT], cp[NCNT];
     for (int i = CNT_ATG; i < NCNT; i++) { cn[i] = B.cnt[fidx(g, i, NCNT)]; cp[i] = B.cnt[fidx(g - 1, i, NCNT)]; }
-    const int64_t lo = listOff(B, p);
+    lo = listOff(B, p);
     for (int i = 0; i < NSITE; i++)
-        st[i] = cn[CNT_LA + i] != cp[CNT_LA + i] ? (int32_t)cn[CNT_LA + i] - 1 : -1;
-    // the candidate lists are indexed by site; positions are known here, the trellis fills in the values
-    if (st[0] >= 0) B.laPos[lo + st[0]] = q;
-    if (st[1] >= 0) B.lrPos[lo + st[1]] = q;
-    if (st[2] >= 0) B.ldEnt[lo + st[2]].pos = q;
-    if (st[3] >= 0) B.rdEnt[lo + st[3]].pos = q;
-    if (cn[CNT_ATG] != cp[CNT_ATG]) B.atgPos[lo + cn[CNT_ATG] - 1] = q;
+        stv[i] = cn[CNT_LA + i] != cp[CNT_LA + i] ? (int32_t)cn[CNT_LA + i] - 1 : -1;
+    if (cn[CNT_ATG] != cp[CNT_ATG]) atgIdx = (int64_t)cn[CNT_ATG] - 1;
     // emission of the equalD states ending at q (reference IntronModel::seqProb, src/intronmodel.cc:1087-1107)
-    if (q - T.dStateLen >= 0) sg[SIG_EQD] = P.seg(FX_INF, q - T.dStateLen + 1, q);
+    if (q - T.dStateLen >= 0) e[SIG_EQD] = P.seg(FX_INF, q - T.dStateLen + 1, q);
     // end gates.  They depend on the state's kind group and (forward splice end) frame only: each is evaluated once
-    uint64_t gate = 0;
     if (q >= 1) {
-        const bool stopOpen = sg[SIG_STOPF] > AUGX_NINF && q - 3 >= 0;              // single, terminal: right = q - 3
-        const bool tisOpen = sg[SIG_TISR] > AUGX_NINF && q - T.W - 3 >= 0;           // rsingle, rinitial: right = q - W - 3
+        const bool stopOpen = e[SIG_STOPF] > AUGX_NINF && q - 3 >= 0;              // single, terminal: right = q - 3
+        const bool tisOpen = e[SIG_TISR] > AUGX_NINF && q - T.W - 3 >= 0;           // rsingle, rinitial: right = q - W - 3
         bool fwdOpen[3];                                                             // initial, internal per frame
         for (int w2 = 0; w2 < 3; w2++) fwdOpen[w2] = exEndPart(P, AUGX_K_INTERNAL, w2, q, AUGX_NINF) > AUGX_NINF;
         const bool revOpen = exEndPart(P, AUGX_K_RINTERNAL, 0, q, AUGX_NINF) > AUGX_NINF; // rinternal, rterminal (no frame in the gate)
@@ -367,7 +365,21 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g, const 
             if (open) gate |= 1ull << T.vbit[s];
         }
     }
+    }
+    // ---- the stores
+    double *sg = B.sig + g * NSIG;
+    for (int i = 0; i < NSIG; i++) sg[i] = e[i];
     B.gate[g] = gate;
+    int32_t *st = B.site + g * NSITE;
+    for (int i = 0; i < NSITE; i++) st[i] = stv[i];
+    if (inPiece) {
+        // the candidate lists are indexed by site; positions are known here, the trellis fills in the values
+        if (stv[0] >= 0) B.laPos[lo + stv[0]] = q;
+        if (stv[1] >= 0) B.lrPos[lo + stv[1]] = q;
+        if (stv[2] >= 0) B.ldEnt[lo + stv[2]].pos = q;
+        if (stv[3] >= 0) B.rdEnt[lo + stv[3]].pos = q;
+        if (atgIdx >= 0) B.atgPos[lo + atgIdx] = q;
+    }
 }
 
 // splice-site signal records: one thread per entry t of the four candidate lists (sel: 0 forward acceptor, 1 reverse
@@ -428,23 +440,26 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
     }
     uint64_t cn[NCNT], cp[NCNT];
     for (int i = CNT_ATG; i < NCNT; i++) { cn[i] = B.cnt[fidx(g, i, NCNT)]; cp[i] = B.cnt[fidx(g - 1, i, NCNT)]; }
+    // (in every branch: all look-ups first, then the stores -- a store between two loads keeps them from being in flight together)
     if (cn[CNT_LA] != cp[CNT_LA]) { // forward acceptor candidate ending (as longass state) at q: exon inner part starts at bs = q+1
         int64_t idx = pL + lo + (int64_t)cn[CNT_LA] - 1;
         int bs = q + 1, eos = bs + k - 1, pn = P.pat(bs, k);
-        for (int a = 0; a < 3; a++) {
-            B.laPls[idx * 3 + a] = k == 0 ? 0.0 : plsK(pn, mod3(eos + a));
-            B.laFx[idx * 3 + a] = fxv(eos, (0 * 3 + a) * 3 + 0);
-        }
+        double vP[3];
+        uint64_t vF[3];
+        for (int a = 0; a < 3; a++) { vP[a] = k == 0 ? 0.0 : plsK(pn, mod3(eos + a)); vF[a] = fxv(eos, (0 * 3 + a) * 3 + 0); }
+        for (int a = 0; a < 3; a++) { B.laPls[idx * 3 + a] = vP[a]; B.laFx[idx * 3 + a] = vF[a]; }
     }
     if (cn[CNT_LR] != cp[CNT_LR]) { // reverse donor candidate
         int64_t idx = pL + lo + (int64_t)cn[CNT_LR] - 1;
         int bs = q + 1, eot = bs + T.Le - 1;
+        double vE[3];
+        uint64_t vF[3];
         for (int a = 0; a < 3; a++) {
             const int fb = (1 * 3 + a) * 3;
-            B.lrEt[idx * 3 + a] = (double)(int64_t)(fxv(eot, fb + 2) - fxv(bs - 1, fb + 2)) * AUGX_FX_INV;
-            if (eot < bs) B.lrEt[idx * 3 + a] = 0.0;
-            B.lrFx[idx * 3 + a] = fxv(eot, fb + 0);
+            vE[a] = eot < bs ? 0.0 : (double)(int64_t)(fxv(eot, fb + 2) - fxv(bs - 1, fb + 2)) * AUGX_FX_INV;
+            vF[a] = fxv(eot, fb + 0);
         }
+        for (int a = 0; a < 3; a++) { B.lrEt[idx * 3 + a] = vE[a]; B.lrFx[idx * 3 + a] = vF[a]; }
     }
     // short-intron starts: content prefix at q and the two bases before the biological intron (spliced-codon check)
     if (cn[CNT_LD] != cp[CNT_LD]) {
@@ -461,10 +476,11 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
         int64_t idx = pL + lo + (int64_t)cn[CNT_ATG] - 1;
         int bs = q + 3, eos = bs + k - 1, eoi = eos + T.Li, a = mod3(-q);
         const int fb = (0 * 3 + a) * 3;
-        B.atgD[idx * 3 + 0] = tisFwd(P, q);
-        B.atgD[idx * 3 + 1] = k == 0 ? 0.0 : plsK(P.pat(bs, k), mod3(eos + a));
-        B.atgD[idx * 3 + 2] = eoi > eos ? (double)(int64_t)(fxv(eoi, fb + 1) - fxv(eos, fb + 1)) * AUGX_FX_INV : 0.0;
-        B.atgFx[idx] = fxv(eoi, fb + 0);
+        const double d0 = tisFwd(P, q), d1 = k == 0 ? 0.0 : plsK(P.pat(bs, k), mod3(eos + a)),
+                     d2 = eoi > eos ? (double)(int64_t)(fxv(eoi, fb + 1) - fxv(eos, fb + 1)) * AUGX_FX_INV : 0.0;
+        const uint64_t f0 = fxv(eoi, fb + 0);
+        B.atgD[idx * 3 + 0] = d0; B.atgD[idx * 3 + 1] = d1; B.atgD[idx * 3 + 2] = d2;
+        B.atgFx[idx] = f0;
     }
     if (cn[CNT_RS] != cp[CNT_RS]) { // reverse stop codon at q..q+2: bs = q+3
         int64_t idx = lo + (int64_t)cn[CNT_RS] - 1;
@@ -472,7 +488,9 @@ AUGX_HD void k1SiteConsts(const DevTables &T, const BatchView &B, int64_t g, int
             B.rsPos[idx] = q;
             B.rsBegin[idx] = (P.b(q) == 3 && P.b(q + 1) == 3) ? T.ln_stop_ochre : (P.b(q) == 1) ? T.ln_stop_amber : T.ln_stop_opal;
         }
-        for (int a = 0; a < 3; a++) B.rsFx[(pL + idx) * 3 + a] = fxv(q + 2, (1 * 3 + a) * 3 + 0);
+        uint64_t vF[3];
+        for (int a = 0; a < 3; a++) vF[a] = fxv(q + 2, (1 * 3 + a) * 3 + 0);
+        for (int a = 0; a < 3; a++) B.rsFx[(pL + idx) * 3 + a] = vF[a];
     }
 }
 
@@ -628,9 +646,9 @@ struct CandCtx {
         return Q;
     }
     AUGX_HD double lenAt(int sel, int len) const {
-        return gp(sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
+        return (sel == 0 ? T.len_single : sel == 1 ? T.len_initial : sel == 2 ? T.len_internal : T.len_terminal)[len];
     }
-    AUGX_HD double lenIAt(int len) const { return gp(T.len_intron)[len]; } // (table pointers read from the model struct are generic to the compiler)
+    AUGX_HD double lenIAt(int len) const { return T.len_intron[len]; }
     AUGX_HD double plsRAt(int pl, int q, int fr) const { return B.plsR[((int64_t)pl * B.N + o + 1 + q) * 3 + fr]; }
     AUGX_HD double sigAt(int q, int i) const { return B.sig[(o + 1 + q) * NSIG + i]; }
 };

@@ -387,7 +387,7 @@ inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
 }
 
 // table element counts, in the order of tablePointers()
-struct TableSpan { const double *src; int64_t count; const double **dst; };
+struct TableSpan { const double *src; int64_t count; TabPtr *dst; };
 inline std::vector<TableSpan> tableSpans(const augx_tables &t, DevTables &D) {
     const int64_t C = t.n_classes, NP = 1 << (2 * (t.k + 1)), S = t.S;
     std::vector<TableSpan> v;
