@@ -34,14 +34,15 @@ def config_path():
     if _cfg_dir is None:
         tar = os.path.join(GOLDEN, "config_min.tar.gz")
         more = os.path.join(GOLDEN, "config_more.tar.gz")  # two more species (nasonia: 5 GC classes, rice: 4)
-        d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d_%d" % (os.getuid(), os.path.getsize(tar), os.path.getsize(more)))
+        caeno = os.path.join(GOLDEN, "config_caeno.tar.gz")  # caenorhabditis: the species of the reference's own test_ab_initio_prediction
+        d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d_%d_%d" % (os.getuid(), os.path.getsize(tar), os.path.getsize(more), os.path.getsize(caeno)))
         marker = os.path.join(d, "config", "model", "states_shadow.cfg")
         if not os.path.exists(marker):
             # several processes may get here at once (one rank per GPU, pytest-xdist): extract privately, publish with one
             # atomic rename; whoever loses the race uses the winner's copy
             import shutil
             tmp = tempfile.mkdtemp(prefix="augx_config_tmp_")
-            for tf in (tar, more):
+            for tf in (tar, more, caeno):
                 with tarfile.open(tf) as t:
                     t.extractall(tmp)
             try:
