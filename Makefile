@@ -10,7 +10,7 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-un
 CXXFLAGS = -O2 -std=c++17 -fPIC -ffp-contract=off
 SRC     = augustus_amd/csrc
 HOSTSRC = $(SRC)/model.cc $(SRC)/capi_model.cc $(SRC)/genes.cc $(SRC)/driver.cc $(SRC)/sharded.cc
-DEVHDR  = $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h $(SRC)/device/launch.h
+DEVHDR  = $(SRC)/device/assmemo.h $(SRC)/device/dp.h $(SRC)/device/kernels.h $(SRC)/device/dense.h $(SRC)/device/layout.h $(SRC)/device/sampler.h $(SRC)/device/snipmemo.h $(SRC)/device/launch.h
 HOSTHDR = $(SRC)/model.h $(SRC)/genes.h $(SRC)/capi_internal.h include/augx.h
 
 all: product oracle emu

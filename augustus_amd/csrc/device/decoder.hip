@@ -25,12 +25,15 @@
 #include <set>
 #include <string>
 #include <system_error>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <vector>
 #include "kernels.h"
 #include "dense.h"
 #include "layout.h"
 #include "launch.h"
+#include "assmemo.h"
 #include "../capi_internal.h"
 
 using namespace augx;
@@ -353,6 +356,36 @@ __global__ void __launch_bounds__(256) kUtrSignals(const DevTables *__restrict__
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g < B.N) k1UtrSignals(*T, B, g, C.c, C.lo, C.lo + 256 + 2 * SLOT_HALO);
 }
+// ---- the two call-history caches of the reference that UTR states read, on pieces with several GC classes (dense.h, assmemo.h)
+struct MemoReq { int n; int s[8]; };
+__global__ void __launch_bounds__(256) kTssReplay(const DevTables *__restrict__ T, BatchView B, const double *mat, int32_t *changed) {
+    const int p = blockIdx.y, li = blockIdx.x * 256 + threadIdx.x;
+    if (B.nPlanes[p] <= 1 || B.cls[p] < 0) return;
+    if (k1TssReplay(*T, B, p, li, mat + (B.off[p] + 1) * T->S)) atomicAdd(changed, 1);
+}
+// what the replay of the aSSProb memo reads: per acceptor site (entry listOffs[p] + 8 p + li; 8 more entries per piece for the sites
+// past its end) q and the aliveness bits, per slot the end-gate bits of the asking UTR exon states
+__global__ void __launch_bounds__(256) kMemoSites(const DevTables *__restrict__ T, BatchView B, const double *mat, MemoReq rq, int32_t *siteQ, uint8_t *alive) {
+    const int p = blockIdx.y, li = blockIdx.x * 256 + threadIdx.x;
+    if (B.nPlanes[p] <= 1 || B.cls[p] < 0) return;
+    const int nList = (int)B.cnt[fidx(B.off[p] + B.len[p], CNT_LA, NCNT)];
+    if (li >= nList + 8) return;
+    uint8_t a = 0;
+    const int q = li < nList + T->Ae ? memoAssSite(*T, B, p, li, mat + (B.off[p] + 1) * T->S, rq.s, rq.n, a) : -1;
+    const int64_t i = B.listOffs[p] + 8 * (int64_t)p + li;
+    siteQ[i] = q; alive[i] = a;
+}
+__global__ void __launch_bounds__(256) kMemoGates(const DevTables *__restrict__ T, BatchView B, MemoReq rq, uint8_t *gate) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= B.N) return;
+    const int p = B.chunkPiece[g / CHUNK];
+    const int j = (int)(g - B.off[p] - 1);
+    gate[g] = (j >= 0 && j < B.len[p] && B.nPlanes[p] > 1 && B.cls[p] >= 0) ? memoGateBits(*T, B, p, j, rq.s, rq.n) : 0;
+}
+__global__ void __launch_bounds__(256) kAssPatch(const DevTables *__restrict__ T, BatchView B, const AssPatch *A, const int32_t *piece, int n, const AssSwIn *sw, LaSw *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) k1AssPatch(*T, B, piece[i], A[i], sw, out);
+}
 // (kUtrDesc, kDense: k_dense.hip; kCand: k_cand.hip; kTrellis: k_trellis.hip; kForward: k_forward.hip -- launch.h)
 __global__ void __launch_bounds__(64) kDenseBacktrace(const DevTables *T, BatchView B) { denseBacktracePiece(*T, B, blockIdx.x); }
 
@@ -446,13 +479,13 @@ struct augx_decoder {
     bool dense = false;        // the model is decoded by the dense kernels (dense.h)
     bool countNearTies = false;    // the back-trace counts the near ties on the chosen paths (AUGX_NEAR_TIES=1, augx_decoder_count_near_ties)
     int64_t nearTies = 0, nearTiePieces = 0; // ... summed over the batches whose paths were fetched
-    int64_t denseMultiForward = 0; // forward runs of the dense kernels over batches with a multi-class piece: no replay of the reference's caches there (augx_decoder_unreplayed_batches)
     double mallocSeconds = 0, mallocBytes = 0; // hipMalloc calls of this decoder so far (AUGX_TIMING; guarded by nothing: one host thread drives a decoder)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
 namespace {
 int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool fromLists, const double *mat); // (below, with the forward algorithm)
+int utrCachesReplay(augx_decoder *d, augx_batch *b, const double *mat, bool &rebuilt); // (below: tssProbsPlus and the aSSProb memo, UTR states on multi-class pieces)
 // every decoder of the process (several may share a device: augx_decoder_set_share, the bench's resident batches): when an
 // allocation fails, the buffers the OTHER decoders of the device keep for re-use are given back to the runtime as well
 std::mutex g_regMu;
@@ -543,6 +576,11 @@ struct augx_batch {
     bool itemsVerified = false; // the candidate buffer in use has held all candidates of this batch once
     SegPlan plan;            // segments of the trellis (layout.h: planSegments)
     int chunkTotPlanes = 1;  // planes the scan totals are allocated for
+    std::vector<int64_t> hListOffs; // host copy of the list offsets (first entry of every piece in the list arrays)
+    bool memoReplayed = false; // the site values of this decode have been rebuilt from the reference's tssProbsPlus / aSSProb caches already
+    void *laSwBuf = nullptr;   // (dense, UTR) acceptor sites whose value changes during the sweep (BatchView::laSw)
+    size_t nLaSw = 0;          // its entries
+    std::vector<std::shared_ptr<augx::dev::AssMemoReplay>> memoOf; // [piece] the aSSProb memo as the sweep left it (the sampler goes on from a copy), or null
 };
 
 namespace {
@@ -674,7 +712,6 @@ int augx_decoder_set_share(augx_decoder *d, int n) {
     return AUGX_OK;
 }
 
-int64_t augx_decoder_unreplayed_batches(const augx_decoder *d) { return d ? d->denseMultiForward : 0; }
 int augx_decoder_count_near_ties(augx_decoder *d, int on) { if (!d) return AUGX_E_ARG; d->countNearTies = on != 0; return AUGX_OK; }
 int64_t augx_decoder_near_ties(const augx_decoder *d, int64_t *pieces) { if (pieces) *pieces = d ? d->nearTiePieces : 0; return d ? d->nearTies : 0; }
 int augx_decoder_exact(const augx_decoder *d) { return d && d->exactMulti ? 1 : 0; }
@@ -722,6 +759,7 @@ void augx_batch_destroy(augx_batch *b) {
         if (p) devFree(b->dec, p);
     if (b->itemBuf) devFree(b->dec, b->itemBuf);
     if (b->udBuf) devFree(b->dec, b->udBuf);
+    if (b->laSwBuf) devFree(b->dec, b->laSwBuf);
     for (auto &e : b->ev)
         if (e) (void)hipEventDestroy(e);
     if (b->evFwd) (void)hipEventDestroy(b->evFwd);
@@ -833,6 +871,8 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
     const unsigned gridN = (unsigned)((V.N + 255) / 256);
     hipStream_t st = d->stream;
     HIP_TRY(hipEventRecord(b->ev[0], st));
+    b->memoReplayed = false; // (the prep kernels write the site values afresh)
+    b->memoOf.clear();
     hipLaunchKernelGGL(kEncode, dim3(gridN), dim3(256), 0, st, V);
     int rc;
     // (developer aid, AUGX_TIMING: where the host spends the first decode of a batch -- classes, list sizes, array allocation)
@@ -904,6 +944,7 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
             std::vector<int64_t> offs;
             HIP_TRY(hipMemcpy(lc.data(), V.listCnt, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
             W.listCap = listOffsets(lc.data(), n, offs);
+            b->hListOffs = offs;
             HIP_TRY(hipMemcpy(b->dListOffs, offs.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice));
             b->listsReady = true;
             changed = true;
@@ -1075,11 +1116,14 @@ int augx_batch_decode(augx_decoder *d, augx_batch *b) {
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (timing) (void)hipStreamSynchronize(st);
         const double t0 = timing ? now() : 0.0;
-        try { rc2 = d->dense ? snippetCacheReplay(d, b, nPatched, false, b->V.cells) : snippetCacheReplay(d, b, nPatched, true, nullptr); }
-        catch (const std::exception &e) { setLastError(std::string("augx_batch_decode: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
+        bool sitesRebuilt = false;
+        try {
+            rc2 = d->dense ? snippetCacheReplay(d, b, nPatched, false, b->V.cells) : snippetCacheReplay(d, b, nPatched, true, nullptr);
+            if (!rc2 && d->dense && d->hostT.utr) rc2 = utrCachesReplay(d, b, b->V.cells, sitesRebuilt);
+        } catch (const std::exception &e) { setLastError(std::string("augx_batch_decode: replay of the reference's caches: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc2) return rc2;
         const double t1 = timing ? now() : 0.0;
-        if (nPatched > 0 && (rc2 = runTrellis())) return rc2;
+        if ((nPatched > 0 || sitesRebuilt) && (rc2 = runTrellis())) return rc2;
         if (timing) {
             (void)hipStreamSynchronize(st);
             fprintf(stderr, "augx timing:     pieces with several GC classes: snippet-cache replay %.3f s (%lld candidate terms rebuilt), second trellis run %.3f s\n", t1 - t0, (long long)nPatched, now() - t1);
@@ -1265,6 +1309,7 @@ struct CopySlot {
 }
 
 #include "snipmemo.h"
+#include "assmemo.h"
 
 namespace {
 // Pieces with several GC classes: within 2 d bases after a class step the reference's short-intron interiors are products of
@@ -1471,6 +1516,145 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     devFree(d, dIdx); devFree(d, dTe);
     return AUGX_OK;
 }
+// UTR states on pieces with several GC classes: the forward TSS windows and the acceptor sites whose value the reference computed
+// under another class than the prep kernels took (tssProbsPlus: first asker; the aSSProb memo: assmemo.h) are rebuilt from the
+// aliveness the first run left in `mat`.  rebuilt: some were -- the UTR descriptors (they hold values made from the site records)
+// have been made again, and the dense kernel has to run once more.
+int utrCachesReplay(augx_decoder *d, augx_batch *b, const double *mat, bool &rebuilt) {
+    rebuilt = false;
+    if (b->memoReplayed || getenv("AUGX_NO_ASSMEMO")) return AUGX_OK;
+    b->memoReplayed = true;
+    BatchView &W = b->V;
+    const int n = W.nPieces;
+    hipStream_t st = d->stream;
+    const bool timing = getenv("AUGX_TIMING") != nullptr; // (developer aid)
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = timing ? now() : 0.0;
+    std::vector<int32_t> nPl((size_t)n);
+    HIP_TRY(hipMemcpyAsync(nPl.data(), W.nPlanes, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int> todo;
+    int64_t maxList = 0;
+    for (int p = 0; p < n; p++)
+        if (nPl[p] > 1) { todo.push_back(p); maxList = std::max(maxList, b->hListOffs[(size_t)p + 1] - b->hListOffs[(size_t)p]); }
+    if (todo.empty()) return AUGX_OK;
+    AssMemoReplay proto;
+    proto.T = &d->hostT;
+    proto.requesters();
+    MemoReq rq;
+    rq.n = proto.nReq;
+    for (int r = 0; r < 8; r++) rq.s[r] = r < proto.nReq ? proto.reqS[r] : 0;
+    const int64_t nSiteSlots = W.listCap + 8 * (int64_t)n + 8;
+    int32_t *dQ = nullptr, *dChanged = nullptr;
+    uint8_t *dAlive = nullptr, *dGate = nullptr;
+    std::vector<void *> tmp;
+    auto freeTmp = [&]() { for (void *q : tmp) devFree(d, q); tmp.clear(); };
+    auto grab = [&](void **ptr, size_t bytes) -> bool { if (devMalloc(d, ptr, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return false; } tmp.push_back(*ptr); return true; };
+    if (!grab((void **)&dQ, sizeof(int32_t) * (size_t)nSiteSlots) || !grab((void **)&dAlive, (size_t)nSiteSlots) || !grab((void **)&dGate, (size_t)W.N) || !grab((void **)&dChanged, sizeof(int32_t))) {
+        freeTmp();
+        setLastError("augx: out of device memory for the replay of the aSSProb memo");
+        return AUGX_E_NOMEM;
+    }
+    HIP_TRY(hipMemsetAsync(dChanged, 0, sizeof(int32_t), st));
+    const dim3 gridSites((unsigned)((maxList + 8 + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(kTssReplay, gridSites, dim3(256), 0, st, d->dT, W, mat, dChanged);
+    hipLaunchKernelGGL(kMemoSites, gridSites, dim3(256), 0, st, d->dT, W, mat, rq, dQ, dAlive);
+    hipLaunchKernelGGL(kMemoGates, dim3((unsigned)((W.N + 255) / 256)), dim3(256), 0, st, d->dT, W, rq, dGate);
+    HIP_TRY(hipGetLastError());
+    // (only what the multi-class pieces own comes over)
+    struct PieceIn { std::vector<int32_t> q; std::vector<uint8_t> alive; std::shared_ptr<AssMemoReplay> Rp; std::vector<AssPatch> pt; std::vector<AssSwIn> sw; int extras = 0; };
+    b->memoOf.assign((size_t)n, nullptr);
+    std::vector<std::unique_ptr<PieceIn>> in;
+    int32_t nTss = 0;
+    HIP_TRY(hipMemcpyAsync(&nTss, dChanged, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    for (int p : todo) {
+        in.emplace_back(new PieceIn());
+        PieceIn &I = *in.back();
+        const int len = b->L.len[p];
+        const int64_t o = b->L.off[p], s0 = b->hListOffs[(size_t)p] + 8 * (int64_t)p, ns = b->hListOffs[(size_t)p + 1] - b->hListOffs[(size_t)p] + 8;
+        I.Rp = std::make_shared<AssMemoReplay>();
+        b->memoOf[(size_t)p] = I.Rp;
+        I.q.resize((size_t)ns); I.alive.resize((size_t)ns); I.Rp->gateOwn.resize((size_t)len); I.Rp->planeOwn.resize((size_t)len);
+        HIP_TRY(hipMemcpyAsync(I.q.data(), dQ + s0, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(I.alive.data(), dAlive + s0, (size_t)ns, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(I.Rp->gateOwn.data(), dGate + o + 1, (size_t)len, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(I.Rp->planeOwn.data(), W.gcPlane + o + 1, (size_t)len, hipMemcpyDeviceToHost, st));
+    }
+    std::vector<int32_t> nLa((size_t)n, 0);
+    {   // length of every piece's LA list: the count at its last slot
+        std::vector<uint32_t> tmpc((size_t)todo.size());
+        for (size_t k = 0; k < todo.size(); k++)
+            HIP_TRY(hipMemcpyAsync(&tmpc[k], W.cnt + fidx(b->L.off[todo[k]] + b->L.len[todo[k]], CNT_LA, NCNT), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t k = 0; k < todo.size(); k++) nLa[(size_t)todo[k]] = (int32_t)tmpc[k];
+    }
+    const double t1 = timing ? now() : 0.0;
+    // the requests of every piece walked on host threads
+    auto job = [&](size_t k) {
+        PieceIn &I = *in[k];
+        const int p = todo[k], nList = nLa[(size_t)p];
+        AssMemoReplay &R = *I.Rp;
+        R.T = &d->hostT; R.n = b->L.len[p]; R.plane = R.planeOwn.data(); R.gate = R.gateOwn.data();
+        R.requesters();
+        for (int li = 0; li < nList + 8 && li < (int)I.q.size(); li++)
+            if (I.q[(size_t)li] >= 0) { R.siteQ.push_back(I.q[(size_t)li]); R.siteLi.push_back(li); R.siteAlive.push_back(I.alive[(size_t)li]); }
+        R.run();
+        I.extras = R.patches(nList, I.pt, I.sw);
+    };
+    {
+        const size_t nThreads = std::min<size_t>(todo.size(), std::max(1u, std::min(32u, std::thread::hardware_concurrency())));
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> th;
+        auto worker = [&]() { for (size_t k; (k = next.fetch_add(1)) < todo.size();) job(k); };
+        try { for (size_t i = 1; i < nThreads; i++) th.emplace_back(worker); } catch (const std::system_error &) {}
+        worker();
+        for (auto &t2 : th) t2.join();
+    }
+    const double t2 = timing ? now() : 0.0;
+    std::vector<AssPatch> pt;
+    std::vector<int32_t> ptPiece;
+    std::vector<AssSwIn> sw;
+    long long calls = 0, flushes = 0, extras = 0;
+    for (size_t k = 0; k < todo.size(); k++) {
+        PieceIn &I = *in[k];
+        for (AssPatch A : I.pt) { A.swOff += (int32_t)sw.size(); pt.push_back(A); ptPiece.push_back(todo[k]); }
+        sw.insert(sw.end(), I.sw.begin(), I.sw.end());
+        calls += I.Rp->calls; flushes += I.Rp->flushes; extras += I.extras;
+    }
+    if (!pt.empty()) {
+        AssPatch *dPt = nullptr; int32_t *dPp = nullptr; AssSwIn *dSw = nullptr;
+        if (b->laSwBuf) { devFree(d, b->laSwBuf); b->laSwBuf = nullptr; W.laSw = nullptr; b->nLaSw = 0; }
+        if (!grab((void **)&dPt, sizeof(AssPatch) * pt.size()) || !grab((void **)&dPp, sizeof(int32_t) * pt.size()) || !grab((void **)&dSw, sizeof(AssSwIn) * (sw.size() + 1)) ||
+            devMalloc(d, &b->laSwBuf, sizeof(LaSw) * (sw.size() + 1)) != hipSuccess) {
+            (void)hipGetLastError();
+            b->laSwBuf = nullptr;
+            freeTmp();
+            setLastError("augx: out of device memory for the replay of the aSSProb memo");
+            return AUGX_E_NOMEM;
+        }
+        HIP_TRY(hipMemcpyAsync(dPt, pt.data(), sizeof(AssPatch) * pt.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dPp, ptPiece.data(), sizeof(int32_t) * pt.size(), hipMemcpyHostToDevice, st));
+        if (!sw.empty()) HIP_TRY(hipMemcpyAsync(dSw, sw.data(), sizeof(AssSwIn) * sw.size(), hipMemcpyHostToDevice, st));
+        W.laSw = (const LaSw *)b->laSwBuf;
+        b->nLaSw = sw.size();
+        HIP_TRY(hipMemcpyAsync(b->dV, &W, sizeof(BatchView), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(kAssPatch, dim3((unsigned)((pt.size() + 255) / 256)), dim3(256), 0, st, d->dT, W, dPt, dPp, (int)pt.size(), dSw, (LaSw *)b->laSwBuf);
+        HIP_TRY(hipGetLastError());
+    }
+    rebuilt = nTss > 0 || !pt.empty();
+    if (rebuilt) { // the descriptors hold the first candidates' terms, made from the site records: once more (same count, same buffer)
+        HIP_TRY(hipMemsetAsync(&W.candAlloc->descs, 0, sizeof(W.candAlloc->descs), st));
+        launchUtrDesc(d->blk, (unsigned)(W.N / (NT / 16)), st, d->dT, W);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st)); // (the host vectors and the temporary buffers go away)
+    freeTmp();
+    if (timing)
+        fprintf(stderr, "augx timing:       UTR states, %zu pieces with several GC classes: %d TSS windows and %zu acceptor sites (%zu changes of value during the sweep; %lld past the end of a piece left) rebuilt from "
+                        "the reference's caches; inputs gathered in %.3f s, %lld calls of the aSSProb memo walked (emptied %lld times) in %.3f s, values rebuilt in %.3f s\n",
+                todo.size(), (int)nTss, pt.size(), sw.size(), extras, t1 - t0, calls, flushes, t2 - t1, now() - t2);
+    return AUGX_OK;
+}
 } // namespace
 
 extern "C" {
@@ -1480,11 +1664,13 @@ int augx_batch_forward(augx_decoder *d, augx_batch *b) {
     if (rc) return rc;
     if (b->nPlAlloc > 1 && !getenv("AUGX_NO_MEMO")) { // (a batch with a multi-class piece)
         int64_t nPatched = 0;
-        try { rc = snippetCacheReplay(d, b, nPatched, false, b->V.fwd); }
-        catch (const std::exception &e) { setLastError(std::string("augx_batch_forward: snippet-cache replay: ") + e.what()); return AUGX_E_NOMEM; }
+        bool sitesRebuilt = false;
+        try {
+            rc = snippetCacheReplay(d, b, nPatched, false, b->V.fwd);
+            if (!rc && d->dense && d->hostT.utr) rc = utrCachesReplay(d, b, b->V.fwd, sitesRebuilt); // (nothing to do when the Viterbi run has replayed them already)
+        } catch (const std::exception &e) { setLastError(std::string("augx_batch_forward: replay of the reference's caches: ") + e.what()); return AUGX_E_NOMEM; }
         if (rc) return rc;
-        if (nPatched > 0 && (rc = augx_batch_forward_launch(d, b))) return rc;
-        if (d->dense && d->hostT.utr) d->denseMultiForward++; // (UTR states: two more caches of the reference are not replayed; the caller is told)
+        if ((nPatched > 0 || sitesRebuilt) && (rc = augx_batch_forward_launch(d, b))) return rc;
     }
     if (!b->evFwd) HIP_TRY(hipEventCreateWithFlags(&b->evFwd, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(b->evFwd, d->stream));
@@ -1593,6 +1779,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     struct CopyDrain { hipStream_t s; ~CopyDrain() { if (s) (void)hipStreamSynchronize(s); } } copyDrain{cst};
     {   // (an object that comes round: everything a piece sets only under a condition goes back to its default)
         P.plane.clear(); P.planeCls.clear(); P.uh.reset(); P.dense = false; P.hT = nullptr; P.hB = nullptr; P.hp = 0;
+        P.memo = nullptr; P.memoOwner.reset(); P.vitPath.clear();
         P.igS = -1; P.termKind = 0; P.anyNuc = true; P.prepared = false; P.item0 = 0;
         P.buildSeconds = 0; P.nBuilt = P.nStops = P.nVar = 0; P.tkChain = P.tkVar = P.tkTail = 0;
     }
@@ -1703,7 +1890,13 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
             U.sites[k].resize((size_t)(nEnt > 0 ? nEnt : 1));
             if (nEnt > 0) HIP_TRY(cp(U.sites[k].data(), src[k] + lo2[0], sizeof(USite) * (size_t)nEnt));
         }
+        if (b->laSwBuf && b->nLaSw) { // (acceptor sites whose value changes during the sweep: the records index the batch's table)
+            U.laSw.resize(b->nLaSw);
+            HIP_TRY(cp(U.laSw.data(), b->laSwBuf, sizeof(LaSw) * b->nLaSw));
+            HIP_TRY(flush());
+        }
         BatchView &HB = U.B;
+        HB.laSw = U.laSw.empty() ? nullptr : U.laSw.data();
         HB.nPieces = 1; HB.N = slots; HB.nChunks = (int)nch;
         HB.off = U.off.data(); HB.len = U.len.data(); HB.initKind = U.initKind.data(); HB.termKind = U.termKind.data(); HB.chunkPiece = U.chunkPiece.data();
         HB.cls = U.cls.data(); HB.nPlanes = U.nPlanes.data(); HB.planeCls = U.planeCls.data(); HB.nPl = 1;
@@ -1714,6 +1907,20 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
         HB.tmSite = U.sites[4].data(); HB.rtSite = U.sites[5].data();
         HB.blk = V.blk;
         P.hT = &U.T; P.hB = &U.B; P.hp = 0;
+        if ((size_t)piece < b->memoOf.size() && b->memoOf[(size_t)piece] && nPl > 1) {
+            // the aSSProb memo goes on from where the sweep left it: through the back-tracking of the Viterbi path, then the sampled
+            // paths (sampler.h: memoStep) -- on a copy, so that the piece can be sampled again
+            auto mc = std::make_shared<AssMemoReplay>(*b->memoOf[(size_t)piece]);
+            mc->T = &U.T; mc->plane = mc->planeOwn.data(); mc->gate = mc->gateOwn.data();
+            int32_t cnt = 0;
+            HIP_TRY(cp(&cnt, V.pathCount + piece, sizeof(int32_t)));
+            HIP_TRY(flush());
+            std::vector<int32_t> rec((size_t)(cnt > 0 ? cnt : 0) * 3);
+            if (cnt > 0) { HIP_TRY(cp(rec.data(), V.pathRec + (b->L.off[piece] / 8 + 64 * (int64_t)piece) * 3, sizeof(int32_t) * rec.size())); HIP_TRY(flush()); }
+            for (int i = cnt - 1; i >= 0; i--) P.vitPath.push_back({rec[(size_t)i * 3], rec[(size_t)i * 3 + 1], (int16_t)rec[(size_t)i * 3 + 2], (int16_t)t.state_type[rec[(size_t)i * 3 + 2]]});
+            P.memo = mc.get();
+            P.memoOwner = mc;
+        }
     }
     {
         std::vector<uint8_t> code((size_t)n);
@@ -1739,6 +1946,7 @@ void augx_sample_prep_destroy(augx_sample_prep *h) {
     h->P.Fown.reset(); // (the forward matrix goes back to its own pool)
     h->P.F = nullptr;
     h->P.uh.reset();
+    h->P.memo = nullptr; h->P.memoOwner.reset();
     {
         std::lock_guard<std::mutex> lk(g_fPoolMu);
         if (g_prepPool.size() < 36) { g_prepPool.push_back(h); return; }

@@ -283,6 +283,109 @@ AUGX_HD void k1UtrSignals(const DevTables &T, const BatchView &B, int64_t g, con
 }
 
 // =================================================================================================
+// two call-history caches of the reference that UTR states read, replayed on pieces with several GC classes from the aliveness a
+// first run left in the dense matrix `mat` ([len][S] of the piece): tssProbsPlus (here, entirely) and the aSSProb memo (assmemo.h
+// walks the requests on the host; here: what it reads, and the values it asks to be rebuilt)
+// =================================================================================================
+AUGX_HD bool memoAnyAlive(const DevTables &T, const double *mat, int S, int s, int eop) { // a request is made for a live predecessor only (src/utrmodel.cc:957-960)
+    const int64_t col = eop > 0 ? eop : 0;
+    for (int ai = 0; ai < T.n_anc[s]; ai++) if (mat[col * S + T.anc[s][ai]] > AUGX_NINF) return true;
+    return false;
+}
+// forward TSS window of TF site li of piece p: the reference computes tssProb(left) when utr5single or utr5init FIRST ask for it --
+// at the first column j whose state passes its end gate, holds left - 1 in its window of predecessor ends and has a live
+// predecessor there -- with the class current in that column, and keeps it (tssProbsPlus, src/utrmodel.cc:1788-1790; the entries of
+// a class region are forgotten only when the sweep ENTERS the region, :779-780, i.e. before any request for them).
+// k1UtrSignals took the class of the transcription start.  true: the value was rebuilt
+AUGX_HD bool k1TssReplay(const DevTables &T, const BatchView &B, int p, int li, const double *mat) {
+    const int64_t o = B.off[p], lo = listOff(B, p);
+    const int n = B.len[p], S = T.S;
+    if (B.nPlanes[p] <= 1 || li >= (int)B.ucnt[fidx(o + n, UCNT_TF, NUCNT)]) return false;
+    USite &e = B.tfSite[lo + li];
+    const int left = e.pos + 1, up = T.tss_upwin, te = T.tss_end;
+    int jFirst = -1;
+    for (int s = 0; s < S; s++) {
+        if (!T.reachable[s] || (T.kind[s] != AUGX_K_UTR5SINGLE && T.kind[s] != AUGX_K_UTR5INIT)) continue;
+        if (!memoAnyAlive(T, mat, S, s, left - 1)) continue;
+        for (int j = left; j < n && (jFirst < 0 || j < jFirst); j++) {
+            int lm, rm;
+            utrWindow(T, T.kind[s], j, n, lm, rm);
+            if (lm > left - 1) break;
+            if (rm < left - 1 || j < 1) continue;
+            if ((B.gate[o + 1 + j] >> T.vbit[s]) & 1ull) { jFirst = j; break; }
+        }
+    }
+    if (jFirst < 0) return false;
+    int qc = left + up; if (qc > n - 1) qc = n - 1;
+    const int plNat = B.gcPlane[o + 1 + qc], plAsk = B.gcPlane[o + 1 + jFirst];
+    if (plNat == plAsk) return false;
+    Piece PF = makePieceAt(T, B, p, plAsk);
+    const double v = tssProbCalc(PF, left, true);
+    B.usig[(o + 1 + left) * NUSIG + USIG_TSSF] = v;
+    int pe = left + up + te - 1; if (pe > n - 1) pe = n - 1;
+    e.b[0] = v - fxD(B.ufx[fidx(o + 1 + pe, UFX_5IF, NUFX)]);
+    return true;
+}
+// what assmemo.h reads of acceptor site li of the LA list (li >= its length: the sites whose AG lies inside the piece while the
+// longass state that belongs to them would end after it, q = n ...): q, and per requester whether a predecessor is alive
+AUGX_HD int memoAssSite(const DevTables &T, const BatchView &B, int p, int li, const double *mat, const int *reqS, int nReq, uint8_t &alive) {
+    const int64_t o = B.off[p], lo = listOff(B, p);
+    const int n = B.len[p], S = T.S, nList = (int)B.cnt[fidx(o + n, CNT_LA, NCNT)];
+    const int off = T.U + T.As + 2 + T.Ae;
+    alive = 0;
+    int q;
+    if (li < nList) q = B.laPos[lo + li];
+    else {
+        q = n + (li - nList);
+        const uint8_t *code = B.code + o + 1;
+        const int pos = q - T.Ae; // isPossibleASS(pos): the AG at pos - 1, pos
+        if (!(q <= n - 2 + T.Ae && pos >= 1 && pos <= n - 2 && code[pos - 1] == 0 && code[pos] == 2)) return -1;
+    }
+    const int eop = q - off;
+    if (eop < 0) return -1;
+    for (int r = 0; r < nReq; r++)
+        if ((li < nList || T.kind[reqS[r]] != AUGX_K_LONGASS) && memoAnyAlive(T, mat, S, reqS[r], eop)) alive |= (uint8_t)(1u << r);
+    return q;
+}
+AUGX_HD uint8_t memoGateBits(const DevTables &T, const BatchView &B, int p, int j, const int *reqS, int nReq) {
+    const uint64_t g = B.gate[B.off[p] + 1 + j];
+    uint8_t m = 0;
+    for (int r = 0; r < nReq; r++) if (T.kind[reqS[r]] != AUGX_K_LONGASS && ((g >> T.vbit[reqS[r]]) & 1ull)) m |= (uint8_t)(1u << r);
+    return m;
+}
+// the values of one acceptor site rebuilt as the replay of the memo asks (dp.h: AssPatch; sw / out: the batch's arrays)
+// value of the acceptor site whose longass state would end at q under the class of plane pl, as k1SiteSignals makes SIG_ASSF: aSSProb +
+// the soft-masking bonus of the intronic part of the window (a site past the end of the piece: the bases inside it)
+AUGX_HD double assSiteValue(const DevTables &T, const BatchView &B, int p, int pl, int q) {
+    const int64_t o = B.off[p];
+    const int n = B.len[p], begin = q - (T.As + 2 + T.Ae) - T.U + 1;
+    Piece P = makePieceAt(T, B, p, pl);
+    double v = assProb(P, begin, true);
+    if (T.soft && v > AUGX_NINF) {
+        const int a = begin < 0 ? 0 : begin;
+        int b2 = q - T.Ae; if (b2 > n - 1) b2 = n - 1;
+        if (b2 >= a) v = v + (double)(int64_t)((uint64_t)B.cnt[fidx(o + 1 + b2, CNT_SOFT, NCNT)] - (uint64_t)B.cnt[fidx(o + a, CNT_SOFT, NCNT)]) * T.lnSoft;
+    }
+    return v;
+}
+AUGX_HD void k1AssPatch(const DevTables &T, const BatchView &B, int p, const AssPatch &A, const AssSwIn *sw, LaSw *out) {
+    const int64_t o = B.off[p], lo = listOff(B, p);
+    const int q = B.laPos[lo + A.li];
+    auto aOf = [&](int pl) -> double { return assSiteValue(T, B, p, pl, q); };
+    if (A.longPl >= 0) B.sig[(o + 1 + q) * NSIG + SIG_ASSF] = aOf(A.longPl);
+    if (A.basePl < 0) return;
+    const double a0 = aOf(A.basePl);
+    USite &e = B.laSite[lo + A.li];
+    e.b[0] = a0 - fxD(B.ufx[fidx(o + 1 + q, UFX_5F, NUFX)]);
+    e.b[1] = a0 - fxD(B.ufx[fidx(o + 1 + q, UFX_3F, NUFX)]);
+    e.pad = 0;
+    if (A.nSw > 0 && a0 > AUGX_NINF) {
+        e.pad = A.swOff + 1;
+        for (int k = 0; k < A.nSw; k++) { out[A.swOff + k].key = sw[A.swOff + k].key; out[A.swOff + k].more = (uint32_t)(A.nSw - 1 - k); out[A.swOff + k].cum = aOf(sw[A.swOff + k].pl) - a0; }
+    }
+}
+
+// =================================================================================================
 // candidates of the exon-like UTR states, evaluated where they are needed (trellis, forward, back-trace, sampler)
 // =================================================================================================
 struct UDesc {          // state s ending at base j
@@ -476,9 +579,27 @@ AUGX_HD int utrCandPre(const UCtx &X, const UDesc &D, int xi, int sitePos, doubl
     if (D.kind == AUGX_K_RUTR3SINGLE && begin <= 0) tail3 = true;                                     // left-truncated (:1312)
     return 1;
 }
+// (begin signal - content prefix) of site record e for the state described by D.  An acceptor site whose value changes during the
+// sweep (assmemo.h; e.pad > 0, rare: near a GC-class step) carries a table of changes by (end base, state) of the asking state
+AUGX_HD double utrSiteB(const BatchView &B, const UDesc &D, const USite &e) {
+    double bv = D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2];
+    if (D.list == UL_LA && e.pad > 0) {
+        const uint32_t key = ((uint32_t)D.j << 7) | (uint32_t)D.s;
+        const LaSw *w = B.laSw + (e.pad - 1);
+        double cum = 0.0;
+        for (;;) {
+            if (key < w->key) break;
+            cum = w->cum;
+            if (!w->more) break;
+            w++;
+        }
+        bv = bv + cum;
+    }
+    return bv;
+}
 AUGX_HD bool utrCandFrom(const UCtx &X, const UDesc &D, int xi, const USite &e, double &te, int &eop) {
     double sig; int len; bool tail3;
-    if (!utrCandPre(X, D, xi, e.pos, D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2], sig, len, tail3, eop)) return false;
+    if (!utrCandPre(X, D, xi, e.pos, utrSiteB(X.B, D, e), sig, len, tail3, eop)) return false;
     const double lp = utrLenAt(X.T, D.len, len, tail3);
     if (!(lp > AUGX_NINF)) return false;
     te = sig + lp;
@@ -562,7 +683,7 @@ AUGX_KFN void utrDescGroup(const DevTables &T, const BatchView &B, UDescLds &L, 
                 const int idx = D.xFirst ? D.nExtra + li : li;
                 const USite e = X.list(D.list)[D.i1 - 1 - li];
                 double sig; int len, eop; bool tail3;
-                if (utrCandPre(X, D, -1, e.pos, D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2], sig, len, tail3, eop, true) != 2) break;
+                if (utrCandPre(X, D, -1, e.pos, utrSiteB(B, D, e), sig, len, tail3, eop, true) != 2) break;
                 double te = AUGX_NINF;
                 if (!utrCand(X, D, idx, te, eop)) te = AUGX_NINF;
                 D.preEop[li] = e.pos; D.preTe[li] = te; D.nPre = (int8_t)(li + 1);
@@ -960,7 +1081,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
                                     if (act[h] && xi[h] < 0 && !pre[h]) {
                                         USite e;
                                         e = ldUSite(sites + ((int64_t)D.i1 - 1 - li));
-                                        sPos[h] = e.pos; sB[h] = D.bsel == 0 ? e.b[0] : D.bsel == 1 ? e.b[1] : e.b[2];
+                                        sPos[h] = e.pos; sB[h] = utrSiteB(B, D, e);
                                     }
                                 }
                                 // the length terms (they depend on the site's position); the rare cases go to the list of stage 2

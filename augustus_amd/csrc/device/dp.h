@@ -108,6 +108,15 @@ struct IntronStart { int32_t pos; uint32_t ctx; uint64_t fx; };
 // one possible begin of a UTR exon (entry of the TF / LA / FS / LR / TM / RT site lists, dense.h): the end of the predecessor state
 // and, per content model that can follow, (ln begin signal) - (content prefix before the first base of the middle part)
 struct USite { int32_t pos; int32_t pad; double b[3]; };
+// an acceptor site whose value changes while the sweep goes on (the reference's aSSProb memo is emptied and the site computed again
+// under another GC class, assmemo.h): laSite[i].pad - 1 is the first of its entries here, ascending by key; a candidate of
+// (end base j, state s) adds `cum` of the last entry with key <= (j << 7 | s) to the site's b value
+struct LaSw { uint32_t key; uint32_t more; double cum; };
+// one acceptor site whose value the replay of the memo found to come from another class than the one k1SiteSignals took (entry li of
+// the LA list): the longass states of its column get the value of plane longPl (-1: as it is), the UTR exons that begin at it the
+// value of plane basePl and, from the calls sw[swOff .. swOff + nSw) on, those of the planes named there (dense.h: k1AssPatch)
+struct AssPatch { int32_t li; int8_t longPl, basePl; int16_t nSw; int32_t swOff; };
+struct AssSwIn { uint32_t key; int32_t pl; };
 // flat model tables on the device (pointers are device pointers; in the emulator, host pointers)
 // Pointers to the MODEL TABLES (ln probabilities of the species' parameter files, read-only for the lifetime of a decoder).  In
 // device code they point into the constant address space: a table look-up may then be moved across the kernel's own stores and
@@ -183,6 +192,7 @@ struct BatchView {
     uint32_t *ucnt;            // [N][NUCNT] prefix counts of the UTR begin sites
     double *usig;              // [N][NUSIG]
     USite *tfSite, *laSite, *fsSite, *lrSite, *tmSite, *rtSite; // [listCap] begin-site lists (laSite / lrSite run parallel to laPos / lrPos)
+    const LaSw *laSw;          // acceptor sites whose value changes during the sweep (NULL: none)
     uint8_t *bpD;              // [N][S] back pointers of the chain and fixed-lag states (ancestor index, 0xFF: none)
     struct UDesc *ud;          // [udCap] descriptors of the open (end base, UTR exon state) pairs, the pairs of a block contiguous (kUtrDesc)
     int64_t udCap;

@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include "assmemo.h"
 #include <system_error>
 #include <thread>
 #include <unordered_map>
@@ -291,8 +292,14 @@ struct SamplePiece {
         std::vector<uint64_t> ufx;
         std::vector<double> usig, sigAll;
         std::vector<USite> sites[6];
+        std::vector<LaSw> laSw;
     };
     std::shared_ptr<UtrHost> uh;
+    // (UTR states on a piece with several GC classes) the reference's memo of acceptor-site values as the sweep of the piece left it
+    // (assmemo.h): it lives on through the back-tracking of the Viterbi path -- vitPath, 5'->3' -- and through the sampled paths
+    struct AssMemoReplay *memo = nullptr;
+    std::shared_ptr<void> memoOwner;
+    std::vector<augx_state> vitPath;
     double lnT(int j, int a, int s) const {
         const int c = plane.empty() ? cls0 : planeCls[plane[j]];
         return t->ln_trans[((int64_t)c * S + a) * S + s];
@@ -391,6 +398,58 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
     }
     sortOptions(L);
 }
+// A step through (state s, base j) of a path that is traced back after the sweep -- the Viterbi path, a sampled path -- evaluates the
+// state once more (reference doBacktracking / doSampling): a longass state asks aSSProb for its site, one of the four UTR exon kinds
+// for every acceptor site of its window with a live predecessor, latest first -- from the memo as it is THEN, with the class of j
+// where it has to be computed again (assmemo.h).  The options of such a UTR exon step (L != NULL) carry the values the memo gives.
+inline void memoStep(const SamplePiece &P, int s, int j, OptList *L) {
+    const augx_tables &t = *P.t;
+    AssMemoReplay &R = *P.memo;
+    const int S = P.S, kind = t.state_kind[s], pl = P.plane.empty() ? 0 : P.plane[(size_t)j];
+    if (kind == AUGX_K_LONGASS) {
+        const int i = R.siteOfQ(j);
+        if (i >= 0) (void)R.late(i, pl);
+        return;
+    }
+    const int off = t.U + t.As + 2 + t.Ae;
+    UCtx X(*P.hT, *P.hB, P.hp);
+    UDesc D;
+    utrDescribe(X, s, j, D);
+    if (L) L->o.clear();
+    const uint32_t key = assKey(j, s);
+    for (int idx = 0; idx < D.total; idx++) {
+        int li, xi;
+        utrCandIndex(D, idx, li, xi);
+        USite e;
+        e.pos = 0; e.pad = 0; e.b[0] = e.b[1] = e.b[2] = AUGX_NINF;
+        int eop;
+        if (xi < 0) { e = X.list(D.list)[D.i1 - 1 - li]; eop = e.pos; } else eop = D.xHi - xi;
+        const int col = eop > 0 ? eop : 0;
+        bool any = false;
+        for (int ai = 0; ai < t.n_anc[s]; ai++) any = any || P.F[(size_t)col * S + t.anc[s][ai]] > -INFINITY;
+        if (!any) continue;
+        const int q = eop + off, site = R.siteOfQ(q);
+        int now = -1, then = -1;
+        if (site >= 0) {
+            now = R.late(site, pl);
+            then = xi < 0 ? R.sweepPlane(site, key) : (int)P.plane[(size_t)(P.n - 1)]; // (a site past the end of the piece is valued on the spot: the class of the last base)
+        }
+        if (!L) continue;
+        double te; int eop2;
+        if (!utrCandFrom(X, D, xi, e, te, eop2)) continue;
+        if (site >= 0 && then >= 0 && now != then) te = te + (assSiteValue(*P.hT, *P.hB, P.hp, now, q) - assSiteValue(*P.hT, *P.hB, P.hp, then, q));
+        for (int ai = 0; ai < t.n_anc[s]; ai++) {
+            const int a = t.anc[s][ai];
+            const double lp = P.F[(size_t)col * S + a] + (P.lnT(j, a, s) + te);
+            if (lp > -INFINITY) L->o.push_back({a, eop2, lp});
+        }
+    }
+    if (L) sortOptions(*L);
+}
+inline bool memoAsks(const SamplePiece &P, int kind) {
+    return P.memo && (kind == AUGX_K_LONGASS || kind == AUGX_K_UTR5INTERNAL || kind == AUGX_K_UTR5TERM || kind == AUGX_K_UTR3INTERNAL || kind == AUGX_K_UTR3TERM);
+}
+
 // reference OptionsList::sample, src/vitmatrix.cc:295-320
 inline const Opt *drawOption(const OptList &L, augx_rand &R) {
     if (L.o.empty() || !(L.cum > 0)) return nullptr;
@@ -544,6 +603,10 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
     if (!P.prepared) prepareStops(P);
     std::vector<std::vector<int32_t>> &stops = P.stops;
     std::vector<int64_t> cur((size_t)S, 0); // per sample: index of the last stop <= the base the path was last at in this state
+    if (P.memo) // the Viterbi path was traced back before the first sample was drawn (reference NAMGene::findGenes, src/namgene.cc:790): 3'->5'
+        for (size_t i = P.vitPath.size(); i-- > 0;)
+            if (memoAsks(P, t.state_kind[P.vitPath[i].state]) && P.vitPath[i].end > 0) memoStep(P, P.vitPath[i].state, P.vitPath[i].end, nullptr);
+    OptList memoList;
     for (int it = 0; it < n_samples; it++) {
         st.clear();
         // a piece without a nucleotide: one intergenic state, no draw (reference src/namgene.cc:380-384)
@@ -617,6 +680,18 @@ inline void samplePaths(SamplePiece &P, int n_samples, augx_rand &R, std::vector
                     continue;
                 }
                 const uint64_t tk1 = samplerTicks();
+                if (memoAsks(P, kd) && kd != AUGX_K_LONGASS) { // (the options of this step depend on what the memo holds now: made afresh)
+                    memoStep(P, state, base, &memoList);
+                    const Opt *x = drawOption(memoList, R);
+                    if (!x) { bad = true; break; }
+                    st.push_back({x->base + 1, base, (int16_t)state, (int16_t)t.state_type[state]});
+                    const int nb = x->base, ns = x->state;
+                    base = nb; state = ns;
+                    P.nVar++;
+                    P.tkVar += samplerTicks() - tk1;
+                    continue;
+                }
+                if (memoAsks(P, kd)) memoStep(P, state, base, nullptr); // (a longass step: asks, its options do not depend on the answer)
                 const uint64_t key = ((uint64_t)base << 8) | (uint64_t)state;
                 SamplerScratch::Ent *f = M.find(key + 1);
                 P.nVar++;

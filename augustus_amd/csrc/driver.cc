@@ -552,6 +552,8 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
     };
 
     std::map<WinKey, Decoded> cache;
+    const bool cutDebug = getenv("AUGX_CUT_DEBUG") != nullptr;
+    std::vector<std::string> cutDebugLines;
     // guesses followed per undecoded window.  Measured on 23 Mbp of uniform-random DNA, fly model: 47 states (a batch costs what its
     // bases cost): 1 -> 8 batches of ~55 windows, 5 -> 5 batches of ~215, slower.  71 states (one workgroup per window, a batch costs
     // what its longest window costs while there are compute units to spare): 1 -> 26 batches, 5 -> 18
@@ -582,6 +584,18 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
                 if (!more) break;
                 stats.used++;
                 if (hit->second.status != 0) { failStatus[r] = hit->second.status; c.done = true; break; } // the record's error
+                if (cutDebug && scouted[r]) { // developer aid: what the map's forecasts said about this window against what its decode says
+                    CutState tr2 = c;
+                    std::vector<PieceRef> tmp;
+                    applyWindow(r, tr2, hit->second.path, &tmp);
+                    std::string line = "F " + std::to_string(r) + " " + std::to_string(c.es) + " " + std::to_string(c.ee) + " " + std::to_string(c.attempt) + " true " + (tr2.attempt == 1 && c.attempt == 0 ? std::string("retry") : std::to_string(tr2.beginPos - 1));
+                    for (auto &path : forecasts(r, c.es, c.ee, c.prevInit, c.prevTerm)) {
+                        CutState g = c;
+                        applyWindow(r, g, path, &tmp);
+                        line += " " + (g.attempt == 1 && c.attempt == 0 ? std::string("retry") : std::to_string(g.beginPos - 1));
+                    }
+                    cutDebugLines.push_back(line);
+                }
                 applyWindow(r, c, hit->second.path, &recPieces[r]);
             }
         }
@@ -678,6 +692,7 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
             }
             for (size_t r = 0; r < recs.size(); r++)
                 for (auto &pr : recPieces[r]) fprintf(f, "C %zu %ld %ld\n", r, pr.begin, pr.end);
+            for (auto &l : cutDebugLines) fprintf(f, "%s\n", l.c_str());
             fclose(f);
         }
     }
@@ -998,13 +1013,6 @@ extern "C" int augx_main(int argc, const char *const *argv) {
         for (size_t k = 0; k < dd.size(); k++) decoded[slot[k]] = std::move(dd[k]);
     }
 
-    if (S.sampleiterations > 0) { // (said once, on stderr: the one input class where sampled probabilities may not be the reference's)
-        int64_t nUn = 0;
-        for (augx_decoder *d : S.decs) nUn += augx_decoder_unreplayed_batches(d);
-        if (nUn > 0)
-            std::cerr << "augustus (MI355X): note: pieces with more than one GC-content class were sampled with the UTR model; a few posterior probabilities near the "
-                         "class steps may differ slightly from the CPU reference's (the predicted genes do not)." << std::endl;
-    }
     if (timing && getenv("AUGX_NEAR_TIES") && atoi(getenv("AUGX_NEAR_TIES")) != 0) { // (counted by a kernel build of its own: asked for by name, not implied by AUGX_TIMING)
         int64_t nt = 0, np = 0;
         for (augx_decoder *d : S.decs) { int64_t q = 0; nt += augx_decoder_near_ties(d, &q); np += q; }

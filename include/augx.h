@@ -203,15 +203,13 @@ int augx_decoder_set_share(augx_decoder *d, int n_decoders_on_device);
  * exact = 1 (the default; environment AUGX_EXACT_MULTICLASS=0 turns it off) the cache is replayed after a first trellis run and
  * the run repeated with the rebuilt terms: every Viterbi variable is then the reference's to 1e-9 there as well -- and the path:
  * a randomised soak found a record where the optimal path depends on it.  exact = 0 saves the second trellis run on batches
- * with such pieces.  The forward algorithm (augx_batch_forward) always replays it. */
+ * with such pieces.  The forward algorithm (augx_batch_forward) always replays it.
+ * Models with UTR states: two more call-history caches of the reference that only UTR states read are replayed with it --
+ * tssProbsPlus (a forward TSS window is scored with the class current when a 5' UTR state first asks for it,
+ * src/utrmodel.cc:748-790,1788-1790) and the memo of IntronModel::aSSProb (first asker, emptied beyond 1000 sites,
+ * src/intronmodel.cc:1120-1135,1182-1186; device/assmemo.h). */
 int augx_decoder_set_exact(augx_decoder *d, int exact);
 int augx_decoder_exact(const augx_decoder *d); /* the current setting (1 / 0) */
-/* number of forward runs (posterior sampling) this decoder made with the UTR model over a batch that holds a piece with more than
- * one GC-content class.  The reference's snippet cache (SnippetProbs, src/statemodel.cc:312-342) is replayed for every model; two
- * more call-history caches that only UTR states use (tssProbsPlus, src/utrmodel.cc:748-790; the aSSProb memo,
- * src/intronmodel.cc:1120-1135) are not: a few forward variables within some dozen bases of a class step may be up to 1e-3 off in
- * ln (the sampled paths of every multi-class record tried are the reference's).  The Viterbi path is not affected. */
-int64_t augx_decoder_unreplayed_batches(const augx_decoder *d);
 /* Near ties.  Every model term is rounded once to 2^-31 (AUGX_Q_BITS), which is what makes the decode exact and order-free; two
  * alternative candidates of a cell whose scores differ by less than ~2e-7 in ln may therefore be decided the other way by the
  * reference, whose own rounding is finer (seen once in 315 randomised runs).  With counting on (also: AUGX_TIMING or

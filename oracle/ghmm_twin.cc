@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <vector>
 #include "../include/augx.h"
 
@@ -708,11 +709,16 @@ struct Twin {
                 eop = j - 1;
                 emi = eIn(c, j) + softB(j);
                 break;
-            case AUGX_K_LONGASS:
+            case AUGX_K_LONGASS: {
                 eop = j - assWhole - t.U;
                 if (eop < 0 || !possASS(j - t.Ae)) return;
-                emi = assProb(c, j - assWhole - t.U + 1, true) + softIn(j - assWhole - t.U + 1, j - t.Ae);
+                // (the value is asked for -- and, the first time since the memo was emptied, computed -- only for a live predecessor, :729-745)
+                bool any = false;
+                for (int ai = 0; ai < t.n_anc[s]; ai++) any = any || Vat(eop, t.anc[s][ai]) > NINF;
+                if (!any) return;
+                emi = assProb(assMemoClass(j - assWhole - t.U + 1), j - assWhole - t.U + 1, true) + softIn(j - assWhole - t.U + 1, j - t.Ae);
                 break;
+            }
             default: // RLONGASS
                 eop = j - assWhole - t.U;
                 if (eop < 0 || !possRASS(j - t.U - t.As - 2 + 1)) return;
@@ -871,15 +877,30 @@ struct Twin {
         if (from < 1) return (double)(int64_t)(P[to + 1] - P[0]) * AUGX_FX_INV;
         return (double)(int64_t)(P[to + 1] - P[from]) * AUGX_FX_INV;
     }
-    // aSSProb as a begin / end signal of a UTR exon.  The reference answers it from a memo filled by whichever state asked first
-    // (src/intronmodel.cc:1120-1135), as a rule the longass state that ends U + As + 2 + Ae - 1 bases after `base`: the class of
-    // that base is used here (single-class pieces: no difference)
-    double assProbU(int base, bool fwd) const {
+    // aSSProb(base, forward strand) is answered from a memo (static map memoF, src/intronmodel.cc:1120-1135, 1182-1186): a value is
+    // computed -- with the class current THEN -- by whichever state asks first (a 5' UTR exon overlapping the start codon asks up to
+    // W + Ae columns before the longass state does; UTR exons that begin at the site ask for thousands of columns after it) and kept
+    // until the memo holds more than 1000 sites: the next call, whatever it asks for, empties it.  The memo is empty when the sweep
+    // of a piece begins (IntronModel::updateToLocalGCEach -> aSSProb(-1), :440-444).  Returns the class the value comes from.
+    // (The reverse-strand memo needs no restating: every request for a reverse site is made in ONE column, its own.)
+    // With the caches off (twin_set_snippet_cache(0): the first pass of the device): the class of the base the longass state ends at.
+    std::map<int, int> memoF;
+    bool useMemo = false;
+    long long memoFlushes = 0, memoForeign = 0; // (test aid: times the memo was emptied; answers that came from another class than the natural one)
+    int assMemoClass(int base) {
         int q = base + t.U + t.As + 2 + t.Ae - 1;
         if (q > n - 1) q = n - 1;
         if (q < 0) q = 0;
-        return assProb(cls[q], base, fwd);
+        if (!useMemo) return cls[q];
+        if (memoF.size() > 1000) { memoF.clear(); memoFlushes++; }
+        auto it = memoF.find(base);
+        if (it != memoF.end()) { if (it->second != cls[q]) memoForeign++; return it->second; }
+        if (!possASS(base + t.U + t.As + 1)) return curCls; // (no acceptor site: the value is 0, nothing is kept, :1140-1143)
+        memoF[base] = curCls;
+        if (curCls != cls[q]) memoForeign++;
+        return curCls;
     }
+    double assProbU(int base, bool fwd) { return assProb(fwd ? assMemoClass(base) : curCls, base, fwd); }
     // (checkF != NULL: instead of the Viterbi cell, ln of the SUM over the same candidates with predecessor values taken from
     //  checkF -- the forward recurrence of one cell, for tests of the forward matrices; result in checkOut)
     const double *checkF = nullptr;
@@ -1111,6 +1132,7 @@ struct Twin {
             for (int j = 1; j < n && g_snippetCache; j++) useSnips = useSnips || cls[j] != cls[0];
             if (useSnips) { snips[0].assign((size_t)n, {}); snips[1].assign((size_t)n, {}); }
             if (t.utr) buildUtr();
+            useMemo = useSnips && t.utr; memoF.clear();
             for (int j = 1; j < n; j++) {
                 curCls = cls[j];
                 if (t.utr && curCls != prevCls) utrEnterRegion(j);

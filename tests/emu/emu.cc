@@ -13,6 +13,7 @@
 #include <vector>
 #include "../../augustus_amd/csrc/device/kernels.h"
 #include "../../augustus_amd/csrc/device/dense.h"
+#include "../../augustus_amd/csrc/device/assmemo.h"
 #include "../../augustus_amd/csrc/device/layout.h"
 #include "../../augustus_amd/csrc/device/sampler.h"
 #include "../../augustus_amd/csrc/device/snipmemo.h"
@@ -232,13 +233,67 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
         if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu stats (dense): piece %d: %zu candidate terms rebuilt from the reference's snippet cache\n", p, R.patches.size());
         return !R.patches.empty();
     };
+    // the two other call-history caches of the reference, read by UTR states only (tssProbsPlus: dense.h k1TssReplay; the aSSProb memo:
+    // assmemo.h): the values concerned are rebuilt in place; true: some were -- the descriptors hold values made from them (kUtrDesc
+    // again), and the pass has to run once more
+    std::vector<LaSw> laSw;
+    std::vector<AssSwIn> laSwIn;
+    std::vector<char> memoDone((size_t)n, 0);
+    std::vector<std::shared_ptr<AssMemoReplay>> memoOf((size_t)n);
+    auto memoReplay = [&](int p, const double *mat) -> bool {
+        if (B.nPlanes[p] <= 1 || !T.utr || memoDone[(size_t)p]) return false;
+        memoDone[(size_t)p] = 1;
+        const int len = L.len[p], S = t->S;
+        const int64_t o = L.off[p];
+        const double *M = mat + (o + 1) * S;
+        int nTss = 0;
+        const int nTf = (int)B.ucnt[fidx(o + len, UCNT_TF, NUCNT)];
+        for (int li = 0; li < nTf; li++) nTss += k1TssReplay(T, B, p, li, M);
+        memoOf[(size_t)p] = std::make_shared<AssMemoReplay>();
+        AssMemoReplay &R = *memoOf[(size_t)p];
+        R.T = &T; R.n = len; R.plane = B.gcPlane + o + 1;
+        R.requesters();
+        const int nList = (int)B.cnt[fidx(o + len, CNT_LA, NCNT)];
+        for (int li = 0; li < nList + T.Ae; li++) {
+            uint8_t alive;
+            const int q = memoAssSite(T, B, p, li, M, R.reqS, R.nReq, alive);
+            if (q < 0) continue;
+            R.siteQ.push_back(q); R.siteLi.push_back(li); R.siteAlive.push_back(alive);
+        }
+        R.gateOwn.resize((size_t)len);
+        for (int j = 0; j < len; j++) R.gateOwn[(size_t)j] = memoGateBits(T, B, p, j, R.reqS, R.nReq);
+        R.gate = R.gateOwn.data();
+        R.run(getenv("AUGX_MEMO_SLOW") != nullptr);
+        std::vector<AssPatch> pt;
+        const size_t sw0 = laSwIn.size();
+        const int extras = R.patches(nList, pt, laSwIn);
+        laSw.resize(laSwIn.size());
+        B.laSw = laSw.data();
+        for (const AssPatch &A : pt) k1AssPatch(T, B, p, A, laSwIn.data(), laSw.data());
+        if (getenv("AUGX_EMU_STATS"))
+            fprintf(stderr, "emu stats (dense): piece %d: %d TSS windows and %zu acceptor sites (%zu changes of value during the sweep, %d sites past the end left) rebuilt from the reference's caches; aSSProb memo: %lld calls walked, emptied %lld times\n",
+                    p, nTss, pt.size(), laSwIn.size() - sw0, extras, R.calls, R.flushes);
+        return nTss > 0 || !pt.empty();
+    };
+    auto describeAgain = [&]() { // (kUtrDesc: the leading candidates of a descriptor are evaluated there, from the site values)
+        if (!T.utr) return;
+        UDescLds *ul = new UDescLds();
+        const int64_t nGrp = B.N / (NT / 16);
+        ca.descs = 0;
+        for (int64_t wg = 0; wg < nGrp; wg++) { if (blk == 8) utrDescGroup<8>(T, B, *ul, wg); else if (blk == 4) utrDescGroup<4>(T, B, *ul, wg); else utrDescGroup<2>(T, B, *ul, wg); }
+        delete ul;
+    };
     const bool exact = !getenv("AUGX_EXACT_MULTICLASS") || atoi(getenv("AUGX_EXACT_MULTICLASS")) != 0; // (augx_decoder_set_exact, on by default)
     auto viterbiPiece = [&](int p) {
         if (blk == 8) densePiece<8, 0, true>(T, B, *dl, p); else if (blk == 4) densePiece<4, 0, true>(T, B, *dl, p); else densePiece<2, 0, true>(T, B, *dl, p);
     };
     for (int p = 0; p < n; p++) {
         viterbiPiece(p);
-        if (exact && snippetReplay(p, B.cells)) viterbiPiece(p);
+        if (exact) {
+            const bool memo = !getenv("AUGX_NO_ASSMEMO") && memoReplay(p, B.cells);
+            if (memo) describeAgain();
+            if (snippetReplay(p, B.cells) || memo) viterbiPiece(p);
+        }
         denseBacktracePiece(T, B, p);
     }
     if (fwd_out) {
@@ -248,7 +303,11 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
         auto fwdPiece = [&](int p) { if (blk == 8) densePiece<8, 1>(T, B, *dl, p); else if (blk == 4) densePiece<4, 1>(T, B, *dl, p); else densePiece<2, 1>(T, B, *dl, p); };
         for (int p = 0; p < n; p++) {
             fwdPiece(p);
-            if (!getenv("AUGX_NO_MEMO") && snippetReplay(p, B.fwd)) fwdPiece(p);
+            if (!getenv("AUGX_NO_MEMO")) { // (the forward pass always replays; the site values may have been rebuilt by the Viterbi pass already)
+                const bool memo = !getenv("AUGX_NO_ASSMEMO") && memoReplay(p, B.fwd);
+                if (memo) describeAgain();
+                if (snippetReplay(p, B.fwd) || memo) fwdPiece(p);
+            }
         }
         int64_t w = 0;
         for (int p = 0; p < n; p++) {
@@ -263,6 +322,11 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
             const int64_t o = L.off[p];
             P.t = t; P.S = S; P.n = len; P.blk = blk; P.cls0 = cls[p]; P.nPlanes = B.nPlanes[p]; P.termKind = L.termKind[p];
             P.dense = true; P.hT = &T; P.hB = &B; P.hp = p;
+            if (memoOf[(size_t)p] && !getenv("AUGX_NO_LATE_MEMO")) { // (the aSSProb memo lives on through the back-tracking and the sampled paths)
+                P.memo = memoOf[(size_t)p].get();
+                const int64_t po = pathOff(B, p);
+                for (int i = pc[p] - 1; i >= 0; i--) { const int32_t *r = B.pathRec + (po + i) * 3; P.vitPath.push_back({r[0], r[1], (int16_t)r[2], (int16_t)t->state_type[r[2]]}); }
+            }
             P.F = B.fwd + (o + 1) * S;
             P.sig.assign(B.sig + (o + 1) * NSIG, B.sig + (o + 1 + len) * NSIG);
             if (P.nPlanes > 1) {

@@ -229,6 +229,20 @@ GENEMODEL_CFGS = {
 }
 
 
+def gc_step_records(count, seed, parts=8, lo=2500, hi=6000):
+    """records of uniform-random stretches whose GC content steps every few kb (two to five GC classes under most models): what the
+    reference's call-history caches (SnippetProbs, tssProbsPlus, the aSSProb memo) are sensitive to"""
+    rng = random.Random(seed)
+    recs = []
+    for i in range(count):
+        p = []
+        for k in range(parts):
+            gc = rng.choice([0.35, 0.42, 0.5, 0.58, 0.65])
+            p.append("".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(rng.randint(lo, hi))))
+        recs.append(("gcsteps%d_%d" % (seed, i), "".join(p)))
+    return recs
+
+
 def genemodel_records():
     return [(n, s) for n, s in golden_inputs() if n not in ("allN", "short7", "short100")]
 

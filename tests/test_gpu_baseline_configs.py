@@ -58,10 +58,7 @@ def test_cli_full_size_gff_identical_to_reference(big_inputs, cfg):
     assert r.returncode == 0, r.stderr
     gold = open(os.path.join(GOLDEN, "golden_big_%s.gff" % cfg)).read().splitlines()
     assert gff_body(r.stdout) == gold
-    if cfg == "human_utr_sampled":  # (UTR states, several GC classes, sampling: the executable says that two caches of the reference are not replayed)
-        assert r.stderr.startswith("augustus (MI355X): note:") and r.stderr.count("\n") == 1
-    else:
-        assert r.stderr == ""
+    assert r.stderr == ""
 
 
 @pytest.mark.parametrize("cfg", ["human", "synth"])

@@ -25,6 +25,8 @@ def test_gpu_utr_cells_bit_identical_to_oracle(species, opts):
     d = ax.Decoder(m, 0)
     S = m.n_states
     seqs = [s for _, s in golden_inputs()] + [random_dna(30000, 1), random_dna(5000, 2).lower(), random_dna(100, 3)]
+    if species == "human":  # (GC steps every few kb: tssProbsPlus and the aSSProb memo of the reference, replayed -- tests/test_memo_replay.py)
+        seqs += [s for _, s in gc_step_records(3, 7)]
     b = ax.Batch(d, seqs)
     b.decode()
     for i, (s, r) in enumerate(zip(seqs, b.paths())):
@@ -34,16 +36,17 @@ def test_gpu_utr_cells_bit_identical_to_oracle(species, opts):
 
 
 @needs_ref
-@pytest.mark.parametrize("species,opts,multi", [("fly", {}, False), ("human", {"UTR": "on", "softmasking": "0"}, False),
+@pytest.mark.parametrize("species,opts,multi", [("fly", {}, False), ("human", {"UTR": "on", "softmasking": "0"}, True),
                                                 ("human", {"genemodel": "exactlyone", "softmasking": "0"}, True)])
 def test_gpu_dense_forward_matches_reference(tmp_path, species, opts, multi):
     """the forward pass of the dense kernels (kDense<BLK, 1>: UTR states; two intergenic states) on the device against every forward
-    variable of the REAL reference, run live: the same cells alive, ln F within 1e-9 relative.  Two intergenic states: also on the
-    records with several GC classes (snippet cache replayed from the dense ln F matrix); UTR states on one-class records (the two
-    caches that are not replayed only matter next to class steps)."""
+    variable of the REAL reference, run live: the same cells alive, ln F within 1e-9 relative -- also on the records with several GC
+    classes: the reference's call-history caches are replayed from the dense matrix (the snippet cache; with UTR states also
+    tssProbsPlus and the aSSProb memo, round 6: records whose GC content steps every few kb, where sites change their value
+    during the sweep)."""
     ex = dict(golden_inputs())
-    names = ["HS04636", "HS08198", "short600", "trunc_both", "trunc_right", "iupac"] + (["multigc_gene", "multigc_rand"] if multi else [])
-    recs = [(k, ex[k]) for k in names] + [("rnd", random_dna(12000, 77))]
+    names = ["HS04636", "HS08198", "short600", "trunc_both", "trunc_right", "iupac"] + (["multigc_gene", "multigc_rand", "multigc_two", "multigc_levels"] if multi else [])
+    recs = [(k, ex[k]) for k in names] + [("rnd", random_dna(12000, 77))] + (gc_step_records(2, 7) if multi and "UTR" in opts else [])
     fa = str(tmp_path / "x.fa")
     write_fasta(fa, recs)
     Fref = ref_forward(fa, species, ["--%s=%s" % kv for kv in opts.items()])
@@ -166,3 +169,25 @@ def test_gpu_utr_descriptor_buffer_grows(monkeypatch):
             rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
             assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, (rep, i)
             assert np.array_equal(b.cells(i), V), (rep, i)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [11037, 11059, 11073, 11088])
+def test_cli_soak_seeds_with_utr_states_gc_steps_and_sampling(tmp_path, monkeypatch, seed):
+    """four cases of the randomised soak (`AUGX_SOAK_DENSE=2 tests/soak_cli.py 11000 90`: human --UTR=on --sample=100 on records whose GC
+    class steps every few kb) that printed ANOTHER SAMPLE than the reference until round 6 (`0.24` where the reference prints `0.35`): the
+    aSSProb memo of the reference is replayed through the sweep (assmemo.h), and it lives on through the back-tracking of the Viterbi
+    path and the 99 sampled paths (sampler.h: memoStep).  GFF byte-identical to the reference binary's, run live."""
+    import soak_cli
+    monkeypatch.setenv("AUGX_SOAK_DENSE", "2")
+    d, g = soak_cli.real_dna()
+    recs, species, opts = soak_cli.make_case(seed, g)
+    assert species == "human" and opts["UTR"] == "on" and opts["sample"] == "100"
+    fa = str(tmp_path / "c.fa")
+    write_fasta(fa, recs)
+    args = ["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()]
+    import subprocess
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    ref = subprocess.run([REF_AUGUSTUS] + args + [fa], capture_output=True, text=True, env=env)
+    assert ref.returncode == 0
+    assert gff_body(_run_cli(args, fa)) == gff_body(ref.stdout)
