@@ -479,7 +479,7 @@ struct augx_decoder {
     bool dense = false;        // the model is decoded by the dense kernels (dense.h)
     bool countNearTies = false;    // the back-trace counts the near ties on the chosen paths (AUGX_NEAR_TIES=1, augx_decoder_count_near_ties)
     int64_t nearTies = 0, nearTiePieces = 0; // ... summed over the batches whose paths were fetched
-    double mallocSeconds = 0, mallocBytes = 0; // hipMalloc calls of this decoder so far (AUGX_TIMING; guarded by nothing: one host thread drives a decoder)
+    double mallocSeconds = 0, mallocBytes = 0; // hipMalloc calls of this decoder so far (AUGX_TIMING; under poolMu: the replay helpers allocate from many threads)
     bool exactMulti = true;    // replay the reference's snippet cache on multi-class pieces for the Viterbi run as well (augx_decoder_set_exact)
 };
 
@@ -490,7 +490,22 @@ int utrCachesReplay(augx_decoder *d, augx_batch *b, const double *mat, bool &reb
 // allocation fails, the buffers the OTHER decoders of the device keep for re-use are given back to the runtime as well
 std::mutex g_regMu;
 std::vector<augx_decoder *> g_decoders;
-constexpr size_t POOL_CAP_BYTES = (size_t)128 << 30; // the decoders of ONE DEVICE together keep at most this much for re-use (288 GB of HBM per device; a batch of 100 Mbp takes 80)
+// the decoders of ONE DEVICE together keep at most this much for re-use (288 GB of HBM per device).  Round 6: a batch of 127 Mbp of
+// multi-class DNA holds 170 GB, and what a destroyed batch could not leave in the pool went back to the driver -- which wipes freed
+// memory lazily, so that the NEXT batch's hipMalloc of the same 40 GB waited 1.5-4 s for it (the 1 Gbp genome run: 33 s of hipMalloc
+// in 26 batches).  An allocation that fails empties the pools and tries again (devMalloc), so the cap only has to leave the runtime
+// some room.
+constexpr size_t POOL_CAP_BYTES = (size_t)250 << 30;
+// Buffers are handed out in size classes (a sixteenth of the next power of two: at most 1/8 larger than asked for): consecutive
+// batches of a genome differ by a fraction of a per cent in their base counts, and a pooled buffer 0.3 % too small is no use
+// (before: every other batch of the genome run found nothing in the pool that fitted and allocated all its arrays afresh)
+size_t sizeClass(size_t bytes) {
+    if (bytes < ((size_t)1 << 20)) return (bytes + 4095) & ~(size_t)4095;
+    size_t p2 = (size_t)1 << 20;
+    while (p2 < bytes) p2 <<= 1;
+    const size_t step = p2 >> 4;
+    return (bytes + step - 1) / step * step;
+}
 void poolReleaseLocked(augx_decoder *d) {
     for (auto &kv : d->pool) (void)hipFree(kv.second);
     d->pool.clear();
@@ -502,6 +517,7 @@ void poolRelease(augx_decoder *d) {
 }
 hipError_t devMalloc(augx_decoder *d, void **out, size_t bytes) {
     if (bytes == 0) bytes = 1;
+    bytes = sizeClass(bytes);
     {
         std::lock_guard<std::mutex> lk(d->poolMu);
         auto it = d->pool.lower_bound(bytes);
@@ -515,8 +531,11 @@ hipError_t devMalloc(augx_decoder *d, void **out, size_t bytes) {
     }
     const auto tm0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, bytes);
-    d->mallocSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count(); // (developer aid: printed under AUGX_TIMING)
-    d->mallocBytes += (double)bytes;
+    {   // (developer aid: printed under AUGX_TIMING)
+        std::lock_guard<std::mutex> lk(d->poolMu);
+        d->mallocSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count();
+        d->mallocBytes += (double)bytes;
+    }
     if (e != hipSuccess) { // this decoder's pool first, then those of the other decoders on the device
         (void)hipGetLastError();
         poolRelease(d);
@@ -1439,10 +1458,14 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
             if (e != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); return AUGX_E_HIP; }
             return AUGX_OK;
         };
-        R.fetch = [=](int, int) -> int { // the next window's part of what prefetch brought
+        R.fetch = [=](int ft0, int ft1) -> int { // the next window's part of what prefetch brought
             SnippetReplay &R2 = DP->R;
             if (DP->nextWin >= DP->wins.size()) return AUGX_E_ARG;
             const GatherWin &g = DP->wins[DP->nextWin++];
+            {   // (the windows are handed out in the order prefetch was told them: this must be the one asked for)
+                const int t0 = ft0 < 0 ? 0 : ft0, t1 = ft1 > len - 1 ? len - 1 : ft1;
+                if (g.b0 != t0 / blkSz || g.b1 != t1 / blkSz || g.r0 != (t0 - R2.d - 2 > 0 ? t0 - R2.d - 2 : 0)) return AUGX_E_ARG;
+            }
             std::fill(R2.blkPool.begin(), R2.blkPool.end(), (int64_t)-1);
             size_t total = 0;
             for (int q = g.b0; q <= g.b1; q++) {
@@ -1469,34 +1492,35 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
     const bool timing = getenv("AUGX_TIMING") != nullptr; // (developer aid)
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tFetch = 0, tRun = 0;
-    for (size_t g0 = 0; g0 < todo.size(); g0 += GROUP) {
-        const size_t g1 = g0 + GROUP < todo.size() ? g0 + GROUP : todo.size();
-        std::vector<std::unique_ptr<PieceData>> grp;
-        const double tf0 = timing ? now() : 0.0;
-        for (size_t k = g0; k < g1; k++) {
-            grp.emplace_back(new PieceData());
-            grp.back()->st = copySt[k - g0];
-        }
+    {   // GROUP host threads, each with a copy stream of its own, take the pieces one after the other (round 6: fixed groups of 48
+        // left the last few pieces of a batch of 52 to run alone -- the replay of a 2 Mbp piece is 0.1 s on one thread)
         const double tf1 = timing ? now() : 0.0;
-        tFetch += tf1 - tf0;
-        std::vector<std::future<int>> runs;
-        int rcRun = 0;
-        for (size_t k = g0; k < g1; k++) { // (the piece's tables are fetched by its own thread, too)
-            PieceData *D = grp[k - g0].get();
-            const int p = todo[k];
-            auto job = [&fetch, D, p, d]() { (void)hipSetDevice(d->device); const int r0 = fetch(p, *D); return r0 ? r0 : D->R.run(); };
-            try {
-                runs.push_back(std::async(std::launch::async, job));
-            } catch (const std::system_error &) { // (no more threads to be had: this piece on the calling thread)
-                const int r1 = job();
-                if (r1 && !rcRun) rcRun = r1;
+        std::atomic<size_t> nextPiece{0};
+        std::atomic<int> rcRun{0};
+        std::mutex outMu;
+        auto worker = [&](int w) {
+            (void)hipSetDevice(d->device);
+            for (size_t k; (k = nextPiece.fetch_add(1)) < todo.size();) {
+                std::unique_ptr<PieceData> D(new PieceData());
+                D->st = copySt[w];
+                int r0 = 0;
+                try { r0 = fetch(todo[k], *D); if (!r0) r0 = D->R.run(); } catch (const std::exception &) { r0 = AUGX_E_NOMEM; }
+                if (r0) { int z = 0; rcRun.compare_exchange_strong(z, r0); continue; }
+                std::lock_guard<std::mutex> lk(outMu);
+                for (const MemoPatch &mp : D->R.patches) { pIdx.push_back(mp.item); pTe.push_back(mp.te); }
             }
+        };
+        // (with a matrix to read -- forward algorithm, dense kernels -- a piece whose class steps crowd brings rows x S doubles for most
+        //  of its length: 1.1 GB for 2 Mbp at S = 71; fewer of those side by side)
+        const int nW = (int)std::min<size_t>(fromLists ? GROUP : 12, todo.size());
+        std::vector<std::thread> th;
+        for (int w = 1; w < nW; w++) {
+            try { th.emplace_back(worker, w); } catch (const std::system_error &) { break; } // (no more threads to be had: fewer of them)
         }
-        for (auto &f : runs) { const int r1 = f.get(); if (r1 && !rcRun) rcRun = r1; }
+        if (nW > 0) worker(0);
+        for (auto &t2 : th) t2.join();
         if (timing) tRun += now() - tf1;
-        if (rcRun) { setLastError("augx: fetching the data of a snippet-cache window failed"); return rcRun; }
-        for (auto &D : grp)
-            for (const MemoPatch &mp : D->R.patches) { pIdx.push_back(mp.item); pTe.push_back(mp.te); }
+        if (rcRun.load()) { setLastError("augx: fetching the data of a snippet-cache window failed"); return rcRun.load(); }
     }
     nPatched = (int64_t)pIdx.size();
     if (timing) fprintf(stderr, "augx timing:       replay of %zu pieces: set up in %.3f s, tables fetched and windows replayed (%d pieces side by side) in %.3f s\n", todo.size(), tFetch, GROUP, tRun);

@@ -11,6 +11,12 @@ using namespace augx::dev;
 // The default build (no near-tie flags) is ROLE-SPECIALISED: every wavefront of the workgroup branches once, on its (scalar)
 // index, into the instantiation of trellisPiece that carries its own role's constants only -- 203 instead of 256 VGPRs and no
 // scratch for <8, 0> (profiles/EXPERIMENTS.md, round 4/5).
+// INVARIANT the switch rests on: the workgroup barriers of trellisPiece (BLOCK_SYNC / __syncthreads -> s_barrier) then sit in
+// wave-divergent control flow, outside HIP's barrier contract; on s_barrier hardware it is sound exactly while all eight
+// instantiations execute the SAME NUMBER of barriers -- every barrier of trellisPiece is reached by every wavefront, none stands
+// under a condition that depends on the wavefront's index (role work between two barriers is guarded per role, the barriers are
+// not).  The sequential emulator cannot see a violation; tests/test_gpu_parity.py::test_gpu_role_specialised_equals_common_body
+// compares this build with the common-body (TIES) build cell for cell on the device.
 template <int BLK, int MODE, bool TIES> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
     if constexpr (!TIES) {

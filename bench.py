@@ -471,7 +471,67 @@ def product_leg(cfg, a, n_dev):
             out[key] = r2
         if not a.no_genome_like:
             out["genome_like"] = genome_like_leg(cfg, a, n_dev, d, exe, run)
+        if not a.no_genome_1g:
+            out["genome_1g"] = genome_1g_leg(cfg, a, n_dev, d, exe, run)
     return out
+
+
+def genome_1g_leg(cfg, a, n_dev, d, exe, run):
+    """BASELINE config 5 AT SIZE: the 1.0 Gbp stand-in (tests/golden/make_golden_long.py: genome_1g_records -- the genome_like recipe
+    scaled to six chromosome-scale records, the first of 250 Mbp like GRCh38's chr1) through the executable at --species=human default
+    flags: rate, number of device batches, HBM high-water and host peak RSS; and the 250 Mbp record ALONE with its cut points + GFF
+    compared (sha256) with the reference binary's golden (tests/golden/golden_long.json: genome_1g_chr1)."""
+    import resource
+    import threading
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from helpers import read_fasta
+    from make_golden_long import genome_1g_records
+    if not os.path.exists(os.path.join(d, "genome.fa")):
+        import tarfile
+        with tarfile.open(os.path.join(ROOT, "tests", "golden", "big_inputs.tar.gz")) as t:
+            t.extractall(d)
+    g = read_fasta(os.path.join(d, "genome.fa"))[0][1]
+
+    def write(fa, recs):
+        with open(fa, "wb") as f:
+            for nm, sq in recs:
+                f.write(b">" + nm.encode() + b"\n")
+                arr = np.frombuffer(sq.encode(), dtype=np.uint8)
+                k = len(arr) // 60 * 60
+                f.write(np.concatenate([arr[:k].reshape(-1, 60), np.full((k // 60, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+                if k < len(arr):
+                    f.write(arr[k:].tobytes() + b"\n")
+    recs = genome_1g_records(g)
+    bases, n_bases = sum(len(s) for _, s in recs), sum(s.count("N") for _, s in recs)
+    fa, f1 = os.path.join(d, "genome_1g.fa"), os.path.join(d, "genome_1g_chr1.fa")
+    write(fa, recs)
+    write(f1, recs[:1])
+    n1 = len(recs[0][1])
+    nrec = len(recs)
+    del recs
+    free0 = [torch.cuda.mem_get_info(i)[0] for i in range(n_dev)]
+    low = list(free0)
+    stop = threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            for i in range(n_dev):
+                low[i] = min(low[i], torch.cuda.mem_get_info(i)[0])
+            stop.wait(0.05)
+    th = threading.Thread(target=watch)
+    th.start()
+    try:
+        r = run(["--species=human"], fa, bases, reps=1)
+        r1 = run(["--species=human"], f1, n1, reps=1, golden="genome_1g_chr1")
+    finally:
+        stop.set()
+        th.join()
+    r["workload"] = "%d records, %.2f Gbp (%.1f Mbp of N; the longest record %d Mbp), --species=human default flags, %d device(s)" % (nrec, bases / 1e9, n_bases / 1e6, n1 // 1000000, n_dev)
+    r["hbm_high_water_gb"] = max(f - l for f, l in zip(free0, low)) / 1e9
+    r["host_peak_rss_gb"] = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss / 1e6
+    r["chr1_alone"] = r1
+    return r
 
 
 def genome_like_leg(cfg, a, n_dev, d, exe, run):
@@ -630,6 +690,7 @@ def main():
     ap.add_argument("--long-contig-len", type=int, default=23000000)
     ap.add_argument("--no-long-utr", action="store_true", help="skip the 23 Mbp contig with --UTR=on (BASELINE config 4's shape)")
     ap.add_argument("--no-genome-like", action="store_true", help="skip the ~100 Mbp GRCh38-shaped genome through the executable (BASELINE config 5's shape)")
+    ap.add_argument("--no-genome-1g", action="store_true", help="skip the 1.0 Gbp genome through the executable (BASELINE config 5 at size; ~40 s with building the input)")
     ap.add_argument("--no-utr", action="store_true", help="skip the --UTR=on leg (the 71-state model, BASELINE config 4's trellis)")
     ap.add_argument("--utr-contigs", type=int, default=256)
     ap.add_argument("--utr-contig-len", type=int, default=160000)

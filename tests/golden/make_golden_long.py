@@ -27,6 +27,7 @@ LONG_CFGS = {
     "long_utr": ["--species=fly", "--UTR=on", "--sample=0", "--softmasking=0"],
     # BASELINE config 5 stand-in (genome_like_big_records): --species=human at default flags (soft-masking bonus on, sample 0)
     "genome_like_big": ["--species=human"],
+    "genome_1g_chr1": ["--species=human"],   # (the first record of genome_1g_records alone: 250 Mbp)
 }
 LONG_LEN = 23000000
 
@@ -36,7 +37,7 @@ def long_contig():
     return bench.synth_contigs(1, LONG_LEN, bench.SEED0 + 77)[0].decode()
 
 
-def genome_like_big_records(g, scale=1.0):
+def genome_like_big_records(g, scale=1.0, sizes=(48e6, 30e6, 22e6), seed0=501, names="ABCDEFGHIJ"):
     """BASELINE config 5 in shape (GRCh38 primary contigs: chromosome-scale records with megabase N runs, isochores, soft-masked
     repeats, plus short unplaced scaffolds) built from what the container has: tiles of examples/autoAug/genome.fa (`g`, 1.0 Mbp of
     real soft-masked DNA) in both orientations, synthetic stretches whose GC content steps between 34 % and 62 % every 50-300 kb
@@ -86,12 +87,23 @@ def genome_like_big_records(g, scale=1.0):
             total += len(a)
         return np.concatenate(parts)[:target].tobytes().decode()
 
-    recs = [("chrA", record(501, int(48e6 * scale))), ("chrB", record(502, int(30e6 * scale))), ("chrC", record(503, int(22e6 * scale)))]
-    rng = np.random.default_rng(504)
+    recs = [("chr" + names[i], record(seed0 + i, int(sz * scale))) for i, sz in enumerate(sizes)]
+    rng = np.random.default_rng(seed0 + 3)
     for i, n in enumerate((200000, 120000, 60000, 25000, 10000)):
         lo = int(rng.integers(0, len(ga) - n))
         recs.append(("scaffold%d" % i, (ga if i % 2 == 0 else rc)[lo:lo + n].tobytes().decode()))
     return recs
+
+
+# BASELINE config 5 AT SIZE (round 6): the same recipe scaled to a genome -- 1.0 Gbp in six chromosome-scale records, the first as
+# long as GRCh38's chr1 (250 Mbp = a chain of ~125 cuts at the human model's 2 Mbp pieces), plus the five scaffolds.  Too large to
+# commit: `genome_1g_records` rebuilds it from the committed 1 Mbp of real DNA.  The golden is the reference binary's output for the
+# 250 Mbp record ALONE (`genome_1g_chr1`, ~35 min on one core): cut points + GFF.
+GENOME_1G_SIZES = (250e6, 200e6, 160e6, 140e6, 130e6, 120e6)
+
+
+def genome_1g_records(g, only_first=False):
+    return genome_like_big_records(g, sizes=GENOME_1G_SIZES[:1] if only_first else GENOME_1G_SIZES, seed0=601, names="123456")[:1 if only_first else None]
 
 
 def golden_text(stdout_text, stderr_text):
@@ -109,13 +121,18 @@ def main():
     write_fasta(fg, genome_like_big_records(read_fasta("/root/reference/examples/autoAug/genome.fa")[0][1]))
     env = dict(os.environ, AUGUSTUS_CONFIG_PATH="/root/reference/config")
     only = [a for a in sys.argv[1:] if a in LONG_CFGS]
+    f1 = os.path.join(d, "genome_1g_chr1.fa")
+    if "genome_1g_chr1" in only:  # (only when asked for by name: 250 Mbp, half an hour)
+        write_fasta(f1, genome_1g_records(read_fasta("/root/reference/examples/autoAug/genome.fa")[0][1], only_first=True))
+    elif not only:
+        only = [c for c in LONG_CFGS if c != "genome_1g_chr1"]
     meta_path = os.path.join(HERE, "golden_long.json")
     meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
     procs = {}
     for cfg, flags in LONG_CFGS.items():
         if only and cfg not in only:
             continue
-        procs[cfg] = subprocess.Popen([REF_AUGUSTUS] + flags + ["--progress=true", fg if cfg == "genome_like_big" else fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        procs[cfg] = subprocess.Popen([REF_AUGUSTUS] + flags + ["--progress=true", fg if cfg == "genome_like_big" else f1 if cfg == "genome_1g_chr1" else fa], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     for cfg, p in procs.items():
         out, err = p.communicate()
         assert p.returncode == 0, err[-2000:]

@@ -392,3 +392,31 @@ def test_cli_genome_like_big_matches_reference(big_inputs, tmp_path):
     ours = golden_text(r.stdout, r.stderr)
     gold = gzip.open(os.path.join(GOLDEN, "golden_genome_like_big.gff.gz"), "rt").read()
     assert ours == gold, _first_difference(ours, gold)
+
+
+def test_cli_chromosome_of_250_mbp_matches_reference(big_inputs, tmp_path):
+    """BASELINE config 5 AT SIZE: one record as long as GRCh38's chr1 (250 Mbp: the first record of the 1.0 Gbp stand-in,
+    make_golden_long.py: genome_1g_records -- real soft-masked DNA in both orientations, GC-shifted stretches, N runs of 0.1-5 Mbp)
+    at --species=human default flags: a chain of ~130 cuts at the model's 2 Mbp pieces with exact mode on nearly every piece, several
+    device batches of 127 Mbp (the buffer pool's size classes).  Cut points and GFF equal the reference binary's (35 min on one core)."""
+    import gzip
+    sys.path.insert(0, GOLDEN)
+    from make_golden_long import LONG_CFGS, genome_1g_records, golden_text
+    import numpy as np
+    fa = str(tmp_path / "genome_1g_chr1.fa")
+    (name, seq), = genome_1g_records(read_fasta(big_inputs["genome"])[0][1], only_first=True)
+    assert len(seq) == 250000000
+    with open(fa, "wb") as f:  # (write_fasta's Python loop takes a minute at this size)
+        f.write(b">" + name.encode() + b"\n")
+        arr = np.frombuffer(seq.encode(), dtype=np.uint8)
+        k = len(arr) // 60 * 60
+        f.write(np.concatenate([arr[:k].reshape(-1, 60), np.full((k // 60, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+        if k < len(arr):
+            f.write(arr[k:].tobytes() + b"\n")
+    del seq
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    r = subprocess.run([EXE] + LONG_CFGS["genome_1g_chr1"] + ["--progress=true", fa], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ours = golden_text(r.stdout, r.stderr)
+    gold = gzip.open(os.path.join(GOLDEN, "golden_genome_1g_chr1.gff.gz"), "rt").read()
+    assert ours == gold, _first_difference(ours, gold)

@@ -328,3 +328,31 @@ def test_gpu_near_ties_are_counted_through_the_c_abi(opts, lo, hi):
     for s, r in zip(seqs, res):
         rc, lnv, path, _, _ = twin_decode(m.tables_ptr, s, m.n_states)
         assert r.status == 0 and r.ln_viterbi == lnv and r.states == path
+
+
+@pytest.mark.parametrize("species", ["human", "fly"])
+def test_gpu_role_specialised_equals_common_body(monkeypatch, species):
+    """the default trellis kernel branches every wavefront into the instantiation of trellisPiece made for its role (k_trellis.hip:
+    workgroup barriers in wave-divergent control flow -- sound only while all eight instantiations pass the same number of barriers);
+    the build that counts near ties runs ONE common body.  Both on the device, cell for cell, on what the sequential emulator cannot
+    judge: segments with fix-ups and continuations, runs of N that are jumped over (quiet tiles: three roles without flags between
+    them), pieces with several GC classes."""
+    from test_emu import _segment_cases
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    monkeypatch.setenv("AUGX_SEG_LEN", "100000")
+    m = ax.Model(config_path(), *GOLDEN_CFGS[species][:1], **GOLDEN_CFGS[species][1])
+    ex = dict(golden_inputs())
+    seqs = _segment_cases() + [random_dna(120000, 41) + "N" * 150000 + random_dna(90000, 42) + "N" * 40000 + random_dna(60000, 43)]
+    seqs += [s for _, s in gc_step_records(2, 11, parts=10, lo=15000, hi=40000)] + [ex["multigc_gene"], ex["multigc_rand"]]
+    outs = []
+    for ties in (False, True):
+        d = ax.Decoder(m, 0)
+        d.count_near_ties(ties)   # (batches created from now on run kTrellis<., ., true>: the common body)
+        b = ax.Batch(d, seqs)
+        b.decode()
+        outs.append(([(r.status, r.ln_viterbi, r.states) for r in b.paths()], [b.cells(i) for i in range(len(seqs))]))
+        d.close()
+    assert outs[0][0] == outs[1][0]
+    for i, (a, c) in enumerate(zip(outs[0][1], outs[1][1])):
+        if set(seqs[i].upper()) != {"N"}:
+            assert np.array_equal(a, c), i
