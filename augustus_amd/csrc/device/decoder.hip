@@ -748,6 +748,14 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     // up to 150 B on site-dense sequence), with head room; a model with several GC classes may need the class-dependent
     // arrays (~0.2 KB per base) once more per extra class met inside one piece: room for two extra
     freeB += d->pooledBytes; // (buffers of earlier batches kept by this decoder are free for the next one)
+    {   // several decoders on one device (the bench's resident batches, AUGX_DEVICES=0,0,...: one host thread each, all allocating at
+        // the same time): a decoder plans for its share of the device, not for what happens to be free while the others have not
+        // allocated yet (round 6: eight decoders on one MI355X each planned 128 Mbp and the 1 Gbp run died out of memory)
+        size_t nOn = 0;
+        std::lock_guard<std::mutex> rk(g_regMu);
+        for (augx_decoder *o : g_decoders) nOn += o->device == d->device;
+        if (nOn > 1) freeB = std::min(freeB, (size_t)((double)totalB * 0.9 / (double)nOn));
+    }
     // (dense kernels: the ln V matrix itself, 8 S bytes per base, and once more for the forward matrix when sampling)
     int64_t cap = (int64_t)(freeB / (d->dense ? 1500 + 18 * (size_t)d->model->m.t.S : d->model->m.t.n_classes > 1 ? 2000 : 1500));
     if (cap > 128L * 1000 * 1000) cap = 128L * 1000 * 1000;
@@ -1803,7 +1811,7 @@ int augx_batch_sample_prepare(augx_decoder *d, augx_batch *b, int piece, augx_sa
     struct CopyDrain { hipStream_t s; ~CopyDrain() { if (s) (void)hipStreamSynchronize(s); } } copyDrain{cst};
     {   // (an object that comes round: everything a piece sets only under a condition goes back to its default)
         P.plane.clear(); P.planeCls.clear(); P.uh.reset(); P.dense = false; P.hT = nullptr; P.hB = nullptr; P.hp = 0;
-        P.memo = nullptr; P.memoOwner.reset(); P.vitPath.clear();
+        P.memo = nullptr; P.memoOwner.reset(); P.vitPath.clear(); P.memoVitDiffs = 0;
         P.igS = -1; P.termKind = 0; P.anyNuc = true; P.prepared = false; P.item0 = 0;
         P.buildSeconds = 0; P.nBuilt = P.nStops = P.nVar = 0; P.tkChain = P.tkVar = P.tkTail = 0;
     }
@@ -1987,8 +1995,9 @@ int augx_sample_prep_run(augx_sample_prep *h, int n_samples, augx_rand *R, augx_
     try { samplePaths(h->P, n_samples, *R, paths, status); }
     catch (const std::exception &e) { setLastError(std::string("augx_batch_sample: ") + e.what() + " (out of host memory?)"); return AUGX_E_NOMEM; }
     if (getenv("AUGX_TIMING_SAMPLER")) // (developer aid)
-        fprintf(stderr, "augx timing:     sampler, piece of %d bases: generator %.4f s, %ld option lists built in %.4f s, %ld stops passed, %ld draws at other states; Mticks: chain runs %.1f, other states %.1f, paths put together %.1f\n", h->P.n,
-                R->refillSeconds - gen0, h->P.nBuilt, h->P.buildSeconds, h->P.nStops, h->P.nVar, h->P.tkChain / 1e6, h->P.tkVar / 1e6, h->P.tkTail / 1e6);
+        fprintf(stderr, "augx timing:     sampler, piece of %d bases: generator %.4f s, %ld option lists built in %.4f s, %ld stops passed, %ld draws at other states; Mticks: chain runs %.1f, other states %.1f, paths put together %.1f%s\n", h->P.n,
+                R->refillSeconds - gen0, h->P.nBuilt, h->P.buildSeconds, h->P.nStops, h->P.nVar, h->P.tkChain / 1e6, h->P.tkVar / 1e6, h->P.tkTail / 1e6,
+                h->P.memo ? (std::string("; aSSProb memo carried on: ") + std::to_string(h->P.memo->calls) + " calls so far, emptied " + std::to_string(h->P.memo->flushes) + " times; candidates of the Viterbi path's UTR exon steps valued under another class by the back-tracking: " + std::to_string(h->P.memoVitDiffs)).c_str() : "");
     for (int it = 0; it < n_samples; it++) {
         out[it].status = status[it];
         if (status[it] != AUGX_OK) continue;

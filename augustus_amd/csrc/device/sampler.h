@@ -300,6 +300,8 @@ struct SamplePiece {
     struct AssMemoReplay *memo = nullptr;
     std::shared_ptr<void> memoOwner;
     std::vector<augx_state> vitPath;
+    mutable long memoVitDiffs = 0; // candidates of UTR exon steps of the VITERBI path whose site the back-tracking would value with another class than
+                                   // the sweep did (the device keeps the sweep's arg-max there; AUGX_TIMING_SAMPLER prints the count)
     double lnT(int j, int a, int s) const {
         const int c = plane.empty() ? cls0 : planeCls[plane[j]];
         return t->ln_trans[((int64_t)c * S + a) * S + s];
@@ -434,7 +436,7 @@ inline void memoStep(const SamplePiece &P, int s, int j, OptList *L) {
             now = R.late(site, pl);
             then = xi < 0 ? R.sweepPlane(site, key) : (int)P.plane[(size_t)(P.n - 1)]; // (a site past the end of the piece is valued on the spot: the class of the last base)
         }
-        if (!L) continue;
+        if (!L) { if (site >= 0 && then >= 0 && now != then) P.memoVitDiffs++; continue; }
         double te; int eop2;
         if (!utrCandFrom(X, D, xi, e, te, eop2)) continue;
         if (site >= 0 && then >= 0 && now != then) te = te + (assSiteValue(*P.hT, *P.hB, P.hp, now, q) - assSiteValue(*P.hT, *P.hB, P.hp, then, q));

@@ -565,6 +565,8 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
     if (const char *e = getenv("AUGX_CUT_NEAR")) nearShift = atol(e);
     size_t maxAsk = 256 * (size_t)std::max(1, nDevices); // windows per batch: one wave of workgroups
     if (const char *e = getenv("AUGX_CUT_ASK")) maxAsk = (size_t)atol(e);
+    // (round 6, measured and dropped: the long "retry" windows first in the batch and up to 2 (256 - L) short ones in their shadow --
+    //  15 batches of 380 windows instead of 18 of 256, but 0.45 s instead of 0.30 s per batch: 6.8 against 5.3 s; profiles/EXPERIMENTS.md)
     // windows per batch (a bound on the forecast's breadth; the nearest rounds come first)
     for (;;) {
         std::vector<WinKey> keys;
@@ -900,6 +902,13 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             rc = augx_decoder_create(S.model, dv, &d);
             if (rc) { restore(); return fail(augx_last_error()); }
             S.decs.push_back(d);
+        }
+        // (a device named several times -- AUGX_DEVICES=0,0,...: the eight host threads of a node on one GPU -- is shared by that many
+        //  decoders: each plans its trellis segments for its share of the compute units; the memory share is the decoder's own
+        //  business, augx_decoder_batch_capacity)
+        for (size_t i = 0; i < devs.size(); i++) {
+            const int cnt = (int)std::count(devs.begin(), devs.end(), devs[i]);
+            if (cnt > 1) (void)augx_decoder_set_share(S.decs[i], cnt);
         }
     }
 
