@@ -17,12 +17,7 @@ using namespace augx::dev;
 // under a condition that depends on the wavefront's index (role work between two barriers is guarded per role, the barriers are
 // not).  The sequential emulator cannot see a violation; tests/test_gpu_parity.py::test_gpu_role_specialised_equals_common_body
 // compares this build with the common-body (TIES) build cell for cell on the device.
-#ifdef AUGX_TRELLIS_OCC2 // (measured variant, round 6: a register budget for FOUR wavefronts per SIMD = two workgroups per compute unit; needs the LDS windows cut to <= 80 KB)
-#define AUGX_TRELLIS_BOUNDS __launch_bounds__(NT, 4)
-#else
-#define AUGX_TRELLIS_BOUNDS __launch_bounds__(NT)
-#endif
-template <int BLK, int MODE, bool TIES> __global__ void AUGX_TRELLIS_BOUNDS kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
+template <int BLK, int MODE, bool TIES> __global__ void __launch_bounds__(NT) kTrellis(const DevTables *__restrict__ T, const BatchView *__restrict__ B) {
     __shared__ TrellisLds lds;
     if constexpr (!TIES) {
         const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -8,7 +8,6 @@
 // Lane discipline: a FOR_LANES block is executed by every lane (concurrently on the device, one after the other
 // in the emulator); lanes communicate only through LDS/global memory BETWEEN blocks, separated by WAVE_SYNC().
 #pragma once
-#include <cstddef>
 #include <type_traits>
 #include "dp.h"
 
@@ -2492,12 +2491,8 @@ AUGX_KFN void trellisPiece(const DevTables &T, const BatchView &B, TrellisLds &L
             jumpRetry = tile + 16; // (no jump from here: the probe is not repeated at every tile of the run's tail)
             if (tJ - (tile + 1) >= JUMP_MIN) {
                 const int jE = tJ * WAVE, len = jE - jS, per = (len + NT - 1) / NT;
-                // [NT][8] sums of the stretches: in the staged candidates (not needed: the run re-stages where it lands) -- or, where the build
-                // keeps fewer of them in LDS (AUGX_ITEM_CAP < 1024), in the ring and the back pointers behind it: the column before the jump has
-                // been taken (jcV0), the last tile's pointers are flushed above, and both are set afresh where the run lands
-                static_assert(sizeof(L.items) >= sizeof(double) * NT * 8 ||
-                              (offsetof(TrellisLds, bp) == offsetof(TrellisLds, ring) + sizeof(L.ring) && sizeof(L.ring) + sizeof(L.bp) >= sizeof(double) * NT * 8), "scratch of the jump");
-                double *part = sizeof(L.items) >= sizeof(double) * NT * 8 ? (double *)&L.items[0][0] : (double *)&L.ring[0][0];
+                double *part = (double *)&L.items[0][0]; // [NT][8] sums of the stretches (the staged candidates are not needed: the run re-stages where it lands)
+                static_assert(sizeof(L.items) >= sizeof(double) * NT * 8, "scratch of the jump");
                 // retire the last tile walked (its back pointers, igenic cells, long-lag cells; quiet tiles have no list sites)
                 FOR_THREADS(t) {
                     flushBpThread(X, tile, buf, t, NT);
