@@ -1372,10 +1372,11 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
         std::vector<double> FAll;
         size_t nextWin = 0;
     };
-    constexpr int GROUP = 48; // pieces replayed side by side
+    constexpr int GROUP_MAX = 128;
+    static const int GROUP = [] { const char *e = getenv("AUGX_REPLAY_THREADS"); const int v = e ? atoi(e) : 48; return v < 1 ? 1 : v > GROUP_MAX ? GROUP_MAX : v; }(); // pieces replayed side by side
     {   // (made once per decoder: creating a stream takes milliseconds; augx_batch_sample_prepare shares the table)
         std::lock_guard<std::mutex> lk(g_copyMu);
-        if (d->copyStreams.empty()) d->copyStreams.assign(GROUP, nullptr);
+        if ((int)d->copyStreams.size() < GROUP) d->copyStreams.resize((size_t)GROUP, nullptr);
         for (int i = 0; i < GROUP; i++)
             if (!d->copyStreams[i] && hipStreamCreateWithFlags(&d->copyStreams[i], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); d->copyStreams[i] = nullptr; }
     }

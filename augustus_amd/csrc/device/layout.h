@@ -274,10 +274,18 @@ inline void checkModelSupported(const augx_tables &t, int BLK) {
 }
 
 // models decoded by the dense kernels (dense.h): everything the wavefront layout of the trellis kernel was not built for
+inline int chooseDenseBlock(const augx_tables &t);
 inline bool modelIsDense(const augx_tables &t) {
     int nIg = 0; // (two intergenic states: --genemodel=atleastone / exactlyone)
     for (int s = 0; s < t.S; s++) nIg += t.state_kind[s] == AUGX_K_IGENIC;
-    return t.utr != 0 || nIg > 1;
+    if (t.utr != 0 || nIg > 1) return true;
+    // a 47-state model whose windows the wavefront layout of the trellis kernel was not built for (an equalD state that looks back 57-63
+    // bases; splice-site windows of more than 63 bases; a translation-initiation window shorter than the smallest block) goes to the
+    // state-graph driven dense kernels as well, where they take it (round 6: Vitrella_brassicaformis, maize, Micromonas_pusilla,
+    // Rhopilema_esculentum -- slower there, but the reference's result instead of a refusal)
+    try { checkModelSupported(t, 2); return false; } catch (std::exception &) {}
+    for (int b = 4; b <= 8; b *= 2) { try { checkModelSupported(t, b); return false; } catch (std::exception &) {} }
+    try { (void)chooseDenseBlock(t); return true; } catch (std::exception &) { return false; } // (neither: chooseBlockSize reports the trellis kernel's reason)
 }
 // block size of the dense kernels (dense.h): no variable-length or fixed-lag state may read a cell of its own block but through
 // the stage order of densePiece (fixed-lag states, early chains, candidates, late chains, reverse terminal exons)

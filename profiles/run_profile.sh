@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --stats -d "$OUT" -o t1 -- python "$ROOT/bench.py" --no
 DB=$(find "$OUT" -name '*results.db' | head -1)
 python "$ROOT/profiles/summarize_rocpd.py" "$DB" > "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 echo "# command: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-e2e --no-product --no-utr $*" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+echo "# (the vgpr= field of the dispatch lines is rocprofv3's: HALF the hardware's count on gfx950.  Registers, spills, LDS and scratch of every kernel as the" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
+echo "#  code objects' ELF notes have them: profiles/${TAG%%_*}_kernel_resources.txt = python profiles/kernel_resources.py build/obj)" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 echo "# source_sha: $SRC_SHA" >> "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 cat "$ROOT/gpurun_out/${TAG}_kernel_stats.txt"
 tail -1 "$ROOT/gpurun_out/${TAG}_bench.json" | cut -c1-600

@@ -349,6 +349,8 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
             samplePaths(P, g_nsamples, *g_rand, g_samples[p], sst);
             if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu sampler: piece %d (%d bases): stops %.3f s, %d paths drawn in %.3f s (the generator's buffers so far: %.3f s)\n", p, P.n, std::chrono::duration<double>(ts1 - ts0).count(), g_nsamples,
                                                   std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count(), g_rand->refillSeconds);
+            if (getenv("AUGX_EMU_STATS") && P.memo) fprintf(stderr, "emu sampler: piece %d: aSSProb memo carried on: %lld calls in all, emptied %lld times; candidates of the Viterbi path's UTR exon steps the back-tracking values under another class: %ld\n",
+                                                            p, P.memo->calls, P.memo->flushes, P.memoVitDiffs);
         }
     }
     delete dl;

@@ -40,6 +40,7 @@ def test_line_is_bounded_and_keeps_the_contract_keys():
     assert back["roofline"]["frac"] == 0.0825 and back["roofline"]["traffic_unit"] == "t" * 80
     assert back["value"] == 421.377
     assert back["leg0"]["laps_s"]["batches"] == 200   # numbers survive, prose goes first
+    assert back["metric"] == out["metric"]             # (round 6: the long "metric" string was the first thing the trimming deleted)
 
 
 def test_a_short_line_is_left_alone():

@@ -639,3 +639,20 @@ def test_emulated_near_tie_counter_flags_the_soak_case():
     res = emu_decode(m2.tables_ptr, [seqs[0][8000:16000], ex["HS04636"]], m2.n_states)
     assert [E.emu_near_ties(i) for i in range(2)] == [1, 0]
     assert res[0][2] == [(b, e, s) for b, e, s, t in twin_decode(m2.tables_ptr, seqs[0][8000:16000], m2.n_states)[2]]
+
+
+@pytest.mark.parametrize("species", ["Vitrella_brassicaformis", "maize"])
+def test_emulated_47_state_models_the_trellis_layout_was_not_built_for(species):
+    """a 47-state model whose windows the wavefront layout of the trellis kernel refuses (Vitrella: an equalD state that looks back 63
+    bases; maize: an acceptor window of 64 bases) goes to the state-graph driven dense kernels (layout.h: modelIsDense): every cell,
+    score and path equal to the oracle twin (round 6; against the reference binary: tests/test_gpu_parity.py, tests/sweep_species.py)"""
+    m = ax.Model(config_path(), species, UTR="off", sample="0", softmasking="0")
+    S = m.n_states
+    assert S == 47
+    ex = dict(golden_inputs())
+    seqs = [ex[k].upper() for k in ("HS04636", "withN", "trunc_both", "multigc_levels")] + [random_dna(15000, 91)]
+    res = emu_decode(m.tables_ptr, seqs, S, cells=True)
+    for s, r in zip(seqs, res):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
+        assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
+        assert np.array_equal(r[3], V)

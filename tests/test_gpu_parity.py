@@ -356,3 +356,31 @@ def test_gpu_role_specialised_equals_common_body(monkeypatch, species):
     for i, (a, c) in enumerate(zip(outs[0][1], outs[1][1])):
         if set(seqs[i].upper()) != {"N"}:
             assert np.array_equal(a, c), i
+
+
+@needs_ref
+@pytest.mark.parametrize("species", ["Vitrella_brassicaformis", "maize"])
+def test_cli_47_state_models_on_the_dense_kernels(tmp_path, species):
+    """two species the trellis kernel's wavefront layout refuses (equalD looking back 63 bases; a 64-base acceptor window) run on the
+    dense kernel family instead (layout.h: modelIsDense, round 6): at their own defaults -- sample 100 -- with pieces cut at 30 kb, GFF
+    byte-identical to the reference binary's, run live; cells of the device equal to the twin"""
+    import subprocess
+    byname = dict(golden_inputs())
+    recs = [(n, byname[n]) for n in ("HS04636", "multigc_levels", "softmask_gene", "trunc_both", "rand20k_b")]
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    args = ["--species=" + species, "--UTR=off", "--maxDNAPieceSize=30000", fa]
+    ours = subprocess.run([os.path.join(ROOT, "augustus_amd", "bin", "augustus")] + args, capture_output=True, text=True, env=env)
+    ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
+    assert ours.returncode == 0 and ref.returncode == 0 and ours.stderr == "", ours.stderr
+    assert gff_body(ours.stdout) == gff_body(ref.stdout)
+    m = ax.Model(config_path(), species, UTR="off", sample="0", softmasking="0")
+    d = ax.Decoder(m, 0)
+    seqs = [s.upper() for _, s in recs]
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (s, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
+        assert np.array_equal(b.cells(i), V), i
