@@ -1475,7 +1475,10 @@ int snippetCacheReplay(augx_decoder *d, augx_batch *b, int64_t &nPatched, bool f
                 const int t0 = ft0 < 0 ? 0 : ft0, t1 = ft1 > len - 1 ? len - 1 : ft1;
                 if (g.b0 != t0 / blkSz || g.b1 != t1 / blkSz || g.r0 != (t0 - R2.d - 2 > 0 ? t0 - R2.d - 2 : 0)) return AUGX_E_ARG;
             }
-            std::fill(R2.blkPool.begin(), R2.blkPool.end(), (int64_t)-1);
+            if (DP->nextWin >= 2) { // (only the blocks of the window before hold anything: a 2 Mbp piece has 250 000 blocks, a window 300)
+                const GatherWin &pw = DP->wins[DP->nextWin - 2];
+                for (int q = pw.b0; q <= pw.b1; q++) R2.blkPool[(size_t)q] = -1;
+            }
             size_t total = 0;
             for (int q = g.b0; q <= g.b1; q++) {
                 if (DP->blkCnt[(size_t)q * 2 + 1]) R2.blkPool[(size_t)q] = (int64_t)total;

@@ -68,11 +68,21 @@ struct SnippetReplay {
         return (int64_t)(a[(size_t)(r + 1 - fx0)] - a[(size_t)(l - fx0)]);
     }
 
-    // ---- the cache of one strand: lists[base] sorted by length (SnippetList)
+    // ---- the cache of one strand: lists[base] sorted by length (SnippetList).  The bases a window touches lie in [flatLo, flatLo + size):
+    //      a vector indexed by base (round 6: the std::map it was cost a third of the replay); anything outside goes to the map
     std::map<int, std::vector<MemoEntry>> lists[2];
+    std::vector<std::vector<MemoEntry>> flat[2];
+    int flatLo = 0;
+    std::vector<MemoEntry> *listAt(int st, int base, bool create) {
+        const int64_t k = (int64_t)base - flatLo;
+        if (k >= 0 && k < (int64_t)flat[st].size()) return &flat[st][(size_t)k];
+        if (create) return &lists[st][base];
+        auto f = lists[st].find(base);
+        return f == lists[st].end() ? nullptr : &f->second;
+    }
 
     void add(int st, int base, int len, const std::vector<MemoChunk> &dec) { // SnippetProbs::addProb, src/statemodel.cc:344-370
-        std::vector<MemoEntry> &v = lists[st][base];
+        std::vector<MemoEntry> &v = *listAt(st, base, true);
         size_t pos = 0;
         while (pos < v.size() && v[pos].len < len) pos++;
         if (pos < v.size() && v[pos].len == len) return; // ("tried to add snippet of same length": the reference keeps the old one)
@@ -81,9 +91,9 @@ struct SnippetReplay {
     std::vector<MemoChunk> get(int st, int base, int len, int curPlane) { // SnippetProbs::getSeqProb, src/statemodel.cc:312-342
         std::vector<MemoChunk> dec;
         if (len == 0) return dec;
-        auto f = lists[st].find(base);
-        if (f != lists[st].end() && !f->second.empty()) {
-            std::vector<MemoEntry> &v = f->second;
+        std::vector<MemoEntry> *fv = listAt(st, base, false);
+        if (fv && !fv->empty()) {
+            std::vector<MemoEntry> &v = *fv;
             if (v.back().len < len) {
                 const int l1 = v.back().len;
                 const std::vector<MemoChunk> last = v.back().dec; // (copy: the recursion may add to other lists, not to this one)
@@ -121,6 +131,8 @@ struct SnippetReplay {
     // their own plane get a new term
     void window(int t0, int t1, int from) {
         lists[0].clear(); lists[1].clear();
+        flatLo = t0 - d - 64;
+        for (int st = 0; st < 2; st++) { flat[st].clear(); flat[st].resize((size_t)(t1 - flatLo + 2 > 0 ? t1 - flatLo + 2 : 0)); }
         const int S2 = S;
         std::vector<int> lessF, lessR;
         for (int s = 0; s < S2; s++) {
@@ -129,18 +141,33 @@ struct SnippetReplay {
         }
         struct Req { int eop; Item *item; uint64_t gidx; };
         std::vector<Req> reqs;
+        // the candidates of a block, ordered by their (base, state) pair once per block (round 6: every one of the block's 8 x 6
+        // (base, short-intron state) pairs went through all of the block's ~120 records)
+        std::vector<uint32_t> byPair, pairFirst;
+        int bucketBlock = -1;
+        const int pidBits = dense ? 7 : 6, nPid = blk << pidBits;
         for (int j = (t0 < 1 ? 1 : t0); j <= t1 && j < n; j++) {
             const int pl = plane[j];
             const int b = j / blk;
             Item *bi = blockItems(b);
             const uint32_t cnt = bi ? blkCnt[(size_t)b * 2 + 1] : 0;
+            if (b != bucketBlock) {
+                bucketBlock = b;
+                pairFirst.assign((size_t)nPid + 1, 0);
+                for (uint32_t it = 0; it < cnt; it++) { const uint32_t pid = bi[it].kp >> KEY_BITS; if (pid < (uint32_t)nPid) pairFirst[(size_t)pid + 1]++; }
+                for (int q = 0; q < nPid; q++) pairFirst[(size_t)q + 1] += pairFirst[(size_t)q];
+                byPair.resize(cnt);
+                std::vector<uint32_t> w(pairFirst.begin(), pairFirst.end() - 1);
+                for (uint32_t it = 0; it < cnt; it++) { const uint32_t pid = bi[it].kp >> KEY_BITS; if (pid < (uint32_t)nPid) byPair[w[(size_t)pid]++] = it; }
+            }
             for (int st = 0; st < 2; st++) {
                 const std::vector<int> &states = st == 0 ? lessF : lessR;
                 for (int s : states) {
                     const uint32_t pid = dense ? (uint32_t)(((j % blk) << 7) | s) : (uint32_t)(((j % blk) << 6) | s);
                     const int a = t->anc[s][0];
                     reqs.clear();
-                    for (uint32_t it = 0; it < cnt; it++) {
+                    for (uint32_t bq = pairFirst[(size_t)pid]; bq < pairFirst[(size_t)pid + 1]; bq++) {
+                        const uint32_t it = byPair[bq];
                         const Item &I = bi[it];
                         if ((I.kp >> KEY_BITS) != pid || !(I.te > -INFINITY)) continue;
                         const int eop = (int)(I.kp & KEY_MASK) - KEY_BIAS;

@@ -661,7 +661,9 @@ int emu_decode(const augx_tables *t, const augx_piece *pieces, int n, double *ln
                 const uint64_t *fx = B.fx + (int64_t)pl * B.N * NFX;
                 for (int g = 0; g <= len; g++) { R.fxF[pl][g] = fx[fidx(o + g, FX_INF, NFX)]; R.fxR[pl][g] = fx[fidx(o + g, FX_INR, NFX)]; }
             }
+            const auto tr0 = std::chrono::steady_clock::now();
             R.run();
+            if (getenv("AUGX_EMU_STATS")) fprintf(stderr, "emu stats: piece %d (%d bases): snippet replay %.3f s, %zu terms rebuilt\n", p, len, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count(), R.patches.size());
             nPatched += R.patches.size();
         }
         if (nPatched) runTrellis();
