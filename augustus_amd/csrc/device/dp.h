@@ -131,6 +131,7 @@ typedef const double *TabPtr;
 struct DevTables {
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
     int tis_n, tis_k, ass_n, ass_k, tis_nbins, tis_mem, synch, gc_win, gc_weighing_type;
+    int dssGc;                 // a donor site may read gc as well as gt (/IntronModel/allow_dss_consensus_gc); dss_pat has a second half for them
     int soft;                  // soft-masking: lower-case bases carry lnSoft on igenic and intron states
     double lnSoft;
     int kind[AUGX_MAX_STATES], win[AUGX_MAX_STATES], type[AUGX_MAX_STATES], reachable[AUGX_MAX_STATES];
@@ -326,8 +327,9 @@ struct Piece {
         return b(p + 2) == 0 && ((b(p + 1) == 3 && (b(p) == 3 || b(p) == 1)) || (b(p + 1) == 1 && b(p) == 3));
     }
     // splice-site gates, reference include/statemodel.hh:98-117 (ab initio: consensus dinucleotides only)
-    AUGX_HD bool possDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 2, 3); }
-    AUGX_HD bool possRDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 1); }
+    // (onGenDSS / onGenRDSS, include/geneticcode.hh:47-54: gt -- reverse strand: ac -- or, where the species allows it, gc)
+    AUGX_HD bool possDSS(int pos) const { return pos >= 1 && pos <= n - 2 && (is2(pos, 2, 3) || (t->dssGc && is2(pos, 2, 1))); }
+    AUGX_HD bool possRDSS(int pos) const { return pos >= 1 && pos <= n - 2 && (is2(pos - 1, 0, 1) || (t->dssGc && is2(pos - 1, 2, 1))); }
     AUGX_HD bool possASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 2); }
     AUGX_HD bool possRASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 1, 3); }
     // Markov-chain content of bases l..r from the fixed-point prefix field f
@@ -395,19 +397,23 @@ AUGX_HD double tisBin(const DevTables &t, int c, double lnp) {
 AUGX_HD double dssProb(const Piece &P, int base, bool fwd) {
     const DevTables &t = *P.t;
     int a = 0, bq = 0;
+    bool nonGt;
     if (fwd) {
         int dsspos = base + t.Ds;
         if (!P.possDSS(dsspos)) return AUGX_NINF;
+        nonGt = !P.is2(dsspos, 2, 3);
         a = P.pat(base, t.Ds);
         bq = P.pat(dsspos + 2, t.De);
         if (a < 0 || bq < 0) return AUGX_NINF;
     } else {
         int dsspos = base + t.De;
         if (!P.possRDSS(dsspos + 1)) return AUGX_NINF;
+        nonGt = !P.is2(dsspos, 0, 1);
         for (int i = 0; i < t.Ds; i++) { int cc = P.b(dsspos + 2 + t.Ds - 1 - i); if (cc > 3) return AUGX_NINF; a = (a << 2) | (3 - cc); }
         for (int i = 0; i < t.De; i++) { int cc = P.b(base + t.De - 1 - i); if (cc > 3) return AUGX_NINF; bq = (bq << 2) | (3 - cc); }
     }
-    return t.dss_pat[(a << (2 * t.De)) | bq];
+    // (a gc site: the second half of the table -- pattern probability times non_gt_dss_prob, binned; src/intronmodel.cc:1232-1239)
+    return t.dss_pat[((a << (2 * t.De)) | bq) + ((nonGt && t.dssGc) ? (1 << (2 * (t.Ds + t.De))) : 0)];
 }
 // IntronModel::aSSProb, reference src/intronmodel.cc:1116-1188
 AUGX_HD double assProb(const Piece &P, int base, bool fwd) {

@@ -794,7 +794,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
         if (!listed) { // eop = 0 (column 0): not a splice site; the reference still applies its gate (src/intronmodel.cc:595-600)
             const int bA = P.b(bobi), bB = P.b(bobi + 1);
             bM1 = P.b(bobi - 1); bM2 = P.b(bobi - 2);
-            siteOk = bobi < 0 || (bobi >= 1 && bobi <= n - 2 && (fwd ? (bA == 2 && bB == 3) : (bA == 1 && bB == 3)));
+            siteOk = bobi < 0 || (bobi >= 1 && bobi <= n - 2 && (fwd ? (bA == 2 && (bB == 3 || (T.dssGc && bB == 1))) : (bA == 1 && bB == 3)));
         }
         const uint64_t cFx = e.fx;
         const int eobi = fwd ? j + T.U + T.As + 2 : j + T.De + 2; // end of the biological intron

@@ -361,6 +361,7 @@ inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
     D.tis_n = t.tis_n; D.tis_k = t.tis_k; D.ass_n = t.ass_n; D.ass_k = t.ass_k; D.tis_nbins = t.tis_nbins; D.tis_mem = t.tis_mem;
     D.synch = t.synch_state; D.gc_win = t.gc_win; D.gc_weighing_type = t.gc_weighing_type;
     D.soft = t.softmasking; D.lnSoft = t.ln_soft_bonus;
+    D.dssGc = t.dss_gc;
     D.utr = t.utr; D.tss_upwin = t.tss_upwin; D.tss_start = t.tss_start; D.tss_end = t.tss_end; D.tata_start = t.tata_start; D.tata_end = t.tata_end;
     D.d_tss_tata_min = t.d_tss_tata_min; D.d_tss_tata_max = t.d_tss_tata_max; D.dpc = t.d_polyasig_cleavage; D.boxlen = t.aataaa_boxlen;
     D.tts_spacing = t.tts_spacing; D.uML = t.utr_max_exon_len; D.uM3S = t.utr_max3single; D.uM3T = t.utr_max3term; D.tssup_k = t.tssup_k;
@@ -412,7 +413,7 @@ inline std::vector<TableSpan> tableSpans(const augx_tables &t, DevTables &D) {
     v.push_back({t.tis_bin_bounds, t.tis_nbins > 0 ? C * (t.tis_nbins - 1) : 0, &D.tis_bin_bounds});
     v.push_back({t.tis_bin_ln, t.tis_nbins > 0 ? C * t.tis_nbins : 0, &D.tis_bin_ln});
     v.push_back({t.ass_pat, (int64_t)1 << (2 * (t.As + t.Ae)), &D.ass_pat});
-    v.push_back({t.dss_pat, (int64_t)1 << (2 * (t.Ds + t.De)), &D.dss_pat});
+    v.push_back({t.dss_pat, ((int64_t)1 << (2 * (t.Ds + t.De))) * (t.dss_gc ? 2 : 1), &D.dss_pat});
     v.push_back({t.len_intron, t.d + 1, &D.len_intron});
     v.push_back({t.len_single, t.max_exon_len + 1, &D.len_single});
     v.push_back({t.len_initial, t.max_exon_len + 1, &D.len_initial});

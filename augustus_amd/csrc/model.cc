@@ -409,8 +409,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     // (without an intron model -- genemodel=intronless -- the intergenic model keeps its own content model: reference
     //  IGenicModel::updateToLocalGC, src/igenicmodel.cc:71-79, IntronModel::GCemiprobs == NULL)
     bool tie = opt.getBool("tieIgenicIntron", true) && genemodel != "intronless";
-    if (opt.getBool("/IntronModel/allow_dss_consensus_gc", false))
-        throw UnsupportedError("allow_dss_consensus_gc is not supported on the MI355X path");
+    t.dss_gc = opt.getBool("/IntronModel/allow_dss_consensus_gc", false) ? 1 : 0; // (donor sites gc as well as gt: Constant::dss_gc_allowed, src/types.cc:427)
     t.ln_quarter = std::log(0.25);
     t.ln_n_coding = std::log(probNinCoding);
     t.ln4 = std::log(4.0);
@@ -699,9 +698,16 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
         ass_pat.resize(assSize);
         for (int i = 0; i < assSize; i++)
             ass_pat[i] = lnp(assBins.nbins >= 1 ? assBins.av[assBins.index(assprobs[i])] : assprobs[i]);
-        dss_pat.resize(dssSize);
+        dss_pat.resize(t.dss_gc ? 2 * dssSize : dssSize);
         for (int i = 0; i < dssSize; i++)
             dss_pat[i] = lnp(dssBins.nbins >= 1 ? dssBins.av[dssBins.index(dssprobs[i])] : dssprobs[i]);
+        if (t.dss_gc) { // a gc donor site: the pattern probability times non_gt_dss_prob, THEN the binning (src/intronmodel.cc:1232-1239)
+            const double nonGt = opt.getDouble("/IntronModel/non_gt_dss_prob", 0.001);
+            for (int i = 0; i < dssSize; i++) {
+                const double pr = dssprobs[i] * nonGt;
+                dss_pat[dssSize + i] = lnp(dssBins.nbins >= 1 ? dssBins.av[dssBins.index(pr)] : pr);
+            }
+        }
         t.ass_pat_invalid = std::log(0.001 * std::pow(.25, (int)(t.As + t.Ae)));
         r.need("[LENGTH]");
         r.comment();

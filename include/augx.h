@@ -103,7 +103,7 @@ typedef struct augx_tables {
     const double *tis_bin_ln;       /* [C][tis_nbins]                                                   */
     /* ---- class independent ---- */
     const double *ass_pat;          /* [4^(As+Ae)]  ln of the (binned) ASS pattern probability           */
-    const double *dss_pat;          /* [4^(Ds+De)]  ln of the (binned) DSS pattern probability           */
+    const double *dss_pat;          /* [4^(Ds+De)]  ln of the (binned) DSS pattern probability (dss_gc: twice as long, see there) */
     double ass_pat_invalid;         /* ln(0.001 * 0.25^(As+Ae)), reference src/intronmodel.cc:1179        */
     const double *len_intron;       /* [d+1]                                                            */
     const double *len_single;       /* [max_exon_len+1]  ln(3*P(len)) as used in notEndPartEmiProb       */
@@ -149,6 +149,10 @@ typedef struct augx_tables {
     const double *tail5_single;     /* [utr_max_exon_len+1] tail probabilities (truncated UTR at the piece start) */
     const double *tail3_single;     /* [utr_max3single+1]   */
     double ln2;                     /* ln 2 (negative-length corrections pow(2.0, .), src/utrmodel.cc:1180) */
+    /* /IntronModel/allow_dss_consensus_gc (Constant::dss_gc_allowed, include/geneticcode.hh:47-54): a donor site may read gc as well as
+     * gt; dss_pat then holds a second half, [4^(Ds+De) ..), for the gc sites: ln of the (binned) pattern probability times
+     * non_gt_dss_prob (src/intronmodel.cc:1232-1239) */
+    int dss_gc;
 } augx_tables;
 
 typedef struct augx_model augx_model;     /* host-side immutable model: tables + option values          */

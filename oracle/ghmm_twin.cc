@@ -317,8 +317,9 @@ struct Twin {
     }
 
     // splice-site gates: reference include/statemodel.hh:98-117 (no hints: consensus dinucleotides only)
-    bool possDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 2, 3); }      // gt at pos
-    bool possRDSS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 1); } // ac at pos-1
+    // (onGenDSS / onGenRDSS, include/geneticcode.hh:47-54: with /IntronModel/allow_dss_consensus_gc also gc)
+    bool possDSS(int pos) const { return pos >= 1 && pos <= n - 2 && (is2(pos, 2, 3) || (t.dss_gc && is2(pos, 2, 1))); }      // gt at pos
+    bool possRDSS(int pos) const { return pos >= 1 && pos <= n - 2 && (is2(pos - 1, 0, 1) || (t.dss_gc && is2(pos - 1, 2, 1))); } // ac at pos-1
     bool possASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos - 1, 0, 2); }  // ag at pos-1
     bool possRASS(int pos) const { return pos >= 1 && pos <= n - 2 && is2(pos, 1, 3); }     // ct at pos
 
@@ -356,22 +357,25 @@ struct Twin {
     // IntronModel::dSSProb, reference src/intronmodel.cc:1195-1248.  base = first position of the pattern
     double dssProb(int base, bool fwd) const {
         int pn;
+        bool nonGt; // (:1216,1224: a gc site -- Constant::dss_gc_allowed -- takes the pattern probability times non_gt_dss_prob: the table's second half)
         if (fwd) {
             int dsspos = base + t.Ds;
             if (!possDSS(dsspos)) return NINF;
+            nonGt = !is2(dsspos, 2, 3);
             int a = pat(base, t.Ds), bq = pat(dsspos + 2, t.De);
             if (a < 0 || bq < 0) return NINF;
             pn = (a << (2 * t.De)) | bq;
         } else {
             int dsspos = base + t.De;
             if (!possRDSS(dsspos + 1)) return NINF;
+            nonGt = !is2(dsspos, 0, 1);
             // astr = rc(s[dsspos+2 .. +Ds)) followed by rc(s[base .. +De))
             int a = 0, bq = 0;
             for (int i = 0; i < t.Ds; i++) { int c = b(dsspos + 2 + t.Ds - 1 - i); if (c > 3) return NINF; a = (a << 2) | (3 - c); }
             for (int i = 0; i < t.De; i++) { int c = b(base + t.De - 1 - i); if (c > 3) return NINF; bq = (bq << 2) | (3 - c); }
             pn = (a << (2 * t.De)) | bq;
         }
-        return t.dss_pat[pn];
+        return t.dss_pat[pn + ((nonGt && t.dss_gc) ? (1 << (2 * (t.Ds + t.De))) : 0)];
     }
     // IntronModel::aSSProb, reference src/intronmodel.cc:1116-1188.  base = first position of the motif window (fwd)
     double assProb(int c, int base, bool fwd) const {

@@ -34,7 +34,7 @@ def config_path():
     if _cfg_dir is None:
         tar = os.path.join(GOLDEN, "config_min.tar.gz")
         more = os.path.join(GOLDEN, "config_more.tar.gz")  # two more species (nasonia: 5 GC classes, rice: 4)
-        caeno = os.path.join(GOLDEN, "config_caeno.tar.gz")  # caenorhabditis (the reference's own test_ab_initio_prediction); Vitrella_brassicaformis, maize (47-state models the dense kernels take)
+        caeno = os.path.join(GOLDEN, "config_caeno.tar.gz")  # caenorhabditis (the reference's own test_ab_initio_prediction); Vitrella_brassicaformis, maize (47-state models the dense kernels take), chlamy2011 (gc donor sites)
         d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d_%d_%d" % (os.getuid(), os.path.getsize(tar), os.path.getsize(more), os.path.getsize(caeno)))
         marker = os.path.join(d, "config", "model", "states_shadow.cfg")
         if not os.path.exists(marker):

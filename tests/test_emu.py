@@ -656,3 +656,27 @@ def test_emulated_47_state_models_the_trellis_layout_was_not_built_for(species):
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, S, cells=True)
         assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
         assert np.array_equal(r[3], V)
+
+
+def test_emulated_gc_donor_sites():
+    """/IntronModel/allow_dss_consensus_gc (chlamy2011; reference Constant::dss_gc_allowed, include/geneticcode.hh:47-54): a donor site may
+    read gc as well as gt, scored with the pattern probability times non_gt_dss_prob before the binning (src/intronmodel.cc:1232-1239):
+    emulator == twin, every cell -- and the switch matters (round 6; against the reference binary: tests/test_gpu_parity.py)"""
+    m = ax.Model(config_path(), "chlamy2011", UTR="off", sample="0", softmasking="0")
+    assert m.n_states == 47
+    ex = dict(golden_inputs())
+    seqs = [ex[k].upper() for k in ("HS04636", "withN", "trunc_both", "multigc_levels")] + [random_dna(15000, 92)]
+    res = emu_decode(m.tables_ptr, seqs, m.n_states, cells=True)
+    gc_live = 0
+    De = 4  # (chlamy2011: /Constant/dss_end 4 -- a longdss state that ends at j has its dinucleotide at j - De - 1, j - De)
+    for s, r in zip(seqs, res):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
+        assert np.array_equal(r[3], V)
+        for st in (10, 15, 20):  # longdss0..2 (config/model/states_shadow.cfg)
+            for j in np.nonzero(np.isfinite(V[:, st]))[0]:
+                if j == 0:  # (column 0: the initial probabilities)
+                    continue
+                assert s[j - De - 1:j - De + 1] in ("GT", "GC"), (j, st)
+                gc_live += s[j - De - 1:j - De + 1] == "GC"
+    assert gc_live > 100  # (live donor-site cells on gc: the switch is in effect)

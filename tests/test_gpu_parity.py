@@ -359,11 +359,12 @@ def test_gpu_role_specialised_equals_common_body(monkeypatch, species):
 
 
 @needs_ref
-@pytest.mark.parametrize("species", ["Vitrella_brassicaformis", "maize"])
+@pytest.mark.parametrize("species", ["Vitrella_brassicaformis", "maize", "chlamy2011"])
 def test_cli_47_state_models_on_the_dense_kernels(tmp_path, species):
     """two species the trellis kernel's wavefront layout refuses (equalD looking back 63 bases; a 64-base acceptor window) run on the
     dense kernel family instead (layout.h: modelIsDense, round 6): at their own defaults -- sample 100 -- with pieces cut at 30 kb, GFF
-    byte-identical to the reference binary's, run live; cells of the device equal to the twin"""
+    byte-identical to the reference binary's, run live; cells of the device equal to the twin.  chlamy2011: the trellis kernel with
+    donor sites that may read gc (/IntronModel/allow_dss_consensus_gc, round 6)."""
     import subprocess
     byname = dict(golden_inputs())
     recs = [(n, byname[n]) for n in ("HS04636", "multigc_levels", "softmask_gene", "trunc_both", "rand20k_b")]
