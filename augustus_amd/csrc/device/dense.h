@@ -38,7 +38,7 @@ AUGX_HD void k1UtrTermsCalc(const DevTables &T, const BatchView &B, int64_t g, u
     Piece P;
     P.t = &T; P.n = n; P.c = baseClass(B, p, g); P.o = o; P.code = B.code + o + 1; P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
     P.lcode = lcode; P.lLo = lLo; P.lHi = lHi;
-    const int k = T.k, NP = T.NP, c = P.c;
+    const int k = T.uk, NP = T.uNP, c = P.c;
     const int pn = (q >= 1 && q >= k) ? P.pat(q - k, k + 1) : -1;
     const int rn = (q >= 1 && q < n - k) ? P.rcpat(q, k + 1) : -1;
     const double *t5i = AUGX_GTAB(T.utr5init_emi) + (int64_t)c * NP, *t5 = AUGX_GTAB(T.utr5_emi) + (int64_t)c * NP, *t3 = AUGX_GTAB(T.utr3_emi) + (int64_t)c * NP;
@@ -509,16 +509,16 @@ AUGX_HD double utrLenAt(const DevTables &T, int sel, int len, bool tail3) {
 // base j of the state (src/statemodel.cc:437-449)
 AUGX_HD double utrEmi1(const UCtx &X, int fxf, int cj, int pos) {
     const DevTables &T = X.T;
-    const double *tab = AUGX_GTAB(fxf <= UFX_5IR ? T.utr5init_emi : fxf <= UFX_5R ? T.utr5_emi : T.utr3_emi) + (int64_t)cj * T.NP;
+    const double *tab = AUGX_GTAB(fxf <= UFX_5IR ? T.utr5init_emi : fxf <= UFX_5R ? T.utr5_emi : T.utr3_emi) + (int64_t)cj * T.uNP;
     const bool fwd = (fxf & 1) == 0;
     const uint8_t *code = X.B.code + X.o + 1;
     auto bb = [&](int q) -> int { return (q >= 0 && q < X.n) ? code[q] : 4; };
     int r = 0;
     if (fwd) {
-        if (pos < T.k) return T.ln_quarter;
-        for (int i = 0; i <= T.k; i++) { const int c = bb(pos - T.k + i); if (c > 3) return T.ln_quarter; r = (r << 2) | c; }
+        if (pos < T.uk) return T.ln_quarter;
+        for (int i = 0; i <= T.uk; i++) { const int c = bb(pos - T.uk + i); if (c > 3) return T.ln_quarter; r = (r << 2) | c; }
     } else
-        for (int i = 0; i <= T.k; i++) { const int c = bb(pos + i); if (c > 3) return T.ln_quarter; r |= (3 - c) << (2 * i); }
+        for (int i = 0; i <= T.uk; i++) { const int c = bb(pos + i); if (c > 3) return T.ln_quarter; r |= (3 - c) << (2 * i); }
     return tab[r];
 }
 // candidate idx (0 = the largest predecessor end) of the state described by D: te = ln emission of the state from eop + 1 to j
@@ -883,7 +883,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             const int na = s2 >= 0 ? T.n_anc[s2] : 0;
             (*lp(&L.chNa[t])) = na;
             (*lp(&L.chEarly[t])) = t < nEarly;
-            (*lp(&L.chSgi[t])) = (s2 >= 0 && T.kind[s2] == AUGX_K_IGENIC) ? SIG_EIG : SIG_EIN;
+            (*lp(&L.chSgi[t])) = (s2 >= 0 && T.kind[s2] == AUGX_K_IGENIC) ? SIG_EIG : (s2 >= 0 && T.uk != T.k && isUtrIntronKind(T.kind[s2])) ? SIG_EUIN : SIG_EIN;
             int nd = 0, nLive = 0, selfAi = -1;
             bool onlySelf = true;
             for (int ai = 0; ai < AUGX_MAX_ANC; ai++) {
@@ -898,7 +898,7 @@ AUGX_KFN void densePiece(const DevTables &T, const BatchView &B, DenseLds &L, in
             for (int k2 = nd; k2 < AUGX_MAX_ANC; k2++) { (*lp(&L.chDead[t][k2])) = 0; (*lp(&L.chDeadAi[t][k2])) = 0; }
             (*lp(&L.chNd[t])) = nd;
             TX(cS2) = s2; TX(cSelf) = selfAi; TX(cFast) = s2 >= 0 && onlySelf && nLive <= 1;
-            TX(cSgi) = (s2 >= 0 && T.kind[s2] == AUGX_K_IGENIC) ? SIG_EIG : SIG_EIN;
+            TX(cSgi) = (s2 >= 0 && T.kind[s2] == AUGX_K_IGENIC) ? SIG_EIG : (s2 >= 0 && T.uk != T.k && isUtrIntronKind(T.kind[s2])) ? SIG_EUIN : SIG_EIN;
         }
     }
     constexpr int NTW = NT - WAVE;

@@ -42,7 +42,7 @@ constexpr int USIG_TSSF = 0, USIG_TSSR = 1, USIG_TTSP = 2, USIG_TTSM = 3;
 constexpr int NFX = 20;         // fixed-point prefix fields per slot: [strand 2][phase 3][table 3], inF, inR
 constexpr int FX_INF = 18, FX_INR = 19;
 constexpr int NSIG = 10;        // per-position signal record: eIg eIn dssF dssR assF assR tisF tisR eqD stopF
-constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4, SIG_ASSR = 5, SIG_TISF = 6, SIG_TISR = 7, SIG_EQD = 8, SIG_STOPF = 9;
+constexpr int SIG_EIG = 0, SIG_EIN = 1, SIG_DSSF = 2, SIG_DSSR = 3, SIG_ASSF = 4, SIG_ASSR = 5, SIG_TISF = 6, SIG_EUIN = 6 /* (SIG_TISF is not in use) */, SIG_TISR = 7, SIG_EQD = 8, SIG_STOPF = 9;
 constexpr int CHUNK = 1024;     // slots per scan chunk; every piece is padded to a multiple of CHUNK
 constexpr int LONG_RING = 1024; // ring depth for the states consumed at lag dStateLen (must exceed it)
 constexpr uint16_t BP_NONE = 0xFFFF;
@@ -142,6 +142,7 @@ struct DevTables {
     double gc_zus[AUGX_MAX_CLASSES][4], gc_weight_matrix[16];
     // untranslated regions (include/augx.h: the utr block of augx_tables)
     int utr, tss_upwin, tss_start, tss_end, tata_start, tata_end, d_tss_tata_min, d_tss_tata_max, dpc, boxlen, tts_spacing;
+    int uk, uNP;               // order and table length of the UTR exon content tables (augx_tables::utr_k)
     int uML, uM3S, uM3T, tssup_k, tss_n, tss_k, tsstata_n, tsstata_k, tata_n, tata_k, tts_n, tts_k;
     double ln_tts_rand, ln2;
     TabPtr utr5init_emi, utr5_emi, utr3_emi, tssup_emi, tss_motif, tsstata_motif, tata_motif, tts_motif, aataaa,
@@ -481,6 +482,13 @@ AUGX_HD double eIg(const Piece &P, int p) {
 AUGX_HD double eIn(const Piece &P, int p) {
     const DevTables &t = *P.t;
     int pn = p >= t.k ? P.pat(p - t.k, t.k + 1) : -1;
+    return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NP + pn] : t.ln_quarter;
+}
+// a base of a utr5intron / utr3intron state where the UTR order uk is below k: the intron pattern read from p - uk on, k + 1 bases
+// -- it ends k - uk bases AFTER p; past the piece: 1/4 (reference src/utrmodel.cc:1255-1262: s2i_intron(sequence + pos - k) with UtrModel::k)
+AUGX_HD double eUin(const Piece &P, int p) {
+    const DevTables &t = *P.t;
+    int pn = (p >= t.uk && p - t.uk + t.k < P.n) ? P.pat(p - t.uk, t.k + 1) : -1;
     return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NP + pn] : t.ln_quarter;
 }
 

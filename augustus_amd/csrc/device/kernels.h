@@ -326,6 +326,7 @@ AUGX_HD void k1Signals(const DevTables &T, const BatchView &B, int64_t g, const 
     const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0; // (src/igenicmodel.cc:306-326)
     e[SIG_EIG] = q >= 1 ? eIg(P, q) + softB : AUGX_NINF;
     e[SIG_EIN] = eIn(P, q) + softB;
+    if (T.utr && T.uk != T.k) e[SIG_EUIN] = eUin(P, q) + softB; // (dense.h: the UTR intron chain states read this one)
     // fixed-length intron states ending at q: gate && emission (reference src/intronmodel.cc:690-717,861-923)
     // (the splice-site records SIG_DSSF/DSSR/ASSF/ASSR are filled by k1SiteSignals, one thread per site instead of one
     //  per base: their motif loops would otherwise run with one lane in sixteen active.  SIG_TISF is not used: the

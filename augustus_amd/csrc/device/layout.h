@@ -365,6 +365,7 @@ inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
     D.utr = t.utr; D.tss_upwin = t.tss_upwin; D.tss_start = t.tss_start; D.tss_end = t.tss_end; D.tata_start = t.tata_start; D.tata_end = t.tata_end;
     D.d_tss_tata_min = t.d_tss_tata_min; D.d_tss_tata_max = t.d_tss_tata_max; D.dpc = t.d_polyasig_cleavage; D.boxlen = t.aataaa_boxlen;
     D.tts_spacing = t.tts_spacing; D.uML = t.utr_max_exon_len; D.uM3S = t.utr_max3single; D.uM3T = t.utr_max3term; D.tssup_k = t.tssup_k;
+    D.uk = t.utr ? t.utr_k : t.k; D.uNP = 1 << (2 * (D.uk + 1));
     D.tss_n = t.tss_n; D.tss_k = t.tss_k; D.tsstata_n = t.tsstata_n; D.tsstata_k = t.tsstata_k; D.tata_n = t.tata_n; D.tata_k = t.tata_k;
     D.tts_n = t.tts_n; D.tts_k = t.tts_k; D.ln_tts_rand = t.ln_tts_rand; D.ln2 = t.ln2;
     D.dense = modelIsDense(t);
@@ -420,7 +421,8 @@ inline std::vector<TableSpan> tableSpans(const augx_tables &t, DevTables &D) {
     v.push_back({t.len_internal, t.max_exon_len + 1, &D.len_internal});
     v.push_back({t.len_terminal, t.max_exon_len + 1, &D.len_terminal});
     if (t.utr) {
-        v.push_back({t.utr5init_emi, C * NP, &D.utr5init_emi}); v.push_back({t.utr5_emi, C * NP, &D.utr5_emi}); v.push_back({t.utr3_emi, C * NP, &D.utr3_emi});
+        const int64_t uNP = (int64_t)1 << (2 * (t.utr_k + 1));
+        v.push_back({t.utr5init_emi, C * uNP, &D.utr5init_emi}); v.push_back({t.utr5_emi, C * uNP, &D.utr5_emi}); v.push_back({t.utr3_emi, C * uNP, &D.utr3_emi});
         v.push_back({t.tssup_emi, C * ((int64_t)1 << (2 * (t.tssup_k + 1))), &D.tssup_emi});
         v.push_back({t.tss_motif, C * t.tss_n * ((int64_t)1 << (2 * (t.tss_k + 1))), &D.tss_motif});
         v.push_back({t.tsstata_motif, C * t.tsstata_n * ((int64_t)1 << (2 * (t.tsstata_k + 1))), &D.tsstata_motif});

@@ -311,6 +311,10 @@ struct Opt { int state, base; double lp; };
 struct OptList { std::vector<Opt> o; std::vector<double> p; double cum = 0; };
 
 inline void sortOptions(OptList &L);
+// the signal field a chain state's one-base emission is read from (dense.h: chSgi)
+inline int chainSig(const augx_tables &t, int kind) {
+    return kind == AUGX_K_IGENIC ? SIG_EIG : (t.utr && t.utr_k != t.k && isUtrIntronKind(kind)) ? SIG_EUIN : SIG_EIN;
+}
 
 // the options of reaching (state s, base j), in the reference's order of listing, then sorted by probability (stable)
 inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
@@ -324,7 +328,7 @@ inline void buildOptions(const SamplePiece &P, int s, int j, OptList &L) {
                        kind == AUGX_K_EQUALD || kind == AUGX_K_REQUALD;
     if (chain || fixed) {
         const int lag = chain ? 1 : (kind == AUGX_K_LONGDSS || kind == AUGX_K_RLONGDSS) ? dssWhole : (kind == AUGX_K_LONGASS || kind == AUGX_K_RLONGASS) ? assLag : dL;
-        const int sg = kind == AUGX_K_IGENIC ? SIG_EIG : chain ? SIG_EIN : kind == AUGX_K_LONGDSS ? SIG_DSSF : kind == AUGX_K_RLONGDSS ? SIG_DSSR
+        const int sg = kind == AUGX_K_IGENIC ? SIG_EIG : chain ? chainSig(t, kind) : kind == AUGX_K_LONGDSS ? SIG_DSSF : kind == AUGX_K_RLONGDSS ? SIG_DSSR
                        : kind == AUGX_K_LONGASS ? SIG_ASSF : kind == AUGX_K_RLONGASS ? SIG_ASSR : SIG_EQD;
         const double emi = P.sig[(size_t)j * NSIG + sg];
         const int eop = j - lag;
@@ -506,7 +510,7 @@ inline void prepareStops(SamplePiece &P) {
         if (isChainKind(t.state_kind[s])) chains.push_back(s);
     for (int j = 1; j < n; j++) // (one pass over the rows of F for all chain states: the matrix is 376 B a base, the pass is bound by reading it)
         for (int s : chains) {
-            const int sg = t.state_kind[s] == AUGX_K_IGENIC ? SIG_EIG : SIG_EIN;
+            const int sg = chainSig(t, t.state_kind[s]);
             int cnt = 0;
             bool self = false;
             if (P.sig[(size_t)j * NSIG + sg] > -INFINITY)

@@ -419,6 +419,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     int kEx = opt.getInt("/ExonModel/k", 4), kIn = opt.getInt("/IntronModel/k", 4), kIg = opt.getInt("/IGenicModel/k", 4);
     if (kEx != kIn || kEx != kIg) throw UnsupportedError("exon/intron/igenic Markov orders differ; not supported");
     t.k = kEx;
+    t.utr_k = kEx; // (loadUtr: the order the UTR parameter file states)
     const int k = t.k, NP = ipow4(k + 1), C = t.n_classes;
     if (t.d < 2 + t.De + t.U + t.As + 2)
         throw ConfigError("Inconsistent intron length parameters. Please increase /IntronModel/d or decrease /IntronModel/ass_motif_memory.");
@@ -869,8 +870,9 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
 // ---- UTR parameters (reference UtrModel::init src/utrmodel.cc:149-264, readAllParameters :540-696,
 //      fillTailsOfLengthDistributions :293-361).  inEmi: the intron emission probabilities (linear), [C][NP]
 void Model::loadUtr(const std::string &full, const std::vector<double> &inEmi) {
-    const int k = t.k, NP = ipow4(k + 1), C = t.n_classes;
-    if (opt.getInt("/UtrModel/k", 4) != k) throw UnsupportedError("UTR Markov order differs from the exon/intron order; not supported");
+    // (the order of the UTR content tables is the one the parameter FILE states: UtrModel::k is overwritten while reading, :620)
+    const int NPin = ipow4(t.k + 1), C = t.n_classes;
+    int k = opt.getInt("/UtrModel/k", 4), NP = ipow4(k + 1);
     t.tss_upwin = opt.getInt("/Constant/tss_upwindow_size", 0);
     t.tss_start = opt.getInt("/UtrModel/tss_start", 4);
     t.tss_end = opt.getInt("/UtrModel/tss_end", 4);
@@ -949,9 +951,7 @@ void Model::loadUtr(const std::string &full, const std::vector<double> &inEmi) {
         aataaa[pn] = lnp(p * probPolya);
     }
     t.ln_tts_rand = lnp((1.0 - probPolya) * (1.0 / ipow4(t.aataaa_boxlen)));
-    utr5init_emi.assign((size_t)C * NP, NEG_INF);
-    utr5_emi.assign((size_t)C * NP, NEG_INF);
-    utr3_emi.assign((size_t)C * NP, NEG_INF);
+    bool sized = false;
     for (int c = 0; c < C; c++) {
         char tag[16];
         snprintf(tag, sizeof tag, "[%d]", c + 1);
@@ -961,6 +961,11 @@ void Model::loadUtr(const std::string &full, const std::vector<double> &inEmi) {
             r.comment(); const int size = r.readInt();
             r.comment(); const int kk = r.readInt();
             r.comment(); (void)r.readDouble();
+            if (!sized) { // (the first section of the first class sets the order)
+                k = kk; NP = ipow4(k + 1); sized = true;
+                if (k < 0 || k > t.k) throw UnsupportedError("UTR Markov order above the exon/intron order; not supported");
+                utr5init_emi.assign((size_t)C * NP, NEG_INF); utr5_emi.assign((size_t)C * NP, NEG_INF); utr3_emi.assign((size_t)C * NP, NEG_INF);
+            }
             if (kk != k || size != NP) throw ConfigError("UtrModel: emission order mismatch");
             lin.assign(NP, 0.0);
             for (int i = 0; i < size; i++) {
@@ -996,14 +1001,16 @@ void Model::loadUtr(const std::string &full, const std::vector<double> &inEmi) {
         readM("[TSSMOTIFTATA]", tsstata_motif, t.tsstata_n, t.tsstata_k);
         readM("[TATAMOTIF]", tata_motif, t.tata_n, t.tata_k);
         readM("[TTSMOTIF]", tts_motif, t.tts_n, t.tts_k);
-        // "change the content models so they are much closer to the intronmodel" (src/utrmodel.cc:681-688)
+        // "change the content models so they are much closer to the intronmodel" (src/utrmodel.cc:681-688).  Entry i meets entry i:
+        // with an order below the intron model's that is the intron pattern 'a..a' + pattern i -- as the reference does it
         for (int i = 0; i < NP; i++) {
-            const double in = inEmi[(size_t)c * NP + i];
+            const double in = inEmi[(size_t)c * NPin + i];
             utr5init_emi[(size_t)c * NP + i] = lnp(e5i[i] * w5 + in * (1.0 - w5));
             utr5_emi[(size_t)c * NP + i] = lnp(e5[i] * w5 + in * (1.0 - w5));
             utr3_emi[(size_t)c * NP + i] = lnp(e3[i] * w3 + in * (1.0 - w3));
         }
     }
+    t.utr_k = k;
 }
 
 // Exact arithmetic (include/augx.h: AUGX_Q_BITS): every ln term of the model is rounded ONCE, here, to a multiple of

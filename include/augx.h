@@ -153,6 +153,13 @@ typedef struct augx_tables {
      * gt; dss_pat then holds a second half, [4^(Ds+De) ..), for the gc sites: ln of the (binned) pattern probability times
      * non_gt_dss_prob (src/intronmodel.cc:1232-1239) */
     int dss_gc;
+    /* Markov order of the three UTR exon content tables (UtrModel::k: the `k` lines of [EMISSION-5INITIAL] / [EMISSION-5] /
+     * [EMISSION-3] in the species' utr_probs file, src/utrmodel.cc:617-655): utr5init_emi / utr5_emi / utr3_emi are
+     * [C][4^(utr_k+1)].  Where it differs from k (chlamydomonas, chlamy2011, culex: 3 against 4) the reference (a) mixes entry i of
+     * the UTR table with entry i of the INTRON table of order k (:681-688) and (b) scores a base of a utr5intron / utr3intron
+     * state with the intron pattern that begins utr_k bases before it, i.e. ends k - utr_k bases after it (:1255-1262,1389-1396);
+     * both are reproduced */
+    int utr_k;
 } augx_tables;
 
 typedef struct augx_model augx_model;     /* host-side immutable model: tables + option values          */

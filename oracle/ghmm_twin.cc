@@ -768,7 +768,9 @@ struct Twin {
     std::vector<double> tssC[2];                    // tssProbsPlus / tssProbsMinus: cached values ...
     std::vector<uint8_t> tssSet[2];                 // ... and whether there is one
     int curCls = 0, prevCls = -1;                   // class of the column being filled
+    // (the UTR content tables have the order the species' UTR file states, UtrModel::k -- 3 against 4 for chlamydomonas, culex)
     double utrEmi1(const double *tab, int c, int p, bool fwd) const { // SegProbs::getSeqProb, from == to (:437-449): the CURRENT class
+        const int k = t.utr_k, NP = 1 << (2 * (k + 1));
         if (fwd) {
             if (p < k) return t.ln_quarter;
             int pn = pat(p - k, k + 1);
@@ -777,7 +779,15 @@ struct Twin {
         int rn = rcpat(p, k + 1); // (reads up to the terminating NUL: invalid)
         return rn >= 0 ? tab[(size_t)c * NP + rn] : t.ln_quarter;
     }
+    // a base of utr5intron / utr3intron (src/utrmodel.cc:1255-1262,1389-1396): s2i_intron -- IntronModel::k + 1 bases -- read from
+    // pos - UtrModel::k on; with a UTR order below the intron order the pattern ends after pos; past the piece: the NUL, invalid
+    double eUin(int c, int p) const {
+        const int uk = t.utr_k;
+        int pn = (p >= uk && p - uk + k < n) ? pat(p - uk, k + 1) : -1;
+        return pn >= 0 ? t.in_emi[(size_t)c * NP + pn] : t.ln_quarter;
+    }
     void buildUtr() {
+        const int k = t.utr_k, NP = 1 << (2 * (k + 1));
         auto build = [&](std::vector<uint64_t> &P, const double *tab, bool fwd) {
             P.assign(n + 2, 0);
             for (int i = 0; i <= n; i++) {
@@ -920,7 +930,7 @@ struct Twin {
         if (kind == AUGX_K_UTR5INTRONVAR || kind == AUGX_K_UTR3INTRONVAR || kind == AUGX_K_RUTR5INTRONVAR || kind == AUGX_K_RUTR3INTRONVAR)
             return; // only introns that match a hint (:985-1041)
         if (kind == AUGX_K_UTR5INTRON || kind == AUGX_K_UTR3INTRON || kind == AUGX_K_RUTR5INTRON || kind == AUGX_K_RUTR3INTRON) {
-            const double emi = eIn(c, j) + softB(j); // (:1260-1271,1395-1406: the intron model's emission, strand does not matter)
+            const double emi = eUin(c, j) + softB(j); // (:1260-1271,1395-1406: the intron model's emission, strand does not matter)
             for (int ai = 0; ai < t.n_anc[s]; ai++) {
                 int a = t.anc[s][ai];
                 double pv = Vat(j - 1, a);

@@ -680,3 +680,18 @@ def test_emulated_gc_donor_sites():
                 assert s[j - De - 1:j - De + 1] in ("GT", "GC"), (j, st)
                 gc_live += s[j - De - 1:j - De + 1] == "GC"
     assert gc_live > 100  # (live donor-site cells on gc: the switch is in effect)
+
+
+def test_emulated_utr_content_order_below_the_intron_order():
+    """chlamy2011 with its own --UTR=on: UTR content tables of order 3 beside exon / intron content of order 4 (augx_tables::utr_k; the
+    reference's index-for-index mixing with the intron table and the shifted intron pattern of the UTR intron states,
+    src/utrmodel.cc:681-688,1255-1262): emulator == twin, every cell; the twin against the live reference: tests/test_oracle.py"""
+    m = ax.Model(config_path(), "chlamy2011", sample="0", softmasking="0")
+    assert m.n_states == 71
+    ex = dict(golden_inputs())
+    seqs = [ex[k].upper() for k in ("HS04636", "withN", "trunc_both")] + [random_dna(12000, 93)]
+    res = emu_decode(m.tables_ptr, seqs, m.n_states, cells=True)
+    for s, r in zip(seqs, res):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
+        assert np.array_equal(r[3], V)

@@ -360,7 +360,7 @@ def test_gpu_role_specialised_equals_common_body(monkeypatch, species):
 
 @needs_ref
 @pytest.mark.parametrize("species", ["Vitrella_brassicaformis", "maize", "chlamy2011"])
-def test_cli_47_state_models_on_the_dense_kernels(tmp_path, species):
+def test_cli_47_state_models_on_the_dense_kernels(tmp_path, monkeypatch, species):
     """two species the trellis kernel's wavefront layout refuses (equalD looking back 63 bases; a 64-base acceptor window) run on the
     dense kernel family instead (layout.h: modelIsDense, round 6): at their own defaults -- sample 100 -- with pieces cut at 30 kb, GFF
     byte-identical to the reference binary's, run live; cells of the device equal to the twin.  chlamy2011: the trellis kernel with
@@ -376,6 +376,7 @@ def test_cli_47_state_models_on_the_dense_kernels(tmp_path, species):
     ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
     assert ours.returncode == 0 and ref.returncode == 0 and ours.stderr == "", ours.stderr
     assert gff_body(ours.stdout) == gff_body(ref.stdout)
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")  # (chlamy2011: the trellis kernel keeps its cells only on request)
     m = ax.Model(config_path(), species, UTR="off", sample="0", softmasking="0")
     d = ax.Decoder(m, 0)
     seqs = [s.upper() for _, s in recs]

@@ -191,3 +191,33 @@ def test_cli_soak_seeds_with_utr_states_gc_steps_and_sampling(tmp_path, monkeypa
     ref = subprocess.run([REF_AUGUSTUS] + args + [fa], capture_output=True, text=True, env=env)
     assert ref.returncode == 0
     assert gff_body(_run_cli(args, fa)) == gff_body(ref.stdout)
+
+
+@needs_ref
+def test_cli_utr_content_order_below_the_intron_order(tmp_path):
+    """chlamy2011 at its OWN defaults (UTR on, sample 100): its UTR content tables have order 3 where exon / intron / intergenic content
+    has order 4 (the `k` lines of the species' utr_probs file: UtrModel::k; also chlamydomonas, culex).  The reference then mixes entry i
+    of the UTR table with entry i of the order-4 INTRON table (src/utrmodel.cc:681-688) and scores a base of a utr5intron / utr3intron
+    state with the intron pattern that begins 3 -- not 4 -- bases before it (:1255-1262,1389-1396): both restated (augx_tables::utr_k,
+    round 6).  GFF byte-identical to the reference binary's, run live; every cell of the device equal to the twin."""
+    import subprocess
+    byname = dict(golden_inputs())
+    recs = [(n, byname[n]) for n in ("HS04636", "rand20k_b", "trunc_both", "revcomp", "multigc_levels", "softmask_gene")]
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    for args in (["--species=chlamy2011"], ["--species=chlamy2011", "--softmasking=0", "--maxDNAPieceSize=30000", "--sample=0"]):
+        ref = subprocess.run([REF_AUGUSTUS] + args + [fa], capture_output=True, text=True, env=env)
+        assert ref.returncode == 0
+        assert gff_body(_run_cli(args, fa)) == gff_body(ref.stdout)
+        assert "five_prime_utr" not in ref.stdout and "\t5'-UTR\t" in ref.stdout  # (UTR is this species' default: there are some to compare)
+    m = ax.Model(config_path(), "chlamy2011", sample="0", softmasking="0")
+    assert m.n_states == 71
+    d = ax.Decoder(m, 0)
+    seqs = [s.upper() for _, s in recs] + [random_dna(30000, 5)]
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (s, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
+        assert np.array_equal(b.cells(i), V), i
