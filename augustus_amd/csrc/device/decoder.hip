@@ -204,17 +204,33 @@ __global__ void __launch_bounds__(256) kSiteConsts(const DevTables *__restrict__
 constexpr int SCAN_T = 256, SCAN_W = SCAN_T / 64;
 static_assert(CHUNK % SCAN_T == 0, "scan blocks do not straddle pieces");
 template <int NF> struct ScanLds { uint64_t w[NF][SCAN_W]; };
+// inclusive scan over the 64 lanes of a wavefront in the data-parallel-primitive form of the VALU moves (no trip through the LDS
+// crossbar as __shfl_up makes: the scans issued 240 ds_bpermute per wavefront and stalled on them 45 % of their time,
+// profiles/r06_sq.txt): row_shr:1/2/4/8 inside the rows of 16 lanes, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2
+// and 3 (gfx9 DPP controls 0x111.., 0x142, 0x143).  A lane without a source reads 0: the identity of the sums and of the maxima
+// of unsigned values
+template <int CTRL, int ROW_MASK> __device__ inline uint64_t dppFrom(uint64_t x) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)x, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(x >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <bool SUM> __device__ inline uint64_t waveScanIncl(uint64_t x) {
+    auto op = [](uint64_t a, uint64_t b) -> uint64_t { return SUM ? a + b : (a > b ? a : b); };
+    x = op(x, dppFrom<0x111, 0xf>(x));
+    x = op(x, dppFrom<0x112, 0xf>(x));
+    x = op(x, dppFrom<0x114, 0xf>(x));
+    x = op(x, dppFrom<0x118, 0xf>(x));
+    x = op(x, dppFrom<0x142, 0xa>(x));
+    x = op(x, dppFrom<0x143, 0xc>(x));
+    return x;
+}
 // the first nSum fields are summed, the rest take the maximum
 template <int NF> __device__ inline void blockTotals(const uint64_t (&v)[NF], int nSum, ScanLds<NF> &L, uint64_t *tot /* [NF] of this block */) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        uint64_t x = v[f];
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint64_t y = (uint64_t)__shfl_xor((unsigned long long)x, o, 64);
-            x = f < nSum ? x + y : (x > y ? x : y);
-        }
-        if (lane == 0) L.w[f][wave] = x;
+        const uint64_t x = f < nSum ? waveScanIncl<true>(v[f]) : waveScanIncl<false>(v[f]);
+        if (lane == 63) L.w[f][wave] = x;
     }
     __syncthreads();
     if (t < NF) {
@@ -228,11 +244,7 @@ template <int NF> __device__ inline void blockScan(uint64_t (&v)[NF], int nSum, 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 #pragma unroll
     for (int f = 0; f < NF; f++) {
-        uint64_t x = v[f];
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint64_t y = (uint64_t)__shfl_up((unsigned long long)x, o, 64);
-            if (lane >= o) x = f < nSum ? x + y : (x > y ? x : y);
-        }
+        const uint64_t x = f < nSum ? waveScanIncl<true>(v[f]) : waveScanIncl<false>(v[f]);
         v[f] = x;
         if (lane == 63) L.w[f][wave] = x;
     }
