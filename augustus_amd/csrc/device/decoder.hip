@@ -775,6 +775,15 @@ int64_t augx_decoder_batch_capacity(augx_decoder *d) {
     return cap;
 }
 
+// with the forward matrix of posterior sampling on top (8 S bytes per base): round 6 -- until then augx_decode_sampled halved the
+// capacity, 64 pieces of 1 Mbp per batch where 100 fit, and a batch more costs a forward pass more (a second per Mbp of its longest piece)
+int64_t augx_decoder_sampled_capacity(augx_decoder *d) {
+    const int64_t cap = augx_decoder_batch_capacity(d);
+    if (!d || d->dense) return cap; // (the estimate of the dense kernels counts both matrices already)
+    const int64_t base = d->model->m.t.n_classes > 1 ? 2000 : 1500;
+    return cap * base / (base + 8 * (int64_t)d->model->m.t.S);
+}
+
 void augx_release_host_pools();
 void augx_decoder_destroy(augx_decoder *d) {
     if (!d) return;

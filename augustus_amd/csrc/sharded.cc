@@ -127,9 +127,9 @@ int augx_decode_sampled(augx_decoder *const *decs, int n_dec, const augx_piece *
     for (int i = 0; i < n; i++) { out[i].states = nullptr; out[i].n_states = 0; out[i].status = AUGX_E_ARG; out[i].ln_viterbi = 0; }
     for (int64_t i = 0; i < (int64_t)n * n_samples; i++) { samples[i].states = nullptr; samples[i].n_states = 0; samples[i].status = AUGX_E_ARG; samples[i].ln_viterbi = 0; }
     if (n == 0) return AUGX_OK;
-    // the forward matrix (S doubles per base) comes on top of what a decode needs: half the bases per batch
-    int64_t budget = augx_decoder_batch_capacity(decs[0]) / 2;
-    for (int d = 1; d < n_dec; d++) budget = std::min<int64_t>(budget, augx_decoder_batch_capacity(decs[d]) / 2);
+    // the forward matrix (S doubles per base) comes on top of what a decode needs
+    int64_t budget = augx_decoder_sampled_capacity(decs[0]);
+    for (int d = 1; d < n_dec; d++) budget = std::min<int64_t>(budget, augx_decoder_sampled_capacity(decs[d]));
     if (const char *e = getenv("AUGX_BATCH_BASES")) budget = atol(e);
     std::vector<std::pair<int, int>> batches; // [first, last)
     for (int i = 0; i < n;) {

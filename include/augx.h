@@ -234,6 +234,9 @@ int64_t augx_decoder_near_ties(const augx_decoder *d, int64_t *pieces /* may be 
 /* host buffers kept between sampled pieces (forward matrices, at most 12 GB) are released when the last decoder is destroyed, or here */
 void augx_release_host_pools(void);
 int64_t augx_decoder_batch_capacity(augx_decoder *d);
+/* the same when the forward matrix (8 S bytes per base) is made on top of the decode: what augx_decode_sampled packs into a batch
+ * (reference: NAMGene::viterbiAndForward keeps both matrices of a piece, src/namgene.cc:168-365) */
+int64_t augx_decoder_sampled_capacity(augx_decoder *d);
 
 /* replaces viterbiAndForward + getViterbiPath for a batch of independent pieces */
 int augx_decode_batch(augx_decoder *d, const augx_piece *pieces, int n, augx_path *out /* array[n] */);

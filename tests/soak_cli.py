@@ -49,6 +49,8 @@ def make_case(seed, g):
         multi = os.environ.get("AUGX_SOAK_DENSE") == "2"
         if rng.random() < 0.6:
             species = rng.choice(["fly", "human", "human"]) if multi else "fly"
+            if os.environ.get("AUGX_SOAK_DENSE") == "3":  # (3: + the species whose UTR content tables have their own Markov order and gc donor sites)
+                species = rng.choice(["chlamy2011", "caenorhabditis", "fly"])
             opts["UTR"] = "on"
             if rng.random() < 0.3:
                 opts["print_utr"] = "on"
