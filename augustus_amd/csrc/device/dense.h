@@ -204,7 +204,7 @@ AUGX_HD bool utrGateOpen(const Piece &P, int kind, int j, double tssR) {
     case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM: {
         if (eobe + 3 > n - 1) return true;
         const int pn = P.pat(eobe + 1, 3);
-        return pn == 14 || pn == 30 || pn == 62; // GeneticCode::isStartcodon: {a,c,t}tg
+        return pn >= 0 && ((T.startMask >> pn) & 1ull); // GeneticCode::isStartcodon: the translation table's start codons ({a,c,t}tg in table 1)
     }
     case AUGX_K_UTR5INIT: case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR3INIT: case AUGX_K_UTR3INTERNAL: return dssProb(P, boep, true) > AUGX_NINF;
     case AUGX_K_RUTR5INTERNAL: case AUGX_K_RUTR5TERM: case AUGX_K_RUTR3INTERNAL: case AUGX_K_RUTR3TERM: return P.possRASS(boep + T.Ae);

@@ -129,6 +129,7 @@ typedef const __attribute__((address_space(4))) double *TabPtr;
 typedef const double *TabPtr;
 #endif
 struct DevTables {
+    int kIn, NPin;             // order and table length of the intron content table (augx_tables::k_in; = k, NP but for one species)
     int S, C, k, NP, W, U, As, Ae, Ds, De, Li, Le, d, dStateLen, max_exon_len, min_exon_len;
     int tis_n, tis_k, ass_n, ass_k, tis_nbins, tis_mem, synch, gc_win, gc_weighing_type;
     int dssGc;                 // a donor site may read gc as well as gt (/IntronModel/allow_dss_consensus_gc); dss_pat has a second half for them
@@ -142,6 +143,8 @@ struct DevTables {
     double gc_zus[AUGX_MAX_CLASSES][4], gc_weight_matrix[16];
     // untranslated regions (include/augx.h: the utr block of augx_tables)
     int utr, tss_upwin, tss_start, tss_end, tata_start, tata_end, d_tss_tata_min, d_tss_tata_max, dpc, boxlen, tts_spacing;
+    unsigned long long startMask; // augx_tables::start_mask: the codons that may start a gene under the translation table
+    int stopMask;              // augx_tables::stop_mask: bit 0 taa, bit 1 tag, bit 2 tga end a reading frame
     int uk, uNP;               // order and table length of the UTR exon content tables (augx_tables::utr_k)
     int uML, uM3S, uM3T, tssup_k, tss_n, tss_k, tsstata_n, tsstata_k, tata_n, tata_k, tts_n, tts_k;
     double ln_tts_rand, ln2;
@@ -276,6 +279,12 @@ AUGX_HD double frameOff(const BatchView &B, int p, int q) {
 }
 
 // view of one piece: pointers pre-offset so that index q is the 0-based base position
+// the codon c0 c1 c2 (0..3 = acgt) ends a reading frame under the translation table: mask bit 0 taa, bit 1 tag, bit 2 tga
+AUGX_HD bool stopCodon3(int c0, int c1, int c2, int mask) {
+    if (c0 != 3) return false;
+    if (c1 == 0) return (c2 == 0 && (mask & 1)) || (c2 == 2 && (mask & 2));
+    return c1 == 2 && c2 == 0 && (mask & 4);
+}
 struct Piece {
     const DevTables *t;
     int n, c;                  // length, GC class
@@ -321,11 +330,11 @@ struct Piece {
         }
         return r;
     }
-    AUGX_HD bool isStop(int p) const {
-        return b(p) == 3 && ((b(p + 1) == 0 && (b(p + 2) == 0 || b(p + 2) == 2)) || (b(p + 1) == 2 && b(p + 2) == 0));
-    }
+    // (which of taa / tag / tga end a reading frame: the translation table, DevTables::stopMask)
+    AUGX_HD bool isStop(int p) const { return stopCodon3(b(p), b(p + 1), b(p + 2), t->stopMask); }
     AUGX_HD bool isRCStop(int p) const {
-        return b(p + 2) == 0 && ((b(p + 1) == 3 && (b(p) == 3 || b(p) == 1)) || (b(p + 1) == 1 && b(p) == 3));
+        const int c0 = b(p + 2), c1 = b(p + 1), c2 = b(p);
+        return stopCodon3(c0 <= 3 ? 3 - c0 : 4, c1 <= 3 ? 3 - c1 : 4, c2 <= 3 ? 3 - c2 : 4, t->stopMask);
     }
     // splice-site gates, reference include/statemodel.hh:98-117 (ab initio: consensus dinucleotides only)
     // (onGenDSS / onGenRDSS, include/geneticcode.hh:47-54: gt -- reverse strand: ac -- or, where the species allows it, gc)
@@ -358,10 +367,6 @@ struct Piece {
     }
 };
 
-AUGX_HD bool stopCodon3(int c0, int c1, int c2) {
-    if (c0 > 3 || c1 > 3 || c2 > 3) return false;
-    return c0 == 3 && ((c1 == 0 && (c2 == 0 || c2 == 2)) || (c1 == 2 && c2 == 0));
-}
 AUGX_HD uint64_t toFx(double lnp) { return (uint64_t)(int64_t)llrint(lnp * AUGX_FX_SCALE); }
 
 // Motif::seqProb (reference src/motif.cc:308-331), forward and reverse-complement
@@ -481,15 +486,15 @@ AUGX_HD double eIg(const Piece &P, int p) {
 }
 AUGX_HD double eIn(const Piece &P, int p) {
     const DevTables &t = *P.t;
-    int pn = p >= t.k ? P.pat(p - t.k, t.k + 1) : -1;
-    return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NP + pn] : t.ln_quarter;
+    int pn = p >= t.kIn ? P.pat(p - t.kIn, t.kIn + 1) : -1;
+    return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NPin + pn] : t.ln_quarter;
 }
 // a base of a utr5intron / utr3intron state where the UTR order uk is below k: the intron pattern read from p - uk on, k + 1 bases
 // -- it ends k - uk bases AFTER p; past the piece: 1/4 (reference src/utrmodel.cc:1255-1262: s2i_intron(sequence + pos - k) with UtrModel::k)
 AUGX_HD double eUin(const Piece &P, int p) {
     const DevTables &t = *P.t;
-    int pn = (p >= t.uk && p - t.uk + t.k < P.n) ? P.pat(p - t.uk, t.k + 1) : -1;
-    return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NP + pn] : t.ln_quarter;
+    int pn = (p >= t.uk && p - t.uk + t.kIn < P.n) ? P.pat(p - t.uk, t.kIn + 1) : -1;
+    return pn >= 0 ? t.in_emi[(int64_t)P.c * t.NPin + pn] : t.ln_quarter;
 }
 
 struct ExGeom { int bpl, ipo, baseOffset, ipeo; bool fwd; };

@@ -259,6 +259,11 @@ AUGX_HD int k1WindowClass(const DevTables &T, const BatchView &B, int64_t g) {
     if (T.C == 1) { B.gcRaw[g] = 0; return 0; } // (a single class: nothing to decide)
     double cnt[4];
     for (int i = 0; i < 4; i++) cnt[i] = (double)(B.cnt[fidx(o + s + win, i, NCNT)] - B.cnt[fidx(o + s, i, NCNT)]);
+    // a window without a single nucleotide (inside a run of N at least as long as the window): the reference's BaseCount keeps the
+    // relative frequencies it was constructed with -- those of the FIRST window of the piece (normalize() leaves them alone when the
+    // counts sum to 0, src/motif.cc:204-212, and computeStairs never refreshes them, :561-575); 1/4 each if that window is empty too
+    if (cnt[0] + cnt[1] + cnt[2] + cnt[3] == 0.0)
+        for (int i = 0; i < 4; i++) cnt[i] = (double)(B.cnt[fidx(o + win, i, NCNT)] - B.cnt[fidx(o, i, NCNT)]);
     const int c = nearestClass(T, cnt);
     B.gcRaw[g] = (uint8_t)c; // input of the content stairs, should the windows of the piece disagree (layout.h: stairsPlanes)
     return c;
@@ -287,11 +292,13 @@ AUGX_HD bool k1FxTermsCalc(const DevTables &T, const BatchView &B, int64_t g, in
             out[(0 * 3 + a) * 3 + tb] = toFx(pn >= 0 ? tabs[tb][mod3(q + a) * NP + pn] : T.ln_n_coding);
             out[(1 * 3 + a) * 3 + tb] = toFx(rn >= 0 ? tabs[tb][mod3(a - q) * NP + rn] : T.ln_n_coding);
         }
-    const double *inE = T.in_emi + (int64_t)c * NP;
+    const double *inE = T.in_emi + (int64_t)c * T.NPin;
     // (intron content; a soft-masked base adds the nonexonpart bonus, reference src/intronmodel.cc:1011-1036)
     const double softB = (T.soft && B.raw[g] >= 'a' && B.raw[g] <= 'z') ? T.lnSoft : 0.0;
-    out[FX_INF] = toFx((pn >= 0 ? inE[pn] : T.ln_quarter) + softB);
-    int rn2 = (q + k < P.n) ? rn : -1;
+    const int ki = T.kIn; // (the intron model's own order: the exon patterns serve where it is k)
+    const int pni = ki == k ? pn : (q >= ki ? P.pat(q - ki, ki + 1) : -1);
+    out[FX_INF] = toFx((pni >= 0 ? inE[pni] : T.ln_quarter) + softB);
+    int rn2 = (q + ki < P.n) ? (ki == k ? rn : P.rcpat(q, ki + 1)) : -1;
     out[FX_INR] = toFx((rn2 >= 0 ? inE[rn2] : T.ln_quarter) + softB);
     }
     return true;
@@ -815,7 +822,7 @@ AUGX_KFN void varEvalItem(const CandCtx &X, int s, int j, const VarDesc &D, int 
                 if (f == 0) { c1 = bM1 <= 3 ? 3 - bM1 : 4; c2 = bM2 <= 3 ? 3 - bM2 : 4; }
                 else c2 = bM1 <= 3 ? 3 - bM1 : 4;
             }
-            veto = stopCodon3(c0, c1, c2);
+            veto = stopCodon3(c0, c1, c2, T.stopMask);
         }
         const double restSeq = listed ? (double)(int64_t)(D.eFx - cFx) * AUGX_FX_INV : P.seg(fwd ? FX_INF : FX_INR, begin, j);
         const double emi = lenI + restSeq;

@@ -354,14 +354,14 @@ inline int chooseBlockSize(const augx_tables &t) {
 // fill the scalar part of DevTables; the caller sets the table pointers (device or host)
 inline void fillDevTablesScalars(const augx_tables &t, DevTables &D) {
     memset(&D, 0, sizeof D);
-    D.S = t.S; D.C = t.n_classes; D.k = t.k; D.NP = 1 << (2 * (t.k + 1));
+    D.S = t.S; D.C = t.n_classes; D.k = t.k; D.NP = 1 << (2 * (t.k + 1)); D.kIn = t.k_in; D.NPin = 1 << (2 * (t.k_in + 1));
     D.W = t.W; D.U = t.U; D.As = t.As; D.Ae = t.Ae; D.Ds = t.Ds; D.De = t.De; D.Li = t.Li; D.Le = t.Le; D.d = t.d;
     D.dStateLen = t.d - 2 - t.De - t.As - 2 - t.U;
     D.max_exon_len = t.max_exon_len; D.min_exon_len = t.min_exon_len;
     D.tis_n = t.tis_n; D.tis_k = t.tis_k; D.ass_n = t.ass_n; D.ass_k = t.ass_k; D.tis_nbins = t.tis_nbins; D.tis_mem = t.tis_mem;
     D.synch = t.synch_state; D.gc_win = t.gc_win; D.gc_weighing_type = t.gc_weighing_type;
     D.soft = t.softmasking; D.lnSoft = t.ln_soft_bonus;
-    D.dssGc = t.dss_gc;
+    D.dssGc = t.dss_gc; D.stopMask = t.stop_mask; D.startMask = t.start_mask;
     D.utr = t.utr; D.tss_upwin = t.tss_upwin; D.tss_start = t.tss_start; D.tss_end = t.tss_end; D.tata_start = t.tata_start; D.tata_end = t.tata_end;
     D.d_tss_tata_min = t.d_tss_tata_min; D.d_tss_tata_max = t.d_tss_tata_max; D.dpc = t.d_polyasig_cleavage; D.boxlen = t.aataaa_boxlen;
     D.tts_spacing = t.tts_spacing; D.uML = t.utr_max_exon_len; D.uM3S = t.utr_max3single; D.uM3T = t.utr_max3term; D.tssup_k = t.tssup_k;
@@ -404,7 +404,7 @@ inline std::vector<TableSpan> tableSpans(const augx_tables &t, DevTables &D) {
     v.push_back({t.ln_trans, C * S * S, &D.ln_trans});
     v.push_back({t.ig_emi, C * NP, &D.ig_emi});
     v.push_back({t.ig_short, C * (t.k + 1) * NP, &D.ig_short});
-    v.push_back({t.in_emi, C * NP, &D.in_emi});
+    v.push_back({t.in_emi, C * ((int64_t)1 << (2 * (t.k_in + 1))), &D.in_emi});
     v.push_back({t.ex_emi, C * 3 * NP, &D.ex_emi});
     v.push_back({t.ex_init, C * 3 * NP, &D.ex_init});
     v.push_back({t.ex_et, C * 3 * NP, &D.ex_et});

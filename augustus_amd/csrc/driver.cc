@@ -847,6 +847,11 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     auto restore = [&]() { std::cout.flush(); std::cerr.flush(); std::cout.rdbuf(coutbuf); std::cerr.rdbuf(cerrbuf); };
 
     const int verbosity = M.opt.getInt("/augustus/verbosity", 1);
+    // (what the reference says while it sets its parameters comes first: a genetic code other than the standard one, on the
+    //  output stream; start codons of the species that the code does not know, on the error stream -- src/augustus.cc:526-528,
+    //  src/geneticcode.cc:157-165,297-299)
+    if (!M.codeWarnings.empty()) std::cout << M.codeWarnings;
+    if (!M.stderrNotes.empty()) std::cerr << M.stderrNotes;
     if (S.oo.gff3) std::cout << "##gff-version 3" << std::endl;
     std::cout << "# This output was generated with AUGUSTUS-MI355X (GHMM Viterbi decode on gfx950; output format of AUGUSTUS 3.5.0).\n"
               << "# AUGUSTUS is a gene prediction tool written by M. Stanke (mario.stanke@uni-greifswald.de),\n"

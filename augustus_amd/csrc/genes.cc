@@ -101,6 +101,7 @@ void Transcript::shift(long d) {
 
 void OutputOptions::fromModel(const Model &m) { // reference Gene::init, src/gene.cc:2447-2459
     const Options &o = m.opt;
+    transTable = m.transTable;
     print_start = o.getBool("start", true);
     print_stop = o.getBool("stop", true);
     print_introns = o.getBool("introns", false);
@@ -254,7 +255,7 @@ double Transcript::meanStateProb() const {
 // reference Gene::hasInFrameStop, src/gene.cc:1422-1438: a stop codon in the reading frame of the CDS before its last codon (the
 // stop codon of a gene can be put together by a long intron; short introns are kept from it in the trellis).  A codon with
 // anything but acgt in it does not count.
-static bool hasInFrameStop(const Transcript &t, const char *seq) {
+static bool hasInFrameStop(const Transcript &t, const char *seq, int stopMask) {
     std::string cds;
     for (const BioState &e : t.exons) cds.append(seq + e.begin, (size_t)e.length());
     if (!t.plus) {
@@ -267,7 +268,7 @@ static bool hasInFrameStop(const Transcript &t, const char *seq) {
     }
     for (size_t i = (size_t)mod3(-t.frame); i + 3 < cds.size(); i += 3) {
         const char a = (char)tolower((unsigned char)cds[i]), b = (char)tolower((unsigned char)cds[i + 1]), c = (char)tolower((unsigned char)cds[i + 2]);
-        if (a == 't' && ((b == 'a' && (c == 'a' || c == 'g')) || (b == 'g' && c == 'a'))) return true;
+        if (a == 't' && ((b == 'a' && ((c == 'a' && (stopMask & 1)) || (c == 'g' && (stopMask & 2)))) || (b == 'g' && c == 'a' && (stopMask & 4)))) return true; // (GeneticCode::isStopcodon: the translation table's)
     }
     return false;
 }
@@ -286,7 +287,7 @@ std::vector<Transcript> filterTranscripts(const Model &m, const std::vector<Tran
         if (g.throwaway) keep = false;
         bool cc = g.completeCDS();
         if ((g.clength < m.t.min_coding_len && cc) || (g.clength < 4 && g.clength < m.t.min_coding_len && !cc)) keep = false;
-        if (noInFrameStop && hasInFrameStop(g, seq)) keep = false;
+        if (noInFrameStop && hasInFrameStop(g, seq, m.t.stop_mask)) keep = false;
         if (keep && g.hasProbs) { // src/gene.cc:2489-2514
             const bool kv = keepViterbi && g.viterbi;
             if (g.meanStateProb() < minmean && !kv) keep = false;
@@ -603,11 +604,12 @@ static int b2i(char c) {
     switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1; case 'g': case 'G': return 2; case 't': case 'T': return 3; default: return -1; }
 }
 // reference getTranslation, src/gene.cc:2337-2354
-std::string translateCDS(const char *cs) {
+std::string translateCDS(const char *cs, const char *table) {
+    const char *g_transTable = (table && strlen(table) == 64) ? table : kTransTable1; // (--translation_table, Model::transTable)
     std::string result;
     while (cs[0] && cs[1] && cs[2]) {
         int a = b2i(cs[0]), b = b2i(cs[1]), c = b2i(cs[2]);
-        char aa = (a < 0 || b < 0 || c < 0) ? 'X' : kTransTable1[a * 16 + b * 4 + c];
+        char aa = (a < 0 || b < 0 || c < 0) ? 'X' : g_transTable[a * 16 + b * 4 + c];
         if (aa != '*') result.append(1, aa);
         else if (cs[3]) result.append("X");
         cs += 3;
@@ -788,7 +790,7 @@ void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const ch
                 if (o.protein) { // reference Gene::printProteinSeq, src/gene.cc:2356-2383
                     const int linelength = 100;
                     const std::string prefix = "# protein sequence = [";
-                    std::string trans = translateCDS(cds.c_str() + mod3(-t.frame));
+                    std::string trans = translateCDS(cds.c_str() + mod3(-t.frame), o.transTable.c_str());
                     size_t i2 = linelength - prefix.size();
                     out += prefix + trans.substr(0, i2);
                     while (i2 < trans.size()) {

@@ -65,6 +65,7 @@ struct OutputOptions {
          gff3 = false, stopCodonExcludedFromCDS = false, protein = true, codingseq = false, evidence = false,
          uniqueGeneId = false, softmasking = true;
     long offset = 0; // added to every printed coordinate (--predictionStart)
+    std::string transTable; // amino acids by codon index (--translation_table; empty: the standard code)
     void fromModel(const Model &m);
 };
 
@@ -98,6 +99,6 @@ void reverseGenes(std::vector<GeneOut> &genes, long endpos);
 void printGeneList(std::string &out, const std::vector<GeneOut> &genes, const char *seq, long seqlen, const OutputOptions &o,
                    const std::vector<std::pair<long, long>> *rmRuns = nullptr);
 
-std::string translateCDS(const char *codingSeq);
+std::string translateCDS(const char *codingSeq, const char *table = nullptr); // (table: 64 letters by codon index, null: the standard code)
 
 } // namespace augx

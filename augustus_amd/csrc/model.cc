@@ -417,8 +417,9 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     t.ln_stop_amber = lnp(amber);
     t.ln_stop_opal = lnp(opal);
     int kEx = opt.getInt("/ExonModel/k", 4), kIn = opt.getInt("/IntronModel/k", 4), kIg = opt.getInt("/IGenicModel/k", 4);
-    if (kEx != kIn || kEx != kIg) throw UnsupportedError("exon/intron/igenic Markov orders differ; not supported");
+    if (kEx != kIg) throw UnsupportedError("exon/igenic Markov orders differ; not supported");
     t.k = kEx;
+    t.k_in = kIn; // (the intron file's own `k` line decides, below)
     t.utr_k = kEx; // (loadUtr: the order the UTR parameter file states)
     const int k = t.k, NP = ipow4(k + 1), C = t.n_classes;
     if (t.d < 2 + t.De + t.U + t.As + 2)
@@ -501,11 +502,58 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
     {
         // translation table 1: {a,c,t}tg may start, only atg has probability 1 by default
         // (reference src/geneticcode.cc:15-19, GeneticCode::chooseTranslationTable :172-196)
-        if (opt.getInt("translation_table", 1) != 1) throw UnsupportedError("translation_table != 1 not supported");
+        // --translation_table: the amino acid of every codon and which codons may start (the published NCBI genetic codes the
+        // reference knows, codons in the order aaa, aac, aag, aat, aca ... ttt; an unknown number means table 1, src/geneticcode.cc:146-148)
+        static const struct { int n; const char *aa, *start; } kCodes[] = {
+            {1, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF", "--------------M---------------M-------------------------------M-"},
+            {2, "KNKNTTTT*S*SMIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "------------MMMM------------------------------M-----------------"},
+            {3, "KNKNTTTTRSRSMIMIQHQHPPPPRRRRTTTTEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "------------M-M-------------------------------------------------"},
+            {4, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "------------MMMM--------------M---------------M-------------M-M-"},
+            {5, "KNKNTTTTSSSSMIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "------------MMMM------------------------------M---------------M-"},
+            {6, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVQYQYSSSS*CWCLFLF", "--------------M-------------------------------------------------"},
+            {9, "NNKNTTTTSSSSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "--------------M-------------------------------M-----------------"},
+            {10, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSCCWCLFLF", "--------------M-------------------------------------------------"},
+            {11, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF", "------------MMMM--------------M---------------M---------------M-"},
+            {12, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLSLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF", "--------------M---------------M---------------------------------"},
+            {13, "KNKNTTTTGSGSMIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "------------M-M-------------------------------M---------------M-"},
+            {14, "NNKNTTTTSSSSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVYY*YSSSSWCWCLFLF", "--------------M-------------------------------------------------"},
+            {15, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*YQYSSSS*CWCLFLF", "--------------M-------------------------------------------------"},
+            {16, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*YLYSSSS*CWCLFLF", "--------------M-------------------------------------------------"},
+            {21, "NNKNTTTTSSSSMIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "--------------M-------------------------------M-----------------"},
+            {22, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*YLY*SSS*CWCLFLF", "--------------M-------------------------------------------------"},
+            {23, "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWC*FLF", "--------------MM------------------------------M-----------------"},
+            {24, "KNKNTTTTSSKSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSSWCWCLFLF", "--------------M---------------M---------------M---------------M-"}};
+        int tt = opt.has("translation_table") ? opt.getInt("translation_table", 1) : 1, ti = 0;
+        for (int i = 0; i < (int)(sizeof kCodes / sizeof kCodes[0]); i++) if (kCodes[i].n == tt) ti = i;
+        if (kCodes[ti].n != tt) tt = 1;
+        transTable = kCodes[ti].aa;
+        {   // "# Warning: Using nonstandard genetic code: ..." (chooseTranslationTable :157-165), one line per codon read differently
+            static const char *kSym = "GDERKNQSTAVLIFYWHMCP";
+            static const char *kName[20] = {"GLYCINE", "ASPARTIC ACID", "GLUTAMIC ACID", "ARGININE", "LYSINE", "ASPARAGINE", "GLUTAMINE", "SERINE", "THREONINE", "ALANINE",
+                                            "VALINE", "LEUCINE", "ISOLEUCINE", "PHENYLALANINE", "TYROSINE", "TRYPTOPHAN", "HISTIDINE", "METHIONINE", "CYSTEINE", "PROLINE"};
+            auto nameOf = [&](char a) -> std::string { if (a == '*') return "STOP"; const char *q = strchr(kSym, a); return q ? kName[q - kSym] : "?"; };
+            codeWarnings.clear();
+            for (int c = 0; c < 64; c++)
+                if (transTable[(size_t)c] != kCodes[0].aa[c]) {
+                    const char cod[4] = {"ACGT"[c >> 4], "ACGT"[(c >> 2) & 3], "ACGT"[c & 3], 0}; // (Seq2Int::INV prints capitals)
+                    codeWarnings += std::string("# Warning: Using nonstandard genetic code: ") + cod + " coding for " + nameOf(transTable[(size_t)c]) + " instead of " +
+                                    nameOf(kCodes[0].aa[c]) + ".\n";
+                }
+        }
+        t.stop_mask = 0;
+        for (int c = 0; c < 64; c++)
+            if (transTable[(size_t)c] == '*') {
+                if (c == 48) t.stop_mask |= 1;       // taa
+                else if (c == 50) t.stop_mask |= 2;  // tag
+                else if (c == 56) t.stop_mask |= 4;  // tga
+                else throw UnsupportedError("translation_table " + std::to_string(tt) + " has a stop codon other than taa / tag / tga (the reference stops with an internal error at the first gene that ends in it); not supported");
+            }
         double startProb[64] = {0};
         bool isStart[64] = {false};
-        isStart[14] = isStart[30] = isStart[62] = true; // atg, ctg, ttg
-        startProb[14] = 1.0;
+        for (int c = 0; c < 64; c++) isStart[c] = kCodes[ti].start[c] != '-'; // (table 1: atg, ctg, ttg)
+        t.start_mask = 0;
+        for (int c = 0; c < 64; c++) if (isStart[c]) t.start_mask |= 1ull << c;
+        startProb[14] = 1.0; // (GeneticCode::start_codon_probs: atg 1 until the species' file says otherwise, src/geneticcode.cc:18)
         PblReader r(full + opt.get("/ExonModel/infile"));
         size_t sp0 = r.tell();
         if (r.gotoLineAfter("[STARTCODONS]")) { // reference GeneticCode::readStart, src/geneticcode.cc:280-306
@@ -525,6 +573,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
                     pn = pn * 4 + b;
                 }
                 if (isStart[pn]) startProb[pn] = p;
+                else stderrNotes += cod + " is not a start codon in the chosen translation table " + std::to_string(tt) + ". Ignoring it.\n"; // (GeneticCode::readStart :297-299)
             }
         } else
             r.seek(sp0);
@@ -716,8 +765,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
         t.d = dd;
         len_intron.resize(dd + 1);
         for (int i = 0; i <= dd; i++) { r.comment(); len_intron[i] = lnp(r.readDouble() / 1000); }
-        in_emi.assign((size_t)C * NP, NEG_INF);
-        inEmiLinear.assign((size_t)C * NP, 0.0);
+        int NPi = 0;
         for (int c = 0; c < C; c++) {
             char tag[16];
             snprintf(tag, sizeof tag, "[%d]", c + 1);
@@ -730,12 +778,18 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
             r.comment(); int kk = r.readInt();
             r.comment(); (void)r.readDouble();
             r.comment();
-            if (kk != k || sz != NP) throw ConfigError("IntronModel: emission order mismatch");
+            if (c == 0) { // (the order of the intron content model is the one its file states, src/intronmodel.cc:358)
+                if (kk < 0 || kk > k) throw UnsupportedError("intron Markov order above the exon order; not supported");
+                t.k_in = kk; NPi = ipow4(kk + 1);
+                in_emi.assign((size_t)C * NPi, NEG_INF);
+                inEmiLinear.assign((size_t)C * NPi, 0.0);
+            }
+            if (kk != t.k_in || sz != NPi) throw ConfigError("IntronModel: emission order mismatch");
             for (int i = 0; i < sz; i++) {
                 r.comment();
-                int pn = r.readPattern(k + 1);
-                inEmiLinear[(size_t)c * NP + pn] = r.readDouble();
-                in_emi[(size_t)c * NP + pn] = lnp(inEmiLinear[(size_t)c * NP + pn]);
+                int pn = r.readPattern(t.k_in + 1);
+                inEmiLinear[(size_t)c * NPi + pn] = r.readDouble();
+                in_emi[(size_t)c * NPi + pn] = lnp(inEmiLinear[(size_t)c * NPi + pn]);
             }
             r.need("[ASSMOTIF]");
             Motif m = readMotif(r);
@@ -801,11 +855,12 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
                     ig_emi[(size_t)c * NP + j] = lnp(r.readDouble());
                 }
             }
-            if (tie) // reference IGenicModel::updateToLocalGC, src/igenicmodel.cc:69-81
+            if (tie && t.k_in == k) // reference IGenicModel::updateToLocalGC, src/igenicmodel.cc:69-81 (not where the orders of the two models differ, :74)
                 for (int j = 0; j < NP; j++) ig_emi[(size_t)c * NP + j] = in_emi[(size_t)c * NP + j];
         }
     }
 
+    if (utr && t.k_in != k) throw UnsupportedError("UTR states with an intron Markov order other than the exon order; not supported");
     if (utr) loadUtr(full, inEmiLinear);
 
     // ---- per-class transition matrices (reference IntronModel::updateToLocalGCEach, src/intronmodel.cc:439-488)
@@ -871,7 +926,7 @@ void Model::load(const std::string &cfgPathIn, const std::string &sp,
 //      fillTailsOfLengthDistributions :293-361).  inEmi: the intron emission probabilities (linear), [C][NP]
 void Model::loadUtr(const std::string &full, const std::vector<double> &inEmi) {
     // (the order of the UTR content tables is the one the parameter FILE states: UtrModel::k is overwritten while reading, :620)
-    const int NPin = ipow4(t.k + 1), C = t.n_classes;
+    const int NPin = ipow4(t.k_in + 1), C = t.n_classes;
     int k = opt.getInt("/UtrModel/k", 4), NP = ipow4(k + 1);
     t.tss_upwin = opt.getInt("/Constant/tss_upwindow_size", 0);
     t.tss_start = opt.getInt("/UtrModel/tss_start", 4);

@@ -40,6 +40,9 @@ struct Model {
     std::string configPath, species, speciesDir;
     std::string transFileUsed;       // for the "# human version. Using ..." header line
     bool speciesSpecificTrans = false;
+    std::string transTable;          // 64 amino-acid letters by codon index aaa, aac, ... ttt ('*': stop) of --translation_table
+    std::string stderrNotes;         // what the reference writes to its error stream while it reads the parameters
+    std::string codeWarnings;        // the lines the reference prints first when the table is not the standard one
     augx_tables t{};
     // owning storage behind the pointers of t
     std::vector<double> ln_trans, ig_emi, ig_short, in_emi, ex_emi, ex_init, ex_et, ex_pls, tis_motif, ass_motif,

@@ -92,7 +92,7 @@ typedef struct augx_tables {
     const double *ig_emi;           /* [C][NP]       igenic emission (intron table when tieIgenicIntron) */
     const double *ig_short;         /* [C][k+1][NP]  ln of the short-pattern ratio used for positions <= k
                                        (reference IGenicModel::emiProbUnderModel, src/igenicmodel.cc:342-356) */
-    const double *in_emi;           /* [C][NP]       intron emission                                    */
+    const double *in_emi;           /* [C][4^(k_in+1)] intron emission (k_in = k for every shipped species but one, see k_in)  */
     const double *ex_emi;           /* [C][3][NP]    exon content, frame-dependent                      */
     const double *ex_init;          /* [C][3][NP]    initial content                                    */
     const double *ex_et;            /* [C][3][NP]    exon-terminal content                              */
@@ -160,6 +160,19 @@ typedef struct augx_tables {
      * state with the intron pattern that begins utr_k bases before it, i.e. ends k - utr_k bases after it (:1255-1262,1389-1396);
      * both are reproduced */
     int utr_k;
+    /* --translation_table (GeneticCode::chooseTranslationTable, src/geneticcode.cc:146-170): which of taa (bit 0), tag (bit 1),
+     * tga (bit 2) end a reading frame -- 7 for the standard code, 4 for table 6 (ciliates: taa, tag read glutamine).  The open
+     * reading frames, the stop of single / terminal exons and the stop-codon veto of short introns follow the table, not the
+     * {ochre,amber,opal}prob values (src/exonmodel.cc:204-219).  A table with a stop codon other than these three is refused:
+     * the reference throws at the first such codon that ends a gene (src/exonmodel.cc:1284-1292) */
+    int stop_mask;
+    /* bit c: codon c (index a=0 c=1 g=2 t=3, first base most significant) may start a gene under the translation table
+     * (GeneticCode::isStartcodon; table 1: atg, ctg, ttg) -- whatever probability the species gives it.  Read by the end gate of
+     * the 5' UTR states next to the start codon (src/utrmodel.cc:1075-1078) */
+    unsigned long long start_mask;
+    /* Markov order of the intron content table where it is not k (tetrahymena: 3 beside 4; IntronModel::k, the `k` line of the
+     * [EMISSION] section of the species' intron file, src/intronmodel.cc:356-372): in_emi is [C][4^(k_in+1)].  Without UTR states only */
+    int k_in;
 } augx_tables;
 
 typedef struct augx_model augx_model;     /* host-side immutable model: tables + option values          */

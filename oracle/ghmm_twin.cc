@@ -113,15 +113,18 @@ struct Twin {
         }
         return r;
     }
-    bool isStop(int p) const { // taa tag tga at p..p+2  (translation table 1)
-        return b(p) == 3 && ((b(p + 1) == 0 && (b(p + 2) == 0 || b(p + 2) == 2)) || (b(p + 1) == 2 && b(p + 2) == 0));
-    }
-    bool isRCStop(int p) const { // tta cta tca
-        return b(p + 2) == 0 && ((b(p + 1) == 3 && (b(p) == 3 || b(p) == 1)) || (b(p + 1) == 1 && b(p) == 3));
-    }
-    static bool stopCodon3(int c0, int c1, int c2) {
+    // which codons end a reading frame follows the translation table (GeneticCode::isStopcodon = translate() == '*',
+    // include/geneticcode.hh:327-329; OpenReadingFrame::isStopcodon, src/exonmodel.cc:204-219): t.stop_mask bit 0 taa, 1 tag, 2 tga
+    bool stopCodon3(int c0, int c1, int c2) const {
         if (c0 > 3 || c1 > 3 || c2 > 3) return false; // translate() -> 'X' (src/geneticcode.cc:198-204)
-        return c0 == 3 && ((c1 == 0 && (c2 == 0 || c2 == 2)) || (c1 == 2 && c2 == 0));
+        if (c0 != 3) return false;
+        if (c1 == 0) return (c2 == 0 && (t.stop_mask & 1)) || (c2 == 2 && (t.stop_mask & 2));
+        return c1 == 2 && c2 == 0 && (t.stop_mask & 4);
+    }
+    bool isStop(int p) const { return stopCodon3(b(p), b(p + 1), b(p + 2)); }
+    bool isRCStop(int p) const { // the reverse complement of p..p+2
+        const int c0 = b(p + 2), c1 = b(p + 1), c2 = b(p);
+        return stopCodon3(c0 <= 3 ? 3 - c0 : 4, c1 <= 3 ? 3 - c1 : 4, c2 <= 3 ? 3 - c2 : 4);
     }
 
     // ------------------------------------------------------------------------------------------
@@ -160,13 +163,17 @@ struct Twin {
         int cnt[4] = {0, 0, 0, 0};
         for (int i = 0; i < win; i++)
             if (code[i] < 4) cnt[code[i]]++;
-        int x = nearestClass(cnt);
+        // (a window without a single nucleotide: BaseCount::normalize leaves the relative frequencies alone when the counts sum to 0,
+        //  :204-212, and the object of computeStairs was normalised once, for the first window: that window's frequencies answer)
+        const int first[4] = {cnt[0], cnt[1], cnt[2], cnt[3]};
+        auto classOf = [&](const int c4[4]) { return nearestClass(c4[0] + c4[1] + c4[2] + c4[3] == 0 ? first : c4); };
+        int x = classOf(cnt);
         for (int i = 0; i <= win / 2 && i < n; i++) cls[i] = x;
         for (int i = win / 2 + 1; i <= n - (win + 1) / 2; i++) {
             int add = i + (win + 1) / 2 - 1, sub = i - win / 2 - 1;
             if (code[add] < 4) cnt[code[add]]++;
             if (code[sub] < 4) cnt[code[sub]]--;
-            cls[i] = x = nearestClass(cnt);
+            cls[i] = x = classOf(cnt);
         }
         for (int i = n - (win + 1) / 2 + 1; i < n; i++) cls[i] = x;
         const int totterywin = 1000;
@@ -219,15 +226,16 @@ struct Twin {
         ClassArrays &A = ca[c];
         if (A.built) return;
         A.built = true;
-        const double *inE = t.in_emi + (size_t)c * NP;
+        const int ki = t.k_in, NPi = 1 << (2 * (ki + 1)); // (IntronModel::k: its own order, tetrahymena 3 beside 4)
+        const double *inE = t.in_emi + (size_t)c * NPi;
         A.inF.assign(n + 1, 0);
         A.inR.assign(n + 1, 0);
         for (int p = 0; p < n; p++) {
             // forward: reference IntronModel::seqProb src/intronmodel.cc:1090-1101 / SnippetProbs fwd src/statemodel.cc:287-297
-            int pn = p >= k ? pat(p - k, k + 1) : -1;
+            int pn = p >= ki ? pat(p - ki, ki + 1) : -1;
             A.inF[p + 1] = A.inF[p] + fx((pn >= 0 ? inE[pn] : t.ln_quarter) + softB(p));
             // reverse snippet (rlessD only): src/statemodel.cc:298-309
-            int rn = (p + k < n) ? rcpat(p, k + 1) : -1;
+            int rn = (p + ki < n) ? rcpat(p, ki + 1) : -1;
             A.inR[p + 1] = A.inR[p] + fx((rn >= 0 ? inE[rn] : t.ln_quarter) + softB(p));
         }
         const double *tabs[3] = {t.ex_emi + (size_t)c * 3 * NP, t.ex_init + (size_t)c * 3 * NP, t.ex_et + (size_t)c * 3 * NP};
@@ -312,8 +320,9 @@ struct Twin {
     }
     // single-base intron emission: reference IntronModel::emiProbUnderModel geometric branch, src/intronmodel.cc:895-915
     double eIn(int c, int p) const {
-        int pn = p >= k ? pat(p - k, k + 1) : -1;
-        return pn >= 0 ? t.in_emi[(size_t)c * NP + pn] : t.ln_quarter;
+        const int ki = t.k_in;
+        int pn = p >= ki ? pat(p - ki, ki + 1) : -1;
+        return pn >= 0 ? t.in_emi[((size_t)c << (2 * (ki + 1))) + pn] : t.ln_quarter;
     }
 
     // splice-site gates: reference include/statemodel.hh:98-117 (no hints: consensus dinucleotides only)
@@ -467,7 +476,7 @@ struct Twin {
         case AUGX_K_SINGLE: case AUGX_K_INITIAL: {
             if (!(bob >= 0 && bob < n - 2)) return NINF;
             int pn = pat(bob, 3);
-            if (pn < 0 || !(pn == 14 || pn == 30 || pn == 62)) return NINF; // isStartcodon: {a,c,t}tg
+            if (pn < 0 || !((t.start_mask >> pn) & 1ull)) return NINF; // isStartcodon: the translation table's ({a,c,t}tg in table 1)
             begin = t.ln_startcodon[pn];
             if (begin == NINF) return NINF;
             int tis = bob - t.W;
@@ -783,8 +792,9 @@ struct Twin {
     // pos - UtrModel::k on; with a UTR order below the intron order the pattern ends after pos; past the piece: the NUL, invalid
     double eUin(int c, int p) const {
         const int uk = t.utr_k;
-        int pn = (p >= uk && p - uk + k < n) ? pat(p - uk, k + 1) : -1;
-        return pn >= 0 ? t.in_emi[(size_t)c * NP + pn] : t.ln_quarter;
+        const int ki = t.k_in;
+        int pn = (p >= uk && p - uk + ki < n) ? pat(p - uk, ki + 1) : -1;
+        return pn >= 0 ? t.in_emi[((size_t)c << (2 * (ki + 1))) + pn] : t.ln_quarter;
     }
     void buildUtr() {
         const int k = t.utr_k, NP = 1 << (2 * (k + 1));
@@ -975,7 +985,7 @@ struct Twin {
         if (boep >= 0) {
             switch (kind) {
             case AUGX_K_UTR5SINGLE: case AUGX_K_UTR5TERM:
-                if (eobe + 3 <= n - 1) { int pn = pat(eobe + 1, 3); if (!(pn == 14 || pn == 30 || pn == 62)) endP = NINF; } // GeneticCode::isStartcodon
+                if (eobe + 3 <= n - 1) { int pn = pat(eobe + 1, 3); if (pn < 0 || !((t.start_mask >> pn) & 1ull)) endP = NINF; } // GeneticCode::isStartcodon (the translation table's)
                 break;
             case AUGX_K_UTR5INTERNAL: case AUGX_K_UTR5INIT: case AUGX_K_UTR3INTERNAL: case AUGX_K_UTR3INIT:
                 endP = dssProb(j - dssWhole + 1, true);

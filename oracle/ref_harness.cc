@@ -110,6 +110,8 @@ int main(int argc, char *argv[]) {
         Constant::init();
         Gene::init();
         GeneticCode::init();
+        if (Properties::hasProperty("translation_table")) // (setParameters(), reference src/augustus.cc:526-528)
+            GeneticCode::chooseTranslationTable(Properties::getIntProperty("translation_table"));
         StateModel::init();
         std::string filename = Properties::getProperty(INPUTFILE_KEY);
         GBProcessor gbank(filename);

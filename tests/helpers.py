@@ -34,7 +34,7 @@ def config_path():
     if _cfg_dir is None:
         tar = os.path.join(GOLDEN, "config_min.tar.gz")
         more = os.path.join(GOLDEN, "config_more.tar.gz")  # two more species (nasonia: 5 GC classes, rice: 4)
-        caeno = os.path.join(GOLDEN, "config_caeno.tar.gz")  # caenorhabditis (the reference's own test_ab_initio_prediction); Vitrella_brassicaformis, maize (47-state models the dense kernels take), chlamy2011 (gc donor sites)
+        caeno = os.path.join(GOLDEN, "config_caeno.tar.gz")  # caenorhabditis (the reference's own test_ab_initio_prediction); Vitrella_brassicaformis, maize (47-state models the dense kernels take), chlamy2011 (gc donor sites, UTR tables of order 3), tetrahymena (translation table 6, intron content of order 3)
         d = os.path.join(tempfile.gettempdir(), "augx_config_%d_%d_%d_%d" % (os.getuid(), os.path.getsize(tar), os.path.getsize(more), os.path.getsize(caeno)))
         marker = os.path.join(d, "config", "model", "states_shadow.cfg")
         if not os.path.exists(marker):
@@ -241,6 +241,15 @@ def gc_step_records(count, seed, parts=8, lo=2500, hi=6000):
             p.append("".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(rng.randint(lo, hi))))
         recs.append(("gcsteps%d_%d" % (seed, i), "".join(p)))
     return recs
+
+
+def n_window_record(seed=5, gcs=(0.36, 0.62), run=12000):
+    """a stretch of low GC content, a run of N longer than the GC window (GCwinsize 10000), a stretch of high GC content: inside the run
+    there are windows without a single nucleotide -- the reference classes them by the composition of the FIRST window of the piece
+    (BaseCount::normalize leaves the relative frequencies alone when the counts sum to 0, src/motif.cc:204-212,561-575)"""
+    rng = random.Random(seed)
+    part = lambda n, gc: "".join(rng.choice("GC") if rng.random() < gc else rng.choice("AT") for _ in range(n))
+    return ("nwin%d" % seed, part(26000, gcs[0]) + "N" * run + part(24000, gcs[1]))
 
 
 def genemodel_records():

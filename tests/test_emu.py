@@ -695,3 +695,32 @@ def test_emulated_utr_content_order_below_the_intron_order():
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
         assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
         assert np.array_equal(r[3], V)
+
+
+@pytest.mark.parametrize("species,table,opts", [("human", "6", {}), ("fly", "12", {"sample": "0"}), ("tetrahymena", "6", {})])
+def test_emulated_translation_table(species, table, opts):
+    """--translation_table: the stop codons and the start codons of the chosen genetic code in the kernels (dp.h: stopCodon3 /
+    DevTables::stopMask, startMask) -- emulator == twin, every cell (the twin against the live reference: tests/test_oracle.py).
+    tetrahymena: its own table 6 and intron content of order 3 beside exon content of order 4 (DevTables::kIn)"""
+    m = ax.Model(config_path(), species, softmasking="0", translation_table=table, **opts)
+    ex = dict(golden_inputs())
+    seqs = [ex[k].upper() for k in ("HS04636", "withN", "trunc_both")] + [random_dna(12000, 94)]
+    res = emu_decode(m.tables_ptr, seqs, m.n_states, cells=True)
+    for s, r in zip(seqs, res):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
+        assert np.array_equal(r[3], V)
+
+
+def test_emulated_gc_class_of_windows_without_a_nucleotide():
+    """kernels.h: k1WindowClass -- a GC window inside a long run of N takes the composition of the piece's first window (the reference's
+    BaseCount keeps its relative frequencies when the counts sum to 0): emulator == twin, classes and every cell (the twin against the
+    live reference: tests/test_oracle.py)"""
+    m = ax.Model(config_path(), "human", softmasking="0")
+    seqs = [n_window_record(5)[1], n_window_record(6, (0.62, 0.36), 15000)[1]]
+    res = emu_decode(m.tables_ptr, seqs, m.n_states, cells=True)
+    for s, r in zip(seqs, res):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r[0] == rc == 0 and r[1] == lnv and r[2] == [(b, e, st) for b, e, st, t in path]
+        assert np.array_equal(r[3], V)
+        assert gc[s.index("N") + s.count("N") // 2] == gc[0] and len(set(np.asarray(gc).tolist())) >= 2

@@ -386,3 +386,42 @@ def test_cli_47_state_models_on_the_dense_kernels(tmp_path, monkeypatch, species
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
         assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
         assert np.array_equal(b.cells(i), V), i
+
+
+@needs_ref
+@pytest.mark.parametrize("species,table,extra", [("human", "6", []), ("fly", "12", []), ("human", "4", ["--sample=20", "--UTR=on"]), ("tetrahymena", None, ["--maxDNAPieceSize=30000"])])
+def test_cli_translation_table(tmp_path, species, table, extra):
+    """--translation_table (round 6; reference src/geneticcode.cc:146-170): the executable against the reference binary, run live, at the
+    species' defaults (fly: UTR states and 99 sampled paths) -- GFF byte-identical incl. the protein lines, and the lines the reference
+    prints first about the nonstandard code"""
+    import subprocess
+    byname = dict(golden_inputs())
+    recs = [(n, byname[n]) for n in ("HS04636", "revcomp", "softmask_gene", "trunc_both", "rand20k_b")]
+    fa = str(tmp_path / "in.fa")
+    write_fasta(fa, recs)
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    args = ["--species=" + species] + (["--translation_table=" + table] if table else []) + extra + [fa]  # (tetrahymena: table 6 is its own; intron content of order 3)
+    ours = subprocess.run([os.path.join(ROOT, "augustus_amd", "bin", "augustus")] + args, capture_output=True, text=True, env=env)
+    ref = subprocess.run([REF_AUGUSTUS] + args, capture_output=True, text=True, env=env)
+    assert ours.returncode == 0 and ref.returncode == 0 and ours.stderr == ref.stderr == "", ours.stderr
+    assert gff_body(ours.stdout) == gff_body(ref.stdout)
+    warn = lambda t: [l for l in t.splitlines() if l.startswith("# Warning: Using nonstandard genetic code")]
+    assert warn(ours.stdout) == warn(ref.stdout) and len(warn(ref.stdout)) > 0
+    assert "# protein sequence" in ref.stdout
+
+
+@pytest.mark.parametrize("opts", [{}, {"UTR": "on"}])
+def test_gpu_gc_class_of_windows_without_a_nucleotide(monkeypatch, opts):
+    """a run of N longer than the GC window between two GC regimes (kernels.h: k1WindowClass takes the composition of the piece's first
+    window for a window that holds no nucleotide, as the reference's BaseCount does; found by the soak in round 6, seed 26011): device
+    cells == twin, both kernel families (the twin against the live reference: tests/test_oracle.py)"""
+    monkeypatch.setenv("AUGX_DEBUG_CELLS", "1")
+    m = ax.Model(config_path(), "human", softmasking="0", **opts)
+    d = ax.Decoder(m, 0)
+    seqs = [n_window_record(5)[1], n_window_record(6, (0.62, 0.36), 15000)[1], n_window_record(7, (0.45, 0.55), 30000)[1]]
+    b = ax.Batch(d, seqs)
+    b.decode()
+    for i, (s, r) in enumerate(zip(seqs, b.paths())):
+        rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
+        assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
+        assert np.array_equal(b.cells(i), V), i
