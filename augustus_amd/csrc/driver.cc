@@ -348,6 +348,7 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
         std::string errmsg;
         for (; pi < np && pieces[pi].rec == (int)r; pi++) {
             const PieceOut &pr = pieces[pi];
+            if (!errmsg.empty()) continue; // (the reference leaves the record at its first error: nothing of the later pieces is printed)
             if (pr.status != 0) {
                 errmsg = pr.status == AUGX_E_UNSUPPORTED ? "piece outside what the MI355X path decodes"
                          : pr.status == AUGX_E_NOPATH    ? "No feasible path found in HMM"
@@ -364,7 +365,7 @@ int formatRecords(const Model &M, const OutputOptions &oo, const std::vector<Rec
             err += "\n augustus: ERROR\n\t" + errmsg + "\n\n";
         } else
             successful++;
-        if (!any) out += "# (none)\n";
+        if (!any && errmsg.empty()) out += "# (none)\n"; // (NAMGene::doViterbiPiecewise says so at its end, which an error does not reach, src/namgene.cc:672-673)
     }
     return 0;
 }
@@ -974,8 +975,9 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     }
     lap("cut finder");
     std::vector<PieceRef> allPieces;
-    for (size_t r = 0; r < recs.size(); r++)
-        if (!recFail[r]) allPieces.insert(allPieces.end(), recPieces[r].begin(), recPieces[r].end());
+    // (a record whose chain of cuts stopped at an exam window without a feasible path: the pieces before that window are decoded and
+    //  printed, then comes the error -- the reference prints a piece's genes before it looks for the next cut, src/namgene.cc:575-655)
+    for (size_t r = 0; r < recs.size(); r++) allPieces.insert(allPieces.end(), recPieces[r].begin(), recPieces[r].end());
     if (M.opt.getBool("progress", false))
         for (auto &pr : allPieces)
             std::cerr << "examining piece " << pr.begin + S.oo.offset + 1 << ".." << pr.end + S.oo.offset + 1 << " (" << (pr.end - pr.begin + 1) << " bp)" << std::endl;
@@ -1051,9 +1053,21 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             }
         }
         po.push_back(o);
+        // (the entry of the exam window that failed follows the record's pieces: formatRecords walks the entries record by record)
+        const int r = allPieces[i].rec;
+        if (recFail[(size_t)r] && (i + 1 == allPieces.size() || allPieces[i + 1].rec != r)) po.push_back(PieceOut{r, 0, (long)recs[(size_t)r].seq.size() - 1, &noPath, recFail[(size_t)r]});
     }
-    for (size_t r = 0; r < recs.size(); r++)
-        if (recFail[r]) { PieceOut o{(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, recFail[r]}; po.push_back(o); }
+    {   // (failed records without a single piece)
+        std::vector<char> has(recs.size(), 0);
+        for (auto &pr : allPieces) has[(size_t)pr.rec] = 1;
+        std::vector<PieceOut> merged;
+        size_t k = 0;
+        for (size_t r = 0; r < recs.size(); r++) {
+            while (k < po.size() && po[k].rec == (int)r) merged.push_back(po[k++]);
+            if (recFail[r] && !has[r]) merged.push_back(PieceOut{(int)r, 0, (long)recs[r].seq.size() - 1, &noPath, recFail[r]});
+        }
+        po.swap(merged);
+    }
     std::string text, errText, fatal;
     if (formatRecords(M, S.oo, rv, po, verbosity, S.geneid, text, errText, fatal, S.sampleiterations)) {
         std::cout << text;

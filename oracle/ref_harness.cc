@@ -90,6 +90,7 @@ int main(int argc, char *argv[]) {
     std::string dumpfile, fwdfile, smpfile;
     int nsamples = 0;
     int initkind = 0, termkind = 0;
+    std::string kindlist, nosample, probecell;
     std::vector<char *> args;
     for (int i = 0; i < argc; i++) {
         if (strncmp(argv[i], "--dumpcells=", 12) == 0) dumpfile = argv[i] + 12;
@@ -98,6 +99,9 @@ int main(int argc, char *argv[]) {
         else if (strncmp(argv[i], "--nsamples=", 11) == 0) nsamples = atoi(argv[i] + 11);
         else if (strncmp(argv[i], "--initkind=", 11) == 0) initkind = atoi(argv[i] + 11);
         else if (strncmp(argv[i], "--termkind=", 11) == 0) termkind = atoi(argv[i] + 11);
+        else if (strncmp(argv[i], "--nosample=", 11) == 0) nosample = std::string(",") + (argv[i] + 11) + ","; // records (0-based, comma separated) that are decoded but not sampled: an exam window of the cut finder
+        else if (strncmp(argv[i], "--probecell=", 12) == 0) probecell = argv[i] + 12; // "state:base:N": N draws of the options of that cell (doSampling), histogram of the predecessor ends on stdout
+        else if (strncmp(argv[i], "--kindlist=", 11) == 0) kindlist = argv[i] + 11; // per record "ik:tk,ik:tk,..." (the pieces of one record, as NAMGene::doViterbiPiecewise sets them, src/namgene.cc:594-603)
         else args.push_back(argv[i]);
     }
     int nargs = (int)args.size();
@@ -133,8 +137,23 @@ int main(int argc, char *argv[]) {
             if (initkind == 1) namgene.initProbs[i] = (i == synch) ? 1.0 : 0.0;
             if (termkind == 1) namgene.termProbs[i] = (i == synch) ? 1.0 : 0.0;
         }
+        std::vector<double> origInit(S), origTerm(S);
+        for (int i = 0; i < S; i++) { origInit[i] = namgene.initProbs[i].doubleValue(); origTerm[i] = namgene.termProbs[i].doubleValue(); }
+        int recNo = 0;
         AnnoSequence *seq = gbank.getSequenceList();
         while (seq) {
+            if (!kindlist.empty()) { // (this record's kinds)
+                size_t at = 0;
+                for (int k = 0; k < recNo && at != std::string::npos; k++) { at = kindlist.find(',', at); if (at != std::string::npos) at++; }
+                if (at != std::string::npos && at + 2 < kindlist.size() + 1) {
+                    const int ik = kindlist[at] - '0', tk = kindlist[at + 2] - '0';
+                    for (int i = 0; i < S; i++) {
+                        namgene.initProbs[i] = ik == 1 ? ((i == synch) ? 1.0 : 0.0) : origInit[i];
+                        namgene.termProbs[i] = tk == 1 ? ((i == synch) ? 1.0 : 0.0) : origTerm[i];
+                    }
+                }
+            }
+            recNo++;
             AnnoSequence *cur = seq;
             seq = seq->next;
             cur->next = NULL;
@@ -198,9 +217,20 @@ int main(int argc, char *argv[]) {
                     fwrite(col.data(), 8, S, fdump);
                 }
             }
+            if (!probecell.empty()) {
+                int ps = 0, pb = 0, pn = 0;
+                sscanf(probecell.c_str(), "%d:%d:%d", &ps, &pb, &pn);
+                std::map<int, int> hist;
+                for (int it = 0; it < pn; it++) {
+                    OptionListItem oli;
+                    namgene.states[ps]->viterbiForwardAndSampling(namgene.viterbi, namgene.forward, ps, pb, doSampling, oli);
+                    hist[oli.base * 1000 + oli.state]++;
+                }
+                for (auto &kv : hist) printf("PROBE base %d state %d count %d\n", kv.first >= 0 ? kv.first / 1000 : -((-kv.first + 999) / 1000), ((kv.first % 1000) + 1000) % 1000, kv.second);
+            }
             if (sdump) { // reference NAMGene::getSampledPath (src/namgene.cc:367): draws from rand(), one stream over the run
                 fprintf(sdump, "SEQ %s\n", cur->seqname);
-                for (int it = 0; it < nsamples; it++) {
+                for (int it = 0; it < nsamples && nosample.find("," + std::to_string(recNo - 1) + ",") == std::string::npos; it++) {
                     StatePath *sp = namgene.getSampledPath(cur->sequence, cur->seqname);
                     std::vector<State> sr;
                     for (State *st = sp->first; st; st = st->next) {
