@@ -259,6 +259,17 @@ class Rand:
             pass
 
 
+def tss0(model, seq):
+    """``augx_tss0``: (forward, reverse) ln value of the TSS window that begins at base 0 of `seq` -- what a later sequence of the same
+    length is decoded with by the reference (include/augx.h)"""
+    L = lib()
+    L.augx_tss0.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
+    b = seq if isinstance(seq, bytes) else seq.encode()
+    out = (ctypes.c_double * 2)()
+    _check(L.augx_tss0(model._h, b, len(b), out))
+    return (out[0], out[1])
+
+
 def decode_sampled(decoders, seqs, n_samples, rand, init_kind=0, term_kind=0):
     """``augx_decode_sampled``: Viterbi path + n_samples sampled paths per piece, batches in input order over the decoders.
     Returns [(DecodedPiece, [sampled paths])]."""

@@ -15,6 +15,8 @@
 #include <sys/mman.h>
 #include <algorithm>
 #include <map>
+#include <array>
+#include <cmath>
 #include <unordered_map>
 #include <cstdio>
 #include <cstdlib>
@@ -814,6 +816,44 @@ void augx_batch_destroy(augx_batch *b) {
     delete b;
 }
 
+// ---- the TSS window that begins at base 0 of a piece (include/augx.h: augx_tss0, augx_tss0_override; dense.h: k1UtrSignals)
+static std::mutex g_tss0Mu;
+static std::map<const char *, std::array<double, 2>> g_tss0Of; // by the piece's sequence pointer
+int augx_tss0_override(const char *seq, const double *v) {
+    if (!seq) { setLastError("augx_tss0_override: bad argument"); return AUGX_E_ARG; }
+    std::lock_guard<std::mutex> lk(g_tss0Mu);
+    if (v) g_tss0Of[seq] = {v[0], v[1]}; else g_tss0Of.erase(seq);
+    return AUGX_OK;
+}
+int augx_tss0(const augx_model *m, const char *seq, int64_t len, double *out) {
+    if (!m || !seq || len < 1 || !out) { setLastError("augx_tss0: bad argument"); return AUGX_E_ARG; }
+    const augx_tables &t = m->m.t;
+    out[0] = out[1] = AUGX_NINF;
+    if (!t.utr) return AUGX_OK;
+    try {
+        DevTables T;
+        fillDevTablesScalars(t, T);
+        for (auto &sp : tableSpans(t, T)) *sp.dst = (TabPtr)sp.src; // (host tables)
+        const int up = t.tss_upwin, te = t.tss_end;
+        const int64_t need = std::min<int64_t>(len, (int64_t)up + te + 64);
+        std::vector<uint8_t> code((size_t)need);
+        auto enc = [](char c) -> uint8_t { switch (c) { case 'a': case 'A': return 0; case 'c': case 'C': return 1; case 'g': case 'G': return 2; case 't': case 'T': return 3; default: return 4; } };
+        for (int64_t i = 0; i < need; i++) code[(size_t)i] = enc(seq[i]);
+        // the class of the first GC window: the first win/2 bases have it (ContentStairs::computeStairs, src/motif.cc:561-565)
+        int win = t.gc_win;
+        if (win > len || win < 1) win = (int)len;
+        double cnt[4] = {0, 0, 0, 0};
+        for (int i = 0; i < win; i++) { const uint8_t c = enc(seq[i]); if (c < 4) cnt[c] += 1.0; }
+        Piece P;
+        P.t = &T; P.n = (int)len; P.c = T.C == 1 ? 0 : nearestClass(T, cnt); P.o = 0; P.code = code.data(); P.fx = nullptr; P.nsm = nullptr; P.sig = nullptr;
+        P.lcode = nullptr; P.lLo = 0; P.lHi = 0;
+        // (the window [0, up + te) and the few bases a reverse pattern reads past it lie inside `need`; the bound `right >= n` is the piece's)
+        out[0] = tssProbCalc(P, 0, true);
+        out[1] = tssProbCalc(P, 0, false);
+    } catch (std::exception &ex) { setLastError(ex.what()); return AUGX_E_UNSUPPORTED; }
+    return AUGX_OK;
+}
+
 int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_batch **out) {
     if (!d || !pieces || n < 1 || !out) { setLastError("augx_batch_create: bad argument"); return AUGX_E_ARG; }
     *out = nullptr;
@@ -871,6 +911,25 @@ int augx_batch_create(augx_decoder *d, const augx_piece *pieces, int n, augx_bat
     DA(V.candAlloc, CandAlloc, 1);
     if (d->dense && d->hostT.utr) { DA(V.udOff, uint64_t, V.nBlk); DA(V.udCnt, uint32_t, V.nBlk); }
     DA(V.lnv, double, n); DA(V.status, int32_t, n); DA(V.finalState, int32_t, n); DA(V.pathCount, int32_t, n);
+    {   // pieces whose TSS window at base 0 is answered from an earlier sequence (augx_tss0_override)
+        std::vector<double> v;
+        {
+            std::lock_guard<std::mutex> lk(g_tss0Mu);
+            if (!g_tss0Of.empty() && d->dense && d->hostT.utr)
+                for (int p = 0; p < n; p++) {
+                    auto it = g_tss0Of.find(pieces[p].seq);
+                    if (it == g_tss0Of.end()) continue;
+                    if (v.empty()) v.assign((size_t)n * 2, std::nan(""));
+                    v[(size_t)p * 2] = it->second[0]; v[(size_t)p * 2 + 1] = it->second[1];
+                }
+        }
+        if (!v.empty()) {
+            double *dv = nullptr;
+            DA(dv, double, (int64_t)n * 2);
+            if (hipMemcpy(dv, v.data(), sizeof(double) * v.size(), hipMemcpyHostToDevice) != hipSuccess) { augx_batch_destroy(b); setLastError("augx_batch_create: upload failed"); return AUGX_E_HIP; }
+            V.tss0 = dv;
+        }
+    }
     DA(V.pathRec, int32_t, Z.pathCap * 3);
     // segments of the trellis: enough workgroups for every compute unit, none shorter than what a fix-up needs
     b->plan = planSegments(L, d->model->m.t, d->nCU / d->share > 0 ? d->nCU / d->share : 1, d->dense ? -1 : 0); // (dense kernels: one workgroup per piece)

@@ -234,6 +234,13 @@ AUGX_HD void k1UtrSignals(const DevTables &T, const BatchView &B, int64_t g, con
         us[USIG_TSSF] = tssProbCalc(PF, q, true);
     }
     us[USIG_TSSR] = tssProbCalc(P, q - up - te + 1, false); // the reverse TSS window ENDING at q is asked for at column q (:1098)
+    // the window that begins at base 0: entry 0 of tssProbsPlus / tssProbsMinus is neither cleared at a class step (updateToLocalGC
+    // clears [from, to) with from = 1, src/utrmodel.cc:779-781) nor re-allocated while the sequences keep one length (:744-747): the
+    // value an earlier sequence of this length computed for ITS base 0 answers (the caller knows which, include/augx.h: augx_tss0)
+    if (B.tss0) {
+        if (q == 0 && B.tss0[2 * p] == B.tss0[2 * p]) us[USIG_TSSF] = B.tss0[2 * p];
+        if (q - up - te + 1 == 0 && B.tss0[2 * p + 1] == B.tss0[2 * p + 1]) us[USIG_TSSR] = B.tss0[2 * p + 1];
+    }
     us[USIG_TTSP] = ttsPlusCalc(P, q);
     us[USIG_TTSM] = ttsMinusCalc(P, q);
     uint64_t gate = 0;
@@ -303,6 +310,7 @@ AUGX_HD bool k1TssReplay(const DevTables &T, const BatchView &B, int p, int li, 
     if (B.nPlanes[p] <= 1 || li >= (int)B.ucnt[fidx(o + n, UCNT_TF, NUCNT)]) return false;
     USite &e = B.tfSite[lo + li];
     const int left = e.pos + 1, up = T.tss_upwin, te = T.tss_end;
+    if (left == 0 && B.tss0 && B.tss0[2 * p] == B.tss0[2 * p]) return false; // (answered from an earlier sequence: k1UtrSignals)
     int jFirst = -1;
     for (int s = 0; s < S; s++) {
         if (!T.reachable[s] || (T.kind[s] != AUGX_K_UTR5SINGLE && T.kind[s] != AUGX_K_UTR5INIT)) continue;

@@ -198,6 +198,9 @@ struct BatchView {
     double *usig;              // [N][NUSIG]
     USite *tfSite, *laSite, *fsSite, *lrSite, *tmSite, *rtSite; // [listCap] begin-site lists (laSite / lrSite run parallel to laPos / lrPos)
     const LaSw *laSw;          // acceptor sites whose value changes during the sweep (NULL: none)
+    const double *tss0;        // [nPieces][2] (NULL: none; NaN: none for that piece) the value of the TSS window that begins at base 0 of the piece,
+                               // forward / reverse, where the reference answers it from what an EARLIER sequence of the same length left in
+                               // tssProbsPlus[0] / tssProbsMinus[0] (dense.h: k1UtrSignals; include/augx.h: augx_tss0)
     uint8_t *bpD;              // [N][S] back pointers of the chain and fixed-lag states (ancestor index, 0xFF: none)
     struct UDesc *ud;          // [udCap] descriptors of the open (end base, UTR exon state) pairs, the pairs of a block contiguous (kUtrDesc)
     int64_t udCap;

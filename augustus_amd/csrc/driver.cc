@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -387,7 +388,9 @@ struct CutFinderStats { double scoutSeconds = 0; int tiles = 0, batches = 0, win
 using DecodeFn = std::function<bool(const std::vector<augx_piece> &, std::vector<Decoded> &, bool scout)>;
 
 bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long maxstep, bool soft, int scoutMode /* -1: decide here */, int nDevices,
-                   const DecodeFn &decode, std::vector<std::vector<PieceRef>> &recPieces, std::vector<int> &failStatus, CutFinderStats &stats) {
+                   const DecodeFn &decode, std::vector<std::vector<PieceRef>> &recPieces, std::vector<int> &failStatus, CutFinderStats &stats,
+                   std::vector<std::vector<std::array<long, 3>>> *events = nullptr /* per record, in the reference's order: {1 piece | 0 exam window, begin, end} */) {
+    if (events) events->assign(recs.size(), {});
     struct CutState {
         long beginPos = 0;
         int prevInit = 0, prevTerm = 0; // init/term kinds in effect while the exam window is decoded (state leak, src/namgene.cc:576 vs 594-603)
@@ -584,8 +587,10 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
                 if (more && hit == cache.end()) break;
                 c = probe;
                 recPieces[r].insert(recPieces[r].end(), emitted.begin(), emitted.end());
+                if (events) for (const PieceRef &pe : emitted) (*events)[r].push_back({1, pe.begin, pe.end});
                 if (!more) break;
                 stats.used++;
+                if (events) (*events)[r].push_back({0, c.es, c.ee});
                 if (hit->second.status != 0) { failStatus[r] = hit->second.status; c.done = true; break; } // the record's error
                 if (cutDebug && scouted[r]) { // developer aid: what the map's forecasts said about this window against what its decode says
                     CutState tr2 = c;
@@ -599,7 +604,9 @@ bool findCutPoints(const Model &M, const std::vector<RecordView> &recs, long max
                     }
                     cutDebugLines.push_back(line);
                 }
+                const size_t before = recPieces[r].size();
                 applyWindow(r, c, hit->second.path, &recPieces[r]);
+                if (events) for (size_t q = before; q < recPieces[r].size(); q++) (*events)[r].push_back({1, recPieces[r][q].begin, recPieces[r][q].end});
             }
         }
         // ... then the batch's room is shared among the records that still wait for a window (short records finished above and
@@ -952,6 +959,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     // ---- phase 1: find the cut points of all records (findCutPoints above; every exam window is decoded on the GPUs)
     std::vector<std::vector<PieceRef>> recPieces;
     std::vector<int> recFail;
+    std::vector<std::vector<std::array<long, 3>>> decodeEvents; // per record: the sequences the reference decodes, in its order
     {
         std::vector<RecordView> views;
         for (auto &r : recs) views.push_back({r.name.c_str(), r.seq.data(), (long)r.seq.size()});
@@ -968,7 +976,7 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             cfErr = S.err;
             return false;
         };
-        if (!findCutPoints(M, views, maxstep, soft, scoutMode, (int)S.decs.size(), decodeFn, recPieces, recFail, st)) { restore(); return fail(cfErr); }
+        if (!findCutPoints(M, views, maxstep, soft, scoutMode, (int)S.decs.size(), decodeFn, recPieces, recFail, st, &decodeEvents)) { restore(); return fail(cfErr); }
         if (timing)
             fprintf(stderr, "augx timing:   cut finder: scout %.3f s (%d tiles), %d batches, %d windows decoded, %d used\n", st.scoutSeconds, st.tiles, st.batches, st.windows,
                     st.used);
@@ -990,6 +998,24 @@ extern "C" int augx_main(int argc, const char *const *argv) {
     const bool runF = !single || strandOpt != "backward", runR = single && strandOpt != "forward";
     const size_t per = single ? 2 : 1;
     std::vector<Decoded> decoded(allPieces.size() * per);
+    // UTR states: the TSS window that begins at base 0 of a piece is answered from entry 0 of the reference's tssProbsPlus /
+    // tssProbsMinus, which lives on while the sequences it decodes -- exam windows and pieces, record after record -- keep ONE length
+    // (include/augx.h: augx_tss0; src/utrmodel.cc:744-747,779-781): a piece that follows such a sequence gets the value of the FIRST
+    // sequence of that run of equal lengths.  (An exam window that reads a stale value is decoded with its own: its path only
+    // places a cut.  --singlestrand=true runs every piece twice, in another order: left alone.)
+    std::map<std::pair<int, long>, std::pair<int, long>> tss0Src; // (record, begin of the piece) -> (record, begin) of the sequence whose value it reads
+    if (M.t.utr && !single) {
+        long cacheSize = -1, srcBegin = 0;
+        int srcRec = -1;
+        for (size_t r = 0; r < recs.size(); r++)
+            for (const auto &ev : decodeEvents[r]) {
+                const long L = ev[2] - ev[1] + 1;
+                if (L + 1 != cacheSize) { cacheSize = L + 1; srcRec = -1; }
+                if (srcRec < 0) { srcRec = (int)r; srcBegin = ev[1]; }
+                else if (ev[0] == 1 && !(srcRec == (int)r && srcBegin == ev[1])) tss0Src[{(int)r, ev[1]}] = {srcRec, srcBegin};
+            }
+    }
+    std::vector<const char *> tss0Set;
     {
         std::vector<augx_piece> ps;
         std::vector<size_t> slot; // ps[k] is decoded[slot[k]]
@@ -1004,6 +1030,15 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             p.init_kind = pr.initKind;
             p.term_kind = pr.termKind;
             if (runF) { ps.push_back(p); slot.push_back(i * per); }
+            if (!tss0Src.empty()) {
+                auto it = tss0Src.find({pr.rec, pr.begin});
+                if (it != tss0Src.end()) {
+                    const long L = pr.end - pr.begin + 1; // (the source has the piece's length: that is what makes it the source)
+                    double v[2];
+                    if (augx_tss0(S.model, recs[(size_t)it->second.first].seq.data() + it->second.second, L, v) == AUGX_OK && augx_tss0_override(p.seq, v) == AUGX_OK)
+                        tss0Set.push_back(p.seq);
+                }
+            }
             if (runR) { // reverse complement, case kept (the soft-masked runs are the hints of this run, too); the initial and
                         // terminal probabilities are the piece's, not swapped (src/namgene.cc:594-603 precede both runs)
                 rcs.emplace_back((size_t)p.len, 'n');
@@ -1025,7 +1060,9 @@ extern "C" int augx_main(int argc, const char *const *argv) {
             }
         }
         std::vector<Decoded> dd;
-        if (!ps.empty() && !(S.sampleiterations > 0 ? S.decodeSampled(ps, dd) : S.decode(ps, dd))) { restore(); return fail(S.err); }
+        const bool okDec = ps.empty() || (S.sampleiterations > 0 ? S.decodeSampled(ps, dd) : S.decode(ps, dd));
+        for (const char *q : tss0Set) (void)augx_tss0_override(q, nullptr);
+        if (!okDec) { restore(); return fail(S.err); }
         for (size_t k = 0; k < dd.size(); k++) decoded[slot[k]] = std::move(dd[k]);
     }
 

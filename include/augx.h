@@ -261,6 +261,15 @@ void augx_path_free(augx_path *p);
  *      free memory, and the results land in input order in out[0..n).  This is the fan-out of the piece loop of
  *      NAMGene::doViterbiPiecewise (reference src/namgene.cc:575-676); the reference itself is single-threaded. ---- */
 int augx_partition_lpt(const int64_t *lens, int n, int n_bins, int32_t *bin_of /* [n] */);
+/* The TSS window that begins at base 0 of a sequence, forward (out[0]) and reverse (out[1]), ln; -inf without UTR states.
+ * The reference keeps entry 0 of its tssProbsPlus / tssProbsMinus from sequence to sequence while the sequences it decodes -- pieces
+ * and the exam windows of its cut finder, in its order -- keep ONE length: the entry is neither cleared at a class step
+ * (UtrModel::updateToLocalGC clears [from, to) with from = 1, src/utrmodel.cc:779-781) nor re-allocated (initAlgorithms, :744-747).
+ * A piece that follows such a sequence is therefore decoded with the value that sequence computed for ITS base 0:
+ * augx_tss0 computes the pair for a sequence, augx_tss0_override hands it to the piece whose `seq` pointer is given (v = NULL:
+ * forget it) -- read by every augx_batch_create that gets that pointer.  augx_main does this for the pieces of a run. */
+int augx_tss0(const augx_model *m, const char *seq, int64_t len, double *out /* [2] */);
+int augx_tss0_override(const char *seq, const double *v /* [2] or NULL */);
 int augx_decode_sharded(augx_decoder *const *decs, int n_dec, const augx_piece *pieces, int n, augx_path *out /* array[n] */);
 
 /* ---- the cut finder: where a record longer than maxDNAPieceSize is cut into pieces.  Replaces NAMGene::getNextCutEndPoint /

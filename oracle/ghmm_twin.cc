@@ -43,6 +43,14 @@
 namespace {
 
 int g_snippetCache = 1; // twin_set_snippet_cache
+// Entry 0 of the reference's tssProbsPlus / tssProbsMinus lives on from sequence to sequence while the sequences keep one length: it is
+// neither cleared at a class step (updateToLocalGC clears [from, to) with from = 1, src/utrmodel.cc:779-781) nor re-allocated
+// (initAlgorithms, :744-747).  twin_set_tss0_carry(1): consecutive twin_decode calls are the reference's consecutive sequences
+// (off by default: every call starts with empty caches; twin_set_tss0_carry(0) also forgets what was carried)
+int g_tss0Carry = 0;
+long g_tss0Size = -1;
+double g_tss0Val[2] = {0, 0};
+int g_tss0Set[2] = {0, 0};
 
 const double NINF = -std::numeric_limits<double>::infinity();
 inline int mod3(int k) { return k >= 0 ? k % 3 : (k % 3 + 3) % 3; }
@@ -836,6 +844,10 @@ struct Twin {
             }
         }
         for (int st = 0; st < 2; st++) { tssC[st].assign(n + 1, NINF); tssSet[st].assign(n + 1, 0); }
+        if (g_tss0Carry) { // (what an earlier sequence of this length left in entry 0)
+            if (g_tss0Size != (long)n + 1) { g_tss0Size = (long)n + 1; g_tss0Set[0] = g_tss0Set[1] = 0; }
+            for (int st = 0; st < 2; st++) { tssSet[st][0] = (uint8_t)g_tss0Set[st]; tssC[st][0] = g_tss0Val[st]; }
+        }
     }
     // UtrModel::updateToLocalGC(from, to): the cached TSS values of [from, to) are forgotten (:779-780)
     void utrEnterRegion(int from) {
@@ -1171,6 +1183,7 @@ struct Twin {
                 }
             }
         }
+        if (g_tss0Carry && t.utr && anyNuc) for (int st = 0; st < 2; st++) { g_tss0Set[st] = tssSet[st][0]; g_tss0Val[st] = tssC[st][0]; }
         // termination + back-tracking: reference NAMGene::getViterbiPath, src/namgene.cc:432-510
         double maxV = NINF;
         int state = -1;
@@ -1226,6 +1239,7 @@ double twin_utr_forward_cell(const augx_tables *t, const char *seq, int64_t len,
 }
 /* 1 (default): short-intron interiors through the restated SnippetProbs cache, as the reference; 0: class of the end base */
 void twin_set_snippet_cache(int on) { g_snippetCache = on; }
+void twin_set_tss0_carry(int on) { g_tss0Carry = on; g_tss0Size = -1; g_tss0Set[0] = g_tss0Set[1] = 0; }
 /* decode one piece on the CPU.  V_out (len*S doubles) and gc_out (len int32) may be NULL.
  * states_out receives at most cap records; *n_states is the number available. */
 int twin_decode(const augx_tables *t, const char *seq, int64_t len, int init_kind, int term_kind, double *V_out,

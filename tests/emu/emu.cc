@@ -43,6 +43,7 @@ template <bool MAX, class E> void scanFields(E *a, int nf, const BatchLayout &L)
 // posterior sampling in the emulator: emu_set_sampling(n, seed) before emu_decode(..., fwd_out != NULL); the generator lives on
 // across emu_decode calls (one stream over the run, as in the reference); emu_sample_get reads sample `it` of piece p
 static int g_nsamples = 0;
+static std::vector<double> g_tss0; // emu_set_tss0: [n][2] for the next emu_decode (BatchView::tss0), empty: none
 static augx_rand *g_rand = nullptr;
 static std::vector<std::vector<std::vector<augx_state>>> g_samples;
 
@@ -65,6 +66,7 @@ static int emu_decode_dense(const augx_tables *t, const augx_piece *pieces, int 
     BatchSizes Z(L);
     BatchView B;
     memset(&B, 0, sizeof B);
+    B.tss0 = (int)g_tss0.size() == 2 * n ? g_tss0.data() : nullptr;
     B.nPieces = n; B.N = L.N; B.nChunks = L.nChunks;
     B.off = L.off.data(); B.len = L.len.data(); B.initKind = L.initKind.data(); B.termKind = L.termKind.data();
     B.chunkPiece = L.chunkPiece.data();
@@ -386,6 +388,8 @@ long long emu_quiet_checks() { return g_emuQuietChecks; }
 long long emu_jump_tiles() { return g_emuJumpTiles; }   // (tests: runs of N were jumped over)
 long long emu_quiet_tiles() { return g_emuQuietTiles; } // (tests: the chain-only path of trellisPiece was taken)
 int emu_near_ties(int p) { return p >= 0 && p < (int)g_nearTies.size() ? g_nearTies[p] : -1; }
+// values of the TSS window at base 0 of the pieces of the NEXT emu_decode, [n][2] forward / reverse, NaN: the piece's own (n = 0: none)
+void emu_set_tss0(const double *v, int n) { g_tss0.assign(v, v + (v ? 2 * (size_t)n : 0)); }
 void emu_set_sampling(int n, unsigned seed) {
     g_nsamples = n;
     delete g_rand;

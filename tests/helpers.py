@@ -98,6 +98,12 @@ def twin():
     return _twin
 
 
+def twin_tss0_carry(on):
+    """consecutive twin_decode calls are the reference's consecutive sequences: entry 0 of its TSS caches lives on while they keep one
+    length (oracle/ghmm_twin.cc: twin_set_tss0_carry); off: every call starts with empty caches"""
+    twin().twin_set_tss0_carry(1 if on else 0)
+
+
 def twin_decode(tables_ptr, seq, S, cells=False, init_kind=0, term_kind=0, cache=None):
     """CPU oracle (oracle/ghmm_twin.cc).  Returns (status, lnv, [(begin,end,state,type)], V or None, gc).
     cache: the restated SnippetProbs cache of the reference (multi-class pieces) on or off; by default it follows
@@ -377,7 +383,7 @@ class _Piece(ctypes.Structure):
 _emu = None
 
 
-def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None, forward=False, samples=0, seed=1):
+def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=None, forward=False, samples=0, seed=1, tss0=None):
     """Run the device kernel bodies on the CPU (tests/emu/emu.cc).  Returns [(status, lnv, path, V, cls)]
     (forward=True: [(status, lnv, path, V, cls, F, lnP)] with the ln forward matrix F and ln P(sequence);
     samples=n: [(status, lnv, path, V, cls, F, lnP, [n sampled paths of (begin, end, type)])], drawn from one rand() stream over seqs)."""
@@ -406,6 +412,11 @@ def emu_decode(tables_ptr, seqs, S, cells=False, init_kind=0, term_kind=0, lib=N
     lnF = np.zeros(n)
     E = _emu_lib if lib is not None else _emu
     E.emu_set_sampling(samples, seed)
+    if tss0 is not None:  # [(forward, reverse) or None per piece]: the value of the TSS window at base 0 an earlier sequence left (BatchView::tss0)
+        tv = np.array([[float('nan')] * 2 if t is None else list(t) for t in tss0], dtype=np.float64)
+        E.emu_set_tss0(tv.ctypes.data_as(ctypes.c_void_p), len(tss0))
+    else:
+        E.emu_set_tss0(None, 0)
     rc = E.emu_decode(tables_ptr, P, n, lnv.ctypes.data_as(ctypes.c_void_p), st.ctypes.data_as(ctypes.c_void_p),
                          po.ctypes.data_as(ctypes.c_void_p), cap, pn.ctypes.data_as(ctypes.c_void_p),
                          C.ctypes.data_as(ctypes.c_void_p) if cells else None, cls.ctypes.data_as(ctypes.c_void_p),

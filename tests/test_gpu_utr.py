@@ -221,3 +221,31 @@ def test_cli_utr_content_order_below_the_intron_order(tmp_path):
         rc, lnv, path, V, gc = twin_decode(m.tables_ptr, s, m.n_states, cells=True)
         assert r.status == rc == 0 and r.ln_viterbi == lnv and r.states == path, i
         assert np.array_equal(b.cells(i), V), i
+
+
+@needs_ref
+def test_cli_tss_window_at_base_0_follows_the_reference_from_sequence_to_sequence(tmp_path, monkeypatch):
+    """entry 0 of the reference's TSS caches lives on while the sequences it decodes keep one length (tests/test_memo_replay.py has the
+    mechanism): (1) soak seed 28004 -- fly --UTR=on --sample=30 --maxDNAPieceSize=20000, two pieces of exactly 20 000 bases: 48 posterior
+    probabilities of the second piece differed; (2) four records of ONE length at fly's defaults: every record after the first reads
+    what the first left.  GFF byte-identical to the reference binary's, run live (driver.cc: tss0Src; augx_tss0 / augx_tss0_override)."""
+    import soak_cli, subprocess
+    for k, v in (("SOAK_NRUNS", "1"), ("AUGX_SOAK_DENSE", "2"), ("SOAK_REAL", "1")):
+        monkeypatch.setenv(k, v)
+    d, g = soak_cli.real_dna()
+    recs, species, opts = soak_cli.make_case(28004, g)
+    assert species == "fly" and opts["maxDNAPieceSize"] == "20000" and len(recs[0][1]) == 40000
+    env = dict(os.environ, AUGUSTUS_CONFIG_PATH=config_path())
+    fa = str(tmp_path / "c.fa")
+    write_fasta(fa, recs)
+    args = ["--species=" + species] + ["--%s=%s" % kv for kv in opts.items()]
+    ref = subprocess.run([REF_AUGUSTUS] + args + [fa], capture_output=True, text=True, env=env)
+    assert ref.returncode == 0
+    assert gff_body(_run_cli(args, fa)) == gff_body(ref.stdout)
+    same = [("e%d" % i, g[o:o + 30000]) for i, o in enumerate((100000, 350000, 610000, 820000))]
+    fa2 = str(tmp_path / "same.fa")
+    write_fasta(fa2, same)
+    for args in (["--species=fly"], ["--species=fly", "--sample=0", "--softmasking=0"]):
+        ref = subprocess.run([REF_AUGUSTUS] + args + [fa2], capture_output=True, text=True, env=env)
+        assert ref.returncode == 0
+        assert gff_body(_run_cli(args, fa2)) == gff_body(ref.stdout)

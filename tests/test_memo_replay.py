@@ -86,3 +86,50 @@ def test_emulated_memo_lives_on_through_the_sampled_paths(tmp_path, monkeypatch)
     monkeypatch.setenv("AUGX_NO_LATE_MEMO", "1")
     res2 = emu_decode(m.tables_ptr, [recs[0][1]], m.n_states, forward=True, samples=99)
     assert [list(p) for p in res2[0][7]] != [list(p) for p in res[0][7]]
+
+
+@needs_ref
+def test_tss_window_at_base_0_is_answered_from_the_sequence_before(tmp_path):
+    """Entry 0 of the reference's tssProbsPlus / tssProbsMinus lives on from sequence to sequence while the sequences keep ONE length
+    (UtrModel::updateToLocalGC clears [from, to) with from = 1, src/utrmodel.cc:779-781; initAlgorithms re-allocates only for another
+    length, :744-747): the second of two pieces of 20 000 bases is decoded with the value the first computed for ITS base 0.  Found by
+    the soak (seed 28004, fly --UTR=on --sample=30 --maxDNAPieceSize=20000: 48 posterior probabilities of the second piece differed).
+    The live reference (oracle/ref_harness --kindlist: both pieces in one run, with their own initial / terminal kinds) against the twin
+    that carries the entry, and against the emulator that is handed the value (augx_tss0 -> BatchView::tss0): every sampled path of
+    both pieces state by state -- and without the value most paths of the second piece differ."""
+    import soak_cli
+    os.environ.update(SOAK_NRUNS="1", AUGX_SOAK_DENSE="2", SOAK_REAL="1")
+    try:
+        d, g = soak_cli.real_dna()
+        recs, species, opts = soak_cli.make_case(28004, g)
+    finally:
+        for k in ("SOAK_NRUNS", "AUGX_SOAK_DENSE", "SOAK_REAL"):
+            del os.environ[k]
+    assert species == "fly" and opts["UTR"] == "on" and opts["maxDNAPieceSize"] == "20000" and len(recs) == 1 and len(recs[0][1]) == 40000
+    seq = recs[0][1]
+    p1, p2 = seq[:20000], seq[20000:]
+    m = ax.Model(config_path(), "fly", UTR="on", sample="30")
+    S = m.n_states
+    fa = str(tmp_path / "k.fa")
+    write_fasta(fa, [("x0", p1), ("x1", p2)])
+    rs = ref_samples(fa, "fly", ["--UTR=on", "--kindlist=0:1,1:0"], n=29)
+    theirs = [[[tuple(x) for x in p] for p in r] for r in rs]
+    t0 = ax.tss0(m, p1)
+    assert t0[0] > -np.inf
+    with_v = emu_decode(m.tables_ptr, [p1, p2], S, init_kind=[0, 1], term_kind=[1, 0], samples=29, tss0=[None, t0])
+    without = emu_decode(m.tables_ptr, [p1, p2], S, init_kind=[0, 1], term_kind=[1, 0], samples=29)
+    for k in range(2):
+        assert [[tuple(x) for x in p] for p in with_v[k][7]] == theirs[k], k
+    ours = [[tuple(x) for x in p] for p in without[1][7]]
+    nd = [i for i, (a, b) in enumerate(zip(ours, theirs[1])) if a != b]
+    assert len(nd) >= 5  # (the begin of a first state that is cut off by the piece start, for most paths)
+    # the twin that carries entry 0 from call to call: its cells of the second piece are the emulator's with the value, and differ from a fresh decode
+    twin_tss0_carry(True)
+    try:
+        twin_decode(m.tables_ptr, p1, S, init_kind=0, term_kind=1)
+        carried = twin_decode(m.tables_ptr, p2, S, cells=True, init_kind=1, term_kind=0)
+    finally:
+        twin_tss0_carry(False)
+    fresh = twin_decode(m.tables_ptr, p2, S, cells=True, init_kind=1, term_kind=0)
+    e2 = emu_decode(m.tables_ptr, [p2], S, cells=True, init_kind=[1], term_kind=[0], tss0=[t0])
+    assert np.array_equal(e2[0][3], carried[3]) and not np.array_equal(carried[3], fresh[3])
