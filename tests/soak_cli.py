@@ -40,6 +40,11 @@ def make_case(seed, g):
             if os.environ.get("SOAK_NRUNS") and rng.random() < 0.5:  # (SOAK_NRUNS=1: long runs of N -- chain-only tiles and jumps of the trellis kernel)
                 parts.append("N" * rng.choice([3000, 12000, 50000, 150000]))
         recs.append(("r%d" % k, "".join(parts)))
+    if os.environ.get("SOAK_EQLEN"):  # (SOAK_EQLEN=1: the records of a case have ONE length -- with UTR states the reference then answers the
+        L = min(len(s) for _, s in recs)   #  TSS window at base 0 of a record from what the record before left in its cache)
+        recs = [(nm, s[:L]) for nm, s in recs]
+        if len(recs) < 3:
+            recs += [("q%d" % k, (recs[0][1][::-1] if k else recs[-1][1][L // 3:] + recs[-1][1][:L // 3])) for k in range(2)]
     species = rng.choice(["human", "fly", "arabidopsis", "saccharomyces", "human", "fly"])
     opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
     if rng.random() < 0.4:
