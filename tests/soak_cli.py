@@ -78,6 +78,11 @@ def make_case(seed, g):
         opts["introns"] = "on"
     if rng.random() < 0.15:
         opts["noInFrameStop"] = "true"
+    if os.environ.get("SOAK_TT") and rng.random() < 0.6:  # (SOAK_TT=1: genetic codes other than the standard one; tetrahymena: its own table 6, intron content of order 3)
+        if opts["UTR"] == "off" and "genemodel" not in opts and rng.random() < 0.3:
+            species = "tetrahymena"
+        else:
+            opts["translation_table"] = rng.choice(["4", "6", "10", "11", "12", "15", "1"])
     if opts["sample"] != "0" and rng.random() < 0.2: # (the order of alternatives with EQUAL mean state probability follows heap
         opts["alternatives-from-sampling"] = "true"  #  addresses in the reference, DESIGN.md section 6: a FAIL that only swaps
         if rng.random() < 0.5:                       #  two t-numbers of a gene is that)
