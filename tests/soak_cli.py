@@ -46,6 +46,8 @@ def make_case(seed, g):
         if len(recs) < 3:
             recs += [("q%d" % k, (recs[0][1][::-1] if k else recs[-1][1][L // 3:] + recs[-1][1][:L // 3])) for k in range(2)]
     species = rng.choice(["human", "fly", "arabidopsis", "saccharomyces", "human", "fly"])
+    if os.environ.get("SOAK_SPECIES"):  # (SOAK_SPECIES=1: the other species of the fixtures -- up to five GC classes, models on the dense kernels, gc donor sites, ciliate code)
+        species = rng.choice(["nasonia", "rice", "Vitrella_brassicaformis", "maize", "chlamy2011", "tetrahymena", "caenorhabditis", "fusarium_graminearum", "phanerochaete_chrysosporium", "human"])
     opts = {"UTR": "off", "sample": rng.choice(["0", "0", "30", "100"])}
     if rng.random() < 0.4:
         opts["softmasking"] = "0"
