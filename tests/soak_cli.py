@@ -74,6 +74,8 @@ def make_case(seed, g):
         opts["strand"] = rng.choice(["forward", "backward"])
     if rng.random() < 0.4:
         opts["maxDNAPieceSize"] = rng.choice(["20000", "50000"])
+    if os.environ.get("SOAK_FORCED"):  # (SOAK_FORCED=1: pieces below the cut finder's exam window of 50 kb -- every window and most pieces have ONE length)
+        opts["maxDNAPieceSize"] = rng.choice(["20000", "20000", "30000"])
     if rng.random() < 0.2:
         opts["gff3"] = "on"
     if rng.random() < 0.2:
