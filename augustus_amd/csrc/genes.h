@@ -41,7 +41,7 @@ struct Transcript {
     // sampling (reference Transcript::apostprob / hasProbs / viterbi / throwaway, include/gene.hh)
     float apostprob = 1.0f;
     bool hasProbs = false, viterbi = true, throwaway = false;
-    int serial = 0;      // order of creation within a run: the transcripts of the Viterbi path, then those of the sampled paths
+    int serial = 0;      // order of creation within a run: the transcripts of the Viterbi path, then those of the sampled paths (the reference's addresses fall in it)
     bool revRun = false; // mapped back from the run on the reverse complement (--singlestrand=true)
     double meanStateProb() const;
     long geneBegin() const { return transstart >= 0 ? transstart : codingstart; }

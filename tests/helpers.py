@@ -284,6 +284,10 @@ SAMPLED_CFGS = {
     # frame become the alternatives t1, t2, ... of a gene (sorted by mean state probability); --maxtracks bounds how many may overlap
     "fly_alt": ("fly", {"UTR": "off", "softmasking": "0", "alternatives-from-sampling": "true"}, None),
     "human_alt": ("human", {"sample": "100", "alternatives-from-sampling": "true", "maxtracks": "2"}, None),
+    # UTR states + alternatives: transcripts that differ in a UTR end only often have EQUAL mean state probability (7 pairs among the
+    # 18 of this record); which of two equals comes first follows the addresses of the reference's Gene objects -- falling in the
+    # order of creation through the sampling loop of a record, restated as that in genes.cc: groupToGenes
+    "human_utr_alt": ("human", {"UTR": "on", "sample": "30", "alternatives-from-sampling": "true"}, ("HS04636",)),
 }
 
 

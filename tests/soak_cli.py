@@ -88,8 +88,9 @@ def make_case(seed, g):
         else:
             opts["translation_table"] = rng.choice(["4", "6", "10", "11", "12", "15", "1"])
     if opts["sample"] != "0" and rng.random() < 0.2: # (the order of alternatives with EQUAL mean state probability follows heap
-        opts["alternatives-from-sampling"] = "true"  #  addresses in the reference, DESIGN.md section 6: a FAIL that only swaps
-        if rng.random() < 0.5:                       #  two t-numbers of a gene is that)
+        opts["alternatives-from-sampling"] = "true"  #  addresses in the reference, DESIGN.md section 6: restated as the reverse order
+        if rng.random() < 0.5:                       #  of creation, which a later record of a run may not keep -- a FAIL that only
+                                                     #  swaps two t-numbers of a gene is that)
             opts["maxtracks"] = rng.choice(["1", "2", "3"])
     return recs, species, opts
 

@@ -383,13 +383,14 @@ def test_emulated_sampling_matches_reference_paths(cfg):
             assert r[7][it] == g[it], (name, it)
 
 
-@pytest.mark.parametrize("cfg", ["fly", "fly_sm", "human1", "fly_filter", "human_all", "fly_alt", "human_alt"])
+@pytest.mark.parametrize("cfg", ["fly", "fly_sm", "human1", "fly_filter", "human_all", "fly_alt", "human_alt", "human_utr_alt"])
 def test_emulated_sampling_gff_is_the_reference_binarys(cfg):
     """--sample=100 end to end on the CPU: emulator decode + forward + 99 sampled paths per record, the host gene stage
     (genes.cc: posteriorTranscripts) -> the GFF with posterior probabilities of genes, transcripts and CDS is byte-identical
     to the reference binary's (fly: sample = 100 is the species default; fly_sm: with the soft-masking bonus; human_all: incl. the
     records with several GC classes in a piece, where the reference's snippet cache is replayed; fly_alt, human_alt:
-    --alternatives-from-sampling=true, the sampled transcripts as alternatives of the genes, with --maxtracks)"""
+    --alternatives-from-sampling=true, the sampled transcripts as alternatives of the genes, with --maxtracks; human_utr_alt: UTR
+    states, where alternatives of EQUAL mean state probability are common and their order is the one the reference's heap gives)"""
     species, opts, _ = SAMPLED_CFGS[cfg]
     n = int(opts.get("sample", 100))
     recs = sampled_records(cfg)
