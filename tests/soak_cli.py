@@ -92,6 +92,12 @@ def make_case(seed, g):
         if rng.random() < 0.5:                       #  of creation, which a later record of a run may not keep -- a FAIL that only
                                                      #  swaps two t-numbers of a gene is that)
             opts["maxtracks"] = rng.choice(["1", "2", "3"])
+    if os.environ.get("SOAK_ALT"):  # (SOAK_ALT=1: every case with sampled alternatives; SOAK_ALT=one: and ONE record, where the order of
+        if opts["sample"] == "0":    #  alternatives of EQUAL mean state probability is the reference's on any machine)
+            opts["sample"] = rng.choice(["30", "100"])
+        opts["alternatives-from-sampling"] = "true"
+        if os.environ["SOAK_ALT"] == "one":
+            recs = recs[:1]
     return recs, species, opts
 
 
