@@ -718,7 +718,7 @@ def main():
     if "AUGX_BENCH_DEVICE" in os.environ:  # (testing the multi-rank path on a box with fewer GPUs than ranks)
         local = int(os.environ["AUGX_BENCH_DEVICE"])
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # (under torch.distributed.run also as the only rank: one code path for N = 1 ... 8)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("AUGX_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")  # ("nccl" is RCCL)
